@@ -1,0 +1,680 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference (nanoporetech/remora
+v3.2.0, read-only at /root/reference) in the build container.
+
+This script is test infrastructure. It is the only place the reference is ever
+imported; nothing here travels to the GPU box except the small `.npz` files it
+writes under tests/golden/ (data only: inputs and the reference's outputs).
+
+Recipe: the three Cython modules are built out-of-tree in
+/tmp, absent third-party deps (pysam, pod5, polars, ...) are replaced by permissive
+stub modules, then `remora.*` is imported from the scratch copy and driven.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+SCRATCH = "/tmp/remora_ref_build"
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit(f"reference not found at {REF}; run in the build container")
+    so_ok = os.path.isdir(SCRATCH) and any(
+        f.startswith("encoded_kmers") and f.endswith(".so")
+        for f in os.listdir(os.path.join(SCRATCH, "src", "remora"))
+    )
+    if not so_ok:
+        shutil.rmtree(SCRATCH, ignore_errors=True)
+        os.makedirs(SCRATCH)
+        for name in ("src", "setup.py", "setup.cfg", "README.rst"):
+            src = os.path.join(REF, name)
+            dst = os.path.join(SCRATCH, name)
+            if os.path.isdir(src):
+                shutil.copytree(src, dst)
+            else:
+                shutil.copy(src, dst)
+        subprocess.check_call(["chmod", "-R", "u+w", SCRATCH])
+        subprocess.check_call(
+            [sys.executable, "setup.py", "build_ext", "--inplace"],
+            cwd=SCRATCH,
+            stdout=subprocess.DEVNULL,
+        )
+    sys.path.insert(0, os.path.join(SCRATCH, "src"))
+
+    class _Any:
+        def __init__(s, *a, **k):
+            pass
+
+        def __call__(s, *a, **k):
+            return _Any()
+
+        def __getattr__(s, n):
+            return _Any()
+
+        def __add__(s, o):
+            return s
+
+    class _Stub(types.ModuleType):
+        def __getattr__(s, n):
+            if n.startswith("__"):
+                raise AttributeError(n)
+            return _Any()
+
+    for m in ("toml", "polars", "pysam", "pod5", "plotnine", "parasail", "thop"):
+        sys.modules.setdefault(m, _Stub(m))
+    import remora  # noqa
+    from remora import (  # noqa
+        data_chunks,
+        data_chunks_core,
+        encoded_kmers,
+        inference,
+        io,
+        model_util,
+        util,
+        validate,
+    )
+
+    return types.SimpleNamespace(
+        remora=remora,
+        data_chunks=data_chunks,
+        data_chunks_core=data_chunks_core,
+        encoded_kmers=encoded_kmers,
+        inference=inference,
+        io=io,
+        model_util=model_util,
+        util=util,
+        validate=validate,
+    )
+
+
+# --------------------------------------------------------------------------------------
+# helpers shared by several fixtures
+# --------------------------------------------------------------------------------------
+
+
+def synth_read(rng, nbases, dwell_lo=5, dwell_hi=15, with_n=False, zero_dwell=False):
+    """SURVEY §8(d) synthetic read: uniform bases, uniform dwell, uniform dacs."""
+    int_seq = rng.integers(0, 4, nbases).astype(np.int64)
+    if with_n:
+        int_seq[rng.choice(nbases, max(1, nbases // 25), replace=False)] = -1
+    dwells = rng.integers(dwell_lo, dwell_hi + 1, nbases)
+    if zero_dwell:
+        dwells[rng.choice(nbases, max(1, nbases // 10), replace=False)] = 0
+        dwells[0] = max(dwells[0], 1)
+    seq_to_sig = np.concatenate([[0], np.cumsum(dwells)]).astype(np.int64)
+    dacs = rng.integers(300, 701, seq_to_sig[-1]).astype(np.int16)
+    return dacs, seq_to_sig, int_seq
+
+
+def randomise_bn(net, gen):
+    """Non-trivial BatchNorm running stats so that folding errors are visible."""
+    import torch
+
+    for name, mod in net.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            n = mod.num_features
+            mod.running_mean.copy_(torch.randn(n, generator=gen))
+            mod.running_var.copy_(torch.rand(n, generator=gen) * 1.5 + 0.5)
+            mod.weight.data.copy_(1.0 + 0.2 * torch.randn(n, generator=gen))
+            mod.bias.data.copy_(0.2 * torch.randn(n, generator=gen))
+
+
+def make_net(R, arch, size, kmer_len, num_out, seed):
+    import torch
+
+    torch.manual_seed(seed)
+    net = R.model_util._load_python_model(
+        f"{REF}/models/{arch}.py", size=size, kmer_len=kmer_len, num_out=num_out
+    )
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        randomise_bn(net, gen)
+        # default init gives logits in a ~0.05-wide band; widen the dynamic range so the
+        # 1e-4 logit tolerance is a discriminating test (still the reference's forward)
+        for pname, p in net.named_parameters():
+            if pname.startswith("lstm") and "weight" in pname:
+                p.mul_(2.5)
+            if pname.startswith("fc."):
+                p.mul_(6.0)
+    net.eval()
+    return net
+
+
+def state_to_np(net, prefix="w__"):
+    return {
+        prefix + k.replace(".", "__"): v.detach().cpu().numpy()
+        for k, v in net.state_dict().items()
+    }
+
+
+def synth_chunks(rng, n, chunk_len, max_seq_len, kb, ka, minus_one_frac=0.0, zero_dwell=False):
+    """Random chunk arrays in CoreRemoraDataset layout (data_chunks.py:786-816)."""
+    seq_w = max_seq_len + kb + ka
+    seqs = np.full((n, seq_w), -1, np.int8)
+    maps = np.zeros((n, max_seq_len + 1), np.int16)
+    lens = np.zeros(n, np.int16)
+    for c in range(n):
+        sl = int(rng.integers(max(1, max_seq_len // 4), max_seq_len + 1))
+        if zero_dwell and c % 3 == 0:
+            cuts = np.sort(rng.integers(0, chunk_len + 1, sl - 1))
+        else:
+            sl = min(sl, chunk_len)
+            cuts = np.sort(rng.choice(np.arange(1, chunk_len), sl - 1, replace=False))
+        maps[c, : sl + 1] = np.concatenate([[0], cuts, [chunk_len]])
+        # padded columns are garbage in the reference (np.empty): emulate
+        maps[c, sl + 1 :] = rng.integers(-5, chunk_len + 5, max_seq_len - sl)
+        seqs[c, : sl + kb + ka] = rng.integers(0, 4, sl + kb + ka)
+        seqs[c, sl + kb + ka :] = rng.integers(-1, 4, seq_w - sl - kb - ka)
+        if minus_one_frac > 0:
+            m = rng.random(sl + kb + ka) < minus_one_frac
+            seqs[c, : sl + kb + ka][m] = -1
+        lens[c] = sl
+    return seqs, maps, lens
+
+
+# --------------------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------------------
+
+
+def gen_parse_move_tag(R, out):
+    """io.parse_move_tag (src/remora/io.py:394-407)."""
+    rng = np.random.default_rng(11)
+    cases = {}
+    idx = 0
+
+    def add(mv_tag, sig_len, seq_len, reverse, check=True):
+        nonlocal idx
+        try:
+            q2s, mv, stride = R.io.parse_move_tag(
+                list(mv_tag), sig_len, seq_len=seq_len, check=check, reverse_signal=reverse
+            )
+            err = ""
+        except R.remora.RemoraError as e:
+            q2s, err = np.zeros(0, np.int64), str(e)
+        cases[f"c{idx}_mv"] = np.asarray(mv_tag, np.int8)
+        cases[f"c{idx}_args"] = np.asarray(
+            [sig_len, -1 if seq_len is None else seq_len, int(reverse), int(check)], np.int64
+        )
+        cases[f"c{idx}_q2s"] = np.asarray(q2s, np.int64)
+        cases[f"c{idx}_err"] = np.asarray(err)
+        idx += 1
+
+    add([5, 1, 0, 0, 1, 1, 0, 1, 0], 40, 4, False)
+    add([5, 1, 0, 0, 1, 1, 0, 1, 0], 40, 4, True)
+    add([5, 1, 0, 0, 1, 1, 0, 1, 0], 43, 4, False)  # sig_len not multiple of stride
+    add([5, 1, 0, 0, 1, 1, 0, 1, 0], 40, 5, False)  # discordant with basecalls
+    add([5, 1, 0, 0, 1, 1, 0, 1], 40, 4, False)  # discordant with signal
+    add([5, 1, 0, 0, 1, 1, 0, 1], 40, 4, False, check=False)
+    add([6, 1], 6, 1, False)
+    for stride in (5, 6):
+        nmv = int(rng.integers(200, 2000))
+        mv = (rng.random(nmv) < 0.45).astype(np.int8)
+        mv[0] = 1
+        sig_len = nmv * stride + int(rng.integers(0, stride))
+        add([stride, *mv], sig_len, int(mv.sum()), False)
+        add([stride, *mv], sig_len, int(mv.sum()), True)
+        add([stride, *mv], sig_len, None, False)
+    cases["num_cases"] = np.asarray(idx)
+    np.savez_compressed(os.path.join(out, "parse_move_tag.npz"), **cases)
+    print("parse_move_tag:", idx, "cases")
+
+
+def gen_seq_motif(R, out):
+    """util.seq_to_int (util.py:131-142), Motif.findall (:281-297),
+    find_focus_bases_in_int_sequence (:413-426; python-set iteration order)."""
+    rng = np.random.default_rng(12)
+    d = {}
+    seqs = [
+        "ACGTACGTNNACGCGCGTTTCGA",
+        "CGCGCGCG",
+        "A",
+        "".join(rng.choice(list("ACGT"), 3000)),
+        "".join(rng.choice(list("ACGTN"), 500, p=[0.24, 0.24, 0.24, 0.24, 0.04])),
+    ]
+    motif_sets = [
+        [("CG", 0)],
+        [("C", 0)],
+        [("CG", 0), ("GC", 1)],
+        [("CHH", 0), ("CHG", 0), ("CG", 0)],
+        [("NCGN", 1)],
+        [("DRACH", 2)],
+        [("A", 0), ("C", 0), ("G", 0), ("T", 0)],
+    ]
+    d["num_seqs"] = np.asarray(len(seqs))
+    d["num_motif_sets"] = np.asarray(len(motif_sets))
+    for si, s in enumerate(seqs):
+        int_seq = R.util.seq_to_int(s)
+        d[f"s{si}_str"] = np.asarray(s)
+        d[f"s{si}_int"] = int_seq.astype(np.int64)
+        for mi, ms in enumerate(motif_sets):
+            motifs = [R.util.Motif(*m) for m in ms]
+            if any(len(m.raw_motif) > len(s) for m in motifs):
+                fb = np.zeros(0, np.int64)
+                skipped = 1
+            else:
+                fb = R.util.find_focus_bases_in_int_sequence(int_seq, motifs)
+                skipped = 0
+            d[f"s{si}_m{mi}_focus"] = np.asarray(fb, np.int64)
+            d[f"s{si}_m{mi}_skipped"] = np.asarray(skipped)
+    for mi, ms in enumerate(motif_sets):
+        d[f"m{mi}_seqs"] = np.asarray([m[0] for m in ms])
+        d[f"m{mi}_offs"] = np.asarray([m[1] for m in ms], np.int64)
+        # Motif normalisation (N-clipping) results
+        mots = [R.util.Motif(*m) for m in ms]
+        d[f"m{mi}_norm_seqs"] = np.asarray([m.raw_motif for m in mots])
+        d[f"m{mi}_norm_offs"] = np.asarray([m.focus_pos for m in mots], np.int64)
+    np.savez_compressed(os.path.join(out, "seq_motif.npz"), **d)
+    print("seq_motif: done")
+
+
+def _chunks_to_arrays(chunks):
+    """Ragged Chunk list -> padded arrays (+ lengths)."""
+    n = len(chunks)
+    L = chunks[0].signal.size if n else 0
+    max_sw = max((c.seq_w_context.size for c in chunks), default=0)
+    max_mw = max((c.seq_to_sig_map.size for c in chunks), default=0)
+    sig = np.zeros((n, L), np.float32)
+    seq = np.full((n, max_sw), -9, np.int64)
+    smap = np.full((n, max_mw), -9999, np.int64)
+    seq_len = np.zeros(n, np.int64)
+    misc = np.zeros((n, 4), np.int64)
+    for i, c in enumerate(chunks):
+        sig[i] = c.signal
+        seq[i, : c.seq_w_context.size] = c.seq_w_context
+        smap[i, : c.seq_to_sig_map.size] = c.seq_to_sig_map
+        seq_len[i] = c.seq_len
+        misc[i] = (c.chunk_sig_focus_idx, c.chunk_focus_base, c.read_focus_base, c.label)
+    return dict(signal=sig, seq_w_context=seq, seq_to_sig_map=smap, seq_len=seq_len, misc=misc)
+
+
+def gen_extract_chunks(R, out):
+    """RemoraRead.sig (data_chunks.py:191-197), iter_chunks (:425-466),
+    extract_chunk (:331-423) incl. both padding branches and -1 sequence fill."""
+    rng = np.random.default_rng(13)
+    d = {}
+    reads = [
+        ("long", synth_read(rng, 400), 500.0, 80.0),
+        ("short", synth_read(rng, 7), 511.25, 77.5),  # shorter than one chunk
+        ("with_n", synth_read(rng, 150, with_n=True), 480.0, 91.3),
+        ("zero_dwell", synth_read(rng, 120, dwell_lo=1, dwell_hi=6, zero_dwell=True), 500.0, 80.0),
+        ("fast", synth_read(rng, 300, dwell_lo=1, dwell_hi=3), 500.0, 80.0),
+    ]
+    configs = [
+        ((50, 50), (4, 4), False, 0),
+        ((100, 100), (4, 4), False, 0),
+        ((50, 50), (2, 3), True, 0),
+        ((30, 25), (4, 4), False, 1),
+        ((50, 50), (4, 4), False, -2),
+        ((200, 200), (1, 10), True, 0),
+    ]
+    d["read_names"] = np.asarray([r[0] for r in reads])
+    d["configs"] = np.asarray([[*c[0], *c[1], int(c[2]), c[3]] for c in configs], np.int64)
+    for rname, (dacs, s2s, int_seq), shift, scale in reads:
+        read = R.data_chunks.RemoraRead(
+            dacs=dacs, shift=shift, scale=scale, seq_to_sig_map=s2s, int_seq=int_seq, read_id=rname
+        )
+        read.check()
+        d[f"{rname}_dacs"] = dacs
+        d[f"{rname}_map"] = s2s
+        d[f"{rname}_int_seq"] = int_seq
+        d[f"{rname}_shift_scale"] = np.asarray([shift, scale], np.float64)
+        d[f"{rname}_sig"] = read.sig
+        for motif in (("CG", 0), ("C", 0)):
+            mname = motif[0]
+            read.set_motif_focus_bases([R.util.Motif(*motif)])
+            d[f"{rname}_{mname}_focus"] = np.asarray(read.focus_bases, np.int64)
+            for ci, (cc, kcb, bsj, off) in enumerate(configs):
+                chunks = list(read.iter_chunks(cc, kcb, bsj, off))
+                assert len(chunks) == read.focus_bases.size
+                arrs = _chunks_to_arrays(chunks)
+                for k, v in arrs.items():
+                    d[f"{rname}_{mname}_c{ci}_{k}"] = v
+    np.savez_compressed(os.path.join(out, "extract_chunks.npz"), **d)
+    print("extract_chunks: done", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
+
+
+def gen_encode_kmers(R, out):
+    """encoded_kmers.compute_encoded_kmer_batch (src/remora/encoded_kmers.pyx:13-45)."""
+    rng = np.random.default_rng(14)
+    d = {}
+    cases = [
+        # n, chunk_len, max_seq_len, kb, ka, minus_one_frac, zero_dwell
+        (40, 100, 20, 4, 4, 0.0, False),
+        (33, 100, 20, 4, 4, 0.1, True),
+        (17, 200, 40, 4, 4, 0.05, True),
+        (21, 100, 20, 2, 3, 0.05, False),
+        (9, 55, 30, 1, 10, 0.0, True),
+        (5, 100, 100, 4, 4, 0.02, True),  # one base per sample possible
+        (1, 100, 20, 4, 4, 0.0, False),
+        (3, 400, 80, 0, 0, 0.0, False),
+    ]
+    d["num_cases"] = np.asarray(len(cases))
+    for i, (n, L, msl, kb, ka, mof, zd) in enumerate(cases):
+        seqs, maps, lens = synth_chunks(rng, n, L, msl, kb, ka, mof, zd)
+        enc = R.encoded_kmers.compute_encoded_kmer_batch(kb, ka, seqs, maps, lens)
+        assert enc.shape == (n, 4 * (kb + ka + 1), L), enc.shape
+        d[f"c{i}_args"] = np.asarray([kb, ka, L], np.int64)
+        d[f"c{i}_seqs"] = seqs
+        d[f"c{i}_maps"] = maps
+        d[f"c{i}_lens"] = lens
+        # one-hot stored compactly: base code per (chunk, kmer_pos, sig_pos), -1 = all zero
+        code = np.where(
+            enc.reshape(n, kb + ka + 1, 4, L).sum(2) > 0,
+            enc.reshape(n, kb + ka + 1, 4, L).argmax(2),
+            -1,
+        ).astype(np.int8)
+        assert np.array_equal(
+            (code[:, :, None, :] == np.arange(4)[None, None, :, None]).astype(np.float32).reshape(enc.shape),
+            enc,
+        )
+        d[f"c{i}_enc_code"] = code
+    np.savez_compressed(os.path.join(out, "encode_kmers.npz"), **d)
+    print("encode_kmers: done")
+
+
+def gen_trim(R, out):
+    """data_chunks_core.trim_sb_chunk_context_core (src/remora/data_chunks_core.pyx:10-45),
+    called as in CoreRemoraDataset.trim_sb_chunk_context (data_chunks.py:1536-1576)."""
+    rng = np.random.default_rng(15)
+    d = {}
+    cases = [
+        # stored cc, new cc, kb, ka, max_seq_len
+        ((50, 50), (30, 25), 4, 4, 20),
+        ((50, 50), (50, 25), 4, 4, 20),
+        ((50, 50), (20, 50), 2, 3, 20),
+        ((100, 100), (50, 50), 4, 4, 40),
+        ((50, 50), (50, 50), 4, 4, 20),
+    ]
+    d["num_cases"] = np.asarray(len(cases))
+    for i, (scc, cc, kb, ka, msl) in enumerate(cases):
+        n = 37
+        seqs, maps, lens = synth_chunks(rng, n, sum(scc), msl, kb, ka, 0.03, i % 2 == 1)
+        # reference zero-fills nothing, but garbage maps beyond seq_len must not
+        # terminate the `while` scans early in a data-dependent way: keep them
+        d[f"c{i}_args"] = np.asarray([*scc, *cc, kb + ka], np.int64)
+        d[f"c{i}_in_seqs"] = seqs.copy()
+        d[f"c{i}_in_maps"] = maps.copy()
+        d[f"c{i}_in_lens"] = lens.copy()
+        st_diff = scc[0] - cc[0]
+        m2 = (maps - st_diff).astype(np.int16)
+        s2 = seqs.copy()
+        l2 = lens.copy()
+        R.data_chunks_core.trim_sb_chunk_context_core(*scc, *cc, kb + ka, s2, m2, l2)
+        d[f"c{i}_out_seqs"] = s2
+        d[f"c{i}_out_maps"] = m2
+        d[f"c{i}_out_lens"] = l2
+        # and the encode of the trimmed arrays (what the model finally sees)
+        enc = R.encoded_kmers.compute_encoded_kmer_batch(kb, ka, s2, m2, l2)
+        K = kb + ka + 1
+        code = np.where(
+            enc.reshape(n, K, 4, -1).sum(2) > 0, enc.reshape(n, K, 4, -1).argmax(2), -1
+        ).astype(np.int8)
+        d[f"c{i}_out_enc_code"] = code
+    np.savez_compressed(os.path.join(out, "trim_chunk_context.npz"), **d)
+    print("trim: done")
+
+
+def gen_model_logits(R, out):
+    """models/ConvLSTM_w_ref.py:39-58 and models/Conv_w_ref.py:44-62 forward in eval mode,
+    non-trivial BN running stats. Weights + inputs + reference logits."""
+    import torch
+
+    rng = np.random.default_rng(16)
+    specs = [
+        # name, arch, size, (kb,ka), chunk_len, num_out, nchunks
+        ("convlstm_s64_l100_o2", "ConvLSTM_w_ref", 64, (4, 4), 100, 2, 48),
+        ("convlstm_s64_l200_o3", "ConvLSTM_w_ref", 64, (4, 4), 200, 3, 24),
+        ("convlstm_s16_l100_o2", "ConvLSTM_w_ref", 16, (4, 4), 100, 2, 32),
+        ("convlstm_s64_l100_k23", "ConvLSTM_w_ref", 64, (2, 3), 100, 4, 16),
+        ("conv_s64_l100_o2", "Conv_w_ref", 64, (4, 4), 100, 2, 48),
+        ("conv_s64_l100_o3", "Conv_w_ref", 64, (4, 4), 100, 3, 16),
+    ]
+    for si, (name, arch, size, (kb, ka), L, num_out, n) in enumerate(specs):
+        K = kb + ka + 1
+        net = make_net(R, arch, size, K, num_out, seed=100 + si)
+        msl = L // 5
+        seqs, maps, lens = synth_chunks(rng, n, L, msl, kb, ka, 0.03, False)
+        sigs = rng.standard_normal((n, 1, L)).astype(np.float32)
+        enc = R.encoded_kmers.compute_encoded_kmer_batch(kb, ka, seqs, maps, lens)
+        with torch.no_grad():
+            logits = net(torch.from_numpy(sigs), torch.from_numpy(enc)).numpy()
+            jit_logits = torch.jit.script(net)(torch.from_numpy(sigs), torch.from_numpy(enc)).numpy()
+        assert np.abs(logits - jit_logits).max() < 1e-5
+        # a dense (non one-hot) seqs input pins the general forward(sigs, seqs) contract
+        dense = rng.standard_normal((8, 4 * K, L)).astype(np.float32)
+        with torch.no_grad():
+            dense_logits = net(torch.from_numpy(sigs[:8]), torch.from_numpy(dense)).numpy()
+        d = state_to_np(net)
+        d.update(
+            arch=np.asarray(arch),
+            params=np.asarray([size, kb, ka, L, num_out], np.int64),
+            sigs=sigs,
+            seqs=seqs,
+            maps=maps,
+            lens=lens,
+            logits=logits,
+            dense_seqs=dense,
+            dense_logits=dense_logits,
+        )
+        np.savez_compressed(os.path.join(out, f"model_{name}.npz"), **d)
+        print("model", name, "logit range", float(logits.min()), float(logits.max()))
+
+
+def _ckpt(kcb, cc, mod_bases, mod_long_names, motifs, size, kmer_len, num_out, bsj=False, off=0):
+    return dict(
+        kmer_context_bases=kcb,
+        chunk_context=cc,
+        modified_base_labels=True,
+        mod_bases=mod_bases,
+        mod_long_names=mod_long_names,
+        reverse_signal=False,
+        refine_kmer_center_idx=-1,
+        refine_do_rough_rescale=False,
+        refine_scale_iters=-1,
+        refine_algo="dwell_penalty",
+        refine_half_bandwidth=5,
+        base_start_justify=bsj,
+        offset=off,
+        pa_scaling=None,
+        model_params=dict(size=size, kmer_len=kmer_len, num_out=num_out),
+        motifs=motifs,
+        refine_kmer_levels=None,
+        refine_sd_arr=None,
+        model_version=3,
+    )
+
+
+def gen_call_read_mods(R, out):
+    """model_util.export_model_torchscript / load_model (model_util.py:115-176, 566-699)
+    and inference.call_read_mods (inference.py:661-712) end to end on synthetic reads."""
+    import json
+    import tempfile
+
+    import torch
+
+    rng = np.random.default_rng(17)
+    specs = [
+        ("cg_5mc", "ConvLSTM_w_ref", (4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 2),
+        ("allc_5hmc_5mc", "ConvLSTM_w_ref", (4, 4), (100, 100), ["h", "m"], ["5hmC", "5mC"], [("C", 0)], 3),
+        ("conv_cg", "Conv_w_ref", (4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 2),
+    ]
+    reads = [
+        ("r_long", synth_read(rng, 600), 500.0, 80.0),
+        ("r_short", synth_read(rng, 9), 505.0, 75.0),
+        ("r_n", synth_read(rng, 200, with_n=True), 495.0, 83.0),
+        ("r_none", (np.full(40, 500, np.int16), np.arange(0, 41, 10, dtype=np.int64), np.array([0, 0, 3, 3])), 500.0, 80.0),
+    ]
+    for si, (name, arch, kcb, cc, mod_bases, mln, motifs, num_out) in enumerate(specs):
+        K = sum(kcb) + 1
+        net = make_net(R, arch, 64, K, num_out, seed=200 + si)
+        ckpt = _ckpt(kcb, cc, mod_bases, mln, motifs, 64, K, num_out)
+        with tempfile.TemporaryDirectory() as td:
+            pt = os.path.join(td, "m.pt")
+            R.model_util.export_model_torchscript(ckpt, net, pt)
+            # raw meta.txt as written by the reference (JSON string) - data, not code
+            extra = {"meta.txt": ""}
+            torch.jit.load(pt, _extra_files=extra, map_location="cpu")
+            meta_txt = extra["meta.txt"]
+            model, md = R.model_util.load_model(pt, quiet=True, eval_only=True)
+        d = state_to_np(net)
+        d["arch"] = np.asarray(arch)
+        d["meta_txt"] = np.asarray(meta_txt if isinstance(meta_txt, str) else meta_txt.decode())
+        md_plain = {
+            k: v
+            for k, v in md.items()
+            if k
+            in (
+                "motifs", "can_base", "mod_bases", "mod_long_names", "chunk_context", "chunk_len",
+                "kmer_context_bases", "kmer_len", "base_start_justify", "offset", "reverse_signal",
+                "pa_scaling", "motif", "alphabet_str",
+            )
+        }
+        d["derived_md_json"] = np.asarray(json.dumps(md_plain))
+        d["read_names"] = np.asarray([r[0] for r in reads])
+        for rname, (dacs, s2s, int_seq), shift, scale in reads:
+            def mk():
+                return R.data_chunks.RemoraRead(
+                    dacs=dacs.copy(), shift=shift, scale=scale, seq_to_sig_map=s2s.copy(),
+                    int_seq=int_seq.copy(), read_id=rname,
+                )
+            d[f"{rname}_dacs"] = dacs
+            d[f"{rname}_map"] = s2s
+            d[f"{rname}_int_seq"] = int_seq
+            d[f"{rname}_shift_scale"] = np.asarray([shift, scale], np.float64)
+            nn_out, labels, pos = R.inference.call_read_mods(mk(), model, md)
+            d[f"{rname}_nn_out"] = np.asarray(nn_out, np.float32)
+            d[f"{rname}_labels"] = np.asarray(labels, np.int64)
+            d[f"{rname}_pos"] = np.asarray(pos, np.int64)
+            probs, _, pos2 = R.inference.call_read_mods(mk(), model, md, return_mod_probs=True)
+            d[f"{rname}_probs"] = np.asarray(probs, np.float64)
+            res = R.inference.call_read_mods(mk(), model, md, return_mm_ml_tags=True)
+            if len(res) == 2:
+                mm, ml = res
+                d[f"{rname}_mm"] = np.asarray(mm)
+                d[f"{rname}_ml"] = np.asarray(list(ml), np.uint8)
+            else:  # no chunks -> 3 empty arrays (inference.py:698-699)
+                d[f"{rname}_mm"] = np.asarray("<EMPTY3>")
+                d[f"{rname}_ml"] = np.zeros(0, np.uint8)
+            if nn_out.size and rname == "r_long":
+                fo = int(pos[len(pos) // 2])
+                o2, _, p2 = R.inference.call_read_mods(mk(), model, md, focus_offset=fo)
+                d[f"{rname}_focus_offset"] = np.asarray(fo)
+                d[f"{rname}_focus_nn_out"] = np.asarray(o2, np.float32)
+                d[f"{rname}_focus_pos"] = np.asarray(p2, np.int64)
+        np.savez_compressed(os.path.join(out, f"call_read_mods_{name}.npz"), **d)
+        print("call_read_mods", name, "done")
+
+
+def gen_post(R, out):
+    """util.softmax_axis1 (util.py:182-186), util.format_mm_ml_tags (:485-537) and the
+    label tally of validate.compute_metrics (validate.py:42-66) that the multi-GPU count
+    reduction reproduces."""
+    rng = np.random.default_rng(18)
+    d = {}
+    x = (rng.standard_normal((257, 3)) * 4).astype(np.float32)
+    d["softmax_in"] = x
+    d["softmax_out"] = R.util.softmax_axis1(x)
+    seq = "".join(rng.choice(list("ACGT"), 400))
+    poss = np.array([i for i, b in enumerate(seq) if b == "C"])
+    rng.shuffle(poss)
+    probs = rng.random((poss.size, 2))
+    probs[0] = (1.0, 0.0)
+    probs[1] = (0.999999, 1.0)
+    mm, ml = R.util.format_mm_ml_tags(seq, poss, probs, ["h", "m"], "C")
+    d["tags_seq"] = np.asarray(seq)
+    d["tags_poss"] = poss.astype(np.int64)
+    d["tags_probs"] = probs
+    d["tags_mm"] = np.asarray(mm)
+    d["tags_ml"] = np.asarray(list(ml), np.uint8)
+    # argmax tally
+    logits = (rng.standard_normal((1000, 3))).astype(np.float32)
+    logits[5] = (1.0, 1.0, 0.5)  # tie -> first index
+    labels = rng.integers(0, 3, 1000)
+    pr = R.util.softmax_axis1(logits)
+    pred = np.argmax(pr, axis=1)
+    d["tally_logits"] = logits
+    d["tally_labels"] = labels.astype(np.int64)
+    d["tally_pred_counts"] = np.bincount(pred, minlength=3).astype(np.int64)
+    conf = np.zeros((3, 3), np.int64)
+    np.add.at(conf, (labels, pred), 1)
+    d["tally_confusion"] = conf
+    np.savez_compressed(os.path.join(out, "post_process.npz"), **d)
+    print("post: done")
+
+
+def gen_dataset_batches(R, out):
+    """CoreRemoraDataset in-memory path: write_chunk (data_chunks.py:1376-1418) then
+    iteration -> extract_batch (:1652-1676), i.e. RemoraRead.prepare_batches (:468-514)."""
+    rng = np.random.default_rng(19)
+    dacs, s2s, int_seq = synth_read(rng, 500)
+    md = dict(
+        sig_map_refiner=R.data_chunks.__dict__.get("SigMapRefiner", None),
+    )
+    from remora.refine_signal_map import SigMapRefiner
+
+    model_metadata = dict(
+        sig_map_refiner=SigMapRefiner(),
+        chunk_context=[50, 50],
+        kmer_context_bases=[4, 4],
+        base_start_justify=False,
+        offset=0,
+        motifs=[("CG", 0)],
+        mod_bases=["m"],
+        mod_long_names=["5mC"],
+    )
+    read = R.data_chunks.RemoraRead(
+        dacs=dacs, shift=500.0, scale=80.0, seq_to_sig_map=s2s, int_seq=int_seq, read_id="ds"
+    )
+    read.set_motif_focus_bases([R.util.Motif("CG", 0)])
+    read.prepare_batches(model_metadata, 2048)
+    assert len(read.batches) == 1
+    sig, enc, labels, rfb = read.batches[0]
+    K = 9
+    code = np.where(
+        enc.reshape(-1, K, 4, 100).sum(2) > 0, enc.reshape(-1, K, 4, 100).argmax(2), -1
+    ).astype(np.int8)
+    d = dict(
+        dacs=dacs, map=s2s, int_seq=int_seq, shift_scale=np.asarray([500.0, 80.0]),
+        signal=sig, enc_code=code, labels=labels, read_focus_bases=rfb,
+    )
+    np.savez_compressed(os.path.join(out, "prepare_batches.npz"), **d)
+    print("prepare_batches: done", sig.shape)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    R = import_reference()
+    gens = dict(
+        parse_move_tag=gen_parse_move_tag,
+        seq_motif=gen_seq_motif,
+        extract_chunks=gen_extract_chunks,
+        encode_kmers=gen_encode_kmers,
+        trim=gen_trim,
+        model_logits=gen_model_logits,
+        call_read_mods=gen_call_read_mods,
+        post=gen_post,
+        dataset_batches=gen_dataset_batches,
+    )
+    for name, fn in gens.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        fn(R, out)
+
+
+if __name__ == "__main__":
+    main()
