@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — chunks/sec of the fused per-read modified-base-call hot path on MI355X.
+
+A step = one pass of the hot path (chunk arrays -> class logits + per-label counts) over the
+rank's batch of synthetic chunks, inputs already resident in HBM.  One process per GPU
+(torchrun); chunks shard across ranks with no data-path collective; the only exchange is one
+all-reduce of the per-label counts (RCCL over xGMI) at the end of the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement; `roofline` and `cpu_baseline`
+objects included).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (arch, synth config, description)
+    "convlstm_c100": ("conv_lstm", "C100", "synthetic 100-sig-pt CG chunks, ConvLSTM_w_ref size 64 k-mer (4,4) 2-class fp32 (BASELINE configs[2])"),
+    "conv_c100": ("conv_only", "C100", "synthetic 100-sig-pt CG chunks, Conv_w_ref size 64 fp32 (BASELINE configs[1])"),
+    "convlstm_c200": ("conv_lstm", "C200", "synthetic 200-sig-pt all-context chunks, ConvLSTM_w_ref 3-class fp32 (BASELINE configs[4] shape, fp32)"),
+}
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def kernel_flops_per_chunk(arch, L, size=64, K=9, num_out=2):
+    """ALGORITHMIC flops (2 per MAC) per chunk of each MFMA kernel (no credit for
+    lstm2's dead steps or for multiplying one-hot zeros)."""
+    kw1 = 5 if arch == "conv_lstm" else 11
+    P1 = L - kw1 + 1
+    P2 = P1 - kw1 + 1
+    P3 = (P2 - 9) // 3 + 1
+    f = {}
+    f["conv_sig3"] = 2 * size * 16 * 9 * P3
+    # front: sig_conv1, sig_conv2 MACs + seq_conv1 as K*kw1 gather-adds x 16 ch
+    f["front_sig12_seq1"] = 2 * (4 * kw1 * P1 + 16 * 4 * kw1 * P2) + 16 * K * kw1 * P1
+    if arch == "conv_lstm":
+        T = P3 - 4
+        f["conv_seq2"] = 2 * size * 16 * 13 * P3
+        f["conv_merge1"] = 2 * size * 2 * size * 5 * T
+        f["lstm_head"] = 2 * (T * 2 * 4 * size * size + 4 * size * size + num_out * size)
+    else:
+        PQ2 = P1 - 10
+        T, T2 = P3 - 4, P3 - 8
+        T3 = (T2 - 3) // 2 + 1
+        T4 = (T3 - 3) // 2 + 1
+        f["conv_seq2"] = 2 * 32 * 16 * 11 * PQ2
+        f["conv_seq3"] = 2 * size * 32 * 9 * P3
+        f["conv_merge1"] = 2 * size * 2 * size * 5 * T
+        f["conv_merge2"] = 2 * size * size * 5 * T2
+        f["conv_merge3"] = 2 * size * size * 3 * T3
+        f["conv_merge4"] = 2 * size * size * 3 * T4
+        f["fc_head"] = 2 * num_out * size * T4
+    return f
+
+
+def cpu_baseline(state, data, kcb, budget_s=12.0):
+    """Reference CPU path timed on this box's host cores: single-thread C restatement of the
+    Cython encode + torch.nn restatement of the network (all cores, eager, batch 2048)."""
+    import torch
+
+    from oracle import oracle as O
+    from oracle import torch_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = torch_ref.from_state(state)
+    B = 2048
+    n_avail = data["sequence_lengths"].shape[0]
+    t_enc = t_net = 0.0
+    done = 0
+    it = 0
+    with torch.no_grad():
+        while True:
+            st = (it * B) % max(n_avail - B, 1)
+            sl = slice(st, st + B)
+            t0 = time.perf_counter()
+            enc = O.compute_encoded_kmer_batch(kcb[0], kcb[1], data["sequence"][sl],
+                                               data["sequence_to_signal_mapping"][sl], data["sequence_lengths"][sl])
+            t1 = time.perf_counter()
+            net(torch.from_numpy(data["signal"][sl]), torch.from_numpy(enc))
+            t2 = time.perf_counter()
+            if it >= 2:  # 2 warm-up batches
+                t_enc += t1 - t0
+                t_net += t2 - t1
+                done += B
+            it += 1
+            if it >= 7 and (t_enc + t_net) >= budget_s:
+                break
+            if it >= 400:
+                break
+    return {
+        "value": done / (t_enc + t_net),
+        "unit": "chunks/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done} chunks in batches of {B}: C port of compute_encoded_kmer_batch (1 thread) + torch.nn "
+                  f"restatement of the network, eager fp32, {cores} threads",
+        "encode_chunks_per_s": done / t_enc,
+        "model_chunks_per_s": done / t_net,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="convlstm_c100", choices=sorted(WORKLOADS))
+    ap.add_argument("--chunks", type=int, default=1_000_000, help="chunks per GPU per step")
+    ap.add_argument("--subbatch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    from remora_amd import dist as rdist
+    from remora_amd import synth
+    from remora_amd.engine import get_engine
+    from remora_amd.model_util import model_from_state
+
+    rank, world, local = rdist.init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    arch, cfg, desc = WORKLOADS[args.workload]
+    cc, kcb, msl, num_out, _ = synth.CONFIGS[cfg]
+    L = sum(cc)
+    state = synth.synth_state(arch, 64, sum(kcb) + 1, num_out, seed=0)
+    eng = get_engine(local)
+    if args.subbatch:
+        eng.set_subbatch(args.subbatch)
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=local)
+
+    n = args.chunks
+    data = synth.synth_chunks_config(cfg, n, shard=rank)
+    dev = [torch.from_numpy(data[k]).cuda(local) for k in
+           ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+    counts = torch.zeros(num_out, dtype=torch.int64, device=f"cuda:{local}")
+
+    def step():
+        return model.infer_chunks(*dev, kcb, label_counts=counts)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    counts.zero_()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    rdist.allreduce_counts(counts)  # the one collective of the job
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t1 = time.perf_counter()
+    eng.profile_enable(False)
+    elapsed = rdist.allreduce_max_float(t1 - t0)
+    prof = eng.profile()
+
+    total_chunks = n * world * args.steps
+    value = total_chunks / elapsed
+    if rank != 0:
+        return
+    assert int(counts.sum().item()) == total_chunks, "label counts do not add up"
+
+    flops = kernel_flops_per_chunk(arch, L, 64, sum(kcb) + 1, num_out)
+    kern = {}
+    for name, (ms, launches) in prof.items():
+        fl = flops.get(name)
+        kern[name] = {"ms_total": ms, "launches": launches, "avg_ms": ms / launches,
+                      "tflops": (fl * n * args.steps / (ms * 1e-3) / 1e12) if fl else None}
+    dom = max((k for k in kern if flops.get(k) and k != "front_sig12_seq1"), key=lambda k: kern[k]["ms_total"])
+    chunks_per_launch = n * args.steps / kern[dom]["launches"]
+    achieved = flops[dom] * chunks_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+    traffic = os.environ.get("RMR_BENCH_TRAFFIC_BYTES")  # PMC-derived HBM bytes/launch (profiles/)
+    roofline = {
+        "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": float(traffic) if traffic else None,
+        "flop_per_chunk": flops[dom], "chunks_per_launch": chunks_per_launch, "avg_launch_ms": kern[dom]["avg_ms"],
+    }
+    gpu_ms = sum(k["ms_total"] for k in kern.values())
+    total_flops = sum(flops.values())
+    out = {
+        "metric": "chunks/sec, 5mC CG ConvLSTM_w_ref inference (fused chunk arrays -> logits + label counts)",
+        "value": value, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "chunks_per_gpu_per_step": n, "chunk_len": L, "kmer_context_bases": list(kcb),
+                   "num_out": num_out, "sharding": f"chunks sharded over {world} GPU(s), 1 count all-reduce"},
+        "reads_per_sec": value / 312.0,
+        "roofline": roofline,
+        "whole_pipeline": {"algorithmic_tflops": total_flops * total_chunks / world / (gpu_ms * 1e-3) / 1e12,
+                           "frac_of_fp32_mfma_peak": total_flops * total_chunks / world / (gpu_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                           "kernel_ms_sum": gpu_ms, "wall_ms": elapsed * 1e3},
+        "kernels": kern,
+        "label_counts": [int(x) for x in counts.tolist()],
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        nb = min(n, 1 << 17)
+        sample = {k: v[:nb] for k, v in data.items() if isinstance(v, np.ndarray)}
+        out["cpu_baseline"] = cpu_baseline(state, sample, kcb, args.cpu_budget)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+/*
+ * remora_hip.h — C ABI of libremora_hip.so, the MI355X (gfx950) engine for the per-read
+ * modified-base-call hot path of nanoporetech/remora (v3.2.0).
+ *
+ * Every entry point replaces one reference interface on that path; the reference
+ * file:line it stands in for is cited on each declaration (paths relative to the
+ * reference checkout).  Plain pointers and sizes only — no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative rmr_status otherwise; the message
+ *     is available (thread-local) from rmr_last_error().  Nothing aborts the process.
+ *     The Python host turns non-zero into remora_amd.RemoraError — the one exception type
+ *     the reference's callers catch (src/remora/__init__.py:4-7, inference.py:88).
+ *   - `mem` says where the caller's data buffers live: RMR_MEM_HOST (numpy / malloc; the
+ *     engine stages them through device scratch and copies results back before returning)
+ *     or RMR_MEM_DEVICE (hipMalloc / torch `data_ptr()`; work is enqueued on the engine
+ *     stream and the call returns without synchronising — call rmr_engine_synchronize).
+ *   - the caller owns every input and output buffer; the engine owns only weights,
+ *     scratch and its stream; no caller pointer is retained past return
+ *     (mirrors the Cython memoryview borrow semantics, src/remora/encoded_kmers.pyx:16-18).
+ *   - chunk arrays use the CoreRemoraDataset layout (src/remora/data_chunks.py:786-816,
+ *     :942-948): signal f32[n,1,L]; sequence i8[n,seq_w]; sequence_to_signal_mapping
+ *     i16[n,map_w]; sequence_lengths i16[n]; all C-contiguous.
+ *   - an engine (and the models created on it) may be used from several host threads; calls
+ *     on one engine are serialised by an internal mutex (reference runs the model from a
+ *     Thread: src/remora/inference.py:544-550, :973-982).
+ */
+#ifndef REMORA_HIP_H
+#define REMORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#pragma GCC visibility push(default)
+
+typedef struct rmr_engine rmr_engine;
+typedef struct rmr_model rmr_model;
+
+enum rmr_status {
+    RMR_OK = 0,
+    RMR_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    RMR_ERR_HIP = -2,         /* HIP runtime error (message carries hipGetErrorString) */
+    RMR_ERR_NOMEM = -3,
+    RMR_ERR_DISCORDANT_SEQ = -4, /* "Move table discordant with basecalls" io.py:403-404 */
+    RMR_ERR_DISCORDANT_SIG = -5  /* "Move table discordant with signal"    io.py:405-406 */
+};
+
+enum rmr_mem { RMR_MEM_HOST = 0, RMR_MEM_DEVICE = 1 };
+enum rmr_arch {
+    RMR_ARCH_CONV_LSTM = 0, /* models/ConvLSTM_w_ref.py */
+    RMR_ARCH_CONV_ONLY = 1  /* models/Conv_w_ref.py     */
+};
+
+const char *rmr_last_error(void);
+const char *rmr_version(void);
+
+/* ---- engine ------------------------------------------------------------------------ */
+
+/* One engine per process per GPU.  With RMR_ENGINE_USE_STREAM in `flags` the engine enqueues
+ * on the caller's hipStream_t `stream` (NULL = the legacy default stream; e.g. torch's current
+ * stream, so that ordering with the caller's tensors is implicit); otherwise `stream` is
+ * ignored and the engine creates its own non-blocking stream.
+ * replaces: `tensor.to(device)` single-device plumbing, src/remora/inference.py:311-314,
+ *           src/remora/util.py:81-92 (parse_device). */
+enum rmr_engine_flags { RMR_ENGINE_OWN_STREAM = 0, RMR_ENGINE_USE_STREAM = 1 };
+int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out);
+void rmr_engine_destroy(rmr_engine *e);
+int rmr_engine_synchronize(rmr_engine *e);
+/* chunks per internal sub-batch of the fused pipeline (scratch = ~33 KB/chunk); 0 = default */
+int rmr_engine_set_subbatch(rmr_engine *e, int64_t chunks);
+
+/* ---- model (L4: model_util.load_model hands the weights over) ------------------------ */
+
+typedef struct {
+    int32_t arch;       /* rmr_arch */
+    int32_t size;       /* model_params["size"]: 16, 32 or 64 (constants.py:1 default 64) */
+    int32_t kmer_len;   /* kmer_context_bases[0] + [1] + 1 */
+    int32_t num_out;    /* len(mod_bases) + 1, <= 16 */
+    int32_t chunk_len;  /* sum(chunk_context) */
+    int32_t dtype;      /* 0 = fp32 (only value accepted in this version) */
+} rmr_model_desc;
+
+/* `weights`: host fp32 blob, the torch state_dict tensors flattened in forward order —
+ *   for each conv layer: conv.weight[oc][ic][k], conv.bias, bn.weight, bn.bias,
+ *   bn.running_mean, bn.running_var; conv layers in the order
+ *     conv_lstm: sig_conv1..3, seq_conv1..2, merge_conv1
+ *     conv_only: sig_conv1..3, seq_conv1..3, merge_conv1..4
+ *   then (conv_lstm) lstm1 {weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0}, lstm2 {same};
+ *   then fc.weight, fc.bias.
+ * The engine folds BatchNorm (eval, eps 1e-5) into the convolutions and repacks everything
+ * into MFMA fragment order on the device.
+ * replaces: torch.jit.load + ScriptModule.state_dict(), src/remora/model_util.py:468-481,
+ *           :532-563; layer sets as in :231-263. */
+int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *weights,
+                     size_t n_floats, rmr_model **out);
+void rmr_model_destroy(rmr_model *m);
+/* number of floats rmr_model_create expects for `desc` (0 if desc is unsupported) */
+size_t rmr_model_weight_count(const rmr_model_desc *desc);
+
+/* ---- E1: k-mer one-hot encode with move-table expansion ------------------------------ */
+/* replaces: encoded_kmers.compute_encoded_kmer_batch, src/remora/encoded_kmers.pyx:13-45.
+ * out: f32[n, 4*(kb+ka+1), sig_len].  The reference takes sig_len from chunk 0
+ * (:23, maps[0, lens[0]]); the host wrapper does the same and passes it in. */
+int rmr_encode_kmers(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
+                     const int16_t *maps, int map_w, const int16_t *lens, int64_t n,
+                     int sig_len, float *out, int mem);
+
+/* ---- T1: trim stored chunk context to the model's (in place) -------------------------- */
+/* replaces: data_chunks_core.trim_sb_chunk_context_core, src/remora/data_chunks_core.pyx:10-45.
+ * As in the reference the caller has already subtracted (stored_before - cc_before) from
+ * `maps` (src/remora/data_chunks.py:1555-1563). */
+int rmr_trim_chunk_context(rmr_engine *e, int stored_before, int stored_after, int cc_before,
+                           int cc_after, int total_seq_context, int8_t *seqs, int seq_w,
+                           int16_t *maps, int map_w, int16_t *lens, int64_t n, int mem);
+
+/* ---- M1: move-table expansion ---------------------------------------------------------- */
+/* replaces: io.parse_move_tag, src/remora/io.py:394-407.  mv_tag = [stride, m0, m1, ...]
+ * (int8, host or device).  q2s capacity must be >= mv_tag_len.  *n_out = #moves + 1.
+ * seq_len < 0 means None.  Errors: RMR_ERR_DISCORDANT_SEQ / _SIG when `check`. */
+int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_t sig_len,
+                    int64_t seq_len, int check, int reverse_signal, int64_t *q2s,
+                    int64_t *n_out, int mem);
+
+/* ---- X1 + X2 + X3 (+X6): chunk extraction for a batch of reads --------------------------- */
+/* replaces: RemoraRead.sig (src/remora/data_chunks.py:191-197), iter_chunks (:425-466),
+ * extract_chunk (:331-423) and the row packing of CoreRemoraDataset.write_chunk
+ * (:1376-1418).  Reads are concatenated; read r owns dacs[sig_off[r]:sig_off[r+1]],
+ * int_seq[seq_off[r]:seq_off[r+1]], seq_to_sig_map[seq_off[r]+r : seq_off[r+1]+r+1]
+ * (one more entry than bases) and focus_bases[focus_off[r]:focus_off[r+1]] (read-local
+ * base indices, in the order the caller wants the chunks).
+ *
+ * Step 1 normalises the signal and computes the geometry of every chunk:
+ *   sig_out      f32[sig_off[n_reads]]            ((dacs - shift)/scale in f64, cast to f32)
+ *   geo          i64[n_chunks, 6] = {seq_len, chunk_sig_focus_idx, chunk_focus_base,
+ *                                    read_focus_base, seq_start, sig_start(signed, unclipped)}
+ *   *max_seq_len max over chunks of seq_len (host int, always written; implies a sync)
+ * Step 2 fills the dataset-layout arrays for widths seq_w >= max_seq_len+kb+ka,
+ *   map_w >= max_seq_len+1 (padding columns: sequence -1, mapping 0; the reference leaves
+ *   them uninitialised). */
+typedef struct {
+    int64_t n_reads;
+    const int16_t *dacs;        /* concatenated */
+    const int64_t *sig_off;     /* [n_reads+1] */
+    const int64_t *seq_to_sig;  /* concatenated, n_bases+1 per read */
+    const int8_t *int_seq;      /* concatenated, values -1..3 */
+    const int64_t *seq_off;     /* [n_reads+1] */
+    const double *shift;        /* [n_reads] */
+    const double *scale;        /* [n_reads] */
+    const int64_t *focus_bases; /* concatenated, read-local */
+    const int64_t *focus_off;   /* [n_reads+1] */
+    int32_t cc_before, cc_after, kb, ka, base_start_justify, offset;
+} rmr_reads;
+
+int rmr_chunk_geometry(rmr_engine *e, const rmr_reads *reads, float *sig_out, int64_t *geo,
+                       int64_t *max_seq_len, int mem);
+int rmr_chunk_fill(rmr_engine *e, const rmr_reads *reads, const float *sig, const int64_t *geo,
+                   float *signal /* f32[n_chunks, L] */, int8_t *seqs, int seq_w, int16_t *maps,
+                   int map_w, int16_t *lens, int64_t *read_focus_bases, int mem);
+
+/* ---- F1 / F2: network forward on materialised inputs ------------------------------------ */
+/* replaces: `model(sigs, enc_kmers)` = ConvLSTM_w_ref.network.forward
+ * (models/ConvLSTM_w_ref.py:39-58) / Conv_w_ref.network.forward (models/Conv_w_ref.py:44-62)
+ * as called from RemoraRead.run_model (src/remora/data_chunks.py:528-533) and
+ * run_model_batched (src/remora/inference.py:311-315).  sigs f32[n,1,L]; seqs f32[n,4K,L]
+ * (any values, not only one-hot); logits f32[n,num_out]. */
+int rmr_forward(rmr_model *m, const float *sigs, const float *seqs, int64_t n, float *logits,
+                int mem);
+
+/* ---- fused hot path: chunk arrays -> logits, never materialising the one-hot ------------- */
+/* replaces: CoreRemoraDataset.extract_batch -> compute_encoded_kmer_batch
+ * (src/remora/data_chunks.py:1652-1676) followed by model(sigs, enc_kmers) — i.e. what
+ * RemoraRead.prepare_batches + run_model (:468-540) and prep_nn_input + run_model_batched
+ * (src/remora/inference.py:152-168, :277-316) compute between them.
+ * label_counts (nullable): i64[num_out], INCREMENTED by the argmax histogram of this call
+ * (first maximum wins, as np.argmax in src/remora/validate.py:42-45). */
+int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w,
+                     const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka,
+                     int64_t n, float *logits, int64_t *label_counts, int mem);
+
+/* argmax histogram of existing logits (same rule), counts[num_out] incremented. */
+int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
+                     int64_t *counts, int mem);
+
+/* ---- measurement: HIP-event timing of every kernel launch on the engine stream ----------- */
+int rmr_profile_enable(rmr_engine *e, int on);
+int rmr_profile_reset(rmr_engine *e);
+int rmr_profile_num_kernels(void);
+const char *rmr_profile_kernel_name(int kernel_id);
+/* synchronises, then returns accumulated event time and launch count for one kernel id */
+int rmr_profile_get(rmr_engine *e, int kernel_id, double *total_ms, int64_t *launches);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMORA_HIP_H */

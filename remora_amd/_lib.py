@@ -1,0 +1,95 @@
+"""ctypes binding of libremora_hip.so (include/remora_hip.h).  Loading fails loudly: the
+product path has no fallback."""
+import ctypes
+import os
+import threading
+
+from . import RemoraError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libremora_hip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+ARCH_CONV_LSTM, ARCH_CONV_ONLY = 0, 1
+ENGINE_OWN_STREAM, ENGINE_USE_STREAM = 0, 1
+ERR_DISCORDANT_SEQ, ERR_DISCORDANT_SIG = -4, -5
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("arch", "size", "kmer_len", "num_out", "chunk_len", "dtype")]
+
+
+class Reads(ctypes.Structure):
+    _fields_ = [
+        ("n_reads", c_i64), ("dacs", c_vp), ("sig_off", c_vp), ("seq_to_sig", c_vp),
+        ("int_seq", c_vp), ("seq_off", c_vp), ("shift", c_vp), ("scale", c_vp),
+        ("focus_bases", c_vp), ("focus_off", c_vp),
+        ("cc_before", ctypes.c_int32), ("cc_after", ctypes.c_int32), ("kb", ctypes.c_int32),
+        ("ka", ctypes.c_int32), ("base_start_justify", ctypes.c_int32), ("offset", ctypes.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/remora_hip.h declares
+SIGNATURES = {
+    "rmr_last_error": (ctypes.c_char_p, []),
+    "rmr_version": (ctypes.c_char_p, []),
+    "rmr_engine_create": (c_int, [c_int, c_vp, c_int, ctypes.POINTER(c_vp)]),
+    "rmr_engine_destroy": (None, [c_vp]),
+    "rmr_engine_synchronize": (c_int, [c_vp]),
+    "rmr_engine_set_subbatch": (c_int, [c_vp, c_i64]),
+    "rmr_model_create": (c_int, [c_vp, ctypes.POINTER(ModelDesc), c_vp, ctypes.c_size_t, ctypes.POINTER(c_vp)]),
+    "rmr_model_destroy": (None, [c_vp]),
+    "rmr_model_weight_count": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc)]),
+    "rmr_encode_kmers": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_int]),
+    "rmr_trim_chunk_context": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int]),
+    "rmr_parse_moves": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, ctypes.POINTER(c_i64), c_int]),
+    "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),
+    "rmr_chunk_fill": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int]),
+    "rmr_forward": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
+    "rmr_infer_chunks": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_int]),
+    "rmr_count_labels": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int]),
+    "rmr_profile_enable": (c_int, [c_vp, c_int]),
+    "rmr_profile_reset": (c_int, [c_vp]),
+    "rmr_profile_num_kernels": (c_int, []),
+    "rmr_profile_kernel_name": (ctypes.c_char_p, [c_int]),
+    "rmr_profile_get": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded library; raises RemoraError if it was not built (python __graft_entry__.py
+    or `make -C remora_amd/csrc`)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RemoraError(
+                    f"{LIB_PATH} not found: build the HIP extension first "
+                    "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                )
+            try:
+                L = ctypes.CDLL(LIB_PATH)
+            except OSError as e:
+                raise RemoraError(f"cannot load {LIB_PATH}: {e}")
+            for name, (res, args) in SIGNATURES.items():
+                try:
+                    fn = getattr(L, name)
+                except AttributeError:
+                    raise RemoraError(f"{LIB_PATH} does not export {name}")
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().rmr_last_error()
+        raise RemoraError((msg or b"unknown error").decode(errors="replace"))

@@ -1,0 +1,839 @@
+// engine.hip — host side of libremora_hip.so: engine/model lifetime, BatchNorm folding and
+// MFMA-fragment packing of the weights, the C ABI entry points and the per-kernel HIP-event
+// profiler.  See include/remora_hip.h for the contract of every entry point and the
+// reference interface (file:line) each one replaces.
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "rmr_internal.h"
+
+namespace rmr {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+static const char *k_names[K_NUM] = {
+    "encode_kmers", "trim_chunk_context", "parse_moves", "normalise_signal", "chunk_geometry",
+    "chunk_fill", "front_sig12_seq1", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
+    "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
+    "count_labels"};
+const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
+
+}  // namespace rmr
+
+using namespace rmr;
+
+// =========================================================================================
+// engine
+// =========================================================================================
+int rmr_engine::ensure(Arena &a, size_t bytes) {
+    if (bytes <= a.cap) return 0;
+    if (a.ptr) {
+        RMR_HIP(hipStreamSynchronize(stream));
+        RMR_HIP(hipFree(a.ptr));
+        a.ptr = nullptr;
+        a.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    hipError_t err = hipMalloc(&a.ptr, want);
+    if (err != hipSuccess) {
+        a.ptr = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(err));
+        return RMR_ERR_NOMEM;
+    }
+    a.cap = want;
+    return 0;
+}
+
+int rmr_engine::prof_begin(int id, hipEvent_t *t1) {
+    hipEvent_t ev[2];
+    for (int k = 0; k < 2; ++k) {
+        if (!pool.empty()) {
+            ev[k] = pool.back();
+            pool.pop_back();
+        } else if (hipEventCreate(&ev[k]) != hipSuccess) {
+            return -1;
+        }
+    }
+    if (hipEventRecord(ev[0], stream) != hipSuccess) return -1;
+    recs.push_back(Rec{id, ev[0], ev[1]});
+    *t1 = ev[1];
+    return 0;
+}
+
+int rmr_engine::prof_collect() {
+    if (recs.empty()) return 0;
+    RMR_HIP(hipStreamSynchronize(stream));
+    for (auto &r : recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.t0, r.t1) == hipSuccess) {
+            acc_ms[r.id] += ms;
+            acc_n[r.id] += 1;
+        }
+        pool.push_back(r.t0);
+        pool.push_back(r.t1);
+    }
+    recs.clear();
+    return 0;
+}
+
+extern "C" {
+
+const char *rmr_last_error(void) { return g_err.c_str(); }
+const char *rmr_version(void) { return "remora_hip 0.1 (gfx950)"; }
+
+int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
+    if (!out) RMR_FAIL(RMR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev == 0) {
+        set_error("no HIP device available (%s)", hipGetErrorString(err));
+        return RMR_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) RMR_FAIL(RMR_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    RMR_HIP(hipSetDevice(device));
+    std::unique_ptr<rmr_engine> e(new rmr_engine());
+    e->device = device;
+    hipDeviceProp_t prop;
+    RMR_HIP(hipGetDeviceProperties(&prop, device));
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (flags & RMR_ENGINE_USE_STREAM) {
+        e->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        RMR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->owns_stream = true;
+    }
+    *out = e.release();
+    return 0;
+}
+
+void rmr_engine_destroy(rmr_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto &r : e->recs) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    if (e->act.ptr) (void)hipFree(e->act.ptr);
+    if (e->staging.ptr) (void)hipFree(e->staging.ptr);
+    if (e->owns_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int rmr_engine_synchronize(rmr_engine *e) {
+    if (!e) RMR_FAIL(RMR_ERR_INVALID, "engine is NULL");
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_engine_set_subbatch(rmr_engine *e, int64_t chunks) {
+    if (!e || chunks < 0) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->subbatch = chunks;
+    return 0;
+}
+
+int rmr_profile_enable(rmr_engine *e, int on) {
+    if (!e) RMR_FAIL(RMR_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_TRY(e->prof_collect());
+    e->profiling = on != 0;
+    return 0;
+}
+int rmr_profile_reset(rmr_engine *e) {
+    if (!e) RMR_FAIL(RMR_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_TRY(e->prof_collect());
+    for (int i = 0; i < K_NUM; ++i) { e->acc_ms[i] = 0; e->acc_n[i] = 0; }
+    return 0;
+}
+int rmr_profile_num_kernels(void) { return K_NUM; }
+const char *rmr_profile_kernel_name(int id) { return kernel_name(id); }
+int rmr_profile_get(rmr_engine *e, int id, double *total_ms, int64_t *launches) {
+    if (!e || id < 0 || id >= K_NUM) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_TRY(e->prof_collect());
+    if (total_ms) *total_ms = e->acc_ms[id];
+    if (launches) *launches = e->acc_n[id];
+    return 0;
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// model: parse the canonical blob, fold BN, pack
+// =========================================================================================
+namespace {
+
+struct ConvSpec { int ic, oc, kw, stride; };
+
+struct Folded {
+    ConvSpec s;
+    std::vector<float> w;  // [oc][ic][kw] folded
+    std::vector<float> b;  // [oc]
+};
+
+size_t conv_count(const ConvSpec &s) { return (size_t)s.oc * s.ic * s.kw + 5 * (size_t)s.oc; }
+
+std::vector<ConvSpec> conv_specs(const rmr_model_desc &d) {
+    const int sz = d.size, ec = 4 * d.kmer_len;
+    if (d.arch == RMR_ARCH_CONV_LSTM)
+        return {{1, 4, 5, 1}, {4, 16, 5, 1}, {16, sz, 9, 3}, {ec, 16, 5, 1}, {16, sz, 13, 3}, {2 * sz, sz, 5, 1}};
+    return {{1, 4, 11, 1}, {4, 16, 11, 1}, {16, sz, 9, 3}, {ec, 16, 11, 1}, {16, 32, 11, 1},
+            {32, sz, 9, 3}, {2 * sz, sz, 5, 1}, {sz, sz, 5, 1}, {sz, sz, 3, 2}, {sz, sz, 3, 2}};
+}
+
+bool desc_ok(const rmr_model_desc &d) {
+    if (d.arch != RMR_ARCH_CONV_LSTM && d.arch != RMR_ARCH_CONV_ONLY) return false;
+    if (d.size != 16 && d.size != 32 && d.size != 64) return false;
+    if (d.kmer_len < 1 || d.kmer_len > 64) return false;
+    if (d.num_out < 1 || d.num_out > 16) return false;
+    if (d.dtype != 0) return false;
+    return true;
+}
+
+Folded fold(const ConvSpec &s, const float *&p) {
+    Folded f;
+    f.s = s;
+    const size_t nw = (size_t)s.oc * s.ic * s.kw;
+    const float *w = p; p += nw;
+    const float *b = p; p += s.oc;
+    const float *g = p; p += s.oc;
+    const float *beta = p; p += s.oc;
+    const float *mean = p; p += s.oc;
+    const float *var = p; p += s.oc;
+    f.w.resize(nw);
+    f.b.resize(s.oc);
+    for (int o = 0; o < s.oc; ++o) {
+        // eval-mode BatchNorm1d, eps = 1e-5 (torch default; the reference folds the same
+        // way for its Dorado export, src/remora/model_util.py:199-221)
+        const double sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+        for (size_t i = 0; i < (size_t)s.ic * s.kw; ++i)
+            f.w[(size_t)o * s.ic * s.kw + i] = (float)((double)w[(size_t)o * s.ic * s.kw + i] * sc);
+        f.b[o] = (float)(((double)b[o] - (double)mean[o]) * sc + (double)beta[o]);
+    }
+    return f;
+}
+
+int upload(rmr_model *m, const std::vector<float> &h, float **dev) {
+    void *p = nullptr;
+    RMR_HIP(hipMalloc(&p, h.size() * sizeof(float) + 16));
+    m->dev_allocs.push_back(p);
+    RMR_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<float *>(p);
+    return 0;
+}
+
+int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
+    const ConvSpec &s = f.s;
+    if (s.ic % 16 || s.oc % 16) RMR_FAIL(RMR_ERR_INVALID, "conv %dx%d not MFMA-tileable", s.ic, s.oc);
+    const int G = s.ic / 16, S = s.kw * s.ic / 4, W = s.oc / 16;
+    std::vector<float> ap((size_t)W * S * 64);
+    for (int w = 0; w < W; ++w)
+        for (int tap = 0; tap < s.kw; ++tap)
+            for (int g = 0; g < G; ++g)
+                for (int j = 0; j < 4; ++j) {
+                    const int st = (tap * G + g) * 4 + j;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int q = lane >> 4, mm = lane & 15;
+                        const int oc = 16 * w + mm, ic = 16 * g + 4 * q + j;
+                        ap[((size_t)w * S + st) * 64 + lane] = f.w[((size_t)oc * s.ic + ic) * s.kw + tap];
+                    }
+                }
+    out->ic = s.ic; out->oc = s.oc; out->kw = s.kw; out->stride = s.stride; out->kid = kid;
+    RMR_TRY(upload(m, ap, &out->apack));
+    RMR_TRY(upload(m, f.b, &out->bias));
+    return 0;
+}
+
+// [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
+std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates) {
+    const int KS = H / 4, G = H / 16, W = H / 16;
+    std::vector<float> ap((size_t)W * ngates * KS * 64);
+    for (int wv = 0; wv < W; ++wv)
+        for (int gi = 0; gi < ngates; ++gi)
+            for (int g = 0; g < G; ++g)
+                for (int j = 0; j < 4; ++j)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int q = lane >> 4, mm = lane & 15;
+                        const int row = gates[gi] * H + 16 * wv + mm, k = 16 * g + 4 * q + j;
+                        ap[(((size_t)wv * ngates + gi) * KS + g * 4 + j) * 64 + lane] = w[(size_t)row * H + k];
+                    }
+    return ap;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rmr_model_weight_count(const rmr_model_desc *d) {
+    if (!d || !desc_ok(*d)) return 0;
+    size_t n = 0;
+    for (auto &s : conv_specs(*d)) n += conv_count(s);
+    const size_t H = d->size;
+    if (d->arch == RMR_ARCH_CONV_LSTM) {
+        n += 2 * (2 * 4 * H * H + 2 * 4 * H);
+        n += (size_t)d->num_out * H + d->num_out;
+    } else {
+        n += (size_t)d->num_out * H * 3 + d->num_out;
+    }
+    return n;
+}
+
+void rmr_model_destroy(rmr_model *m) {
+    if (!m) return;
+    if (m->eng) {
+        (void)hipSetDevice(m->eng->device);
+        (void)hipStreamSynchronize(m->eng->stream);
+    }
+    for (void *p : m->dev_allocs) (void)hipFree(p);
+    delete m;
+}
+
+int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *weights,
+                     size_t n_floats, rmr_model **out) {
+    if (!e || !desc || !weights || !out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (!desc_ok(*desc))
+        RMR_FAIL(RMR_ERR_INVALID,
+                 "unsupported model: arch=%d size=%d kmer_len=%d num_out=%d dtype=%d "
+                 "(size must be 16/32/64, num_out<=16, fp32)",
+                 desc->arch, desc->size, desc->kmer_len, desc->num_out, desc->dtype);
+    const size_t want = rmr_model_weight_count(desc);
+    if (want != n_floats) RMR_FAIL(RMR_ERR_INVALID, "weight blob has %zu floats, expected %zu", n_floats, want);
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    std::unique_ptr<rmr_model, void (*)(rmr_model *)> m(new rmr_model(), rmr_model_destroy);
+    m->eng = e;
+    m->desc = *desc;
+    const int sz = desc->size, K = desc->kmer_len, L = desc->chunk_len;
+
+    const float *p = weights;
+    std::vector<Folded> convs;
+    for (auto &s : conv_specs(*desc)) convs.push_back(fold(s, p));
+
+    // ---- geometry ----
+    const int kw1 = convs[0].s.kw;
+    m->L = L;
+    m->P1 = L - kw1 + 1;
+    m->P2 = m->P1 - kw1 + 1;
+    if (m->P2 < 9) RMR_FAIL(RMR_ERR_INVALID, "chunk_len %d too short for this architecture", L);
+    m->P3 = (m->P2 - 9) / 3 + 1;
+    if (desc->arch == RMR_ARCH_CONV_LSTM) {
+        if ((m->P1 - 13) / 3 + 1 != m->P3) RMR_FAIL(RMR_ERR_INVALID, "branch lengths differ");
+        m->T = m->P3 - 4;
+        if (m->T < 1) RMR_FAIL(RMR_ERR_INVALID, "chunk_len %d too short", L);
+    } else {
+        m->PQ2 = m->P1 - 10;
+        if (m->PQ2 < 9 || (m->PQ2 - 9) / 3 + 1 != m->P3) RMR_FAIL(RMR_ERR_INVALID, "branch lengths differ");
+        m->T = m->P3 - 4;
+        m->T2 = m->T - 4;
+        m->T3 = (m->T2 - 3) / 2 + 1;
+        m->T4 = (m->T3 - 3) / 2 + 1;
+        if (m->T2 < 3 || m->T3 < 3 || m->T4 != 3)
+            RMR_FAIL(RMR_ERR_INVALID, "Conv_w_ref needs 3 final positions (fc in = size*3), chunk_len %d gives %d", L, m->T4);
+    }
+
+    // ---- front weights ----
+    {
+        const Folded &s1 = convs[0], &s2 = convs[1], &q1 = convs[3];
+        std::vector<float> w1((size_t)kw1 * 4), w2((size_t)kw1 * 64), wt((size_t)kw1 * K * 64);
+        for (int t = 0; t < kw1; ++t)
+            for (int o = 0; o < 4; ++o) w1[t * 4 + o] = s1.w[(size_t)o * kw1 + t];
+        for (int t = 0; t < kw1; ++t)
+            for (int ic = 0; ic < 4; ++ic)
+                for (int o = 0; o < 16; ++o) w2[(t * 4 + ic) * 16 + o] = s2.w[((size_t)o * 4 + ic) * kw1 + t];
+        const int ec = 4 * K;
+        for (int t = 0; t < kw1; ++t)
+            for (int c = 0; c < ec; ++c)
+                for (int o = 0; o < 16; ++o) wt[((size_t)t * ec + c) * 16 + o] = q1.w[((size_t)o * ec + c) * kw1 + t];
+        m->front.kw1 = kw1;
+        RMR_TRY(upload(m.get(), w1, &m->front.w_sig1));
+        RMR_TRY(upload(m.get(), s1.b, &m->front.b_sig1));
+        RMR_TRY(upload(m.get(), w2, &m->front.w_sig2));
+        RMR_TRY(upload(m.get(), s2.b, &m->front.b_sig2));
+        RMR_TRY(upload(m.get(), wt, &m->front.wt_seq1));
+        RMR_TRY(upload(m.get(), q1.b, &m->front.b_seq1));
+    }
+    RMR_TRY(pack_conv(m.get(), convs[2], K_CONV_SIG3, &m->sig3));
+    RMR_TRY(pack_conv(m.get(), convs[4], K_CONV_SEQ2, &m->seq2));
+    if (desc->arch == RMR_ARCH_CONV_LSTM) {
+        RMR_TRY(pack_conv(m.get(), convs[5], K_CONV_MERGE1, &m->merge1));
+        const int H = sz;
+        const float *wih1 = p; p += (size_t)4 * H * H;
+        const float *whh1 = p; p += (size_t)4 * H * H;
+        const float *bih1 = p; p += 4 * H;
+        const float *bhh1 = p; p += 4 * H;
+        const float *wih2 = p; p += (size_t)4 * H * H;
+        p += (size_t)4 * H * H;  // lstm2.weight_hh_l0 multiplies h0 == 0: never reaches the output
+        const float *bih2 = p; p += 4 * H;
+        const float *bhh2 = p; p += 4 * H;
+        const float *wfc = p; p += (size_t)desc->num_out * H;
+        const float *bfc = p; p += desc->num_out;
+        const int g4[4] = {0, 1, 2, 3}, g3[3] = {0, 2, 3};
+        RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4), &m->lstm.a_ih1));
+        RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4), &m->lstm.a_hh1));
+        RMR_TRY(upload(m.get(), pack_lstm(wih2, H, g3, 3), &m->lstm.a_ih2));
+        std::vector<float> b1(4 * H), b2(3 * H);
+        for (int i = 0; i < 4 * H; ++i) b1[i] = bih1[i] + bhh1[i];
+        for (int gi = 0; gi < 3; ++gi)
+            for (int u = 0; u < H; ++u) b2[gi * H + u] = bih2[g3[gi] * H + u] + bhh2[g3[gi] * H + u];
+        RMR_TRY(upload(m.get(), b1, &m->lstm.b1));
+        RMR_TRY(upload(m.get(), b2, &m->lstm.b2));
+        RMR_TRY(upload(m.get(), std::vector<float>(wfc, wfc + (size_t)desc->num_out * H), &m->lstm.w_fc));
+        RMR_TRY(upload(m.get(), std::vector<float>(bfc, bfc + desc->num_out), &m->lstm.b_fc));
+    } else {
+        RMR_TRY(pack_conv(m.get(), convs[5], K_CONV_SEQ3, &m->seq3));
+        RMR_TRY(pack_conv(m.get(), convs[6], K_CONV_MERGE1, &m->merge1));
+        RMR_TRY(pack_conv(m.get(), convs[7], K_CONV_MERGE2, &m->merge2));
+        RMR_TRY(pack_conv(m.get(), convs[8], K_CONV_MERGE3, &m->merge3));
+        RMR_TRY(pack_conv(m.get(), convs[9], K_CONV_MERGE4, &m->merge4));
+        const float *wfc = p; p += (size_t)desc->num_out * sz * 3;
+        const float *bfc = p; p += desc->num_out;
+        RMR_TRY(upload(m.get(), std::vector<float>(wfc, wfc + (size_t)desc->num_out * sz * 3), &m->w_fc));
+        RMR_TRY(upload(m.get(), std::vector<float>(bfc, bfc + desc->num_out), &m->b_fc));
+    }
+    if ((size_t)(p - weights) != n_floats) RMR_FAIL(RMR_ERR_INVALID, "internal: blob walk mismatch");
+    *out = m.release();
+    return 0;
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// fused pipeline
+// =========================================================================================
+namespace {
+
+size_t act_floats_per_chunk(const rmr_model *m) {
+    const size_t sz = m->desc.size;
+    size_t n = (size_t)m->P1 * 16 + (size_t)m->P2 * 16 + (size_t)m->P3 * 2 * sz;
+    if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
+        n += (size_t)m->T * sz;
+    } else {
+        n += (size_t)m->PQ2 * 32 + (size_t)(m->T + m->T2 + m->T3 + m->T4) * sz;
+    }
+    return n;
+}
+
+// enc != nullptr: dense seqs path; otherwise gather path from (seqs, maps, lens)
+int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8_t *seqs, int seq_w,
+                 const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
+                 float *logits) {
+    rmr_engine *e = m->eng;
+    if (n <= 0) return 0;
+    const size_t per = act_floats_per_chunk(m);
+    int64_t sb = e->subbatch > 0 ? e->subbatch : 16384;
+    if (sb > n) sb = n;
+    RMR_TRY(e->ensure(e->act, per * sb * sizeof(float)));
+    const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;
+    for (int64_t c0 = 0; c0 < n; c0 += sb) {
+        const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
+        float *base = reinterpret_cast<float *>(e->act.ptr);
+        float *seq1 = base; base += (size_t)nb * m->P1 * 16;
+        float *sig2 = base; base += (size_t)nb * m->P2 * 16;
+        float *cat = base; base += (size_t)nb * m->P3 * 2 * sz;
+        const float *sig_b = signal + (size_t)c0 * L;
+        if (enc) {
+            RMR_TRY(launch_front(m, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
+            RMR_TRY(launch_seq1_dense(m, enc + (size_t)c0 * EC * L, nb, seq1));
+        } else {
+            RMR_TRY(launch_front(m, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
+                                 map_w, lens + c0, kb, ka, nb, sig2, seq1));
+        }
+        RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
+        if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
+            float *x = base; base += (size_t)nb * m->T * sz;
+            RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
+            RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
+            RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
+        } else {
+            float *seq2 = base; base += (size_t)nb * m->PQ2 * 32;
+            float *m1 = base; base += (size_t)nb * m->T * sz;
+            float *m2 = base; base += (size_t)nb * m->T2 * sz;
+            float *m3 = base; base += (size_t)nb * m->T3 * sz;
+            float *m4 = base; base += (size_t)nb * m->T4 * sz;
+            RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, seq2, 32, 0, m->PQ2, nb));
+            RMR_TRY(launch_conv(e, m->seq3, seq2, 32, m->PQ2, cat, 2 * sz, sz, m->P3, nb));
+            RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, m1, sz, 0, m->T, nb));
+            RMR_TRY(launch_conv(e, m->merge2, m1, sz, m->T, m2, sz, 0, m->T2, nb));
+            RMR_TRY(launch_conv(e, m->merge3, m2, sz, m->T2, m3, sz, 0, m->T3, nb));
+            RMR_TRY(launch_conv(e, m->merge4, m3, sz, m->T3, m4, sz, 0, m->T4, nb));
+            RMR_TRY(launch_fc_head(m, m4, nb, logits + (size_t)c0 * m->desc.num_out));
+        }
+    }
+    return 0;
+}
+
+// host <-> device staging helper: a bump allocator over the engine's staging arena
+struct Stage {
+    rmr_engine *e;
+    char *base = nullptr;
+    size_t off = 0, cap = 0;
+    int init(size_t bytes) {
+        RMR_TRY(e->ensure(e->staging, bytes));
+        base = reinterpret_cast<char *>(e->staging.ptr);
+        cap = bytes;
+        return 0;
+    }
+    template <typename T>
+    T *take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+};
+
+#define H2D(dst, src, bytes) do { if ((bytes) > 0) RMR_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, e->stream)); } while (0)
+#define D2H(dst, src, bytes) do { if ((bytes) > 0) RMR_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, e->stream)); } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int rmr_encode_kmers(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
+                     const int16_t *maps, int map_w, const int16_t *lens, int64_t n, int sig_len,
+                     float *out, int mem) {
+    if (!e || !seqs || !maps || !lens || !out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (kb < 0 || ka < 0 || n < 0 || sig_len <= 0 || seq_w <= 0 || map_w <= 0)
+        RMR_FAIL(RMR_ERR_INVALID, "bad sizes");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    const size_t out_b = (size_t)n * 4 * (kb + ka + 1) * sig_len * sizeof(float);
+    if (mem == RMR_MEM_DEVICE) return launch_encode(e, kb, ka, seqs, seq_w, maps, map_w, lens, n, sig_len, out);
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad(n * seq_w) + Stage::pad(n * map_w * 2) + Stage::pad(n * 2) + Stage::pad(out_b) + 1024));
+    int8_t *ds = st.take<int8_t>(n * seq_w);
+    int16_t *dm = st.take<int16_t>(n * map_w);
+    int16_t *dl = st.take<int16_t>(n);
+    float *dout = st.take<float>(out_b / 4);
+    H2D(ds, seqs, (size_t)n * seq_w);
+    H2D(dm, maps, (size_t)n * map_w * 2);
+    H2D(dl, lens, (size_t)n * 2);
+    RMR_TRY(launch_encode(e, kb, ka, ds, seq_w, dm, map_w, dl, n, sig_len, dout));
+    D2H(out, dout, out_b);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_trim_chunk_context(rmr_engine *e, int sb, int sa, int cb, int ca, int tsc, int8_t *seqs,
+                           int seq_w, int16_t *maps, int map_w, int16_t *lens, int64_t n, int mem) {
+    if (!e || !seqs || !maps || !lens) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n <= 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    if (mem == RMR_MEM_DEVICE) return launch_trim(e, sb, sa, cb, ca, tsc, seqs, seq_w, maps, map_w, lens, n);
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad(n * seq_w) + Stage::pad(n * map_w * 2) + Stage::pad(n * 2) + 1024));
+    int8_t *ds = st.take<int8_t>(n * seq_w);
+    int16_t *dm = st.take<int16_t>(n * map_w);
+    int16_t *dl = st.take<int16_t>(n);
+    H2D(ds, seqs, (size_t)n * seq_w);
+    H2D(dm, maps, (size_t)n * map_w * 2);
+    H2D(dl, lens, (size_t)n * 2);
+    RMR_TRY(launch_trim(e, sb, sa, cb, ca, tsc, ds, seq_w, dm, map_w, dl, n));
+    D2H(seqs, ds, (size_t)n * seq_w);
+    D2H(maps, dm, (size_t)n * map_w * 2);
+    D2H(lens, dl, (size_t)n * 2);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_t sig_len,
+                    int64_t seq_len, int check, int reverse_signal, int64_t *q2s, int64_t *n_out,
+                    int mem) {
+    if (!e || !mv_tag || !q2s || !n_out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (mv_tag_len < 1) RMR_FAIL(RMR_ERR_INVALID, "empty move tag");
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad(mv_tag_len) + Stage::pad((mv_tag_len + 1) * 8) + 2048));
+    int64_t *dcount = st.take<int64_t>(1);
+    int8_t stride_h = 0;
+    const int8_t *dmv = mv_tag;
+    int64_t *dq = q2s;
+    if (mem == RMR_MEM_HOST) {
+        int8_t *t = st.take<int8_t>(mv_tag_len);
+        H2D(t, mv_tag, (size_t)mv_tag_len);
+        dmv = t;
+        dq = st.take<int64_t>(mv_tag_len + 1);
+        stride_h = mv_tag[0];
+    } else {
+        RMR_HIP(hipMemcpyAsync(&stride_h, mv_tag, 1, hipMemcpyDeviceToHost, e->stream));
+    }
+    RMR_TRY(launch_moves(e, dmv, mv_tag_len, sig_len, reverse_signal, dq, dcount));
+    int64_t cnt = 0;
+    D2H(&cnt, dcount, 8);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    if (mem == RMR_MEM_HOST) {
+        RMR_HIP(hipMemcpy(q2s, dq, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    }
+    *n_out = cnt;
+    if (stride_h <= 0) RMR_FAIL(RMR_ERR_INVALID, "move table stride %d", (int)stride_h);
+    if (check && seq_len >= 0 && cnt - 1 != seq_len) {
+        set_error("Move table discordant with basecalls");
+        return RMR_ERR_DISCORDANT_SEQ;
+    }
+    if (check && (mv_tag_len - 1) != sig_len / stride_h) {
+        set_error("Move table discordant with signal");
+        return RMR_ERR_DISCORDANT_SIG;
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- chunk extraction ------------------------------------------------------------------------
+namespace {
+
+// device-side copy of an rmr_reads whose arrays live on the host
+struct DevReads {
+    rmr_reads d{};
+    int32_t *chunk_read = nullptr;
+    int32_t *sig_read = nullptr;
+    int64_t n_chunks = 0, total_sig = 0, total_bases = 0;
+};
+
+int read_offsets_host(rmr_engine *e, const rmr_reads *r, int mem, std::vector<int64_t> &sig_off,
+                      std::vector<int64_t> &seq_off, std::vector<int64_t> &foc_off) {
+    const size_t n1 = (size_t)r->n_reads + 1;
+    sig_off.resize(n1); seq_off.resize(n1); foc_off.resize(n1);
+    if (mem == RMR_MEM_HOST) {
+        memcpy(sig_off.data(), r->sig_off, n1 * 8);
+        memcpy(seq_off.data(), r->seq_off, n1 * 8);
+        memcpy(foc_off.data(), r->focus_off, n1 * 8);
+    } else {
+        RMR_HIP(hipMemcpy(sig_off.data(), r->sig_off, n1 * 8, hipMemcpyDeviceToHost));
+        RMR_HIP(hipMemcpy(seq_off.data(), r->seq_off, n1 * 8, hipMemcpyDeviceToHost));
+        RMR_HIP(hipMemcpy(foc_off.data(), r->focus_off, n1 * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int stage_reads(rmr_engine *e, Stage &st, const rmr_reads *r, int mem, bool need_dacs, DevReads *o) {
+    std::vector<int64_t> sig_off, seq_off, foc_off;
+    RMR_TRY(read_offsets_host(e, r, mem, sig_off, seq_off, foc_off));
+    const int64_t nr = r->n_reads;
+    o->total_sig = sig_off[nr];
+    o->total_bases = seq_off[nr];
+    o->n_chunks = foc_off[nr];
+    o->d = *r;
+    // read index per chunk / per sample (host-built, tiny next to the data itself)
+    std::vector<int32_t> cr((size_t)o->n_chunks), sr;
+    for (int64_t k = 0; k < nr; ++k)
+        for (int64_t i = foc_off[k]; i < foc_off[k + 1]; ++i) cr[(size_t)i] = (int32_t)k;
+    o->chunk_read = st.take<int32_t>(o->n_chunks + 1);
+    H2D(o->chunk_read, cr.data(), cr.size() * 4);
+    if (need_dacs && nr > 1) {
+        sr.resize((size_t)o->total_sig);
+        for (int64_t k = 0; k < nr; ++k)
+            for (int64_t i = sig_off[k]; i < sig_off[k + 1]; ++i) sr[(size_t)i] = (int32_t)k;
+        o->sig_read = st.take<int32_t>(o->total_sig + 1);
+        H2D(o->sig_read, sr.data(), sr.size() * 4);
+    }
+    if (mem == RMR_MEM_HOST) {
+#define STAGE_ARR(field, T, count)                                        \
+    {                                                                     \
+        T *d_ = st.take<T>((count) + 1);                                  \
+        H2D(d_, r->field, (size_t)(count) * sizeof(T));                   \
+        o->d.field = d_;                                                  \
+    }
+        if (need_dacs) STAGE_ARR(dacs, int16_t, o->total_sig)
+        STAGE_ARR(sig_off, int64_t, nr + 1)
+        STAGE_ARR(seq_to_sig, int64_t, o->total_bases + nr)
+        STAGE_ARR(int_seq, int8_t, o->total_bases)
+        STAGE_ARR(seq_off, int64_t, nr + 1)
+        STAGE_ARR(shift, double, nr)
+        STAGE_ARR(scale, double, nr)
+        STAGE_ARR(focus_bases, int64_t, o->n_chunks)
+        STAGE_ARR(focus_off, int64_t, nr + 1)
+#undef STAGE_ARR
+    }
+    // the H2D copies above read from host vectors that die with this frame
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+size_t reads_stage_bytes(const rmr_reads *r, int64_t total_sig, int64_t total_bases, int64_t n_chunks) {
+    const int64_t nr = r->n_reads;
+    return Stage::pad(total_sig * 2) + Stage::pad(total_sig * 4 + 8) + 4 * Stage::pad((nr + 2) * 8) +
+           Stage::pad((total_bases + nr + 1) * 8) + Stage::pad(total_bases + 1) + 2 * Stage::pad((nr + 1) * 8) +
+           Stage::pad((n_chunks + 1) * 8) + Stage::pad((n_chunks + 1) * 4) + 8192;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmr_chunk_geometry(rmr_engine *e, const rmr_reads *reads, float *sig_out, int64_t *geo,
+                       int64_t *max_seq_len, int mem) {
+    if (!e || !reads || !sig_out || !geo || !max_seq_len) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (reads->n_reads < 0) RMR_FAIL(RMR_ERR_INVALID, "n_reads < 0");
+    *max_seq_len = 0;
+    if (reads->n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    std::vector<int64_t> so, qo, fo;
+    RMR_TRY(read_offsets_host(e, reads, mem, so, qo, fo));
+    const int64_t nr = reads->n_reads, ts = so[nr], tb = qo[nr], nc = fo[nr];
+    Stage st{e};
+    RMR_TRY(st.init(reads_stage_bytes(reads, ts, tb, nc) + Stage::pad(ts * 4) + Stage::pad(nc * 48) + 4096));
+    DevReads dr;
+    RMR_TRY(stage_reads(e, st, reads, mem, true, &dr));
+    int *dmax = st.take<int>(4);
+    RMR_HIP(hipMemsetAsync(dmax, 0, 16, e->stream));
+    float *dsig = sig_out;
+    int64_t *dgeo = geo;
+    if (mem == RMR_MEM_HOST) {
+        dsig = st.take<float>(ts + 1);
+        dgeo = st.take<int64_t>(nc * 6 + 1);
+    }
+    RMR_TRY(launch_geometry(e, dr.d, nc, dr.chunk_read, dsig, ts, dr.sig_read, dgeo, dmax));
+    int hmax = 0;
+    D2H(&hmax, dmax, 4);
+    if (mem == RMR_MEM_HOST) {
+        D2H(sig_out, dsig, (size_t)ts * 4);
+        D2H(geo, dgeo, (size_t)nc * 48);
+    }
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    *max_seq_len = hmax;
+    return 0;
+}
+
+int rmr_chunk_fill(rmr_engine *e, const rmr_reads *reads, const float *sig, const int64_t *geo,
+                   float *signal, int8_t *seqs, int seq_w, int16_t *maps, int map_w, int16_t *lens,
+                   int64_t *read_focus_bases, int mem) {
+    if (!e || !reads || !sig || !geo || !signal || !seqs || !maps || !lens || !read_focus_bases)
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (reads->n_reads <= 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    std::vector<int64_t> so, qo, fo;
+    RMR_TRY(read_offsets_host(e, reads, mem, so, qo, fo));
+    const int64_t nr = reads->n_reads, ts = so[nr], tb = qo[nr], nc = fo[nr];
+    if (nc == 0) return 0;
+    const int L = reads->cc_before + reads->cc_after;
+    Stage st{e};
+    RMR_TRY(st.init(reads_stage_bytes(reads, ts, tb, nc) + Stage::pad(ts * 4) + Stage::pad(nc * 48) +
+                    Stage::pad((size_t)nc * L * 4) + Stage::pad((size_t)nc * seq_w) +
+                    Stage::pad((size_t)nc * map_w * 2) + Stage::pad(nc * 2) + Stage::pad(nc * 8) + 8192));
+    DevReads dr;
+    RMR_TRY(stage_reads(e, st, reads, mem, false, &dr));
+    if (mem == RMR_MEM_DEVICE)
+        return launch_fill(e, dr.d, nc, dr.chunk_read, sig, geo, signal, seqs, seq_w, maps, map_w, lens,
+                           read_focus_bases);
+    float *dsig = st.take<float>(ts + 1);
+    int64_t *dgeo = st.take<int64_t>(nc * 6);
+    float *dsignal = st.take<float>((size_t)nc * L);
+    int8_t *dseqs = st.take<int8_t>((size_t)nc * seq_w);
+    int16_t *dmaps = st.take<int16_t>((size_t)nc * map_w);
+    int16_t *dlens = st.take<int16_t>(nc);
+    int64_t *drfb = st.take<int64_t>(nc);
+    H2D(dsig, sig, (size_t)ts * 4);
+    H2D(dgeo, geo, (size_t)nc * 48);
+    RMR_TRY(launch_fill(e, dr.d, nc, dr.chunk_read, dsig, dgeo, dsignal, dseqs, seq_w, dmaps, map_w, dlens, drfb));
+    D2H(signal, dsignal, (size_t)nc * L * 4);
+    D2H(seqs, dseqs, (size_t)nc * seq_w);
+    D2H(maps, dmaps, (size_t)nc * map_w * 2);
+    D2H(lens, dlens, (size_t)nc * 2);
+    D2H(read_focus_bases, drfb, (size_t)nc * 8);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts,
+                     int mem) {
+    if (!e || !logits || !counts) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (num_out < 1 || num_out > 16) RMR_FAIL(RMR_ERR_INVALID, "num_out %d not in [1,16]", num_out);
+    if (n <= 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    if (mem == RMR_MEM_DEVICE) return launch_count(e, logits, n, num_out, counts);
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad((size_t)n * num_out * 4) + 4096));
+    float *dl = st.take<float>((size_t)n * num_out);
+    int64_t *dc = st.take<int64_t>(16);
+    H2D(dl, logits, (size_t)n * num_out * 4);
+    H2D(dc, counts, (size_t)num_out * 8);
+    RMR_TRY(launch_count(e, dl, n, num_out, dc));
+    D2H(counts, dc, (size_t)num_out * 8);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_forward(rmr_model *m, const float *sigs, const float *seqs, int64_t n, float *logits, int mem) {
+    if (!m || !sigs || !seqs || !logits) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n <= 0) return 0;
+    rmr_engine *e = m->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    if (mem == RMR_MEM_DEVICE) return run_pipeline(m, sigs, seqs, nullptr, 0, nullptr, 0, nullptr, 0, 0, n, logits);
+    const size_t L = m->L, EC = 4 * (size_t)m->desc.kmer_len, no = m->desc.num_out;
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad(n * L * 4) + Stage::pad(n * EC * L * 4) + Stage::pad(n * no * 4) + 4096));
+    float *ds = st.take<float>(n * L);
+    float *dq = st.take<float>(n * EC * L);
+    float *dl = st.take<float>(n * no);
+    H2D(ds, sigs, n * L * 4);
+    H2D(dq, seqs, n * EC * L * 4);
+    RMR_TRY(run_pipeline(m, ds, dq, nullptr, 0, nullptr, 0, nullptr, 0, 0, n, dl));
+    D2H(logits, dl, n * no * 4);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w,
+                     const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
+                     float *logits, int64_t *label_counts, int mem) {
+    if (!m || !signal || !seqs || !maps || !lens || !logits) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (kb < 0 || ka < 0 || kb + ka + 1 != m->desc.kmer_len)
+        RMR_FAIL(RMR_ERR_INVALID, "kmer context (%d,%d) does not match model kmer_len %d", kb, ka, m->desc.kmer_len);
+    if (seq_w < kb + ka + 1 || map_w < 2) RMR_FAIL(RMR_ERR_INVALID, "bad array widths");
+    if (n <= 0) return 0;
+    rmr_engine *e = m->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    const int no = m->desc.num_out;
+    if (mem == RMR_MEM_DEVICE) {
+        RMR_TRY(run_pipeline(m, signal, nullptr, seqs, seq_w, maps, map_w, lens, kb, ka, n, logits));
+        if (label_counts) RMR_TRY(launch_count(e, logits, n, no, label_counts));
+        return 0;
+    }
+    const size_t L = m->L;
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad(n * L * 4) + Stage::pad((size_t)n * seq_w) + Stage::pad((size_t)n * map_w * 2) +
+                    Stage::pad(n * 2) + Stage::pad((size_t)n * no * 4) + 8192));
+    float *dsig = st.take<float>(n * L);
+    int8_t *ds = st.take<int8_t>((size_t)n * seq_w);
+    int16_t *dm = st.take<int16_t>((size_t)n * map_w);
+    int16_t *dl = st.take<int16_t>(n);
+    float *dlog = st.take<float>((size_t)n * no);
+    int64_t *dc = st.take<int64_t>(16);
+    H2D(dsig, signal, n * L * 4);
+    H2D(ds, seqs, (size_t)n * seq_w);
+    H2D(dm, maps, (size_t)n * map_w * 2);
+    H2D(dl, lens, (size_t)n * 2);
+    RMR_TRY(run_pipeline(m, dsig, nullptr, ds, seq_w, dm, map_w, dl, kb, ka, n, dlog));
+    if (label_counts) {
+        H2D(dc, label_counts, (size_t)no * 8);
+        RMR_TRY(launch_count(e, dlog, n, no, dc));
+        D2H(label_counts, dc, (size_t)no * 8);
+    }
+    D2H(logits, dlog, (size_t)n * no * 4);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+}  // extern "C"

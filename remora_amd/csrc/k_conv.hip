@@ -1,0 +1,181 @@
+// k_conv.hip — 1-D convolution + folded BatchNorm + swish as an implicit GEMM on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32), channel-last activations.
+//
+// Replaces the nn.Conv1d/BatchNorm1d/swish triples of the reference networks that have
+// >= 16 input channels: models/ConvLSTM_w_ref.py:43 (sig_conv3), :46 (seq_conv2),
+// :50 (merge_conv1); models/Conv_w_ref.py:47,50-51,54-57.
+//
+// GEMM view:  out[oc][col] = sum_{tap, ic} W[oc][ic][tap] * in[chunk(col)][pos(col)*S + tap][ic]
+//   M = oc  (one 16-row MFMA tile per wave: wave w owns channels 16w..16w+15; the whole
+//            K-extent of its weight slice lives in VGPRs for the lifetime of the block)
+//   N = (chunk, output position) flattened, 16 columns per MFMA tile
+//   K = (tap, ic); within a 16-channel group g the four MFMA k-lanes q=lane>>4 take
+//       channels 16g+4q+j for MFMA j=0..3, so ONE ds_read_b128 of 4 consecutive channels
+//       feeds four MFMAs, and the D fragment (4 consecutive oc x 1 column per lane) is
+//       ONE 16-byte store in the channel-last output.
+//
+// LDS: CB chunks of input staged as rows of IC floats padded to IC+4 (row stride/4 odd ->
+// the 16 columns of a tile land on distinct 16-byte bank slots for ds_read_b128).
+#include "rmr_internal.h"
+
+namespace rmr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float *in;
+    float *out;
+    const float *apack;
+    const float *bias;
+    int64_t n;      // chunks
+    int in_row;     // floats per input position (== IC)
+    int pin, pout;  // positions per chunk in / out
+    int out_row;    // floats per output position
+    int out_coff;   // channel offset of this layer's output inside out_row
+    int cb;         // chunks per block iteration
+    FastDiv div_pout;
+};
+
+__device__ __forceinline__ float swish_f(float x) {
+    // x * sigmoid(x)   (src/remora/activations.py:4-18)
+    return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+template <int IC, int KW, int STRIDE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RS = IC + 4;        // padded LDS row (floats)
+    constexpr int G = IC / 16;        // 16-channel groups
+    constexpr int S = KW * IC / 4;    // MFMA k-steps
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+
+    // register-resident weight slice of this wave
+    float A[S];
+    {
+        const float *ap = a.apack + (size_t)w * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) A[s] = ap[(size_t)s * 64];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        __syncthreads();  // all reads of the previous iteration are done
+        {                 // stage nch * pin rows of IC floats
+            constexpr int R4 = IC / 4;
+            const int total4 = nch * a.pin * R4;
+            const float4 *src = reinterpret_cast<const float4 *>(a.in + (size_t)chunk0 * a.pin * a.in_row);
+            for (int i = tid; i < total4; i += blockDim.x) {
+                const int row = i / R4, c4 = i - row * R4;
+                const float4 v = src[i];
+                *reinterpret_cast<float4 *>(smem + (size_t)row * RS + 4 * c4) = v;
+            }
+        }
+        __syncthreads();
+        const int ncols = nch * a.pout;
+        const int ntiles = (ncols + 15) >> 4;
+        for (int tile = 0; tile < ntiles; tile += 2) {
+            int col0 = tile * 16 + nn, col1 = col0 + 16;
+            const bool v0 = col0 < ncols, v1 = col1 < ncols;
+            col0 = v0 ? col0 : ncols - 1;
+            col1 = v1 ? col1 : ncols - 1;
+            const int ch0 = (int)(((float)col0 + 0.5f) * a.div_pout.inv);
+            const int ch1 = (int)(((float)col1 + 0.5f) * a.div_pout.inv);
+            const int p0 = col0 - ch0 * a.pout, p1 = col1 - ch1 * a.pout;
+            const float *r0 = smem + (size_t)(ch0 * a.pin + p0 * STRIDE) * RS + 4 * q;
+            const float *r1 = smem + (size_t)(ch1 * a.pin + p1 * STRIDE) * RS + 4 * q;
+            f32x4 acc0 = b4, acc1 = b4;
+#pragma unroll
+            for (int tap = 0; tap < KW; ++tap) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0 + tap * RS + 16 * g);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(r1 + tap * RS + 16 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = (tap * G + g) * 4 + j;
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], x0[j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], x1[j], acc1, 0, 0, 0);
+                    }
+                }
+            }
+            if (v0) {
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = swish_f(acc0[r]);
+                float *dst = a.out + ((size_t)(chunk0 + ch0) * a.pout + p0) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                *reinterpret_cast<f32x4 *>(dst) = y;
+            }
+            if (v1) {
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = swish_f(acc1[r]);
+                float *dst = a.out + ((size_t)(chunk0 + ch1) * a.pout + p1) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                *reinterpret_cast<f32x4 *>(dst) = y;
+            }
+        }
+    }
+}
+
+template <int IC, int KW, int STRIDE>
+static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
+                         float *out, int out_row, int out_coff, int pout, int64_t n) {
+    constexpr int RS = IC + 4;
+    // chunks per iteration: fill <= 72 KB of LDS (2 blocks per CU) and give an even
+    // number of 16-column tiles where possible
+    const size_t row_bytes = (size_t)pin * RS * sizeof(float);
+    int cb = (int)(73728 / row_bytes);
+    if (cb < 1) cb = 1;
+    if (cb > 8) cb = 8;
+    if (cb >= 4) cb &= ~3;  // multiples of 4 chunks -> cb*pout divisible by 4
+    const size_t lds = row_bytes * cb;
+    if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "conv layer needs %zu B of LDS", lds);
+    ConvArgs a;
+    a.in = in; a.out = out; a.apack = c.apack; a.bias = c.bias; a.n = n;
+    a.in_row = in_row; a.pin = pin; a.pout = pout; a.out_row = out_row; a.out_coff = out_coff;
+    a.cb = cb; a.div_pout = make_fastdiv(pout);
+    const int64_t iters = (n + cb - 1) / cb;
+    const int threads = 64 * (c.oc / 16);
+    int64_t grid = (int64_t)e->num_cus * 2;
+    if (grid > iters) grid = iters;
+    if (grid < 1) return 0;
+    auto kern = conv_mfma_kernel<IC, KW, STRIDE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    ProfScope ps(e, c.kid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
+                float *out, int out_row, int out_coff, int pout, int64_t n) {
+    if (in_row != c.ic) RMR_FAIL(RMR_ERR_INVALID, "conv input row %d != ic %d", in_row, c.ic);
+#define RMR_CONV_CASE(IC_, KW_, ST_)                                  \
+    if (c.ic == IC_ && c.kw == KW_ && c.stride == ST_)                \
+        return launch_conv_t<IC_, KW_, ST_>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);
+    // ConvLSTM_w_ref (size 64 / 32 / 16)
+    RMR_CONV_CASE(16, 9, 3)    // sig_conv3
+    RMR_CONV_CASE(16, 13, 3)   // seq_conv2
+    RMR_CONV_CASE(128, 5, 1)   // merge_conv1, size 64
+    RMR_CONV_CASE(64, 5, 1)    // merge_conv1 size 32; Conv_w_ref merge_conv2 size 64
+    RMR_CONV_CASE(32, 5, 1)    // merge_conv1 size 16; merge_conv2 size 32
+    // Conv_w_ref
+    RMR_CONV_CASE(16, 11, 1)   // seq_conv2
+    RMR_CONV_CASE(32, 9, 3)    // seq_conv3
+    RMR_CONV_CASE(64, 3, 2)    // merge_conv3/4 size 64
+    RMR_CONV_CASE(32, 3, 2)
+    RMR_CONV_CASE(16, 5, 1)
+    RMR_CONV_CASE(16, 3, 2)
+#undef RMR_CONV_CASE
+    RMR_FAIL(RMR_ERR_INVALID, "no conv kernel for ic=%d kw=%d stride=%d", c.ic, c.kw, c.stride);
+}
+
+}  // namespace rmr

@@ -1,0 +1,385 @@
+// k_data.hip — the integer / byte side of the hot path (all HBM-bound):
+//   E1 encode_kmers   src/remora/encoded_kmers.pyx:13-45
+//   T1 trim           src/remora/data_chunks_core.pyx:10-45
+//   M1 parse_moves    src/remora/io.py:394-407
+//   X1 normalise      src/remora/data_chunks.py:191-197
+//   X2/X3 geometry + fill   src/remora/data_chunks.py:425-466, :331-423, :1376-1418
+//   label tally       src/remora/validate.py:42-45 (argmax), data_chunks.py:1074-1082
+#include "rmr_internal.h"
+
+namespace rmr {
+
+// ======================================================================================
+// E1: out f32[n][4K][L].  One block iteration = one chunk: the mapping row is expanded to
+// p(s) once in LDS (upper_bound, the gather form of the reference's scatter loops), then
+// the chunk's 4K*L floats are produced as coalesced 16-byte stores, each lane deriving
+// (row, s) from its flat element index.  Algorithmic traffic: 72 B in, 14,400 B out per
+// C100 chunk -> pure HBM-write roofline.
+// ======================================================================================
+struct EncodeArgs {
+    const int8_t *seqs;
+    const int16_t *maps;
+    const int16_t *lens;
+    float *out;
+    int64_t n;
+    int seq_w, map_w, K, L;
+    float inv_L;
+};
+
+__global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    // per wave-pair? keep simple: one chunk per block iteration
+    int16_t *s_pidx = reinterpret_cast<int16_t *>(smem_i);                 // [Lp]
+    const int Lp = (a.L + 7) & ~7;
+    int8_t *s_seq = reinterpret_cast<int8_t *>(s_pidx + Lp);               // [seq_w]
+    const int tid = threadIdx.x;
+    const int total = 4 * a.K * a.L;       // floats per chunk (multiple of 4)
+    for (int64_t c = blockIdx.x; c < a.n; c += gridDim.x) {
+        __syncthreads();
+        const int len = a.lens[c];
+        const int16_t *mp = a.maps + (size_t)c * a.map_w;
+        for (int s = tid; s < a.L; s += blockDim.x) {
+            int lo = 0, hi = len + 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (mp[mid] <= s) lo = mid + 1; else hi = mid;
+            }
+            const int p = lo - 1;
+            s_pidx[s] = (int16_t)((p >= 0 && p < len) ? p : -1);
+        }
+        for (int j = tid; j < a.seq_w; j += blockDim.x) s_seq[j] = a.seqs[(size_t)c * a.seq_w + j];
+        __syncthreads();
+        float4 *dst = reinterpret_cast<float4 *>(a.out + (size_t)c * total);
+        for (int f = tid; f < total / 4; f += blockDim.x) {
+            float v[4];
+            const int e0 = 4 * f;
+            int row = (int)(((float)e0 + 0.5f) * a.inv_L);
+            int s = e0 - row * a.L;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = s_pidx[s];
+                const int kp = row >> 2, b = row & 3;
+                v[k] = (p >= 0 && s_seq[p + kp] == b) ? 1.0f : 0.0f;
+                if (++s == a.L) { s = 0; ++row; }
+            }
+            dst[f] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
+                  const int16_t *maps, int map_w, const int16_t *lens, int64_t n, int sig_len,
+                  float *out) {
+    if (n <= 0) return 0;
+    EncodeArgs a;
+    a.seqs = seqs; a.maps = maps; a.lens = lens; a.out = out; a.n = n;
+    a.seq_w = seq_w; a.map_w = map_w; a.K = kb + ka + 1; a.L = sig_len;
+    a.inv_L = 1.0f / (float)sig_len;
+    if ((size_t)4 * a.K * sig_len >= (1u << 21)) RMR_FAIL(RMR_ERR_INVALID, "encode: chunk too large");
+    const int Lp = (sig_len + 7) & ~7;
+    const size_t lds = (size_t)Lp * 2 + ((seq_w + 15) & ~15);
+    int64_t grid = (int64_t)e->num_cus * 8;
+    if (grid > n) grid = n;
+    ProfScope ps(e, K_ENCODE);
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ======================================================================================
+// T1: one thread per chunk, in-row shifts exactly as the reference's loops (rows are a
+// few tens of bytes; the work is a byte shuffle bounded by HBM).
+// ======================================================================================
+__global__ void trim_kernel(int sb, int sa, int cb, int ca, int tsc, int8_t *seqs, int seq_w,
+                            int16_t *maps, int map_w, int16_t *lens, int64_t n) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int16_t *cm = maps + (size_t)c * map_w;
+    int8_t *cs = seqs + (size_t)c * seq_w;
+    const int16_t cc_width = (int16_t)(cb + ca);
+    int sl = lens[c];
+    if (sb > cb) {
+        int st_clip = 0;
+        while (st_clip + 1 < map_w && cm[st_clip + 1] <= 0) st_clip++;
+        for (int i = 0; i < sl + 1 - st_clip; ++i) cm[i] = cm[st_clip + i];
+        for (int i = 0; i < sl + tsc - st_clip; ++i) cs[i] = cs[i + st_clip];
+        sl -= st_clip;
+        cm[0] = 0;
+    }
+    if (sa > ca) {
+        while (sl > 1 && cm[sl - 1] >= cc_width) sl--;
+        cm[sl] = cc_width;
+    }
+    lens[c] = (int16_t)sl;
+}
+
+int launch_trim(rmr_engine *e, int sb, int sa, int cb, int ca, int tsc, int8_t *seqs, int seq_w,
+                int16_t *maps, int map_w, int16_t *lens, int64_t n) {
+    if (n <= 0) return 0;
+    ProfScope ps(e, K_TRIM);
+    hipLaunchKernelGGL(trim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, sb,
+                       sa, cb, ca, tsc, seqs, seq_w, maps, map_w, lens, n);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ======================================================================================
+// M1: move table -> query_to_signal.  Stream compaction of the non-zero moves with a
+// block-wide ballot/popcount prefix (64-wide wavefronts), one block per table.
+// ======================================================================================
+__global__ __launch_bounds__(1024) void moves_kernel(const int8_t *mv_tag, int64_t mv_tag_len,
+                                                      int64_t sig_len, int reverse, int64_t *q2s,
+                                                      int64_t *d_count) {
+    __shared__ int wave_tot[16];
+    __shared__ long long base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t stride = mv_tag[0];
+    const int64_t nmv = mv_tag_len - 1;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    // pass 1 (only when reversing): total count is needed to place entries from the end
+    int64_t total = 0;
+    if (reverse) {
+        int cnt = 0;
+        for (int64_t i = tid; i < nmv; i += blockDim.x) cnt += (mv_tag[1 + i] != 0);
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) wave_tot[wv] = cnt;
+        __syncthreads();
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) total += wave_tot[k];
+        __syncthreads();
+    }
+    for (int64_t start = 0; start < nmv; start += blockDim.x) {
+        const int64_t i = start + tid;
+        const bool nz = (i < nmv) && (mv_tag[1 + i] != 0);
+        const unsigned long long bal = __ballot(nz);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int wave_off = 0, blk = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+            if (k < wv) wave_off += wave_tot[k];
+            blk += wave_tot[k];
+        }
+        const long long base = base_sh;
+        if (nz) {
+            const int64_t k = base + wave_off + before;
+            if (!reverse) q2s[k] = i * stride;
+            else q2s[total - k] = sig_len - i * stride;  // reversed: [0]=sig_len-sig_len .. see below
+        }
+        __syncthreads();
+        if (tid == 0) base_sh = base + blk;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int64_t cnt = base_sh;
+        if (!reverse) q2s[cnt] = sig_len;
+        else q2s[0] = 0;  // sig_len - sig_len
+        *d_count = cnt + 1;
+    }
+}
+
+int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_t sig_len,
+                 int reverse, int64_t *q2s, int64_t *d_count) {
+    ProfScope ps(e, K_MOVES);
+    hipLaunchKernelGGL(moves_kernel, dim3(1), dim3(1024), 0, e->stream, mv_tag, mv_tag_len, sig_len,
+                       reverse, q2s, d_count);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ======================================================================================
+// X1 + X2/X3 geometry.  Signal normalisation in float64 then one rounding to float32
+// (bit-exact with numpy); per chunk: focus clip, focus signal index, window with clipping,
+// the two binary searches on the read's seq_to_signal map.
+// ======================================================================================
+__global__ void normalise_kernel(const int16_t *dacs, const int32_t *sig_read, const double *shift,
+                                 const double *scale, float *sig, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = sig_read ? sig_read[i] : 0;
+    sig[i] = (float)(((double)dacs[i] - shift[r]) / scale[r]);
+}
+
+struct GeoArgs {
+    rmr_reads d;
+    const int32_t *chunk_read;
+    int64_t *geo;
+    int *max_seq_len;
+    int64_t n_chunks;
+};
+
+__device__ __forceinline__ int64_t ub_right(const int64_t *a, int64_t n, int64_t v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int64_t lb_left(const int64_t *a, int64_t n, int64_t v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ void geometry_kernel(GeoArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int sl_i = 0;
+    if (i < a.n_chunks) {
+        const int r = a.chunk_read[i];
+        const int64_t nb = a.d.seq_off[r + 1] - a.d.seq_off[r];
+        const int64_t *map = a.d.seq_to_sig + a.d.seq_off[r] + r;  // nb + 1 entries
+        const int64_t sig_len = a.d.sig_off[r + 1] - a.d.sig_off[r];
+        int64_t fb = a.d.focus_bases[i] + a.d.offset;
+        if (fb > nb - 1) fb = nb - 1;   // map.size - 2
+        if (fb < 0) fb = 0;
+        const int64_t fsig = a.d.base_start_justify ? map[fb] : (map[fb] + map[fb + 1]) / 2;
+        const int64_t sig_start0 = fsig - a.d.cc_before;
+        int64_t sig_start = sig_start0, sig_end = fsig + a.d.cc_after;
+        if (sig_start < 0) sig_start = 0;
+        if (sig_end > sig_len) sig_end = sig_len;
+        const int64_t seq_start = ub_right(map, nb + 1, sig_start) - 1;
+        const int64_t seq_end = lb_left(map, nb + 1, sig_end);
+        const int64_t sl = seq_end - seq_start;
+        int64_t *g = a.geo + i * 6;
+        g[0] = sl;
+        g[1] = fsig - sig_start;
+        g[2] = fb - seq_start;
+        g[3] = fb;
+        g[4] = seq_start;
+        g[5] = sig_start0;
+        sl_i = (int)sl;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(sl_i, o); sl_i = v > sl_i ? v : sl_i; }
+    if ((threadIdx.x & 63) == 0) atomicMax(a.max_seq_len, sl_i);
+}
+
+int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
+                    float *sig_out, int64_t total_sig, const int32_t *sig_read, int64_t *geo,
+                    int *d_max_seq_len) {
+    if (total_sig > 0) {
+        ProfScope ps(e, K_NORMALISE);
+        hipLaunchKernelGGL(normalise_kernel, dim3((unsigned)((total_sig + 255) / 256)), dim3(256), 0,
+                           e->stream, d.dacs, sig_read, d.shift, d.scale, sig_out, total_sig);
+        RMR_HIP(hipGetLastError());
+    }
+    if (n_chunks > 0) {
+        GeoArgs a{d, chunk_read, geo, d_max_seq_len, n_chunks};
+        ProfScope ps(e, K_GEOMETRY);
+        hipLaunchKernelGGL(geometry_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0,
+                           e->stream, a);
+        RMR_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// ======================================================================================
+// X3/X6 fill: one wavefront per chunk writes the dataset-layout rows: signal window with
+// zero padding (coalesced gather), mapping shifted to the chunk with forced ends, context
+// sequence with -1 outside the read.
+// ======================================================================================
+struct FillArgs {
+    rmr_reads d;
+    const int32_t *chunk_read;
+    const float *sig;
+    const int64_t *geo;
+    float *signal;
+    int8_t *seqs;
+    int16_t *maps;
+    int16_t *lens;
+    int64_t *rfb;
+    int64_t n_chunks;
+    int seq_w, map_w;
+};
+
+__global__ __launch_bounds__(256) void fill_kernel(FillArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= a.n_chunks) return;
+    const int r = a.chunk_read[i];
+    const int64_t nb = a.d.seq_off[r + 1] - a.d.seq_off[r];
+    const int64_t *map = a.d.seq_to_sig + a.d.seq_off[r] + r;
+    const int8_t *iseq = a.d.int_seq + a.d.seq_off[r];
+    const float *rsig = a.sig + a.d.sig_off[r];
+    const int64_t sig_len = a.d.sig_off[r + 1] - a.d.sig_off[r];
+    const int64_t *g = a.geo + i * 6;
+    const int64_t sl = g[0], seq_start = g[4], sig_start0 = g[5];
+    const int L = a.d.cc_before + a.d.cc_after;
+    // signal: chunk sample j <- read sample sig_start0 + j, zero outside [0, sig_len)
+    float *so = a.signal + (size_t)i * L;
+    for (int j = lane; j < L; j += 64) {
+        const int64_t src = sig_start0 + j;
+        so[j] = (src >= 0 && src < sig_len) ? rsig[src] : 0.0f;
+    }
+    // mapping: map[seq_start + k] - sig_start0 (== - (sig_start - seq_to_sig_offset)); ends forced
+    int16_t *mo = a.maps + (size_t)i * a.map_w;
+    for (int k = lane; k < a.map_w; k += 64) {
+        int v = 0;
+        if (k <= sl) {
+            v = (int)(map[seq_start + k] - sig_start0);
+            if (k == 0) v = 0;
+            if (k == sl) v = L;
+        }
+        mo[k] = (int16_t)v;
+    }
+    int8_t *qo = a.seqs + (size_t)i * a.seq_w;
+    const int64_t nctx = sl + a.d.kb + a.d.ka;
+    for (int k = lane; k < a.seq_w; k += 64) {
+        int8_t v = -1;
+        if (k < nctx) {
+            const int64_t src = seq_start - a.d.kb + k;
+            if (src >= 0 && src < nb) v = iseq[src];
+        }
+        qo[k] = v;
+    }
+    if (lane == 0) {
+        a.lens[i] = (int16_t)sl;
+        a.rfb[i] = g[3];
+    }
+}
+
+int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
+                const float *sig, const int64_t *geo, float *signal, int8_t *seqs, int seq_w,
+                int16_t *maps, int map_w, int16_t *lens, int64_t *rfb) {
+    if (n_chunks <= 0) return 0;
+    FillArgs a{d, chunk_read, sig, geo, signal, seqs, maps, lens, rfb, n_chunks, seq_w, map_w};
+    ProfScope ps(e, K_FILL);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ======================================================================================
+// label tally: argmax (first maximum) histogram, block-level LDS bins then one atomic per bin
+// ======================================================================================
+__global__ __launch_bounds__(256) void count_kernel(const float *logits, int64_t n, int num_out,
+                                                     unsigned long long *counts) {
+    __shared__ unsigned int bins[16];
+    if (threadIdx.x < 16) bins[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float *p = logits + i * num_out;
+        int best = 0;
+        float bv = p[0];
+        for (int o = 1; o < num_out; ++o) {
+            const float v = p[o];
+            if (v > bv) { bv = v; best = o; }
+        }
+        atomicAdd(&bins[best], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < num_out && bins[threadIdx.x])
+        atomicAdd(&counts[threadIdx.x], (unsigned long long)bins[threadIdx.x]);
+}
+
+int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts) {
+    if (n <= 0) return 0;
+    if (num_out > 16) RMR_FAIL(RMR_ERR_INVALID, "num_out %d > 16", num_out);
+    int64_t grid = (n + 255) / 256;
+    if (grid > (int64_t)e->num_cus * 4) grid = (int64_t)e->num_cus * 4;
+    ProfScope ps(e, K_COUNT);
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)grid), dim3(256), 0, e->stream, logits, n, num_out,
+                       reinterpret_cast<unsigned long long *>(counts));
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rmr

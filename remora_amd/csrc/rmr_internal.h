@@ -1,0 +1,188 @@
+// Internal declarations shared by the translation units of libremora_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/remora_hip.h"
+
+namespace rmr {
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define RMR_FAIL(code, ...)            \
+    do {                               \
+        ::rmr::set_error(__VA_ARGS__); \
+        return (code);                 \
+    } while (0)
+#define RMR_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::rmr::set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, \
+                             __LINE__, #expr);                                            \
+            return RMR_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+#define RMR_TRY(expr)          \
+    do {                       \
+        int _rc = (expr);      \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ---- kernel ids for the profiling table ------------------------------------------------
+enum KernelId {
+    K_ENCODE = 0,
+    K_TRIM,
+    K_MOVES,
+    K_NORMALISE,
+    K_GEOMETRY,
+    K_FILL,
+    K_FRONT,
+    K_SEQ1_DENSE,
+    K_CONV_SIG3,
+    K_CONV_SEQ2,
+    K_CONV_SEQ3,
+    K_CONV_MERGE1,
+    K_CONV_MERGE2,
+    K_CONV_MERGE3,
+    K_CONV_MERGE4,
+    K_LSTM_HEAD,
+    K_FC_HEAD,
+    K_COUNT,
+    K_NUM
+};
+const char *kernel_name(int id);
+
+}  // namespace rmr
+
+// ---- engine ------------------------------------------------------------------------------
+struct rmr_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cus = 256;
+    std::mutex mu;
+    int64_t subbatch = 0;
+
+    // grow-only device scratch arenas
+    struct Arena {
+        void *ptr = nullptr;
+        size_t cap = 0;
+    };
+    Arena act;      // activations of the fused pipeline
+    Arena staging;  // host<->device staging for RMR_MEM_HOST calls
+    int ensure(Arena &a, size_t bytes);
+
+    // profiling
+    bool profiling = false;
+    struct Rec {
+        int id;
+        hipEvent_t t0, t1;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double acc_ms[rmr::K_NUM] = {};
+    int64_t acc_n[rmr::K_NUM] = {};
+    int prof_begin(int id, hipEvent_t *t1);
+    int prof_collect();
+};
+
+// RAII-less helper: brackets one launch with events when profiling is on
+struct ProfScope {
+    rmr_engine *e;
+    hipEvent_t t1 = nullptr;
+    bool on = false;
+    ProfScope(rmr_engine *eng, int id) : e(eng) {
+        if (e->profiling) on = (e->prof_begin(id, &t1) == 0);
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(t1, e->stream);
+    }
+};
+
+// ---- model -------------------------------------------------------------------------------
+namespace rmr {
+
+// One convolution executed on the MFMA path: out[oc][n] = sum_{tap,ic} W[oc][ic][tap] * in
+struct ConvLayer {
+    int ic = 0, oc = 0, kw = 0, stride = 1;
+    float *apack = nullptr;  // device, fragment order [oc/16][kw*ic/4][64]
+    float *bias = nullptr;   // device, folded bias [oc]
+    int kid = 0;             // profiling id
+};
+
+struct FrontWeights {
+    int kw1 = 5;               // kernel width of sig_conv1, sig_conv2, seq_conv1
+    float *w_sig1 = nullptr;   // [kw1][4]
+    float *b_sig1 = nullptr;   // [4]
+    float *w_sig2 = nullptr;   // [kw1][4 ic][16 oc]
+    float *b_sig2 = nullptr;   // [16]
+    float *wt_seq1 = nullptr;  // [kw1][K][4 base][16 oc]  (one-hot gather table)
+    float *b_seq1 = nullptr;   // [16]
+};
+
+struct LstmWeights {
+    float *a_ih1 = nullptr, *a_hh1 = nullptr;  // [H/16 waves][4 gates][H/4][64]
+    float *b1 = nullptr;                       // [4H]  b_ih + b_hh
+    float *a_ih2 = nullptr;                    // [H/16][3 gates i,g,o][H/4][64]
+    float *b2 = nullptr;                       // [3H]  (i,g,o) b_ih + b_hh
+    float *w_fc = nullptr, *b_fc = nullptr;    // [num_out][H], [num_out]
+};
+
+}  // namespace rmr
+
+struct rmr_model {
+    rmr_engine *eng = nullptr;
+    rmr_model_desc desc{};
+    std::vector<void *> dev_allocs;
+    rmr::FrontWeights front;
+    // conv_lstm: sig3, seq2, merge1;  conv_only: sig3, seq2, seq3, merge1..4
+    rmr::ConvLayer sig3, seq2, seq3, merge1, merge2, merge3, merge4;
+    rmr::LstmWeights lstm;
+    float *w_fc = nullptr, *b_fc = nullptr;  // conv_only head: [num_out][size*3]
+    // derived geometry
+    int L = 0, P1 = 0, P2 = 0, P3 = 0, PQ2 = 0, T = 0, T2 = 0, T3 = 0, T4 = 0;
+};
+
+// ---- kernel launchers (defined in k_*.hip) ------------------------------------------------
+namespace rmr {
+
+int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
+                  const int16_t *maps, int map_w, const int16_t *lens, int64_t n, int sig_len,
+                  float *out);
+int launch_trim(rmr_engine *e, int sb, int sa, int cb, int ca, int tsc, int8_t *seqs, int seq_w,
+                int16_t *maps, int map_w, int16_t *lens, int64_t n);
+int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_t sig_len,
+                 int reverse, int64_t *q2s, int64_t *d_count);
+int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
+                    float *sig_out, int64_t total_sig, const int32_t *sig_read, int64_t *geo,
+                    int *d_max_seq_len);
+int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
+                const float *sig, const int64_t *geo, float *signal, int8_t *seqs, int seq_w,
+                int16_t *maps, int map_w, int16_t *lens, int64_t *rfb);
+int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts);
+
+// fused pipeline stages; all tensors channel-last in device scratch
+int launch_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w,
+                 const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
+                 float *sig2, float *seq1 /* nullptr: skip seq path */);
+int launch_seq1_dense(rmr_model *m, const float *enc, int64_t n, float *seq1);
+int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
+                float *out, int out_row, int out_coff, int pout, int64_t n);
+int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
+int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits);
+
+// fast integer division by a small runtime constant (exact for 0 <= x < 2^24, d < 2^12)
+struct FastDiv {
+    int d;
+    float inv;
+};
+inline FastDiv make_fastdiv(int d) { return FastDiv{d, 1.0f / (float)d}; }
+
+}  // namespace rmr

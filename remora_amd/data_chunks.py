@@ -1,0 +1,311 @@
+"""Read model and chunk extraction of the hot path — the inference half of
+`remora.data_chunks` (src/remora/data_chunks.py): RemoraRead :126-540, Chunk :544-641.
+
+The per-chunk Python of the reference (extract_chunk :331-423 called once per focus base,
+write_chunk :1376-1418) is replaced by two kernel launches for the whole read
+(rmr_chunk_geometry + rmr_chunk_fill); the arrays stay on the GPU in the CoreRemoraDataset
+layout (:786-816) and feed `HipModel.infer_chunks` without ever materialising the one-hot.
+"""
+import ctypes
+import dataclasses
+
+import numpy as np
+
+from . import RemoraError
+from . import _lib as L
+from . import util
+from .engine import HipModel, get_engine, _torch
+
+
+@dataclasses.dataclass
+class Chunk:
+    """Host-side view of one extracted chunk (src/remora/data_chunks.py:544-641)."""
+
+    signal: np.ndarray
+    seq_w_context: np.ndarray
+    seq_to_sig_map: np.ndarray
+    kmer_context_bases: tuple
+    chunk_sig_focus_idx: int
+    chunk_focus_base: int
+    read_focus_base: int
+    read_id: str = None
+    label: int = None
+
+    @property
+    def kmer_len(self):
+        return sum(self.kmer_context_bases) + 1
+
+    @property
+    def seq_len(self):
+        return self.seq_w_context.size - sum(self.kmer_context_bases)
+
+    @property
+    def seq(self):
+        kb = self.kmer_context_bases[0]
+        return self.seq_w_context[kb : kb + self.seq_len]
+
+    def check(self):
+        """Validity rules of the reference (:584-620)."""
+        if self.signal.size <= 0:
+            raise RemoraError("No signal for chunk")
+        if np.any(np.isnan(self.signal)):
+            raise RemoraError("Signal contains NaN")
+        if self.seq_w_context.size - sum(self.kmer_context_bases) != self.seq_to_sig_map.size - 1:
+            raise RemoraError("Invalid sig to seq map length")
+        if self.seq_to_sig_map[0] < 0:
+            raise RemoraError("Seq to sig map starts before 0")
+        if self.seq_to_sig_map[-1] > self.signal.size:
+            raise RemoraError("Seq to sig map ends after signal")
+
+
+class ChunkArrays:
+    """Chunks of one or more reads as GPU-resident arrays in the CoreRemoraDataset layout
+    (signal f32[n,1,L], sequence i8[n,W], sequence_to_signal_mapping i16[n,W'],
+    sequence_lengths i16[n]) plus read_focus_bases / labels / geometry."""
+
+    def __init__(self, signal, sequence, mapping, lengths, read_focus_bases, labels, geo,
+                 kmer_context_bases, chunk_context):
+        self.signal, self.sequence, self.mapping, self.lengths = signal, sequence, mapping, lengths
+        self.read_focus_bases, self.labels, self.geo = read_focus_bases, labels, geo
+        self.kmer_context_bases = tuple(int(x) for x in kmer_context_bases)
+        self.chunk_context = tuple(int(x) for x in chunk_context)
+
+    def __len__(self):
+        return int(self.lengths.shape[0])
+
+    def enc_kmers(self):
+        from .encoded_kmers import compute_encoded_kmer_batch
+
+        return compute_encoded_kmer_batch(*self.kmer_context_bases, self.sequence, self.mapping, self.lengths)
+
+    def as_reference_batch(self):
+        """(signal, enc_kmers, labels, read_focus_bases) numpy tuple, the element type of
+        RemoraRead.batches in the reference (src/remora/data_chunks.py:506-514)."""
+        return (self.signal.cpu().numpy(), self.enc_kmers().cpu().numpy(), self.labels.copy(),
+                self.read_focus_bases.cpu().numpy())
+
+    def __iter__(self):  # tuple-unpacking compatibility
+        return iter(self.as_reference_batch())
+
+
+def extract_chunk_arrays(reads, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,
+                         engine=None):
+    """Chunk arrays for a list of RemoraRead objects whose `focus_bases` are set.
+    GPU counterpart of iter_chunks + extract_chunk + write_chunk for every focus base
+    (src/remora/data_chunks.py:425-466, :331-423, :1376-1418).  Returns (ChunkArrays, sig)
+    where sig is the normalised signal of all reads (float32, CUDA)."""
+    torch = _torch()
+    eng = engine if engine is not None else get_engine()
+    dev = eng.torch_device
+    lib = L.lib()
+    nr = len(reads)
+    sig_off = np.zeros(nr + 1, np.int64)
+    seq_off = np.zeros(nr + 1, np.int64)
+    foc_off = np.zeros(nr + 1, np.int64)
+    for i, r in enumerate(reads):
+        sig_off[i + 1] = sig_off[i] + r.dacs.size
+        seq_off[i + 1] = seq_off[i] + r.int_seq.size
+        foc_off[i + 1] = foc_off[i] + (0 if r.focus_bases is None else len(r.focus_bases))
+        if r.seq_to_sig_map.size != r.int_seq.size + 1:
+            raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
+    n_chunks = int(foc_off[-1])
+    cat = lambda arrs, dt: (np.concatenate([np.asarray(a).ravel() for a in arrs]).astype(dt, copy=False)
+                            if arrs else np.zeros(0, dt))
+    dacs = cat([r.dacs for r in reads], np.int16)
+    s2s = cat([r.seq_to_sig_map for r in reads], np.int64)
+    iseq = cat([r.int_seq for r in reads], np.int8)
+    focus = cat([r.focus_bases for r in reads if r.focus_bases is not None and len(r.focus_bases)], np.int64)
+    shift = np.array([float(r.shift) for r in reads], np.float64)
+    scale = np.array([float(r.scale) for r in reads], np.float64)
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = dict(dacs=to_dev(dacs), sig_off=to_dev(sig_off), s2s=to_dev(s2s), iseq=to_dev(iseq),
+             seq_off=to_dev(seq_off), shift=to_dev(shift), scale=to_dev(scale),
+             focus=to_dev(focus if focus.size else np.zeros(1, np.int64)), foc_off=to_dev(foc_off))
+    rs = L.Reads(nr, d["dacs"].data_ptr(), d["sig_off"].data_ptr(), d["s2s"].data_ptr(), d["iseq"].data_ptr(),
+                 d["seq_off"].data_ptr(), d["shift"].data_ptr(), d["scale"].data_ptr(), d["focus"].data_ptr(),
+                 d["foc_off"].data_ptr(), int(chunk_context[0]), int(chunk_context[1]),
+                 int(kmer_context_bases[0]), int(kmer_context_bases[1]), int(bool(base_start_justify)), int(offset))
+    L_chunk = int(chunk_context[0]) + int(chunk_context[1])
+    sig = torch.empty(max(int(sig_off[-1]), 1), dtype=torch.float32, device=dev)
+    geo = torch.empty((max(n_chunks, 1), 6), dtype=torch.int64, device=dev)
+    max_sl = ctypes.c_int64(0)
+    L.check(lib.rmr_chunk_geometry(eng.handle, ctypes.byref(rs), sig.data_ptr(), geo.data_ptr(),
+                                   ctypes.byref(max_sl), L.MEM_DEVICE))
+    sig = sig[: int(sig_off[-1])]
+    geo = geo[:n_chunks]
+    msl = int(max_sl.value)
+    seq_w = msl + int(kmer_context_bases[0]) + int(kmer_context_bases[1])
+    map_w = msl + 1
+    signal = torch.empty((n_chunks, 1, L_chunk), dtype=torch.float32, device=dev)
+    sequence = torch.empty((n_chunks, max(seq_w, 1)), dtype=torch.int8, device=dev)
+    mapping = torch.empty((n_chunks, max(map_w, 2)), dtype=torch.int16, device=dev)
+    lengths = torch.empty(n_chunks, dtype=torch.int16, device=dev)
+    rfb = torch.empty(n_chunks, dtype=torch.int64, device=dev)
+    if n_chunks:
+        L.check(lib.rmr_chunk_fill(eng.handle, ctypes.byref(rs), sig.data_ptr(), geo.data_ptr(), signal.data_ptr(),
+                                   sequence.data_ptr(), sequence.shape[1], mapping.data_ptr(), mapping.shape[1],
+                                   lengths.data_ptr(), rfb.data_ptr(), L.MEM_DEVICE))
+    # the kernels above read the staged inputs in `d`: keep them alive until the stream drains
+    eng.synchronize()
+    labels = np.full(n_chunks, -1, np.int64)
+    for i, r in enumerate(reads):
+        if r.labels is not None and foc_off[i + 1] > foc_off[i]:
+            labels[foc_off[i] : foc_off[i + 1]] = np.asarray(r.labels)[np.asarray(r.focus_bases)]
+    return ChunkArrays(signal, sequence, mapping, lengths, rfb, labels, geo, kmer_context_bases, chunk_context), sig
+
+
+@dataclasses.dataclass
+class RemoraRead:
+    """Same fields and methods as the reference's RemoraRead for the inference path
+    (src/remora/data_chunks.py:126-540)."""
+
+    dacs: np.ndarray
+    shift: float
+    scale: float
+    seq_to_sig_map: np.ndarray
+    int_seq: np.ndarray = None
+    str_seq: str = None
+    read_id: str = None
+    labels: np.ndarray = None
+    focus_bases: np.ndarray = None
+    batches: list = None
+
+    def __post_init__(self):
+        if self.int_seq is None:
+            if self.str_seq is None:
+                raise RemoraError("Must provide sequence to initialize RemoraRead")
+            self.int_seq = util.seq_to_int(self.str_seq)
+        else:
+            self.int_seq = np.asarray(self.int_seq)
+            self.str_seq = util.int_to_seq(self.int_seq)
+        self.dacs = np.asarray(self.dacs)
+        self.seq_to_sig_map = np.asarray(self.seq_to_sig_map)
+        self._sig = None
+
+    @classmethod
+    def test_read(cls, nbases=20, signal_per_base=10):
+        """Spoofed read (src/remora/data_chunks.py:178-189)."""
+        return cls(np.zeros(nbases * signal_per_base), 0.0, 1.0,
+                   np.arange(nbases * signal_per_base + 1, step=signal_per_base),
+                   np.arange(nbases) % 4, "test_read", np.zeros(nbases, dtype=np.int64))
+
+    @property
+    def sig(self):
+        """((dacs - shift) / scale).astype(float32), float64 arithmetic (:191-197); computed by
+        the normalise kernel."""
+        if self._sig is None:
+            saved, self.focus_bases = self.focus_bases, None
+            try:
+                _, sig = extract_chunk_arrays([self], (1, 1), (0, 0))
+            finally:
+                self.focus_bases = saved
+            self._sig = sig.cpu().numpy()
+        return self._sig
+
+    def check(self):
+        """:222-249"""
+        if self.seq_to_sig_map.size != self.int_seq.size + 1:
+            raise RemoraError(f"Invalid read: seq ({self.int_seq.size}) and mapping "
+                              f"({self.seq_to_sig_map.size}) sizes incompatible")
+        if self.seq_to_sig_map[0] != 0:
+            raise RemoraError("Invalid read: mapping start")
+        if self.seq_to_sig_map[-1] != self.dacs.size:
+            raise RemoraError("Invalid read: mapping end")
+        if self.int_seq.max() > 3:
+            raise RemoraError("Invalid read: Invalid base")
+        if self.int_seq.min() < -1:
+            raise RemoraError("Invalid read: Invalid base")
+
+    def copy(self):
+        return RemoraRead(
+            dacs=self.dacs.copy(), shift=self.shift, scale=self.scale, seq_to_sig_map=self.seq_to_sig_map,
+            int_seq=None if self.int_seq is None else self.int_seq.copy(), str_seq=self.str_seq,
+            read_id=self.read_id, labels=None if self.labels is None else self.labels.copy(),
+            focus_bases=None if self.focus_bases is None else self.focus_bases.copy())
+
+    def refine_signal_mapping(self, sig_map_refiner, check_read=False):
+        """No-op unless the model carries a k-mer level table (:267-308).  Refinement itself is
+        a 'next' row and not part of this engine yet."""
+        if sig_map_refiner is None or not getattr(sig_map_refiner, "is_loaded", False):
+            return
+        raise RemoraError("signal-mapping refinement (SigMapRefiner with a k-mer table) is not "
+                          "implemented in remora_amd yet")
+
+    def set_motif_focus_bases(self, motifs):
+        """:310-317"""
+        self.focus_bases = util.find_focus_bases_in_int_sequence(self.int_seq, motifs)
+
+    def downsample_focus_bases(self, max_sites):
+        if self.focus_bases is not None and self.focus_bases.size > max_sites:
+            self.focus_bases = np.random.choice(self.focus_bases, size=max_sites, replace=False)
+
+    # ---- chunk extraction -------------------------------------------------------------
+    def extract_chunk_arrays(self, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,
+                             motifs=None):
+        fbs = self.focus_bases
+        if motifs is not None and fbs is not None:
+            keep = [fb for fb in fbs if any(m.match(self.int_seq, fb) for m in motifs)]
+            saved, self.focus_bases = fbs, np.asarray(keep, dtype=np.int64)
+            try:
+                arrs, _ = extract_chunk_arrays([self], chunk_context, kmer_context_bases, base_start_justify, offset)
+            finally:
+                self.focus_bases = saved
+            return arrs
+        arrs, _ = extract_chunk_arrays([self], chunk_context, kmer_context_bases, base_start_justify, offset)
+        return arrs
+
+    def iter_chunks(self, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,
+                    check_chunks=False, motifs=None):
+        """Generator of host `Chunk` objects, same arguments as the reference (:425-466); all
+        chunks are extracted on the GPU in one go and sliced here."""
+        arrs = self.extract_chunk_arrays(chunk_context, kmer_context_bases, base_start_justify, offset, motifs)
+        n = len(arrs)
+        if n == 0:
+            return
+        sig = arrs.signal.cpu().numpy()[:, 0]
+        seqs = arrs.sequence.cpu().numpy()
+        maps = arrs.mapping.cpu().numpy()
+        geo = arrs.geo.cpu().numpy()
+        ctx = sum(arrs.kmer_context_bases)
+        for i in range(n):
+            sl = int(geo[i, 0])
+            ch = Chunk(signal=sig[i].copy(), seq_w_context=seqs[i, : sl + ctx].copy(),
+                       seq_to_sig_map=maps[i, : sl + 1].astype(np.int32),
+                       kmer_context_bases=arrs.kmer_context_bases, chunk_sig_focus_idx=int(geo[i, 1]),
+                       chunk_focus_base=int(geo[i, 2]), read_focus_base=int(geo[i, 3]), read_id=self.read_id,
+                       label=int(arrs.labels[i]))
+            if check_chunks:
+                try:
+                    ch.check()
+                except RemoraError:
+                    continue
+            yield ch
+
+    def prepare_batches(self, model_metadata, batch_size=None):
+        """:468-514.  `batch_size` is accepted and ignored, as in the reference (it is not
+        forwarded there either)."""
+        self.batches = []
+        self.refine_signal_mapping(model_metadata.get("sig_map_refiner"))
+        if self.focus_bases is None or len(self.focus_bases) == 0:
+            return
+        arrs = self.extract_chunk_arrays(model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
+                                         model_metadata["base_start_justify"], model_metadata["offset"])
+        if len(arrs) == 0:
+            return
+        self.batches.append(arrs)
+
+    def run_model(self, model):
+        """:516-540 -> (nn_out f32[N,num_out], labels i64[N], pos i64[N])."""
+        torch = _torch()
+        outs, labs, poss = [], [], []
+        for arrs in self.batches:
+            if isinstance(model, HipModel):
+                out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths,
+                                         arrs.kmer_context_bases)
+            else:  # any other callable with the reference's model(sigs, enc_kmers) contract
+                device = next(model.parameters()).device
+                out = model(arrs.signal.to(device), arrs.enc_kmers().to(device)).detach()
+            outs.append(out.cpu().numpy())
+            labs.append(arrs.labels)
+            poss.append(arrs.read_focus_bases.cpu().numpy())
+        return np.concatenate(outs, axis=0), np.concatenate(labs), np.concatenate(poss)

@@ -1,0 +1,151 @@
+"""Sequence / motif / tag helpers of the hot path that stay on the host, mirroring the
+reference's `remora.util` for these names (src/remora/util.py): seq_to_int :131-142,
+int_to_seq :145-159, softmax_axis1 :182-186, Motif :190-378, find_focus_bases_in_int_sequence
+:413-426, format_mm_ml_tags :485-537.  Pure numpy / python (string and set handling; nothing
+here is on the GPU roofline)."""
+import array
+import re
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import RemoraError
+
+CAN_ALPHABET = "ACGT"
+CONV_ALPHABET = "ACGTN"
+SINGLE_LETTER_CODE = {
+    "A": "A", "C": "C", "G": "G", "T": "T", "B": "CGT", "D": "AGT", "H": "ACT", "K": "GT",
+    "M": "AC", "N": "ACGT", "R": "AG", "S": "CG", "V": "ACG", "W": "AT", "Y": "CT",
+}
+_SEQ_LUT = np.full(256, -1, dtype=int)
+for _i, _b in enumerate(CAN_ALPHABET):
+    _SEQ_LUT[ord(_b)] = _i
+
+
+def seq_to_int(seq):
+    """A,C,G,T -> 0..3, any other upper-case letter -> -1 (src/remora/util.py:131-142)."""
+    codes = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
+    if codes.size and (codes.min() < ord("A") or codes.max() > ord("Z")):
+        raise IndexError("sequence contains characters outside A-Z")
+    return _SEQ_LUT[codes]
+
+
+def int_to_seq(np_seq, alphabet=CONV_ALPHABET):
+    """src/remora/util.py:145-159 (-1 indexes the last letter, N, as in the reference)."""
+    if np_seq.shape[0] == 0:
+        return ""
+    if np_seq.max() >= len(alphabet):
+        raise RemoraError(f"Invalid value in int sequence ({np_seq.max()})")
+    return "".join(alphabet[b] for b in np_seq)
+
+
+def softmax_axis1(x):
+    """src/remora/util.py:182-186."""
+    shifted = x - np.max(x, axis=1, keepdims=True)
+    e_x = np.exp(shifted)
+    with np.errstate(divide="ignore"):
+        return e_x / e_x.sum(axis=1, keepdims=True)
+
+
+@dataclass
+class Motif:
+    """IUPAC motif + focus position (src/remora/util.py:190-378, the subset the hot path
+    uses: normalisation, findall, match)."""
+
+    raw_motif: str
+    focus_pos: int = 0
+
+    def __post_init__(self):
+        try:
+            self.focus_pos = int(self.focus_pos)
+        except ValueError:
+            raise RemoraError(f'Motif focus position not an integer: "{self.focus_pos}"')
+        if not isinstance(self.raw_motif, str):
+            raise RemoraError("Motif sequence must be a string")
+        bad = set(self.raw_motif) - set(SINGLE_LETTER_CODE)
+        if bad:
+            raise RemoraError(f"Motif contains invalid characters: {bad}")
+        if self.focus_pos >= len(self.raw_motif):
+            raise RemoraError("Motif focus position is past the end of the motif")
+        while len(self.raw_motif) > 1 and self.raw_motif.startswith("N"):
+            self.raw_motif = self.raw_motif[1:]
+            self.focus_pos -= 1
+        while len(self.raw_motif) > 1 and self.raw_motif.endswith("N"):
+            self.raw_motif = self.raw_motif[:-1]
+
+    def to_tuple(self):
+        return self.raw_motif, self.focus_pos
+
+    def __hash__(self):
+        return hash(self.to_tuple())
+
+    @property
+    def focus_base(self):
+        return self.raw_motif[self.focus_pos]
+
+    @property
+    def any_context(self):
+        return self.raw_motif == "N"
+
+    @property
+    def num_bases_after_focus(self):
+        return len(self.raw_motif) - self.focus_pos - 1
+
+    @property
+    def pattern(self):
+        return re.compile("(?=({}))".format("".join(f"[{SINGLE_LETTER_CODE[c]}]" for c in self.raw_motif)))
+
+    @property
+    def int_pattern(self):
+        return [np.array([CAN_ALPHABET.index(b) for b in SINGLE_LETTER_CODE[c]]) for c in self.raw_motif]
+
+    def findall(self, int_seq):
+        """Start index of every (overlapping) hit in an integer sequence."""
+        m = len(self.raw_motif)
+        nwin = int_seq.size - m + 1
+        if nwin <= 0:
+            return np.zeros(0, dtype=np.int64)
+        hit = np.ones(nwin, dtype=bool)
+        for po, allowed in enumerate(self.int_pattern):
+            hit &= np.isin(int_seq[po : po + nwin], allowed)
+        return np.flatnonzero(hit)
+
+    def match(self, int_seq, pos):
+        st = pos - self.focus_pos
+        if st < 0 or st + len(self.raw_motif) > int_seq.size:
+            return False
+        return all(int_seq[st + i] in allowed for i, allowed in enumerate(self.int_pattern))
+
+
+def find_focus_bases_in_int_sequence(int_seq, motifs):
+    """Union of motif hits (+focus offset).  The reference builds a python `set` and iterates
+    it (src/remora/util.py:413-426); chunk order downstream follows that iteration order, so
+    it is reproduced here the same way."""
+    hits = set()
+    for mot in motifs:
+        for pos in mot.findall(int_seq):
+            hits.add(pos + mot.focus_pos)
+    return np.fromiter(hits, int)
+
+
+def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
+    """MM / ML SAM tags from per-site probabilities (src/remora/util.py:485-537)."""
+    order = np.argsort(np.asarray(poss), kind="stable")
+    sorted_pos = np.asarray(poss)[order]
+    mm_tag, ml_tag = "", array.array("B")
+    if sorted_pos.size == 0:
+        return mm_tag, ml_tag
+    can_running = np.cumsum(np.frombuffer(seq.encode(), np.uint8) == ord(can_base))
+    can_idx = can_running[sorted_pos] - 1
+    gaps = np.diff(np.concatenate([[-1], can_idx])) - 1
+    gap_str = ",".join(str(int(g)) for g in gaps)
+    valid = [p is not None for p in probs] if isinstance(probs, list) else None
+    if valid is not None and not all(valid):
+        raise RemoraError("per-site None probabilities are not supported")
+    probs = np.asarray(probs, dtype=np.float64)[order]
+    for mi, mod_base in enumerate(mod_bases):
+        mm_tag += f"{can_base}{strand}{mod_base}?,{gap_str};"
+        scaled = np.floor(probs[:, mi] * 256)
+        scaled[scaled == 256] = 255
+        ml_tag.extend(scaled.astype(np.uint8))
+    return mm_tag, ml_tag

@@ -1,0 +1,424 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors generated from the
+reference and against the CPU oracle.  Needs a real MI355X: run with `-m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import code_to_onehot, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def test_native_library_loaded(torch_cuda):
+    from remora_amd import _lib
+    from remora_amd.engine import get_engine
+
+    assert os.path.exists(_lib.LIB_PATH)
+    assert get_engine(0).handle
+    assert b"gfx950" in _lib.lib().rmr_version()
+
+
+# ---- E1 -----------------------------------------------------------------------------------
+def test_encode_kmers_golden_bit_exact(torch_cuda):
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+
+    torch = torch_cuda
+    g = golden("encode_kmers.npz")
+    for i in range(int(g["num_cases"])):
+        kb, ka, L = (int(x) for x in g[f"c{i}_args"])
+        ref = code_to_onehot(g[f"c{i}_enc_code"])
+        enc = compute_encoded_kmer_batch(kb, ka, g[f"c{i}_seqs"], g[f"c{i}_maps"], g[f"c{i}_lens"])
+        assert enc.dtype == np.float32 and enc.shape == ref.shape
+        assert np.array_equal(enc, ref), f"case {i} (host path)"
+        dev = compute_encoded_kmer_batch(kb, ka, torch.from_numpy(g[f"c{i}_seqs"]).cuda(),
+                                         torch.from_numpy(g[f"c{i}_maps"]).cuda(),
+                                         torch.from_numpy(g[f"c{i}_lens"]).cuda())
+        assert np.array_equal(dev.cpu().numpy(), ref), f"case {i} (device path)"
+
+
+@pytest.mark.parametrize("cfg", ["C100", "C200"])
+def test_encode_kmers_oracle_synth(torch_cuda, O, cfg):
+    from remora_amd import synth
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+
+    d = synth.synth_chunks_config(cfg, 3000, shard=3)
+    kb, ka = d["kmer_context_bases"]
+    enc = compute_encoded_kmer_batch(kb, ka, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+    ref = O.compute_encoded_kmer_batch(kb, ka, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+    assert np.array_equal(enc, ref)
+    # one 1.0 per (k-mer slot, signal position): SURVEY appendix A.9 checksum
+    assert np.all(enc.sum(axis=(1, 2)) == (kb + ka + 1) * d["chunk_len"])
+
+
+def test_encode_kmers_full_size_checksum(torch_cuda):
+    """1M C100 chunks (BASELINE config size): per-chunk sum == kmer_len * L, every value in {0,1}."""
+    from remora_amd import synth
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+
+    torch = torch_cuda
+    n = 1_000_000
+    d = synth.synth_chunks_config("C100", n, shard=5)
+    seqs = torch.from_numpy(d["sequence"]).cuda()
+    maps = torch.from_numpy(d["sequence_to_signal_mapping"]).cuda()
+    lens = torch.from_numpy(d["sequence_lengths"]).cuda()
+    step = 250_000
+    for st in range(0, n, step):
+        enc = compute_encoded_kmer_batch(4, 4, seqs[st : st + step], maps[st : st + step], lens[st : st + step])
+        sums = enc.sum(dim=(1, 2))
+        assert bool((sums == 900).all())
+        assert bool(((enc == 0) | (enc == 1)).all())
+        # each 4-row group holds exactly one 1 per column
+        assert bool((enc.view(-1, 9, 4, 100).sum(dim=2) == 1).all())
+        del enc
+
+
+# ---- T1 / M1 --------------------------------------------------------------------------------
+def test_trim_golden(torch_cuda):
+    from remora_amd.data_chunks_core import trim_sb_chunk_context_core
+
+    g = golden("trim_chunk_context.npz")
+    for i in range(int(g["num_cases"])):
+        scc0, scc1, cc0, cc1, tsc = (int(x) for x in g[f"c{i}_args"])
+        seqs, lens = g[f"c{i}_in_seqs"].copy(), g[f"c{i}_in_lens"].copy()
+        maps = (g[f"c{i}_in_maps"] - (scc0 - cc0)).astype(np.int16)
+        trim_sb_chunk_context_core(scc0, scc1, cc0, cc1, tsc, seqs, maps, lens)
+        assert np.array_equal(lens, g[f"c{i}_out_lens"])
+        assert np.array_equal(maps, g[f"c{i}_out_maps"])
+        assert np.array_equal(seqs, g[f"c{i}_out_seqs"])
+
+
+def test_parse_move_tag_golden(torch_cuda):
+    from remora_amd import RemoraError
+    from remora_amd.io import parse_move_tag
+
+    g = golden("parse_move_tag.npz")
+    for i in range(int(g["num_cases"])):
+        mv = g[f"c{i}_mv"]
+        sig_len, seq_len, rev, check = (int(x) for x in g[f"c{i}_args"])
+        err = str(g[f"c{i}_err"])
+        kw = dict(seq_len=None if seq_len < 0 else seq_len, check=bool(check), reverse_signal=bool(rev))
+        if err:
+            with pytest.raises(RemoraError, match=err):
+                parse_move_tag(mv, sig_len, **kw)
+        else:
+            q2s, mvt, stride = parse_move_tag(mv, sig_len, **kw)
+            assert np.array_equal(q2s, g[f"c{i}_q2s"]) and q2s.dtype == np.int64
+            assert stride == mv[0] and np.array_equal(mvt, mv[1:])
+
+
+def test_parse_move_tag_large_vs_oracle(torch_cuda, O):
+    from remora_amd.io import parse_move_tag
+
+    rng = np.random.default_rng(5)
+    for rev in (False, True):
+        mv = (rng.random(300_000) < 0.4).astype(np.int8)
+        mv[0] = 1
+        tag = np.concatenate([[6], mv]).astype(np.int8)
+        sig_len = mv.size * 6 + 3
+        q, _, _ = parse_move_tag(tag, sig_len, seq_len=int(mv.sum()), reverse_signal=rev)
+        qo, _, _ = O.parse_move_tag(tag, sig_len, seq_len=int(mv.sum()), reverse_signal=rev)
+        assert np.array_equal(q, qo)
+        assert np.all(np.diff(q) > 0) and q[-1] == sig_len or rev
+
+
+# ---- X1 / X2 / X3 -----------------------------------------------------------------------------
+def test_extract_chunks_golden(torch_cuda):
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.util import Motif
+
+    g = golden("extract_chunks.npz")
+    for rname in g["read_names"]:
+        rname = str(rname)
+        shift, scale = (float(x) for x in g[f"{rname}_shift_scale"])
+        read = RemoraRead(dacs=g[f"{rname}_dacs"], shift=shift, scale=scale, seq_to_sig_map=g[f"{rname}_map"],
+                          int_seq=g[f"{rname}_int_seq"], read_id=rname)
+        read.check()
+        assert np.array_equal(read.sig.view(np.uint32), g[f"{rname}_sig"].view(np.uint32)), "signal bits"
+        for mname in ("CG", "C"):
+            read.set_motif_focus_bases([Motif(mname, 0)])
+            assert np.array_equal(read.focus_bases, g[f"{rname}_{mname}_focus"])
+            for ci, cfg in enumerate(g["configs"]):
+                cc, kcb, bsj, off = (int(cfg[0]), int(cfg[1])), (int(cfg[2]), int(cfg[3])), bool(cfg[4]), int(cfg[5])
+                pre = f"{rname}_{mname}_c{ci}_"
+                arrs = read.extract_chunk_arrays(cc, kcb, bsj, off)
+                n = read.focus_bases.size
+                assert len(arrs) == n
+                if n == 0:
+                    continue
+                sig = arrs.signal.cpu().numpy().reshape(n, -1)
+                assert np.array_equal(sig.view(np.uint32), g[pre + "signal"].view(np.uint32))
+                sl = g[pre + "seq_len"]
+                assert np.array_equal(arrs.lengths.cpu().numpy(), sl)
+                seqs, maps = arrs.sequence.cpu().numpy(), arrs.mapping.cpu().numpy()
+                assert seqs.shape[1] == sl.max() + sum(kcb) and maps.shape[1] == sl.max() + 1
+                for i in range(n):
+                    assert np.array_equal(seqs[i, : sl[i] + sum(kcb)], g[pre + "seq_w_context"][i, : sl[i] + sum(kcb)])
+                    assert np.array_equal(maps[i, : sl[i] + 1], g[pre + "seq_to_sig_map"][i, : sl[i] + 1])
+                    assert np.all(seqs[i, sl[i] + sum(kcb):] == -1) and np.all(maps[i, sl[i] + 1:] == 0)
+                misc, geo = g[pre + "misc"], arrs.geo.cpu().numpy()
+                assert np.array_equal(geo[:, 1], misc[:, 0])
+                assert np.array_equal(geo[:, 2], misc[:, 1])
+                assert np.array_equal(arrs.read_focus_bases.cpu().numpy(), misc[:, 2])
+                # host Chunk view agrees too
+                chunks = list(read.iter_chunks(cc, kcb, bsj, off))
+                assert len(chunks) == n and chunks[0].seq_len == sl[0]
+
+
+def test_extract_multi_read_batch_vs_oracle(torch_cuda, O):
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead, extract_chunk_arrays
+    from remora_amd.util import Motif
+
+    reads = []
+    for i in range(6):
+        r = synth.synth_read(800 + 37 * i, idx=i)
+        rd = RemoraRead(dacs=r["dacs"], shift=r["shift"] + i, scale=r["scale"] - i, seq_to_sig_map=r["seq_to_sig_map"],
+                        int_seq=r["int_seq"], read_id=f"r{i}")
+        rd.set_motif_focus_bases([Motif("CG", 0)])
+        reads.append(rd)
+    arrs, sig = extract_chunk_arrays(reads, (50, 50), (4, 4))
+    st = 0
+    sig = sig.cpu().numpy()
+    s_off = 0
+    for rd in reads:
+        osig = O.normalise_signal(rd.dacs, rd.shift, rd.scale)
+        assert np.array_equal(sig[s_off : s_off + osig.size].view(np.uint32), osig.view(np.uint32))
+        s_off += osig.size
+        ch = O.extract_chunks(osig, rd.seq_to_sig_map, rd.int_seq, rd.focus_bases, (50, 50), (4, 4))
+        n = rd.focus_bases.size
+        sl = ch["sequence_lengths"]
+        assert np.array_equal(arrs.lengths[st : st + n].cpu().numpy(), sl)
+        assert np.array_equal(arrs.signal[st : st + n].cpu().numpy().view(np.uint32), ch["signal"].view(np.uint32))
+        seqs, maps = arrs.sequence[st : st + n].cpu().numpy(), arrs.mapping[st : st + n].cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(seqs[i, : sl[i] + 8], ch["sequence"][i, : sl[i] + 8])
+            assert np.array_equal(maps[i, : sl[i] + 1], ch["sequence_to_signal_mapping"][i, : sl[i] + 1])
+        assert np.array_equal(arrs.read_focus_bases[st : st + n].cpu().numpy(), ch["read_focus_bases"])
+        st += n
+    assert st == len(arrs)
+
+
+# ---- F1 / F2 ------------------------------------------------------------------------------------
+MODELS = ["convlstm_s64_l100_o2", "convlstm_s64_l200_o3", "convlstm_s16_l100_o2",
+          "convlstm_s64_l100_k23", "conv_s64_l100_o2", "conv_s64_l100_o3"]
+
+
+def _model_from_golden(g, O):
+    from remora_amd.model_util import model_from_state
+
+    state = O.state_from_npz(g)
+    size, kb, ka, L, num_out = (int(x) for x in g["params"])
+    md = dict(chunk_context=(L // 2, L - L // 2), kmer_context_bases=(kb, ka))
+    return model_from_state(state, md, device=0), state, (kb, ka)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_fused_logits_golden(torch_cuda, O, name):
+    """fp32 tolerance from the north star: <= 1e-4 on per-chunk class logits."""
+    torch = torch_cuda
+    g = golden(f"model_{name}.npz")
+    model, state, kcb = _model_from_golden(g, O)
+    out = model.infer_chunks(g["sigs"], g["seqs"], g["maps"], g["lens"], kcb)
+    assert out.shape == g["logits"].shape
+    assert np.abs(out - g["logits"]).max() <= 1e-4
+    dev = model.infer_chunks(torch.from_numpy(g["sigs"]).cuda(), torch.from_numpy(g["seqs"]).cuda(),
+                             torch.from_numpy(g["maps"]).cuda(), torch.from_numpy(g["lens"]).cuda(), kcb)
+    assert np.array_equal(dev.cpu().numpy(), out), "host-staged and device paths must agree bit for bit"
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_dense_forward_golden(torch_cuda, O, name):
+    """model(sigs, enc_kmers) contract with a materialised one-hot AND with arbitrary dense seqs."""
+    torch = torch_cuda
+    g = golden(f"model_{name}.npz")
+    model, state, (kb, ka) = _model_from_golden(g, O)
+    enc = O.compute_encoded_kmer_batch(kb, ka, g["seqs"], g["maps"], g["lens"])
+    out = model(torch.from_numpy(g["sigs"]).cuda(), torch.from_numpy(enc).cuda())
+    assert out.is_cuda and out.dtype == torch.float32
+    assert np.abs(out.cpu().numpy() - g["logits"]).max() <= 1e-4
+    out_d = model(torch.from_numpy(g["sigs"][:8]).cuda(), torch.from_numpy(g["dense_seqs"]).cuda())
+    assert np.abs(out_d.cpu().numpy() - g["dense_logits"]).max() <= 1e-4
+    assert next(model.parameters()).device.type == "cuda" and model.eval() is model
+
+
+@pytest.mark.parametrize("arch,cfg,num_out", [("conv_lstm", "C100", 2), ("conv_lstm", "C200", 3), ("conv_only", "C100", 2)])
+def test_fused_logits_oracle_synth(torch_cuda, O, arch, cfg, num_out):
+    """Ragged batch sizes (not multiples of any tile) on the SURVEY §8(d) generator."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    net = torch_ref.random_model(arch, 64, 9, num_out, seed=7)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    cc = synth.CONFIGS[cfg][0]
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0)
+    for n in (1, 17, 1000, 4099):
+        d = synth.synth_chunks_config(cfg, n, shard=n)
+        out = model.infer_chunks(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
+        enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+        with torch.no_grad():
+            ref = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
+        assert np.abs(out - ref).max() <= 1e-4, (arch, cfg, n)
+
+
+def test_full_size_properties(torch_cuda, O):
+    """BASELINE config 3 size (1M C100 chunks, ConvLSTM_w_ref fp32): determinism, permutation
+    equivariance across sub-batch / tile boundaries, exact label tally, and a 20k-chunk sample
+    against the CPU restatement of the reference network."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    n = 1_000_000
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=0)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    model = model_from_state(state, dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0)
+    d = synth.synth_chunks_config("C100", n)
+    dev = [torch.from_numpy(d[k]).cuda() for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    out = model.infer_chunks(*dev, (4, 4), label_counts=counts)
+    out2 = model.infer_chunks(*dev, (4, 4))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2), "non-deterministic"
+    assert bool(torch.isfinite(out).all())
+    host_counts = torch.bincount(out.argmax(dim=1), minlength=2)
+    assert torch.equal(counts, host_counts) and int(counts.sum()) == n
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    outp = model.infer_chunks(*[t[perm].contiguous() for t in dev], (4, 4))
+    assert torch.equal(outp, out[perm]), "result of a chunk depends on its batch position"
+    idx = np.sort(np.random.default_rng(0).choice(n, 20000, replace=False))
+    enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"][idx], d["sequence_to_signal_mapping"][idx], d["sequence_lengths"][idx])
+    with torch.no_grad():
+        ref = net(torch.from_numpy(d["signal"][idx]), torch.from_numpy(enc)).numpy()
+    assert np.abs(out[torch.from_numpy(idx).cuda()].cpu().numpy() - ref).max() <= 1e-4
+
+
+def test_count_labels_golden(torch_cuda):
+    import ctypes
+
+    from remora_amd import _lib as L
+    from remora_amd.engine import get_engine
+
+    g = golden("post_process.npz")
+    logits = np.ascontiguousarray(g["tally_logits"])
+    counts = np.zeros(3, np.int64)
+    L.check(L.lib().rmr_count_labels(get_engine(0).handle, logits.ctypes.data, logits.shape[0], 3, counts.ctypes.data, L.MEM_HOST))
+    assert np.array_equal(counts, g["tally_pred_counts"])
+
+
+# ---- boundary: load_model + call_read_mods -----------------------------------------------------------
+def _mint_pt(tmp_path, g, O):
+    """TorchScript file in the reference's format (model_util.py:115-176): the oracle's torch
+    restatement scripted + the reference-written meta.txt string from the golden file."""
+    import torch
+    from oracle import torch_ref
+
+    net = torch_ref.from_state(O.state_from_npz(g))
+    pt = str(tmp_path / "model.pt")
+    torch.jit.save(torch.jit.script(net), pt, _extra_files={"meta.txt": str(g["meta_txt"])})
+    return pt
+
+
+@pytest.mark.parametrize("name", ["cg_5mc", "allc_5hmc_5mc", "conv_cg"])
+def test_load_model_and_call_read_mods_golden(torch_cuda, O, tmp_path, name):
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_read_mods
+    from remora_amd.model_util import load_model
+
+    g = golden(f"call_read_mods_{name}.npz")
+    model, md = load_model(_mint_pt(tmp_path, g, O), device=0, quiet=True, eval_only=True)
+    ref_md = json.loads(str(g["derived_md_json"]))
+    for k, v in ref_md.items():
+        got = md[k]
+        if isinstance(v, list):
+            got = json.loads(json.dumps(got))
+        assert got == v, (k, got, v)
+    assert md["sig_map_refiner"].is_loaded is False
+    for rname in g["read_names"]:
+        rname = str(rname)
+        shift, scale = (float(x) for x in g[f"{rname}_shift_scale"])
+
+        def mk():
+            return RemoraRead(dacs=g[f"{rname}_dacs"].copy(), shift=shift, scale=scale,
+                              seq_to_sig_map=g[f"{rname}_map"].copy(), int_seq=g[f"{rname}_int_seq"].copy(), read_id=rname)
+
+        nn_out, labels, pos = call_read_mods(mk(), model, md)
+        assert np.array_equal(pos, g[f"{rname}_pos"]), "chunk order must follow the reference's set order"
+        assert np.array_equal(labels, g[f"{rname}_labels"])
+        if pos.size == 0:
+            assert nn_out.size == 0
+            res = call_read_mods(mk(), model, md, return_mm_ml_tags=True)
+            assert len(res) == 3 and str(g[f"{rname}_mm"]) == "<EMPTY3>"
+            continue
+        assert nn_out.dtype == np.float32 and pos.dtype == np.int64
+        assert np.abs(nn_out - g[f"{rname}_nn_out"]).max() <= 1e-4
+        probs, _, _ = call_read_mods(mk(), model, md, return_mod_probs=True)
+        assert probs.dtype == np.float64 and np.abs(probs - g[f"{rname}_probs"]).max() <= 1e-4
+        mm, ml = call_read_mods(mk(), model, md, return_mm_ml_tags=True)
+        assert mm == str(g[f"{rname}_mm"])
+        ml = np.asarray(list(ml), np.uint8).astype(int)
+        assert np.abs(ml - g[f"{rname}_ml"].astype(int)).max() <= 1  # floor(p*256) next to a bin edge
+    fo = int(g["r_long_focus_offset"])
+    shift, scale = (float(x) for x in g["r_long_shift_scale"])
+    rd = RemoraRead(dacs=g["r_long_dacs"], shift=shift, scale=scale, seq_to_sig_map=g["r_long_map"], int_seq=g["r_long_int_seq"])
+    o2, _, p2 = call_read_mods(rd, model, md, focus_offset=fo)
+    assert np.array_equal(p2, g["r_long_focus_pos"]) and np.abs(o2 - g["r_long_focus_nn_out"]).max() <= 1e-4
+
+
+def test_prepare_batches_reference_tuple(torch_cuda):
+    """read.batches elements unpack to (signal, enc_kmers, labels, read_focus_bases) like the reference's."""
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.util import Motif
+
+    g = golden("prepare_batches.npz")
+    shift, scale = (float(x) for x in g["shift_scale"])
+    read = RemoraRead(dacs=g["dacs"], shift=shift, scale=scale, seq_to_sig_map=g["map"], int_seq=g["int_seq"])
+    read.set_motif_focus_bases([Motif("CG", 0)])
+    md = dict(chunk_context=[50, 50], kmer_context_bases=[4, 4], base_start_justify=False, offset=0, sig_map_refiner=None)
+    read.prepare_batches(md, 2048)
+    assert len(read.batches) == 1
+    sig, enc, labels, rfb = read.batches[0]
+    assert np.array_equal(sig.view(np.uint32), g["signal"].view(np.uint32))
+    assert np.array_equal(enc, code_to_onehot(g["enc_code"]))
+    assert np.array_equal(labels, g["labels"]) and np.array_equal(rfb, g["read_focus_bases"])
+
+
+def test_errors_surface_as_remora_error(torch_cuda):
+    from remora_amd import RemoraError
+    from remora_amd.model_util import load_model, model_from_state
+
+    with pytest.raises(RemoraError, match="not found"):
+        load_model("/nonexistent/model.pt")
+    with pytest.raises(RemoraError):
+        load_model(None)
+    from oracle import torch_ref
+
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    model = model_from_state(state, dict(chunk_context=(50, 50)), device=0)
+    import torch
+
+    with pytest.raises(RemoraError, match="do not match"):
+        model(torch.zeros(2, 1, 90).cuda(), torch.zeros(2, 36, 90).cuda())
+    with pytest.raises(RemoraError, match="kmer"):
+        model.infer_chunks(np.zeros((2, 1, 100), np.float32), np.zeros((2, 24), np.int8), np.zeros((2, 21), np.int16),
+                           np.ones(2, np.int16), (2, 3))
