@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh output directory (rocprofv3 CSVs) into one markdown file
+for profiles/.  HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB
+(x1024), collected in separate passes; on gfx950 FETCH_SIZE under-reports wide coalesced reads
+by 2x, so the corrected read figure (x2) is shown next to the raw one."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void rmr::", "").replace("rmr::", "")
+    return name.split("(")[0]
+
+
+def load_counters(d):
+    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    disp_seen = defaultdict(set)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            c = row["Counter_Name"]
+            agg[k][c][0] += float(row["Counter_Value"])
+            disp_seen[(k, c)].add(row["Dispatch_Id"])
+    out = {}
+    for k in agg:
+        out[k] = {c: (v[0], len(disp_seen[(k, c)])) for c, v in agg[k].items()}
+    return out
+
+
+def main():
+    d = sys.argv[1]
+    tag = os.path.basename(d.rstrip("/"))
+    lines = [f"# rocprofv3 summary — {tag}", "",
+             "Command per pass: `rocprofv3 <flags> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
+             "(tools/profile_gpu.sh); 1 x MI355X, 1M chunks/step.", ""]
+    stats = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        lines += ["## --kernel-trace --stats", "", "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
+        for row in csv.DictReader(open(stats[0])):
+            if "rmr::" not in row["Name"]:
+                continue
+            lines.append(f"| {short(row['Name'])} | {row['Calls']} | {float(row['TotalDurationNs'])/1e6:.2f} | "
+                         f"{float(row['AverageNs'])/1e3:.1f} | {float(row['Percentage']):.2f} | "
+                         f"{float(row['MinNs'])/1e3:.1f} | {float(row['MaxNs'])/1e3:.1f} |")
+        lines.append("")
+    fetch = load_counters(os.path.join(d, "pmc_FETCH_SIZE"))
+    write = load_counters(os.path.join(d, "pmc_WRITE_SIZE"))
+    if fetch or write:
+        lines += ["## HBM traffic per launch (separate --pmc passes)", "",
+                  "| kernel | launches | FETCH_SIZE raw MB | read MB (x2 gfx950 corr.) | WRITE_SIZE MB | total MB (corr.) |", "|---|---|---|---|---|---|"]
+        for k in sorted(set(fetch) | set(write)):
+            if "rocclr" in k or "at::" in k:
+                continue
+            fv, fn = fetch.get(k, {}).get("FETCH_SIZE", (0, 0))
+            wv, wn = write.get(k, {}).get("WRITE_SIZE", (0, 0))
+            n = max(fn, wn, 1)
+            fr = fv * 1024 / max(fn, 1) / 1e6
+            wr = wv * 1024 / max(wn, 1) / 1e6
+            lines.append(f"| {k} | {n} | {fr:.2f} | {2*fr:.2f} | {wr:.2f} | {2*fr+wr:.2f} |")
+        lines.append("")
+    for sub, title in (("pmc_mfma", "MFMA / busy counters (sum over launches)"), ("pmc_lds", "LDS / issue counters (sum over launches)")):
+        c = load_counters(os.path.join(d, sub))
+        c = {k: v for k, v in c.items() if "rocclr" not in k and "at::" not in k}
+        if not c:
+            continue
+        names = sorted({n for k in c for n in c[k]})
+        lines += [f"## {title}", "", "| kernel | launches | " + " | ".join(names) + " |", "|---|---|" + "---|" * len(names)]
+        for k in sorted(c):
+            n = max(v[1] for v in c[k].values())
+            lines.append(f"| {k} | {n} | " + " | ".join(f"{c[k].get(nm, (0, 0))[0]:.4g}" for nm in names) + " |")
+        lines.append("")
+        if sub == "pmc_mfma":
+            lines += ["MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs) "
+                      "(GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x #v_mfma_f32_16x16x4_f32, summed over all SIMDs):", ""]
+            for k in sorted(c):
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in c[k] and "GRBM_GUI_ACTIVE" in c[k] and c[k]["GRBM_GUI_ACTIVE"][0] > 0:
+                    u = c[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (c[k]["GRBM_GUI_ACTIVE"][0] / 8 * 1024)
+                    lines.append(f"- {k}: {u:.3f}")
+            lines.append("")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
