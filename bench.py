@@ -45,7 +45,8 @@ def kernel_flops_per_chunk(arch, L, size=64, K=9, num_out=2):
     f = {}
     f["conv_sig3"] = 2 * size * 16 * 9 * P3
     # front: sig_conv1, sig_conv2 MACs + seq_conv1 as K*kw1 gather-adds x 16 ch
-    f["front_sig12_seq1"] = 2 * (4 * kw1 * P1 + 16 * 4 * kw1 * P2) + 16 * K * kw1 * P1
+    f["front_sig"] = 2 * (4 * kw1 * P1 + 16 * 4 * kw1 * P2)
+    f["front_seq"] = 16 * K * kw1 * P1  # seq_conv1 as K*kw1 gather-adds x 16 channels
     if arch == "conv_lstm":
         T = P3 - 4
         f["conv_seq2"] = 2 * size * 16 * 13 * P3
@@ -188,7 +189,7 @@ def main():
         fl = flops.get(name)
         kern[name] = {"ms_total": ms, "launches": launches, "avg_ms": ms / launches,
                       "tflops": (fl * n * args.steps / (ms * 1e-3) / 1e12) if fl else None}
-    dom = max((k for k in kern if flops.get(k) and k != "front_sig12_seq1"), key=lambda k: kern[k]["ms_total"])
+    dom = max((k for k in kern if flops.get(k) and not k.startswith("front_")), key=lambda k: kern[k]["ms_total"])
     chunks_per_launch = n * args.steps / kern[dom]["launches"]
     achieved = flops[dom] * chunks_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
     traffic = os.environ.get("RMR_BENCH_TRAFFIC_BYTES")  # PMC-derived HBM bytes/launch (profiles/)

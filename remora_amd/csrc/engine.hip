@@ -23,7 +23,7 @@ void set_error(const char *fmt, ...) {
 
 static const char *k_names[K_NUM] = {
     "encode_kmers", "trim_chunk_context", "parse_moves", "normalise_signal", "chunk_geometry",
-    "chunk_fill", "front_sig12_seq1", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
+    "chunk_fill", "front_sig", "front_seq", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
     "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
     "count_labels"};
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
@@ -362,6 +362,13 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
         RMR_TRY(upload(m.get(), w2, &m->front.w_sig2));
         RMR_TRY(upload(m.get(), s2.b, &m->front.b_sig2));
         RMR_TRY(upload(m.get(), wt, &m->front.wt_seq1));
+        std::vector<float> wt5((size_t)kw1 * K * 80, 0.0f);
+        for (int t = 0; t < kw1; ++t)
+            for (int kp = 0; kp < K; ++kp)
+                for (int b = 0; b < 4; ++b)
+                    for (int o = 0; o < 16; ++o)
+                        wt5[(((size_t)t * K + kp) * 5 + b) * 16 + o] = q1.w[((size_t)o * ec + 4 * kp + b) * kw1 + t];
+        RMR_TRY(upload(m.get(), wt5, &m->front.wt5_seq1));
         RMR_TRY(upload(m.get(), q1.b, &m->front.b_seq1));
     }
     RMR_TRY(pack_conv(m.get(), convs[2], K_CONV_SIG3, &m->sig3));

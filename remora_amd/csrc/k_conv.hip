@@ -14,9 +14,14 @@
 //       feeds four MFMAs, and the D fragment (4 consecutive oc x 1 column per lane) is
 //       ONE 16-byte store in the channel-last output.
 //
-// LDS: CB chunks of input staged as rows of IC floats padded to IC+4 (row stride/4 odd ->
-// the 16 columns of a tile land on distinct 16-byte bank slots for ds_read_b128).
+// LDS: CB chunks of input staged as FOUR PLANES, plane q holding channels {16g+4q+j} of every
+// row (IC/4 floats per row, padded so that rowstride/4 is odd), plane stride a multiple of
+// 64 floats.  ds_read_b128 is serviced in 16-lane groups that contain all 16 columns n of a
+// tile but mixed q; with the q-dependence a multiple of 256 B and an odd row stride the 16
+// lanes of every group land on 16 distinct 16-byte bank slots: conflict-free (a row-padded
+// [row][IC+4] image measured 54 % of LDS cycles lost to 2-way conflicts, profiles/r01).
 #include "rmr_internal.h"
+#include "rmr_math.h"
 
 namespace rmr {
 
@@ -33,19 +38,16 @@ struct ConvArgs {
     int out_row;    // floats per output position
     int out_coff;   // channel offset of this layer's output inside out_row
     int cb;         // chunks per block iteration
+    int plane;      // LDS plane stride in floats (multiple of 64)
     FastDiv div_pout;
 };
 
-__device__ __forceinline__ float swish_f(float x) {
-    // x * sigmoid(x)   (src/remora/activations.py:4-18)
-    return x * __frcp_rn(1.0f + __expf(-x));
-}
 
 template <int IC, int KW, int STRIDE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int RS = IC + 4;        // padded LDS row (floats)
     constexpr int G = IC / 16;        // 16-channel groups
+    constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;  // floats per row per plane, RS/4 odd
     constexpr int S = KW * IC / 4;    // MFMA k-steps
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
@@ -64,14 +66,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
         __syncthreads();  // all reads of the previous iteration are done
-        {                 // stage nch * pin rows of IC floats
+        {                 // stage nch * pin rows of IC floats into the 4 planes
             constexpr int R4 = IC / 4;
+            constexpr int UNR = 8;  // loads in flight per thread before the first LDS write
             const int total4 = nch * a.pin * R4;
             const float4 *src = reinterpret_cast<const float4 *>(a.in + (size_t)chunk0 * a.pin * a.in_row);
-            for (int i = tid; i < total4; i += blockDim.x) {
-                const int row = i / R4, c4 = i - row * R4;
-                const float4 v = src[i];
-                *reinterpret_cast<float4 *>(smem + (size_t)row * RS + 4 * c4) = v;
+            for (int base = tid; base < total4; base += UNR * (int)blockDim.x) {
+                float4 v[UNR];
+                int dsto[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = base + u * (int)blockDim.x;
+                    const int ii = i < total4 ? i : total4 - 1;
+                    const int row = ii / R4, c = ii - row * R4;
+                    const int qq = c / G, g = c - qq * G;  // consecutive lanes: same plane, consecutive g
+                    v[u] = src[row * R4 + 4 * g + qq];
+                    dsto[u] = i < total4 ? qq * a.plane + row * RS + 4 * g : 4 * a.plane;  // trash slot
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) *reinterpret_cast<float4 *>(smem + dsto[u]) = v[u];
             }
         }
         __syncthreads();
@@ -85,22 +98,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             const int ch0 = (int)(((float)col0 + 0.5f) * a.div_pout.inv);
             const int ch1 = (int)(((float)col1 + 0.5f) * a.div_pout.inv);
             const int p0 = col0 - ch0 * a.pout, p1 = col1 - ch1 * a.pout;
-            const float *r0 = smem + (size_t)(ch0 * a.pin + p0 * STRIDE) * RS + 4 * q;
-            const float *r1 = smem + (size_t)(ch1 * a.pin + p1 * STRIDE) * RS + 4 * q;
+            const float *r0 = smem + (size_t)q * a.plane + (size_t)(ch0 * a.pin + p0 * STRIDE) * RS;
+            const float *r1 = smem + (size_t)q * a.plane + (size_t)(ch1 * a.pin + p1 * STRIDE) * RS;
             f32x4 acc0 = b4, acc1 = b4;
+            // B fragments are fetched one (tap, g) step ahead of the MFMAs that consume them
+            constexpr int NS = KW * G;
+            f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0), x1 = *reinterpret_cast<const f32x4 *>(r1);
 #pragma unroll
-            for (int tap = 0; tap < KW; ++tap) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0 + tap * RS + 16 * g);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(r1 + tap * RS + 16 * g);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int s = (tap * G + g) * 4 + j;
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], x0[j], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], x1[j], acc1, 0, 0, 0);
-                    }
+            for (int st = 0; st < NS; ++st) {
+                f32x4 y0 = x0, y1 = x1;
+                if (st + 1 < NS) {
+                    const int tap = (st + 1) / G, g = (st + 1) % G;
+                    y0 = *reinterpret_cast<const f32x4 *>(r0 + tap * RS + 4 * g);
+                    y1 = *reinterpret_cast<const f32x4 *>(r1 + tap * RS + 4 * g);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x0[j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x1[j], acc1, 0, 0, 0);
+                }
+                x0 = y0;
+                x1 = y1;
+            }
+            // pin the software pipeline: reads of step st+1 are issued before the MFMAs of step st
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
             if (v0) {
                 f32x4 y;
@@ -123,20 +148,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 template <int IC, int KW, int STRIDE>
 static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                          float *out, int out_row, int out_coff, int pout, int64_t n) {
-    constexpr int RS = IC + 4;
+    constexpr int G = IC / 16;
+    constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;
     // chunks per iteration: fill <= 72 KB of LDS (2 blocks per CU) and give an even
     // number of 16-column tiles where possible
-    const size_t row_bytes = (size_t)pin * RS * sizeof(float);
+    const size_t row_bytes = (size_t)pin * RS * 4 * sizeof(float);  // all four planes
     int cb = (int)(73728 / row_bytes);
     if (cb < 1) cb = 1;
     if (cb > 8) cb = 8;
     if (cb >= 4) cb &= ~3;  // multiples of 4 chunks -> cb*pout divisible by 4
-    const size_t lds = row_bytes * cb;
+    const int plane = ((cb * pin * RS) + 63) & ~63;
+    const size_t lds = (size_t)plane * 4 * sizeof(float) + 64;  // + trash slot for masked staging writes
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "conv layer needs %zu B of LDS", lds);
     ConvArgs a;
     a.in = in; a.out = out; a.apack = c.apack; a.bias = c.bias; a.n = n;
     a.in_row = in_row; a.pin = pin; a.pout = pout; a.out_row = out_row; a.out_coff = out_coff;
-    a.cb = cb; a.div_pout = make_fastdiv(pout);
+    a.cb = cb; a.plane = plane; a.div_pout = make_fastdiv(pout);
     const int64_t iters = (n + cb - 1) / cb;
     const int threads = 64 * (c.oc / 16);
     int64_t grid = (int64_t)e->num_cus * 2;

@@ -14,141 +14,202 @@
 //
 // Outputs are channel-last: sig2 f32[n][P2][16], seq1 f32[n][P1][16].
 #include "rmr_internal.h"
+#include "rmr_math.h"
 
 namespace rmr {
 
-__device__ __forceinline__ float swish_ff(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
-struct FrontArgs {
-    const float *signal;   // [n][L]
-    const int8_t *seqs;    // [n][seq_w]
-    const int16_t *maps;   // [n][map_w]
-    const int16_t *lens;   // [n]
-    const float *w_sig1, *b_sig1, *w_sig2, *b_sig2, *wt_seq1, *b_seq1;
-    float *sig2, *seq1;
+// ---------------------------------------------------------------------------------------
+// signal branch: sig_conv1 (1->4) -> LDS -> sig_conv2 (4->16).  32 threads per chunk, the
+// thread's output-channel quad (tid & 3) is fixed, so its 4-channel slice of the sig_conv2
+// weights (KW*4*4 floats) lives in VGPRs.
+// ---------------------------------------------------------------------------------------
+struct FrontSigArgs {
+    const float *signal;  // [n][L]
+    const float *w_sig1, *b_sig1, *w_sig2, *b_sig2;
+    float *sig2;          // [n][P2][16]
     int64_t n;
-    int L, seq_w, map_w, K, P1, P2, cb;
-    int seq_w_pad;  // LDS row of the sequence bytes (multiple of 4)
+    int L, P1, P2, cb;
 };
 
-// LDS carve (floats unless noted), all offsets multiples of 4 floats:
-//   w_sig2 [KW][4][16] | wt_seq1 [KW][K][4][16] | sig [cb][Lp] | sig1 [cb][P1][4] |
-//   pidx (int16) [cb][Lp] | seqrow (int8) [cb][seq_w_pad]
 template <int KW>
-__global__ __launch_bounds__(256) void front_kernel(FrontArgs a) {
+__global__ __launch_bounds__(256) void front_sig_kernel(FrontSigArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
+    const int c = tid >> 5, sub = tid & 31, quad = sub & 3;
     const int Lp = (a.L + 3) & ~3;
-    float *s_w2 = smem;
-    float *s_wt = s_w2 + KW * 64;
-    float *s_sig = s_wt + KW * a.K * 64;
-    float *s_sig1 = s_sig + a.cb * Lp;
-    int16_t *s_pidx = reinterpret_cast<int16_t *>(s_sig1 + a.cb * a.P1 * 4);
-    int8_t *s_seq = reinterpret_cast<int8_t *>(s_pidx + a.cb * Lp);
+    float *s_sig = smem + (size_t)c * Lp;
+    float *s_sig1 = smem + (size_t)a.cb * Lp + (size_t)c * a.P1 * 4;
 
-    for (int i = tid; i < KW * 64; i += blockDim.x) s_w2[i] = a.w_sig2[i];
-    if (a.seq1)
-        for (int i = tid; i < KW * a.K * 64; i += blockDim.x) s_wt[i] = a.wt_seq1[i];
     float w1[KW][4];
 #pragma unroll
     for (int t = 0; t < KW; ++t)
 #pragma unroll
         for (int o = 0; o < 4; ++o) w1[t][o] = a.w_sig1[t * 4 + o];
     const float4 b1 = *reinterpret_cast<const float4 *>(a.b_sig1);
+    float4 w2[KW][4];  // [tap][ic] -> 4 oc of this thread's quad
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int ic = 0; ic < 4; ++ic)
+            w2[t][ic] = *reinterpret_cast<const float4 *>(a.w_sig2 + (t * 4 + ic) * 16 + 4 * quad);
+    const float4 b2 = *reinterpret_cast<const float4 *>(a.b_sig2 + 4 * quad);
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
-        const int64_t chunk0 = it * a.cb;
-        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        const int64_t chunk = it * a.cb + c;
+        const bool live = chunk < a.n;
         __syncthreads();
-        // ---- phase 1: stage signal + sequence bytes; p(s) by upper_bound on the mapping --
-        for (int i = tid; i < nch * a.L; i += blockDim.x) {
-            const int c = i / a.L, s = i - c * a.L;
-            s_sig[c * Lp + s] = a.signal[(size_t)(chunk0 + c) * a.L + s];
-            if (a.seq1) {
-                const int16_t *mp = a.maps + (size_t)(chunk0 + c) * a.map_w;
-                const int len = a.lens[chunk0 + c];
-                // first index in [0, len] with map[idx] > s
+        if (live) {
+            const float *src = a.signal + (size_t)chunk * a.L;
+            for (int s = sub; s < a.L; s += 32) s_sig[s] = src[s];
+        }
+        __syncthreads();
+        if (live) {
+            for (int pos = sub; pos < a.P1; pos += 32) {
+                float4 acc = b1;
+#pragma unroll
+                for (int t = 0; t < KW; ++t) {
+                    const float xv = s_sig[pos + t];
+                    acc.x += w1[t][0] * xv; acc.y += w1[t][1] * xv;
+                    acc.z += w1[t][2] * xv; acc.w += w1[t][3] * xv;
+                }
+                acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
+                acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
+                *reinterpret_cast<float4 *>(s_sig1 + pos * 4) = acc;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            float *dst = a.sig2 + (size_t)chunk * a.P2 * 16;
+            for (int i = sub; i < a.P2 * 4; i += 32) {  // i & 3 == quad
+                const int pos = i >> 2;
+                float4 acc = b2;
+#pragma unroll
+                for (int t = 0; t < KW; ++t) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(s_sig1 + (pos + t) * 4);
+                    acc.x += w2[t][0].x * xv.x + w2[t][1].x * xv.y + w2[t][2].x * xv.z + w2[t][3].x * xv.w;
+                    acc.y += w2[t][0].y * xv.x + w2[t][1].y * xv.y + w2[t][2].y * xv.z + w2[t][3].y * xv.w;
+                    acc.z += w2[t][0].z * xv.x + w2[t][1].z * xv.y + w2[t][2].z * xv.z + w2[t][3].z * xv.w;
+                    acc.w += w2[t][0].w * xv.x + w2[t][1].w * xv.y + w2[t][2].w * xv.z + w2[t][3].w * xv.w;
+                }
+                acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
+                acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
+                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sequence branch, two-level gather.  The k-mer at signal position s depends only on the
+// base p(s) covering it, so the sum over the K k-mer slots is done once per BASE and tap:
+//     U[p][tap][oc] = sum_kp W[oc][4kp + seq[p+kp]][tap]            (<= max_seq_len bases)
+//     seq1[pos][oc] = swish(b[oc] + sum_tap U[p(pos+tap)][tap][oc])  (P1 positions)
+// ~3x fewer LDS gathers than summing K*KW table rows per position.  The K bases of a window
+// are packed 3 bits each into one 64-bit word (value 4 = missing base -> an all-zero table
+// row), so the gather is branch-free; p(s) comes from a binary search on the LDS-resident
+// mapping row (upper_bound: the gather form of the reference's scatter loops,
+// src/remora/encoded_kmers.pyx:33-44); positions outside every base use a zero U row.
+// ---------------------------------------------------------------------------------------
+struct FrontSeqArgs {
+    const int8_t *seqs;    // [n][seq_w]
+    const int16_t *maps;   // [n][map_w]
+    const int16_t *lens;   // [n]
+    const float *wt5;      // [KW][K][5][16]  (row 4 of each slot = zeros)
+    const float *b_seq1;   // [16]
+    float *seq1;           // [n][P1][16]
+    int64_t n;
+    int L, seq_w, map_w, K, P1, cb, maxlen;
+    int o_map, o_seq, o_code, o_pidx, o_u, per_chunk;  // LDS offsets (in 4-byte words) per chunk
+};
+
+template <int KW>
+__global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int c = tid >> 5, sub = tid & 31, quad = sub & 3;
+    float *s_wt = smem;  // [KW][K][5][16]
+    const int wt_words = KW * a.K * 80;
+    float *cbase = smem + wt_words + (size_t)c * a.per_chunk;
+    int16_t *s_map = reinterpret_cast<int16_t *>(cbase + a.o_map);
+    int8_t *s_seq = reinterpret_cast<int8_t *>(cbase + a.o_seq);
+    unsigned long long *s_code = reinterpret_cast<unsigned long long *>(cbase + a.o_code);
+    int16_t *s_pidx = reinterpret_cast<int16_t *>(cbase + a.o_pidx);
+    float *s_u = cbase + a.o_u;  // [(maxlen+1)][KW][16], row `maxlen` = zeros
+
+    for (int i = tid; i < wt_words; i += blockDim.x) s_wt[i] = a.wt5[i];
+    for (int i = sub; i < KW * 16; i += 32) s_u[(size_t)a.maxlen * KW * 16 + i] = 0.0f;
+    const float4 bq = *reinterpret_cast<const float4 *>(a.b_seq1 + 4 * quad);
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk = it * a.cb + c;
+        const bool live = chunk < a.n;
+        int len = 0;
+        __syncthreads();
+        if (live) {
+            len = a.lens[chunk];
+            len = len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len);
+            const int16_t *mp = a.maps + (size_t)chunk * a.map_w;
+            for (int j = sub; j < a.map_w; j += 32) s_map[j] = mp[j];
+            const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
+            for (int j = sub; j < a.seq_w; j += 32) s_seq[j] = sq[j];
+        }
+        __syncthreads();
+        if (live) {
+            for (int s = sub; s < a.L; s += 32) {  // first index in [0, len] with map[idx] > s
                 int lo = 0, hi = len + 1;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (mp[mid] <= s) lo = mid + 1; else hi = mid;
+                    if (s_map[mid] <= s) lo = mid + 1; else hi = mid;
                 }
                 const int p = lo - 1;
-                s_pidx[c * Lp + s] = (int16_t)((p >= 0 && p < len) ? p : -1);
+                s_pidx[s] = (int16_t)((p >= 0 && p < len) ? p : a.maxlen);
+            }
+            for (int p = sub; p < len; p += 32) {
+                unsigned long long wv = 0;
+                for (int kp = 0; kp < a.K; ++kp) {
+                    const int b = s_seq[p + kp];
+                    wv |= (unsigned long long)((b >= 0 && b < 4) ? b : 4) << (3 * kp);
+                }
+                s_code[p] = wv;
             }
         }
-        if (a.seq1)
-            for (int i = tid; i < nch * a.seq_w; i += blockDim.x) {
-                const int c = i / a.seq_w, j = i - c * a.seq_w;
-                s_seq[c * a.seq_w_pad + j] = a.seqs[(size_t)(chunk0 + c) * a.seq_w + j];
-            }
         __syncthreads();
-        // ---- phase 2: sig_conv1 (1 -> 4) into LDS ---------------------------------------
-        for (int i = tid; i < nch * a.P1; i += blockDim.x) {
-            const int c = i / a.P1, pos = i - c * a.P1;
-            const float *x = s_sig + c * Lp + pos;
-            float4 acc = b1;
-#pragma unroll
-            for (int t = 0; t < KW; ++t) {
-                const float xv = x[t];
-                acc.x += w1[t][0] * xv; acc.y += w1[t][1] * xv;
-                acc.z += w1[t][2] * xv; acc.w += w1[t][3] * xv;
+        if (live) {
+            const int items = len * KW * 4;
+            for (int i = sub; i < items; i += 32) {  // i & 3 == quad
+                const int pt = i >> 2;
+                const int p = pt / KW, t = pt - p * KW;
+                unsigned long long wv = s_code[p];
+                const float *wt = s_wt + (size_t)t * a.K * 80 + 4 * quad;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int kp = 0; kp < a.K; ++kp) {
+                    const int b = (int)(wv & 7ull);
+                    wv >>= 3;
+                    const float4 v = *reinterpret_cast<const float4 *>(wt + (kp * 5 + b) * 16);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = acc;
             }
-            acc.x = swish_ff(acc.x); acc.y = swish_ff(acc.y);
-            acc.z = swish_ff(acc.z); acc.w = swish_ff(acc.w);
-            *reinterpret_cast<float4 *>(s_sig1 + (size_t)(c * a.P1 + pos) * 4) = acc;
         }
-        // ---- phase 3a: seq_conv1 as gather-sum (independent of phase 2) -------------------
-        if (a.seq1) {
-            for (int i = tid; i < nch * a.P1 * 4; i += blockDim.x) {
-                const int quad = i & 3, cp = i >> 2;
-                const int c = cp / a.P1, pos = cp - c * a.P1;
-                float4 acc = *reinterpret_cast<const float4 *>(a.b_seq1 + 4 * quad);
-                const int16_t *pp = s_pidx + c * Lp + pos;
-                const int8_t *sq = s_seq + c * a.seq_w_pad;
+        __syncthreads();
+        if (live) {
+            float *dst = a.seq1 + (size_t)chunk * a.P1 * 16;
+            for (int i = sub; i < a.P1 * 4; i += 32) {
+                const int pos = i >> 2;
+                float4 acc = bq;
 #pragma unroll
                 for (int t = 0; t < KW; ++t) {
-                    const int p = pp[t];
-                    if (p >= 0) {
-                        const float *wt = s_wt + (size_t)t * a.K * 64 + 4 * quad;
-                        for (int kp = 0; kp < a.K; ++kp) {
-                            const int b = sq[p + kp];
-                            if (b >= 0) {
-                                const float4 wv = *reinterpret_cast<const float4 *>(wt + (kp * 4 + b) * 16);
-                                acc.x += wv.x; acc.y += wv.y; acc.z += wv.z; acc.w += wv.w;
-                            }
-                        }
-                    }
+                    const int p = s_pidx[pos + t];
+                    const float4 v = *reinterpret_cast<const float4 *>(s_u + ((size_t)p * KW + t) * 16 + 4 * quad);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
-                acc.x = swish_ff(acc.x); acc.y = swish_ff(acc.y);
-                acc.z = swish_ff(acc.z); acc.w = swish_ff(acc.w);
-                *reinterpret_cast<float4 *>(a.seq1 + ((size_t)(chunk0 + c) * a.P1 + pos) * 16 + 4 * quad) = acc;
+                acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
+                acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
+                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = acc;
             }
-        }
-        __syncthreads();
-        // ---- phase 3b: sig_conv2 (4 -> 16) -------------------------------------------------
-        for (int i = tid; i < nch * a.P2 * 4; i += blockDim.x) {
-            const int quad = i & 3, cp = i >> 2;
-            const int c = cp / a.P2, pos = cp - c * a.P2;
-            float4 acc = *reinterpret_cast<const float4 *>(a.b_sig2 + 4 * quad);
-            const float *x = s_sig1 + (size_t)(c * a.P1 + pos) * 4;
-#pragma unroll
-            for (int t = 0; t < KW; ++t) {
-                const float4 xv = *reinterpret_cast<const float4 *>(x + 4 * t);
-                const float *wv = s_w2 + t * 64 + 4 * quad;
-                const float4 w0 = *reinterpret_cast<const float4 *>(wv);
-                const float4 w1v = *reinterpret_cast<const float4 *>(wv + 16);
-                const float4 w2v = *reinterpret_cast<const float4 *>(wv + 32);
-                const float4 w3v = *reinterpret_cast<const float4 *>(wv + 48);
-                acc.x += w0.x * xv.x + w1v.x * xv.y + w2v.x * xv.z + w3v.x * xv.w;
-                acc.y += w0.y * xv.x + w1v.y * xv.y + w2v.y * xv.z + w3v.y * xv.w;
-                acc.z += w0.z * xv.x + w1v.z * xv.y + w2v.z * xv.z + w3v.z * xv.w;
-                acc.w += w0.w * xv.x + w1v.w * xv.y + w2v.w * xv.z + w3v.w * xv.w;
-            }
-            acc.x = swish_ff(acc.x); acc.y = swish_ff(acc.y);
-            acc.z = swish_ff(acc.z); acc.w = swish_ff(acc.w);
-            *reinterpret_cast<float4 *>(a.sig2 + ((size_t)(chunk0 + c) * a.P2 + pos) * 16 + 4 * quad) = acc;
         }
     }
 }
@@ -159,33 +220,58 @@ int launch_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
     const int K = m->desc.kmer_len;
-    if (seq1 && kb + ka + 1 != K) RMR_FAIL(RMR_ERR_INVALID, "kmer context (%d,%d) != model kmer_len %d", kb, ka, K);
     const int kw = m->front.kw1;
-    FrontArgs a;
-    a.signal = signal; a.seqs = seqs; a.maps = maps; a.lens = lens;
-    a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1; a.w_sig2 = m->front.w_sig2;
-    a.b_sig2 = m->front.b_sig2; a.wt_seq1 = m->front.wt_seq1; a.b_seq1 = m->front.b_seq1;
-    a.sig2 = sig2; a.seq1 = seq1; a.n = n; a.L = m->L; a.seq_w = seq_w; a.map_w = map_w;
-    a.K = K; a.P1 = m->P1; a.P2 = m->P2;
-    a.seq_w_pad = (seq_w + 3) & ~3;
-    const int Lp = (m->L + 3) & ~3;
-    const size_t fixed = (size_t)(kw * 64 + kw * K * 64) * 4;
-    const size_t per_chunk = (size_t)Lp * 4 + (size_t)m->P1 * 16 + (size_t)Lp * 2 + a.seq_w_pad;
-    int cb = (int)((65536 - fixed) / per_chunk);
-    if (cb > 16) cb = 16;
-    if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "front kernel: chunk too large for LDS");
+    if (kw != 5 && kw != 11) RMR_FAIL(RMR_ERR_INVALID, "front kernel width %d unsupported", kw);
+    {   // ---- signal branch ----
+        FrontSigArgs a;
+        a.signal = signal; a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1;
+        a.w_sig2 = m->front.w_sig2; a.b_sig2 = m->front.b_sig2; a.sig2 = sig2; a.n = n;
+        a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.cb = 8;
+        const int Lp = (m->L + 3) & ~3;
+        const size_t lds = (size_t)a.cb * (Lp + m->P1 * 4) * 4;
+        const int64_t iters = (n + a.cb - 1) / a.cb;
+        int64_t grid = (int64_t)e->num_cus * 8;
+        if (grid > iters) grid = iters;
+        ProfScope ps(e, K_FRONT_SIG);
+        if (kw == 5) hipLaunchKernelGGL(front_sig_kernel<5>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        else hipLaunchKernelGGL(front_sig_kernel<11>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        RMR_HIP(hipGetLastError());
+    }
+    if (!seq1) return 0;
+    if (kb + ka + 1 != K) RMR_FAIL(RMR_ERR_INVALID, "kmer context (%d,%d) != model kmer_len %d", kb, ka, K);
+    if (K > 21) RMR_FAIL(RMR_ERR_INVALID, "kmer_len %d > 21 not supported by the fused encode", K);
+    FrontSeqArgs a;
+    a.seqs = seqs; a.maps = maps; a.lens = lens; a.wt5 = m->front.wt5_seq1; a.b_seq1 = m->front.b_seq1;
+    a.seq1 = seq1; a.n = n; a.L = m->L; a.seq_w = seq_w; a.map_w = map_w; a.K = K; a.P1 = m->P1;
+    a.maxlen = map_w - 1;
+    if (seq_w < a.maxlen + K - 1) RMR_FAIL(RMR_ERR_INVALID, "sequence width %d too small for mapping width %d", seq_w, map_w);
+    // per-chunk LDS carve in 4-byte words, every region 16-byte aligned
+    auto up4 = [](int words) { return (words + 3) & ~3; };
+    int off = 0;
+    a.o_map = off; off += up4((map_w * 2 + 3) / 4);
+    a.o_seq = off; off += up4((seq_w + 3) / 4);
+    a.o_code = off; off += up4(a.maxlen * 2);
+    a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
+    a.o_u = off; off += (a.maxlen + 1) * kw * 16;
+    a.per_chunk = up4(off);
+    const size_t fixed = (size_t)kw * K * 80 * 4;
+    int cb = 8;
+    while (cb > 1 && fixed + (size_t)cb * a.per_chunk * 4 > 78 * 1024) cb >>= 1;
+    const size_t lds = fixed + (size_t)cb * a.per_chunk * 4;
+    if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "front_seq: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
     a.cb = cb;
-    const size_t lds = fixed + per_chunk * cb + 64;
+    auto kern = (kw == 5) ? front_seq_kernel<5> : front_seq_kernel<11>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[kw == 5 ? 0 : 1]) {
+        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done[kw == 5 ? 0 : 1] = true;
+    }
     const int64_t iters = (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * 4;
     if (grid > iters) grid = iters;
-    ProfScope ps(e, K_FRONT);
-    if (kw == 5)
-        hipLaunchKernelGGL(front_kernel<5>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
-    else if (kw == 11)
-        hipLaunchKernelGGL(front_kernel<11>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
-    else
-        RMR_FAIL(RMR_ERR_INVALID, "front kernel width %d unsupported", kw);
+    ProfScope ps(e, K_FRONT_SEQ);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(32 * cb), lds, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }
@@ -224,8 +310,8 @@ __global__ __launch_bounds__(256) void seq1_dense_kernel(DenseArgs a) {
                     acc.x += wv.x * xv; acc.y += wv.y * xv; acc.z += wv.z * xv; acc.w += wv.w * xv;
                 }
             }
-            acc.x = swish_ff(acc.x); acc.y = swish_ff(acc.y);
-            acc.z = swish_ff(acc.z); acc.w = swish_ff(acc.w);
+            acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
+            acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
             *reinterpret_cast<float4 *>(a.seq1 + ((size_t)c * a.P1 + pos) * 16 + 4 * quad) = acc;
         }
     }

@@ -17,17 +17,12 @@
 // D fragment = 4 consecutive hidden units of one chunk = one ds_write_b128; B fragment =
 // one ds_read_b128 per 16-wide k group, each feeding 4 MFMAs x 4 gates.
 #include "rmr_internal.h"
+#include "rmr_math.h"
 
 namespace rmr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) {
-    // 1 - 2/(1+e^{2x}); saturates correctly at +-inf, abs error ~1e-7
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
-}
-__device__ __forceinline__ float swish_l(float x) { return x * sigmoid_f(x); }
 
 struct LstmArgs {
     const float *x;  // [n][T][H] channel-last merge_conv1 output
@@ -37,14 +32,45 @@ struct LstmArgs {
     int T, num_out;
 };
 
+// acc[gt] += A[gt][:] (register-resident weight slice) x B fragments read from one LDS image
+template <int KS, int G, int RS>
+__device__ __forceinline__ void xproj(const float (&buf)[4][16][RS], int q, int nn,
+                                      const float (&A)[4][KS], f32x4 (&acc)[4]) {
+    const float *b = &buf[q][nn][0];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const f32x4 bx = *reinterpret_cast<const f32x4 *>(b + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+                acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[gt][g * 4 + j], bx[j], acc[gt], 0, 0, 0);
+    }
+}
+
+// LSTM cell update for this lane's 4 hidden units (torch gate order i, f, g, o)
+__device__ __forceinline__ void gates(const f32x4 (&acc)[4], f32x4 &c, f32x4 &h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]);
+        const float gg = tanh_f(acc[2][r]), og = sigmoid_f(acc[3][r]);
+        c[r] = fg * c[r] + ig * gg;
+        h[r] = og * tanh_f(c[r]);
+    }
+}
+
 template <int H>
 __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
     constexpr int NW = H / 16;   // waves
     constexpr int KS = H / 4;    // MFMA k-steps per operand
     constexpr int G = H / 16;    // 16-wide k groups
-    constexpr int RS = H + 4;    // padded LDS row
-    __shared__ __attribute__((aligned(16))) float xbuf[2][16][RS];
-    __shared__ __attribute__((aligned(16))) float hbuf[2][16][RS];
+    // LDS images are 4 planes (plane q = channels {16g+4q+j}), rows of H/4 floats padded so that
+    // rowstride/4 is odd, plane size a multiple of 64 floats: every 16-lane ds_read_b128 group
+    // hits 16 distinct bank slots (see k_conv.hip).
+    constexpr int RS = (G % 2 == 0) ? H / 4 + 4 : H / 4;
+    static_assert((16 * RS) % 64 == 0, "plane must be a multiple of 64 floats");
+    __shared__ __attribute__((aligned(16))) float xbuf[2][4][16][RS];
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4][16][RS];
     __shared__ float part[NW][16][16];
 
     const int tid = threadIdx.x;
@@ -68,6 +94,7 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
 
     // staging role of this thread: chunk row = tid / (H/4), 16-byte piece = tid % (H/4)
     const int st_row = tid / (H / 4), st_c4 = tid - st_row * (H / 4);
+    const int st_q = st_c4 & 3, st_g = st_c4 >> 2;  // float4 index 4g+q -> plane q, group g
 
     const int64_t n_groups = (a.n + 15) / 16;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -76,47 +103,63 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
         if (st_chunk >= a.n) st_chunk = a.n - 1;  // clamp ragged tail (results masked)
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.x + (size_t)st_chunk * a.T * H) + st_c4;
         __syncthreads();  // previous group's LDS traffic is done
-        *reinterpret_cast<float4 *>(&xbuf[0][st_row][4 * st_c4]) = xsrc[0];
+        *reinterpret_cast<float4 *>(&xbuf[0][st_q][st_row][4 * st_g]) = xsrc[0];
+        // second x tile (prefetch distance 2: x_{t+2} is fetched while step t runs)
+        *reinterpret_cast<float4 *>(&xbuf[1][st_q][st_row][4 * st_g]) = xsrc[(size_t)(a.T > 1 ? 1 : 0) * (H / 4)];
+        // h_{-1} = 0
+        *reinterpret_cast<float4 *>(&hbuf[1][st_q][st_row][4 * st_g]) = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 
+        // Software pipeline: the input projection of step t+1 (accN = b + W_ih x_{t+1}) does not
+        // depend on h_t, so its 4*KS MFMAs are issued in the same basic block as the gate
+        // non-linearities of step t and keep the matrix pipe busy while the VALU/transcendental
+        // work runs; only W_hh h_{t-1} (4*KS MFMAs) sits on the recurrent critical path.
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accN[4] = {bias[0], bias[1], bias[2], bias[3]};
+        xproj<KS, G, RS>(xbuf[0], q, nn, Aih, accN);
         for (int t = 0; t < a.T; ++t) {
-            float4 xnext;
-            const bool more = (t + 1 < a.T);
-            if (more) xnext = xsrc[(size_t)(t + 1) * (H / 4)];
-            f32x4 acc[4] = {bias[0], bias[1], bias[2], bias[3]};
-            const float *xb = &xbuf[t & 1][nn][4 * q];
+            // x_{t+2} (clamped: the last two fetches are redundant re-reads, never consumed)
+            const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
+            const float4 xnext = xsrc[(size_t)tf * (H / 4)];
+            f32x4 acc[4] = {accN[0], accN[1], accN[2], accN[3]};
+            f32x4 h;
+            // h_{-1} = 0 lives in hbuf[1] (zeroed above); the x projection issued in the last
+            // step reads a stale tile and its result is dropped: both keep the step body ONE
+            // basic block so that the scheduler can interleave MFMA and VALU streams.
+            // B fragments of x_{t+1} first (LDS latency hidden behind the recurrent MFMAs)
+            f32x4 bx[G];
+            {
+                const float *xb = &xbuf[(t + 1) & 1][q][nn][0];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 bx = *reinterpret_cast<const f32x4 *>(xb + 16 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int gt = 0; gt < 4; ++gt)
-                        acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aih[gt][g * 4 + j], bx[j], acc[gt], 0, 0, 0);
+                for (int g = 0; g < G; ++g) bx[g] = *reinterpret_cast<const f32x4 *>(xb + 4 * g);
             }
-            if (t > 0) {
-                const float *hb = &hbuf[(t - 1) & 1][nn][4 * q];
+            xproj<KS, G, RS>(hbuf[(t + 1) & 1], q, nn, Ahh, acc);   // recurrent critical path
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const f32x4 bh = *reinterpret_cast<const f32x4 *>(hb + 16 * g);
+            for (int gt = 0; gt < 4; ++gt) accN[gt] = bias[gt];
+            // 4*KS projection MFMAs of step t+1 interleaved with the gate math of step t:
+            // KS slices of {4 MFMAs (one k-step, 4 gates), 1/KS of the VALU/transcendental work},
+            // order pinned between slices so that the matrix pipe never waits for the VALU.
+            float ig[4], fg[4], gg[4], og[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < KS; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int gt = 0; gt < 4; ++gt)
-                            acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ahh[gt][g * 4 + j], bh[j], acc[gt], 0, 0, 0);
+                for (int gt = 0; gt < 4; ++gt)
+                    accN[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aih[gt][s], bx[s >> 2][s & 3], accN[gt], 0, 0, 0);
+                // gate work slice: 16 slices cover r = 0..3 x {i, f, g+c, o+h}
+                if (s * 16 / KS != (s + 1) * 16 / KS || KS >= 16) {
+                    for (int piece = s * 16 / KS; piece < (s + 1) * 16 / KS; ++piece) {
+                        const int r = piece >> 2, st = piece & 3;
+                        if (st == 0) ig[r] = sigmoid_f(acc[0][r]);
+                        if (st == 1) fg[r] = sigmoid_f(acc[1][r]);
+                        if (st == 2) { gg[r] = tanh_f(acc[2][r]); c[r] = fg[r] * c[r] + ig[r] * gg[r]; }
+                        if (st == 3) { og[r] = sigmoid_f(acc[3][r]); h[r] = og[r] * tanh_f(c[r]); }
+                    }
                 }
             }
-            f32x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]);
-                const float gg = tanh_f(acc[2][r]), og = sigmoid_f(acc[3][r]);
-                c[r] = fg * c[r] + ig * gg;
-                h[r] = og * tanh_f(c[r]);
-            }
-            *reinterpret_cast<f32x4 *>(&hbuf[t & 1][nn][16 * w + 4 * q]) = h;
-            if (more) *reinterpret_cast<float4 *>(&xbuf[(t + 1) & 1][st_row][4 * st_c4]) = xnext;
+            __builtin_amdgcn_sched_barrier(0);
+            *reinterpret_cast<f32x4 *>(&hbuf[t & 1][q][nn][4 * w]) = h;
+            *reinterpret_cast<float4 *>(&xbuf[t & 1][st_q][st_row][4 * st_g]) = xnext;
             __syncthreads();
         }
 
@@ -126,12 +169,12 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
         for (int gt = 0; gt < 3; ++gt)
             acc2[gt] = *reinterpret_cast<const f32x4 *>(a.b2 + gt * H + 16 * w + 4 * q);
         {
-            const float *hb = &hbuf[(a.T - 1) & 1][nn][4 * q];
+            const float *hb = &hbuf[(a.T - 1) & 1][q][nn][0];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                f32x4 z = *reinterpret_cast<const f32x4 *>(hb + 16 * g);
+                f32x4 z = *reinterpret_cast<const f32x4 *>(hb + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) z[j] = swish_l(z[j]);
+                for (int j = 0; j < 4; ++j) z[j] = swish_f(z[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -146,7 +189,7 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
         for (int r = 0; r < 4; ++r) {
             const float c2 = sigmoid_f(acc2[0][r]) * tanh_f(acc2[1][r]);
             const float h2 = sigmoid_f(acc2[2][r]) * tanh_f(c2);
-            y[r] = swish_l(h2);
+            y[r] = swish_f(h2);
         }
         // ---- fc: partial dot over this lane's 4 hidden units, reduce over q then waves ----
         for (int o = 0; o < a.num_out; ++o) {

@@ -43,7 +43,8 @@ enum KernelId {
     K_NORMALISE,
     K_GEOMETRY,
     K_FILL,
-    K_FRONT,
+    K_FRONT_SIG,
+    K_FRONT_SEQ,
     K_SEQ1_DENSE,
     K_CONV_SIG3,
     K_CONV_SEQ2,
@@ -123,7 +124,8 @@ struct FrontWeights {
     float *b_sig1 = nullptr;   // [4]
     float *w_sig2 = nullptr;   // [kw1][4 ic][16 oc]
     float *b_sig2 = nullptr;   // [16]
-    float *wt_seq1 = nullptr;  // [kw1][K][4 base][16 oc]  (one-hot gather table)
+    float *wt_seq1 = nullptr;  // [kw1][K][4 base][16 oc] == [kw1][EC][16] (dense seq_conv1)
+    float *wt5_seq1 = nullptr; // [kw1][K][5][16]: gather table, row 4 = zeros (missing base)
     float *b_seq1 = nullptr;   // [16]
 };
 
