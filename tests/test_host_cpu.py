@@ -1,0 +1,262 @@
+"""CPU-only tests: host-side logic against the golden vectors, the C-ABI library loads and
+exports every symbol include/remora_hip.h declares, the product path fails loudly without a
+GPU, the synthetic generators, and the world_size-2 (gloo) count reduction."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+
+# ---- C ABI ---------------------------------------------------------------------------------
+def _header_functions():
+    hdr = open(os.path.join(ROOT, "include", "remora_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(rmr_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+
+    from remora_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    names = _header_functions()
+    assert len(names) >= 20
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/remora_hip.h but not exported"
+    # and the ctypes binding covers exactly the header
+    assert sorted(_lib.SIGNATURES) == names
+    assert b"gfx950" in _lib.lib().rmr_version()
+
+
+def test_library_embeds_gfx950_code_object():
+    from remora_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"conv_mfma_kernel" in blob and b"lstm_head_kernel" in blob
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    """No CPU fallback: without a GPU every compute entry point raises RemoraError."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from remora_amd import RemoraError
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+    from remora_amd.io import parse_move_tag
+    from remora_amd.model_util import model_from_state
+    from remora_amd import synth
+
+    with pytest.raises(RemoraError, match="no GPU|no HIP device"):
+        compute_encoded_kmer_batch(4, 4, np.zeros((1, 28), np.int8), np.zeros((1, 21), np.int16), np.ones(1, np.int16))
+    with pytest.raises(RemoraError):
+        parse_move_tag([5, 1, 0, 1], 15)
+    with pytest.raises(RemoraError):
+        model_from_state(synth.synth_state(), dict(chunk_context=(50, 50)))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "remora_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "libremora_oracle" not in src, f
+
+
+# ---- host logic vs golden ----------------------------------------------------------------------
+def test_util_seq_motif_golden():
+    from remora_amd import util
+
+    g = golden("seq_motif.npz")
+    for si in range(int(g["num_seqs"])):
+        s = str(g[f"s{si}_str"])
+        int_seq = util.seq_to_int(s)
+        assert np.array_equal(int_seq, g[f"s{si}_int"])
+        assert util.int_to_seq(int_seq) == s.replace("N", "N")
+        for mi in range(int(g["num_motif_sets"])):
+            if int(g[f"s{si}_m{mi}_skipped"]):
+                continue
+            motifs = [util.Motif(str(a), int(b)) for a, b in zip(g[f"m{mi}_seqs"], g[f"m{mi}_offs"])]
+            fb = util.find_focus_bases_in_int_sequence(int_seq, motifs)
+            assert np.array_equal(fb, g[f"s{si}_m{mi}_focus"]), (si, mi)
+    for mi in range(int(g["num_motif_sets"])):
+        for raw, off, nraw, noff in zip(g[f"m{mi}_seqs"], g[f"m{mi}_offs"], g[f"m{mi}_norm_seqs"], g[f"m{mi}_norm_offs"]):
+            m = util.Motif(str(raw), int(off))
+            assert m.to_tuple() == (str(nraw), int(noff))
+
+
+def test_motif_errors_and_match():
+    from remora_amd import RemoraError, util
+
+    with pytest.raises(RemoraError):
+        util.Motif("CX", 0)
+    with pytest.raises(RemoraError):
+        util.Motif("CG", 2)
+    with pytest.raises(RemoraError):
+        util.Motif("CG", "a")
+    m = util.Motif("CG", 0)
+    seq = util.seq_to_int("ACGTCG")
+    assert m.match(seq, 1) and m.match(seq, 4) and not m.match(seq, 0) and not m.match(seq, 5)
+    assert list(m.findall(seq)) == [1, 4]
+    assert m.focus_base == "C" and m.num_bases_after_focus == 1
+
+
+def test_post_process_golden():
+    from remora_amd import util
+
+    g = golden("post_process.npz")
+    assert np.allclose(util.softmax_axis1(g["softmax_in"]), g["softmax_out"], rtol=0, atol=1e-7)
+    mm, ml = util.format_mm_ml_tags(str(g["tags_seq"]), g["tags_poss"], g["tags_probs"], ["h", "m"], "C")
+    assert mm == str(g["tags_mm"])
+    assert np.array_equal(np.asarray(list(ml), np.uint8), g["tags_ml"])
+    assert util.format_mm_ml_tags("ACGT", np.array([], int), np.zeros((0, 1)), ["m"], "C")[0] == ""
+
+
+@pytest.mark.parametrize("name", ["cg_5mc", "allc_5hmc_5mc", "conv_cg"])
+def test_add_derived_metadata_golden(name):
+    from remora_amd.model_util import add_derived_metadata
+
+    g = golden(f"call_read_mods_{name}.npz")
+    md = json.loads(str(g["meta_txt"]))
+    add_derived_metadata(md)
+    ref = json.loads(str(g["derived_md_json"]))
+    for k, v in ref.items():
+        assert json.loads(json.dumps(md[k])) == v, k
+    assert md["sig_map_refiner"].is_loaded is False
+    assert not any(k.startswith("refine_") for k in md)
+
+
+def test_state_to_blob_layout_matches_engine_count():
+    import ctypes
+
+    from remora_amd import _lib as L
+    from remora_amd import synth
+    from remora_amd.engine import detect_arch, state_to_blob
+
+    for arch, size, K, no in (("conv_lstm", 64, 9, 2), ("conv_lstm", 16, 6, 4), ("conv_only", 64, 9, 3), ("conv_only", 32, 9, 2)):
+        st = synth.synth_state(arch, size, K, no)
+        a, s, k, n, blob = state_to_blob(st)
+        assert (a, s, k, n) == (arch, size, K, no)
+        desc = L.ModelDesc(0 if arch == "conv_lstm" else 1, size, K, no, 100, 0)
+        assert L.lib().rmr_model_weight_count(ctypes.byref(desc)) == blob.size
+    bad = L.ModelDesc(0, 48, 9, 2, 100, 0)
+    assert L.lib().rmr_model_weight_count(ctypes.byref(bad)) == 0
+    from remora_amd import RemoraError
+
+    with pytest.raises(RemoraError):
+        detect_arch({"sig_conv1", "fc"})
+
+
+def test_remora_read_host_semantics():
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import RemoraRead
+
+    r = RemoraRead.test_read()
+    assert r.str_seq == "ACGT" * 5 and r.seq_to_sig_map[-1] == 200
+    r.check()
+    with pytest.raises(RemoraError):
+        RemoraRead(np.zeros(10), 0.0, 1.0, np.arange(4))
+    bad = RemoraRead(np.zeros(10), 0.0, 1.0, np.array([0, 5, 9]), int_seq=np.array([0, 1]))
+    with pytest.raises(RemoraError, match="mapping end"):
+        bad.check()
+    r2 = r.copy()
+    assert r2 is not r and np.array_equal(r2.int_seq, r.int_seq)
+    from remora_amd.util import Motif
+
+    r.set_motif_focus_bases([Motif("CG", 0)])
+    assert sorted(r.focus_bases) == [1, 5, 9, 13, 17]
+
+
+# ---- synthetic generators -------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", ["C100", "C200"])
+def test_synth_chunks_are_valid_dataset_rows(cfg):
+    from oracle import oracle as O
+    from remora_amd import synth
+
+    d = synth.synth_chunks_config(cfg, 3000, shard=1)
+    cc, kcb, msl, num_out, cg = synth.CONFIGS[cfg]
+    L = sum(cc)
+    m, l, s = d["sequence_to_signal_mapping"], d["sequence_lengths"], d["sequence"]
+    assert m.dtype == np.int16 and s.dtype == np.int8 and l.dtype == np.int16 and d["signal"].dtype == np.float32
+    assert m.shape == (3000, msl + 1) and s.shape == (3000, msl + 8) and d["signal"].shape == (3000, 1, L)
+    for c in range(3000):
+        row = m[c, : l[c] + 1]
+        assert row[0] == 0 and row[-1] == L and np.all(np.diff(row) > 0)
+        assert np.all(m[c, l[c] + 1:] == 0) and np.all(s[c, l[c] + 8:] == -1) and np.all(s[c, : l[c] + 8] >= 0)
+        p = np.searchsorted(row, L // 2, side="right") - 1
+        assert s[c, 4 + p] == 1 and (not cg or s[c, 4 + p + 1] == 2)
+    enc = O.compute_encoded_kmer_batch(*kcb, s, m, l)
+    assert np.all(enc.sum(axis=(1, 2)) == 9 * L)
+    d2 = synth.synth_chunks_config(cfg, 3000, shard=1)
+    assert all(np.array_equal(d[k], d2[k]) for k in ("signal", "sequence", "sequence_lengths"))
+    d3 = synth.synth_chunks_config(cfg, 3000, shard=2)
+    assert not np.array_equal(d["signal"], d3["signal"])
+
+
+def test_synth_state_loads_into_reference_shaped_module():
+    from oracle import torch_ref
+    from remora_amd import synth
+
+    for arch in ("conv_lstm", "conv_only"):
+        net = torch_ref.from_state(synth.synth_state(arch, 64, 9, 3))
+        assert sum(p.numel() for p in net.parameters()) > 100000
+
+
+# ---- multi-GPU layer on CPU (gloo, world size 2) -------------------------------------------------------
+def test_shard_range_partitions_exactly():
+    from remora_amd.dist import shard_range
+
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+from remora_amd import dist as rdist
+rank, world, local = rdist.init_process_group("gloo")
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "post_process.npz"))
+logits = g["tally_logits"]
+lo, hi = rdist.shard_range(logits.shape[0], rank, world)
+pred = logits[lo:hi].argmax(1)               # np.argmax: first maximum, as validate.py:42-45
+counts = np.bincount(pred, minlength=3).astype(np.int64)
+total = rdist.allreduce_counts(counts.copy())
+t = torch.from_numpy(counts.copy())
+total_t = rdist.allreduce_counts(t)
+mx = rdist.allreduce_max_float(float(rank + 1))
+if rank == 0:
+    print(json.dumps({"total": total.tolist(), "total_t": total_t.tolist(), "max": mx, "n": [int(lo), int(hi)]}))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_count_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731", str(script), ROOT]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    g = golden("post_process.npz")
+    assert res["total"] == g["tally_pred_counts"].tolist() == res["total_t"]
+    assert res["max"] == 2.0 and res["n"] == [0, 500]
