@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=1_000_000, help="chunks per GPU per step")
     ap.add_argument("--subbatch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -168,12 +169,25 @@ def main():
     eng = get_engine(local)
     if args.subbatch:
         eng.set_subbatch(args.subbatch)
-    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=local)
+    md = dict(chunk_context=cc, kmer_context_bases=kcb)
+    model = model_from_state(state, md, device=local)
 
     n = args.chunks
     data = synth.synth_chunks_config(cfg, n, shard=rank)
     dev = [torch.from_numpy(data[k]).cuda(local) for k in
            ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+    # centre the class logits on a sample (random weights otherwise call one class for every
+    # chunk): shift fc.bias by the per-class median, identically on every rank and for the CPU leg
+    probe = model.infer_chunks(*[t[:8192] for t in dev], kcb).cpu().numpy() if rank == 0 else None
+    shift = torch.zeros(num_out, dtype=torch.float64)
+    if rank == 0:
+        shift = torch.from_numpy(np.median(probe, axis=0).astype(np.float64))
+    if world > 1:
+        shift = shift.cuda(local)
+        torch.distributed.broadcast(shift, src=0)
+        shift = shift.cpu()
+    state["fc.bias"] = (state["fc.bias"].astype(np.float64) - shift.numpy()).astype(np.float32)
+    model = model_from_state(state, md, device=local)
     counts = torch.zeros(num_out, dtype=torch.int64, device=f"cuda:{local}")
 
     def step():
@@ -202,6 +216,28 @@ def main():
 
     total_chunks = n * world * args.steps
     value = total_chunks / elapsed
+
+    # ---- E1 standalone (materialised one-hot): HBM-write roofline, outside the timed region ----
+    enc_roof = None
+    if rank == 0 and not args.no_encode:
+        from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+
+        blk = min(n, 250_000)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        for rep in range(3):
+            enc = compute_encoded_kmer_batch(kcb[0], kcb[1], dev[1][:blk], dev[2][:blk], dev[3][:blk])
+        torch.cuda.synchronize()
+        eng.profile_enable(False)
+        ms, launches = eng.profile()["encode_kmers"]
+        K = sum(kcb) + 1
+        bytes_per_chunk = dev[1].shape[1] + 2 * dev[2].shape[1] + 2 + 4 * 4 * K * L
+        gbs = bytes_per_chunk * blk * launches / (ms * 1e-3) / 1e9
+        assert float(enc[:4096].sum()) == 4096 * K * L
+        enc_roof = {"kernel": "encode_kmers", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": gbs / PEAK_HBM_GBS, "bytes_per_chunk": bytes_per_chunk, "chunks_per_launch": blk,
+                    "avg_launch_ms": ms / launches, "chunks_per_s": blk * launches / (ms * 1e-3)}
+        del enc
     if rank != 0:
         return
     assert int(counts.sum().item()) == total_chunks, "label counts do not add up"
@@ -236,6 +272,7 @@ def main():
                            "frac_of_fp32_mfma_peak": total_flops * total_chunks / world / (gpu_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                            "kernel_ms_sum": gpu_ms, "wall_ms": elapsed * 1e3},
         "kernels": kern,
+        "encode_roofline": enc_roof,
         "label_counts": [int(x) for x in counts.tolist()],
     }
     if world == 1 and not args.no_cpu_baseline:

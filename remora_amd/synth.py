@@ -80,7 +80,10 @@ def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0):
 
     def conv(name, bn, ic, oc, k):
         b = 1.0 / np.sqrt(ic * k)
-        st[f"{name}.weight"] = rng.uniform(-b, b, (oc, ic, k)).astype(np.float32)
+        # He-scale weights (x2.45 torch's default bound) so that input variation survives to the
+        # logits: with the default bound the random BN offsets swamp the signal and every chunk
+        # gets nearly the same logits, which would make parity tests blind to early-layer bugs
+        st[f"{name}.weight"] = rng.uniform(-2.45 * b, 2.45 * b, (oc, ic, k)).astype(np.float32)
         st[f"{name}.bias"] = rng.uniform(-b, b, oc).astype(np.float32)
         st[f"{bn}.weight"] = (1.0 + 0.2 * rng.standard_normal(oc)).astype(np.float32)
         st[f"{bn}.bias"] = (0.2 * rng.standard_normal(oc)).astype(np.float32)
@@ -98,6 +101,7 @@ def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0):
             st[f"{l}.weight_ih_l0"] = rng.uniform(-2.5 * b, 2.5 * b, (4 * size, size)).astype(np.float32)
             st[f"{l}.weight_hh_l0"] = rng.uniform(-2.5 * b, 2.5 * b, (4 * size, size)).astype(np.float32)
             st[f"{l}.bias_ih_l0"] = rng.uniform(-b, b, 4 * size).astype(np.float32)
+            st[f"{l}.bias_ih_l0"][size : 2 * size] += 2.0  # forget-gate bias: longer memory, as in trained LSTMs
             st[f"{l}.bias_hh_l0"] = rng.uniform(-b, b, 4 * size).astype(np.float32)
         fin = size
     else:
@@ -108,7 +112,7 @@ def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0):
         conv("merge_conv1", "merge_bn1", 2 * size, size, 5); conv("merge_conv2", "merge_bn2", size, size, 5)
         conv("merge_conv3", "merge_bn3", size, size, 3); conv("merge_conv4", "merge_bn4", size, size, 3)
         fin = size * 3
-    b = 6.0 / np.sqrt(fin)
+    b = (12.0 if arch == "conv_lstm" else 1.5) / np.sqrt(fin)  # logits within a few units
     st["fc.weight"] = rng.uniform(-b, b, (num_out, fin)).astype(np.float32)
     st["fc.bias"] = rng.uniform(-b, b, num_out).astype(np.float32)
     return st

@@ -144,7 +144,12 @@ def make_net(R, arch, size, kmer_len, num_out, seed):
             if pname.startswith("lstm") and "weight" in pname:
                 p.mul_(2.5)
             if pname.startswith("fc."):
-                p.mul_(6.0)
+                p.mul_(12.0 if hasattr(net, "lstm1") else 1.5)  # keep logits within a few units
+            if pname.startswith("lstm") and pname.endswith("bias_ih_l0"):
+                n4 = p.shape[0] // 4
+                p[n4 : 2 * n4] += 2.0  # forget-gate bias: longer memory, as in trained LSTMs
+            if "conv" in pname and pname.endswith("weight"):
+                p.mul_(2.45)  # He-scale: keeps the logits sensitive to the inputs
     net.eval()
     return net
 

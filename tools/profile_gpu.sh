@@ -6,7 +6,7 @@ TAG=${1:-r1}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-encode $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- $BENCH > $OUT/bench_$C.json 2> $OUT/pmc_$C.err
