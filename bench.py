@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--force-device", type=int, default=None, help="testing: put every rank on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -157,7 +159,9 @@ def main():
     from remora_amd.engine import get_engine
     from remora_amd.model_util import model_from_state
 
-    rank, world, local = rdist.init_process_group()
+    rank, world, local = rdist.init_process_group(args.dist_backend, set_device=args.force_device is None)
+    if args.force_device is not None:
+        local = args.force_device
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -183,7 +187,8 @@ def main():
     if rank == 0:
         shift = torch.from_numpy(np.median(probe, axis=0).astype(np.float64))
     if world > 1:
-        shift = shift.cuda(local)
+        on_gpu = torch.distributed.get_backend() == "nccl"
+        shift = shift.cuda(local) if on_gpu else shift
         torch.distributed.broadcast(shift, src=0)
         shift = shift.cpu()
     state["fc.bias"] = (state["fc.bias"].astype(np.float64) - shift.numpy()).astype(np.float32)

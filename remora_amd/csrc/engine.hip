@@ -255,8 +255,15 @@ int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
     return 0;
 }
 
+// gate pre-scale used by lstm_step (k_lstm.hip): sigmoid(x) = 1/(1+2^(-x log2 e)) for i,f,o;
+// tanh(x) = 1 - 2/(1+2^(2x log2 e)) for g.  torch gate order i,f,g,o.
+static inline double lstm1_gate_scale(int gate) {
+    const double log2e = 1.4426950408889634;
+    return gate == 2 ? 2.0 * log2e : -log2e;
+}
+
 // [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
-std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates) {
+std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates, bool prescale = false) {
     const int KS = H / 4, G = H / 16, W = H / 16;
     std::vector<float> ap((size_t)W * ngates * KS * 64);
     for (int wv = 0; wv < W; ++wv)
@@ -266,7 +273,8 @@ std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates
                     for (int lane = 0; lane < 64; ++lane) {
                         const int q = lane >> 4, mm = lane & 15;
                         const int row = gates[gi] * H + 16 * wv + mm, k = 16 * g + 4 * q + j;
-                        ap[(((size_t)wv * ngates + gi) * KS + g * 4 + j) * 64 + lane] = w[(size_t)row * H + k];
+                        const double sc = prescale ? lstm1_gate_scale(gates[gi]) : 1.0;
+                        ap[(((size_t)wv * ngates + gi) * KS + g * 4 + j) * 64 + lane] = (float)((double)w[(size_t)row * H + k] * sc);
                     }
     return ap;
 }
@@ -387,11 +395,12 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
         const float *wfc = p; p += (size_t)desc->num_out * H;
         const float *bfc = p; p += desc->num_out;
         const int g4[4] = {0, 1, 2, 3}, g3[3] = {0, 2, 3};
-        RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4), &m->lstm.a_ih1));
-        RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4), &m->lstm.a_hh1));
+        RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4, true), &m->lstm.a_ih1));
+        RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4, true), &m->lstm.a_hh1));
         RMR_TRY(upload(m.get(), pack_lstm(wih2, H, g3, 3), &m->lstm.a_ih2));
         std::vector<float> b1(4 * H), b2(3 * H);
-        for (int i = 0; i < 4 * H; ++i) b1[i] = bih1[i] + bhh1[i];
+        for (int i = 0; i < 4 * H; ++i)
+            b1[i] = (float)(((double)bih1[i] + (double)bhh1[i]) * lstm1_gate_scale(i / H));
         for (int gi = 0; gi < 3; ++gi)
             for (int u = 0; u < H; ++u) b2[gi * H + u] = bih2[g3[gi] * H + u] + bhh2[g3[gi] * H + u];
         RMR_TRY(upload(m.get(), b1, &m->lstm.b1));
@@ -439,7 +448,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
     const size_t per = act_floats_per_chunk(m);
-    int64_t sb = e->subbatch > 0 ? e->subbatch : 16384;
+    int64_t sb = e->subbatch > 0 ? e->subbatch : 65536;
     if (sb > n) sb = n;
     RMR_TRY(e->ensure(e->act, per * sb * sizeof(float)));
     const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;

@@ -30,6 +30,7 @@ struct LstmArgs {
     const float *a_ih1, *a_hh1, *b1, *a_ih2, *b2, *w_fc, *b_fc;
     int64_t n;
     int T, num_out;
+    int skew;  // s_sleep iterations for the second half of the grid (de-phases co-resident blocks)
 };
 
 // acc[gt] += A[gt][:] (register-resident weight slice) x B fragments read from one LDS image
@@ -59,8 +60,67 @@ __device__ __forceinline__ void gates(const f32x4 (&acc)[4], f32x4 &c, f32x4 &h)
     }
 }
 
-template <int H>
-__global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
+// One LSTM step for this wave's 16 hidden units x 16 chunks.
+//   acc  = accN (bias + W_ih x_t, computed during the previous step) [+ W_hh h_{t-1} if HAS_H]
+//   accN = bias + W_ih x_{t+1}   [if HAS_X]   -- independent of h_t
+// The fp32 MFMA shares the SIMD's fp32 datapath with ordinary VALU work (ablation: removing
+// the gate transcendentals raised the kernel from 114 to 134 TFLOP/s), so the gate math is
+// kept minimal: the i/f/o rows of W and b are pre-scaled by -log2(e) and the g rows by
+// 2 log2(e) on the host (engine.hip), making sigmoid = rcp(1 + exp2(a)) and
+// tanh = 1 - 2 rcp(1 + exp2(a)) three/four instructions each.  The projection MFMAs of step
+// t+1 are sliced between the gate slices so that MFMA issue never waits for a long
+// dependent VALU chain.
+template <int H, bool HAS_H, bool HAS_X, int ABL>
+__device__ __forceinline__ void lstm_step(const float (&xb_img)[4][16][(H / 16 % 2 == 0) ? H / 4 + 4 : H / 4],
+                                          const float (&hb_img)[4][16][(H / 16 % 2 == 0) ? H / 4 + 4 : H / 4],
+                                          int q, int nn, const float (&Aih)[4][H / 4], const float (&Ahh)[4][H / 4],
+                                          const f32x4 (&bias)[4], f32x4 (&accN)[4], f32x4 &c, f32x4 &h) {
+    constexpr int KS = H / 4, G = H / 16;
+    constexpr int RS = (G % 2 == 0) ? H / 4 + 4 : H / 4;
+    f32x4 acc[4] = {accN[0], accN[1], accN[2], accN[3]};
+    f32x4 bx[G];
+    if (HAS_X) {  // B fragments of x_{t+1} first (LDS latency hidden behind the recurrent MFMAs)
+        const float *xb = &xb_img[q][nn][0];
+#pragma unroll
+        for (int g = 0; g < G; ++g) bx[g] = *reinterpret_cast<const f32x4 *>(xb + 4 * g);
+    }
+    if (HAS_H) xproj<KS, G, RS>(hb_img, q, nn, Ahh, acc);  // recurrent critical path
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) accN[gt] = bias[gt];
+    float ig[4], fg[4], gg[4];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (HAS_X) {
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+                accN[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aih[gt][s], bx[s >> 2][s & 3], accN[gt], 0, 0, 0);
+        }
+        // gate work: 16 pieces (r = 0..3 x {i, f, g + c, o + h}) spread over the KS slices
+        for (int piece = s * 16 / KS; piece < (s + 1) * 16 / KS; ++piece) {
+            const int r = piece >> 2, st = piece & 3;
+            if (ABL & 1) {  // timing ablation: no transcendental work
+                if (st == 3) { c[r] += acc[0][r] * acc[1][r]; h[r] = acc[2][r] + acc[3][r] * c[r]; }
+                continue;
+            }
+            // acc rows are pre-scaled: i,f,o by -log2(e); g by 2 log2(e)
+            if (st == 0) ig[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
+            if (st == 1) fg[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
+            if (st == 2) {
+                gg[r] = fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[2][r])), 1.0f);
+                c[r] = fmaf(fg[r], c[r], ig[r] * gg[r]);
+            }
+            if (st == 3) {
+                const float og = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
+                h[r] = og * tanh_f(c[r]);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int H, int ABL = 0>
+__global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
     constexpr int NW = H / 16;   // waves
     constexpr int KS = H / 4;    // MFMA k-steps per operand
     constexpr int G = H / 16;    // 16-wide k groups
@@ -96,6 +156,12 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
     const int st_row = tid / (H / 4), st_c4 = tid - st_row * (H / 4);
     const int st_q = st_c4 & 3, st_g = st_c4 >> 2;  // float4 index 4g+q -> plane q, group g
 
+    // Co-resident blocks start together and take identical time per group, so their load /
+    // epilogue phases would coincide for the whole launch; a one-off delay of every other
+    // block keeps one block's matrix work under the other's latency-bound phases.
+    if (blockIdx.x >= (gridDim.x + 1) / 2)
+        for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
+
     const int64_t n_groups = (a.n + 15) / 16;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t chunk0 = grp * 16;
@@ -106,8 +172,6 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
         *reinterpret_cast<float4 *>(&xbuf[0][st_q][st_row][4 * st_g]) = xsrc[0];
         // second x tile (prefetch distance 2: x_{t+2} is fetched while step t runs)
         *reinterpret_cast<float4 *>(&xbuf[1][st_q][st_row][4 * st_g]) = xsrc[(size_t)(a.T > 1 ? 1 : 0) * (H / 4)];
-        // h_{-1} = 0
-        *reinterpret_cast<float4 *>(&hbuf[1][st_q][st_row][4 * st_g]) = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 
         // Software pipeline: the input projection of step t+1 (accN = b + W_ih x_{t+1}) does not
@@ -121,46 +185,16 @@ __global__ __launch_bounds__(4 * H) void lstm_head_kernel(LstmArgs a) {
             // x_{t+2} (clamped: the last two fetches are redundant re-reads, never consumed)
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
             const float4 xnext = xsrc[(size_t)tf * (H / 4)];
-            f32x4 acc[4] = {accN[0], accN[1], accN[2], accN[3]};
             f32x4 h;
-            // h_{-1} = 0 lives in hbuf[1] (zeroed above); the x projection issued in the last
-            // step reads a stale tile and its result is dropped: both keep the step body ONE
-            // basic block so that the scheduler can interleave MFMA and VALU streams.
-            // B fragments of x_{t+1} first (LDS latency hidden behind the recurrent MFMAs)
-            f32x4 bx[G];
-            {
-                const float *xb = &xbuf[(t + 1) & 1][q][nn][0];
-#pragma unroll
-                for (int g = 0; g < G; ++g) bx[g] = *reinterpret_cast<const f32x4 *>(xb + 4 * g);
-            }
-            xproj<KS, G, RS>(hbuf[(t + 1) & 1], q, nn, Ahh, acc);   // recurrent critical path
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) accN[gt] = bias[gt];
-            // 4*KS projection MFMAs of step t+1 interleaved with the gate math of step t:
-            // KS slices of {4 MFMAs (one k-step, 4 gates), 1/KS of the VALU/transcendental work},
-            // order pinned between slices so that the matrix pipe never waits for the VALU.
-            float ig[4], fg[4], gg[4], og[4];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-                    accN[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aih[gt][s], bx[s >> 2][s & 3], accN[gt], 0, 0, 0);
-                // gate work slice: 16 slices cover r = 0..3 x {i, f, g+c, o+h}
-                if (s * 16 / KS != (s + 1) * 16 / KS || KS >= 16) {
-                    for (int piece = s * 16 / KS; piece < (s + 1) * 16 / KS; ++piece) {
-                        const int r = piece >> 2, st = piece & 3;
-                        if (st == 0) ig[r] = sigmoid_f(acc[0][r]);
-                        if (st == 1) fg[r] = sigmoid_f(acc[1][r]);
-                        if (st == 2) { gg[r] = tanh_f(acc[2][r]); c[r] = fg[r] * c[r] + ig[r] * gg[r]; }
-                        if (st == 3) { og[r] = sigmoid_f(acc[3][r]); h[r] = og[r] * tanh_f(c[r]); }
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            if (t == 0)
+                lstm_step<H, false, true, ABL>(xbuf[1], hbuf[1], q, nn, Aih, Ahh, bias, accN, c, h);
+            else if (t + 1 < a.T)
+                lstm_step<H, true, true, ABL>(xbuf[(t + 1) & 1], hbuf[(t + 1) & 1], q, nn, Aih, Ahh, bias, accN, c, h);
+            else
+                lstm_step<H, true, false, ABL>(xbuf[(t + 1) & 1], hbuf[(t + 1) & 1], q, nn, Aih, Ahh, bias, accN, c, h);
             *reinterpret_cast<f32x4 *>(&hbuf[t & 1][q][nn][4 * w]) = h;
             *reinterpret_cast<float4 *>(&xbuf[t & 1][st_q][st_row][4 * st_g]) = xnext;
-            __syncthreads();
+            if (!(ABL & 2)) __syncthreads();  // ABL&2: timing ablation without the per-step barrier
         }
 
         // ---- lstm2: one step on swish(h1[T-1]), gates i, g, o only (c0 = 0 kills f) ----
@@ -219,12 +253,18 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
     a.x = x; a.logits = logits; a.n = n; a.T = m->T; a.num_out = m->desc.num_out;
     a.a_ih1 = m->lstm.a_ih1; a.a_hh1 = m->lstm.a_hh1; a.b1 = m->lstm.b1;
     a.a_ih2 = m->lstm.a_ih2; a.b2 = m->lstm.b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
+    a.skew = tune_int("RMR_LSTM_SKEW", 0);
     const int64_t groups = (n + 15) / 16;
-    int64_t grid = (int64_t)e->num_cus * 2;
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTM_BLOCKS_PER_CU", 2);
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);
-    hipLaunchKernelGGL(lstm_head_kernel<H>, dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    const int abl = tune_int("RMR_LSTM_ABLATE", 0);  // timing experiments only (results are wrong)
+    if (abl == 1) hipLaunchKernelGGL((lstm_head_kernel<H, 1>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    else if (abl == 2) hipLaunchKernelGGL((lstm_head_kernel<H, 2>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    else if (abl == 3) hipLaunchKernelGGL((lstm_head_kernel<H, 3>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    else
+    hipLaunchKernelGGL((lstm_head_kernel<H, 0>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -179,6 +180,12 @@ int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, 
                 float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits);
+
+// integer tuning knob from the environment (read once per call site; for experiments only)
+inline int tune_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 // fast integer division by a small runtime constant (exact for 0 <= x < 2^24, d < 2^12)
 struct FastDiv {

@@ -20,7 +20,7 @@ def shard_range(n, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, set_device=True):
     """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
     import torch
     import torch.distributed as dist
@@ -32,7 +32,7 @@ def init_process_group(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -52,6 +52,11 @@ def allreduce_counts(counts):
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.cpu().numpy()
+    if counts.is_cuda and dist.get_backend() != "nccl":  # gloo (tests): reduce through the host
+        t = counts.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        counts.copy_(t)
+        return counts
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
 
