@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--workload", default="convlstm_c100", choices=sorted(WORKLOADS))
     ap.add_argument("--chunks", type=int, default=1_000_000, help="chunks per GPU per step")
     ap.add_argument("--subbatch", type=int, default=0)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16x6", "bf16x3", "bf16"],
+                    help="GEMM arithmetic: fp32 MFMA (default) or bf16 MFMA with split operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -174,7 +176,7 @@ def main():
     if args.subbatch:
         eng.set_subbatch(args.subbatch)
     md = dict(chunk_context=cc, kmer_context_bases=kcb)
-    model = model_from_state(state, md, device=local)
+    model = model_from_state(state, md, device=local, dtype=args.dtype)
 
     n = args.chunks
     data = synth.synth_chunks_config(cfg, n, shard=rank)
@@ -192,7 +194,7 @@ def main():
         torch.distributed.broadcast(shift, src=0)
         shift = shift.cpu()
     state["fc.bias"] = (state["fc.bias"].astype(np.float64) - shift.numpy()).astype(np.float32)
-    model = model_from_state(state, md, device=local)
+    model = model_from_state(state, md, device=local, dtype=args.dtype)
     counts = torch.zeros(num_out, dtype=torch.int64, device=f"cuda:{local}")
 
     def step():
@@ -268,7 +270,7 @@ def main():
         "metric": "chunks/sec, 5mC CG ConvLSTM_w_ref inference (fused chunk arrays -> logits + label counts)",
         "value": value, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32"}.get(args.dtype, args.dtype), "data": "synthetic",
         "config": {"workload": desc, "chunks_per_gpu_per_step": n, "chunk_len": L, "kmer_context_bases": list(kcb),
                    "num_out": num_out, "sharding": f"chunks sharded over {world} GPU(s), 1 count all-reduce"},
         "reads_per_sec": value / 312.0,

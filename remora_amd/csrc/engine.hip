@@ -192,12 +192,50 @@ std::vector<ConvSpec> conv_specs(const rmr_model_desc &d) {
             {32, sz, 9, 3}, {2 * sz, sz, 5, 1}, {sz, sz, 5, 1}, {sz, sz, 3, 2}, {sz, sz, 3, 2}};
 }
 
+// ---- split-bf16 helpers (host twins of split_parts/pack2 in k_lstm_bf16s.hip) -------------
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+static inline uint32_t rne_bf16(uint32_t b) { return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u; }
+static void split_parts_host(float x, int np, uint32_t *p) {
+    if (np == 1) { p[0] = rne_bf16(f2u(x)); return; }
+    float r = x;
+    for (int i = 0; i < np; ++i) {
+        const uint32_t b = f2u(r);
+        p[i] = (i + 1 < np || np == 3) ? (b & 0xffff0000u) : rne_bf16(b);
+        r -= u2f(p[i]);
+    }
+}
+
+// [rows][K] row-major fp32 (row = gates[gi]*H + 16*wv + m) -> bf16x8 A fragments
+// [H/16 waves][ngates][K/32][np][64 lanes][4 dwords]; lane (q, m) holds k = 32ks + 8q + j
+std::vector<float> pack_split_a(const std::vector<float> &w, int K, int nw, const int *rowbase, int ngates, int np) {
+    const int KS32 = K / 32;
+    std::vector<uint32_t> out((size_t)nw * ngates * KS32 * np * 64 * 4);
+    for (int wv = 0; wv < nw; ++wv)
+        for (int gi = 0; gi < ngates; ++gi)
+            for (int ks = 0; ks < KS32; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, mm = lane & 15;
+                    const int row = rowbase[gi] + 16 * wv + mm;
+                    uint32_t parts[8][3];
+                    for (int j = 0; j < 8; ++j) split_parts_host(w[(size_t)row * K + 32 * ks + 8 * q + j], np, parts[j]);
+                    for (int p = 0; p < np; ++p)
+                        for (int i = 0; i < 4; ++i)
+                            out[(((((size_t)wv * ngates + gi) * KS32 + ks) * np + p) * 64 + lane) * 4 + i] =
+                                (parts[2 * i][p] >> 16) | parts[2 * i + 1][p];
+                }
+    std::vector<float> f(out.size());
+    memcpy(f.data(), out.data(), out.size() * 4);
+    return f;
+}
+
 bool desc_ok(const rmr_model_desc &d) {
     if (d.arch != RMR_ARCH_CONV_LSTM && d.arch != RMR_ARCH_CONV_ONLY) return false;
     if (d.size != 16 && d.size != 32 && d.size != 64) return false;
     if (d.kmer_len < 1 || d.kmer_len > 64) return false;
     if (d.num_out < 1 || d.num_out > 16) return false;
-    if (d.dtype != 0) return false;
+    if (d.dtype < 0 || d.dtype > 3) return false;
+    if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || d.size % 32)) return false;
     return true;
 }
 
@@ -262,6 +300,37 @@ static inline double lstm1_gate_scale(int gate) {
     return gate == 2 ? 2.0 * log2e : -log2e;
 }
 
+// conv weights -> split-bf16 A fragments [oc/16][steps][np][64 lanes][4 dwords]
+// (k-slot mapping documented at the top of k_conv_bf16s.hip)
+int pack_conv_split(rmr_model *m, const Folded &f, int np, ConvLayer *out) {
+    const ConvSpec &s = f.s;
+    const bool pair = (s.ic == 16);
+    if (!pair && s.ic % 32) RMR_FAIL(RMR_ERR_INVALID, "split conv needs ic 16 or a multiple of 32 (got %d)", s.ic);
+    const int KS = pair ? 1 : s.ic / 32;
+    const int steps = pair ? (s.kw + 1) / 2 : s.kw * KS;
+    const int W = s.oc / 16;
+    std::vector<uint32_t> o((size_t)W * steps * np * 64 * 4);
+    for (int w = 0; w < W; ++w)
+        for (int st = 0; st < steps; ++st)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane >> 4, oc = 16 * w + (lane & 15);
+                uint32_t parts[8][3];
+                for (int j = 0; j < 8; ++j) {
+                    int tap, ch;
+                    if (pair) { tap = 2 * st + (q >> 1); ch = 8 * (q & 1) + j; }
+                    else { tap = st / KS; ch = 32 * (st % KS) + 8 * q + j; }
+                    const float v = tap < s.kw ? f.w[((size_t)oc * s.ic + ch) * s.kw + tap] : 0.0f;
+                    split_parts_host(v, np, parts[j]);
+                }
+                for (int p = 0; p < np; ++p)
+                    for (int i = 0; i < 4; ++i)
+                        o[((((size_t)w * steps + st) * np + p) * 64 + lane) * 4 + i] = (parts[2 * i][p] >> 16) | parts[2 * i + 1][p];
+            }
+    std::vector<float> fl(o.size());
+    memcpy(fl.data(), o.data(), o.size() * 4);
+    return upload(m, fl, &out->spack);
+}
+
 // [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
 std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates, bool prescale = false) {
     const int KS = H / 4, G = H / 16, W = H / 16;
@@ -323,6 +392,7 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
     std::unique_ptr<rmr_model, void (*)(rmr_model *)> m(new rmr_model(), rmr_model_destroy);
     m->eng = e;
     m->desc = *desc;
+    m->nparts = desc->dtype;  // 0 fp32 MFMA; 1 bf16; 2 bf16x3 (2-part split); 3 bf16x6 (3-part split)
     const int sz = desc->size, K = desc->kmer_len, L = desc->chunk_len;
 
     const float *p = weights;
@@ -383,6 +453,11 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
     RMR_TRY(pack_conv(m.get(), convs[4], K_CONV_SEQ2, &m->seq2));
     if (desc->arch == RMR_ARCH_CONV_LSTM) {
         RMR_TRY(pack_conv(m.get(), convs[5], K_CONV_MERGE1, &m->merge1));
+        if (m->nparts > 0) {
+            RMR_TRY(pack_conv_split(m.get(), convs[2], m->nparts, &m->sig3));
+            RMR_TRY(pack_conv_split(m.get(), convs[4], m->nparts, &m->seq2));
+            RMR_TRY(pack_conv_split(m.get(), convs[5], m->nparts, &m->merge1));
+        }
         const int H = sz;
         const float *wih1 = p; p += (size_t)4 * H * H;
         const float *whh1 = p; p += (size_t)4 * H * H;
@@ -398,6 +473,17 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
         RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4, true), &m->lstm.a_ih1));
         RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4, true), &m->lstm.a_hh1));
         RMR_TRY(upload(m.get(), pack_lstm(wih2, H, g3, 3), &m->lstm.a_ih2));
+        if (m->nparts > 0) {
+            std::vector<float> si((size_t)4 * H * H), sh((size_t)4 * H * H);
+            for (int r = 0; r < 4 * H; ++r)
+                for (int k = 0; k < H; ++k) {
+                    si[(size_t)r * H + k] = (float)((double)wih1[(size_t)r * H + k] * lstm1_gate_scale(r / H));
+                    sh[(size_t)r * H + k] = (float)((double)whh1[(size_t)r * H + k] * lstm1_gate_scale(r / H));
+                }
+            const int rb[4] = {0, H, 2 * H, 3 * H};
+            RMR_TRY(upload(m.get(), pack_split_a(si, H, H / 16, rb, 4, m->nparts), &m->lstm.s_ih1));
+            RMR_TRY(upload(m.get(), pack_split_a(sh, H, H / 16, rb, 4, m->nparts), &m->lstm.s_hh1));
+        }
         std::vector<float> b1(4 * H), b2(3 * H);
         for (int i = 0; i < 4 * H; ++i)
             b1[i] = (float)(((double)bih1[i] + (double)bhh1[i]) * lstm1_gate_scale(i / H));
@@ -466,12 +552,20 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             RMR_TRY(launch_front(m, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
                                  map_w, lens + c0, kb, ka, nb, sig2, seq1));
         }
-        RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
+        const bool split_conv = m->nparts > 0 && tune_int("RMR_SPLIT_CONV", 1);
+        if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
+        else RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
         if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
             float *x = base; base += (size_t)nb * m->T * sz;
-            RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
-            RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
-            RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
+            if (split_conv) {
+                RMR_TRY(launch_conv_split(e, m->seq2, m->nparts, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
+                RMR_TRY(launch_conv_split(e, m->merge1, m->nparts, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
+            } else {
+                RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
+                RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
+            }
+            if (m->nparts > 0) RMR_TRY(launch_lstm_head_split(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
+            else RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
         } else {
             float *seq2 = base; base += (size_t)nb * m->PQ2 * 32;
             float *m1 = base; base += (size_t)nb * m->T * sz;

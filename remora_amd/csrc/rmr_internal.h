@@ -115,6 +115,7 @@ namespace rmr {
 struct ConvLayer {
     int ic = 0, oc = 0, kw = 0, stride = 1;
     float *apack = nullptr;  // device, fragment order [oc/16][kw*ic/4][64]
+    float *spack = nullptr;  // device, split-bf16 fragments [oc/16][steps][nparts][64] x 16 B (dtype != 0)
     float *bias = nullptr;   // device, folded bias [oc]
     int kid = 0;             // profiling id
 };
@@ -136,6 +137,8 @@ struct LstmWeights {
     float *a_ih2 = nullptr;                    // [H/16][3 gates i,g,o][H/4][64]
     float *b2 = nullptr;                       // [3H]  (i,g,o) b_ih + b_hh
     float *w_fc = nullptr, *b_fc = nullptr;    // [num_out][H], [num_out]
+    // split-bf16 fragments (dtype != 0): [H/16][4 gates][H/32][nparts][64 lanes] x 16 B
+    float *s_ih1 = nullptr, *s_hh1 = nullptr;
 };
 
 }  // namespace rmr
@@ -143,6 +146,7 @@ struct LstmWeights {
 struct rmr_model {
     rmr_engine *eng = nullptr;
     rmr_model_desc desc{};
+    int nparts = 0;  // 0: fp32 MFMA path; 1..3: bf16 MFMA with 1 / 2 / 3-part split operands
     std::vector<void *> dev_allocs;
     rmr::FrontWeights front;
     // conv_lstm: sig3, seq2, merge1;  conv_only: sig3, seq2, seq3, merge1..4
@@ -179,6 +183,9 @@ int launch_seq1_dense(rmr_model *m, const float *enc, int64_t n, float *seq1);
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                 float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
+int launch_lstm_head_split(rmr_model *m, const float *x, int64_t n, float *logits);
+int launch_conv_split(rmr_engine *e, const ConvLayer &c, int np, const float *in, int in_row, int pin,
+                      float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits);
 
 // integer tuning knob from the environment (read once per call site; for experiments only)

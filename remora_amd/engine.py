@@ -165,19 +165,25 @@ class HipModel:
     callers use (src/remora/data_chunks.py:528-533, src/remora/inference.py:286,311-315,390,
     src/remora/model_util.py:559-562) — plus the fused `infer_chunks` fast path."""
 
-    def __init__(self, state, chunk_len, device=None, engine=None):
+    DTYPES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+
+    def __init__(self, state, chunk_len, device=None, engine=None, dtype="fp32"):
         torch = _torch()
         self.engine = engine if engine is not None else get_engine(device)
         arch, size, kmer_len, num_out, blob = state_to_blob(state)
         self.arch, self.size, self.kmer_len, self.num_out = arch, size, kmer_len, num_out
         self.chunk_len = int(chunk_len)
+        if dtype not in self.DTYPES:
+            raise RemoraError(f"unknown dtype {dtype!r}; choose from {sorted(self.DTYPES)}")
+        self.dtype = dtype
         desc = L.ModelDesc(L.ARCH_CONV_LSTM if arch == "conv_lstm" else L.ARCH_CONV_ONLY, size,
-                           kmer_len, num_out, self.chunk_len, 0)
+                           kmer_len, num_out, self.chunk_len, self.DTYPES[dtype])
         lib = L.lib()
         want = lib.rmr_model_weight_count(ctypes.byref(desc))
         if want == 0:
             raise RemoraError(f"model not supported by the HIP engine: arch={arch} size={size} "
-                              f"kmer_len={kmer_len} num_out={num_out} (size must be 16, 32 or 64)")
+                              f"kmer_len={kmer_len} num_out={num_out} dtype={dtype} (size must be 16, 32 or 64; "
+                              "bf16* dtypes need conv_lstm with size 32/64)")
         if want != blob.size:
             raise RemoraError(f"weight blob has {blob.size} floats, engine expects {want}")
         h = ctypes.c_void_p()

@@ -8,6 +8,7 @@ HIP engine (BatchNorm folding and MFMA packing happen inside rmr_model_create) a
 returned in place of the ScriptModule is a `HipModel`.
 """
 import json
+import os
 from os.path import isfile
 
 import numpy as np
@@ -67,10 +68,13 @@ def _raw_load_torchscript_model(model_filename, device=None):
     return state, md
 
 
-def load_torchscript_model(model_filename, device=None, quiet=False, eval_only=False):
+def load_torchscript_model(model_filename, device=None, quiet=False, eval_only=False, dtype=None):
     state, md = _raw_load_torchscript_model(model_filename, device)
     add_derived_metadata(md)
-    model = HipModel(state, md["chunk_len"], device=device)
+    # arithmetic of the GEMM stages: "fp32" (default, exact fp32 MFMA) or a bf16-MFMA mode
+    # ("bf16x6" fp32-class split, "bf16x3", "bf16"); REMORA_HIP_DTYPE overrides the default
+    dtype = dtype or os.environ.get("REMORA_HIP_DTYPE", "fp32")
+    model = HipModel(state, md["chunk_len"], device=device, dtype=dtype)
     if model.kmer_len != md["kmer_len"]:
         raise RemoraError(f"model weights expect kmer_len {model.kmer_len}, metadata says {md['kmer_len']}")
     return model.eval(), md
@@ -95,7 +99,7 @@ def load_model(model_filename=None, *, pore=None, basecall_model_type=None, base
                       "(a TorchScript .pt with meta.txt, e.g. one fetched with `remora model download`)")
 
 
-def model_from_state(state, model_metadata, device=None, engine=None):
+def model_from_state(state, model_metadata, device=None, engine=None, dtype="fp32"):
     """HipModel straight from a state_dict-like {name: array} (numpy or torch) — the entry point
     for callers that already hold the weights."""
     st = {}
@@ -103,4 +107,4 @@ def model_from_state(state, model_metadata, device=None, engine=None):
         if k.endswith("num_batches_tracked"):
             continue
         st[k] = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
-    return HipModel(st, int(sum(model_metadata["chunk_context"])), device=device, engine=engine)
+    return HipModel(st, int(sum(model_metadata["chunk_context"])), device=device, engine=engine, dtype=dtype)

@@ -422,3 +422,39 @@ def test_errors_surface_as_remora_error(torch_cuda):
     with pytest.raises(RemoraError, match="kmer"):
         model.infer_chunks(np.zeros((2, 1, 100), np.float32), np.zeros((2, 24), np.int8), np.zeros((2, 21), np.int16),
                            np.ones(2, np.int16), (2, 3))
+
+
+# ---- bf16-MFMA modes (split operands): own tolerances ---------------------------------------------
+SPLIT_TOL = {"bf16x6": 1e-4, "bf16x3": 1e-4, "bf16": 3e-2}
+
+
+@pytest.mark.parametrize("dtype", ["bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("name", ["convlstm_s64_l100_o2", "convlstm_s64_l200_o3", "convlstm_s64_l100_k23"])
+def test_split_bf16_logits_golden(torch_cuda, O, name, dtype):
+    """bf16x6 / bf16x3 must still meet the fp32 gate (<= 1e-4); plain bf16 has its own tolerance
+    plus an argmax-agreement requirement on clearly separated chunks."""
+    from remora_amd.model_util import model_from_state
+
+    g = golden(f"model_{name}.npz")
+    state = O.state_from_npz(g)
+    size, kb, ka, L, num_out = (int(x) for x in g["params"])
+    md = dict(chunk_context=(L // 2, L - L // 2), kmer_context_bases=(kb, ka))
+    model = model_from_state(state, md, device=0, dtype=dtype)
+    out = model.infer_chunks(g["sigs"], g["seqs"], g["maps"], g["lens"], (kb, ka))
+    err = np.abs(out - g["logits"]).max()
+    assert err <= SPLIT_TOL[dtype], (dtype, err)
+    ref = g["logits"]
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 4 * SPLIT_TOL[dtype]
+    assert np.array_equal(out.argmax(1)[clear], ref.argmax(1)[clear])
+
+
+def test_split_bf16_rejects_unsupported(torch_cuda, O):
+    from remora_amd import RemoraError
+    from remora_amd.model_util import model_from_state
+
+    g = golden("model_conv_s64_l100_o2.npz")
+    with pytest.raises(RemoraError):
+        model_from_state(O.state_from_npz(g), dict(chunk_context=(50, 50)), device=0, dtype="bf16x6")
+    with pytest.raises(RemoraError):
+        model_from_state(O.state_from_npz(g), dict(chunk_context=(50, 50)), device=0, dtype="fp8")
