@@ -31,6 +31,10 @@ WORKLOADS = {
     "convlstm_c200": ("conv_lstm", "C200", "synthetic 200-sig-pt all-context chunks, ConvLSTM_w_ref 3-class fp32 (BASELINE configs[4] shape, fp32)"),
 }
 
+# algorithmic HBM bytes per chunk of the MFMA kernels (fp32 channel-last in + out), C100 ConvLSTM
+ALG_BYTES = {"conv_merge1": 28 * 128 * 4 + 24 * 64 * 4, "conv_sig3": 92 * 16 * 4 + 28 * 64 * 4,
+             "conv_seq2": 96 * 16 * 4 + 28 * 64 * 4, "lstm_head": 24 * 64 * 4 + 8}
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 
@@ -149,6 +153,7 @@ def main():
                     help="GEMM arithmetic: fp32 MFMA (default) or bf16 MFMA with split operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")
+    ap.add_argument("--no-alt", action="store_true", help="skip the bf16x6 (fp32-class split bf16 MFMA) comparison leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing: put every rank on this GPU")
@@ -245,6 +250,24 @@ def main():
                     "frac": gbs / PEAK_HBM_GBS, "bytes_per_chunk": bytes_per_chunk, "chunks_per_launch": blk,
                     "avg_launch_ms": ms / launches, "chunks_per_s": blk * launches / (ms * 1e-3)}
         del enc
+    # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
+    alt = None
+    if rank == 0 and world == 1 and args.dtype == "fp32" and arch == "conv_lstm" and not args.no_alt:
+        model6 = model_from_state(state, md, device=local, dtype="bf16x6")
+        c6 = torch.zeros(num_out, dtype=torch.int64, device=f"cuda:{local}")
+        for _ in range(max(args.warmup, 1)):
+            lg6 = model6.infer_chunks(*dev, kcb)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            lg6 = model6.infer_chunks(*dev, kcb, label_counts=c6)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        alt = {"dtype": "bf16x6 (3-part exact split of fp32 operands, 6 bf16 MFMA products, fp32 accumulate)",
+               "value": n * args.steps / (tb - ta), "unit": "chunks/s", "ms_per_step": (tb - ta) / args.steps * 1e3,
+               "max_abs_logit_diff_vs_fp32_mfma_path": float((lg6 - logits).abs().max().item()),
+               "label_counts": [int(x) for x in c6.tolist()]}
+        del model6
     if rank != 0:
         return
     assert int(counts.sum().item()) == total_chunks, "label counts do not add up"
@@ -258,10 +281,27 @@ def main():
     dom = max((k for k in kern if flops.get(k) and not k.startswith("front_")), key=lambda k: kern[k]["ms_total"])
     chunks_per_launch = n * args.steps / kern[dom]["launches"]
     achieved = flops[dom] * chunks_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
-    traffic = os.environ.get("RMR_BENCH_TRAFFIC_BYTES")  # PMC-derived HBM bytes/launch (profiles/)
+    # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this workload
+    # (profiles/traffic.json, written by tools/summarize_profile.py --traffic; MI355X_MICROARCH.md
+    # corrections applied there); scaled to this run's chunks per launch
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        ent = tj.get(args.dtype, {}).get(dom)
+        if ent:
+            traffic = ent["bytes_per_chunk"] * chunks_per_launch
+    except (OSError, ValueError, KeyError):
+        pass
+    # fp32 MFMA: peak 157.3 TF.  bf16 MFMA with split operands executes NPROD bf16 products per
+    # algorithmic MAC, so the matrix-pipe ceiling for algorithmic flops is 2.5 PF / NPROD.
+    nprod = {"fp32": None, "bf16": 1, "bf16x3": 3, "bf16x6": 6}[args.dtype]
+    peak = PEAK_FP32_MFMA_TFLOPS if nprod is None else PEAK_BF16_MFMA_TFLOPS / nprod
     roofline = {
-        "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": float(traffic) if traffic else None,
+        "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+        "peak_note": ("v_mfma_f32_16x16x4_f32 dense peak" if nprod is None else
+                      f"bf16 dense peak 2500 / {nprod} part products per algorithmic MAC"),
+        "frac": achieved / peak, "traffic": float(traffic) if traffic else None,
+        "algorithmic_bytes": float(ALG_BYTES.get(dom, 0) * chunks_per_launch) if dom in ALG_BYTES else None,
         "flop_per_chunk": flops[dom], "chunks_per_launch": chunks_per_launch, "avg_launch_ms": kern[dom]["avg_ms"],
     }
     gpu_ms = sum(k["ms_total"] for k in kern.values())
@@ -280,6 +320,7 @@ def main():
                            "kernel_ms_sum": gpu_ms, "wall_ms": elapsed * 1e3},
         "kernels": kern,
         "encode_roofline": enc_roof,
+        "alt_bf16x6": alt,
         "label_counts": [int(x) for x in counts.tolist()],
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -52,6 +52,30 @@ template <> struct Prod<1> { static constexpr int N = 1; static constexpr int A[
 template <> struct Prod<2> { static constexpr int N = 3; static constexpr int A[3] = {0, 0, 1}; static constexpr int B[3] = {0, 1, 0}; };
 template <> struct Prod<3> { static constexpr int N = 6; static constexpr int A[6] = {0, 0, 1, 0, 2, 1}; static constexpr int B[6] = {0, 1, 0, 2, 0, 1}; };
 
+// acc[gt] += sum over k-steps and part products of A[gt][ks][pa] * B(img)[ks][pb]
+template <int KS32, int NP, int SL>
+__device__ __forceinline__ void mm_split_impl(const uint4 (&img)[NP][4][16][SL], int q, int nn,
+                                              const uint4 (&A)[4][KS32][NP], f32x4 (&acc)[4]) {
+    using P = Prod<NP>;
+#pragma unroll
+    for (int ks = 0; ks < KS32; ++ks) {
+        bf16x8 b[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(bf16x8, img[p][q][nn][ks]);
+#pragma unroll
+        for (int pr = 0; pr < P::N; ++pr)
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+                acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[gt][ks][P::A[pr]]),
+                                                                 b[P::B[pr]], acc[gt], 0, 0, 0);
+    }
+}
+template <int KS32, int NP, int SL>
+__device__ __forceinline__ void mm_split(const uint4 (&img)[NP][4][16][SL], int q, int nn,
+                                         const uint4 (&A)[4][KS32][NP], f32x4 (&acc)[4]) {
+    mm_split_impl<KS32, NP, SL>(img, q, nn, A, acc);
+}
+
 struct LstmSArgs {
     const float *x;       // [n][T][H] fp32, channel-last
     float *logits;        // [n][num_out]
@@ -119,52 +143,54 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.x + (size_t)st_chunk * a.T * H) + st_c4;
         __syncthreads();
         stage_x(0, xsrc[0]);
+        stage_x(1, xsrc[(size_t)(a.T > 1 ? 1 : 0) * (H / 4)]);
         __syncthreads();
 
+        // Software pipeline as in k_lstm.hip: accN = b + W_ih x_{t+1} is issued in slices between
+        // the gate-math slices of step t (bf16 MFMA and VALU are separate pipes, but a wave issues
+        // in order: without the interleave the matrix pipe idles while the wave does its VALU work).
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accN[4] = {bias[0], bias[1], bias[2], bias[3]};
+        mm_split<KS32, NP, SL>(xs[0], q, nn, Aih, accN);
         for (int t = 0; t < a.T; ++t) {
-            const int tf = (t + 1 < a.T) ? t + 1 : a.T - 1;
+            const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
             const float4 xnext = xsrc[(size_t)tf * (H / 4)];
-            f32x4 acc[4] = {bias[0], bias[1], bias[2], bias[3]};
-            // ---- input projection: W_ih x_t ----
+            f32x4 acc[4] = {accN[0], accN[1], accN[2], accN[3]};
+            bf16x8 bxn[KS32][NP];
 #pragma unroll
-            for (int ks = 0; ks < KS32; ++ks) {
-                bf16x8 b[NP];
+            for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(bf16x8, xs[t & 1][p][q][nn][ks]);
+                for (int p = 0; p < NP; ++p) bxn[ks][p] = __builtin_bit_cast(bf16x8, xs[(t + 1) & 1][p][q][nn][ks]);
+            if (t > 0) mm_split<KS32, NP, SL>(hs[(t - 1) & 1], q, nn, Ahh, acc);  // recurrent critical path
 #pragma unroll
-                for (int pr = 0; pr < P::N; ++pr)
+            for (int gt = 0; gt < 4; ++gt) accN[gt] = bias[gt];
+            f32x4 h;
+            float ig[4], fg[4], gg[4];
+            constexpr int NM = KS32 * P::N * 4;  // projection MFMAs of the next step
 #pragma unroll
-                    for (int gt = 0; gt < 4; ++gt)
-                        acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, Aih[gt][ks][P::A[pr]]), b[P::B[pr]], acc[gt], 0, 0, 0);
-            }
-            // ---- recurrence: W_hh h_{t-1} ----
-            if (t > 0) {
+            for (int s = 0; s < 16; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                // (in the last step this projects a stale, finite tile and the result is dropped:
+                //  keeps the step body branch-free so the slices stay in one scheduling region)
 #pragma unroll
-                for (int ks = 0; ks < KS32; ++ks) {
-                    bf16x8 b[NP];
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(bf16x8, hs[(t - 1) & 1][p][q][nn][ks]);
-#pragma unroll
-                    for (int pr = 0; pr < P::N; ++pr)
-#pragma unroll
-                        for (int gt = 0; gt < 4; ++gt)
-                            acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, Ahh[gt][ks][P::A[pr]]), b[P::B[pr]], acc[gt], 0, 0, 0);
+                for (int mi = s * NM / 16; mi < (s + 1) * NM / 16; ++mi) {
+                    const int gt = mi & 3, pr = (mi >> 2) % P::N, ks = (mi >> 2) / P::N;
+                    accN[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, Aih[gt][ks][P::A[pr]]), bxn[ks][P::B[pr]], accN[gt], 0, 0, 0);
+                }
+                const int r = s >> 2, st = s & 3;
+                if (st == 0) ig[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
+                if (st == 1) fg[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
+                if (st == 2) {
+                    gg[r] = fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[2][r])), 1.0f);
+                    c[r] = fmaf(fg[r], c[r], ig[r] * gg[r]);
+                }
+                if (st == 3) {
+                    const float og = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
+                    h[r] = og * tanh_f(c[r]);
                 }
             }
-            // ---- gates (rows pre-scaled: i,f,o by -log2 e; g by 2 log2 e) ----
-            f32x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ig = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
-                const float fg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
-                const float gg = fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[2][r])), 1.0f);
-                const float og = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
-                c[r] = fmaf(fg, c[r], ig * gg);
-                h[r] = og * tanh_f(c[r]);
-            }
+            __builtin_amdgcn_sched_barrier(0);
             // h parts -> LDS: this lane's 4 units are channels 16w+4q..+3 of chunk nn
             {
                 unsigned e[4][NP];
@@ -178,7 +204,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
                 }
             }
             if (t + 1 == a.T) *reinterpret_cast<f32x4 *>(&hlast[q][nn][4 * w]) = h;
-            if (t + 1 < a.T) stage_x((t + 1) & 1, xnext);
+            stage_x(t & 1, xnext);  // x_{t+2} into the buffer whose last reader was step t-1
             __syncthreads();
         }
 

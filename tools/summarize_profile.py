@@ -31,7 +31,42 @@ def load_counters(d):
     return out
 
 
+BENCH_NAME = [("conv_mfma_kernel<128, 5, 1>", "conv_merge1"), ("conv_mfma_kernel<16, 13, 3>", "conv_seq2"),
+              ("conv_mfma_kernel<16, 9, 3>", "conv_sig3"), ("lstm_head_kernel", "lstm_head"),
+              ("conv_bf16s_kernel<128, 5, 1", "conv_merge1"), ("conv_bf16s_kernel<16, 13, 3", "conv_seq2"),
+              ("conv_bf16s_kernel<16, 9, 3", "conv_sig3"), ("lstm_bf16s_kernel", "lstm_head"),
+              ("front_sig_kernel", "front_sig"), ("front_seq_kernel", "front_seq")]
+
+
+def write_traffic(d, dtype, chunks_per_launch, path):
+    """profiles/traffic.json: corrected HBM bytes per chunk per kernel (2 x FETCH_SIZE + WRITE_SIZE, KiB)."""
+    import json
+
+    fetch = load_counters(os.path.join(d, "pmc_FETCH_SIZE"))
+    write = load_counters(os.path.join(d, "pmc_WRITE_SIZE"))
+    try:
+        tj = json.load(open(path))
+    except (OSError, ValueError):
+        tj = {}
+    ent = {}
+    for k in set(fetch) | set(write):
+        name = next((b for a, b in BENCH_NAME if k.startswith(a)), None)
+        if not name:
+            continue
+        fv, fn = fetch.get(k, {}).get("FETCH_SIZE", (0, 0))
+        wv, wn = write.get(k, {}).get("WRITE_SIZE", (0, 0))
+        per_launch = 2 * fv * 1024 / max(fn, 1) + wv * 1024 / max(wn, 1)
+        ent[name] = {"bytes_per_chunk": per_launch / chunks_per_launch, "source": os.path.basename(d.rstrip("/")),
+                     "fetch_raw_kib_per_launch": fv / max(fn, 1), "write_kib_per_launch": wv / max(wn, 1),
+                     "chunks_per_launch": chunks_per_launch}
+    tj[dtype] = ent
+    json.dump(tj, open(path, "w"), indent=1, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "--traffic":
+        write_traffic(sys.argv[1], sys.argv[3], float(sys.argv[4]), sys.argv[5])
+        return
     d = sys.argv[1]
     tag = os.path.basename(d.rstrip("/"))
     lines = [f"# rocprofv3 summary — {tag}", "",
