@@ -71,6 +71,29 @@ def kernel_flops_per_chunk(arch, L, size=64, K=9, num_out=2):
     return f
 
 
+def precision_check(state, data, kcb, gpu_logits):
+    """Max |logit error| of each GPU path against a float64 CPU evaluation of the same network on
+    the first 512 chunks (and the fp32 CPU reference's own error, for scale)."""
+    import torch
+
+    from oracle import oracle as O
+    from oracle import torch_ref
+
+    k = 512
+    enc = O.compute_encoded_kmer_batch(kcb[0], kcb[1], data["sequence"][:k], data["sequence_to_signal_mapping"][:k],
+                                       data["sequence_lengths"][:k])
+    sig = torch.from_numpy(data["signal"][:k])
+    with torch.no_grad():
+        ref64 = torch_ref.from_state(state).double()(sig.double(), torch.from_numpy(enc).double()).numpy()
+        ref32 = torch_ref.from_state(state)(sig, torch.from_numpy(enc)).numpy()
+    out = {"chunks": k, "cpu_fp32_reference_vs_fp64": float(np.abs(ref32 - ref64).max())}
+    for name, lg in gpu_logits.items():
+        if lg is not None:
+            out[f"{name}_vs_fp64"] = float(np.abs(lg[:k] - ref64).max())
+            out[f"{name}_vs_cpu_fp32_reference"] = float(np.abs(lg[:k] - ref32).max())
+    return out
+
+
 def cpu_baseline(state, data, kcb, budget_s=12.0):
     """Reference CPU path timed on this box's host cores: single-thread C restatement of the
     Cython encode + torch.nn restatement of the network (all cores, eager, batch 2048)."""
@@ -251,7 +274,7 @@ def main():
                     "avg_launch_ms": ms / launches, "chunks_per_s": blk * launches / (ms * 1e-3)}
         del enc
     # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
-    alt = None
+    alt, alt_head = None, None
     if rank == 0 and world == 1 and args.dtype == "fp32" and arch == "conv_lstm" and not args.no_alt:
         model6 = model_from_state(state, md, device=local, dtype="bf16x6")
         c6 = torch.zeros(num_out, dtype=torch.int64, device=f"cuda:{local}")
@@ -267,6 +290,7 @@ def main():
                "value": n * args.steps / (tb - ta), "unit": "chunks/s", "ms_per_step": (tb - ta) / args.steps * 1e3,
                "max_abs_logit_diff_vs_fp32_mfma_path": float((lg6 - logits).abs().max().item()),
                "label_counts": [int(x) for x in c6.tolist()]}
+        alt_head = lg6[:512].cpu().numpy()
         del model6
     if rank != 0:
         return
@@ -328,6 +352,8 @@ def main():
         sample = {k: v[:nb] for k, v in data.items() if isinstance(v, np.ndarray)}
         out["cpu_baseline"] = cpu_baseline(state, sample, kcb, args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        out["precision"] = precision_check(state, sample, kcb, {args.dtype + "_path": logits[:512].cpu().numpy(),
+                                                                  "bf16x6_path": alt_head})
     print(json.dumps(out))
 
 

@@ -54,7 +54,7 @@ int rmr_engine::ensure(Arena &a, size_t bytes) {
     return 0;
 }
 
-int rmr_engine::prof_begin(int id, hipEvent_t *t1) {
+int rmr_engine::prof_begin(int id, hipEvent_t *t1, hipStream_t s) {
     hipEvent_t ev[2];
     for (int k = 0; k < 2; ++k) {
         if (!pool.empty()) {
@@ -64,7 +64,7 @@ int rmr_engine::prof_begin(int id, hipEvent_t *t1) {
             return -1;
         }
     }
-    if (hipEventRecord(ev[0], stream) != hipSuccess) return -1;
+    if (hipEventRecord(ev[0], s) != hipSuccess) return -1;
     recs.push_back(Rec{id, ev[0], ev[1]});
     *t1 = ev[1];
     return 0;
@@ -73,6 +73,7 @@ int rmr_engine::prof_begin(int id, hipEvent_t *t1) {
 int rmr_engine::prof_collect() {
     if (recs.empty()) return 0;
     RMR_HIP(hipStreamSynchronize(stream));
+    if (aux) RMR_HIP(hipStreamSynchronize(aux));
     for (auto &r : recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.t0, r.t1) == hipSuccess) {
@@ -113,6 +114,12 @@ int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
         RMR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->owns_stream = true;
     }
+    RMR_HIP(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+    RMR_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+        RMR_HIP(hipEventCreateWithFlags(&e->ev_front[k], hipEventDisableTiming));
+        RMR_HIP(hipEventCreateWithFlags(&e->ev_done[k], hipEventDisableTiming));
+    }
     *out = e.release();
     return 0;
 }
@@ -121,6 +128,12 @@ void rmr_engine_destroy(rmr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    for (int k = 0; k < 2; ++k) {
+        if (e->ev_front[k]) (void)hipEventDestroy(e->ev_front[k]);
+        if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
+    }
     for (auto &r : e->recs) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->act.ptr) (void)hipFree(e->act.ptr);
@@ -536,22 +549,52 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     const size_t per = act_floats_per_chunk(m);
     int64_t sb = e->subbatch > 0 ? e->subbatch : 65536;
     if (sb > n) sb = n;
-    RMR_TRY(e->ensure(e->act, per * sb * sizeof(float)));
     const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;
-    for (int64_t c0 = 0; c0 < n; c0 += sb) {
-        const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
-        float *base = reinterpret_cast<float *>(e->act.ptr);
-        float *seq1 = base; base += (size_t)nb * m->P1 * 16;
-        float *sig2 = base; base += (size_t)nb * m->P2 * 16;
-        float *cat = base; base += (size_t)nb * m->P3 * 2 * sz;
+    // front outputs (seq1, sig2) are double-buffered so that the front kernels of sub-batch i+1
+    // can run on the aux stream while the matrix kernels of sub-batch i run on the main stream
+    const size_t front_fl = (size_t)(m->P1 + m->P2) * 16;
+    RMR_TRY(e->ensure(e->act, (per + front_fl) * sb * sizeof(float)));
+    const bool two_stream = tune_int("RMR_TWO_STREAM", 0) && n > sb;
+    hipStream_t fs = two_stream ? e->aux : e->stream;
+    float *arena = reinterpret_cast<float *>(e->act.ptr);
+    float *front_buf[2] = {arena, arena + front_fl * sb};
+    float *rest = arena + 2 * front_fl * sb;
+    if (two_stream) {  // inputs were produced on the main stream
+        RMR_HIP(hipEventRecord(e->ev_in, e->stream));
+        RMR_HIP(hipStreamWaitEvent(e->aux, e->ev_in, 0));
+    }
+    auto front = [&](int64_t c0, int64_t nb, int slot) -> int {
+        float *seq1 = front_buf[slot], *sig2 = seq1 + (size_t)nb * m->P1 * 16;
         const float *sig_b = signal + (size_t)c0 * L;
         if (enc) {
-            RMR_TRY(launch_front(m, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
+            RMR_TRY(launch_front(m, fs, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
+            if (two_stream) {  // the dense seq_conv1 kernel runs on the main stream
+                RMR_HIP(hipEventRecord(e->ev_front[slot], fs));
+                RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_front[slot], 0));
+            }
             RMR_TRY(launch_seq1_dense(m, enc + (size_t)c0 * EC * L, nb, seq1));
         } else {
-            RMR_TRY(launch_front(m, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
+            RMR_TRY(launch_front(m, fs, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
                                  map_w, lens + c0, kb, ka, nb, sig2, seq1));
+            if (two_stream) RMR_HIP(hipEventRecord(e->ev_front[slot], fs));
         }
+        return 0;
+    };
+    int64_t idx = 0;
+    if (n > 0) RMR_TRY(front(0, n < sb ? n : sb, 0));
+    for (int64_t c0 = 0; c0 < n; c0 += sb, ++idx) {
+        const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
+        const int slot = (int)(idx & 1);
+        // launch the NEXT sub-batch's front kernels before this sub-batch's matrix kernels
+        if (c0 + sb < n) {
+            const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
+            if (two_stream && idx >= 1) RMR_HIP(hipStreamWaitEvent(fs, e->ev_done[slot ^ 1], 0));
+            if (two_stream) RMR_TRY(front(c0 + sb, nn, slot ^ 1));
+        }
+        if (two_stream && !enc) RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_front[slot], 0));
+        float *seq1 = front_buf[slot], *sig2 = seq1 + (size_t)nb * m->P1 * 16;
+        float *base = rest;
+        float *cat = base; base += (size_t)nb * m->P3 * 2 * sz;
         const bool split_conv = m->nparts > 0 && tune_int("RMR_SPLIT_CONV", 1);
         if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
         else RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
@@ -564,6 +607,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                 RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
                 RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
             }
+            if (two_stream) RMR_HIP(hipEventRecord(e->ev_done[slot], e->stream));  // seq1/sig2[slot] consumed
             if (m->nparts > 0) RMR_TRY(launch_lstm_head_split(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
             else RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
         } else {
@@ -573,12 +617,17 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             float *m3 = base; base += (size_t)nb * m->T3 * sz;
             float *m4 = base; base += (size_t)nb * m->T4 * sz;
             RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, seq2, 32, 0, m->PQ2, nb));
+            if (two_stream) RMR_HIP(hipEventRecord(e->ev_done[slot], e->stream));
             RMR_TRY(launch_conv(e, m->seq3, seq2, 32, m->PQ2, cat, 2 * sz, sz, m->P3, nb));
             RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, m1, sz, 0, m->T, nb));
             RMR_TRY(launch_conv(e, m->merge2, m1, sz, m->T, m2, sz, 0, m->T2, nb));
             RMR_TRY(launch_conv(e, m->merge3, m2, sz, m->T2, m3, sz, 0, m->T3, nb));
             RMR_TRY(launch_conv(e, m->merge4, m3, sz, m->T3, m4, sz, 0, m->T4, nb));
             RMR_TRY(launch_fc_head(m, m4, nb, logits + (size_t)c0 * m->desc.num_out));
+        }
+        if (!two_stream && c0 + sb < n) {
+            const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
+            RMR_TRY(front(c0 + sb, nn, slot ^ 1));
         }
     }
     return 0;

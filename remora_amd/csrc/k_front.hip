@@ -18,6 +18,17 @@
 
 namespace rmr {
 
+// The 32 threads that own a chunk live in ONE wavefront and every per-chunk LDS region is
+// private to them, so phases only need ordering inside the wave: LDS operations of a wave are
+// processed in issue order; the fence keeps the compiler from reordering across the phase
+// boundary.  No block-wide barrier -> the 4 waves of a block drift apart and hide each
+// other's LDS / global latency.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 
 // ---------------------------------------------------------------------------------------
 // signal branch: sig_conv1 (1->4) -> LDS -> sig_conv2 (4->16).  32 threads per chunk, the
@@ -59,12 +70,12 @@ __global__ __launch_bounds__(256) void front_sig_kernel(FrontSigArgs a) {
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk = it * a.cb + c;
         const bool live = chunk < a.n;
-        __syncthreads();
+        wave_sync();
         if (live) {
             const float *src = a.signal + (size_t)chunk * a.L;
             for (int s = sub; s < a.L; s += 32) s_sig[s] = src[s];
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             for (int pos = sub; pos < a.P1; pos += 32) {
                 float4 acc = b1;
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(256) void front_sig_kernel(FrontSigArgs a) {
                 *reinterpret_cast<float4 *>(s_sig1 + pos * 4) = acc;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             float *dst = a.sig2 + (size_t)chunk * a.P2 * 16;
             for (int i = sub; i < a.P2 * 4; i += 32) {  // i & 3 == quad
@@ -141,13 +152,14 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     for (int i = tid; i < wt_words; i += blockDim.x) s_wt[i] = a.wt5[i];
     for (int i = sub; i < KW * 16; i += 32) s_u[(size_t)a.maxlen * KW * 16 + i] = 0.0f;
     const float4 bq = *reinterpret_cast<const float4 *>(a.b_seq1 + 4 * quad);
+    __syncthreads();  // gather table visible to every wave
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk = it * a.cb + c;
         const bool live = chunk < a.n;
         int len = 0;
-        __syncthreads();
+        wave_sync();
         if (live) {
             len = a.lens[chunk];
             len = len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len);
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
             const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
             for (int j = sub; j < a.seq_w; j += 32) s_seq[j] = sq[j];
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             for (int s = sub; s < a.L; s += 32) {  // first index in [0, len] with map[idx] > s
                 int lo = 0, hi = len + 1;
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
                 s_code[p] = wv;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             const int items = len * KW * 4;
             for (int i = sub; i < items; i += 32) {  // i & 3 == quad
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
                 *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = acc;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             float *dst = a.seq1 + (size_t)chunk * a.P1 * 16;
             for (int i = sub; i < a.P1 * 4; i += 32) {
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     }
 }
 
-int launch_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w,
+int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t *seqs, int seq_w,
                  const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
                  float *sig2, float *seq1) {
     rmr_engine *e = m->eng;
@@ -232,9 +244,9 @@ int launch_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_
         const int64_t iters = (n + a.cb - 1) / a.cb;
         int64_t grid = (int64_t)e->num_cus * 8;
         if (grid > iters) grid = iters;
-        ProfScope ps(e, K_FRONT_SIG);
-        if (kw == 5) hipLaunchKernelGGL(front_sig_kernel<5>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
-        else hipLaunchKernelGGL(front_sig_kernel<11>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        ProfScope ps(e, K_FRONT_SIG, st, true);
+        if (kw == 5) hipLaunchKernelGGL(front_sig_kernel<5>, dim3((unsigned)grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(front_sig_kernel<11>, dim3((unsigned)grid), dim3(256), lds, st, a);
         RMR_HIP(hipGetLastError());
     }
     if (!seq1) return 0;
@@ -270,8 +282,8 @@ int launch_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_
     const int64_t iters = (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * 4;
     if (grid > iters) grid = iters;
-    ProfScope ps(e, K_FRONT_SEQ);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(32 * cb), lds, e->stream, a);
+    ProfScope ps(e, K_FRONT_SEQ, st, true);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(32 * cb), lds, st, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }

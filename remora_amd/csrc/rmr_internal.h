@@ -68,6 +68,10 @@ struct rmr_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    // second stream + events for the two-stage sub-batch pipeline (front kernels of sub-batch
+    // i+1 run under the matrix kernels of sub-batch i)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int num_cus = 256;
     std::mutex mu;
     int64_t subbatch = 0;
@@ -91,7 +95,7 @@ struct rmr_engine {
     std::vector<hipEvent_t> pool;
     double acc_ms[rmr::K_NUM] = {};
     int64_t acc_n[rmr::K_NUM] = {};
-    int prof_begin(int id, hipEvent_t *t1);
+    int prof_begin(int id, hipEvent_t *t1, hipStream_t s);
     int prof_collect();
 };
 
@@ -100,11 +104,13 @@ struct ProfScope {
     rmr_engine *e;
     hipEvent_t t1 = nullptr;
     bool on = false;
-    ProfScope(rmr_engine *eng, int id) : e(eng) {
-        if (e->profiling) on = (e->prof_begin(id, &t1) == 0);
+    hipStream_t s;
+    ProfScope(rmr_engine *eng, int id, hipStream_t st = nullptr, bool use_st = false)
+        : e(eng), s(use_st ? st : eng->stream) {
+        if (e->profiling) on = (e->prof_begin(id, &t1, s) == 0);
     }
     ~ProfScope() {
-        if (on) (void)hipEventRecord(t1, e->stream);
+        if (on) (void)hipEventRecord(t1, s);
     }
 };
 
@@ -176,7 +182,7 @@ int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts);
 
 // fused pipeline stages; all tensors channel-last in device scratch
-int launch_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w,
+int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t *seqs, int seq_w,
                  const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
                  float *sig2, float *seq1 /* nullptr: skip seq path */);
 int launch_seq1_dense(rmr_model *m, const float *enc, int64_t n, float *seq1);
