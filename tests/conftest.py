@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the HIP library is built in-tree (git-ignored): build it if this checkout has none yet
+    lib = os.path.join(ROOT, "remora_amd", "libremora_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+
+        subprocess.call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "remora_amd", "csrc")])
 
 
 def golden(name):
