@@ -25,3 +25,348 @@ def parse_move_tag(mv_tag, sig_len, seq_len=None, check=True, reverse_signal=Fal
     L.check(rc)
     stride = int(mv[0])
     return q2s[: n_out.value].copy(), mv[1:].astype(np.int64), stride
+
+
+# =======================================================================================
+# POD5 + BAM ingest without pysam / pod5: the reference reads these with
+# pod5.DatasetReader (src/remora/io.py:441-474) and pysam (:184-358); both formats are simple
+# enough to parse with the standard library + pyarrow:
+#   BAM  = BGZF (concatenated gzip members) around fixed binary records (SAM spec §4.2)
+#   POD5 = a container of three Arrow IPC files (signal / run info / reads tables); signal
+#          rows are "VBZ": zstd( streamvbyte-16( zigzag( delta( int16 samples ))))
+# =======================================================================================
+import array
+import dataclasses
+import gzip
+import struct
+
+_SEQ_NT16 = "=ACMGRSVTWYHKDBN"
+_CIGAR_OPS = "MIDNSHP=XB"
+
+
+@dataclasses.dataclass
+class BamRecord:
+    """The pysam.AlignedSegment attributes the hot path touches (src/remora/io.py:1972-2084)."""
+
+    query_name: str
+    flag: int
+    reference_id: int
+    reference_name: str
+    reference_start: int
+    mapping_quality: int
+    cigartuples: list
+    query_sequence: str
+    query_qualities: bytes
+    tags: list  # [(name, value)] in file order
+
+    @property
+    def is_reverse(self):
+        return bool(self.flag & 0x10)
+
+    @property
+    def is_unmapped(self):
+        return bool(self.flag & 0x4)
+
+    @property
+    def is_secondary(self):
+        return bool(self.flag & 0x100)
+
+    @property
+    def is_supplementary(self):
+        return bool(self.flag & 0x800)
+
+    def get_tag(self, name):
+        for k, v in self.tags:
+            if k == name:
+                return v
+        raise KeyError(name)
+
+    def to_dict(self):
+        return {"name": self.query_name, "flag": str(self.flag), "ref_name": self.reference_name or "*",
+                "ref_pos": str(self.reference_start + 1), "map_quality": str(self.mapping_quality),
+                "seq": self.query_sequence}
+
+
+def _parse_tags(buf):
+    tags, p, n = [], 0, len(buf)
+    scalar = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+    while p < n:
+        name = buf[p : p + 2].decode()
+        t = chr(buf[p + 2])
+        p += 3
+        if t == "A":
+            val = chr(buf[p]); p += 1
+        elif t in scalar:
+            sz = struct.calcsize(scalar[t])
+            val = struct.unpack_from(scalar[t], buf, p)[0]; p += sz
+        elif t in "ZH":
+            e = buf.index(b"\x00", p)
+            val = buf[p:e].decode(); p = e + 1
+        elif t == "B":
+            sub = chr(buf[p]); cnt = struct.unpack_from("<i", buf, p + 1)[0]; p += 5
+            dt = {"c": np.int8, "C": np.uint8, "s": np.int16, "S": np.uint16, "i": np.int32, "I": np.uint32,
+                  "f": np.float32}[sub]
+            arr = np.frombuffer(buf, dtype=np.dtype(dt).newbyteorder("<"), count=cnt, offset=p)
+            # pysam hands B tags over as array.array: same here
+            val = array.array({"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub], arr.tolist())
+            p += cnt * np.dtype(dt).itemsize
+        else:
+            raise RemoraError(f"unknown BAM tag type {t!r}")
+        tags.append((name, val))
+    return tags
+
+
+def iter_bam_records(bam_path):
+    """Yield BamRecord for every alignment of an (unindexed read of a) BAM file."""
+    with gzip.open(bam_path, "rb") as fh:  # BGZF members are valid concatenated gzip members
+        data = fh.read()
+    if data[:4] != b"BAM\x01":
+        raise RemoraError(f"{bam_path} is not a BAM file")
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, p)[0]
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, p)[0]
+        refs.append(data[p + 4 : p + 4 + l_name - 1].decode())
+        p += 4 + l_name + 4
+    n = len(data)
+    while p < n:
+        block = struct.unpack_from("<i", data, p)[0]
+        rec = data[p + 4 : p + 4 + block]
+        p += 4 + block
+        ref_id, pos, l_read_name, mapq, _bin, n_cig, flag, l_seq, _nref, _npos, _tlen = struct.unpack_from(
+            "<iiBBHHHiiii", rec, 0)
+        q = 32
+        name = rec[q : q + l_read_name - 1].decode(); q += l_read_name
+        cig = np.frombuffer(rec, dtype="<u4", count=n_cig, offset=q); q += 4 * n_cig
+        cigartuples = [(int(c & 0xF), int(c >> 4)) for c in cig]
+        sb = np.frombuffer(rec, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q); q += (l_seq + 1) // 2
+        codes = np.empty(2 * sb.size, np.uint8)
+        codes[0::2], codes[1::2] = sb >> 4, sb & 0xF
+        seq = "".join(_SEQ_NT16[c] for c in codes[:l_seq])
+        qual = bytes(rec[q : q + l_seq]); q += l_seq
+        yield BamRecord(name, flag, ref_id, refs[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq,
+                        qual, _parse_tags(rec[q:]))
+
+
+def _vbz_decode(blob, n_samples):
+    """zstd -> streamvbyte16 (1 key bit per value: 0 = one byte, 1 = two bytes; keys first) ->
+    zigzag -> running sum, int16."""
+    import pyarrow as pa
+
+    raw = np.frombuffer(pa.CompressedInputStream(pa.BufferReader(blob), "zstd").read(), np.uint8)
+    nkeys = (n_samples + 7) // 8
+    keys = np.unpackbits(raw[:nkeys], bitorder="little")[:n_samples].astype(np.int64)
+    data = raw[nkeys:]
+    if data.size != n_samples + int(keys.sum()):
+        raise RemoraError("corrupt VBZ signal block")
+    offs = np.cumsum(keys + 1) - (keys + 1)
+    lo = data[offs].astype(np.uint16)
+    hi = np.where(keys == 1, data[np.minimum(offs + 1, data.size - 1)], 0).astype(np.uint16)
+    v = lo | (hi << 8)
+    d = (v >> 1).astype(np.int16) ^ (-(v & 1).astype(np.int16))
+    return np.cumsum(d, dtype=np.int16)
+
+
+@dataclasses.dataclass
+class Pod5Read:
+    read_id: str
+    signal: np.ndarray       # int16 DAC samples
+    calibration_offset: float
+    calibration_scale: float
+
+
+def iter_pod5_reads(pod5_path, read_ids=None):
+    """Yield Pod5Read for every read of a POD5 file (Arrow tables located by their magic)."""
+    import uuid
+
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+
+    blob = open(pod5_path, "rb").read()
+    if blob[:8] != b"\x8bPOD\r\n\x1a\n":
+        raise RemoraError(f"{pod5_path} is not a POD5 file")
+    marks = []
+    i = blob.find(b"ARROW1")
+    while i >= 0:
+        marks.append(i)
+        i = blob.find(b"ARROW1", i + 1)
+    tables = {}
+    k = 0
+    while k + 1 < len(marks):  # files are [ARROW1\0\0 ... ARROW1] pairs
+        st = marks[k]
+        opened = False
+        for e in marks[k + 1 :]:
+            try:
+                t = ipc.open_file(pa.BufferReader(blob[st : e + 6])).read_all()
+            except (pa.ArrowInvalid, OSError):
+                continue
+            names = set(t.schema.names)
+            if {"signal", "samples"} <= names:
+                tables["signal"] = t
+            elif "calibration_offset" in names:
+                tables["reads"] = t
+            k = marks.index(e) + 1
+            opened = True
+            break
+        if not opened:
+            k += 1
+    if "signal" not in tables or "reads" not in tables:
+        raise RemoraError(f"could not locate the signal / reads tables in {pod5_path}")
+    sig_t, reads_t = tables["signal"], tables["reads"]
+    sig_rows, sig_n = sig_t.column("signal"), sig_t.column("samples")
+    want = None if read_ids is None else set(read_ids)
+    for r in range(reads_t.num_rows):
+        rid = str(uuid.UUID(bytes=reads_t.column("read_id")[r].as_py()))
+        if want is not None and rid not in want:
+            continue
+        parts = [_vbz_decode(sig_rows[i].as_py(), sig_n[i].as_py()) for i in reads_t.column("signal")[r].as_py()]
+        # delta coding restarts in every signal row
+        yield Pod5Read(rid, np.concatenate(parts) if len(parts) > 1 else parts[0],
+                       float(reads_t.column("calibration_offset")[r].as_py()),
+                       float(reads_t.column("calibration_scale")[r].as_py()))
+
+
+_COMP = str.maketrans("ACGTBVDHKMRYacgt", "TGCAVBHDMKYRtgca")
+
+
+def revcomp(seq):
+    return seq.translate(_COMP)[::-1]
+
+
+PA_TO_NORM_SCALING_FACTOR = 1.4826
+
+
+@dataclasses.dataclass
+class Read:
+    """Signal + basecalls + their mapping for one read: the subset of remora.io.Read
+    (src/remora/io.py:1747-2177) that the basecall-anchored inference path uses."""
+
+    read_id: str
+    dacs: np.ndarray = None
+    seq: str = None
+    stride: int = None
+    mv_table: np.ndarray = None
+    query_to_signal: np.ndarray = None
+    shift_dacs_to_pa: float = None
+    scale_dacs_to_pa: float = None
+    shift_pa_to_norm: float = None
+    scale_pa_to_norm: float = None
+    shift_dacs_to_norm: float = None
+    scale_dacs_to_norm: float = None
+    shift_pa_to_zc_pa: float = None
+    scale_pa_to_zc_pa: float = None
+    full_align: dict = None
+    _child_read_id: str = None
+
+    @property
+    def child_read_id(self):
+        return self.read_id if self._child_read_id is None else self._child_read_id
+
+    @property
+    def sig_len(self):
+        return None if self.dacs is None else self.dacs.size
+
+    @property
+    def pa_signal(self):
+        return (self.dacs - self.shift_dacs_to_pa) / self.scale_dacs_to_pa
+
+    def compute_pa_to_norm_scaling(self, factor=PA_TO_NORM_SCALING_FACTOR):
+        """src/remora/io.py:1851-1856 (median / MAD)."""
+        pa = self.pa_signal
+        self.shift_pa_to_norm = np.median(pa)
+        self.scale_pa_to_norm = max(1.0, np.median(np.abs(pa - self.shift_pa_to_norm)) * factor)
+
+    @classmethod
+    def from_pod5(cls, pod5_read, reverse_signal=False, infer_convention=True):
+        """`infer_convention=True` follows iter_signal (used by `remora infer`:
+        shift=offset, scale=scale, src/remora/io.py:466-472); False follows
+        from_pod5_and_alignment (shift=-offset, scale=1/scale, :2105-2115)."""
+        dacs = pod5_read.signal[::-1] if reverse_signal else pod5_read.signal
+        if infer_convention:
+            sh, sc = pod5_read.calibration_offset, pod5_read.calibration_scale
+        else:
+            sh, sc = -pod5_read.calibration_offset, 1 / pod5_read.calibration_scale
+        return cls(read_id=pod5_read.read_id, dacs=dacs, shift_dacs_to_pa=sh, scale_dacs_to_pa=sc)
+
+    def add_alignment(self, rec, reverse_signal=False, pa_scaling=None):
+        """Signal trimming by sp/ts/ns, read-id checks, strand-aware sequence, move table ->
+        query_to_signal, sm/sd (or median/MAD) norm scaling composed with the pA calibration
+        (src/remora/io.py:1972-2044).  Reference-anchored fields are not parsed."""
+        if pa_scaling is not None:
+            self.shift_pa_to_zc_pa, self.scale_pa_to_zc_pa = pa_scaling
+        if rec.reference_name is None and rec.is_reverse:
+            raise RemoraError("Unmapped reads cannot map to reverse strand.")
+        if self.dacs is None:
+            raise RemoraError("Must add signal to io.Read before alignment.")
+        self.full_align = rec.to_dict()
+        tags = dict(rec.tags)
+        if reverse_signal:
+            self.dacs = self.dacs[::-1]
+        self.dacs = self.dacs[tags.get("sp", 0) :]
+        self.dacs = self.dacs[tags.get("ts", 0) : tags.get("ns", self.dacs.size)]
+        if reverse_signal:
+            self.dacs = self.dacs[::-1]
+        parent = tags.get("pi", None)
+        if parent is None:
+            if rec.query_name != self.read_id:
+                raise RemoraError("Read IDs mismatch")
+        else:
+            if parent != self.read_id:
+                raise RemoraError("Split read IDs mismatch")
+            self._child_read_id = rec.query_name
+        self.seq = revcomp(rec.query_sequence) if rec.is_reverse else rec.query_sequence
+        if "mv" in tags:
+            self.query_to_signal, self.mv_table, self.stride = parse_move_tag(
+                tags["mv"], sig_len=self.sig_len, seq_len=len(self.seq), reverse_signal=reverse_signal)
+        else:
+            self.query_to_signal = self.mv_table = self.stride = None
+        if "sm" in tags and "sd" in tags:
+            self.shift_pa_to_norm, self.scale_pa_to_norm = tags["sm"], tags["sd"]
+        else:
+            self.compute_pa_to_norm_scaling()
+        self.shift_dacs_to_norm = self.shift_dacs_to_pa + (self.scale_dacs_to_pa * self.shift_pa_to_norm)
+        self.scale_dacs_to_norm = self.scale_dacs_to_pa * self.scale_pa_to_norm
+
+    def into_remora_read(self, use_reference_anchor=False):
+        """Basecall-anchored RemoraRead (src/remora/io.py:2123-2177)."""
+        from .data_chunks import RemoraRead
+
+        if use_reference_anchor:
+            raise RemoraError("reference-anchored reads are not implemented in remora_amd")
+        if self.query_to_signal is None:
+            raise RemoraError("Missing query_to_signal (move table)")
+        trim = self.dacs[self.query_to_signal[0] : self.query_to_signal[-1]]
+        if self.shift_pa_to_zc_pa is None or self.scale_pa_to_zc_pa is None:
+            shift, scale = self.shift_dacs_to_norm, self.scale_dacs_to_norm
+        else:
+            shift = self.shift_dacs_to_pa + self.scale_dacs_to_pa * self.shift_pa_to_zc_pa
+            scale = self.scale_dacs_to_pa * self.scale_pa_to_zc_pa
+        rr = RemoraRead(dacs=trim, shift=shift, scale=scale,
+                        seq_to_sig_map=self.query_to_signal - self.query_to_signal[0], str_seq=self.seq,
+                        read_id=self.read_id)
+        rr.check()
+        return rr
+
+
+def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_scaling=None,
+                                 skip_non_primary=True):
+    """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
+    read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519)."""
+    signals = {r.read_id: r for r in iter_pod5_reads(pod5_path)}
+    for rec in iter_bam_records(bam_path):
+        if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
+            continue
+        tags = dict(rec.tags)
+        rid = tags.get("pi", rec.query_name)
+        if rid not in signals:
+            continue
+        read = Read.from_pod5(signals[rid], reverse_signal=reverse_signal)
+        try:
+            read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling)
+        except RemoraError as e:
+            yield read, str(e)
+            continue
+        yield read, None

@@ -460,3 +460,35 @@ def test_split_bf16_rejects_unsupported(torch_cuda, O):
         model_from_state(O.state_from_npz(g), dict(chunk_context=(50, 50)), device=0, dtype="bf16x6")
     with pytest.raises(RemoraError):
         model_from_state(O.state_from_npz(g), dict(chunk_context=(50, 50)), device=0, dtype="fp8")
+
+
+# ---- BASELINE configs[0] shape: the reference's own POD5 + BAM test data end to end ------------------
+def test_real_reads_pod5_bam_end_to_end(torch_cuda, O, tmp_path):
+    """tests/data/can_reads.pod5 + can_mappings.bam (copied under tests/golden/data) ->
+    remora_amd.io ingest -> Read.add_alignment -> into_remora_read -> call_read_mods, against the
+    reference's own Read / call_read_mods run on the same parsed records (tools/gen_golden.py)."""
+    from remora_amd import io as rio
+    from remora_amd.inference import call_read_mods
+    from remora_amd.model_util import load_model
+
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    g = golden("real_reads_can.npz")
+    model, md = load_model(_mint_pt(tmp_path, g, O), device=0)
+    n = 0
+    for i, (read, err) in enumerate(rio.iter_reads_from_pod5_and_bam(os.path.join(data, "can_reads.pod5"),
+                                                                     os.path.join(data, "can_mappings.bam"))):
+        assert err is None and read.read_id == str(g[f"r{i}_name"])
+        rr = read.into_remora_read(False)
+        assert [rr.shift, rr.scale] == list(g[f"r{i}_shift_scale"]), "scaling composition must match bit for bit"
+        assert rr.dacs.size == int(g[f"r{i}_ndacs"])
+        crc = int(np.bitwise_xor.reduce(rr.dacs.astype(np.int64) * (np.arange(rr.dacs.size) % 251 + 1)))
+        assert crc == int(g[f"r{i}_dacs_crc"])
+        assert np.array_equal(rr.seq_to_sig_map, g[f"r{i}_map"]) and rr.str_seq == str(g[f"r{i}_seq"])
+        nn_out, labels, pos = call_read_mods(rr, model, md)
+        assert np.array_equal(pos, g[f"r{i}_pos"])
+        assert np.abs(nn_out - g[f"r{i}_nn_out"]).max() <= 1e-4
+        mm, ml = call_read_mods(read.into_remora_read(False), model, md, return_mm_ml_tags=True)
+        assert mm == str(g[f"r{i}_mm"])
+        assert np.abs(np.asarray(list(ml), np.uint8).astype(int) - g[f"r{i}_ml"].astype(int)).max() <= 1
+        n += pos.size
+    assert i == 13 and n == 922

@@ -260,3 +260,33 @@ def test_count_allreduce_gloo_world2(tmp_path):
     g = golden("post_process.npz")
     assert res["total"] == g["tally_pred_counts"].tolist() == res["total_t"]
     assert res["max"] == 2.0 and res["n"] == [0, 500]
+
+
+# ---- POD5 / BAM ingest on the reference's own test data (next row N1) ------------------------------
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+def test_bam_and_pod5_parsers_on_reference_test_data():
+    from oracle import oracle as O
+    from remora_amd import io as rio
+
+    recs = list(rio.iter_bam_records(os.path.join(DATA, "can_mappings.bam")))
+    pods = {p.read_id: p for p in rio.iter_pod5_reads(os.path.join(DATA, "can_reads.pod5"))}
+    g = golden("real_reads_can.npz")
+    assert len(recs) == len(pods) == int(g["num_records"]) == 14
+    assert sum(r.is_reverse for r in recs) == 4 and all(r.reference_name == "chr13" for r in recs)
+    for i, rec in enumerate(recs):
+        assert rec.query_name == str(g[f"r{i}_name"]) and rec.flag == int(g[f"r{i}_flag"])
+        tags = dict(rec.tags)
+        assert {"mv", "ts", "ns", "sm", "sd"} <= set(tags) and set(rec.query_sequence) <= set("ACGTN")
+        sig = pods[rec.query_name].signal
+        assert sig.dtype == np.int16 and 300 < sig.mean() < 1500
+        # move table, trimmed signal and basecalls must be mutually concordant (io.py:403-406)
+        n_sig = sig[tags["ts"] : tags["ns"]].size
+        q2s, mv, stride = O.parse_move_tag(np.asarray(tags["mv"], np.int8), n_sig, seq_len=len(rec.query_sequence))
+        assert q2s[-1] == n_sig and q2s.size == len(rec.query_sequence) + 1
+        # the reference's into_remora_read trims to [q2s[0], q2s[-1]) and re-bases the map
+        assert np.array_equal(q2s - q2s[0], g[f"r{i}_map"]) and n_sig - q2s[0] == int(g[f"r{i}_ndacs"])
+        seq = rio.revcomp(rec.query_sequence) if rec.is_reverse else rec.query_sequence
+        assert seq == str(g[f"r{i}_seq"])
+    assert rio.revcomp("ACGTN") == "NACGT"

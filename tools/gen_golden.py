@@ -656,6 +656,57 @@ def gen_dataset_batches(R, out):
     print("prepare_batches: done", sig.shape)
 
 
+def gen_real_reads(R, out):
+    """BASELINE configs[0] shape on the reference's own test data (tests/data/can_reads.pod5 +
+    can_mappings.bam, copied to tests/golden/data/): the files are parsed by remora_amd.io
+    (pysam/pod5 are not installed here), the parsed records are fed to the REFERENCE's
+    io.Read.add_alignment (src/remora/io.py:1972-2044, iter_signal calibration convention
+    :466-472), into_remora_read (:2123-2177) and inference.call_read_mods (inference.py:661-712)."""
+    import json
+    import tempfile
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from remora_amd import io as rio
+
+    data = os.path.join(out, "data")
+    pods = {p.read_id: p for p in rio.iter_pod5_reads(os.path.join(data, "can_reads.pod5"))}
+    recs = list(rio.iter_bam_records(os.path.join(data, "can_mappings.bam")))
+    net = make_net(R, "ConvLSTM_w_ref", 64, 9, 2, seed=300)
+    ckpt = _ckpt((4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 64, 9, 2)
+    with tempfile.TemporaryDirectory() as td:
+        pt = os.path.join(td, "m.pt")
+        R.model_util.export_model_torchscript(ckpt, net, pt)
+        extra = {"meta.txt": ""}
+        torch.jit.load(pt, _extra_files=extra, map_location="cpu")
+        model, md = R.model_util.load_model(pt, quiet=True, eval_only=True)
+    d = state_to_np(net)
+    d["meta_txt"] = np.asarray(extra["meta.txt"] if isinstance(extra["meta.txt"], str) else extra["meta.txt"].decode())
+    d["num_records"] = np.asarray(len(recs))
+    for i, rec in enumerate(recs):
+        pod = pods[rec.query_name]
+        read = R.io.Read(read_id=pod.read_id, dacs=pod.signal, shift_dacs_to_pa=pod.calibration_offset,
+                         scale_dacs_to_pa=pod.calibration_scale)
+        read.add_alignment(rec, parse_ref_align=False)
+        rr = read.into_remora_read(False)
+        d[f"r{i}_name"] = np.asarray(rec.query_name)
+        d[f"r{i}_flag"] = np.asarray(rec.flag)
+        d[f"r{i}_shift_scale"] = np.asarray([rr.shift, rr.scale], np.float64)
+        d[f"r{i}_ndacs"] = np.asarray(rr.dacs.size)
+        d[f"r{i}_dacs_crc"] = np.asarray(int(np.bitwise_xor.reduce(rr.dacs.astype(np.int64) * (np.arange(rr.dacs.size) % 251 + 1))))
+        d[f"r{i}_map"] = np.asarray(rr.seq_to_sig_map, np.int64)
+        d[f"r{i}_seq"] = np.asarray(rr.str_seq)
+        nn_out, labels, pos = R.inference.call_read_mods(rr, model, md)
+        d[f"r{i}_nn_out"] = np.asarray(nn_out, np.float32)
+        d[f"r{i}_pos"] = np.asarray(pos, np.int64)
+        mm, ml = R.inference.call_read_mods(read.into_remora_read(False), model, md, return_mm_ml_tags=True)
+        d[f"r{i}_mm"] = np.asarray(mm)
+        d[f"r{i}_ml"] = np.asarray(list(ml), np.uint8)
+    np.savez_compressed(os.path.join(out, "real_reads_can.npz"), **d)
+    print("real_reads:", len(recs), "records,", sum(int(d[f"r{i}_pos"].size) for i in range(len(recs))), "chunks")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -674,6 +725,7 @@ def main():
         call_read_mods=gen_call_read_mods,
         post=gen_post,
         dataset_batches=gen_dataset_batches,
+        real_reads=gen_real_reads,
     )
     for name, fn in gens.items():
         if args.only and name not in args.only.split(","):
