@@ -176,6 +176,7 @@ def main():
                     help="GEMM arithmetic: fp32 MFMA (default) or bf16 MFMA with split operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")
+    ap.add_argument("--no-reads", action="store_true", help="skip the measured reads/sec leg (extract + infer from whole reads)")
     ap.add_argument("--no-alt", action="store_true", help="skip the bf16x6 (fp32-class split bf16 MFMA) comparison leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -273,6 +274,38 @@ def main():
                     "frac": gbs / PEAK_HBM_GBS, "bytes_per_chunk": bytes_per_chunk, "chunks_per_launch": blk,
                     "avg_launch_ms": ms / launches, "chunks_per_s": blk * launches / (ms * 1e-3)}
         del enc
+    # ---- reads/sec measured end to end from whole reads (motif scan on the host, chunk extraction +
+    #      fused inference on the GPU, logits back on the host), outside the timed region ----
+    reads_leg = None
+    if rank == 0 and not args.no_reads and arch == "conv_lstm" and cfg == "C100":
+        from remora_amd.data_chunks import RemoraRead
+        from remora_amd.inference import call_read_mods, call_reads_mods
+
+        mdr = dict(md, motifs=[("CG", 0)], mod_bases=["m"], mod_long_names=["5mC"], can_base="C",
+                   base_start_justify=False, offset=0, sig_map_refiner=None)
+        nreads = 512
+        rs = []
+        for i in range(nreads):
+            r = synth.synth_read(5000, idx=i)
+            rs.append(RemoraRead(dacs=r["dacs"], shift=r["shift"], scale=r["scale"], seq_to_sig_map=r["seq_to_sig_map"],
+                                 int_seq=r["int_seq"], read_id=f"syn{i}"))
+        res = call_reads_mods(rs, model, mdr)  # warm-up
+        nchunks = sum(r[2].size for r in res)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(3):
+            call_reads_mods(rs, model, mdr)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        t1a = time.perf_counter()
+        for r in rs[:32]:
+            call_read_mods(r, model, mdr)
+        t1b = time.perf_counter()
+        reads_leg = {"reads": nreads, "bases_per_read": 5000, "chunks_per_read": nchunks / nreads,
+                     "batched_reads_per_s": 3 * nreads / (tb - ta), "batched_chunks_per_s": 3 * nchunks / (tb - ta),
+                     "single_read_api_reads_per_s": 32 / (t1b - t1a),
+                     "note": "call_reads_mods: host motif scan + H2D + geometry/fill + fused inference + D2H per batch of 512 reads"}
+
     # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
     alt, alt_head = None, None
     if rank == 0 and world == 1 and args.dtype == "fp32" and arch == "conv_lstm" and not args.no_alt:
@@ -345,6 +378,7 @@ def main():
         "kernels": kern,
         "encode_roofline": enc_roof,
         "alt_bf16x6": alt,
+        "reads_pipeline": reads_leg,
         "label_counts": [int(x) for x in counts.tolist()],
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -795,13 +795,6 @@ int stage_reads(rmr_engine *e, Stage &st, const rmr_reads *r, int mem, bool need
         for (int64_t i = foc_off[k]; i < foc_off[k + 1]; ++i) cr[(size_t)i] = (int32_t)k;
     o->chunk_read = st.take<int32_t>(o->n_chunks + 1);
     H2D(o->chunk_read, cr.data(), cr.size() * 4);
-    if (need_dacs && nr > 1) {
-        sr.resize((size_t)o->total_sig);
-        for (int64_t k = 0; k < nr; ++k)
-            for (int64_t i = sig_off[k]; i < sig_off[k + 1]; ++i) sr[(size_t)i] = (int32_t)k;
-        o->sig_read = st.take<int32_t>(o->total_sig + 1);
-        H2D(o->sig_read, sr.data(), sr.size() * 4);
-    }
     if (mem == RMR_MEM_HOST) {
 #define STAGE_ARR(field, T, count)                                        \
     {                                                                     \

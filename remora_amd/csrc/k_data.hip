@@ -192,12 +192,17 @@ int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_
 // (bit-exact with numpy); per chunk: focus clip, focus signal index, window with clipping,
 // the two binary searches on the read's seq_to_signal map.
 // ======================================================================================
-__global__ void normalise_kernel(const int16_t *dacs, const int32_t *sig_read, const double *shift,
-                                 const double *scale, float *sig, int64_t total) {
+__global__ void normalise_kernel(const int16_t *dacs, const int64_t *sig_off, int64_t n_reads,
+                                 const double *shift, const double *scale, float *sig, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int r = sig_read ? sig_read[i] : 0;
-    sig[i] = (float)(((double)dacs[i] - shift[r]) / scale[r]);
+    // owning read: last r with sig_off[r] <= i (reads are concatenated; offsets ascend)
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sig_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    sig[i] = (float)(((double)dacs[i] - shift[lo]) / scale[lo]);
 }
 
 struct GeoArgs {
@@ -257,7 +262,7 @@ int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const i
     if (total_sig > 0) {
         ProfScope ps(e, K_NORMALISE);
         hipLaunchKernelGGL(normalise_kernel, dim3((unsigned)((total_sig + 255) / 256)), dim3(256), 0,
-                           e->stream, d.dacs, sig_read, d.shift, d.scale, sig_out, total_sig);
+                           e->stream, d.dacs, d.sig_off, d.n_reads, d.shift, d.scale, sig_out, total_sig);
         RMR_HIP(hipGetLastError());
     }
     if (n_chunks > 0) {

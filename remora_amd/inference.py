@@ -28,3 +28,65 @@ def call_read_mods(read, model, model_metadata, batch_size=DEFAULT_BATCH_SIZE, f
         return format_mm_ml_tags(seq=read.str_seq, poss=pos, probs=probs, mod_bases=model_metadata["mod_bases"],
                                  can_base=model_metadata["can_base"])
     return probs, labels, pos
+
+
+def find_focus_bases_batch(reads, motifs):
+    """Motif hits for many reads at once (sorted ascending per read).  Vectorised restatement of
+    Motif.findall (src/remora/util.py:281-297) over the concatenated sequences; unlike
+    find_focus_bases_in_int_sequence (:413-426) the per-read order is ascending, not python-set
+    order (downstream consumers sort by position anyway, src/remora/util.py:506,518)."""
+    lens = np.array([r.int_seq.size for r in reads], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    cat = np.concatenate([np.asarray(r.int_seq, dtype=np.int64) for r in reads]) if len(reads) else np.zeros(0, np.int64)
+    read_of = np.repeat(np.arange(len(reads)), lens)
+    hit_any = np.zeros(cat.size, dtype=bool)
+    cat1 = (cat + 1).astype(np.intp)  # -1 (N) -> 0
+    for mot in motifs:
+        m = len(mot.raw_motif)
+        nwin = cat.size - m + 1
+        if nwin <= 0:
+            continue
+        hit = np.ones(nwin, dtype=bool)
+        for po, allowed in enumerate(mot.int_pattern):
+            lut = np.zeros(5, dtype=bool)
+            lut[np.asarray(allowed) + 1] = True
+            hit &= lut[cat1[po : po + nwin]]
+        # a window must not straddle two reads
+        hit &= read_of[:nwin] == read_of[m - 1 : m - 1 + nwin]
+        focus = np.flatnonzero(hit) + mot.focus_pos
+        focus = focus[(focus >= 0) & (focus < cat.size)]
+        hit_any[focus] = True
+    pos = np.flatnonzero(hit_any)
+    owner = read_of[pos]
+    counts = np.bincount(owner, minlength=len(reads))
+    local = pos - offs[owner]
+    return np.split(local, np.cumsum(counts)[:-1]) if len(reads) else []
+
+
+def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
+    """Batched form of call_read_mods for a list of RemoraRead objects: one motif scan, one chunk
+    extraction and one fused inference for all reads (the reference processes reads one by one
+    in Python, src/remora/inference.py:62-137, 661-712).  Returns a list of per-read
+    (nn_out | probs, labels, pos) tuples; pos ascending within a read."""
+    from .data_chunks import extract_chunk_arrays
+
+    motifs = [Motif(*m) for m in model_metadata["motifs"]]
+    focus = find_focus_bases_batch(reads, motifs)
+    for r, fb in zip(reads, focus):
+        r.refine_signal_mapping(model_metadata.get("sig_map_refiner"))
+        r.focus_bases = fb
+    arrs, _ = extract_chunk_arrays(reads, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
+                                   model_metadata["base_start_justify"], model_metadata["offset"])
+    counts = np.array([len(fb) for fb in focus], dtype=np.int64)
+    if len(arrs) == 0:
+        return [(np.array([]), np.array([]), np.array([])) for _ in reads]
+    out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
+    out = out.cpu().numpy()
+    pos = arrs.read_focus_bases.cpu().numpy()
+    if return_mod_probs:
+        out = softmax_axis1(out)[:, 1:].astype(np.float64)
+    cuts = np.cumsum(counts)[:-1]
+    res = []
+    for o, l, p in zip(np.split(out, cuts), np.split(arrs.labels, cuts), np.split(pos, cuts)):
+        res.append((o, l, p) if p.size else (np.array([]), np.array([]), np.array([])))
+    return res

@@ -492,3 +492,36 @@ def test_real_reads_pod5_bam_end_to_end(torch_cuda, O, tmp_path):
         assert np.abs(np.asarray(list(ml), np.uint8).astype(int) - g[f"r{i}_ml"].astype(int)).max() <= 1
         n += pos.size
     assert i == 13 and n == 922
+
+
+def test_batched_call_reads_mods_matches_single_read_api(torch_cuda, O):
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_read_mods, call_reads_mods
+    from remora_amd.model_util import model_from_state
+
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=3)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)], mod_bases=["m"],
+              mod_long_names=["5mC"], can_base="C", base_start_justify=False, offset=0, sig_map_refiner=None)
+    model = model_from_state(state, md, device=0)
+
+    def mk(i, nb):
+        r = synth.synth_read(nb, idx=i)
+        return RemoraRead(dacs=r["dacs"], shift=r["shift"], scale=r["scale"], seq_to_sig_map=r["seq_to_sig_map"],
+                          int_seq=r["int_seq"], read_id=f"r{i}")
+
+    sizes = [700, 5, 1200, 64, 3000]
+    sizes_no_cg = np.array([0, 0, 3, 3, 0, 0])  # a read without any CG
+    reads = [mk(i, nb) for i, nb in enumerate(sizes)]
+    reads.insert(2, RemoraRead(dacs=np.full(60, 500, np.int16), shift=500.0, scale=80.0,
+                               seq_to_sig_map=np.arange(0, 61, 10), int_seq=sizes_no_cg, read_id="nocg"))
+    batched = call_reads_mods(reads, model, md)
+    assert len(batched) == len(reads) and batched[2][0].size == 0
+    for rd, (o, l, p) in zip(reads, batched):
+        so, sl, sp = call_read_mods(rd.copy(), model, md)
+        order = np.argsort(sp, kind="stable")
+        assert np.array_equal(p, sp[order])
+        if p.size:
+            assert np.array_equal(o, so[order]), "same chunks must give bit-identical logits in any batch"
