@@ -547,7 +547,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
     const size_t per = act_floats_per_chunk(m);
-    int64_t sb = e->subbatch > 0 ? e->subbatch : 65536;
+    int64_t sb = e->subbatch > 0 ? e->subbatch : 131072;
     if (sb > n) sb = n;
     const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;
     // front outputs (seq1, sig2) are double-buffered so that the front kernels of sub-batch i+1

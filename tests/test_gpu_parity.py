@@ -525,3 +525,39 @@ def test_batched_call_reads_mods_matches_single_read_api(torch_cuda, O):
         assert np.array_equal(p, sp[order])
         if p.size:
             assert np.array_equal(o, so[order]), "same chunks must give bit-identical logits in any batch"
+
+
+def test_fused_edge_cases_vs_oracle(torch_cuda, O):
+    """One base per sample (max_seq_len == chunk_len), zero-dwell bases, missing (-1) bases,
+    garbage in the padding columns, wide arrays, and empty batches."""
+    from oracle import torch_ref
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=11)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    model = model_from_state(state, dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0)
+    rng = np.random.default_rng(3)
+    n, L, msl = 37, 100, 100
+    seqs = rng.integers(-1, 4, (n, msl + 8 + 5)).astype(np.int8)      # 5 extra garbage columns
+    maps = rng.integers(-50, 150, (n, msl + 1 + 3)).astype(np.int16)  # garbage everywhere first
+    lens = np.zeros(n, np.int16)
+    for c in range(n):
+        sl = [100, 1, 2, 57][c % 4] if c < 8 else int(rng.integers(1, 101))
+        cuts = np.sort(rng.integers(0, L + 1, sl - 1)) if c % 3 else np.sort(rng.choice(np.arange(1, L), sl - 1, replace=False))
+        maps[c, : sl + 1] = np.concatenate([[0], cuts, [L]])
+        lens[c] = sl
+    sig = rng.standard_normal((n, 1, L)).astype(np.float32)
+    out = model.infer_chunks(sig, seqs, maps, lens, (4, 4))
+    enc = O.compute_encoded_kmer_batch(4, 4, seqs, maps, lens)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(sig), torch.from_numpy(enc)).numpy()
+    assert np.abs(out - ref).max() <= 1e-4
+    # the standalone encode agrees bit for bit on the same awkward rows
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+
+    assert np.array_equal(compute_encoded_kmer_batch(4, 4, seqs, maps, lens), enc)
+    # empty batch: shapes preserved, nothing launched
+    e = model.infer_chunks(sig[:0], seqs[:0], maps[:0], lens[:0], (4, 4))
+    assert e.shape == (0, 2)
+    assert model(torch.zeros(0, 1, 100).cuda(), torch.zeros(0, 36, 100).cuda()).shape == (0, 2)
