@@ -28,17 +28,22 @@ struct EncodeArgs {
 
 __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
-    // per wave-pair? keep simple: one chunk per block iteration
-    int16_t *s_pidx = reinterpret_cast<int16_t *>(smem_i);                 // [Lp]
+    // one WAVE per chunk: the wave's LDS slice is private, so only wave-level ordering is needed
+    // and the four waves of a block stream their 14 KB of stores independently
     const int Lp = (a.L + 7) & ~7;
-    int8_t *s_seq = reinterpret_cast<int8_t *>(s_pidx + Lp);               // [seq_w]
-    const int tid = threadIdx.x;
+    const int per_wave = (Lp * 2 + ((a.seq_w + 15) & ~15) + 15) & ~15;  // bytes
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    char *base = reinterpret_cast<char *>(smem_i) + (size_t)wv * per_wave;
+    int16_t *s_pidx = reinterpret_cast<int16_t *>(base);   // [Lp]
+    int8_t *s_seq = reinterpret_cast<int8_t *>(base + Lp * 2);  // [seq_w]
     const int total = 4 * a.K * a.L;       // floats per chunk (multiple of 4)
-    for (int64_t c = blockIdx.x; c < a.n; c += gridDim.x) {
-        __syncthreads();
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t c = wave_id; c < a.n; c += n_waves) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int len = a.lens[c];
         const int16_t *mp = a.maps + (size_t)c * a.map_w;
-        for (int s = tid; s < a.L; s += blockDim.x) {
+        for (int s = lane; s < a.L; s += 64) {
             int lo = 0, hi = len + 1;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -47,10 +52,12 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
             const int p = lo - 1;
             s_pidx[s] = (int16_t)((p >= 0 && p < len) ? p : -1);
         }
-        for (int j = tid; j < a.seq_w; j += blockDim.x) s_seq[j] = a.seqs[(size_t)c * a.seq_w + j];
-        __syncthreads();
+        for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = a.seqs[(size_t)c * a.seq_w + j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float4 *dst = reinterpret_cast<float4 *>(a.out + (size_t)c * total);
-        for (int f = tid; f < total / 4; f += blockDim.x) {
+        for (int f = lane; f < total / 4; f += 64) {
             float v[4];
             const int e0 = 4 * f;
             int row = (int)(((float)e0 + 0.5f) * a.inv_L);
@@ -62,7 +69,9 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
                 v[k] = (p >= 0 && s_seq[p + kp] == b) ? 1.0f : 0.0f;
                 if (++s == a.L) { s = 0; ++row; }
             }
-            dst[f] = make_float4(v[0], v[1], v[2], v[3]);
+            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+            const nt_f32x4 ov = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<nt_f32x4 *>(dst) + f);
         }
     }
 }
@@ -77,9 +86,10 @@ int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
     a.inv_L = 1.0f / (float)sig_len;
     if ((size_t)4 * a.K * sig_len >= (1u << 21)) RMR_FAIL(RMR_ERR_INVALID, "encode: chunk too large");
     const int Lp = (sig_len + 7) & ~7;
-    const size_t lds = (size_t)Lp * 2 + ((seq_w + 15) & ~15);
+    const size_t per_wave = ((size_t)Lp * 2 + ((seq_w + 15) & ~15) + 15) & ~(size_t)15;
+    const size_t lds = per_wave * 4;
     int64_t grid = (int64_t)e->num_cus * 8;
-    if (grid > n) grid = n;
+    if (grid > (n + 3) / 4) grid = (n + 3) / 4;
     ProfScope ps(e, K_ENCODE);
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
     RMR_HIP(hipGetLastError());

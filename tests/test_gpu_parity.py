@@ -561,3 +561,32 @@ def test_fused_edge_cases_vs_oracle(torch_cuda, O):
     e = model.infer_chunks(sig[:0], seqs[:0], maps[:0], lens[:0], (4, 4))
     assert e.shape == (0, 2)
     assert model(torch.zeros(0, 1, 100).cuda(), torch.zeros(0, 36, 100).cuda()).shape == (0, 2)
+
+
+def test_concurrent_calls_from_threads(torch_cuda, O):
+    """The reference calls the model from several Python threads (src/remora/inference.py:973-982);
+    the engine serialises calls internally, results must be unaffected."""
+    import threading
+
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=5)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    model = model_from_state(state, dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0)
+    datas = [synth.synth_chunks_config("C100", 3000 + 101 * i, shard=40 + i) for i in range(4)]
+    args = [(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"]) for d in datas]
+    expect = [model.infer_chunks(*a, (4, 4)) for a in args]
+    got = [[None] * 6 for _ in args]
+
+    def work(i):
+        for rep in range(6):
+            got[i][rep] = model.infer_chunks(*args[i], (4, 4))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(args))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for i in range(len(args)):
+        for rep in range(6):
+            assert np.array_equal(got[i][rep], expect[i])
