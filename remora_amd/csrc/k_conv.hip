@@ -153,7 +153,7 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     // chunks per iteration: fill <= 72 KB of LDS (2 blocks per CU) and give an even
     // number of 16-column tiles where possible
     const size_t row_bytes = (size_t)pin * RS * 4 * sizeof(float);  // all four planes
-    int cb = (int)((size_t)tune_int("RMR_CONV_LDS_BUDGET", 73728) / row_bytes);
+    int cb = (int)((size_t)tune_int("RMR_CONV_LDS_BUDGET", 73728) / (c.oc >= 64 ? 1 : 64 / c.oc) / row_bytes);
     if (cb < 1) cb = 1;
     if (cb > 8) cb = 8;
     if (cb >= 4) cb &= ~3;  // multiples of 4 chunks -> cb*pout divisible by 4
@@ -166,7 +166,8 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     a.cb = cb; a.plane = plane; a.div_pout = make_fastdiv(pout);
     const int64_t iters = (n + cb - 1) / cb;
     const int threads = 64 * (c.oc / 16);
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 2);
+    // two 256-thread blocks per CU (or four 128-thread blocks for the 32-channel layer)
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 2) * (c.oc >= 64 ? 1 : 64 / c.oc);
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_mfma_kernel<IC, KW, STRIDE>;

@@ -135,7 +135,10 @@ struct FrontSeqArgs {
     int o_map, o_seq, o_code, o_pidx, o_u, per_chunk;  // LDS offsets (in 4-byte words) per chunk
 };
 
-template <int KW>
+// DIRECT = true skips the per-base table U and sums the KW*K gather rows per output position
+// (3x the LDS gathers, but no U buffer: with KW = 11 the U rows would cost 15 KB of LDS per chunk
+// and leave two waves per CU; the direct form keeps 16+ waves resident).
+template <int KW, bool DIRECT>
 __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     float *s_u = cbase + a.o_u;  // [(maxlen+1)][KW][16], row `maxlen` = zeros
 
     for (int i = tid; i < wt_words; i += blockDim.x) s_wt[i] = a.wt5[i];
-    for (int i = sub; i < KW * 16; i += 32) s_u[(size_t)a.maxlen * KW * 16 + i] = 0.0f;
+    if (!DIRECT)
+        for (int i = sub; i < KW * 16; i += 32) s_u[(size_t)a.maxlen * KW * 16 + i] = 0.0f;
     const float4 bq = *reinterpret_cast<const float4 *>(a.b_seq1 + 4 * quad);
     __syncthreads();  // gather table visible to every wave
 
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
             }
         }
         wave_sync();
-        if (live) {
+        if (live && !DIRECT) {
             const int items = len * KW * 4;
             for (int i = sub; i < items; i += 32) {  // i & 3 == quad
                 const int pt = i >> 2;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
                 *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = acc;
             }
         }
-        wave_sync();
+        if (!DIRECT) wave_sync();
         if (live) {
             float *dst = a.seq1 + (size_t)chunk * a.P1 * 16;
             for (int i = sub; i < a.P1 * 4; i += 32) {
@@ -215,6 +219,19 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
 #pragma unroll
                 for (int t = 0; t < KW; ++t) {
                     const int p = s_pidx[pos + t];
+                    if (DIRECT) {
+                        if (p < a.maxlen) {
+                            unsigned long long wv = s_code[p];
+                            const float *wt = s_wt + (size_t)t * a.K * 80 + 4 * quad;
+                            for (int kp = 0; kp < a.K; ++kp) {
+                                const int b = (int)(wv & 7ull);
+                                wv >>= 3;
+                                const float4 v = *reinterpret_cast<const float4 *>(wt + (kp * 5 + b) * 16);
+                                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                            }
+                        }
+                        continue;
+                    }
                     const float4 v = *reinterpret_cast<const float4 *>(s_u + ((size_t)p * KW + t) * 16 + 4 * quad);
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
@@ -264,7 +281,8 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     a.o_seq = off; off += up4((seq_w + 3) / 4);
     a.o_code = off; off += up4(a.maxlen * 2);
     a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
-    a.o_u = off; off += (a.maxlen + 1) * kw * 16;
+    const bool direct = (kw == 11);
+    a.o_u = off; if (!direct) off += (a.maxlen + 1) * kw * 16;
     a.per_chunk = up4(off);
     const size_t fixed = (size_t)kw * K * 80 * 4;
     int cb = 8;
@@ -272,7 +290,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     const size_t lds = fixed + (size_t)cb * a.per_chunk * 4;
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "front_seq: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
     a.cb = cb;
-    auto kern = (kw == 5) ? front_seq_kernel<5> : front_seq_kernel<11>;
+    auto kern = (kw == 5) ? front_seq_kernel<5, false> : front_seq_kernel<11, true>;
     static bool attr_done[2] = {false, false};
     if (!attr_done[kw == 5 ? 0 : 1]) {
         RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -280,7 +298,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
         attr_done[kw == 5 ? 0 : 1] = true;
     }
     const int64_t iters = (n + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * 4;
+    int64_t grid = (int64_t)e->num_cus * (direct ? 8 : 4);
     if (grid > iters) grid = iters;
     ProfScope ps(e, K_FRONT_SEQ, st, true);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(32 * cb), lds, st, a);

@@ -279,18 +279,28 @@ int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits) {
 }
 
 // ---- Conv_w_ref head: flatten (channel-major, models/Conv_w_ref.py:59) + fc (:60) --------
-__global__ void fc_head_kernel(const float *m4, const float *w, const float *b, float *logits,
-                               int64_t n, int size, int t4, int num_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * num_out) return;
-    const int64_t ch = i / num_out;
-    const int o = (int)(i - ch * num_out);
+// one wavefront per chunk: coalesced read of the chunk's t4*size activations, per-lane partial
+// dot products for every class, butterfly reduction over the 64 lanes
+__global__ __launch_bounds__(256) void fc_head_kernel(const float *m4, const float *w, const float *b, float *logits,
+                                                      int64_t n, int size, int t4, int num_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= n) return;
     const float *src = m4 + (size_t)ch * t4 * size;  // channel-last [t4][size]
-    const float *wo = w + (size_t)o * size * t4;     // torch flatten index = c * t4 + t
-    float s = b[o];
-    for (int c = 0; c < size; ++c)
-        for (int t = 0; t < t4; ++t) s += wo[c * t4 + t] * src[t * size + c];
-    logits[i] = s;
+    const int total = t4 * size;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.0f;
+    for (int e = lane; e < total; e += 64) {
+        const float x = src[e];
+        const int t = e / size, c = e - t * size;  // torch flatten index = c * t4 + t
+        for (int o = 0; o < num_out; ++o) acc[o] += w[(size_t)o * total + c * t4 + t] * x;
+    }
+    for (int o = 0; o < num_out; ++o) {
+        float v = acc[o];
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if (lane == 0) logits[ch * num_out + o] = v + b[o];
+    }
 }
 
 int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits) {
@@ -298,7 +308,7 @@ int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits) {
     const int64_t total = n * m->desc.num_out;
     if (total == 0) return 0;
     ProfScope ps(e, K_FC_HEAD);
-    hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
+    hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, e->stream,
                        m4, m->w_fc, m->b_fc, logits, n, m->desc.size, m->T4, m->desc.num_out);
     RMR_HIP(hipGetLastError());
     return 0;
