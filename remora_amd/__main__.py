@@ -1,0 +1,44 @@
+"""`python -m remora_amd infer from_pod5_and_bam POD5 BAM --model MODEL.pt --out-bam OUT.bam`
+— the sub-command of the reference CLI that sits on the hot path (src/remora/parsers.py:1294-1417,
+:1582-1612), same positional arguments and the same meaning of --model / --out-bam / --device /
+--num-reads."""
+import argparse
+import sys
+
+from . import RemoraError
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="remora_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    infer = sub.add_parser("infer").add_subparsers(dest="sub", required=True)
+    p = infer.add_parser("from_pod5_and_bam", help="Infer modified bases from POD5 + BAM on an MI355X")
+    p.add_argument("pod5")
+    p.add_argument("in_bam")
+    p.add_argument("--model", required=True, help="TorchScript model file (with meta.txt)")
+    p.add_argument("--out-bam", required=True)
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--num-reads", type=int, default=None)
+    p.add_argument("--reads-per-batch", type=int, default=256)
+    p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")
+    args = ap.parse_args(argv)
+
+    from .inference import infer_from_pod5_and_bam
+    from .model_util import load_torchscript_model
+
+    try:
+        model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
+        stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
+                                        reads_per_batch=args.reads_per_batch)
+    except RemoraError as e:
+        print(f"remora_amd: {e}", file=sys.stderr)
+        return 1
+    ok = stats.pop(None, 0)
+    print(f"called {ok} reads -> {args.out_bam}")
+    for reason, cnt in sorted(stats.items(), key=lambda kv: -kv[1]):
+        print(f"{cnt:>7} : {reason}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -90,3 +90,60 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
     for o, l, p in zip(np.split(out, cuts), np.split(arrs.labels, cuts), np.split(pos, cuts)):
         res.append((o, l, p) if p.size else (np.array([]), np.array([]), np.array([])))
     return res
+
+
+def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
+                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True):
+    """`remora infer from_pod5_and_bam` for one model, basecall-anchored
+    (src/remora/inference.py:462-641): every input alignment is written to `out_bam_path` with
+    MM/ML tags from the model (records whose read cannot be called are written unchanged and
+    counted by reason, as the reference does).  Reads are grouped into batches that go through
+    ONE chunk extraction and ONE fused inference on the GPU.  Returns {reason: count, ...} with
+    the key None counting successfully called reads."""
+    from collections import Counter
+
+    from . import io as rio
+
+    if reverse_signal is None:
+        reverse_signal = bool(model_metadata.get("reverse_signal", False))
+    pa_scaling = model_metadata.get("pa_scaling")
+    stats = Counter()
+    header = rio.read_bam_header_bytes(in_bam_path)
+
+    def flush(batch, writer):
+        good = []
+        for io_read, err in batch:
+            if err is None:
+                try:
+                    good.append((io_read, io_read.into_remora_read(False)))
+                    continue
+                except RemoraError as e:
+                    err = f"Read prep error: {e}"
+            stats[err] += 1
+            writer.write(rio.record_with_mod_tags(io_read.record, None, None))
+        if not good:
+            return
+        results = call_reads_mods([rr for _, rr in good], model, model_metadata, return_mod_probs=True)
+        for (io_read, rr), (probs, _, pos) in zip(good, results):
+            if pos.size == 0:
+                stats[f"No {model_metadata['can_base']} mod calls"] += 1
+                writer.write(rio.record_with_mod_tags(io_read.record, None, None))
+                continue
+            mm, ml = format_mm_ml_tags(seq=io_read.seq, poss=pos, probs=probs, mod_bases=model_metadata["mod_bases"],
+                                       can_base=model_metadata["can_base"])
+            stats[None] += 1
+            writer.write(rio.record_with_mod_tags(io_read.record, mm, ml))
+
+    with rio.BamWriter(out_bam_path, header) as writer:
+        batch = []
+        for i, item in enumerate(rio.iter_reads_from_pod5_and_bam(pod5_path, in_bam_path, reverse_signal=reverse_signal,
+                                                                  pa_scaling=pa_scaling, skip_non_primary=skip_non_primary)):
+            if num_reads is not None and i >= num_reads:
+                break
+            batch.append(item)
+            if len(batch) >= reads_per_batch:
+                flush(batch, writer)
+                batch = []
+        if batch:
+            flush(batch, writer)
+    return dict(stats)

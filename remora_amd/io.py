@@ -58,6 +58,9 @@ class BamRecord:
     query_sequence: str
     query_qualities: bytes
     tags: list  # [(name, value)] in file order
+    raw: bytes = b""          # the record as stored (without the leading block_size)
+    tags_offset: int = 0      # byte offset of the tag region inside `raw`
+    tag_spans: list = None    # [(name, start, end)] byte spans inside the tag region
 
     @property
     def is_reverse(self):
@@ -87,10 +90,11 @@ class BamRecord:
                 "seq": self.query_sequence}
 
 
-def _parse_tags(buf):
+def _parse_tags(buf, spans=None):
     tags, p, n = [], 0, len(buf)
     scalar = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
     while p < n:
+        p0 = p
         name = buf[p : p + 2].decode()
         t = chr(buf[p + 2])
         p += 3
@@ -113,6 +117,8 @@ def _parse_tags(buf):
         else:
             raise RemoraError(f"unknown BAM tag type {t!r}")
         tags.append((name, val))
+        if spans is not None:
+            spans.append((name, p0, p))
     return tags
 
 
@@ -147,8 +153,9 @@ def iter_bam_records(bam_path):
         codes[0::2], codes[1::2] = sb >> 4, sb & 0xF
         seq = "".join(_SEQ_NT16[c] for c in codes[:l_seq])
         qual = bytes(rec[q : q + l_seq]); q += l_seq
+        spans = []
         yield BamRecord(name, flag, ref_id, refs[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq,
-                        qual, _parse_tags(rec[q:]))
+                        qual, _parse_tags(rec[q:], spans), bytes(rec), q, spans)
 
 
 def _vbz_decode(blob, n_samples):
@@ -260,6 +267,7 @@ class Read:
     scale_pa_to_zc_pa: float = None
     full_align: dict = None
     _child_read_id: str = None
+    record: object = None  # the BamRecord this read was aligned with (for output)
 
     @property
     def child_read_id(self):
@@ -302,6 +310,7 @@ class Read:
         if self.dacs is None:
             raise RemoraError("Must add signal to io.Read before alignment.")
         self.full_align = rec.to_dict()
+        self.record = rec
         tags = dict(rec.tags)
         if reverse_signal:
             self.dacs = self.dacs[::-1]
@@ -370,3 +379,77 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
             yield read, str(e)
             continue
         yield read, None
+
+
+# ---- BAM output: the reference writes `pysam.AlignedSegment.from_dict(
+# io_read.full_align)` = the input record + MM/ML tags (src/remora/inference.py:450, :619-623);
+# here the stored record bytes are copied, old MM/ML tags dropped, new ones appended, and the
+# stream is BGZF-compressed (gzip members <= 64 KiB with the BC extra field + EOF marker). ----
+import zlib
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def read_bam_header_bytes(bam_path):
+    """Everything before the first alignment record (magic, text header, reference list)."""
+    with gzip.open(bam_path, "rb") as fh:
+        data = fh.read()
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, p)[0]
+        p += 4 + l_name + 4
+    return data[:p]
+
+
+def record_with_mod_tags(rec, mm_tag, ml_tag):
+    """Record bytes (incl. block_size) of `rec` with any MM/ML/Mm/Ml tags replaced by the given
+    MM string / ML uint8 values (None = leave the record without modified-base tags)."""
+    tag_region = rec.raw[rec.tags_offset :]
+    kept = b"".join(tag_region[s:e] for name, s, e in rec.tag_spans if name not in ("MM", "ML", "Mm", "Ml"))
+    new = b""
+    if mm_tag is not None:
+        ml = np.asarray(ml_tag, dtype=np.uint8)
+        new = b"MMZ" + mm_tag.encode() + b"\x00" + b"MLBC" + struct.pack("<i", ml.size) + ml.tobytes()
+    body = rec.raw[: rec.tags_offset] + kept + new
+    return struct.pack("<i", len(body)) + body
+
+
+class BamWriter:
+    """Minimal BGZF/BAM writer: header bytes copied from the template BAM, records appended."""
+
+    def __init__(self, path, header_bytes):
+        self._fh = open(path, "wb")
+        self._buf = bytearray(header_bytes)
+
+    def _flush_block(self, chunk):
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = comp.compress(bytes(chunk)) + comp.flush()
+        bsize = len(cdata) + 25  # total block size - 1
+        self._fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize))
+        self._fh.write(cdata)
+        self._fh.write(struct.pack("<II", zlib.crc32(bytes(chunk)) & 0xFFFFFFFF, len(chunk)))
+
+    def write(self, record_bytes):
+        self._buf += record_bytes
+        while len(self._buf) >= 0xFF00:
+            self._flush_block(self._buf[:0xFF00])
+            del self._buf[:0xFF00]
+
+    def close(self):
+        if self._fh is None:
+            return
+        if self._buf:
+            self._flush_block(self._buf)
+            self._buf = bytearray()
+        self._fh.write(_BGZF_EOF)
+        self._fh.close()
+        self._fh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -590,3 +590,31 @@ def test_concurrent_calls_from_threads(torch_cuda, O):
     for i in range(len(args)):
         for rep in range(6):
             assert np.array_equal(got[i][rep], expect[i])
+
+
+def test_infer_from_pod5_and_bam_cli(torch_cuda, O, tmp_path):
+    """`python -m remora_amd infer from_pod5_and_bam` on the reference's test data: every input record
+    comes back with the MM/ML tags the reference's call_read_mods produces for that read."""
+    import subprocess
+    import sys
+
+    from remora_amd import io as rio
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = os.path.join(root, "tests", "golden", "data")
+    g = golden("real_reads_can.npz")
+    pt = _mint_pt(tmp_path, g, O)
+    out = str(tmp_path / "out.bam")
+    res = subprocess.run([sys.executable, "-m", "remora_amd", "infer", "from_pod5_and_bam", os.path.join(data, "can_reads.pod5"),
+                          os.path.join(data, "can_mappings.bam"), "--model", pt, "--out-bam", out, "--reads-per-batch", "5"],
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "called 14 reads" in res.stdout
+    recs = list(rio.iter_bam_records(out))
+    assert len(recs) == 14
+    for i, rec in enumerate(recs):
+        assert rec.query_name == str(g[f"r{i}_name"])
+        assert rec.get_tag("MM") == str(g[f"r{i}_mm"])
+        ml = np.asarray(list(rec.get_tag("ML")), int)
+        assert np.abs(ml - g[f"r{i}_ml"].astype(int)).max() <= 1
+        assert "mv" in dict(rec.tags)  # input tags are carried over

@@ -290,3 +290,30 @@ def test_bam_and_pod5_parsers_on_reference_test_data():
         seq = rio.revcomp(rec.query_sequence) if rec.is_reverse else rec.query_sequence
         assert seq == str(g[f"r{i}_seq"])
     assert rio.revcomp("ACGTN") == "NACGT"
+
+
+def test_bam_writer_roundtrip(tmp_path):
+    from remora_amd import io as rio
+
+    src = os.path.join(DATA, "can_mappings.bam")
+    recs = list(rio.iter_bam_records(src))
+    out = str(tmp_path / "rt.bam")
+    with rio.BamWriter(out, rio.read_bam_header_bytes(src)) as w:
+        for i, r in enumerate(recs):
+            w.write(rio.record_with_mod_tags(r, "C+m?,1,2;" if i % 2 == 0 else None, [10, 200] if i % 2 == 0 else None))
+    back = list(rio.iter_bam_records(out))
+    assert len(back) == len(recs)
+    for i, (b, r) in enumerate(zip(back, recs)):
+        assert (b.query_name, b.flag, b.reference_start, b.cigartuples, b.query_sequence) == \
+               (r.query_name, r.flag, r.reference_start, r.cigartuples, r.query_sequence)
+        got = [(k, list(v) if not isinstance(v, (str, int, float)) else v) for k, v in b.tags]
+        want = [(k, list(v) if not isinstance(v, (str, int, float)) else v) for k, v in r.tags]
+        if i % 2 == 0:
+            want += [("MM", "C+m?,1,2;"), ("ML", [10, 200])]
+        assert got == want
+    # re-tagging an already tagged record replaces, not duplicates
+    again = rio.record_with_mod_tags(back[0], "C+m?,5;", [7])
+    with rio.BamWriter(out, rio.read_bam_header_bytes(src)) as w:
+        w.write(again)
+    (only,) = list(rio.iter_bam_records(out))
+    assert [k for k, _ in only.tags].count("MM") == 1 and only.get_tag("MM") == "C+m?,5;" and list(only.get_tag("ML")) == [7]
