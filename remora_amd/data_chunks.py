@@ -309,3 +309,117 @@ class RemoraRead:
             labs.append(arrs.labels)
             poss.append(arrs.read_focus_bases.cpu().numpy())
         return np.concatenate(outs, axis=0), np.concatenate(labs), np.concatenate(poss)
+
+
+# =======================================================================================
+# On-disk chunk datasets (read side): the directory format of the
+# reference's CoreRemoraDataset (src/remora/data_chunks.py:926-1702) — `metadata.jsn` plus raw
+# C-contiguous memmaps `signal.npy` f32[N,1,L], `sequence.npy` i8[N,W], `sequence_to_signal_
+# mapping.npy` i16[N,W'], `sequence_lengths.npy` i16[N], `labels.npy` i64[N] (no .npy header,
+# :1280-1311).  Rows go to the GPU as they are; a smaller model context than the stored one is
+# applied per batch exactly as the reference does (trim_sb_kmer_context_bases :1512-1534,
+# trim_sb_chunk_context :1536-1576 -> the T1 kernel).
+# =======================================================================================
+import json
+import os
+
+DATASET_VERSION = 3
+
+
+class CoreRemoraDataset:
+    _core_dtypes = {"signal": np.float32, "sequence": np.int8, "sequence_to_signal_mapping": np.int16,
+                    "sequence_lengths": np.int16, "labels": np.int64}
+
+    def __init__(self, data_path, override_metadata=None, batch_size=2048):
+        self.data_path = data_path
+        self.batch_size = int(batch_size)
+        with open(os.path.join(data_path, "metadata.jsn")) as fh:
+            md = json.load(fh)
+        if md.get("version") != DATASET_VERSION:
+            raise RemoraError(f"Remora dataset version ({md.get('version')}) does not match current "
+                              f"distribution ({DATASET_VERSION})")
+        self.metadata = md
+        self.stored_chunk_context = tuple(md.get("_stored_chunk_context") or md["chunk_context"])
+        self.stored_kmer_context_bases = tuple(md.get("_stored_kmer_context_bases") or md["kmer_context_bases"])
+        self.chunk_context = tuple(md["chunk_context"])
+        self.kmer_context_bases = tuple(md["kmer_context_bases"])
+        for k, v in (override_metadata or {}).items():
+            if k == "chunk_context":
+                v = tuple(int(x) for x in v)
+                if v[0] > self.stored_chunk_context[0] or v[1] > self.stored_chunk_context[1]:
+                    raise RemoraError("Cannot expand chunk context beyond stored chunk context")
+                self.chunk_context = v
+            elif k == "kmer_context_bases":
+                v = tuple(int(x) for x in v)
+                if v[0] > self.stored_kmer_context_bases[0] or v[1] > self.stored_kmer_context_bases[1]:
+                    raise RemoraError("Cannot expand kmer context beyond stored kmer context")
+                self.kmer_context_bases = v
+            elif k in ("dataset_start", "dataset_end"):
+                md[k] = int(v)
+            else:
+                raise RemoraError(f"cannot override dataset metadata attribute {k!r}")
+        n, msl = int(md["allocate_size"]), int(md["max_seq_len"])
+        L = sum(self.stored_chunk_context)
+        shapes = {"signal": (n, 1, L), "sequence": (n, msl + sum(self.stored_kmer_context_bases)),
+                  "sequence_to_signal_mapping": (n, msl + 1), "sequence_lengths": (n,), "labels": (n,)}
+        self.arrays = {}
+        for name, dt in self._core_dtypes.items():
+            path = os.path.join(data_path, f"{name}.npy")
+            if os.path.getsize(path) != int(np.prod(shapes[name])) * np.dtype(dt).itemsize:
+                raise RemoraError(f"{path} does not have the size metadata.jsn implies")
+            self.arrays[name] = np.memmap(path, dt, mode="r", shape=shapes[name])
+
+    @property
+    def size(self):
+        return int(self.metadata["dataset_end"]) - int(self.metadata["dataset_start"])
+
+    @property
+    def chunk_len(self):
+        return sum(self.chunk_context)
+
+    def load_batch(self, st, en):
+        """Rows [st, en) of the dataset as writable numpy arrays, trimmed to the loaded contexts."""
+        from .data_chunks_core import trim_sb_chunk_context_core
+
+        a0 = int(self.metadata["dataset_start"])
+        b = {k: np.array(v[a0 + st : a0 + en]) for k, v in self.arrays.items()}
+        seq_diff = self.stored_kmer_context_bases[0] - self.kmer_context_bases[0]
+        if seq_diff > 0:  # :1512-1534 (the trailing trim happens in the encode via the smaller ka)
+            b["sequence"][:, :-seq_diff] = b["sequence"][:, seq_diff:].copy()
+        if self.chunk_context != self.stored_chunk_context:  # :1536-1576
+            st_diff = self.stored_chunk_context[0] - self.chunk_context[0]
+            new_en = self.stored_chunk_context[0] + self.chunk_context[1]
+            b["signal"] = np.ascontiguousarray(b["signal"][:, :, st_diff:new_en])
+            b["sequence_to_signal_mapping"] = (b["sequence_to_signal_mapping"] - st_diff).astype(np.int16)
+            trim_sb_chunk_context_core(*self.stored_chunk_context, *self.chunk_context,
+                                       sum(self.kmer_context_bases), b["sequence"],
+                                       b["sequence_to_signal_mapping"], b["sequence_lengths"])
+        return b
+
+    def iter_batches(self):
+        for st in range(0, self.size, self.batch_size):
+            yield self.load_batch(st, min(st + self.batch_size, self.size))
+
+    def get_label_counts(self):
+        a0, a1 = int(self.metadata["dataset_start"]), int(self.metadata["dataset_end"])
+        return np.bincount(self.arrays["labels"][a0:a1], minlength=len(self.metadata["mod_bases"]) + 1)
+
+
+def validate_dataset(dataset, model):
+    """Per-chunk calls for an on-disk dataset: logits through the fused path, argmax tally on the GPU
+    (label counts) and the confusion matrix against the stored labels — the numbers
+    `remora validate from_remora_dataset` derives (src/remora/validate.py:42-66, 190-259)."""
+    num_out = model.num_out
+    counts = np.zeros(num_out, np.int64)
+    conf = np.zeros((num_out, num_out), np.int64)
+    logits = []
+    for b in dataset.iter_batches():
+        out = model.infer_chunks(b["signal"], b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"],
+                                 dataset.kmer_context_bases, label_counts=counts)
+        pred = out.argmax(axis=1)
+        ok = (b["labels"] >= 0) & (b["labels"] < num_out)
+        np.add.at(conf, (b["labels"][ok], pred[ok]), 1)
+        logits.append(out)
+    logits = np.concatenate(logits) if logits else np.zeros((0, num_out), np.float32)
+    total = int(conf.sum())
+    return dict(logits=logits, pred_counts=counts, confusion=conf, acc=(np.trace(conf) / total) if total else float("nan"))

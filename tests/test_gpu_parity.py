@@ -618,3 +618,40 @@ def test_infer_from_pod5_and_bam_cli(torch_cuda, O, tmp_path):
         ml = np.asarray(list(rec.get_tag("ML")), int)
         assert np.abs(ml - g[f"r{i}_ml"].astype(int)).max() <= 1
         assert "mv" in dict(rec.tags)  # input tags are carried over
+
+
+@pytest.mark.parametrize("tag", ["stored", "trim", "trimcc", "trimk"])
+def test_core_dataset_on_disk(torch_cuda, O, tag):
+    """Memory-mapped CoreRemoraDataset directory written by the reference: rows (after the dynamic
+    k-mer / chunk-context trimming, which runs the T1 kernel) must encode to exactly what the
+    reference's own iteration produced, and the fused path must agree with the oracle forward."""
+    from oracle import torch_ref
+    from remora_amd.data_chunks import CoreRemoraDataset, validate_dataset
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    g = golden("core_dataset.npz")
+    override = json.loads(str(g[f"{tag}_override"]))
+    ddir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data", "core_dataset")
+    ds = CoreRemoraDataset(ddir, override_metadata=override, batch_size=64)
+    assert ds.size == int(g["num_chunks"]) == 120
+    sig, code, labs = [], [], []
+    for b in ds.iter_batches():
+        enc = compute_encoded_kmer_batch(*ds.kmer_context_bases, b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"])
+        sig.append(b["signal"]); labs.append(b["labels"]); code.append(enc)
+    assert np.array_equal(np.concatenate(sig).view(np.uint32), g[f"{tag}_signal"].view(np.uint32))
+    assert np.array_equal(np.concatenate(labs), g[f"{tag}_labels"])
+    assert np.array_equal(np.concatenate(code), code_to_onehot(g[f"{tag}_enc_code"]))
+    if ds.chunk_len == 100:  # a ConvLSTM for this context: fused path + tallies
+        K = sum(ds.kmer_context_bases) + 1
+        net = torch_ref.random_model("conv_lstm", 64, K, 2, seed=9)
+        state = {k: v.numpy() for k, v in net.state_dict().items()}
+        model = model_from_state(state, dict(chunk_context=ds.chunk_context, kmer_context_bases=ds.kmer_context_bases), device=0)
+        res = validate_dataset(ds, model)
+        with torch.no_grad():
+            ref = net(torch.from_numpy(np.concatenate(sig)), torch.from_numpy(np.concatenate(code))).numpy()
+        assert np.abs(res["logits"] - ref).max() <= 1e-4
+        assert np.array_equal(res["pred_counts"], np.bincount(ref.argmax(1), minlength=2))
+        assert res["confusion"].sum() == 120 and np.array_equal(res["confusion"].sum(0), res["pred_counts"])
+        assert np.array_equal(ds.get_label_counts(), np.bincount(g[f"{tag}_labels"], minlength=2))

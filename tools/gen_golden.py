@@ -13,6 +13,7 @@ stub modules, then `remora.*` is imported from the scratch copy and driven.
 Usage:  python tools/gen_golden.py [--out tests/golden]
 """
 import argparse
+import json
 import os
 import shutil
 import subprocess
@@ -707,6 +708,67 @@ def gen_real_reads(R, out):
     print("real_reads:", len(recs), "records,", sum(int(d[f"r{i}_pos"].size) for i in range(len(recs))), "chunks")
 
 
+def gen_core_dataset(R, out):
+    """On-disk CoreRemoraDataset (src/remora/data_chunks.py:926-1702) written by the reference from
+    two synthetic labelled reads (chunk_context (50,50), k-mer (4,4)), then read back by the
+    reference as stored AND with the dynamic overrides chunk_context (30,25) / k-mer (2,3), which
+    drive trim_sb_kmer_context_bases (:1512-1534), trim_sb_chunk_context (:1536-1576) and
+    extract_batch (:1652-1676).  The dataset directory itself is committed as fixture data."""
+    import shutil
+
+    from remora.refine_signal_map import SigMapRefiner
+
+    rng = np.random.default_rng(21)
+    ddir = os.path.join(out, "data", "core_dataset")
+    shutil.rmtree(ddir, ignore_errors=True)
+    os.makedirs(ddir)
+    chunks = []
+    for ri in range(2):
+        dacs, s2s, int_seq = synth_read(rng, 900 + 300 * ri)
+        labels = rng.integers(0, 2, int_seq.size).astype(np.int64)
+        read = R.data_chunks.RemoraRead(dacs=dacs, shift=500.0, scale=80.0, seq_to_sig_map=s2s, int_seq=int_seq,
+                                        read_id=f"ds{ri}", labels=labels)
+        read.set_motif_focus_bases([R.util.Motif("CG", 0)])
+        chunks += list(read.iter_chunks((50, 50), (4, 4), False, 0))
+    md = R.data_chunks.DatasetMetadata(
+        allocate_size=len(chunks) + 7, max_seq_len=20, mod_bases=["m"], mod_long_names=["5mC"],
+        motif_sequences=["CG"], motif_offsets=[0], chunk_context=(50, 50), kmer_context_bases=(4, 4),
+        sig_map_refiner=SigMapRefiner())
+    ds = R.data_chunks.CoreRemoraDataset(data_path=ddir, mode="w", metadata=md)
+    kept = 0
+    for c in chunks:
+        if c.seq_len <= 20:
+            ds.write_chunk(c)
+            kept += 1
+    ds.write_metadata()
+    ds.flush()
+    ds.close_memmaps()
+    d = {"num_chunks": np.asarray(kept)}
+    for tag, override in (("stored", None),
+                          ("trim", {"chunk_context": (30, 25), "kmer_context_bases": (2, 3)}),
+                          ("trimcc", {"chunk_context": (40, 50)}),
+                          ("trimk", {"kmer_context_bases": (4, 1)})):
+        rd = R.data_chunks.CoreRemoraDataset(data_path=ddir, mode="r", override_metadata=override, batch_size=64,
+                                             super_batch_size=160, infinite_iter=False)
+        sigs, codes, labs = [], [], []
+        for batch in rd:
+            enc = batch["enc_kmers"]
+            K = enc.shape[1] // 4
+            n, L = enc.shape[0], enc.shape[2]
+            e4 = enc.reshape(n, K, 4, L)
+            codes.append(np.where(e4.sum(2) > 0, e4.argmax(2), -1).astype(np.int8))
+            sigs.append(batch["signal"])
+            labs.append(batch["labels"])
+        d[f"{tag}_signal"] = np.concatenate(sigs)
+        d[f"{tag}_enc_code"] = np.concatenate(codes)
+        d[f"{tag}_labels"] = np.concatenate(labs)
+        d[f"{tag}_override"] = np.asarray(json.dumps(override))
+        print("core_dataset", tag, d[f"{tag}_signal"].shape, d[f"{tag}_enc_code"].shape)
+    np.savez_compressed(os.path.join(out, "core_dataset.npz"), **d)
+    print(open(os.path.join(ddir, "metadata.jsn")).read()[:900])
+    print(sorted(os.listdir(ddir)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -726,6 +788,7 @@ def main():
         post=gen_post,
         dataset_batches=gen_dataset_batches,
         real_reads=gen_real_reads,
+        core_dataset=gen_core_dataset,
     )
     for name, fn in gens.items():
         if args.only and name not in args.only.split(","):
