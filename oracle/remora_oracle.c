@@ -354,3 +354,141 @@ ORC_API int orc_forward(int arch, int size, int kmer_len, int num_out, int L,
     free(a); free(b); free(cat);
     return 0;
 }
+
+/* ====================================================================================
+ * N2  signal-mapping refinement core (banded dynamic programming).
+ *     reference: src/remora/refine_signal_map_core.pyx
+ *       adjust_seq_band :31-74, extract_levels :87-101, banded_traceback :119-148,
+ *       banded_forward_dwell_penalty_step :150-253, banded_forward_vit_step :256-317,
+ *       banded_forward_dp :320-400, seq_banded_dp :403-473
+ *     All score arithmetic is float32, one operation per rounding (no fused multiply-add),
+ *     comparisons strict '<' exactly as in the reference, so paths are reproduced bit for bit.
+ * ==================================================================================== */
+#define ORC_LARGE_SCORE 100.0f
+
+ORC_API void orc_adjust_seq_band(int32_t *band, int n, int min_step) {
+    int32_t *lo = band, *hi = band + n;
+    const int32_t band_min = lo[0];
+    for (int p = n - 2; p >= 0; --p)
+        if (lo[p] > lo[p + 1] - min_step) lo[p] = lo[p + 1] - min_step;
+    lo[0] = band_min;
+    int p = 1;
+    while (lo[p] <= lo[p - 1]) { lo[p] = lo[p - 1] + 1; p++; }
+    const int32_t band_max = hi[n - 1];
+    for (p = 1; p < n; ++p)
+        if (hi[p] < hi[p - 1] + min_step) hi[p] = hi[p - 1] + min_step;
+    hi[n - 1] = band_max;
+    p = n - 2;
+    while (hi[p] >= hi[p + 1]) { hi[p] = hi[p + 1] - 1; p--; }
+}
+
+ORC_API void orc_extract_levels(const int32_t *int_seq, int n, const float *kmer_levels, int kmer_len,
+                                int center_idx, float *levels) {
+    for (int i = 0; i < n; ++i) levels[i] = 0.0f;
+    for (int pos = 0; pos < n - kmer_len + 1; ++pos) {
+        int idx = 0, mul = 1;
+        for (int kp = 0; kp < kmer_len; ++kp) { idx += int_seq[pos + kmer_len - kp - 1] * mul; mul *= 4; }
+        levels[pos + center_idx] = kmer_levels[idx];
+    }
+}
+
+static float orc_sq(float s, float l) { const float t = s - l; return t * t; }
+
+/* prev has prev_n entries, curr/cur_sig have bw entries; follows :256-317 */
+static void orc_vit_step(float *curr, int32_t *tb, const float *prev, int prev_n, float level,
+                         const float *sig, int bw, int bsd) {
+    if (bsd == 0) {
+        curr[0] = ORC_LARGE_SCORE + prev[prev_n - 1];
+        tb[0] = -1;
+    } else {
+        curr[0] = prev[bsd - 1] + orc_sq(level, sig[0]);
+        tb[0] = 0;
+        prev += bsd; prev_n -= bsd;
+    }
+    if (prev_n == bw) prev_n -= 1;
+    for (int b = 1; b < prev_n + 1; ++b) {
+        const float base = orc_sq(level, sig[b]);
+        const float move = prev[b - 1] + base, stay = curr[b - 1] + base;
+        if (move < stay) { curr[b] = move; tb[b] = 0; }
+        else { curr[b] = stay; tb[b] = tb[b - 1] + 1; }
+    }
+    for (int b = prev_n + 1; b < bw; ++b) {
+        curr[b] = curr[b - 1] + orc_sq(level, sig[b]);
+        tb[b] = tb[b - 1] + 1;
+    }
+}
+
+/* follows :150-253 */
+static void orc_dwell_step(float *curr, int32_t *tb, const float *prev, int prev_n, float level,
+                           const float *sig, int bw, int bsd, const float *sdp, int d,
+                           float *unpen, int32_t *unpen_tb) {
+    orc_vit_step(unpen, unpen_tb, prev, prev_n, level, sig, bw, bsd);
+    for (int b = 0; b < bw; ++b) {
+        if (b + bsd - prev_n >= d) {
+            curr[b] = curr[b - 1] + orc_sq(level, sig[b]);
+            tb[b] = tb[b - 1] + 1;
+            continue;
+        }
+        curr[b] = ORC_LARGE_SCORE + prev[prev_n - 1];
+        tb[b] = -1;
+        if (b == 0 && bsd == 0) continue;
+        float run = 0.0f;
+        for (int di = 0; di < d; ++di) {
+            if (di > b || (bsd == 0 && b == di)) break;
+            run += orc_sq(level, sig[b - di]);
+            if (b - di - 1 + bsd >= prev_n) continue;
+            const float ps = prev[b - di - 1 + bsd] + run + sdp[di];
+            if (ps < curr[b]) { curr[b] = ps; tb[b] = di; }
+        }
+        if (b >= d) {
+            const float ps = unpen[b - d] + run;
+            if (ps < curr[b]) { curr[b] = ps; tb[b] = unpen_tb[b - d] + d; }
+        }
+    }
+}
+
+/* seq_band: [2][n] (lower row then upper row); base_offsets: [n+1] (uint32 in the reference);
+ * all_scores / traceback: [band_len]; path: [n+1].  method 0 = Viterbi, 1 = dwell_penalty.
+ * returns 0, or -1 on allocation failure. */
+ORC_API int orc_seq_banded_dp(const float *signal, const float *levels, int n, const int32_t *seq_band,
+                              const float *sdp, int d, int method, float *all_scores, int32_t *path,
+                              int32_t *traceback, uint32_t *base_offsets) {
+    const int32_t *lo = seq_band, *hi = seq_band + n;
+    base_offsets[0] = 0;
+    int maxbw = 0;
+    for (int b = 0; b < n; ++b) {
+        base_offsets[b + 1] = base_offsets[b] + (uint32_t)(hi[b] - lo[b]);
+        if (hi[b] - lo[b] > maxbw) maxbw = hi[b] - lo[b];
+    }
+    float *unpen = (float *)malloc((size_t)(maxbw + 1) * sizeof(float));
+    int32_t *unpen_tb = (int32_t *)malloc((size_t)(maxbw + 1) * sizeof(int32_t));
+    int bw = hi[0];
+    float *spoof = (float *)malloc((size_t)(bw + 1) * sizeof(float));
+    if (!unpen || !unpen_tb || !spoof) return -1;
+    for (int i = 0; i < bw; ++i) spoof[i] = HUGE_VALF;
+    spoof[0] = 0.0f;
+    if (method == 0) orc_vit_step(all_scores, traceback, spoof, bw, levels[0], signal, bw, 1);
+    else orc_dwell_step(all_scores, traceback, spoof, bw, levels[0], signal, bw, 1, sdp, d, unpen, unpen_tb);
+    int prev_bw = bw, prev_st = 0;
+    uint32_t prev_off = 0;
+    for (int b = 1; b < n; ++b) {
+        const int st = lo[b], en = hi[b];
+        bw = en - st;
+        const uint32_t off = base_offsets[b];
+        if (method == 0)
+            orc_vit_step(all_scores + off, traceback + off, all_scores + prev_off, prev_bw, levels[b], signal + st, bw, st - prev_st);
+        else
+            orc_dwell_step(all_scores + off, traceback + off, all_scores + prev_off, prev_bw, levels[b], signal + st, bw,
+                           st - prev_st, sdp, d, unpen, unpen_tb);
+        prev_st = st; prev_bw = bw; prev_off = off;
+    }
+    /* traceback :119-148 */
+    path[0] = 0;
+    path[n] = hi[n - 1];
+    for (int b = n - 1; b > 0; --b) {
+        const int look = path[b + 1] - 1;
+        path[b] = look - traceback[base_offsets[b] + look - lo[b]];
+    }
+    free(unpen); free(unpen_tb); free(spoof);
+    return 0;
+}

@@ -180,3 +180,54 @@ def test_prepare_batches_golden():
     enc = O.compute_encoded_kmer_batch(4, 4, ch["sequence"], ch["sequence_to_signal_mapping"],
                                        ch["sequence_lengths"])
     assert np.array_equal(enc, code_to_onehot(g["enc_code"]))
+
+
+# ---------------------------------------------------------------------------------------
+# N2: signal-mapping refinement (refine_signal_map.py / refine_signal_map_core.pyx)
+# ---------------------------------------------------------------------------------------
+
+REFINE_READS = ["a", "b", "c", "d"]
+
+
+def _refine_golden():
+    return golden("refine_signal_map.npz")
+
+
+@pytest.mark.parametrize("name", REFINE_READS)
+def test_refine_levels_and_bands(name):
+    g = _refine_golden()
+    lv = O.extract_levels(g[f"{name}_int_seq"], g["kmer_levels"], int(g["center_idx"]))
+    np.testing.assert_array_equal(lv, g[f"{name}_levels"])
+    for hbw in (5, 2):
+        band = O.convert_to_seq_band(O.compute_sig_band(g[f"{name}_map"], lv, hbw))
+        np.testing.assert_array_equal(band, g[f"{name}_hbw{hbw}_band_raw"])
+        band = np.ascontiguousarray(band, np.int32)
+        O.lib().orc_adjust_seq_band(O._p(band), band.shape[1], 2)
+        np.testing.assert_array_equal(band, g[f"{name}_hbw{hbw}_band"])
+
+
+@pytest.mark.parametrize("algo", ["Viterbi", "dwell_penalty"])
+@pytest.mark.parametrize("name", REFINE_READS)
+def test_refine_banded_dp(name, algo):
+    g = _refine_golden()
+    sig = ((g[f"{name}_dacs"] - 505.0) / 83.0).astype(np.float32)
+    for hbw in (5, 2):
+        pre = f"{name}_hbw{hbw}_{algo}_"
+        scores, path, tb, _ = O.seq_banded_dp(sig, g[f"{name}_levels"], g[f"{name}_hbw{hbw}_band"], g["sd_arr"], algo)
+        np.testing.assert_array_equal(path, g[pre + "path"])
+        if pre + "scores" in g:
+            np.testing.assert_array_equal(scores, g[pre + "scores"])  # bit-exact fp32 recurrence
+            np.testing.assert_array_equal(tb, g[pre + "tb"])
+
+
+def test_refine_read_flow():
+    g = _refine_golden()
+    settings = json.loads(str(g["settings_json"]))
+    for si, st in enumerate(settings):
+        ref = dict(st, levels=g["kmer_levels"], center_idx=int(g["center_idx"]), sd_arr=g["sd_arr"])
+        for name in REFINE_READS:
+            np.random.seed(1000 + si)
+            s2s, shift, scale = O.refine_read(ref, g[f"{name}_dacs"], 505.0, 83.0, g[f"{name}_map"].copy(),
+                                                   g[f"{name}_int_seq"])
+            np.testing.assert_array_equal(s2s, g[f"s{si}_{name}_map"], err_msg=f"setting {si} read {name}")
+            np.testing.assert_allclose([shift, scale], g[f"s{si}_{name}_shift_scale"], rtol=1e-12)

@@ -769,6 +769,87 @@ def gen_core_dataset(R, out):
     print(sorted(os.listdir(ddir)))
 
 
+def synth_levels_read(rng, levels_arr, kmer_len, center_idx, nbases, noise=0.25, stall_every=0):
+    """A read whose signal follows a k-mer level table: per base level + N(0, noise), dwell
+    U[4,16] (optionally a long stall), DAC = 500 + 80 * norm, then a deliberately wrong
+    (shift, scale) and a jittered mapping so that refinement has work to do."""
+    int_seq = rng.integers(0, 4, nbases).astype(np.int64)
+    lv = np.zeros(nbases, np.float32)
+    for pos in range(nbases - kmer_len + 1):
+        idx = 0
+        for b in int_seq[pos : pos + kmer_len]:
+            idx = idx * 4 + int(b)
+        lv[pos + center_idx] = levels_arr[idx]
+    dwell = rng.integers(4, 17, nbases)
+    if stall_every:
+        dwell[stall_every::stall_every] = rng.integers(150, 400, dwell[stall_every::stall_every].size)
+    true_map = np.concatenate([[0], np.cumsum(dwell)]).astype(np.int64)
+    norm = np.repeat(lv, dwell) + noise * rng.standard_normal(true_map[-1])
+    dacs = np.round(500 + 80 * norm).astype(np.int16)
+    jit = true_map.copy()
+    jit[1:-1] += rng.integers(-3, 4, nbases - 1)
+    jit = np.maximum.accumulate(np.clip(jit, 0, true_map[-1]))
+    jit[0], jit[-1] = 0, true_map[-1]
+    return dacs, jit, int_seq
+
+
+def gen_refine(R, out):
+    """Signal-mapping refinement: refine_signal_map_core.pyx (adjust_seq_band :31-74, extract_levels
+    :87-101, seq_banded_dp :403-473) and SigMapRefiner.rough_rescale / refine_sig_map
+    (refine_signal_map.py:366-408, :472-497) as driven by RemoraRead.refine_signal_mapping
+    (data_chunks.py:267-308)."""
+    from remora.refine_signal_map import (SigMapRefiner, compute_sig_band, convert_to_seq_band,
+                                          refine_signal_mapping)
+    from remora.refine_signal_map_core import adjust_seq_band, extract_levels, seq_banded_dp
+
+    rng = np.random.default_rng(23)
+    kmer_len, center = 5, 2
+    levels_arr = rng.normal(0, 1, 4**kmer_len).astype(np.float32)
+    d = {"kmer_levels": levels_arr, "center_idx": np.asarray(center)}
+    reads = [("a", 400, 0.25, 0), ("b", 1500, 0.4, 0), ("c", 260, 0.15, 60), ("d", 40, 0.2, 0)]
+    d["read_names"] = np.asarray([r[0] for r in reads])
+    # function level: one DP per read and algorithm
+    for name, nb, noise, stall in reads:
+        dacs, s2s, int_seq = synth_levels_read(rng, levels_arr, kmer_len, center, nb, noise, stall)
+        d[f"{name}_dacs"], d[f"{name}_map"], d[f"{name}_int_seq"] = dacs, s2s, int_seq
+        lv = extract_levels(int_seq.astype(np.int32), levels_arr, kmer_len, center)
+        d[f"{name}_levels"] = lv
+        sig = ((dacs - 505.0) / 83.0).astype(np.float32)
+        for hbw in (5, 2):
+            band = convert_to_seq_band(compute_sig_band(s2s, lv, bhw=hbw))
+            d[f"{name}_hbw{hbw}_band_raw"] = band.copy()
+            adjust_seq_band(band, min_step=2)
+            d[f"{name}_hbw{hbw}_band"] = band
+            for algo in ("Viterbi", "dwell_penalty"):
+                sdp = SigMapRefiner().sd_arr
+                scores, path, tb, offs = seq_banded_dp(sig, lv, band, sdp, algo)
+                pre = f"{name}_hbw{hbw}_{algo}_"
+                d[pre + "path"] = np.asarray(path)
+                if name != "b":  # keep the fixture small: full score/traceback bands for the short reads only
+                    d[pre + "scores"], d[pre + "tb"] = np.asarray(scores), np.asarray(tb)
+        d["sd_arr"] = np.asarray(SigMapRefiner().sd_arr, np.float32)
+    # object level: RemoraRead.refine_signal_mapping with several refiner settings
+    settings = [
+        dict(do_rough_rescale=True, scale_iters=0, algo="dwell_penalty", half_bandwidth=5, rough_rescale_method="least_squares"),
+        dict(do_rough_rescale=True, scale_iters=-1, algo="dwell_penalty", half_bandwidth=5, rough_rescale_method="theil_sen"),
+        dict(do_rough_rescale=False, scale_iters=0, algo="Viterbi", half_bandwidth=3, rough_rescale_method="least_squares"),
+        dict(do_rough_rescale=True, scale_iters=2, algo="dwell_penalty", half_bandwidth=5, rough_rescale_method="least_squares"),
+    ]
+    d["settings_json"] = np.asarray(json.dumps(settings))
+    for si, st in enumerate(settings):
+        ref = SigMapRefiner(_levels_array=levels_arr, center_idx=center, **st)
+        for name, nb, noise, stall in reads:
+            np.random.seed(1000 + si)
+            read = R.data_chunks.RemoraRead(dacs=d[f"{name}_dacs"], shift=505.0, scale=83.0, seq_to_sig_map=d[f"{name}_map"].copy(),
+                                            int_seq=d[f"{name}_int_seq"], read_id=name)
+            read.refine_signal_mapping(ref)
+            d[f"s{si}_{name}_map"] = np.asarray(read.seq_to_sig_map, np.int64)
+            d[f"s{si}_{name}_shift_scale"] = np.asarray([read.shift, read.scale], np.float64)
+    np.savez_compressed(os.path.join(out, "refine_signal_map.npz"), **d)
+    print("refine: done;", "moved", int((d["s0_b_map"] != d["b_map"]).sum()), "of", d["b_map"].size, "breakpoints in read b;",
+          "shift/scale", d["s0_b_shift_scale"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -789,6 +870,7 @@ def main():
         dataset_batches=gen_dataset_batches,
         real_reads=gen_real_reads,
         core_dataset=gen_core_dataset,
+        refine=gen_refine,
     )
     for name, fn in gens.items():
         if args.only and name not in args.only.split(","):
