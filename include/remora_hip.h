@@ -186,6 +186,48 @@ int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int 
 int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
                      int64_t *counts, int mem);
 
+/* ---- N2: signal-mapping refinement (banded dynamic programming) --------------------------- */
+/* replaces, for a batch of reads, the body of refine_signal_mapping
+ * (src/remora/refine_signal_map.py:780-840) as called by SigMapRefiner.refine_sig_map (:472-497):
+ * extract_levels (src/remora/refine_signal_map_core.pyx:87-101), compute_sig_band (.py:631-683),
+ * convert_to_seq_band (.py:740-772), adjust_seq_band (core.pyx:31-74), validate_band (.py:686-737),
+ * the signal normalisation (dacs - shift) / scale (f64, cast to f32, .py:479), and seq_banded_dp
+ * (core.pyx:403-473) with either forward step (Viterbi core.pyx:256-317, dwell penalty :150-253)
+ * and the traceback (:119-148).  Scores are float32 with the reference's operation order, so the
+ * returned paths equal the reference's. */
+enum rmr_refine_algo { RMR_REFINE_VITERBI = 0, RMR_REFINE_DWELL_PENALTY = 1 };
+enum rmr_refine_status {   /* per read; > 0 are the RemoraError cases of validate_band */
+    RMR_REFINE_OK = 0,
+    RMR_REFINE_BAND_START = 1,   /* "Band does not start with 0 coordinate." */
+    RMR_REFINE_ZERO_LEN = 2,     /* "Band contains 0-length region" */
+    RMR_REFINE_START_ORDER = 3,  /* "Band start positions are not monotonically increasing" */
+    RMR_REFINE_END_ORDER = 4,    /* "Band end positions are not monotonically increasing" */
+    RMR_REFINE_BAND_END = 5,     /* "Invalid seq_band end coordinate" */
+    RMR_REFINE_BAND_LENGTH = 6,  /* "Invalid sig_band length" */
+    RMR_REFINE_EMPTY = 7         /* read without bases */
+};
+typedef struct {
+    const float *kmer_levels;   /* host, f32[4^kmer_len], index = sum base_j * 4^(kmer_len-1-j); no NaN */
+    int32_t kmer_len, center_idx;
+    const float *sd_arr;        /* host, short dwell penalties (SigMapRefiner.sd_arr); dwell_penalty only */
+    int32_t sd_len;
+    int32_t algo;               /* rmr_refine_algo */
+    int32_t half_bandwidth;     /* SigMapRefiner.half_bandwidth */
+    int32_t min_step;           /* adjust_band_min_step (2 in the reference) */
+} rmr_refine_desc;
+typedef struct rmr_refiner rmr_refiner;
+
+int rmr_refiner_create(rmr_engine *e, const rmr_refine_desc *desc, rmr_refiner **out);
+void rmr_refiner_destroy(rmr_refiner *r);
+const char *rmr_refine_status_message(int status);
+/* Reads are concatenated exactly as in rmr_reads (dacs / sig_off / seq_to_sig / int_seq / seq_off /
+ * shift / scale).  out_map has the layout of seq_to_sig and receives the refined mapping of every
+ * read whose status is 0 (other reads are left untouched); status i32[n_reads]. */
+int rmr_refine_signal_maps(rmr_refiner *r, int64_t n_reads, const int16_t *dacs, const int64_t *sig_off,
+                           const int64_t *seq_to_sig, const int8_t *int_seq, const int64_t *seq_off,
+                           const double *shift, const double *scale, int64_t *out_map, int32_t *status,
+                           int mem);
+
 /* ---- measurement: HIP-event timing of every kernel launch on the engine stream ----------- */
 int rmr_profile_enable(rmr_engine *e, int on);
 int rmr_profile_reset(rmr_engine *e);

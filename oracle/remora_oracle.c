@@ -373,13 +373,14 @@ ORC_API void orc_adjust_seq_band(int32_t *band, int n, int min_step) {
         if (lo[p] > lo[p + 1] - min_step) lo[p] = lo[p + 1] - min_step;
     lo[0] = band_min;
     int p = 1;
-    while (lo[p] <= lo[p - 1]) { lo[p] = lo[p - 1] + 1; p++; }
+    /* the reference has no bound here (boundscheck off: undefined past the row); stop at n */
+    while (p < n && lo[p] <= lo[p - 1]) { lo[p] = lo[p - 1] + 1; p++; }
     const int32_t band_max = hi[n - 1];
     for (p = 1; p < n; ++p)
         if (hi[p] < hi[p - 1] + min_step) hi[p] = hi[p - 1] + min_step;
     hi[n - 1] = band_max;
     p = n - 2;
-    while (hi[p] >= hi[p + 1]) { hi[p] = hi[p + 1] - 1; p--; }
+    while (p >= 0 && hi[p] >= hi[p + 1]) { hi[p] = hi[p + 1] - 1; p--; }
 }
 
 ORC_API void orc_extract_levels(const int32_t *int_seq, int n, const float *kmer_levels, int kmer_len,

@@ -57,6 +57,9 @@ enum KernelId {
     K_LSTM_HEAD,
     K_FC_HEAD,
     K_COUNT,
+    K_REFINE_BAND,
+    K_REFINE_DP,
+    K_REFINE_ROWWISE,
     K_NUM
 };
 const char *kernel_name(int id);

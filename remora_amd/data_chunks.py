@@ -224,12 +224,21 @@ class RemoraRead:
             focus_bases=None if self.focus_bases is None else self.focus_bases.copy())
 
     def refine_signal_mapping(self, sig_map_refiner, check_read=False):
-        """No-op unless the model carries a k-mer level table (:267-308).  Refinement itself is
-        a 'next' row and not part of this engine yet."""
+        """Re-scale and re-map the read against the k-mer level table of the model (:267-308);
+        no-op for refiners without a table.  The banded DP runs on the GPU
+        (remora_amd.refine_signal_map.SigMapRefiner.refine_sig_map)."""
         if sig_map_refiner is None or not getattr(sig_map_refiner, "is_loaded", False):
             return
-        raise RemoraError("signal-mapping refinement (SigMapRefiner with a k-mer table) is not "
-                          "implemented in remora_amd yet")
+        if sig_map_refiner.do_rough_rescale:
+            self.shift, self.scale = sig_map_refiner.rough_rescale(
+                self.shift, self.scale, self.seq_to_sig_map, self.int_seq, self.dacs)
+            self._sig = None
+        if sig_map_refiner.scale_iters >= 0:
+            self.seq_to_sig_map, self.shift, self.scale = sig_map_refiner.refine_sig_map(
+                self.shift, self.scale, self.seq_to_sig_map, self.int_seq, self.dacs)
+            self._sig = None
+        if check_read:
+            self.check()
 
     def set_motif_focus_bases(self, motifs):
         """:310-317"""

@@ -72,8 +72,12 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
 
     motifs = [Motif(*m) for m in model_metadata["motifs"]]
     focus = find_focus_bases_batch(reads, motifs)
+    refiner = model_metadata.get("sig_map_refiner")
+    if refiner is not None and getattr(refiner, "is_loaded", False):
+        for err in refiner.refine_reads(reads):  # one GPU pass per DP round for the whole batch
+            if err is not None:
+                raise err
     for r, fb in zip(reads, focus):
-        r.refine_signal_mapping(model_metadata.get("sig_map_refiner"))
         r.focus_bases = fb
     arrs, _ = extract_chunk_arrays(reads, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
                                    model_metadata["base_start_justify"], model_metadata["offset"])
