@@ -23,6 +23,7 @@
 //     refine_dp_rowwise_kernel, a row-by-row evaluation in global memory.
 //   * the traceback is a pointer chase over the int32 traceback band (L2 resident).
 #pragma clang fp contract(off)
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -34,13 +35,15 @@ struct rmr_refiner {
     float *d_levels = nullptr;  // [4^kmer_len]
     float *d_sdp = nullptr;     // [sd_len]
     int kmer_len = 0, center_idx = 0, sd_len = 0, algo = 1, hbw = 5, min_step = 2;
+    uint32_t *d_ckpt = nullptr;  // checkpoints of the persistent DP waves (dwell penalty only)
+    int *d_counter = nullptr;    // work counter of the persistent DP waves
+    int max_grid = 0;
 };
 
 namespace rmr {
 namespace {
 
 constexpr float kLargeScore = 100.0f;  // refine_signal_map_core.pyx:22
-constexpr int kRing = 256;             // staged row parameters per wave (power of two)
 constexpr int kMaxD = 6;               // longest short-dwell penalty array on the register path
 
 struct RefineReads {
@@ -55,9 +58,9 @@ struct RefineScratch {
     float *lv;             // [total_bases]  expected level of each base
     uint32_t *tboff;       // [total_bases]  offset of each row in the read's traceback band
     int64_t *band_len;     // [n_reads]
-    int64_t *tb_base;      // [n_reads]      offset of the read's band in `tb`
     int32_t *status;       // [n_reads]      0 ok, >0 rmr_refine_status, <0 needs the row-wise kernel
-    int32_t *tb;           // traceback bands
+    int32_t *maxwin;       // [n_reads]      most rows that share one sample
+    int32_t *tb;           // traceback bands of the reads in flight (one region per lane group of a wave)
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(64) void refine_band_kernel(RefineReads a, RefineSc
     int n = (int)(a.seq_off[r + 1] - q0);
     const int64_t *m = a.s2s + q0 + r;
     int32_t *lo = w.lo + q0, *hi = w.hi + q0;
-    if (lane == 0) { w.band_len[r] = 0; w.status[r] = 0; }
+    if (lane == 0) { w.band_len[r] = 0; w.status[r] = 0; w.maxwin[r] = 0; }
     if (n <= 0) { if (lane == 0) w.status[r] = RMR_REFINE_EMPTY; return; }
     const int64_t st = m[0];
     const int nsig = (int)(m[n] - st);
@@ -216,6 +219,20 @@ __global__ __launch_bounds__(64) void refine_band_kernel(RefineReads a, RefineSc
         total += tot;
     }
     bad = wave_max_i((bad & 1) ? 1 : 0) | (wave_max_i((bad & 2) ? 1 : 0) << 1) | (wave_max_i((bad & 4) ? 1 : 0) << 2);
+    // widest column: rows p..j share sample hi[p]-1 when lo[j] <= hi[p]-1 (lo is non-decreasing for valid bands)
+    int win = 0;
+    if (!bad) {
+        for (int p = lane; p < n; p += 64) {
+            const int last = hi[p] - 1;
+            int a0 = p, a1 = n - 1;  // largest j in [p, n) with lo[j] <= last
+            while (a0 < a1) {
+                const int mid = (a0 + a1 + 1) >> 1;
+                if (lo[mid] <= last) a0 = mid; else a1 = mid - 1;
+            }
+            win = max(win, a0 - p + 1);
+        }
+    }
+    win = wave_max_i(win);
     if (lane == 0) {
         int s = 0;
         if (lo[0] != 0) s = RMR_REFINE_BAND_START;
@@ -226,190 +243,330 @@ __global__ __launch_bounds__(64) void refine_band_kernel(RefineReads a, RefineSc
         else if (n != n_bases) s = RMR_REFINE_BAND_LENGTH;
         w.status[r] = s;
         w.band_len[r] = total;
+        w.maxwin[r] = win;
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // column-wise forward pass + traceback
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_ror1(float v) {
-    // lane l receives lane (l-1) & 63
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
-}
 __device__ __forceinline__ float readlane_f(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-__device__ void refine_traceback(const int32_t *__restrict__ lo, const uint32_t *__restrict__ tboff, const int32_t *tbr,
-                                 int64_t band_len, int n, int nsig, int64_t st, int64_t *out) {
-    // banded_traceback (core.pyx:119-148): path[n] = hi[n-1]; path[b] = look - tb[row b][look - lo[b]]
-    const int lane = threadIdx.x;
-    if (lane == 0) { out[0] = st; out[n] = st + nsig; }
+constexpr int kLT = 256;  // known "large score" terms remembered per read (direct mapped by row)
+constexpr int kCk = 8;    // checkpoints kept per wave: a replay can reach back kCk blocks of 64 samples
+
+// lane l receives the value of the previous lane of its W-lane group (wrapping inside the group)
+template <int W>
+__device__ __forceinline__ float rot1(float v) {
+    constexpr int ctrl = (W == 64) ? 0x13C /* wave_ror:1 */ : 0x121 /* row_ror:1 */;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+}
+
+// banded_traceback (core.pyx:119-148) for the read of each W-lane group:
+// path[n] = hi[n-1]; path[b] = look - tb[row b][look - lo[b]], look = path[b+1] - 1
+template <int W>
+__device__ void refine_traceback(bool valid, const int32_t *__restrict__ lo, const uint32_t *__restrict__ tboff,
+                                 const int32_t *tbr, int64_t band_len, int n, int nsig, int64_t st, int64_t *out) {
+    const int lane = threadIdx.x, gl = lane % W, gbase = lane - gl;
+    if (valid && gl == 0) { out[0] = st; out[n] = st + nsig; }
     int pos = nsig;
-    for (int c = ((n - 1) / 64) * 64; c >= 0; c -= 64) {
-        const int p = c + lane;
-        const int l = (p < n) ? lo[p] : 0;
-        const uint32_t o = (p < n) ? tboff[p] : 0;
+    const int nmax = wave_max_i(valid ? n : 0);
+    for (int c = ((nmax - 1) / W) * W; c >= 0; c -= W) {
+        const int p = c + gl;
+        const bool in = valid && p < n;
+        const int l = in ? lo[p] : 0;
+        const int o = in ? (int)tboff[p] : 0;
         int res = 0;
-        for (int j = min(63, n - 1 - c); j >= 0; --j) {
-            if (c + j == 0) break;
-            const int look = pos - 1;
-            int64_t idx = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)o, j) + look - __builtin_amdgcn_readlane(l, j);
-            idx = idx < 0 ? 0 : (idx >= band_len ? band_len - 1 : idx);
-            const int t = __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(tbr + idx));
-            pos = look - t;
-            if (lane == j) res = pos;
+        for (int j = W - 1; j >= 0; --j) {
+            const int lj = __shfl(l, gbase + j), oj = __shfl(o, gbase + j);
+            const int b = c + j;
+            if (valid && b >= 1 && b < n) {
+                const int look = pos - 1;
+                int64_t idx = (int64_t)(uint32_t)oj + look - lj;
+                idx = idx < 0 ? 0 : (idx >= band_len ? band_len - 1 : idx);
+                pos = look - __builtin_nontemporal_load(tbr + idx);
+                if (gl == j) res = pos;
+            }
         }
-        if (p >= 1 && p < n) out[p] = st + res;
+        if (in && p >= 1) out[p] = st + res;
     }
 }
 
-template <int D, int ALGO>
+// W lanes per read (64 / W reads per wave).  Lane (i mod W) of a group hosts row (base) i.
+template <int W, int D, int ALGO>
 __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScratch w, const float *__restrict__ sdp_g,
-                                                       int r0, int64_t *__restrict__ out_map) {
-    __shared__ int4 ring[kRing];
-    const int r = r0 + blockIdx.x, lane = threadIdx.x;
-    if (w.status[r] != 0) return;
-    const int64_t q0 = a.seq_off[r];
-    const int n = (int)(a.seq_off[r + 1] - q0);
-    const int64_t *m = a.s2s + q0 + r;
-    const int64_t st = m[0];
-    const int nsig = (int)(m[n] - st);
-    const int16_t *dac = a.dacs + a.sig_off[r] + st;
-    const double sh = a.shift[r], sc = a.scale[r];
-    const int32_t *lo = w.lo + q0, *hi = w.hi + q0;
-    const float *lv = w.lv + q0;
-    const uint32_t *tboff = w.tboff + q0;
-    int32_t *tbr = w.tb + w.tb_base[r];
-    const float INF = std::numeric_limits<float>::infinity();
+                                                       const int32_t *__restrict__ order, int n_group, int *counter,
+                                                       const int64_t *__restrict__ slot_base, uint32_t *ckpt_all,
+                                                       int64_t *__restrict__ out_map) {
+    constexpr int G = 64 / W;
+    constexpr int RN = (W == 64) ? 256 : 128;  // staged row parameters per read (power of two)
     constexpr int DD = (ALGO == 1) ? D : 1;
+    constexpr int NCK = 13 + 4 * DD;  // dwords per lane in a checkpoint
+    constexpr int IMAX = std::numeric_limits<int>::max();
+    __shared__ int4 ring[G][RN];
+    __shared__ float Ltab[G][(ALGO == 1) ? kLT : 1];
+    __shared__ int Lrow[G][(ALGO == 1) ? kLT : 1];
+    const int lane = threadIdx.x, grp = lane / W, gl = lane % W, gbase = grp * W;
+    const float INF = std::numeric_limits<float>::infinity();
+    uint32_t *ck = ckpt_all + (size_t)blockIdx.x * kCk * NCK * 64 + lane;
     float sdp[DD];
 #pragma unroll
     for (int k = 0; k < DD; ++k) sdp[k] = (ALGO == 1) ? sdp_g[k] : 0.f;
 
-    // per-lane row state
-    bool act = false, is0 = false, lknown = false;
-    int my_lo = 0, my_hi = 0, prev_hi = 0, fail = 0;
-    uint32_t my_off = 0;
-    float lvl = 0.f, cur = 0.f, L = INF, specmax = -INF;
-    int ctb = 0;
-    float P[DD + 1], Q[DD], U[DD + 1];
-    int Ut[DD + 1];
-#pragma unroll
-    for (int k = 0; k <= DD; ++k) { P[k] = 0.f; U[k] = 0.f; Ut[k] = 0; }
-#pragma unroll
-    for (int k = 0; k < DD; ++k) Q[k] = 0.f;
+    // Persistent waves: `order` lists the reads by decreasing band size; wave b starts with reads
+    // b*G .. b*G+G-1 and then takes the next G from the counter, so the traceback region of a lane
+    // group (sized for its first read) fits every later one.
+    int32_t *const tb_slot = w.tb + slot_base[blockIdx.x * G + grp];
+    for (int base = blockIdx.x * G;;) {
+        if (base >= n_group) break;
+        __syncthreads();  // the previous reads of this wave are done with the LDS tables
 
-    int ib_next = 0, next_lo = 0, staged_hi = 0;  // wave-uniform
-    for (int s0 = 0; s0 < nsig; s0 += 64) {
-        // rows that can start inside this block of 64 samples are staged in LDS
-        while (staged_hi < n && staged_hi < ib_next + 65) {
-            const int i = staged_hi + lane;
-            if (i < n) ring[i & (kRing - 1)] = make_int4(lo[i], hi[i], __builtin_bit_cast(int, lv[i]), (int)tboff[i]);
-            staged_hi += 64;
-        }
-        __syncthreads();
-        if (s0 == 0) next_lo = ring[0].x;
-        const int sidx = s0 + lane;
-        const float sv = (sidx < nsig) ? (float)(((double)dac[sidx] - sh) / sc) : 0.f;
-        const int send = min(64, nsig - s0);
-        for (int j = 0; j < send; ++j) {
-            const int s = s0 + j;
-            const float x = readlane_f(sv, j);
-            float pv = wave_ror1(cur);
-            if (s == next_lo) {  // a new row starts (rows start at strictly increasing samples)
-                const int i = ib_next;
-                const int4 pr = ring[i & (kRing - 1)];
-                const int ph = (i > 0) ? ring[(i - 1) & (kRing - 1)].y : (std::numeric_limits<int>::max() >> 1);
-                if (lane == (i & 63)) {
-                    if (act && s < my_hi) fail = 1;            // more than 64 rows in one column
-                    if (i > 0 && (pr.x > ph || pr.y <= ph)) fail = 1;  // gap to / nested in the previous row
-                    act = true; is0 = (i == 0);
-                    my_lo = pr.x; my_hi = pr.y; lvl = __builtin_bit_cast(float, pr.z); my_off = (uint32_t)pr.w;
-                    prev_hi = ph;
-                    lknown = is0;
-                    L = is0 ? ((pr.y == 1) ? kLargeScore : INF) : INF;
-                    specmax = -INF;
+        // ---- the read of this lane group ----
+        const int r = (base + grp < n_group) ? order[base + grp] : -1;
+        bool gvalid = r >= 0;
+        const int64_t q0 = gvalid ? a.seq_off[r] : 0;
+        const int n = gvalid ? (int)(a.seq_off[r + 1] - q0) : 0;
+        const int64_t *m = a.s2s + q0 + (gvalid ? r : 0);
+        const int64_t st = gvalid ? m[0] : 0;
+        const int nsig = gvalid ? (int)(m[n] - st) : 0;
+        const int16_t *dac = a.dacs + (gvalid ? a.sig_off[r] + st : 0);
+        const double sh = gvalid ? a.shift[r] : 0.0, sc = gvalid ? a.scale[r] : 1.0;
+        const int32_t *lo = w.lo + q0, *hi = w.hi + q0;
+        const float *lv = w.lv + q0;
+        const uint32_t *tboff = w.tboff + q0;
+        int32_t *tbr = tb_slot;
+        if (ALGO == 1)
+            for (int k = gl; k < kLT; k += W) Lrow[grp][k] = -1;
+
+        // per-lane row state
+        bool act = false, lknown = false;
+        int my_i = 0, my_lo = 0, my_hi = 0, prev_hi = 0, fail = 0, ctb = 0;
+        int32_t *my_tb = tbr;  // &traceback[row][0] - my_lo
+        float lvl = 0.f, cur = 0.f, L = INF, specmax = -INF;
+        float P[DD + 1], Q[DD], U[DD + 1];
+        int Ut[DD + 1];
+#pragma unroll
+        for (int k = 0; k <= DD; ++k) { P[k] = 0.f; U[k] = 0.f; Ut[k] = 0; }
+#pragma unroll
+        for (int k = 0; k < DD; ++k) Q[k] = 0.f;
+        int ib_next = 0, next_lo = IMAX, staged_hi = 0;  // uniform inside a lane group
+        bool gfail = false;
+
+        const int nblk = (wave_max_i(nsig) + 63) / 64;
+        int blk = 0, nroll = 0;
+        while (blk < nblk) {
+            const int s0 = blk * 64;
+            // rows that can start inside this block of 64 samples are staged in LDS
+            for (;;) {
+                const bool need = gvalid && staged_hi < n && staged_hi < ib_next + 65;
+                if (!__any(need)) break;
+                if (need) {
+                    const int i = staged_hi + gl;
+                    if (i < n) ring[grp][i & (RN - 1)] = make_int4(lo[i], hi[i], __builtin_bit_cast(int, lv[i]), (int)tboff[i]);
+                    staged_hi += W;
                 }
-                ib_next = i + 1;
-                next_lo = (ib_next < n) ? __builtin_amdgcn_readfirstlane(ring[ib_next & (kRing - 1)].x)
-                                        : std::numeric_limits<int>::max();
-                if (next_lo <= s) fail = 1;  // rows must start at strictly increasing samples
             }
-            if (act && s < my_hi) {
-                if (is0) pv = (s == 0) ? 0.f : INF;  // spoofed previous row [0, inf, ...] (core.pyx:360-362)
-                const float dlt = lvl - x;
-                const float qq = dlt * dlt;
-                const int b = s - my_lo;
-                float nc;
-                int nt;
-                if (ALGO == 0) {
-                    // banded_forward_vit_step (core.pyx:256-317)
-                    if (b == 0) { nc = pv + qq; nt = 0; }
-                    else if (s <= prev_hi) {
-                        const float mv = pv + qq, sy = cur + qq;
-                        if (mv < sy) { nc = mv; nt = 0; } else { nc = sy; nt = ctb + 1; }
-                    } else { nc = cur + qq; nt = ctb + 1; }
-                } else {
-                    // un-penalised Viterbi row (core.pyx:183-190)
-                    float un;
-                    int ut;
-                    if (b == 0) { un = pv + qq; ut = 0; }
-                    else if (s <= prev_hi) {
-                        const float mv = pv + qq, sy = U[1] + qq;
-                        if (mv < sy) { un = mv; ut = 0; } else { un = sy; ut = Ut[1] + 1; }
-                    } else { un = U[1] + qq; ut = Ut[1] + 1; }
+            __syncthreads();
+            if (blk == 0 && gvalid) next_lo = ring[grp][0].x;
+
+            if (ALGO == 1) {  // checkpoint of the state at the start of block `blk`
+                uint32_t *c = ck + (size_t)(blk % kCk) * NCK * 64;
+                int k = 0;
+#define CK_I(v) c[(k++) * 64] = (uint32_t)(v);
+#define CK_F(v) c[(k++) * 64] = __builtin_bit_cast(uint32_t, v);
+                CK_I((act ? 1 : 0) | (lknown ? 2 : 0))
+                CK_I(my_i) CK_I(my_lo) CK_I(my_hi) CK_I(prev_hi) CK_I(ctb) CK_I(ib_next) CK_I(next_lo)
+                CK_I((uint32_t)(my_tb - tbr))
+                CK_F(lvl) CK_F(cur) CK_F(L) CK_F(specmax)
 #pragma unroll
-                    for (int k = DD; k >= 2; --k) P[k] = P[k - 1];
-                    P[1] = pv;
+                for (int d = 1; d <= DD; ++d) { CK_F(P[d]) CK_F(U[d]) CK_I(Ut[d]) CK_F(Q[d - 1]) }
+#undef CK_I
+#undef CK_F
+            }
+
+            // 64 samples of every read, normalised as the reference does ((dac - shift) / scale in f64)
+            float sv[(W == 64) ? 1 : 4];
+            if (W == 64) {
+                const int t = s0 + lane;
+                sv[0] = (t < nsig) ? (float)(((double)dac[t] - sh) / sc) : 0.f;
+            } else {
 #pragma unroll
-                    for (int k = DD - 1; k >= 1; --k) Q[k] = Q[k - 1];
-                    Q[0] = qq;
-                    if (!lknown && s == prev_hi) {  // the previous row just completed: pv is its last score
-                        L = kLargeScore + pv;
-                        lknown = true;
-                        if (!(specmax < L)) fail = 1;
-                    }
-                    // banded_forward_dwell_penalty_step (core.pyx:192-253)
-                    if (s - prev_hi >= DD) { nc = cur + qq; nt = ctb + 1; }
-                    else {
-                        float best = lknown ? L : INF;
-                        int bt = -1;
-                        float run = 0.f;
+                for (int k = 0; k < 4; ++k) {
+                    const int t = s0 + 16 * k + gl;
+                    sv[(W == 64) ? 0 : k] = (t < nsig) ? (float)(((double)dac[t] - sh) / sc) : 0.f;
+                }
+            }
+            int viol = IMAX;
 #pragma unroll
-                        for (int di = 0; di < DD; ++di) {
-                            if (di <= b) {
-                                run += Q[di];
-                                if (s - di - 1 < prev_hi) {
-                                    const float ps = (P[di + 1] + run) + sdp[di];
-                                    if (ps < best) { best = ps; bt = di; }
-                                }
+            for (int kq = 0; kq < ((W == 64) ? 1 : 4); ++kq) {
+                constexpr int NJ = (W == 64) ? 64 : 16, UN = 1;
+#pragma nounroll
+                for (int jb = 0; jb < NJ; jb += UN) {
+#pragma unroll
+                  for (int ju = 0; ju < UN; ++ju) {
+                    const int jj = jb + ju;
+                    if (NJ % UN != 0 && jj >= NJ) break;
+                    const int s = s0 + ((W == 64) ? jj : 16 * kq + jj);
+                    const float x = (W == 64) ? readlane_f(sv[0], jj) : __shfl(sv[(W == 64) ? 0 : kq], gbase + jj);
+                    float pv = rot1<W>(cur);
+                    if (s == next_lo) {  // a new row starts (rows start at strictly increasing samples)
+                        const int i = ib_next;
+                        const int4 pr = ring[grp][i & (RN - 1)];
+                        const int ph = (i > 0) ? ring[grp][(i - 1) & (RN - 1)].y : (IMAX >> 1);
+                        if (gl == (i % W)) {
+                            if (act && s < my_hi) fail = 1;                    // more than W rows in one column
+                            if (i > 0 && (pr.x > ph || pr.y <= ph)) fail = 1;  // gap to / nested in the previous row
+                            act = true; my_i = i;
+                            my_lo = pr.x; my_hi = pr.y; lvl = __builtin_bit_cast(float, pr.z);
+                            my_tb = tbr + (int64_t)(uint32_t)pr.w - pr.x;
+                            prev_hi = ph;
+                            lknown = (i == 0);
+                            L = (i == 0 && pr.y == 1) ? kLargeScore : INF;
+                            specmax = -INF;
+                            if (ALGO == 0) { cur = INF; ctb = -1; }  // the first cell can only be a move
+#pragma unroll
+                            for (int k = 1; k <= DD; ++k) { P[k] = INF; U[k] = INF; Ut[k] = -1; }
+#pragma unroll
+                            for (int k = 0; k < DD; ++k) Q[k] = 0.f;
+                            if (ALGO == 1 && i > 0 && Lrow[grp][i & (kLT - 1)] == i) {  // learnt in an earlier pass
+                                lknown = true;
+                                L = Ltab[grp][i & (kLT - 1)];
                             }
                         }
-                        if (b >= DD) {
-                            const float ps = U[DD] + run;
-                            if (ps < best) { best = ps; bt = Ut[DD] + DD; }
-                        }
-                        if (!lknown) specmax = fmaxf(specmax, best);
-                        nc = best; nt = bt;
+                        ib_next = i + 1;
+                        next_lo = (ib_next < n) ? ring[grp][ib_next & (RN - 1)].x : IMAX;
+                        if (next_lo <= s) fail = 1;  // rows must start at strictly increasing samples
                     }
+                    if (act && s < my_hi) {
+                        if (my_i == 0) pv = (s == 0) ? 0.f : INF;  // spoofed previous row [0, inf, ...] (core.pyx:360-362)
+                        // score of row i-1 at sample s-1, +inf once that row has ended: a move from it, and every
+                        // penalised candidate built on it, then loses all '<' tests exactly as the reference's
+                        // index checks skip them
+                        const float pvm = (s <= prev_hi) ? pv : INF;
+                        const float dlt = lvl - x;
+                        const float qq = dlt * dlt;
+                        float nc;
+                        int nt;
+                        if (ALGO == 0) {
+                            // banded_forward_vit_step (core.pyx:256-317); cur = +inf, ctb = -1 at the row start
+                            const float mv = pvm + qq, sy = cur + qq;
+                            const bool c = mv < sy;
+                            nc = c ? mv : sy;
+                            nt = c ? 0 : ctb + 1;
+                        } else {
+                            // un-penalised Viterbi row (core.pyx:183-190); U[1] = +inf, Ut[1] = -1 at the row start
+                            const float mv = pvm + qq, sy = U[1] + qq;
+                            const bool c = mv < sy;
+                            const float un = c ? mv : sy;
+                            const int ut = c ? 0 : Ut[1] + 1;
+                            if (!lknown && s == prev_hi) {  // the previous row just completed: pv is its last score
+                                L = kLargeScore + pv;
+                                lknown = true;
+                                if (!(specmax < L)) {  // a cell of this row should have taken L: replay from the row start
+                                    viol = min(viol, my_lo);
+                                    Ltab[grp][my_i & (kLT - 1)] = L;
+                                    Lrow[grp][my_i & (kLT - 1)] = my_i;
+                                }
+                            }
+                            // banded_forward_dwell_penalty_step (core.pyx:192-253).  P[k] = row i-1 at sample s-k
+                            // (+inf before this row started or after row i-1 ended), Q[k] = residual at s-k
+                            // (0 before the row started), U[k] = un-penalised score at s-k (+inf before the row
+                            // started): candidates that the reference does not evaluate are +inf here
 #pragma unroll
-                    for (int k = DD; k >= 2; --k) { U[k] = U[k - 1]; Ut[k] = Ut[k - 1]; }
-                    U[1] = un; Ut[1] = ut;
+                            for (int k = DD; k >= 2; --k) P[k] = P[k - 1];
+                            P[1] = pvm;
+#pragma unroll
+                            for (int k = DD - 1; k >= 1; --k) Q[k] = Q[k - 1];
+                            Q[0] = qq;
+                            float best = lknown ? L : INF;
+                            int bt = -1;
+                            float run = 0.f;
+#pragma unroll
+                            for (int di = 0; di < DD; ++di) {
+                                run += Q[di];
+                                const float ps = (P[di + 1] + run) + sdp[di];
+                                const bool cc = ps < best;
+                                best = cc ? ps : best;
+                                bt = cc ? di : bt;
+                            }
+                            {
+                                const float ps = U[DD] + run;
+                                const bool cc = ps < best;
+                                best = cc ? ps : best;
+                                bt = cc ? Ut[DD] + DD : bt;
+                            }
+                            const bool tail = (s - prev_hi >= DD);  // beyond the reach of row i-1: stay (core.pyx:201-209)
+                            if (!lknown && !tail) specmax = fmaxf(specmax, best);
+                            nc = tail ? cur + qq : best;
+                            nt = tail ? ctb + 1 : bt;
+#pragma unroll
+                            for (int k = DD; k >= 2; --k) { U[k] = U[k - 1]; Ut[k] = Ut[k - 1]; }
+                            U[1] = un; Ut[1] = ut;
+                        }
+                        cur = nc; ctb = nt;
+                        my_tb[s] = nt;
+                    }
+                  }
                 }
-                cur = nc; ctb = nt;
-                tbr[(int64_t)my_off + b] = nt;
             }
+            // a lane group that hit an unsupported band shape stops here (its read goes to the row-wise kernel)
+            {
+                const unsigned long long fb = __ballot(fail != 0);
+                const unsigned long long gm = ((W == 64) ? ~0ull : ((1ull << W) - 1)) << gbase;
+                if (fb & gm) { gfail = true; gvalid = false; act = false; next_lo = IMAX; fail = 0; viol = IMAX; }
+            }
+            if (!__any(gvalid)) break;
+            if (ALGO == 1) {
+                const int v = wave_min_i(viol);
+                if (v != IMAX) {
+                    const int tblk = v / 64;  // block holding the first sample of the earliest row to redo
+                    ++nroll;
+                    if (blk - tblk >= kCk || nroll > 4 * nblk + 64) {
+                        // out of reach of the checkpoints: the reads of this wave that asked for it go row-wise
+                        if (viol != IMAX) fail = 1;
+                        const unsigned long long fb = __ballot(fail != 0);
+                        const unsigned long long gm = ((W == 64) ? ~0ull : ((1ull << W) - 1)) << gbase;
+                        if ((fb & gm) || nroll > 4 * nblk + 64) { gfail = true; gvalid = false; act = false; next_lo = IMAX; }
+                        fail = 0;
+                        if (!__any(gvalid)) break;
+                        ++blk;
+                        continue;
+                    }
+                    __syncthreads();  // Ltab / Lrow written above are read after the restore
+                    const uint32_t *c = ck + (size_t)(tblk % kCk) * NCK * 64;
+                    int k = 0;
+#define CK_I(v) v = (int)c[(k++) * 64];
+#define CK_F(v) v = __builtin_bit_cast(float, c[(k++) * 64]);
+                    int fl, tboffs;
+                    CK_I(fl)
+                    CK_I(my_i) CK_I(my_lo) CK_I(my_hi) CK_I(prev_hi) CK_I(ctb) CK_I(ib_next) CK_I(next_lo)
+                    CK_I(tboffs)
+                    CK_F(lvl) CK_F(cur) CK_F(L) CK_F(specmax)
+#pragma unroll
+                    for (int d = 1; d <= DD; ++d) { CK_F(P[d]) CK_F(U[d]) CK_I(Ut[d]) CK_F(Q[d - 1]) }
+#undef CK_I
+#undef CK_F
+                    act = (fl & 1) != 0; lknown = (fl & 2) != 0;
+                    my_tb = tbr + (int64_t)(uint32_t)tboffs;
+                    if (!gvalid) { act = false; next_lo = IMAX; }
+                    staged_hi = max(ib_next - 1, 0) / W * W;  // re-stage the row parameters from there
+                    blk = tblk;
+                    continue;
+                }
+            }
+            ++blk;
         }
-        if (__any(fail)) break;
+        if (!gfail && r >= 0 && ib_next != n) gfail = true;
+        if (gfail && r >= 0 && gl == 0) w.status[r] = -1;  // the row-wise kernel takes this read
+        __threadfence();
+        __syncthreads();
+        refine_traceback<W>(r >= 0 && !gfail, lo, tboff, tbr, (r >= 0) ? w.band_len[r] : 0, n, nsig, st,
+                            out_map + q0 + (r >= 0 ? r : 0));
+        if (lane == 0) base = atomicAdd(counter, G);
+        base = __builtin_amdgcn_readfirstlane(base);
     }
-    if (__any(fail) || ib_next != n) {
-        if (lane == 0) w.status[r] = -1;  // row-wise kernel takes this read
-        return;
-    }
-    __threadfence();
-    __syncthreads();
-    refine_traceback(lo, tboff, tbr, w.band_len[r], n, nsig, st, out_map + q0 + r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -464,7 +621,8 @@ __device__ void row_dwell(float *curr, int32_t *tb, const float *prev, int prev_
 __global__ __launch_bounds__(64) void refine_dp_rowwise_kernel(RefineReads a, RefineScratch w, const float *__restrict__ sdp,
                                                                int d, int algo, const int32_t *__restrict__ todo,
                                                                const int64_t *__restrict__ sc_base, float *scores,
-                                                               float *sigbuf, int64_t *__restrict__ out_map) {
+                                                               float *sigbuf, int32_t *tbbuf,
+                                                               int64_t *__restrict__ out_map) {
     const int r = todo[blockIdx.x], lane = threadIdx.x;
     const int64_t q0 = a.seq_off[r];
     const int n = (int)(a.seq_off[r + 1] - q0);
@@ -476,7 +634,7 @@ __global__ __launch_bounds__(64) void refine_dp_rowwise_kernel(RefineReads a, Re
     const int32_t *lo = w.lo + q0, *hi = w.hi + q0;
     const float *lv = w.lv + q0;
     const uint32_t *tboff = w.tboff + q0;
-    int32_t *tbr = w.tb + w.tb_base[r];
+    int32_t *tbr = tbbuf + sc_base[blockIdx.x];
     // scratch of this read: scores[band_len] | signal[nsig] | unpen[maxbw] | unpen_tb[maxbw] | spoof[hi0]
     float *sco = scores + sc_base[blockIdx.x];
     const int64_t bl = w.band_len[r];
@@ -509,7 +667,7 @@ __global__ __launch_bounds__(64) void refine_dp_rowwise_kernel(RefineReads a, Re
     }
     __threadfence();
     __syncthreads();
-    refine_traceback(lo, tboff, tbr, bl, n, nsig, st, out_map + q0 + r);
+    refine_traceback<64>(true, lo, tboff, tbr, bl, n, nsig, st, out_map + q0 + r);
 }
 
 // ---- host helpers -------------------------------------------------------------------------
@@ -526,18 +684,23 @@ struct Bump {
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-template <int ALGO>
-int launch_dp(rmr_engine *e, int d, const RefineReads &dr, const RefineScratch &w, const float *sdp, int r0, int nr,
-              int64_t *out) {
+template <int W, int ALGO>
+int launch_dp(rmr_refiner *rf, const RefineReads &dr, const RefineScratch &w, const int32_t *d_order, int n_group,
+              int grid, const int64_t *d_slot_base, int64_t *out) {
+    rmr_engine *e = rf->e;
+    constexpr int G = 64 / W;
+    const int first = grid * G;  // reads handed out statically
+    RMR_HIP(hipMemcpyAsync(rf->d_counter, &first, sizeof(int), hipMemcpyHostToDevice, e->stream));
     ProfScope ps(e, K_REFINE_DP);
-#define RMR_DP_CASE(DV)                                                                                   \
-    case DV:                                                                                              \
-        hipLaunchKernelGGL((refine_dp_kernel<DV, ALGO>), dim3(nr), dim3(64), 0, e->stream, dr, w, sdp, r0, out); \
+#define RMR_DP_CASE(DV)                                                                                           \
+    case DV:                                                                                                      \
+        hipLaunchKernelGGL((refine_dp_kernel<W, DV, ALGO>), dim3(grid), dim3(64), 0, e->stream, dr, w, rf->d_sdp,  \
+                           d_order, n_group, rf->d_counter, d_slot_base, rf->d_ckpt, out);                                      \
         break;
     if constexpr (ALGO == 0) {
         switch (1) { RMR_DP_CASE(1) }
     } else {
-        switch (d) {
+        switch (rf->sd_len) {
             RMR_DP_CASE(1)
             RMR_DP_CASE(2)
             RMR_DP_CASE(3)
@@ -586,9 +749,15 @@ int rmr_refiner_create(rmr_engine *e, const rmr_refine_desc *desc, rmr_refiner *
     if (he == hipSuccess && r->sd_len) he = hipMalloc(&r->d_sdp, (size_t)r->sd_len * 4);
     if (he == hipSuccess) he = hipMemcpy(r->d_levels, desc->kmer_levels, nk * 4, hipMemcpyHostToDevice);
     if (he == hipSuccess && r->sd_len) he = hipMemcpy(r->d_sdp, desc->sd_arr, (size_t)r->sd_len * 4, hipMemcpyHostToDevice);
+    r->max_grid = e->num_cus * tune_int("RMR_REFINE_WAVES_PER_CU", 8);
+    if (he == hipSuccess) he = hipMalloc(&r->d_counter, 256);
+    if (he == hipSuccess && r->sd_len && r->sd_len <= kMaxD)
+        he = hipMalloc(&r->d_ckpt, (size_t)r->max_grid * kCk * (13 + 4 * r->sd_len) * 64 * sizeof(uint32_t));
     if (he != hipSuccess) {
         if (r->d_levels) (void)hipFree(r->d_levels);
         if (r->d_sdp) (void)hipFree(r->d_sdp);
+        if (r->d_counter) (void)hipFree(r->d_counter);
+        if (r->d_ckpt) (void)hipFree(r->d_ckpt);
         delete r;
         RMR_FAIL(RMR_ERR_HIP, "HIP error %s creating refiner", hipGetErrorString(he));
     }
@@ -601,6 +770,8 @@ void rmr_refiner_destroy(rmr_refiner *r) {
     (void)hipSetDevice(r->e->device);
     if (r->d_levels) (void)hipFree(r->d_levels);
     if (r->d_sdp) (void)hipFree(r->d_sdp);
+    if (r->d_counter) (void)hipFree(r->d_counter);
+    if (r->d_ckpt) (void)hipFree(r->d_ckpt);
     delete r;
 }
 
@@ -642,7 +813,8 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
         if (so[r + 1] < so[r] || qo[r + 1] < qo[r] || qo[r + 1] - qo[r] > (int64_t)1 << 30)
             RMR_FAIL(RMR_ERR_INVALID, "offsets of read %lld are not increasing", (long long)r);
 
-    size_t bytes = 4 * pad256((size_t)tb * 4 + 4) + 3 * pad256(n1 * 8) + pad256(n1 * 4) + pad256((size_t)(tb + n_reads) * 8) + 8192;
+    size_t bytes = 4 * pad256((size_t)tb * 4 + 4) + 3 * pad256(n1 * 8) + 2 * pad256(n1 * 4) + pad256((size_t)(tb + n_reads) * 8) +
+                   pad256(((size_t)rf->max_grid * 4 + 4) * 8) + 8192;
     if (mem == RMR_MEM_HOST)
         bytes += pad256((size_t)ts * 2) + 2 * pad256(n1 * 8) + pad256((size_t)(tb + n_reads) * 8) + pad256((size_t)tb) + 2 * pad256(n1 * 8);
     RMR_TRY(e->ensure(e->staging, bytes));
@@ -674,11 +846,11 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
     w.lv = st.take<float>(tb + 1);
     w.tboff = st.take<uint32_t>(tb + 1);
     w.band_len = st.take<int64_t>(n1);
-    w.tb_base = st.take<int64_t>(n1);
     w.status = st.take<int32_t>(n1);
+    w.maxwin = st.take<int32_t>(n1);
     int64_t *d_out = (mem == RMR_MEM_HOST) ? st.take<int64_t>(tb + n_reads) : out_map;
     int32_t *d_todo = reinterpret_cast<int32_t *>(st.take<int64_t>(n1));  // reused: row-wise work list
-    int64_t *d_scb = st.take<int64_t>(n1);
+    int64_t *d_scb = st.take<int64_t>(std::max<size_t>(n1, (size_t)rf->max_grid * 4 + 4));
 
     {
         ProfScope ps(e, K_REFINE_BAND);
@@ -686,59 +858,88 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
                            rf->kmer_len, rf->center_idx, rf->hbw, rf->min_step);
         RMR_HIP(hipGetLastError());
     }
-    std::vector<int64_t> band_len(n_reads), tb_base(n_reads);
-    std::vector<int32_t> hstat(n_reads);
+    std::vector<int64_t> band_len(n_reads);
+    std::vector<int32_t> hstat(n_reads), maxwin(n_reads);
     RMR_D2H(band_len.data(), w.band_len, (size_t)n_reads * 8);
     RMR_D2H(hstat.data(), w.status, (size_t)n_reads * 4);
+    RMR_D2H(maxwin.data(), w.maxwin, (size_t)n_reads * 4);
     RMR_HIP(hipStreamSynchronize(e->stream));
 
-    // groups of consecutive reads whose traceback bands fit the arena budget
-    const int64_t cap_cells = (int64_t)tune_int("RMR_REFINE_TB_MIB", 4096) * (1 << 18);
     const bool force_rowwise = tune_int("RMR_REFINE_ROWWISE", 0) != 0 || rf->sd_len > kMaxD;
-    int64_t r0 = 0;
-    std::vector<int32_t> todo;
-    while (r0 < n_reads) {
-        int64_t cells = 0, r1 = r0;
-        while (r1 < n_reads) {
-            const int64_t need = hstat[r1] == 0 ? ((band_len[r1] + 63) & ~(int64_t)63) : 0;
-            if (r1 > r0 && cells + need > cap_cells) break;
-            tb_base[r1] = cells;
-            cells += need;
-            ++r1;
+    const int64_t cap_cells = (int64_t)tune_int("RMR_REFINE_TB_MIB", 32768) * (1 << 18);
+    std::vector<int32_t> l16, l64, todo;
+    if (!force_rowwise) {
+        // 16 lanes per read (4 reads per wave) when no sample is shared by more than 16 rows, else 64;
+        // largest bands first: the persistent waves finish together and a wave's traceback region,
+        // sized for its first read, fits all its later ones
+        const int force_w = tune_int("RMR_REFINE_W", 0);
+        for (int64_t r = 0; r < n_reads; ++r) {
+            if (hstat[r] != 0) continue;
+            if (maxwin[r] <= 16 && force_w != 64) l16.push_back((int32_t)r);
+            else if (maxwin[r] <= 64) l64.push_back((int32_t)r);
         }
-        RMR_TRY(e->ensure(e->act, (size_t)cells * 4 + 256));
-        w.tb = reinterpret_cast<int32_t *>(e->act.ptr);
-        RMR_H2D(w.tb_base + r0, tb_base.data() + r0, (size_t)(r1 - r0) * 8);
-        if (!force_rowwise) {
-            if (rf->algo == RMR_REFINE_VITERBI) RMR_TRY(launch_dp<0>(e, 1, dr, w, rf->d_sdp, (int)r0, (int)(r1 - r0), d_out));
-            else RMR_TRY(launch_dp<1>(e, rf->sd_len, dr, w, rf->d_sdp, (int)r0, (int)(r1 - r0), d_out));
-            RMR_D2H(hstat.data() + r0, w.status + r0, (size_t)(r1 - r0) * 4);
-            RMR_HIP(hipStreamSynchronize(e->stream));
+        auto by_len = [&](int32_t x, int32_t y) { return band_len[x] > band_len[y]; };
+        std::stable_sort(l16.begin(), l16.end(), by_len);
+        std::stable_sort(l64.begin(), l64.end(), by_len);
+        std::vector<int64_t> slot_base;
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<int32_t> &lst = pass == 0 ? l16 : l64;
+            if (lst.empty()) continue;
+            const int G = pass == 0 ? 4 : 1;
+            int grid = std::min((int)((lst.size() + G - 1) / G), rf->max_grid);
+            int64_t cells = 0;
+            for (;;) {  // one traceback region per lane group in flight, within the arena budget
+                slot_base.assign((size_t)grid * G, 0);
+                cells = 0;
+                for (size_t k = 0; k < slot_base.size(); ++k) {
+                    slot_base[k] = cells;
+                    if (k < lst.size()) cells += (band_len[lst[k]] + 63) & ~(int64_t)63;
+                }
+                if (cells <= cap_cells || grid == 1) break;
+                grid = std::max(1, grid / 2);
+            }
+            RMR_TRY(e->ensure(e->act, (size_t)cells * 4 + 256));
+            w.tb = reinterpret_cast<int32_t *>(e->act.ptr);
+            RMR_H2D(d_todo, lst.data(), lst.size() * 4);
+            RMR_H2D(d_scb, slot_base.data(), slot_base.size() * 8);
+            if (pass == 0) {
+                if (rf->algo == RMR_REFINE_VITERBI) RMR_TRY((launch_dp<16, 0>(rf, dr, w, d_todo, (int)lst.size(), grid, d_scb, d_out)));
+                else RMR_TRY((launch_dp<16, 1>(rf, dr, w, d_todo, (int)lst.size(), grid, d_scb, d_out)));
+            } else {
+                if (rf->algo == RMR_REFINE_VITERBI) RMR_TRY((launch_dp<64, 0>(rf, dr, w, d_todo, (int)lst.size(), grid, d_scb, d_out)));
+                else RMR_TRY((launch_dp<64, 1>(rf, dr, w, d_todo, (int)lst.size(), grid, d_scb, d_out)));
+            }
+            RMR_HIP(hipStreamSynchronize(e->stream));  // host lists and the arena are reused by the next pass
         }
-        // reads handed back by the column kernel (or all of them when forced)
-        todo.clear();
+        RMR_D2H(hstat.data(), w.status, (size_t)n_reads * 4);
+        RMR_HIP(hipStreamSynchronize(e->stream));
+        for (int64_t r = 0; r < n_reads; ++r)
+            if (maxwin[r] > 64 && hstat[r] == 0) hstat[r] = -1;  // too wide for the column kernel
+    }
+    // reads handed back by the column kernel (or all of them when forced) are evaluated row by row
+    {
         std::vector<int64_t> scb;
         int64_t sc_cells = 0;
-        for (int64_t r = r0; r < r1; ++r)
+        for (int64_t r = 0; r < n_reads; ++r)
             if (hstat[r] < 0 || (force_rowwise && hstat[r] == 0)) {
                 todo.push_back((int32_t)r);
                 scb.push_back(sc_cells);
-                // scores[band_len] are followed by signal + unpen + unpen_tb + spoof of the same read
+                // per read: scores[band_len] | signal + unpen + unpen_tb + spoof (<= 4 * samples + 8) | tb[band_len],
+                // three buffers with identical offsets
                 sc_cells += ((band_len[r] + (so[r + 1] - so[r]) * 4 + 64) + 63) & ~(int64_t)63;
             }
         if (!todo.empty()) {
-            // two arenas of sc_cells floats each would double count: scores and the per-read tail share one buffer,
-            // laid out as [scores region of all reads][tail region of all reads] with identical offsets
             void *extra = nullptr;
-            RMR_HIP(hipMalloc(&extra, (size_t)sc_cells * 8 + 256));
+            RMR_HIP(hipMalloc(&extra, (size_t)sc_cells * 12 + 256));
             float *scores = reinterpret_cast<float *>(extra);
             float *tails = scores + sc_cells;
+            int32_t *tbbuf = reinterpret_cast<int32_t *>(tails + sc_cells);
             hipError_t he = hipMemcpyAsync(d_todo, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, e->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(d_scb, scb.data(), scb.size() * 8, hipMemcpyHostToDevice, e->stream);
             if (he == hipSuccess) {
                 ProfScope ps(e, K_REFINE_ROWWISE);
                 hipLaunchKernelGGL(refine_dp_rowwise_kernel, dim3((unsigned)todo.size()), dim3(64), 0, e->stream, dr, w,
-                                   rf->d_sdp, rf->sd_len, rf->algo, d_todo, d_scb, scores, tails, d_out);
+                                   rf->d_sdp, rf->sd_len, rf->algo, d_todo, d_scb, scores, tails, tbbuf, d_out);
                 he = hipGetLastError();
             }
             if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -746,7 +947,6 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
             if (he != hipSuccess) RMR_FAIL(RMR_ERR_HIP, "HIP error %s in row-wise refinement", hipGetErrorString(he));
             for (int32_t r : todo) hstat[r] = 0;
         }
-        r0 = r1;
     }
     if (mem == RMR_MEM_HOST) {
         RMR_D2H(out_map, d_out, (size_t)(tb + n_reads) * 8);
