@@ -56,11 +56,13 @@ struct RefineReads {
 struct RefineScratch {
     int32_t *lo, *hi;      // [total_bases]  seq band, sample coordinates relative to s2s[0]
     float *lv;             // [total_bases]  expected level of each base
-    uint32_t *tboff;       // [total_bases]  offset of each row in the read's traceback band
-    int64_t *band_len;     // [n_reads]
+    uint32_t *tboff;       // [total_bases]  offset of each row in the read's traceback band (multiple of 8)
+    uint32_t *flat;        // [total_bases]  offset of each row in the reference's flat band (core.pyx:445-450)
+    int64_t *band_len;     // [n_reads]      traceback elements of the read (padded layout)
     int32_t *status;       // [n_reads]      0 ok, >0 rmr_refine_status, <0 needs the row-wise kernel
     int32_t *maxwin;       // [n_reads]      most rows that share one sample
-    int32_t *tb;           // traceback bands of the reads in flight (one region per lane group of a wave)
+    int16_t *tb;           // traceback bands of the reads in flight (one region per lane group of a wave);
+                           // row i holds samples (lo[i] & ~7) .. ((hi[i] + 7) & ~7) - 1 at tboff[i], 16-byte groups
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(64) void refine_band_kernel(RefineReads a, RefineSc
     __syncthreads();
 
     // validate_band (refine_signal_map.py:686-737) + row offsets (core.pyx:445-450)
-    int bad = 0;
-    uint32_t carry = 0;
+    int bad = 0, maxw = 0;
+    uint32_t carry = 0, fcarry = 0;
     int64_t total = 0;
     for (int c = 0; c < n; c += 64) {
         const int p = c + lane;
@@ -207,16 +209,27 @@ __global__ __launch_bounds__(64) void refine_band_kernel(RefineReads a, RefineSc
                 if (hi[p + 1] < h) bad |= 4;
             }
         }
-        uint32_t v = (uint32_t)max(wdt, 0);
+        // rows are stored from the 8-sample boundary below lo to the one above hi (16-byte groups of int16)
+        const uint32_t wal = (p < n && wdt > 0) ? (uint32_t)(((hi[p] + 7) & ~7) - (lo[p] & ~7)) : 0u;
+        maxw = max(maxw, wdt);
+        uint32_t v = wal;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(v, o);
             if (lane >= o) v += t;
         }
-        if (p < n) w.tboff[q0 + p] = carry + v - (uint32_t)max(wdt, 0);
+        if (p < n) w.tboff[q0 + p] = carry + v - wal;
         const uint32_t tot = __shfl(v, 63);
         carry += tot;
         total += tot;
+        uint32_t fv = (uint32_t)max(wdt, 0);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(fv, o);
+            if (lane >= o) fv += t;
+        }
+        if (p < n) w.flat[q0 + p] = fcarry + fv - (uint32_t)max(wdt, 0);
+        fcarry += __shfl(fv, 63);
     }
     bad = wave_max_i((bad & 1) ? 1 : 0) | (wave_max_i((bad & 2) ? 1 : 0) << 1) | (wave_max_i((bad & 4) ? 1 : 0) << 2);
     // widest column: rows p..j share sample hi[p]-1 when lo[j] <= hi[p]-1 (lo is non-decreasing for valid bands)
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(64) void refine_band_kernel(RefineReads a, RefineSc
         }
     }
     win = wave_max_i(win);
+    if (wave_max_i(maxw) > 32767) win = 1 << 20;  // stay counts would not fit the int16 traceback: row-wise kernel
     if (lane == 0) {
         int s = 0;
         if (lo[0] != 0) s = RMR_REFINE_BAND_START;
@@ -254,7 +268,6 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-constexpr int kLT = 256;  // known "large score" terms remembered per read (direct mapped by row)
 constexpr int kCk = 8;    // checkpoints kept per wave: a replay can reach back kCk blocks of 64 samples
 
 // lane l receives the value of the previous lane of its W-lane group (wrapping inside the group)
@@ -265,28 +278,49 @@ __device__ __forceinline__ float rot1(float v) {
 }
 
 // banded_traceback (core.pyx:119-148) for the read of each W-lane group:
-// path[n] = hi[n-1]; path[b] = look - tb[row b][look - lo[b]], look = path[b+1] - 1
-template <int W>
-__device__ void refine_traceback(bool valid, const int32_t *__restrict__ lo, const uint32_t *__restrict__ tboff,
-                                 const int32_t *tbr, int64_t band_len, int n, int nsig, int64_t st, int64_t *out) {
+// path[n] = hi[n-1]; path[b] = look - tb[flat[b] + look - lo[b]], look = path[b+1] - 1, where tb is the
+// reference's flat band (rows back to back).  When a 'large score' cell (traceback -1) is on the path, look can
+// fall outside row b and the reference then reads a cell of a neighbouring row; that is reproduced by mapping
+// the flat index back to (row, sample).
+// TB = int16_t: padded layout of the column kernel (row b at tboff[b], first element = sample lo[b] & ~7);
+// TB = int32_t: the flat layout itself (row-wise kernel).
+template <int W, typename TB>
+__device__ void refine_traceback(bool valid, const int32_t *__restrict__ lo, const int32_t *__restrict__ hi,
+                                 const uint32_t *__restrict__ tboff, const uint32_t *__restrict__ flat, const TB *tbr,
+                                 int n, int nsig, int64_t st, int64_t *out) {
+    constexpr bool PADDED = sizeof(TB) == 2;
     const int lane = threadIdx.x, gl = lane % W, gbase = lane - gl;
     if (valid && gl == 0) { out[0] = st; out[n] = st + nsig; }
     int pos = nsig;
     const int nmax = wave_max_i(valid ? n : 0);
+    const int64_t flat_total = valid ? (int64_t)flat[n - 1] + (hi[n - 1] - lo[n - 1]) : 0;
     for (int c = ((nmax - 1) / W) * W; c >= 0; c -= W) {
         const int p = c + gl;
         const bool in = valid && p < n;
         const int l = in ? lo[p] : 0;
-        const int o = in ? (int)tboff[p] : 0;
+        const int wd = in ? hi[p] - l : 0;
+        const int o = in ? (int)(PADDED ? tboff[p] : flat[p]) : 0;
         int res = 0;
         for (int j = W - 1; j >= 0; --j) {
-            const int lj = __shfl(l, gbase + j), oj = __shfl(o, gbase + j);
+            const int lj = __shfl(l, gbase + j), oj = __shfl(o, gbase + j), wj = __shfl(wd, gbase + j);
             const int b = c + j;
             if (valid && b >= 1 && b < n) {
                 const int look = pos - 1;
-                int64_t idx = (int64_t)(uint32_t)oj + look - lj;
-                idx = idx < 0 ? 0 : (idx >= band_len ? band_len - 1 : idx);
-                pos = look - __builtin_nontemporal_load(tbr + idx);
+                const int loc = look - lj;
+                int64_t idx;
+                if (loc >= 0 && loc < wj) {
+                    idx = (int64_t)(uint32_t)oj + loc + (PADDED ? (lj & 7) : 0);
+                } else {  // outside row b: the cell the reference's flat index lands on
+                    int64_t f = (int64_t)flat[b] + loc;
+                    f = f < 0 ? 0 : (f >= flat_total ? flat_total - 1 : f);
+                    int r0 = 0, r1 = n - 1;  // last row with flat[row] <= f
+                    while (r0 < r1) {
+                        const int mid = (r0 + r1 + 1) >> 1;
+                        if ((int64_t)flat[mid] <= f) r0 = mid; else r1 = mid - 1;
+                    }
+                    idx = PADDED ? (int64_t)tboff[r0] + (f - flat[r0]) + (lo[r0] & 7) : f;
+                }
+                pos = look - (int)__builtin_nontemporal_load(tbr + idx);
                 if (gl == j) res = pos;
             }
         }
@@ -301,7 +335,10 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                                                        const int64_t *__restrict__ slot_base, uint32_t *ckpt_all,
                                                        int64_t *__restrict__ out_map) {
     constexpr int G = 64 / W;
-    constexpr int RN = (W == 64) ? 256 : 128;  // staged row parameters per read (power of two)
+    constexpr int RN = (W == 64) ? 256 : 64;   // staged row parameters per read (power of two)
+    constexpr int SB = (W == 64) ? 64 : 16;    // samples between two staging points
+    constexpr int kLT = (W == 64) ? 256 : 64;  // known "large score" terms per read, direct mapped by row: a
+                                               // collision costs a replay (bounded by nroll), never correctness
     constexpr int DD = (ALGO == 1) ? D : 1;
     constexpr int NCK = 13 + 4 * DD;  // dwords per lane in a checkpoint
     constexpr int IMAX = std::numeric_limits<int>::max();
@@ -318,7 +355,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
     // Persistent waves: `order` lists the reads by decreasing band size; wave b starts with reads
     // b*G .. b*G+G-1 and then takes the next G from the counter, so the traceback region of a lane
     // group (sized for its first read) fits every later one.
-    int32_t *const tb_slot = w.tb + slot_base[blockIdx.x * G + grp];
+    int16_t *const tb_slot = w.tb + slot_base[blockIdx.x * G + grp];
     for (int base = blockIdx.x * G;;) {
         if (base >= n_group) break;
         __syncthreads();  // the previous reads of this wave are done with the LDS tables
@@ -336,14 +373,16 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
         const int32_t *lo = w.lo + q0, *hi = w.hi + q0;
         const float *lv = w.lv + q0;
         const uint32_t *tboff = w.tboff + q0;
-        int32_t *tbr = tb_slot;
+        int16_t *tbr = tb_slot;
         if (ALGO == 1)
             for (int k = gl; k < kLT; k += W) Lrow[grp][k] = -1;
 
         // per-lane row state
         bool act = false, lknown = false;
         int my_i = 0, my_lo = 0, my_hi = 0, prev_hi = 0, fail = 0, ctb = 0;
-        int32_t *my_tb = tbr;  // &traceback[row][0] - my_lo
+        int16_t *my_tb = tbr;  // &traceback[row][0] - (my_lo & ~7)
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // the row's traceback values of the current 8-sample group
+        bool dirty = false;
         float lvl = 0.f, cur = 0.f, L = INF, specmax = -INF;
         float P[DD + 1], Q[DD], U[DD + 1];
         int Ut[DD + 1];
@@ -358,17 +397,22 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
         int blk = 0, nroll = 0;
         while (blk < nblk) {
             const int s0 = blk * 64;
-            // rows that can start inside this block of 64 samples are staged in LDS
-            for (;;) {
-                const bool need = gvalid && staged_hi < n && staged_hi < ib_next + 65;
-                if (!__any(need)) break;
-                if (need) {
-                    const int i = staged_hi + gl;
-                    if (i < n) ring[grp][i & (RN - 1)] = make_int4(lo[i], hi[i], __builtin_bit_cast(int, lv[i]), (int)tboff[i]);
-                    staged_hi += W;
+            // rows that can start within the next SB samples are staged in LDS
+            auto stage_rows = [&]() {
+                bool any = false;
+                for (;;) {
+                    const bool need = gvalid && staged_hi < n && staged_hi < ib_next + SB + 1;
+                    if (!__any(need)) break;
+                    any = true;
+                    if (need) {
+                        const int i = staged_hi + gl;
+                        if (i < n) ring[grp][i & (RN - 1)] = make_int4(lo[i], hi[i], __builtin_bit_cast(int, lv[i]), (int)tboff[i]);
+                        staged_hi += W;
+                    }
                 }
-            }
-            __syncthreads();
+                if (any) __syncthreads();
+            };
+            stage_rows();
             if (blk == 0 && gvalid) next_lo = ring[grp][0].x;
 
             if (ALGO == 1) {  // checkpoint of the state at the start of block `blk`
@@ -401,6 +445,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
             int viol = IMAX;
 #pragma unroll
             for (int kq = 0; kq < ((W == 64) ? 1 : 4); ++kq) {
+                if (kq > 0) stage_rows();
                 constexpr int NJ = (W == 64) ? 64 : 16, UN = 1;
 #pragma nounroll
                 for (int jb = 0; jb < NJ; jb += UN) {
@@ -418,9 +463,17 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                         if (gl == (i % W)) {
                             if (act && s < my_hi) fail = 1;                    // more than W rows in one column
                             if (i > 0 && (pr.x > ph || pr.y <= ph)) fail = 1;  // gap to / nested in the previous row
+                            if (dirty) {  // the row this lane hosted before ended inside the current group: flush it
+                                for (int t = s & 7; t < 8; ++t) {
+                                    a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
+                                    a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 >>= 16;
+                                }
+                                *reinterpret_cast<uint4 *>(my_tb + (s & ~7)) = make_uint4(a0, a1, a2, a3);
+                                dirty = false;
+                            }
                             act = true; my_i = i;
                             my_lo = pr.x; my_hi = pr.y; lvl = __builtin_bit_cast(float, pr.z);
-                            my_tb = tbr + (int64_t)(uint32_t)pr.w - pr.x;
+                            my_tb = tbr + (int64_t)(uint32_t)pr.w - (pr.x & ~7);
                             prev_hi = ph;
                             lknown = (i == 0);
                             L = (i == 0 && pr.y == 1) ? kLargeScore : INF;
@@ -506,7 +559,15 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                             U[1] = un; Ut[1] = ut;
                         }
                         cur = nc; ctb = nt;
-                        my_tb[s] = nt;
+                        dirty = true;
+                    }
+                    // traceback values travel through a 128-bit shift register and leave as one 16-byte store per
+                    // row every 8 samples (a 4-byte store per cell makes the kernel store-issue bound)
+                    a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
+                    a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 = __builtin_amdgcn_alignbit((uint32_t)ctb, a3, 16);
+                    if ((s & 7) == 7) {
+                        if (dirty) *reinterpret_cast<uint4 *>(my_tb + (s & ~7)) = make_uint4(a0, a1, a2, a3);
+                        dirty = false;
                     }
                   }
                 }
@@ -562,8 +623,8 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
         if (gfail && r >= 0 && gl == 0) w.status[r] = -1;  // the row-wise kernel takes this read
         __threadfence();
         __syncthreads();
-        refine_traceback<W>(r >= 0 && !gfail, lo, tboff, tbr, (r >= 0) ? w.band_len[r] : 0, n, nsig, st,
-                            out_map + q0 + (r >= 0 ? r : 0));
+        refine_traceback<W, int16_t>(r >= 0 && !gfail, lo, hi, tboff, w.flat + q0, tbr, n, nsig, st,
+                                     out_map + q0 + (r >= 0 ? r : 0));
         if (lane == 0) base = atomicAdd(counter, G);
         base = __builtin_amdgcn_readfirstlane(base);
     }
@@ -633,11 +694,10 @@ __global__ __launch_bounds__(64) void refine_dp_rowwise_kernel(RefineReads a, Re
     const double sh = a.shift[r], sc = a.scale[r];
     const int32_t *lo = w.lo + q0, *hi = w.hi + q0;
     const float *lv = w.lv + q0;
-    const uint32_t *tboff = w.tboff + q0;
+    const uint32_t *tboff = w.flat + q0;  // rows back to back, as the reference stores them
     int32_t *tbr = tbbuf + sc_base[blockIdx.x];
     // scratch of this read: scores[band_len] | signal[nsig] | unpen[maxbw] | unpen_tb[maxbw] | spoof[hi0]
     float *sco = scores + sc_base[blockIdx.x];
-    const int64_t bl = w.band_len[r];
     float *sig = sigbuf + sc_base[blockIdx.x];
     for (int i = lane; i < nsig; i += 64) sig[i] = (float)(((double)dac[i] - sh) / sc);
     int maxbw = 0;
@@ -667,7 +727,7 @@ __global__ __launch_bounds__(64) void refine_dp_rowwise_kernel(RefineReads a, Re
     }
     __threadfence();
     __syncthreads();
-    refine_traceback<64>(true, lo, tboff, tbr, bl, n, nsig, st, out_map + q0 + r);
+    refine_traceback<64, int32_t>(true, lo, hi, tboff, tboff, tbr, n, nsig, st, out_map + q0 + r);
 }
 
 // ---- host helpers -------------------------------------------------------------------------
@@ -813,7 +873,7 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
         if (so[r + 1] < so[r] || qo[r + 1] < qo[r] || qo[r + 1] - qo[r] > (int64_t)1 << 30)
             RMR_FAIL(RMR_ERR_INVALID, "offsets of read %lld are not increasing", (long long)r);
 
-    size_t bytes = 4 * pad256((size_t)tb * 4 + 4) + 3 * pad256(n1 * 8) + 2 * pad256(n1 * 4) + pad256((size_t)(tb + n_reads) * 8) +
+    size_t bytes = 5 * pad256((size_t)tb * 4 + 4) + 3 * pad256(n1 * 8) + 2 * pad256(n1 * 4) + pad256((size_t)(tb + n_reads) * 8) +
                    pad256(((size_t)rf->max_grid * 4 + 4) * 8) + 8192;
     if (mem == RMR_MEM_HOST)
         bytes += pad256((size_t)ts * 2) + 2 * pad256(n1 * 8) + pad256((size_t)(tb + n_reads) * 8) + pad256((size_t)tb) + 2 * pad256(n1 * 8);
@@ -845,6 +905,7 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
     w.hi = st.take<int32_t>(tb + 1);
     w.lv = st.take<float>(tb + 1);
     w.tboff = st.take<uint32_t>(tb + 1);
+    w.flat = st.take<uint32_t>(tb + 1);
     w.band_len = st.take<int64_t>(n1);
     w.status = st.take<int32_t>(n1);
     w.maxwin = st.take<int32_t>(n1);
@@ -866,7 +927,7 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
     RMR_HIP(hipStreamSynchronize(e->stream));
 
     const bool force_rowwise = tune_int("RMR_REFINE_ROWWISE", 0) != 0 || rf->sd_len > kMaxD;
-    const int64_t cap_cells = (int64_t)tune_int("RMR_REFINE_TB_MIB", 32768) * (1 << 18);
+    const int64_t cap_cells = (int64_t)tune_int("RMR_REFINE_TB_MIB", 32768) * (1 << 19);
     std::vector<int32_t> l16, l64, todo;
     if (!force_rowwise) {
         // 16 lanes per read (4 reads per wave) when no sample is shared by more than 16 rows, else 64;
@@ -898,8 +959,8 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
                 if (cells <= cap_cells || grid == 1) break;
                 grid = std::max(1, grid / 2);
             }
-            RMR_TRY(e->ensure(e->act, (size_t)cells * 4 + 256));
-            w.tb = reinterpret_cast<int32_t *>(e->act.ptr);
+            RMR_TRY(e->ensure(e->act, (size_t)cells * 2 + 256));
+            w.tb = reinterpret_cast<int16_t *>(e->act.ptr);
             RMR_H2D(d_todo, lst.data(), lst.size() * 4);
             RMR_H2D(d_scb, slot_base.data(), slot_base.size() * 8);
             if (pass == 0) {
