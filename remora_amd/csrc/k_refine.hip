@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
 #pragma unroll
         for (int k = 0; k < DD; ++k) Q[k] = 0.f;
         int ib_next = 0, next_lo = IMAX, staged_hi = 0;  // uniform inside a lane group
+        int dnext = 0, dnext_s = -1;                     // raw samples fetched ahead, and the sample they start at
         bool gfail = false;
 
         const int nblk = (wave_max_i(nsig) + 63) / 64;
@@ -430,31 +431,21 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
 #undef CK_F
             }
 
-            // 64 samples of every read, normalised as the reference does ((dac - shift) / scale in f64)
-            float sv[(W == 64) ? 1 : 4];
-            if (W == 64) {
-                const int t = s0 + lane;
-                sv[0] = (t < nsig) ? (float)(((double)dac[t] - sh) / sc) : 0.f;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = s0 + 16 * k + gl;
-                    sv[(W == 64) ? 0 : k] = (t < nsig) ? (float)(((double)dac[t] - sh) / sc) : 0.f;
-                }
-            }
             int viol = IMAX;
-#pragma unroll
-            for (int kq = 0; kq < ((W == 64) ? 1 : 4); ++kq) {
-                if (kq > 0) stage_rows();
-                constexpr int NJ = (W == 64) ? 64 : 16, UN = 1;
 #pragma nounroll
-                for (int jb = 0; jb < NJ; jb += UN) {
-#pragma unroll
-                  for (int ju = 0; ju < UN; ++ju) {
-                    const int jj = jb + ju;
-                    if (NJ % UN != 0 && jj >= NJ) break;
-                    const int s = s0 + ((W == 64) ? jj : 16 * kq + jj);
-                    const float x = (W == 64) ? readlane_f(sv[0], jj) : __shfl(sv[(W == 64) ? 0 : kq], gbase + jj);
+            for (int kq = 0; kq < 64 / SB; ++kq) {
+                if (kq > 0) stage_rows();
+                const int sq = s0 + SB * kq;
+                // SB samples of every read, normalised as the reference does ((dac - shift) / scale in f64); the raw
+                // value of the following SB samples is fetched now and converted when its turn comes
+                const int tq = sq + gl;
+                if (dnext_s != sq) dnext = (tq < nsig) ? (int)dac[tq] : 0;
+                const float sv = (tq < nsig) ? (float)(((double)dnext - sh) / sc) : 0.f;
+                dnext = (tq + SB < nsig) ? (int)dac[tq + SB] : 0;
+                dnext_s = sq + SB;
+                // one cell of every active row: sample sq + jj, whose value x is broadcast inside the lane group
+                auto step = [&](const int jj, const float x) {
+                    const int s = sq + jj;
                     float pv = rot1<W>(cur);
                     if (s == next_lo) {  // a new row starts (rows start at strictly increasing samples)
                         const int i = ib_next;
@@ -565,11 +556,19 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                     // row every 8 samples (a 4-byte store per cell makes the kernel store-issue bound)
                     a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
                     a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 = __builtin_amdgcn_alignbit((uint32_t)ctb, a3, 16);
-                    if ((s & 7) == 7) {
+                    if ((jj & 7) == 7) {
                         if (dirty) *reinterpret_cast<uint4 *>(my_tb + (s & ~7)) = make_uint4(a0, a1, a2, a3);
                         dirty = false;
                     }
-                  }
+                };
+                if constexpr (W == 64) {
+                    for (int jj = 0; jj < 64; ++jj) step(jj, readlane_f(sv, jj));
+                } else {
+                    // 16 steps with the broadcast lane as an immediate (DPP row_newbcast)
+#define RMR_STEP16(J) step(J, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x150 + J, 0xf, 0xf, false)));
+                    RMR_STEP16(0) RMR_STEP16(1) RMR_STEP16(2) RMR_STEP16(3) RMR_STEP16(4) RMR_STEP16(5) RMR_STEP16(6) RMR_STEP16(7)
+                    RMR_STEP16(8) RMR_STEP16(9) RMR_STEP16(10) RMR_STEP16(11) RMR_STEP16(12) RMR_STEP16(13) RMR_STEP16(14) RMR_STEP16(15)
+#undef RMR_STEP16
                 }
             }
             // a lane group that hit an unsupported band shape stops here (its read goes to the row-wise kernel)
@@ -613,6 +612,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                     my_tb = tbr + (int64_t)(uint32_t)tboffs;
                     if (!gvalid) { act = false; next_lo = IMAX; }
                     staged_hi = max(ib_next - 1, 0) / W * W;  // re-stage the row parameters from there
+                    dnext_s = -1;
                     blk = tblk;
                     continue;
                 }
