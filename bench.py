@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")
     ap.add_argument("--no-reads", action="store_true", help="skip the measured reads/sec leg (extract + infer from whole reads)")
     ap.add_argument("--no-alt", action="store_true", help="skip the bf16x6 (fp32-class split bf16 MFMA) comparison leg")
+    ap.add_argument("--no-refine", action="store_true", help="skip the signal-mapping refinement (banded DP) leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing: put every rank on this GPU")
@@ -306,6 +307,37 @@ def main():
                      "single_read_api_reads_per_s": 32 / (t1b - t1a),
                      "note": "call_reads_mods: host motif scan + H2D + geometry/fill + fused inference + D2H per batch of 512 reads"}
 
+    # ---- signal-mapping refinement: banded DP kernels on resident reads, and the reads/sec of
+    #      the whole per-read path for a model that carries a k-mer level table (rough re-scale + DP + calls) ----
+    refine_leg = None
+    if rank == 0 and world == 1 and not args.no_refine:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_refine
+
+        refine_leg = bench_refine.measure(n_reads=8192, n_bases=5000, steps=2, warmup=1, cpu_reads=4, device=local)
+        if reads_leg is not None:
+            from remora_amd.refine_signal_map import SigMapRefiner
+
+            table, center, base = bench_refine.synth_reads(64, 5000, seed=5)
+            refiner = SigMapRefiner(_levels_array=table, center_idx=center, do_rough_rescale=True, scale_iters=0)
+            mdf = dict(mdr, sig_map_refiner=refiner)
+
+            def fresh():
+                return [RemoraRead(dacs=base[i % 64][0], shift=400.0, scale=60.0, seq_to_sig_map=base[i % 64][1].copy(),
+                                   int_seq=base[i % 64][2], read_id=f"lv{i}") for i in range(nreads)]
+
+            call_reads_mods(fresh(), model, mdf)  # warm-up (also creates the device refiner)
+            rs2 = fresh()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            call_reads_mods(rs2, model, mdf)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            refine_leg["reads_pipeline_with_refiner"] = {
+                "reads": nreads, "batched_reads_per_s": nreads / (tb - ta),
+                "note": "call_reads_mods with a loaded SigMapRefiner (do_rough_rescale, scale_iters=0, dwell_penalty): "
+                        "host rough re-scale per read + one batched GPU refinement + extraction + inference"}
+
     # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
     alt, alt_head = None, None
     if rank == 0 and world == 1 and args.dtype == "fp32" and arch == "conv_lstm" and not args.no_alt:
@@ -379,6 +411,7 @@ def main():
         "encode_roofline": enc_roof,
         "alt_bf16x6": alt,
         "reads_pipeline": reads_leg,
+        "refine_signal_map": refine_leg,
         "label_counts": [int(x) for x in counts.tolist()],
     }
     if world == 1 and not args.no_cpu_baseline:
