@@ -809,7 +809,7 @@ int rmr_refiner_create(rmr_engine *e, const rmr_refine_desc *desc, rmr_refiner *
     if (he == hipSuccess && r->sd_len) he = hipMalloc(&r->d_sdp, (size_t)r->sd_len * 4);
     if (he == hipSuccess) he = hipMemcpy(r->d_levels, desc->kmer_levels, nk * 4, hipMemcpyHostToDevice);
     if (he == hipSuccess && r->sd_len) he = hipMemcpy(r->d_sdp, desc->sd_arr, (size_t)r->sd_len * 4, hipMemcpyHostToDevice);
-    r->max_grid = e->num_cus * tune_int("RMR_REFINE_WAVES_PER_CU", 8);
+    r->max_grid = e->num_cus * tune_int("RMR_REFINE_WAVES_PER_CU", 16);
     if (he == hipSuccess) he = hipMalloc(&r->d_counter, 256);
     if (he == hipSuccess && r->sd_len && r->sd_len <= kMaxD)
         he = hipMalloc(&r->d_ckpt, (size_t)r->max_grid * kCk * (13 + 4 * r->sd_len) * 64 * sizeof(uint32_t));

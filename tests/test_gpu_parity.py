@@ -338,8 +338,10 @@ def _mint_pt(tmp_path, g, O):
     return pt
 
 
-@pytest.mark.parametrize("name", ["cg_5mc", "allc_5hmc_5mc", "conv_cg"])
+@pytest.mark.parametrize("name", ["cg_5mc", "allc_5hmc_5mc", "conv_cg", "cg_5mc_refine"])
 def test_load_model_and_call_read_mods_golden(torch_cuda, O, tmp_path, name):
+    """cg_5mc_refine carries a k-mer level table (base_start_justify, offset 1): call_read_mods then
+    re-scales and re-maps every read (rough re-scale + dwell-penalty DP on the GPU) before extraction."""
     from remora_amd.data_chunks import RemoraRead
     from remora_amd.inference import call_read_mods
     from remora_amd.model_util import load_model
@@ -352,7 +354,7 @@ def test_load_model_and_call_read_mods_golden(torch_cuda, O, tmp_path, name):
         if isinstance(v, list):
             got = json.loads(json.dumps(got))
         assert got == v, (k, got, v)
-    assert md["sig_map_refiner"].is_loaded is False
+    assert md["sig_map_refiner"].is_loaded is name.endswith("_refine")
     for rname in g["read_names"]:
         rname = str(rname)
         shift, scale = (float(x) for x in g[f"{rname}_shift_scale"])
@@ -377,6 +379,8 @@ def test_load_model_and_call_read_mods_golden(torch_cuda, O, tmp_path, name):
         assert mm == str(g[f"{rname}_mm"])
         ml = np.asarray(list(ml), np.uint8).astype(int)
         assert np.abs(ml - g[f"{rname}_ml"].astype(int)).max() <= 1  # floor(p*256) next to a bin edge
+    if "r_long_focus_offset" not in g:
+        return
     fo = int(g["r_long_focus_offset"])
     shift, scale = (float(x) for x in g["r_long_shift_scale"])
     rd = RemoraRead(dacs=g["r_long_dacs"], shift=shift, scale=scale, seq_to_sig_map=g["r_long_map"], int_seq=g["r_long_int_seq"])

@@ -317,3 +317,101 @@ def test_bam_writer_roundtrip(tmp_path):
         w.write(again)
     (only,) = list(rio.iter_bam_records(out))
     assert [k for k, _ in only.tags].count("MM") == 1 and only.get_tag("MM") == "C+m?,5;" and list(only.get_tag("ML")) == [7]
+
+
+# ---- N2 host side: SigMapRefiner without a GPU ---------------------------------------------------
+def test_sig_map_refiner_table_file_matches_reference():
+    """load_kmer_table / determine_dominant_pos / fix_gauge against values the reference produced
+    for the same table file (tools/gen_golden.py gen_refine)."""
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    g = golden("refine_signal_map.npz")
+    path = os.path.join(ROOT, "tests", "golden", "data", "levels_4mer.txt")
+    for tag, fix in (("raw", False), ("fix", True)):
+        ref = SigMapRefiner(kmer_model_filename=path, do_rough_rescale=True, do_fix_guage=fix)
+        assert ref.is_loaded and ref.is_valid and ref.kmer_len == 4
+        assert int(ref.center_idx) == int(g[f"table_{tag}_center"])
+        np.testing.assert_allclose(ref.kmer_idx_stats, g[f"table_{tag}_stats"], rtol=1e-12)
+        np.testing.assert_array_equal(np.asarray(ref.levels_array, np.float64), g[f"table_{tag}_levels"])
+        assert ref.bases_before == 2 and ref.bases_after == 1
+    assert "4-mer table" in repr(ref)
+
+
+def test_sig_map_refiner_host_rescale_matches_reference():
+    """Settings without a DP pass (scale_iters = -1) are pure host arithmetic: shift/scale equal the
+    reference's for both rough re-scale methods; extract_levels equals the Cython function."""
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    g = golden("refine_signal_map.npz")
+    settings = json.loads(str(g["settings_json"]))
+    si = [i for i, st in enumerate(settings) if st["scale_iters"] < 0][0]
+    ref = SigMapRefiner(_levels_array=g["kmer_levels"], center_idx=int(g["center_idx"]), **settings[si])
+    for n in "abcd":
+        np.testing.assert_array_equal(ref.extract_levels(g[f"{n}_int_seq"]), g[f"{n}_levels"])
+        read = RemoraRead(dacs=g[f"{n}_dacs"], shift=505.0, scale=83.0, seq_to_sig_map=g[f"{n}_map"].copy(),
+                          int_seq=g[f"{n}_int_seq"], read_id=n)
+        read.refine_signal_mapping(ref)
+        np.testing.assert_array_equal(read.seq_to_sig_map, g[f"s{si}_{n}_map"])
+        np.testing.assert_allclose([read.shift, read.scale], g[f"s{si}_{n}_shift_scale"], rtol=1e-12)
+    # least squares flavour against the oracle restatement of the reference
+    ref2 = SigMapRefiner(_levels_array=g["kmer_levels"], center_idx=int(g["center_idx"]), do_rough_rescale=True)
+    from oracle import oracle as O
+
+    want = O.refiner_rough_rescale(dict(levels=g["kmer_levels"], center_idx=int(g["center_idx"]),
+                                        rough_rescale_method="least_squares"), 505.0, 83.0, g["b_map"], g["b_int_seq"],
+                                   g["b_dacs"])
+    got = ref2.rough_rescale(505.0, 83.0, g["b_map"], g["b_int_seq"], g["b_dacs"])
+    assert tuple(got) == tuple(want)
+
+
+def test_fast_quantile_is_numpy_quantile():
+    from remora_amd import refine_signal_map as R
+
+    rng = np.random.default_rng(3)
+    q = np.arange(0.05, 1, 0.05)
+    for t in range(300):
+        n = int(rng.integers(1, 3000))
+        a = rng.normal(0, 1, n).astype(np.float32 if t % 2 else np.float64)
+        if t % 3 == 0:
+            a = np.round(a, 1)  # ties
+        got, want = R._quantile(a, q), np.quantile(a, q)
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want)
+    assert R._QUANTILE_OK is True  # the replica is in use with this numpy
+
+
+def test_sig_map_refiner_metadata_roundtrip_and_errors():
+    from remora_amd import RemoraError
+    from remora_amd.refine_signal_map import SigMapRefiner, compute_dwell_pen_array, index_from_kmer
+
+    g = golden("refine_signal_map.npz")
+    np.testing.assert_array_equal(compute_dwell_pen_array(4, 3, 0.5), g["sd_arr"])
+    assert index_from_kmer("CAAAAAAAA") == 65536 and index_from_kmer("AAA") == 0
+    a = SigMapRefiner(_levels_array=g["kmer_levels"], center_idx=2, do_rough_rescale=True, scale_iters=0)
+    b = SigMapRefiner.load_from_metadata(a.asdict())
+    assert a == b and a != SigMapRefiner()
+    assert SigMapRefiner() == SigMapRefiner() and not SigMapRefiner().is_loaded
+    table = {"".join(k): float(i) for i, k in enumerate(__import__("itertools").product("ACGT", repeat=2))}
+    c = SigMapRefiner.load_from_dict(table)
+    assert c.kmer_len == 2 and c.levels_array[index_from_kmer("CA")] == 4.0
+    with pytest.raises(RemoraError):
+        SigMapRefiner(scale_iters=0)  # refinement without a table
+    with pytest.raises(RemoraError):
+        SigMapRefiner(_levels_array=g["kmer_levels"], rough_rescale_method="nope", do_rough_rescale=True)
+
+
+def test_refinement_fails_loudly_without_gpu():
+    import torch
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = golden("refine_signal_map.npz")
+    ref = SigMapRefiner(_levels_array=g["kmer_levels"], center_idx=2, scale_iters=0)
+    read = RemoraRead(dacs=g["d_dacs"], shift=505.0, scale=83.0, seq_to_sig_map=g["d_map"].copy(),
+                      int_seq=g["d_int_seq"], read_id="d")
+    with pytest.raises(RemoraError, match="no GPU|GPU"):
+        read.refine_signal_mapping(ref)

@@ -231,3 +231,30 @@ def test_refine_read_flow():
                                                    g[f"{name}_int_seq"])
             np.testing.assert_array_equal(s2s, g[f"s{si}_{name}_map"], err_msg=f"setting {si} read {name}")
             np.testing.assert_allclose([shift, scale], g[f"s{si}_{name}_shift_scale"], rtol=1e-12)
+
+
+def test_call_read_mods_with_refiner_golden():
+    """A model whose metadata carries a k-mer level table: the oracle's refinement (rough re-scale +
+    dwell-penalty DP) followed by its call_read_mods reproduces the reference's call_read_mods."""
+    g = golden("call_read_mods_cg_5mc_refine.npz")
+    state = O.state_from_npz(g)
+    md = json.loads(str(g["derived_md_json"]))
+    raw = json.loads(str(g["meta_txt"]))
+    assert md["base_start_justify"] is True and md["offset"] == 1
+    ref = dict(levels=np.frombuffer(raw["refine_kmer_levels"].encode("cp437"), dtype=np.float32),
+               center_idx=int(raw["refine_kmer_center_idx"]), do_rough_rescale=bool(raw["refine_do_rough_rescale"]),
+               scale_iters=int(raw["refine_scale_iters"]), algo=raw["refine_algo"],
+               half_bandwidth=int(raw["refine_half_bandwidth"]),
+               sd_arr=np.frombuffer(raw["refine_sd_arr"].encode("cp437"), dtype=np.float32),
+               rough_rescale_method="least_squares")
+    moved = 0
+    for rname in g["read_names"]:
+        rname = str(rname)
+        shift, scale = (float(x) for x in g[f"{rname}_shift_scale"])
+        s2s, shift2, scale2 = O.refine_read(ref, g[f"{rname}_dacs"], shift, scale, g[f"{rname}_map"].copy(),
+                                            g[f"{rname}_int_seq"])
+        moved += int((s2s != g[f"{rname}_map"]).sum())
+        nn_out, labels, pos = O.call_read_mods(g[f"{rname}_dacs"], shift2, scale2, s2s, g[f"{rname}_int_seq"], state, md)
+        assert np.array_equal(pos, g[f"{rname}_pos"])
+        assert pos.size and np.abs(nn_out - g[f"{rname}_nn_out"]).max() < 2e-5
+    assert moved > 100  # the refinement really changed the mappings

@@ -520,10 +520,29 @@ def gen_call_read_mods(R, out):
         ("r_n", synth_read(rng, 200, with_n=True), 495.0, 83.0),
         ("r_none", (np.full(40, 500, np.int16), np.arange(0, 41, 10, dtype=np.int64), np.array([0, 0, 3, 3])), 500.0, 80.0),
     ]
+    # a model that carries a k-mer level table (like the released ONT models): RemoraRead.refine_signal_mapping
+    # (rough re-scale + one dwell-penalty DP pass) runs inside call_read_mods; reads follow the table
+    lrng = np.random.default_rng(91)
+    ref_levels = lrng.normal(0, 1, 4**5).astype(np.float32)
+    specs.append(("cg_5mc_refine", "ConvLSTM_w_ref", (4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 2))
+    level_reads = [
+        ("l_long", synth_levels_read(lrng, ref_levels, 5, 2, 700, 0.3), 508.0, 84.0),
+        ("l_mid", synth_levels_read(lrng, ref_levels, 5, 2, 150, 0.2), 492.0, 77.0),
+        ("l_stall", synth_levels_read(lrng, ref_levels, 5, 2, 320, 0.25, 70), 500.0, 80.0),
+    ]
+    generic_reads = reads
     for si, (name, arch, kcb, cc, mod_bases, mln, motifs, num_out) in enumerate(specs):
         K = sum(kcb) + 1
         net = make_net(R, arch, 64, K, num_out, seed=200 + si)
         ckpt = _ckpt(kcb, cc, mod_bases, mln, motifs, 64, K, num_out)
+        reads = generic_reads
+        if name.endswith("_refine"):
+            from remora.refine_signal_map import SigMapRefiner
+
+            ckpt.update(refine_kmer_levels=ref_levels, refine_kmer_center_idx=2, refine_do_rough_rescale=True,
+                        refine_scale_iters=0, refine_sd_arr=np.asarray(SigMapRefiner().sd_arr, np.float32),
+                        base_start_justify=True, offset=1)
+            reads = level_reads
         with tempfile.TemporaryDirectory() as td:
             pt = os.path.join(td, "m.pt")
             R.model_util.export_model_torchscript(ckpt, net, pt)
@@ -845,6 +864,24 @@ def gen_refine(R, out):
             read.refine_signal_mapping(ref)
             d[f"s{si}_{name}_map"] = np.asarray(read.seq_to_sig_map, np.int64)
             d[f"s{si}_{name}_shift_scale"] = np.asarray([read.shift, read.scale], np.float64)
+    # k-mer table file -> SigMapRefiner (load_kmer_table, determine_dominant_pos, fix_gauge; :226-349)
+    from itertools import product as _product
+
+    trng = np.random.default_rng(77)
+    base_lv = {"A": -1.2, "C": -0.3, "G": 0.5, "T": 1.4}
+    os.makedirs(os.path.join(out, "data"), exist_ok=True)
+    table_path = os.path.join(out, "data", "levels_4mer.txt")
+    with open(table_path, "w") as fh:
+        for kmer in _product("ACGT", repeat=4):
+            # position 2 dominates, position 1 contributes a little, plus noise; one NaN entry (reads as 0)
+            lvl = 80 + 12 * base_lv[kmer[2]] + 3 * base_lv[kmer[1]] + trng.normal(0, 0.8)
+            fh.write("".join(kmer).lower() + "\t" + ("nan" if "".join(kmer) == "ACGT" else f"{lvl:.4f}") + "\n")
+    for fix in (False, True):
+        ref = SigMapRefiner(kmer_model_filename=table_path, do_rough_rescale=True, do_fix_guage=fix)
+        tag = "fix" if fix else "raw"
+        d[f"table_{tag}_levels"] = np.asarray(ref.levels_array, np.float64)
+        d[f"table_{tag}_center"] = np.asarray(int(ref.center_idx))
+        d[f"table_{tag}_stats"] = np.asarray(ref.kmer_idx_stats, np.float64)
     np.savez_compressed(os.path.join(out, "refine_signal_map.npz"), **d)
     print("refine: done;", "moved", int((d["s0_b_map"] != d["b_map"]).sum()), "of", d["b_map"].size, "breakpoints in read b;",
           "shift/scale", d["s0_b_shift_scale"])

@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_refine
 mkdir -p $OUT
-for wpc in 4 8 12 16; do
+for wpc in 4 8 16; do
   echo "waves_per_cu=$wpc" >> $OUT/sweep.log
   RMR_REFINE_WAVES_PER_CU=$wpc timeout 300 python tools/bench_refine.py --reads 16384 2>/dev/null | tail -1 >> $OUT/sweep.log
   RMR_REFINE_WAVES_PER_CU=$wpc timeout 300 python tools/bench_refine.py --reads 2048 2>/dev/null | tail -1 >> $OUT/sweep.log
