@@ -151,3 +151,271 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         if batch:
             flush(batch, writer)
     return dict(stats)
+
+
+# ---------------------------------------------------------------------------------------------
+# Batching stages of `remora infer`, same names and bookkeeping as
+# the reference so that its queue plumbing can drive them unchanged.  The one deliberate
+# difference: a batch carries the chunks' compact k-mer arrays (`PackedKmers`: int8 sequence,
+# int16 mapping, int16 lengths = 72 B per chunk @C100) in the slot where the reference carries
+# the dense one-hot `enc_kmers` (14,400 B per chunk): the one-hot is never materialised, the
+# fused kernels expand it in LDS.  `PackedKmers.dense()` gives the reference's array when wanted.
+# ---------------------------------------------------------------------------------------------
+import queue as _queue
+from collections import defaultdict as _defaultdict
+
+
+class PackedKmers:
+    """Compact k-mer inputs of a batch of chunks (CoreRemoraDataset layout, data_chunks.py:942-948)."""
+
+    __slots__ = ("sequence", "mapping", "lengths", "kmer_context_bases")
+
+    def __init__(self, sequence, mapping, lengths, kmer_context_bases):
+        self.sequence, self.mapping, self.lengths = sequence, mapping, lengths
+        self.kmer_context_bases = tuple(int(x) for x in kmer_context_bases)
+
+    def __len__(self):
+        return int(self.lengths.shape[0])
+
+    def __getitem__(self, sl):
+        return PackedKmers(self.sequence[sl], self.mapping[sl], self.lengths[sl], self.kmer_context_bases)
+
+    def dense(self):
+        """float32 [n, 4*kmer_len, chunk_len] one-hot, as compute_encoded_kmer_batch returns it (GPU kernel)."""
+        from .encoded_kmers import compute_encoded_kmer_batch
+
+        return compute_encoded_kmer_batch(*self.kmer_context_bases, np.ascontiguousarray(self.sequence),
+                                          np.ascontiguousarray(self.mapping), np.ascontiguousarray(self.lengths))
+
+
+def _put_item(item, out_q):
+    while True:
+        try:
+            return out_q.put(item, timeout=0.1)
+        except _queue.Full:
+            continue
+
+
+def _queue_iter(in_q, num_proc=1):
+    done = 0
+    while done < num_proc:
+        try:
+            item = in_q.get(timeout=0.1)
+        except _queue.Empty:
+            continue
+        if item is StopIteration:
+            done += 1
+        else:
+            yield item
+
+
+def prepare_reads(read_errs, models_metadata, ref_anchored=False):
+    """[(io_read, err)] -> [(io_read, {can_base: chunk dict} | None, err)] (src/remora/inference.py:62-137).
+    A chunk dict holds `signal` f32[n,1,L], `kmers` (PackedKmers) and `read_focus_bases` i64[n] as host
+    arrays; chunk extraction runs on the GPU for the whole read at once instead of through an in-memory
+    CoreRemoraDataset per read and model."""
+    from .data_chunks import extract_chunk_arrays
+
+    out = []
+    for io_read, err in read_errs:
+        if err is not None:
+            out.append((io_read, None, err))
+            continue
+        try:
+            remora_read = io_read.into_remora_read(ref_anchored)
+        except RemoraError as e:
+            out.append((io_read, None, f"Read prep error: {e}"))
+            continue
+        except Exception as e:  # noqa: BLE001  (the reference reports and carries on, :95-99)
+            out.append((io_read, None, f"Unexpected error: {e}"))
+            continue
+        chunks = {}
+        for md in models_metadata:
+            rr = remora_read.copy()
+            rr.set_motif_focus_bases([Motif(*m) for m in md["motifs"]])
+            rr.refine_signal_mapping(md.get("sig_map_refiner"))
+            arrs = None
+            if rr.focus_bases is not None and len(rr.focus_bases):
+                arrs, _ = extract_chunk_arrays([rr], md["chunk_context"], md["kmer_context_bases"],
+                                               md["base_start_justify"], md["offset"])
+            if arrs is None or len(arrs) == 0:
+                out.append((io_read, None, f"No {md['can_base']} mod calls"))
+                continue
+            chunks[md["can_base"]] = {
+                "signal": arrs.signal.cpu().numpy(),
+                "kmers": PackedKmers(arrs.sequence.cpu().numpy(), arrs.mapping.cpu().numpy(), arrs.lengths.cpu().numpy(),
+                                     md["kmer_context_bases"]),
+                "read_focus_bases": arrs.read_focus_bases.cpu().numpy(),
+            }
+        out.append((io_read, chunks, None))
+    return out
+
+
+def prep_nn_input(read_errs):
+    """:152-168 - the per-read chunk dicts are already network inputs here."""
+    if len(read_errs) == 0:
+        return [(None, None, "No valid mappings")]
+    return [(io_read, None, err) if err is not None else (io_read, chunks, None) for io_read, chunks, err in read_errs]
+
+
+def batch_reads(prepped_nn_inputs, batches_q, batch_size, models_metadata):
+    """Pack per-read chunk dicts into batches of exactly `batch_size` chunks per canonical base and put
+    `(can_base, sigs f32[B,1,L], kmers PackedKmers[B], read_pos i64[B], b_reads)` on `batches_q`;
+    `b_reads` = [[io_read, b_st, b_en, err], ...] with the reference's meaning (b_st None: the read
+    continues from the previous batch; b_en None: it continues into the next), :171-262."""
+    md_dict = dict((md["can_base"], md) for md in models_metadata)
+    can_bases = list(md_dict)
+
+    class _Acc:
+        def __init__(self, cb):
+            L = md_dict[cb]["chunk_len"]
+            self.sig = np.empty((batch_size, 1, L), dtype=np.float32)
+            self.pos = np.empty(batch_size, dtype=int)
+            self.seq = self.map = None
+            self.len = np.zeros(batch_size, dtype=np.int16)
+            self.kcb = None
+            self.fill = 0
+            self.reads = []
+
+        def put(self, r_chunks, lo, hi):
+            n = hi - lo
+            k = r_chunks["kmers"]
+            if self.seq is None or k.sequence.shape[1] > self.seq.shape[1] or k.mapping.shape[1] > self.map.shape[1]:
+                # reads differ in their widest chunk: widen the batch arrays (sequence pads with -1, mapping with 0)
+                sw = max(k.sequence.shape[1], 0 if self.seq is None else self.seq.shape[1])
+                mw = max(k.mapping.shape[1], 0 if self.map is None else self.map.shape[1])
+                seq = np.full((batch_size, sw), -1, dtype=np.int8)
+                mp = np.zeros((batch_size, mw), dtype=np.int16)
+                if self.seq is not None:
+                    seq[: self.fill, : self.seq.shape[1]] = self.seq[: self.fill]
+                    mp[: self.fill, : self.map.shape[1]] = self.map[: self.fill]
+                self.seq, self.map = seq, mp
+            self.kcb = k.kmer_context_bases
+            self.sig[self.fill : self.fill + n] = r_chunks["signal"][lo:hi]
+            self.pos[self.fill : self.fill + n] = r_chunks["read_focus_bases"][lo:hi]
+            self.seq[self.fill : self.fill + n] = -1
+            self.map[self.fill : self.fill + n] = 0
+            self.seq[self.fill : self.fill + n, : k.sequence.shape[1]] = k.sequence[lo:hi]
+            self.map[self.fill : self.fill + n, : k.mapping.shape[1]] = k.mapping[lo:hi]
+            self.len[self.fill : self.fill + n] = k.lengths[lo:hi]
+            self.fill += n
+
+        def emit(self, cb):
+            n = self.fill
+            kmers = PackedKmers(self.seq[:n], self.map[:n], self.len[:n], self.kcb) if self.seq is not None else None
+            _put_item((cb, self.sig[:n], kmers, self.pos[:n], self.reads), batches_q)
+
+    acc = dict((cb, _Acc(cb)) for cb in can_bases)
+    for read_nn_inputs in prepped_nn_inputs:
+        for io_read, bases_chunks, err in read_nn_inputs:
+            if err is not None:
+                for cb in can_bases:
+                    acc[cb].reads.append([io_read, None, None, err])
+                continue
+            for cb, r_chunks in bases_chunks.items():
+                num_chunks = r_chunks["read_focus_bases"].size
+                consumed = 0
+                while acc[cb].fill + num_chunks - consumed >= batch_size:  # the read fills this batch up
+                    b_st = acc[cb].fill if consumed == 0 else None
+                    take = batch_size - acc[cb].fill
+                    acc[cb].put(r_chunks, consumed, consumed + take)
+                    acc[cb].reads.append([io_read, b_st, None, None])
+                    acc[cb].emit(cb)
+                    consumed += take
+                    acc[cb] = _Acc(cb)
+                b_st = acc[cb].fill if consumed == 0 else None
+                acc[cb].put(r_chunks, consumed, num_chunks)
+                acc[cb].reads.append([io_read, b_st, acc[cb].fill, None])
+    for cb in can_bases:
+        if acc[cb].fill > 0:
+            acc[cb].emit(cb)
+    _put_item(StopIteration, batches_q)
+
+
+def run_model_batched(batches_q, called_batches_q, models, models_metadata, batch_size):
+    """:277-316 - `models[can_base]` is a HipModel; a batch goes through the fused chunk-arrays -> logits path
+    (one H2D of 472 B per chunk instead of 14.8 KB).  `nn_out` is a torch tensor, as in the reference."""
+    for can_base, b_sigs, b_kmers, b_read_pos, b_reads in _queue_iter(batches_q):
+        model = models[can_base]
+        if isinstance(b_kmers, PackedKmers):
+            nn_out = model.infer_chunks(b_sigs, b_kmers.sequence, b_kmers.mapping, b_kmers.lengths, b_kmers.kmer_context_bases)
+        else:  # a dense one-hot from a reference-side producer
+            import torch
+
+            dev = next(model.parameters()).device
+            nn_out = model(torch.from_numpy(np.ascontiguousarray(b_sigs)).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(b_kmers)).to(dev))
+        _put_item((can_base, nn_out, b_read_pos, b_reads), called_batches_q)
+    _put_item(StopIteration, called_batches_q)
+
+
+def unbatch_reads(curr_read, b_nn_out, b_read_pos, b_reads):
+    """Re-assemble per-read outputs from one called batch (:331-367).  Returns (completed reads, read still open)."""
+    comp = []
+    for io_read, b_st, b_en, err in b_reads:
+        if err is not None:
+            if curr_read is not None:
+                comp.append(curr_read)
+            comp.append((io_read, None, None, err))
+            curr_read = None
+        elif b_st is None:  # continues from the previous batch
+            if curr_read is None:
+                raise RemoraError("Unbatching encountered None read")
+            if curr_read[0].read_id != io_read.read_id:
+                raise RemoraError("Unbatching encountered mismatching reads")
+            io_read, r_out, r_pos, _ = curr_read
+            curr_read = (io_read, np.concatenate([r_out, b_nn_out[:b_en]], axis=0),
+                         np.concatenate([r_pos, b_read_pos[:b_en]]), None)
+        else:
+            if curr_read is not None:
+                comp.append(curr_read)
+            curr_read = (io_read, b_nn_out[b_st:b_en], b_read_pos[b_st:b_en], None)
+    return comp, curr_read
+
+
+def unbatch(called_batches_q, called_reads_q, models_metadata):
+    """Called batches -> `(io_read, [(can_base, nn_out, read_pos), ...], err)` once every model has finished
+    a read (:370-415)."""
+
+    def finished(reads):
+        calls, errs = [], set()
+        for can_base, (io_read, nn_out, r_pos, err) in reads:
+            errs.add(err)
+            if err is None:
+                calls.append((can_base, nn_out, r_pos))
+        r_err = None if any(e is None for e in errs) else ",".join(sorted(errs))
+        return io_read, calls, r_err
+
+    can_bases = [md["can_base"] for md in models_metadata]
+    curr = dict((cb, None) for cb in can_bases)
+    comp = _defaultdict(list)
+    for can_base, nn_out, b_read_pos, b_reads in _queue_iter(called_batches_q):
+        done, curr[can_base] = unbatch_reads(curr[can_base], nn_out.cpu().numpy(), b_read_pos, b_reads)
+        for c in done:
+            comp[c[0].read_id].append((can_base, c))
+        for rid in [rid for rid, cs in comp.items() if len(cs) == len(can_bases)]:
+            _put_item(finished(comp[rid]), called_reads_q)
+            del comp[rid]
+    if curr[can_bases[0]] is not None:
+        _put_item(finished([(cb, curr[cb]) for cb in can_bases]), called_reads_q)
+    _put_item(StopIteration, called_reads_q)
+
+
+def post_process_reads(read_mapping, models_metadata, ref_anchored=False):
+    """(io_read, mod_calls, err) -> (io_read, MM string, ML array) | (io_read, err): softmax, drop the canonical
+    class, MM/ML formatting per model (:429-459).  The BAM record itself is rebuilt by io.record_with_mod_tags."""
+    import array
+
+    io_read, mod_calls, err = read_mapping
+    if err is not None:
+        return io_read, err
+    md_dict = dict((md["can_base"], md) for md in models_metadata)
+    mm_tags, ml_arr = [], array.array("B")
+    for can_base, nn_out, r_poss in mod_calls:
+        probs = softmax_axis1(nn_out)[:, 1:].astype(np.float64)
+        seq = io_read.ref_seq if ref_anchored else io_read.seq
+        mm, ml = format_mm_ml_tags(seq=seq, poss=r_poss, probs=probs, mod_bases=md_dict[can_base]["mod_bases"],
+                                   can_base=can_base)
+        mm_tags.append(mm)
+        ml_arr.extend(ml)
+    return io_read, "".join(mm_tags), ml_arr

@@ -659,3 +659,47 @@ def test_core_dataset_on_disk(torch_cuda, O, tag):
         assert np.array_equal(res["pred_counts"], np.bincount(ref.argmax(1), minlength=2))
         assert res["confusion"].sum() == 120 and np.array_equal(res["confusion"].sum(0), res["pred_counts"])
         assert np.array_equal(ds.get_label_counts(), np.bincount(g[f"{tag}_labels"], minlength=2))
+
+
+def test_staged_infer_pipeline_on_real_reads(torch_cuda, O, tmp_path):
+    """The reference's `remora infer` stages under their own names (prepare_reads -> prep_nn_input ->
+    batch_reads -> run_model_batched -> unbatch -> post_process_reads) on the reference's POD5 + BAM test
+    data, batch size 64 so that reads straddle batches: per-read positions, logits and MM strings equal
+    the reference's call_read_mods on the same reads."""
+    import queue
+
+    from remora_amd import io as rio
+    from remora_amd.inference import (batch_reads, post_process_reads, prep_nn_input, prepare_reads, run_model_batched,
+                                      unbatch)
+    from remora_amd.model_util import load_model
+
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    g = golden("real_reads_can.npz")
+    model, md = load_model(_mint_pt(tmp_path, g, O), device=0)
+    read_errs = list(rio.iter_reads_from_pod5_and_bam(os.path.join(data, "can_reads.pod5"),
+                                                      os.path.join(data, "can_mappings.bam")))
+    names = [r.read_id for r, _ in read_errs]
+    prepped = [prep_nn_input(prepare_reads([re], [md])) for re in read_errs]
+    bq, cq, rq = queue.Queue(), queue.Queue(), queue.Queue()
+    batch_reads(iter(prepped), bq, 64, [md])
+    run_model_batched(bq, cq, {md["can_base"]: model}, [md], 64)
+    unbatch(cq, rq, [md])
+    done = []
+    while True:
+        it = rq.get()
+        if it is StopIteration:
+            break
+        done.append(it)
+    assert [d[0].read_id for d in done] == names
+    total = 0
+    for i, rm in enumerate(done):
+        io_read, mod_calls, err = rm
+        assert err is None and len(mod_calls) == 1
+        _, nn_out, pos = mod_calls[0]
+        assert np.array_equal(pos, g[f"r{i}_pos"])
+        assert np.abs(nn_out - g[f"r{i}_nn_out"]).max() <= 1e-4
+        _, mm, ml = post_process_reads(rm, [md])
+        assert mm == str(g[f"r{i}_mm"])
+        assert np.abs(np.asarray(list(ml), np.uint8).astype(int) - g[f"r{i}_ml"].astype(int)).max() <= 1
+        total += pos.size
+    assert total == 922

@@ -415,3 +415,95 @@ def test_refinement_fails_loudly_without_gpu():
                       int_seq=g["d_int_seq"], read_id="d")
     with pytest.raises(RemoraError, match="no GPU|GPU"):
         read.refine_signal_mapping(ref)
+
+
+# ---- B1 / N3: batching bookkeeping of `remora infer` ---------------------------------------------
+def _batching_inputs(g):
+    from types import SimpleNamespace
+
+    from remora_amd.inference import PackedKmers
+
+    kcb = tuple(int(x) for x in g["kmer_context_bases"])
+    reads, prepped = {}, []
+    for ri in range(6):
+        io_read = SimpleNamespace(read_id=f"read{ri}")
+        reads[io_read.read_id] = io_read
+        if f"r{ri}_err" in g:
+            prepped.append([(io_read, None, str(g[f"r{ri}_err"]))])
+            continue
+        chunks = {}
+        for cb in "CA":
+            chunks[cb] = {"signal": g[f"r{ri}_{cb}_signal"],
+                          "kmers": PackedKmers(g[f"r{ri}_{cb}_sequence"], g[f"r{ri}_{cb}_mapping"], g[f"r{ri}_{cb}_lengths"], kcb),
+                          "read_focus_bases": g[f"r{ri}_{cb}_rfb"]}
+        prepped.append([(io_read, chunks, None)])
+    prepped.append([])
+    L = int(g["chunk_len"])
+    mds = [dict(can_base="C", chunk_len=L, kmer_len=sum(kcb) + 1), dict(can_base="A", chunk_len=L, kmer_len=sum(kcb) + 1)]
+    return prepped, mds, kcb
+
+
+def test_batch_reads_and_unbatch_match_reference():
+    """Same batches (signals, read positions, [read, b_st, b_en, err] spans, k-mer content) and the same per-read
+    re-assembly as the reference's batch_reads / unbatch on reads that straddle batches (tools/gen_golden.py
+    gen_batching): 6 reads incl. an error read, 2 canonical-base models, batch size 4."""
+    import queue
+    from types import SimpleNamespace
+
+    from oracle import oracle as O
+    from remora_amd.inference import batch_reads, unbatch
+
+    g = golden("batching.npz")
+    prepped, mds, kcb = _batching_inputs(g)
+    bq = queue.Queue()
+    batch_reads(iter(prepped), bq, int(g["batch_size"]), mds)
+    batches = []
+    while True:
+        it = bq.get()
+        if it is StopIteration:
+            break
+        batches.append(it)
+    assert len(batches) == int(g["num_batches"])
+    called = queue.Queue()
+    for bi, (cb, b_sigs, b_kmers, b_pos, b_reads) in enumerate(batches):
+        assert cb == str(g[f"b{bi}_can_base"])
+        np.testing.assert_array_equal(b_sigs, g[f"b{bi}_sigs"])
+        np.testing.assert_array_equal(b_pos, g[f"b{bi}_pos"])
+        assert json.dumps([[r.read_id, st, en, err] for r, st, en, err in b_reads]) == str(g[f"b{bi}_spans"])
+        enc = O.compute_encoded_kmer_batch(kcb[0], kcb[1], b_kmers.sequence, b_kmers.mapping, b_kmers.lengths)
+        np.testing.assert_array_equal(enc.astype(np.uint8), g[f"b{bi}_enc"])
+        nn_out = g[f"b{bi}_nn_out"]
+        called.put((cb, SimpleNamespace(cpu=lambda a=nn_out: SimpleNamespace(numpy=lambda a=a: a)), b_pos, b_reads))
+    called.put(StopIteration)
+    rq = queue.Queue()
+    unbatch(called, rq, mds)
+    done = []
+    while True:
+        it = rq.get()
+        if it is StopIteration:
+            break
+        done.append(it)
+    assert len(done) == int(g["num_done"])
+    for di, (io_read, mod_calls, err) in enumerate(done):
+        assert io_read.read_id == str(g[f"d{di}_read_id"])
+        assert (err or "") == str(g[f"d{di}_err"])
+        assert [cb for cb, _, _ in mod_calls] == [str(x) for x in g[f"d{di}_bases"]]
+        for cb, nn_out, pos in mod_calls:
+            np.testing.assert_array_equal(nn_out, g[f"d{di}_{cb}_nn_out"])
+            np.testing.assert_array_equal(pos, g[f"d{di}_{cb}_pos"])
+
+
+def test_prep_nn_input_and_unbatch_errors():
+    from types import SimpleNamespace
+
+    from remora_amd import RemoraError
+    from remora_amd.inference import prep_nn_input, unbatch_reads
+
+    assert prep_nn_input([]) == [(None, None, "No valid mappings")]
+    r = SimpleNamespace(read_id="a")
+    assert prep_nn_input([(r, None, "boom")]) == [(r, None, "boom")]
+    with pytest.raises(RemoraError, match="None read"):
+        unbatch_reads(None, np.zeros((2, 2)), np.zeros(2), [[r, None, 1, None]])
+    other = (SimpleNamespace(read_id="b"), np.zeros((1, 2)), np.zeros(1), None)
+    with pytest.raises(RemoraError, match="mismatching"):
+        unbatch_reads(other, np.zeros((2, 2)), np.zeros(2), [[r, None, 1, None]])

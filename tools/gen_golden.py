@@ -887,6 +887,86 @@ def gen_refine(R, out):
           "shift/scale", d["s0_b_shift_scale"])
 
 
+def gen_batching(R, out):
+    """inference.batch_reads (inference.py:171-262), unbatch_reads (:331-367) and unbatch (:370-415): reads
+    whose chunks straddle fixed-size batches, error reads in between, two canonical-base models."""
+    import queue
+    from types import SimpleNamespace
+
+    rng = np.random.default_rng(31)
+    L, kb, ka, W = 20, 1, 1, 8
+    mds = [dict(can_base="C", chunk_len=L, kmer_len=kb + ka + 1), dict(can_base="A", chunk_len=L, kmer_len=kb + ka + 1)]
+    counts = {"C": [5, 13, None, 2, 9, 1], "A": [3, 7, None, 6, 4, 2]}  # None: error read
+    d = {"batch_size": np.asarray(4), "chunk_len": np.asarray(L), "kmer_context_bases": np.asarray([kb, ka])}
+    reads, prepped = [], []
+    for ri in range(6):
+        io_read = SimpleNamespace(read_id=f"read{ri}")
+        reads.append(io_read)
+        if counts["C"][ri] is None:
+            prepped.append([(io_read, None, "Read prep error: spoofed")])
+            d[f"r{ri}_err"] = np.asarray("Read prep error: spoofed")
+            continue
+        bases_chunks = {}
+        for cb in "CA":
+            n = counts[cb][ri]
+            if n == 0:
+                continue
+            lens = rng.integers(2, W - kb - ka, n).astype(np.int16)
+            seqs = np.full((n, W), -1, np.int8)
+            maps = np.zeros((n, W - kb - ka + 1), np.int16)
+            for c in range(n):
+                seqs[c, : lens[c] + kb + ka] = rng.integers(0, 4, lens[c] + kb + ka)
+                cuts = np.sort(rng.choice(np.arange(1, L), lens[c] - 1, replace=False))
+                maps[c, : lens[c] + 1] = np.concatenate([[0], cuts, [L]])
+            sig = rng.standard_normal((n, 1, L)).astype(np.float32)
+            enc = R.encoded_kmers.compute_encoded_kmer_batch(kb, ka, seqs, maps, lens)
+            rfb = rng.integers(0, 5000, n).astype(np.int64)
+            bases_chunks[cb] = {"signal": sig, "enc_kmers": enc, "read_focus_bases": rfb}
+            for k, v in (("signal", sig), ("sequence", seqs), ("mapping", maps), ("lengths", lens), ("rfb", rfb)):
+                d[f"r{ri}_{cb}_{k}"] = v
+        prepped.append([(io_read, bases_chunks, None)])
+    prepped.append([])  # a read without valid mappings contributes nothing (prep_nn_input turns [] into an error)
+    bq = queue.Queue()
+    R.inference.batch_reads(iter(prepped), bq, 4, mds)
+    batches = []
+    while True:
+        it = bq.get()
+        if it is StopIteration:
+            break
+        batches.append(it)
+    d["num_batches"] = np.asarray(len(batches))
+    called = queue.Queue()
+    for bi, (cb, b_sigs, b_enc, b_pos, b_reads) in enumerate(batches):
+        d[f"b{bi}_can_base"] = np.asarray(cb)
+        d[f"b{bi}_sigs"] = np.asarray(b_sigs)
+        d[f"b{bi}_enc"] = np.asarray(b_enc).astype(np.uint8)
+        d[f"b{bi}_pos"] = np.asarray(b_pos, np.int64)
+        d[f"b{bi}_spans"] = np.asarray(json.dumps([[r.read_id, st, en, err] for r, st, en, err in b_reads]))
+        # a stand-in network output that depends on the chunk: (mean signal, read position)
+        nn_out = np.stack([b_sigs.mean(axis=(1, 2)), b_pos.astype(np.float32)], axis=1).astype(np.float32)
+        d[f"b{bi}_nn_out"] = nn_out
+        called.put((cb, SimpleNamespace(cpu=lambda a=nn_out: SimpleNamespace(numpy=lambda a=a: a)), b_pos, b_reads))
+    called.put(StopIteration)
+    rq = queue.Queue()
+    R.inference.unbatch(called, rq, mds)
+    done = []
+    while True:
+        it = rq.get()
+        if it is StopIteration:
+            break
+        done.append(it)
+    d["num_done"] = np.asarray(len(done))
+    for di, (io_read, mod_calls, err) in enumerate(done):
+        d[f"d{di}_read_id"] = np.asarray(io_read.read_id)
+        d[f"d{di}_err"] = np.asarray("" if err is None else err)
+        d[f"d{di}_bases"] = np.asarray([cb for cb, _, _ in mod_calls])
+        for cb, nn_out, pos in mod_calls:
+            d[f"d{di}_{cb}_nn_out"] = np.asarray(nn_out)
+            d[f"d{di}_{cb}_pos"] = np.asarray(pos)
+    np.savez_compressed(os.path.join(out, "batching.npz"), **d)
+    print("batching:", len(batches), "batches;", len(done), "reads returned:", [str(x[0].read_id) + ("!" if x[2] else "") for x in done])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -908,6 +988,7 @@ def main():
         real_reads=gen_real_reads,
         core_dataset=gen_core_dataset,
         refine=gen_refine,
+        batching=gen_batching,
     )
     for name, fn in gens.items():
         if args.only and name not in args.only.split(","):
