@@ -34,6 +34,7 @@ struct rmr_refiner {
     rmr_engine *e = nullptr;
     float *d_levels = nullptr;  // [4^kmer_len]
     float *d_sdp = nullptr;     // [sd_len]
+    int device = 0;  // copy: the engine may be gone when the refiner is destroyed at interpreter exit
     int kmer_len = 0, center_idx = 0, sd_len = 0, algo = 1, hbw = 5, min_step = 2;
     uint32_t *d_ckpt = nullptr;  // checkpoints of the persistent DP waves (dwell penalty only)
     int *d_counter = nullptr;    // work counter of the persistent DP waves
@@ -802,6 +803,7 @@ int rmr_refiner_create(rmr_engine *e, const rmr_refine_desc *desc, rmr_refiner *
     RMR_HIP(hipSetDevice(e->device));
     auto *r = new rmr_refiner;
     r->e = e;
+    r->device = e->device;
     r->kmer_len = desc->kmer_len; r->center_idx = desc->center_idx; r->algo = desc->algo;
     r->hbw = desc->half_bandwidth; r->min_step = desc->min_step;
     r->sd_len = desc->algo == RMR_REFINE_DWELL_PENALTY ? desc->sd_len : 0;
@@ -827,7 +829,7 @@ int rmr_refiner_create(rmr_engine *e, const rmr_refine_desc *desc, rmr_refiner *
 
 void rmr_refiner_destroy(rmr_refiner *r) {
     if (!r) return;
-    (void)hipSetDevice(r->e->device);
+    (void)hipSetDevice(r->device);
     if (r->d_levels) (void)hipFree(r->d_levels);
     if (r->d_sdp) (void)hipFree(r->d_sdp);
     if (r->d_counter) (void)hipFree(r->d_counter);

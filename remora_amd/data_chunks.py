@@ -335,15 +335,64 @@ import os
 DATASET_VERSION = 3
 
 
+def dataset_metadata(allocate_size, max_seq_len, mod_bases, mod_long_names, motif_sequences, motif_offsets,
+                     chunk_context=(50, 50), kmer_context_bases=(4, 4), base_start_justify=False, offset=0,
+                     reverse_signal=False, pa_scaling=None, extra_arrays=None, sig_map_refiner=None,
+                     modified_base_labels=True, rough_rescale_method="least_squares"):
+    """The JSON-able dict the reference's DatasetMetadata.write stores in metadata.jsn
+    (src/remora/data_chunks.py:786-888): same keys, same order, refiner fields flattened in."""
+    from .refine_signal_map import SigMapRefiner
+
+    ref = sig_map_refiner if sig_map_refiner is not None else SigMapRefiner()
+    md = {
+        "allocate_size": int(allocate_size), "max_seq_len": int(max_seq_len), "mod_bases": list(mod_bases),
+        "mod_long_names": list(mod_long_names), "motif_sequences": list(motif_sequences),
+        "motif_offsets": [int(x) for x in motif_offsets], "dataset_start": 0, "dataset_end": 0,
+        "version": DATASET_VERSION, "modified_base_labels": bool(modified_base_labels), "extra_arrays": extra_arrays,
+        "chunk_context": [int(x) for x in chunk_context], "base_start_justify": bool(base_start_justify),
+        "offset": int(offset), "kmer_context_bases": [int(x) for x in kmer_context_bases],
+        "reverse_signal": bool(reverse_signal), "pa_scaling": pa_scaling, "rough_rescale_method": rough_rescale_method,
+        "_stored_kmer_context_bases": None, "_stored_chunk_context": None,
+    }
+    md.update(ref.asdict())
+    md.pop("rough_rescale_method")
+    md["rough_rescale_method"] = ref.rough_rescale_method if ref.is_loaded else rough_rescale_method
+    # keep the reference's key order: ..., pa_scaling, rough_rescale_method, _stored_*, refine_*
+    order = ["allocate_size", "max_seq_len", "mod_bases", "mod_long_names", "motif_sequences", "motif_offsets",
+             "dataset_start", "dataset_end", "version", "modified_base_labels", "extra_arrays", "chunk_context",
+             "base_start_justify", "offset", "kmer_context_bases", "reverse_signal", "pa_scaling",
+             "rough_rescale_method", "_stored_kmer_context_bases", "_stored_chunk_context", "refine_kmer_levels",
+             "refine_kmer_center_idx", "refine_do_rough_rescale", "refine_scale_iters", "refine_algo",
+             "refine_half_bandwidth", "refine_sd_arr"]
+    return {k: md[k] for k in order}
+
+
 class CoreRemoraDataset:
+    """On-disk chunk dataset in the reference's format (src/remora/data_chunks.py:926-1702): five raw
+    memmapped core arrays named `<array>.npy` (no npy header) + `metadata.jsn` (+ `kmer_table.npy`).
+    mode "r" reads a directory (optionally with smaller chunk / k-mer contexts than stored);
+    mode "w" creates one from `metadata` (see `dataset_metadata`) and appends chunk arrays that the
+    extraction kernels already produce in this layout."""
+
     _core_dtypes = {"signal": np.float32, "sequence": np.int8, "sequence_to_signal_mapping": np.int16,
                     "sequence_lengths": np.int16, "labels": np.int64}
 
-    def __init__(self, data_path, override_metadata=None, batch_size=2048):
+    def __init__(self, data_path, override_metadata=None, batch_size=2048, mode="r", metadata=None):
         self.data_path = data_path
         self.batch_size = int(batch_size)
-        with open(os.path.join(data_path, "metadata.jsn")) as fh:
-            md = json.load(fh)
+        self.mode = mode
+        if mode not in ("r", "w"):
+            raise RemoraError("mode must be 'r' or 'w'")
+        if mode == "w":
+            if not isinstance(metadata, dict) or "allocate_size" not in metadata:
+                raise RemoraError("Must provide metadata for new dataset")
+            if override_metadata:
+                raise RemoraError("Cannot override metadata of a dataset opened for writing")
+            os.makedirs(data_path, exist_ok=True)
+            md = dict(metadata)
+        else:
+            with open(os.path.join(data_path, "metadata.jsn")) as fh:
+                md = json.load(fh)
         if md.get("version") != DATASET_VERSION:
             raise RemoraError(f"Remora dataset version ({md.get('version')}) does not match current "
                               f"distribution ({DATASET_VERSION})")
@@ -374,9 +423,117 @@ class CoreRemoraDataset:
         self.arrays = {}
         for name, dt in self._core_dtypes.items():
             path = os.path.join(data_path, f"{name}.npy")
+            if mode == "w":
+                self.arrays[name] = np.memmap(path, dt, mode="w+", shape=shapes[name])
+                continue
             if os.path.getsize(path) != int(np.prod(shapes[name])) * np.dtype(dt).itemsize:
                 raise RemoraError(f"{path} does not have the size metadata.jsn implies")
             self.arrays[name] = np.memmap(path, dt, mode="r", shape=shapes[name])
+        if mode == "w":
+            self.write_metadata()
+
+    # ---- writing (:1268-1469) ----------------------------------------------------------------
+    def write_metadata(self):
+        """metadata.jsn (+ kmer_table.npy when a level table is attached), as DatasetMetadata.write (:865-888)."""
+        md = dict(self.metadata)
+        levels = md.get("refine_kmer_levels")
+        if levels is not None:
+            np.save(os.path.join(self.data_path, "kmer_table.npy"), np.asarray(levels), allow_pickle=False)
+            del md["refine_kmer_levels"]
+
+        def enc(o):
+            if isinstance(o, np.integer):
+                return int(o)
+            if isinstance(o, np.floating):
+                return float(o)
+            if isinstance(o, np.bool_):
+                return bool(o)
+            if isinstance(o, np.ndarray):
+                return o.tolist()
+            raise TypeError(type(o))
+
+        with open(os.path.join(self.data_path, "metadata.jsn"), "w") as fh:
+            json.dump(md, fh, default=enc)
+
+    def write_batch(self, arrays):
+        """Append rows given as {array name: array[n, ...]} in the core dtypes (:1345-1374)."""
+        if self.mode != "w":
+            raise RemoraError("Cannot write when mode is not 'w'")
+        n = next(iter(arrays.values())).shape[0]
+        if any(a.shape[0] != n for a in arrays.values()):
+            raise RemoraError("All arrays in a batch must be the same size")
+        end = int(self.metadata["dataset_end"])
+        if end + n > int(self.metadata["allocate_size"]):
+            self.write_metadata()
+            raise RemoraError("Batch write greater than allocated memory")
+        missing = set(self.arrays).difference(arrays)
+        if missing:
+            raise RemoraError(f"Batch write must include all arrays. Missing: {', '.join(sorted(missing))}")
+        extra = set(arrays).difference(self.arrays)
+        if extra:
+            raise RemoraError(f"Batch write must only include spcified arrays. Found: {', '.join(sorted(extra))}")
+        for name, a in arrays.items():
+            out = self.arrays[name]
+            a = np.asarray(a)
+            if a.ndim == 2 and a.shape[1] < out.shape[1]:  # narrower rows: the tail columns are padding
+                out[end : end + n, : a.shape[1]] = a
+                out[end : end + n, a.shape[1] :] = -1 if name == "sequence" else 0
+            else:
+                out[end : end + n] = a
+        self.metadata["dataset_end"] = end + n
+
+    def write_chunk(self, chunk):
+        """One `Chunk` (:1376-1418)."""
+        self.write_batch({
+            "signal": np.asarray(chunk.signal, np.float32)[None, None, :],
+            "sequence": np.asarray(chunk.seq_w_context, np.int8)[None, :],
+            "sequence_to_signal_mapping": np.asarray(chunk.seq_to_sig_map, np.int16)[None, :],
+            "sequence_lengths": np.asarray([chunk.seq_len], np.int16),
+            "labels": np.asarray([chunk.label], np.int64),
+        })
+
+    def write_chunk_arrays(self, arrs, keep=None):
+        """Append GPU-extracted `ChunkArrays` (extract_chunk_arrays); chunks longer than max_seq_len are
+        dropped, as `remora dataset prepare` does (src/remora/prepare_train_data.py:213-221).  Returns
+        the number of chunks written."""
+        lens = arrs.lengths.cpu().numpy()
+        ok = lens <= int(self.metadata["max_seq_len"])
+        if keep is not None:
+            ok &= np.asarray(keep, bool)
+        if not ok.any():
+            return 0
+        msl = int(self.metadata["max_seq_len"])
+        sw, mw = msl + sum(self.stored_kmer_context_bases), msl + 1
+        seq = arrs.sequence.cpu().numpy()[ok]
+        mp = arrs.mapping.cpu().numpy()[ok]
+        self.write_batch({
+            "signal": arrs.signal.cpu().numpy()[ok],
+            "sequence": seq[:, :sw],
+            "sequence_to_signal_mapping": mp[:, :mw],
+            "sequence_lengths": lens[ok],
+            "labels": np.asarray(arrs.labels, np.int64)[ok],
+        })
+        return int(ok.sum())
+
+    def shuffle(self, batch_size=100_000):
+        """Random permutation of the written rows, every array with the same permutation (:1420-1469)."""
+        if self.mode != "w":
+            raise RemoraError("Cannot write when mode is not 'w'")
+        a0, a1 = int(self.metadata["dataset_start"]), int(self.metadata["dataset_end"])
+        perm = np.random.permutation(a1 - a0)
+        for a in self.arrays.values():
+            view = a[a0:a1]
+            src = view.copy()
+            for st in range(0, a1 - a0, batch_size):
+                view[st : st + batch_size] = src[perm[st : st + batch_size]]
+            a.flush()
+
+    def flush(self):
+        for a in self.arrays.values():
+            if hasattr(a, "flush"):
+                a.flush()
+        if self.mode == "w":
+            self.write_metadata()
 
     @property
     def size(self):

@@ -345,6 +345,10 @@ def run_model_batched(batches_q, called_batches_q, models, models_metadata, batc
             dev = next(model.parameters()).device
             nn_out = model(torch.from_numpy(np.ascontiguousarray(b_sigs)).to(dev),
                            torch.from_numpy(np.ascontiguousarray(b_kmers)).to(dev))
+        if isinstance(nn_out, np.ndarray):
+            import torch
+
+            nn_out = torch.from_numpy(nn_out)
         _put_item((can_base, nn_out, b_read_pos, b_reads), called_batches_q)
     _put_item(StopIteration, called_batches_q)
 

@@ -703,3 +703,44 @@ def test_staged_infer_pipeline_on_real_reads(torch_cuda, O, tmp_path):
         assert np.abs(np.asarray(list(ml), np.uint8).astype(int) - g[f"r{i}_ml"].astype(int)).max() <= 1
         total += pos.size
     assert total == 922
+
+
+def test_core_dataset_writer_matches_reference_files(torch_cuda, tmp_path):
+    """CoreRemoraDataset(mode="w") fed by the GPU extraction kernels writes the directory the reference wrote
+    from the same two labelled reads (tests/golden/data/core_dataset): identical metadata.jsn text, identical
+    signal / lengths / labels files, identical sequence / mapping rows up to each chunk's length (the reference
+    leaves the padding columns uninitialised), and the result reads back through the trimming reader."""
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraRead, dataset_metadata, extract_chunk_arrays
+    from remora_amd.util import Motif
+
+    g = golden("core_dataset.npz")
+    ref_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data", "core_dataset")
+    md = dataset_metadata(allocate_size=int(g["num_chunks"]) + 7, max_seq_len=20, mod_bases=["m"], mod_long_names=["5mC"],
+                          motif_sequences=["CG"], motif_offsets=[0], chunk_context=(50, 50), kmer_context_bases=(4, 4))
+    out_dir = str(tmp_path / "ds")
+    ds = CoreRemoraDataset(out_dir, mode="w", metadata=md)
+    for ri in range(2):
+        read = RemoraRead(dacs=g[f"ds{ri}_dacs"], shift=500.0, scale=80.0, seq_to_sig_map=g[f"ds{ri}_map"],
+                          int_seq=g[f"ds{ri}_int_seq"], read_id=f"ds{ri}", labels=g[f"ds{ri}_labels"])
+        read.set_motif_focus_bases([Motif("CG", 0)])
+        arrs, _ = extract_chunk_arrays([read], (50, 50), (4, 4), False, 0)
+        ds.write_chunk_arrays(arrs)
+    ds.flush()
+    n = int(g["num_chunks"])
+    assert int(ds.metadata["dataset_end"]) == n
+    assert open(os.path.join(out_dir, "metadata.jsn")).read() == str(g["metadata_jsn"])
+    for name in ("signal", "sequence_lengths", "labels"):
+        nb = n * ds.arrays[name][0:1].nbytes
+        mine = open(os.path.join(out_dir, f"{name}.npy"), "rb").read()[:nb]
+        assert mine == open(os.path.join(ref_dir, f"{name}.npy"), "rb").read()[:nb], name
+    ref = CoreRemoraDataset(ref_dir)
+    lens = np.asarray(ref.arrays["sequence_lengths"][:n]).astype(int)
+    for i in range(n):
+        np.testing.assert_array_equal(ds.arrays["sequence"][i, : lens[i] + 8], ref.arrays["sequence"][i, : lens[i] + 8])
+        np.testing.assert_array_equal(ds.arrays["sequence_to_signal_mapping"][i, : lens[i] + 1],
+                                      ref.arrays["sequence_to_signal_mapping"][i, : lens[i] + 1])
+    back = CoreRemoraDataset(out_dir, override_metadata={"chunk_context": (30, 25), "kmer_context_bases": (2, 3)})
+    b = back.load_batch(0, n)
+    np.testing.assert_array_equal(b["signal"], g["trim_signal"])
+    with pytest.raises(Exception):
+        ds.write_batch({"signal": np.zeros((100, 1, 100), np.float32)})  # beyond the allocation / missing arrays

@@ -741,7 +741,7 @@ def gen_core_dataset(R, out):
     ddir = os.path.join(out, "data", "core_dataset")
     shutil.rmtree(ddir, ignore_errors=True)
     os.makedirs(ddir)
-    chunks = []
+    chunks, src_reads = [], []
     for ri in range(2):
         dacs, s2s, int_seq = synth_read(rng, 900 + 300 * ri)
         labels = rng.integers(0, 2, int_seq.size).astype(np.int64)
@@ -749,6 +749,7 @@ def gen_core_dataset(R, out):
                                         read_id=f"ds{ri}", labels=labels)
         read.set_motif_focus_bases([R.util.Motif("CG", 0)])
         chunks += list(read.iter_chunks((50, 50), (4, 4), False, 0))
+        src_reads.append((dacs, s2s, int_seq, labels))
     md = R.data_chunks.DatasetMetadata(
         allocate_size=len(chunks) + 7, max_seq_len=20, mod_bases=["m"], mod_long_names=["5mC"],
         motif_sequences=["CG"], motif_offsets=[0], chunk_context=(50, 50), kmer_context_bases=(4, 4),
@@ -763,6 +764,9 @@ def gen_core_dataset(R, out):
     ds.flush()
     ds.close_memmaps()
     d = {"num_chunks": np.asarray(kept)}
+    for ri, (dacs, s2s, int_seq, labels) in enumerate(src_reads):  # the reads the dataset was cut from
+        d[f"ds{ri}_dacs"], d[f"ds{ri}_map"], d[f"ds{ri}_int_seq"], d[f"ds{ri}_labels"] = dacs, s2s, int_seq, labels
+    d["metadata_jsn"] = np.asarray(open(os.path.join(ddir, "metadata.jsn")).read())
     for tag, override in (("stored", None),
                           ("trim", {"chunk_context": (30, 25), "kmer_context_bases": (2, 3)}),
                           ("trimcc", {"chunk_context": (40, 50)}),
