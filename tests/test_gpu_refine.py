@@ -221,3 +221,76 @@ def test_refine_errors(torch_cuda, G):
     m[:] = m[0]  # no signal assigned at all
     with pytest.raises(RemoraError):
         ref.refine_maps([G["d_dacs"]], [505.0], [83.0], [m], [G["d_int_seq"]])
+
+
+@pytest.mark.parametrize("hbw,force_w", [(5, "64"), (10, None), (40, None)])
+def test_refine_all_three_kernels_vs_oracle(torch_cuda, O, monkeypatch, hbw, force_w):
+    """half_bandwidth 5 forced onto the 64-lane kernel, 10 (21 rows per column: the 64-lane kernel by itself)
+    and 40 (81 rows per column: the row-wise kernel by itself), both algorithms."""
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    if force_w:
+        monkeypatch.setenv("RMR_REFINE_W", force_w)
+    rng = np.random.default_rng(900 + hbw)
+    k, center = 4, 2
+    table = rng.normal(0, 1, 4**k).astype(np.float32)
+    reads = [_random_read(rng, table, k, center, int(rng.integers(100, 500)), stall=(i == 2)) for i in range(6)]
+    for algo in ("dwell_penalty", "Viterbi"):
+        ref = SigMapRefiner(_levels_array=table, center_idx=center, scale_iters=0, algo=algo, half_bandwidth=hbw)
+        outs, status, dev = ref._refine_batch([r[0] for r in reads], [400.0] * 6, [60.0] * 6, [r[1] for r in reads],
+                                              [r[2] for r in reads])
+        for i, (d, m, s) in enumerate(reads):
+            want, err = O.refine_one(d, 400.0, 60.0, m, s, table, center, hbw, algo, ref.sd_arr)
+            assert err is None and status[i] == 0, (i, err, status[i])
+            np.testing.assert_array_equal(outs[i], want, err_msg=f"{algo} hbw {hbw} read {i}")
+
+
+def test_refine_tiny_reads_and_device_pointers(torch_cuda, O):
+    """Reads of 2..12 bases, and the RMR_MEM_DEVICE flavour of the entry point (torch tensors in, torch out)."""
+    import ctypes
+
+    import torch
+
+    from remora_amd import _lib as L
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    rng = np.random.default_rng(4)
+    k, center = 3, 1
+    table = rng.normal(0, 1, 4**k).astype(np.float32)
+    ref = SigMapRefiner(_levels_array=table, center_idx=center, scale_iters=0, half_bandwidth=2)
+    reads = []
+    for nb in (2, 3, 4, 5, 7, 12):
+        seq = rng.integers(0, 4, nb).astype(np.int8)
+        dwell = rng.integers(3, 9, nb)
+        m = np.concatenate([[0], np.cumsum(dwell)]).astype(np.int64)
+        d = np.round(400 + 60 * rng.standard_normal(m[-1])).astype(np.int16)
+        reads.append((d, m, seq))
+    outs, status, dev = ref._refine_batch([r[0] for r in reads], [400.0] * 6, [60.0] * 6, [r[1] for r in reads],
+                                          [r[2] for r in reads])
+    want = []
+    for i, (d, m, s) in enumerate(reads):
+        w, err = O.refine_one(d, 400.0, 60.0, m, s, table, center, 2, "dwell_penalty", ref.sd_arr)
+        if err is None:
+            assert status[i] == 0
+            np.testing.assert_array_equal(outs[i], w, err_msg=f"read {i}")
+        else:
+            assert status[i] != 0 and dev.status_message(status[i]) == err
+        want.append(w)
+    # the same batch through device pointers
+    n = len(reads)
+    so = np.concatenate([[0], np.cumsum([r[0].size for r in reads])]).astype(np.int64)
+    qo = np.concatenate([[0], np.cumsum([r[2].size for r in reads])]).astype(np.int64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    d_d, d_so, d_m = t(np.concatenate([r[0] for r in reads])), t(so), t(np.concatenate([r[1] for r in reads]))
+    d_s, d_qo, d_sh, d_sc = t(np.concatenate([r[2] for r in reads])), t(qo), t(np.full(n, 400.0)), t(np.full(n, 60.0))
+    d_out, d_st = d_m.clone(), torch.zeros(n, dtype=torch.int32, device="cuda")
+    p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+    L.check(L.lib().rmr_refine_signal_maps(dev._h, n, p(d_d), p(d_so), p(d_m), p(d_s), p(d_qo), p(d_sh), p(d_sc),
+                                           p(d_out), p(d_st), L.MEM_DEVICE))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_st.cpu().numpy(), status)
+    got = d_out.cpu().numpy()
+    mo = qo + np.arange(n + 1)
+    for i in range(n):
+        if status[i] == 0:
+            np.testing.assert_array_equal(got[mo[i] : mo[i + 1]], want[i])
