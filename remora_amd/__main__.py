@@ -21,6 +21,8 @@ def main(argv=None):
     p.add_argument("--num-reads", type=int, default=None)
     p.add_argument("--reads-per-batch", type=int, default=256)
     p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")
+    p.add_argument("--reference-anchored", action="store_true",
+                   help="call at reference positions; output records become <len>M with the reference sequence")
     args = ap.parse_args(argv)
 
     from .inference import infer_from_pod5_and_bam
@@ -29,7 +31,7 @@ def main(argv=None):
     try:
         model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
         stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
-                                        reads_per_batch=args.reads_per_batch)
+                                        reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored)
     except RemoraError as e:
         print(f"remora_amd: {e}", file=sys.stderr)
         return 1

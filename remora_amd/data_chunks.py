@@ -58,6 +58,46 @@ class Chunk:
             raise RemoraError("Seq to sig map ends after signal")
 
 
+# BAM CIGAR operations (M I D N S H P = X) that align a base / consume the query / consume the reference
+MATCH_OPS = np.array([True, False, False, False, False, False, False, True, True])
+QUERY_OPS = np.array([True, True, False, False, True, False, False, True, True])
+REF_OPS = np.array([True, False, True, True, False, False, False, True, True])
+
+
+def map_ref_to_signal(*, query_to_signal, ref_to_query_knots):
+    """Signal coordinate of every reference position: the (fractional) query coordinate of each
+    reference base interpolated through the move table, floored (src/remora/data_chunks.py:60-74)."""
+    return np.floor(np.interp(ref_to_query_knots, np.arange(query_to_signal.size), query_to_signal)).astype(int)
+
+
+def make_sequence_coordinate_mapping(cigar):
+    """Query coordinate (float) of every reference position 0..ref_len from the cigartuples: exact inside
+    match runs, linearly interpolated across insertions / deletions (src/remora/data_chunks.py:77-115)."""
+    cigar = list(cigar)
+    while cigar and not MATCH_OPS[cigar[-1][0]]:
+        cigar.pop()
+    if not cigar:
+        raise RemoraError("No match operations found in alignment cigar")
+    ops, lens = (np.array(x) for x in zip(*cigar))
+    if ops.min() < 0 or ops.max() > 8:
+        raise RemoraError("Invalid cigar op(s)")
+    if lens.min() < 0:
+        raise RemoraError("Cigar lengths may not be negative")
+    is_match = MATCH_OPS[ops]
+    # two knots per match run: its first and its last base
+    back = np.array([lens[is_match], np.ones_like(lens[is_match])])
+    ref_end = np.cumsum(np.where(REF_OPS[ops], lens, 0))
+    query_end = np.cumsum(np.where(QUERY_OPS[ops], lens, 0))
+    ref_knots = np.concatenate([[0], (ref_end[is_match] - back).T.flatten(), [ref_end[-1]]])
+    query_knots = np.concatenate([[0], (query_end[is_match] - back).T.flatten(), [query_end[-1]]])
+    return np.interp(np.arange(ref_knots[-1] + 1), ref_knots, query_knots)
+
+
+def compute_ref_to_signal(query_to_signal, cigar):
+    """src/remora/data_chunks.py:118-122"""
+    return map_ref_to_signal(query_to_signal=query_to_signal, ref_to_query_knots=make_sequence_coordinate_mapping(cigar))
+
+
 class ChunkArrays:
     """Chunks of one or more reads as GPU-resident arrays in the CoreRemoraDataset layout
     (signal f32[n,1,L], sequence i8[n,W], sequence_to_signal_mapping i16[n,W'],

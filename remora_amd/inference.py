@@ -97,9 +97,10 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
 
 
 def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
-                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True):
-    """`remora infer from_pod5_and_bam` for one model, basecall-anchored
-    (src/remora/inference.py:462-641): every input alignment is written to `out_bam_path` with
+                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False):
+    """`remora infer from_pod5_and_bam` for one model, basecall-anchored by default or reference-anchored
+    (`--reference-anchored`: calls at reference positions, output records rewritten to `<len>M` + reference
+    sequence) (src/remora/inference.py:462-641): every input alignment is written to `out_bam_path` with
     MM/ML tags from the model (records whose read cannot be called are written unchanged and
     counted by reason, as the reference does).  Reads are grouped into batches that go through
     ONE chunk extraction and ONE fused inference on the GPU.  Returns {reason: count, ...} with
@@ -119,7 +120,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         for io_read, err in batch:
             if err is None:
                 try:
-                    good.append((io_read, io_read.into_remora_read(False)))
+                    good.append((io_read, io_read.into_remora_read(ref_anchored)))
                     continue
                 except RemoraError as e:
                     err = f"Read prep error: {e}"
@@ -133,10 +134,13 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                 stats[f"No {model_metadata['can_base']} mod calls"] += 1
                 writer.write(rio.record_with_mod_tags(io_read.record, None, None))
                 continue
-            mm, ml = format_mm_ml_tags(seq=io_read.seq, poss=pos, probs=probs, mod_bases=model_metadata["mod_bases"],
-                                       can_base=model_metadata["can_base"])
+            mm, ml = format_mm_ml_tags(seq=io_read.ref_seq if ref_anchored else io_read.seq, poss=pos, probs=probs,
+                                       mod_bases=model_metadata["mod_bases"], can_base=model_metadata["can_base"])
             stats[None] += 1
-            writer.write(rio.record_with_mod_tags(io_read.record, mm, ml))
+            fwd = None
+            if ref_anchored:
+                fwd = io_read.ref_seq if io_read.ref_reg.strand == "+" else rio.revcomp(io_read.ref_seq)
+            writer.write(rio.record_with_mod_tags(io_read.record, mm, ml, ref_anchored_seq=fwd))
 
     with rio.BamWriter(out_bam_path, header) as writer:
         batch = []

@@ -84,6 +84,50 @@ class BamRecord:
                 return v
         raise KeyError(name)
 
+    def get_reference_sequence(self):
+        """Reference bases spanned by the alignment, rebuilt from the query, the CIGAR and the MD tag as
+        pysam.AlignedSegment.get_reference_sequence does (mismatched bases in lower case); ValueError
+        without an MD tag."""
+        try:
+            md = self.get_tag("MD")
+        except KeyError:
+            raise ValueError("MD tag not present")
+        # reference-consuming columns of the alignment: query base for M/=/X, placeholder for D/N
+        cols, q = [], 0
+        for op, ln in self.cigartuples:
+            if op in (0, 7, 8):
+                cols.extend(self.query_sequence[q : q + ln])
+                q += ln
+            elif op in (1, 4):
+                q += ln
+            elif op in (2, 3):
+                cols.extend("-" * ln)
+        out, i, p, n = [], 0, 0, len(md)
+        while p < n:
+            c = md[p]
+            if c.isdigit():
+                e = p
+                while e < n and md[e].isdigit():
+                    e += 1
+                run = int(md[p:e])
+                out.extend(cols[i : i + run])
+                i += run
+                p = e
+            elif c == "^":
+                e = p + 1
+                while e < n and md[e].isalpha():
+                    e += 1
+                out.extend(md[p + 1 : e].upper())
+                i += e - p - 1
+                p = e
+            else:
+                out.append(c.lower())
+                i += 1
+                p += 1
+        if i != len(cols):
+            raise ValueError("MD tag and CIGAR disagree about the reference span")
+        return "".join(out)
+
     def to_dict(self):
         return {"name": self.query_name, "flag": str(self.flag), "ref_name": self.reference_name or "*",
                 "ref_pos": str(self.reference_start + 1), "map_quality": str(self.mapping_quality),
@@ -247,6 +291,20 @@ PA_TO_NORM_SCALING_FACTOR = 1.4826
 
 
 @dataclasses.dataclass
+class RefRegion:
+    """Contig, strand and 0-based half-open span of an alignment (src/remora/io.py:86-101)."""
+
+    ctg: str
+    strand: str
+    start: int
+    end: int = None
+
+    @property
+    def len(self):
+        return self.end - self.start
+
+
+@dataclasses.dataclass
 class Read:
     """Signal + basecalls + their mapping for one read: the subset of remora.io.Read
     (src/remora/io.py:1747-2177) that the basecall-anchored inference path uses."""
@@ -268,6 +326,10 @@ class Read:
     full_align: dict = None
     _child_read_id: str = None
     record: object = None  # the BamRecord this read was aligned with (for output)
+    ref_seq: str = None
+    ref_reg: object = None
+    cigar: list = None
+    ref_to_signal: np.ndarray = None
 
     @property
     def child_read_id(self):
@@ -299,10 +361,11 @@ class Read:
             sh, sc = -pod5_read.calibration_offset, 1 / pod5_read.calibration_scale
         return cls(read_id=pod5_read.read_id, dacs=dacs, shift_dacs_to_pa=sh, scale_dacs_to_pa=sc)
 
-    def add_alignment(self, rec, reverse_signal=False, pa_scaling=None):
+    def add_alignment(self, rec, parse_ref_align=True, reverse_signal=False, pa_scaling=None):
         """Signal trimming by sp/ts/ns, read-id checks, strand-aware sequence, move table ->
-        query_to_signal, sm/sd (or median/MAD) norm scaling composed with the pA calibration
-        (src/remora/io.py:1972-2044).  Reference-anchored fields are not parsed."""
+        query_to_signal, sm/sd (or median/MAD) norm scaling composed with the pA calibration, and - for
+        mapped records when `parse_ref_align` - the reference region, the reference sequence (MD tag),
+        the read-oriented CIGAR and the reference-to-signal mapping (src/remora/io.py:1972-2084)."""
         if pa_scaling is not None:
             self.shift_pa_to_zc_pa, self.scale_pa_to_zc_pa = pa_scaling
         if rec.reference_name is None and rec.is_reverse:
@@ -338,13 +401,48 @@ class Read:
             self.compute_pa_to_norm_scaling()
         self.shift_dacs_to_norm = self.shift_dacs_to_pa + (self.scale_dacs_to_pa * self.shift_pa_to_norm)
         self.scale_dacs_to_norm = self.scale_dacs_to_pa * self.scale_pa_to_norm
+        if not parse_ref_align or rec.is_unmapped:
+            return
+        from .data_chunks import compute_ref_to_signal
+
+        self.ref_reg = RefRegion(ctg=rec.reference_name, strand="-" if rec.is_reverse else "+", start=rec.reference_start)
+        try:
+            self.ref_seq = rec.get_reference_sequence().upper()
+        except ValueError:
+            self.ref_seq = None
+        self.cigar = list(rec.cigartuples)
+        if rec.is_reverse:
+            if self.ref_seq is not None:
+                self.ref_seq = revcomp(self.ref_seq)
+            self.cigar = self.cigar[::-1]
+        if self.ref_reg.ctg is not None and self.ref_seq is not None and self.query_to_signal is not None:
+            self.ref_to_signal = compute_ref_to_signal(query_to_signal=self.query_to_signal, cigar=self.cigar)
+            if self.ref_to_signal.size != len(self.ref_seq) + 1:  # knots include the end of the last base
+                raise RemoraError("Discordant ref seq lengths")
+            self.ref_reg.end = self.ref_reg.start + self.ref_to_signal.size - 1
 
     def into_remora_read(self, use_reference_anchor=False):
-        """Basecall-anchored RemoraRead (src/remora/io.py:2123-2177)."""
-        from .data_chunks import RemoraRead
+        """RemoraRead anchored on the basecalls (move table) or on the reference (move table composed with the
+        alignment), src/remora/io.py:2123-2177."""
+        from .data_chunks import RemoraRead, compute_ref_to_signal
 
         if use_reference_anchor:
-            raise RemoraError("reference-anchored reads are not implemented in remora_amd")
+            if self.ref_to_signal is None:
+                if self.cigar is None or self.ref_seq is None:
+                    raise RemoraError("Missing reference alignment")
+                self.ref_to_signal = compute_ref_to_signal(self.query_to_signal, self.cigar)
+                if self.ref_to_signal.size != len(self.ref_seq) + 1:
+                    raise RemoraError("Discordant ref seq lengths")
+            trim = self.dacs[self.ref_to_signal[0] : self.ref_to_signal[-1]]
+            if self.shift_pa_to_zc_pa is None or self.scale_pa_to_zc_pa is None:
+                shift, scale = self.shift_dacs_to_norm, self.scale_dacs_to_norm
+            else:
+                shift = self.shift_dacs_to_pa + self.scale_dacs_to_pa * self.shift_pa_to_zc_pa
+                scale = self.scale_dacs_to_pa * self.scale_pa_to_zc_pa
+            rr = RemoraRead(dacs=trim, shift=shift, scale=scale, seq_to_sig_map=self.ref_to_signal - self.ref_to_signal[0],
+                            str_seq=self.ref_seq, read_id=self.read_id)
+            rr.check()
+            return rr
         if self.query_to_signal is None:
             raise RemoraError("Missing query_to_signal (move table)")
         trim = self.dacs[self.query_to_signal[0] : self.query_to_signal[-1]]
@@ -404,16 +502,39 @@ def read_bam_header_bytes(bam_path):
     return data[:p]
 
 
-def record_with_mod_tags(rec, mm_tag, ml_tag):
+def _pack_seq(seq):
+    codes = np.frombuffer(seq.encode(), dtype=np.uint8)
+    lut = np.full(256, 15, np.uint8)
+    for i, c in enumerate(_SEQ_NT16):
+        lut[ord(c)] = i
+    nib = lut[codes]
+    if nib.size % 2:
+        nib = np.concatenate([nib, np.zeros(1, np.uint8)])
+    return ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes()
+
+
+def record_with_mod_tags(rec, mm_tag, ml_tag, ref_anchored_seq=None):
     """Record bytes (incl. block_size) of `rec` with any MM/ML/Mm/Ml tags replaced by the given
-    MM string / ML uint8 values (None = leave the record without modified-base tags)."""
+    MM string / ML uint8 values (None = leave the record without modified-base tags).
+    `ref_anchored_seq` (the reference bases of the alignment in forward-strand orientation) turns the
+    record into the reference-anchored form the reference writes: CIGAR `<len>M`, that sequence, no
+    qualities (src/remora/inference.py:452-458)."""
     tag_region = rec.raw[rec.tags_offset :]
     kept = b"".join(tag_region[s:e] for name, s, e in rec.tag_spans if name not in ("MM", "ML", "Mm", "Ml"))
     new = b""
     if mm_tag is not None:
         ml = np.asarray(ml_tag, dtype=np.uint8)
         new = b"MMZ" + mm_tag.encode() + b"\x00" + b"MLBC" + struct.pack("<i", ml.size) + ml.tobytes()
-    body = rec.raw[: rec.tags_offset] + kept + new
+    core = rec.raw[: rec.tags_offset]
+    if ref_anchored_seq is not None:
+        l_name = core[8]
+        n = len(ref_anchored_seq)
+        fixed = bytearray(core[:32])
+        struct.pack_into("<H", fixed, 12, 1)  # n_cigar_op
+        struct.pack_into("<i", fixed, 16, n)  # l_seq
+        core = (bytes(fixed) + core[32 : 32 + l_name] + struct.pack("<I", (n << 4) | 0) + _pack_seq(ref_anchored_seq)
+                + b"\xff" * n)
+    body = core + kept + new
     return struct.pack("<i", len(body)) + body
 
 

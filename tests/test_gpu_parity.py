@@ -744,3 +744,43 @@ def test_core_dataset_writer_matches_reference_files(torch_cuda, tmp_path):
     np.testing.assert_array_equal(b["signal"], g["trim_signal"])
     with pytest.raises(Exception):
         ds.write_batch({"signal": np.zeros((100, 1, 100), np.float32)})  # beyond the allocation / missing arrays
+
+
+def test_real_reads_reference_anchored(torch_cuda, O, tmp_path):
+    """Reference-anchored flavour of the same reads: Read.add_alignment(parse_ref_align=True) ->
+    ref_to_signal / ref region / ref_seq -> into_remora_read(True) -> call_read_mods, and the
+    `--reference-anchored` pipeline output (records rewritten to <len>M + reference sequence + MM/ML),
+    against the reference's results on the same records."""
+    from remora_amd import io as rio
+    from remora_amd.inference import call_read_mods, infer_from_pod5_and_bam
+    from remora_amd.model_util import load_model
+
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    pod5, bam = os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam")
+    g = golden("real_reads_can.npz")
+    model, md = load_model(_mint_pt(tmp_path, g, O), device=0)
+    n = 0
+    for i, (read, err) in enumerate(rio.iter_reads_from_pod5_and_bam(pod5, bam)):
+        assert err is None
+        np.testing.assert_array_equal(read.ref_to_signal, g[f"r{i}_ra_ref_to_signal"])
+        assert [read.ref_reg.ctg, read.ref_reg.strand, str(read.ref_reg.start), str(read.ref_reg.end)] == \
+            [str(x) for x in g[f"r{i}_ra_region"]]
+        rr = read.into_remora_read(True)
+        assert rr.str_seq == str(g[f"r{i}_ra_ref_seq"]) and rr.dacs.size == int(g[f"r{i}_ra_ndacs"])
+        np.testing.assert_array_equal(rr.seq_to_sig_map, g[f"r{i}_ra_map"])
+        nn_out, _, pos = call_read_mods(rr, model, md)
+        np.testing.assert_array_equal(pos, g[f"r{i}_ra_pos"])
+        assert np.abs(nn_out - g[f"r{i}_ra_nn_out"]).max() <= 1e-4
+        mm, _ = call_read_mods(read.into_remora_read(True), model, md, return_mm_ml_tags=True)
+        assert mm == str(g[f"r{i}_ra_mm"])
+        n += pos.size
+    assert n == 847
+    out_bam = str(tmp_path / "ra.bam")
+    stats = infer_from_pod5_and_bam(pod5, bam, model, md, out_bam, ref_anchored=True)
+    assert stats.get(None) == 14
+    for i, rec in enumerate(rio.iter_bam_records(out_bam)):
+        ref_len = len(str(g[f"r{i}_ra_ref_seq"]))
+        assert rec.cigartuples == [(0, ref_len)] and len(rec.query_sequence) == ref_len
+        fwd = str(g[f"r{i}_ra_ref_seq"])
+        assert rec.query_sequence == (rio.revcomp(fwd) if rec.is_reverse else fwd)
+        assert dict(rec.tags)["MM"] == str(g[f"r{i}_ra_mm"])

@@ -507,3 +507,70 @@ def test_prep_nn_input_and_unbatch_errors():
     other = (SimpleNamespace(read_id="b"), np.zeros((1, 2)), np.zeros(1), None)
     with pytest.raises(RemoraError, match="mismatching"):
         unbatch_reads(other, np.zeros((2, 2)), np.zeros(2), [[r, None, 1, None]])
+
+
+# ---- N1: reference-anchored reads (host part) ----------------------------------------------------
+def test_reference_sequence_from_md_is_pinned_three_ways():
+    """BamRecord.get_reference_sequence (MD tag + CIGAR + query) on the reference's test BAM: (1) mismatches +
+    inserted + deleted bases equal the NM tag of every record, (2) every CpG of the reference's ground-truth
+    BED (tests/data/can_gt.bed) inside a read's span is C / G in the rebuilt sequence, (3) the strand-aware
+    sequence and compute_ref_to_signal equal what the reference's Read.add_alignment derived from the same
+    records (tools/gen_golden.py gen_real_reads)."""
+    from remora_amd import io as rio
+    from remora_amd.data_chunks import compute_ref_to_signal, make_sequence_coordinate_mapping
+
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    g = golden("real_reads_can.npz")
+    gt = [(ln.split()[0], int(ln.split()[1]), ln.split()[5]) for ln in open(os.path.join(data, "can_gt.bed"))]
+    checked = 0
+    for i, rec in enumerate(rio.iter_bam_records(os.path.join(data, "can_mappings.bam"))):
+        ref = rec.get_reference_sequence()
+        tags = dict(rec.tags)
+        ins = sum(ln for op, ln in rec.cigartuples if op == 1)
+        dele = sum(ln for op, ln in rec.cigartuples if op == 2)
+        assert sum(c.islower() for c in ref) + ins + dele == tags["NM"]
+        span = sum(ln for op, ln in rec.cigartuples if op in (0, 2, 3, 7, 8))
+        assert len(ref) == span
+        for ctg, pos, strand in gt:
+            if ctg == rec.reference_name and rec.reference_start <= pos < rec.reference_start + span:
+                assert ref[pos - rec.reference_start].upper() == ("C" if strand == "+" else "G")
+                checked += 1
+        seq = rio.revcomp(ref.upper()) if rec.is_reverse else ref.upper()
+        assert seq == str(g[f"r{i}_ra_ref_seq"])
+        cigar = rec.cigartuples[::-1] if rec.is_reverse else rec.cigartuples
+        assert make_sequence_coordinate_mapping(cigar).size == len(seq) + 1
+        # the golden stores maps relative to their first entry; an integer offset commutes with the floor
+        r2s = compute_ref_to_signal(g[f"r{i}_map"], cigar)
+        r2s_full = g[f"r{i}_ra_ref_to_signal"]
+        np.testing.assert_array_equal(r2s - r2s[0], r2s_full - r2s_full[0])
+    assert i == 13 and checked > 1000
+
+
+def test_cigar_mapping_errors_and_ref_anchored_record_bytes():
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+    from remora_amd.data_chunks import make_sequence_coordinate_mapping
+
+    with pytest.raises(RemoraError, match="No match"):
+        make_sequence_coordinate_mapping([(4, 10), (1, 3)])
+    with pytest.raises(RemoraError, match="Invalid cigar"):
+        make_sequence_coordinate_mapping([(0, 5), (9, 1), (0, 2)])
+    knots = make_sequence_coordinate_mapping([(4, 2), (0, 3), (1, 2), (0, 2), (2, 1), (0, 1), (4, 7)])
+    np.testing.assert_allclose(knots, [2, 3, 4, 7, 8, 8.5, 9, 10])
+    # a reference-anchored output record parses back as <len>M + the reference sequence, tags preserved
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    rec = next(iter(rio.iter_bam_records(os.path.join(data, "can_mappings.bam"))))
+    fwd = rec.get_reference_sequence().upper()
+    raw = rio.record_with_mod_tags(rec, "C+m?,1,2;", [7, 200], ref_anchored_seq=fwd)
+    hdr = rio.read_bam_header_bytes(os.path.join(data, "can_mappings.bam"))
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "o.bam")
+        with rio.BamWriter(path, hdr) as w:
+            w.write(raw)
+        back = next(iter(rio.iter_bam_records(path)))
+    assert back.cigartuples == [(0, len(fwd))] and back.query_sequence == fwd
+    assert back.reference_start == rec.reference_start and back.flag == rec.flag and back.query_name == rec.query_name
+    t = dict(back.tags)
+    assert t["MM"] == "C+m?,1,2;" and list(t["ML"]) == [7, 200] and t["NM"] == dict(rec.tags)["NM"]

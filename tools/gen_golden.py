@@ -723,6 +723,23 @@ def gen_real_reads(R, out):
         mm, ml = R.inference.call_read_mods(read.into_remora_read(False), model, md, return_mm_ml_tags=True)
         d[f"r{i}_mm"] = np.asarray(mm)
         d[f"r{i}_ml"] = np.asarray(list(ml), np.uint8)
+        # reference-anchored flavour: add_alignment with parse_ref_align (io.py:2045-2084; the record's
+        # get_reference_sequence is remora_amd's MD-tag reconstruction, pinned separately on the NM tags and
+        # the CpG ground truth of tests/data/can_gt.bed), into_remora_read(True), call_read_mods
+        read = R.io.Read(read_id=pod.read_id, dacs=pod.signal, shift_dacs_to_pa=pod.calibration_offset,
+                         scale_dacs_to_pa=pod.calibration_scale)
+        read.add_alignment(rec, parse_ref_align=True)
+        ra = read.into_remora_read(True)
+        d[f"r{i}_ra_ref_seq"] = np.asarray(read.ref_seq)
+        d[f"r{i}_ra_ref_to_signal"] = np.asarray(read.ref_to_signal, np.int64)
+        d[f"r{i}_ra_region"] = np.asarray([read.ref_reg.ctg, read.ref_reg.strand, str(read.ref_reg.start), str(read.ref_reg.end)])
+        d[f"r{i}_ra_map"] = np.asarray(ra.seq_to_sig_map, np.int64)
+        d[f"r{i}_ra_ndacs"] = np.asarray(ra.dacs.size)
+        nn_out, labels, pos = R.inference.call_read_mods(ra, model, md)
+        d[f"r{i}_ra_nn_out"] = np.asarray(nn_out, np.float32)
+        d[f"r{i}_ra_pos"] = np.asarray(pos, np.int64)
+        mm, ml = R.inference.call_read_mods(read.into_remora_read(True), model, md, return_mm_ml_tags=True)
+        d[f"r{i}_ra_mm"] = np.asarray(mm)
     np.savez_compressed(os.path.join(out, "real_reads_can.npz"), **d)
     print("real_reads:", len(recs), "records,", sum(int(d[f"r{i}_pos"].size) for i in range(len(recs))), "chunks")
 
