@@ -343,7 +343,8 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
     constexpr int DD = (ALGO == 1) ? D : 1;
     constexpr int NCK = 13 + 4 * DD;  // dwords per lane in a checkpoint
     constexpr int IMAX = std::numeric_limits<int>::max();
-    __shared__ int4 ring[G][RN];
+    __shared__ int4 ring[G][RN];   // {lo, hi, level bits, traceback offset} of staged rows
+    __shared__ int2 ring2[G][RN];  // {hi of the previous row, lo of the next row}
     __shared__ float Ltab[G][(ALGO == 1) ? kLT : 1];
     __shared__ int Lrow[G][(ALGO == 1) ? kLT : 1];
     const int lane = threadIdx.x, grp = lane / W, gl = lane % W, gbase = grp * W;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
         // per-lane row state
         bool act = false, lknown = false;
         int my_i = 0, my_lo = 0, my_hi = 0, prev_hi = 0, fail = 0, ctb = 0;
-        int16_t *my_tb = tbr;  // &traceback[row][0] - (my_lo & ~7)
+        int my_toff = 0;  // traceback element offset of the row, minus (my_lo & ~7): sample s is stored at tbr[my_toff + s]
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // the row's traceback values of the current 8-sample group
         bool dirty = false;
         float lvl = 0.f, cur = 0.f, L = INF, specmax = -INF;
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
         int ib_next = 0, next_lo = IMAX, staged_hi = 0;  // uniform inside a lane group
         int dnext = 0, dnext_s = -1;                     // raw samples fetched ahead, and the sample they start at
         bool gfail = false;
+        bool have_known = false;  // some row of this read has a recorded 'large score' term (set by a replay)
 
         const int nblk = (wave_max_i(nsig) + 63) / 64;
         int blk = 0, nroll = 0;
@@ -408,7 +410,10 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                     any = true;
                     if (need) {
                         const int i = staged_hi + gl;
-                        if (i < n) ring[grp][i & (RN - 1)] = make_int4(lo[i], hi[i], __builtin_bit_cast(int, lv[i]), (int)tboff[i]);
+                        if (i < n) {
+                            ring[grp][i & (RN - 1)] = make_int4(lo[i], hi[i], __builtin_bit_cast(int, lv[i]), (int)tboff[i]);
+                            ring2[grp][i & (RN - 1)] = make_int2(i > 0 ? hi[i - 1] : (IMAX >> 1), i + 1 < n ? lo[i + 1] : IMAX);
+                        }
                         staged_hi += W;
                     }
                 }
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
 #define CK_F(v) c[(k++) * 64] = __builtin_bit_cast(uint32_t, v);
                 CK_I((act ? 1 : 0) | (lknown ? 2 : 0))
                 CK_I(my_i) CK_I(my_lo) CK_I(my_hi) CK_I(prev_hi) CK_I(ctb) CK_I(ib_next) CK_I(next_lo)
-                CK_I((uint32_t)(my_tb - tbr))
+                CK_I(my_toff)
                 CK_F(lvl) CK_F(cur) CK_F(L) CK_F(specmax)
 #pragma unroll
                 for (int d = 1; d <= DD; ++d) { CK_F(P[d]) CK_F(U[d]) CK_I(Ut[d]) CK_F(Q[d - 1]) }
@@ -451,8 +456,9 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                     if (s == next_lo) {  // a new row starts (rows start at strictly increasing samples)
                         const int i = ib_next;
                         const int4 pr = ring[grp][i & (RN - 1)];
-                        const int ph = (i > 0) ? ring[grp][(i - 1) & (RN - 1)].y : (IMAX >> 1);
-                        if (gl == (i % W)) {
+                        const int2 pq = ring2[grp][i & (RN - 1)];
+                        const int ph = pq.x;
+                        if (gl == (i & (W - 1))) {
                             if (act && s < my_hi) fail = 1;                    // more than W rows in one column
                             if (i > 0 && (pr.x > ph || pr.y <= ph)) fail = 1;  // gap to / nested in the previous row
                             if (dirty) {  // the row this lane hosted before ended inside the current group: flush it
@@ -460,12 +466,12 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                                     a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
                                     a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 >>= 16;
                                 }
-                                *reinterpret_cast<uint4 *>(my_tb + (s & ~7)) = make_uint4(a0, a1, a2, a3);
+                                *reinterpret_cast<uint4 *>(tbr + ((int64_t)my_toff + (s & ~7))) = make_uint4(a0, a1, a2, a3);
                                 dirty = false;
                             }
                             act = true; my_i = i;
                             my_lo = pr.x; my_hi = pr.y; lvl = __builtin_bit_cast(float, pr.z);
-                            my_tb = tbr + (int64_t)(uint32_t)pr.w - (pr.x & ~7);
+                            my_toff = pr.w - (pr.x & ~7);
                             prev_hi = ph;
                             lknown = (i == 0);
                             L = (i == 0 && pr.y == 1) ? kLargeScore : INF;
@@ -475,13 +481,13 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                             for (int k = 1; k <= DD; ++k) { P[k] = INF; U[k] = INF; Ut[k] = -1; }
 #pragma unroll
                             for (int k = 0; k < DD; ++k) Q[k] = 0.f;
-                            if (ALGO == 1 && i > 0 && Lrow[grp][i & (kLT - 1)] == i) {  // learnt in an earlier pass
+                            if (ALGO == 1 && have_known && i > 0 && Lrow[grp][i & (kLT - 1)] == i) {  // learnt in an earlier pass
                                 lknown = true;
                                 L = Ltab[grp][i & (kLT - 1)];
                             }
                         }
                         ib_next = i + 1;
-                        next_lo = (ib_next < n) ? ring[grp][ib_next & (RN - 1)].x : IMAX;
+                        next_lo = pq.y;
                         if (next_lo <= s) fail = 1;  // rows must start at strictly increasing samples
                     }
                     if (act && s < my_hi) {
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                     a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
                     a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 = __builtin_amdgcn_alignbit((uint32_t)ctb, a3, 16);
                     if ((jj & 7) == 7) {
-                        if (dirty) *reinterpret_cast<uint4 *>(my_tb + (s & ~7)) = make_uint4(a0, a1, a2, a3);
+                        if (dirty) *reinterpret_cast<uint4 *>(tbr + ((int64_t)my_toff + (s & ~7))) = make_uint4(a0, a1, a2, a3);
                         dirty = false;
                     }
                 };
@@ -595,22 +601,26 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                         ++blk;
                         continue;
                     }
+                    {   // lane groups that recorded a term look it up at row starts from now on
+                        const unsigned long long vb = __ballot(viol != IMAX);
+                        const unsigned long long gm = ((W == 64) ? ~0ull : ((1ull << W) - 1)) << gbase;
+                        if (vb & gm) have_known = true;
+                    }
                     __syncthreads();  // Ltab / Lrow written above are read after the restore
                     const uint32_t *c = ck + (size_t)(tblk % kCk) * NCK * 64;
                     int k = 0;
 #define CK_I(v) v = (int)c[(k++) * 64];
 #define CK_F(v) v = __builtin_bit_cast(float, c[(k++) * 64]);
-                    int fl, tboffs;
+                    int fl;
                     CK_I(fl)
                     CK_I(my_i) CK_I(my_lo) CK_I(my_hi) CK_I(prev_hi) CK_I(ctb) CK_I(ib_next) CK_I(next_lo)
-                    CK_I(tboffs)
+                    CK_I(my_toff)
                     CK_F(lvl) CK_F(cur) CK_F(L) CK_F(specmax)
 #pragma unroll
                     for (int d = 1; d <= DD; ++d) { CK_F(P[d]) CK_F(U[d]) CK_I(Ut[d]) CK_F(Q[d - 1]) }
 #undef CK_I
 #undef CK_F
                     act = (fl & 1) != 0; lknown = (fl & 2) != 0;
-                    my_tb = tbr + (int64_t)(uint32_t)tboffs;
                     if (!gvalid) { act = false; next_lo = IMAX; }
                     staged_hi = max(ib_next - 1, 0) / W * W;  // re-stage the row parameters from there
                     dnext_s = -1;
