@@ -126,6 +126,22 @@ int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int
                     int64_t seq_len, int check, int reverse_signal, int64_t *q2s,
                     int64_t *n_out, int mem);
 
+/* ---- M3: motif scan ---------------------------------------------------------------------- */
+/* replaces: Motif.findall (src/remora/util.py:281-297) + find_focus_bases_in_int_sequence (:413-426) as
+ * called by RemoraRead.set_motif_focus_bases (src/remora/data_chunks.py:310-317), for a batch of reads:
+ * flags[b] = 1 iff base b (index into the concatenated int_seq) is the focus base of a hit of any motif
+ * that lies entirely inside its read.  mask[m][j] has bit k set when base k (0..3 = ACGT) is allowed at
+ * motif position j; N bases (-1) never match.  The positions come out in ascending order once the
+ * flags are compacted (the reference's python-set order is a property of the single-read host API). */
+typedef struct {
+    int32_t n_motifs;            /* <= 8 */
+    int32_t len[8];              /* <= 16 */
+    int32_t focus_pos[8];        /* may be negative after leading-N stripping (util.py:208-214) */
+    uint8_t mask[8][16];
+} rmr_motif_set;
+int rmr_motif_flags(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads,
+                    const rmr_motif_set *motifs, uint8_t *flags, int mem);
+
 /* ---- X1 + X2 + X3 (+X6): chunk extraction for a batch of reads --------------------------- */
 /* replaces: RemoraRead.sig (src/remora/data_chunks.py:191-197), iter_chunks (:425-466),
  * extract_chunk (:331-423) and the row packing of CoreRemoraDataset.write_chunk

@@ -23,6 +23,11 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("arch", "size", "kmer_len", "num_out", "chunk_len", "dtype")]
 
 
+class MotifSet(ctypes.Structure):
+    _fields_ = [("n_motifs", ctypes.c_int32), ("len", ctypes.c_int32 * 8), ("focus_pos", ctypes.c_int32 * 8),
+                ("mask", (ctypes.c_uint8 * 16) * 8)]
+
+
 class Reads(ctypes.Structure):
     _fields_ = [
         ("n_reads", c_i64), ("dacs", c_vp), ("sig_off", c_vp), ("seq_to_sig", c_vp),
@@ -47,6 +52,7 @@ SIGNATURES = {
     "rmr_encode_kmers": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_int]),
     "rmr_trim_chunk_context": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int]),
     "rmr_parse_moves": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, ctypes.POINTER(c_i64), c_int]),
+    "rmr_motif_flags": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),
     "rmr_chunk_fill": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int]),
     "rmr_forward": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),

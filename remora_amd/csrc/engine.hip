@@ -25,7 +25,7 @@ static const char *k_names[K_NUM] = {
     "encode_kmers", "trim_chunk_context", "parse_moves", "normalise_signal", "chunk_geometry",
     "chunk_fill", "front_sig", "front_seq", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
     "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
-    "count_labels", "refine_band", "refine_dp", "refine_dp_rowwise"};
+    "count_labels", "motif_scan", "refine_band", "refine_dp", "refine_dp_rowwise"};
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
 
 }  // namespace rmr
@@ -921,6 +921,36 @@ int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
     H2D(dc, counts, (size_t)num_out * 8);
     RMR_TRY(launch_count(e, dl, n, num_out, dc));
     D2H(counts, dc, (size_t)num_out * 8);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_motif_flags(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads,
+                    const rmr_motif_set *motifs, uint8_t *flags, int mem) {
+    if (!e || !int_seq || !seq_off || !motifs || !flags) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_reads < 0 || n_reads > (int64_t)1 << 30) RMR_FAIL(RMR_ERR_INVALID, "bad n_reads");
+    if (motifs->n_motifs < 1 || motifs->n_motifs > 8) RMR_FAIL(RMR_ERR_INVALID, "1..8 motifs supported");
+    for (int m = 0; m < motifs->n_motifs; ++m)
+        if (motifs->len[m] < 1 || motifs->len[m] > 16 || motifs->focus_pos[m] >= motifs->len[m] ||
+            motifs->focus_pos[m] < -64)
+            RMR_FAIL(RMR_ERR_INVALID, "motif %d: length %d / focus %d unsupported", m, motifs->len[m], motifs->focus_pos[m]);
+    if (n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    int64_t total = 0;
+    if (mem == RMR_MEM_HOST) total = seq_off[n_reads];
+    else RMR_HIP(hipMemcpy(&total, seq_off + n_reads, 8, hipMemcpyDeviceToHost));
+    if (total <= 0) return 0;
+    if (mem == RMR_MEM_DEVICE) return launch_motif(e, int_seq, seq_off, (int)n_reads, total, *motifs, flags);
+    Stage st{e};
+    RMR_TRY(st.init(2 * Stage::pad((size_t)total) + Stage::pad((size_t)(n_reads + 1) * 8) + 4096));
+    int8_t *ds = st.take<int8_t>(total);
+    int64_t *d_off = st.take<int64_t>(n_reads + 1);
+    uint8_t *df = st.take<uint8_t>(total);
+    H2D(ds, int_seq, (size_t)total);
+    H2D(d_off, seq_off, (size_t)(n_reads + 1) * 8);
+    RMR_TRY(launch_motif(e, ds, d_off, (int)n_reads, total, *motifs, df));
+    D2H(flags, df, (size_t)total);
     RMR_HIP(hipStreamSynchronize(e->stream));
     return 0;
 }

@@ -385,6 +385,45 @@ __global__ __launch_bounds__(256) void count_kernel(const float *logits, int64_t
         atomicAdd(&counts[threadIdx.x], (unsigned long long)bins[threadIdx.x]);
 }
 
+// ---- M3: motif scan ------------------------------------------------------------------------
+// One thread per base of the concatenated sequences; the read of a base is found by bisection of
+// seq_off (reads are thousands of bases, the table stays in L1/L2).  HBM traffic: 1 B read (+ the
+// motif window from cache) and 1 B written per base.
+__global__ __launch_bounds__(256) void motif_kernel(const int8_t *__restrict__ seq, const int64_t *__restrict__ seq_off,
+                                                    int n_reads, int64_t total, rmr_motif_set ms,
+                                                    uint8_t *__restrict__ flags) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= total) return;
+    int lo = 0, hi = n_reads - 1;  // last read with seq_off[r] <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seq_off[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int64_t rs = seq_off[lo], re = seq_off[lo + 1];
+    uint8_t hit = 0;
+    for (int m = 0; m < ms.n_motifs && !hit; ++m) {
+        const int64_t j = b - ms.focus_pos[m];  // start of the window whose focus base is b
+        if (j < rs || j + ms.len[m] > re) continue;
+        bool ok = true;
+        for (int k = 0; k < ms.len[m] && ok; ++k) {
+            const int c = seq[j + k];
+            ok = c >= 0 && ((ms.mask[m][k] >> c) & 1);
+        }
+        hit = ok;
+    }
+    flags[b] = hit;
+}
+
+int launch_motif(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, int64_t total,
+                 const rmr_motif_set &ms, uint8_t *flags) {
+    if (total <= 0) return 0;
+    ProfScope ps(e, K_MOTIF);
+    hipLaunchKernelGGL(motif_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, seq, seq_off,
+                       n_reads, total, ms, flags);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts) {
     if (n <= 0) return 0;
     if (num_out > 16) RMR_FAIL(RMR_ERR_INVALID, "num_out %d > 16", num_out);

@@ -57,6 +57,7 @@ enum KernelId {
     K_LSTM_HEAD,
     K_FC_HEAD,
     K_COUNT,
+    K_MOTIF,
     K_REFINE_BAND,
     K_REFINE_DP,
     K_REFINE_ROWWISE,
@@ -183,6 +184,8 @@ int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32
                 const float *sig, const int64_t *geo, float *signal, int8_t *seqs, int seq_w,
                 int16_t *maps, int map_w, int16_t *lens, int64_t *rfb);
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts);
+int launch_motif(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, int64_t total,
+                 const rmr_motif_set &ms, uint8_t *flags);
 
 // fused pipeline stages; all tensors channel-last in device scratch
 int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t *seqs, int seq_w,

@@ -128,50 +128,88 @@ class ChunkArrays:
         return iter(self.as_reference_batch())
 
 
-def extract_chunk_arrays(reads, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,
-                         engine=None):
-    """Chunk arrays for a list of RemoraRead objects whose `focus_bases` are set.
-    GPU counterpart of iter_chunks + extract_chunk + write_chunk for every focus base
-    (src/remora/data_chunks.py:425-466, :331-423, :1376-1418).  Returns (ChunkArrays, sig)
-    where sig is the normalised signal of all reads (float32, CUDA)."""
+class DeviceReads:
+    """The arrays of a batch of reads, concatenated and resident in HBM (the rmr_reads layout of
+    include/remora_hip.h) - uploaded once and shared by the motif scan, the signal-mapping refinement
+    and the chunk extraction."""
+
+    def __init__(self, reads, engine=None):
+        torch = _torch()
+        self.engine = engine if engine is not None else get_engine()
+        dev = self.engine.torch_device
+        nr = len(reads)
+        self.n_reads = nr
+        self.sig_off = np.zeros(nr + 1, np.int64)
+        self.seq_off = np.zeros(nr + 1, np.int64)
+        for i, r in enumerate(reads):
+            self.sig_off[i + 1] = self.sig_off[i] + r.dacs.size
+            self.seq_off[i + 1] = self.seq_off[i] + r.int_seq.size
+            if r.seq_to_sig_map.size != r.int_seq.size + 1:
+                raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
+        cat = lambda arrs, dt: (np.concatenate([np.asarray(a).ravel() for a in arrs]).astype(dt, copy=False)
+                                if arrs else np.zeros(0, dt))
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.dacs = to_dev(cat([r.dacs for r in reads], np.int16))
+        self.s2s = to_dev(cat([r.seq_to_sig_map for r in reads], np.int64))
+        self.iseq = to_dev(cat([r.int_seq for r in reads], np.int8))
+        self.d_sig_off, self.d_seq_off = to_dev(self.sig_off), to_dev(self.seq_off)
+        self.set_scaling([float(r.shift) for r in reads], [float(r.scale) for r in reads])
+
+    def set_scaling(self, shift, scale):
+        torch = _torch()
+        dev = self.engine.torch_device
+        self.shift = torch.from_numpy(np.asarray(shift, np.float64)).to(dev)
+        self.scale = torch.from_numpy(np.asarray(scale, np.float64)).to(dev)
+
+    def motif_focus_bases(self, motifs):
+        """Focus bases of all motif hits, ascending inside each read: (focus i64[F] read-local, on the device;
+        foc_off i64[n_reads+1] on the host).  GPU counterpart of RemoraRead.set_motif_focus_bases for a batch
+        (src/remora/data_chunks.py:310-317)."""
+        torch = _torch()
+        ms = L.MotifSet()
+        if not 1 <= len(motifs) <= 8:
+            raise RemoraError("1..8 motifs supported")
+        ms.n_motifs = len(motifs)
+        for m, mot in enumerate(motifs):
+            if len(mot.raw_motif) > 16:
+                raise RemoraError("motifs longer than 16 bases are not supported on the GPU scan")
+            ms.len[m] = len(mot.raw_motif)
+            ms.focus_pos[m] = int(mot.focus_pos)
+            for k, allowed in enumerate(mot.int_pattern):
+                ms.mask[m][k] = int(sum(1 << int(b) for b in allowed))
+        total = int(self.seq_off[-1])
+        flags = torch.zeros(max(total, 1), dtype=torch.uint8, device=self.engine.torch_device)
+        if total:
+            L.check(L.lib().rmr_motif_flags(self.engine.handle, self.iseq.data_ptr(), self.d_seq_off.data_ptr(),
+                                            self.n_reads, ctypes.byref(ms), flags.data_ptr(), L.MEM_DEVICE))
+        pos = torch.nonzero(flags[:total]).flatten()  # ascending
+        read_of = torch.searchsorted(self.d_seq_off, pos, right=True) - 1
+        counts = torch.bincount(read_of, minlength=self.n_reads)[: self.n_reads]
+        foc_off = np.zeros(self.n_reads + 1, np.int64)
+        np.cumsum(counts.cpu().numpy(), out=foc_off[1:])
+        return pos - self.d_seq_off[read_of], foc_off
+
+
+def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset, labels=None):
+    """Chunk extraction for device-resident reads and focus bases (see extract_chunk_arrays)."""
     torch = _torch()
-    eng = engine if engine is not None else get_engine()
+    eng, lib = dr.engine, L.lib()
     dev = eng.torch_device
-    lib = L.lib()
-    nr = len(reads)
-    sig_off = np.zeros(nr + 1, np.int64)
-    seq_off = np.zeros(nr + 1, np.int64)
-    foc_off = np.zeros(nr + 1, np.int64)
-    for i, r in enumerate(reads):
-        sig_off[i + 1] = sig_off[i] + r.dacs.size
-        seq_off[i + 1] = seq_off[i] + r.int_seq.size
-        foc_off[i + 1] = foc_off[i] + (0 if r.focus_bases is None else len(r.focus_bases))
-        if r.seq_to_sig_map.size != r.int_seq.size + 1:
-            raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
     n_chunks = int(foc_off[-1])
-    cat = lambda arrs, dt: (np.concatenate([np.asarray(a).ravel() for a in arrs]).astype(dt, copy=False)
-                            if arrs else np.zeros(0, dt))
-    dacs = cat([r.dacs for r in reads], np.int16)
-    s2s = cat([r.seq_to_sig_map for r in reads], np.int64)
-    iseq = cat([r.int_seq for r in reads], np.int8)
-    focus = cat([r.focus_bases for r in reads if r.focus_bases is not None and len(r.focus_bases)], np.int64)
-    shift = np.array([float(r.shift) for r in reads], np.float64)
-    scale = np.array([float(r.scale) for r in reads], np.float64)
-    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d = dict(dacs=to_dev(dacs), sig_off=to_dev(sig_off), s2s=to_dev(s2s), iseq=to_dev(iseq),
-             seq_off=to_dev(seq_off), shift=to_dev(shift), scale=to_dev(scale),
-             focus=to_dev(focus if focus.size else np.zeros(1, np.int64)), foc_off=to_dev(foc_off))
-    rs = L.Reads(nr, d["dacs"].data_ptr(), d["sig_off"].data_ptr(), d["s2s"].data_ptr(), d["iseq"].data_ptr(),
-                 d["seq_off"].data_ptr(), d["shift"].data_ptr(), d["scale"].data_ptr(), d["focus"].data_ptr(),
-                 d["foc_off"].data_ptr(), int(chunk_context[0]), int(chunk_context[1]),
+    d_foc_off = torch.from_numpy(np.ascontiguousarray(foc_off)).to(dev)
+    if focus.numel() == 0:
+        focus = torch.zeros(1, dtype=torch.int64, device=dev)
+    rs = L.Reads(dr.n_reads, dr.dacs.data_ptr(), dr.d_sig_off.data_ptr(), dr.s2s.data_ptr(), dr.iseq.data_ptr(),
+                 dr.d_seq_off.data_ptr(), dr.shift.data_ptr(), dr.scale.data_ptr(), focus.data_ptr(),
+                 d_foc_off.data_ptr(), int(chunk_context[0]), int(chunk_context[1]),
                  int(kmer_context_bases[0]), int(kmer_context_bases[1]), int(bool(base_start_justify)), int(offset))
     L_chunk = int(chunk_context[0]) + int(chunk_context[1])
-    sig = torch.empty(max(int(sig_off[-1]), 1), dtype=torch.float32, device=dev)
+    sig = torch.empty(max(int(dr.sig_off[-1]), 1), dtype=torch.float32, device=dev)
     geo = torch.empty((max(n_chunks, 1), 6), dtype=torch.int64, device=dev)
     max_sl = ctypes.c_int64(0)
     L.check(lib.rmr_chunk_geometry(eng.handle, ctypes.byref(rs), sig.data_ptr(), geo.data_ptr(),
                                    ctypes.byref(max_sl), L.MEM_DEVICE))
-    sig = sig[: int(sig_off[-1])]
+    sig = sig[: int(dr.sig_off[-1])]
     geo = geo[:n_chunks]
     msl = int(max_sl.value)
     seq_w = msl + int(kmer_context_bases[0]) + int(kmer_context_bases[1])
@@ -185,13 +223,34 @@ def extract_chunk_arrays(reads, chunk_context, kmer_context_bases, base_start_ju
         L.check(lib.rmr_chunk_fill(eng.handle, ctypes.byref(rs), sig.data_ptr(), geo.data_ptr(), signal.data_ptr(),
                                    sequence.data_ptr(), sequence.shape[1], mapping.data_ptr(), mapping.shape[1],
                                    lengths.data_ptr(), rfb.data_ptr(), L.MEM_DEVICE))
-    # the kernels above read the staged inputs in `d`: keep them alive until the stream drains
+    # the kernels above read the staged inputs: keep them alive until the stream drains
     eng.synchronize()
+    if labels is None:
+        labels = np.full(n_chunks, -1, np.int64)
+    return ChunkArrays(signal, sequence, mapping, lengths, rfb, labels, geo, kmer_context_bases, chunk_context), sig
+
+
+def extract_chunk_arrays(reads, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,
+                         engine=None):
+    """Chunk arrays for a list of RemoraRead objects whose `focus_bases` are set.
+    GPU counterpart of iter_chunks + extract_chunk + write_chunk for every focus base
+    (src/remora/data_chunks.py:425-466, :331-423, :1376-1418).  Returns (ChunkArrays, sig)
+    where sig is the normalised signal of all reads (float32, CUDA)."""
+    torch = _torch()
+    dr = DeviceReads(reads, engine)
+    nr = len(reads)
+    foc_off = np.zeros(nr + 1, np.int64)
+    for i, r in enumerate(reads):
+        foc_off[i + 1] = foc_off[i] + (0 if r.focus_bases is None else len(r.focus_bases))
+    n_chunks = int(foc_off[-1])
+    fl = [np.asarray(r.focus_bases).ravel() for r in reads if r.focus_bases is not None and len(r.focus_bases)]
+    focus = np.concatenate(fl).astype(np.int64, copy=False) if fl else np.zeros(1, np.int64)
     labels = np.full(n_chunks, -1, np.int64)
     for i, r in enumerate(reads):
         if r.labels is not None and foc_off[i + 1] > foc_off[i]:
             labels[foc_off[i] : foc_off[i + 1]] = np.asarray(r.labels)[np.asarray(r.focus_bases)]
-    return ChunkArrays(signal, sequence, mapping, lengths, rfb, labels, geo, kmer_context_bases, chunk_context), sig
+    d_focus = torch.from_numpy(np.ascontiguousarray(focus)).to(dr.engine.torch_device)
+    return _extract_device(dr, d_focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset, labels)
 
 
 @dataclasses.dataclass

@@ -64,24 +64,29 @@ def find_focus_bases_batch(reads, motifs):
 
 
 def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
-    """Batched form of call_read_mods for a list of RemoraRead objects: one motif scan, one chunk
-    extraction and one fused inference for all reads (the reference processes reads one by one
-    in Python, src/remora/inference.py:62-137, 661-712).  Returns a list of per-read
-    (nn_out | probs, labels, pos) tuples; pos ascending within a read."""
-    from .data_chunks import extract_chunk_arrays
+    """Batched form of call_read_mods for a list of RemoraRead objects: the reads are uploaded once, then the
+    (optional) signal-mapping refinement, the motif scan, the chunk extraction and the fused inference all run
+    on the resident arrays (the reference processes reads one by one in Python,
+    src/remora/inference.py:62-137, 661-712).  Returns a list of per-read (nn_out | probs, labels, pos) tuples;
+    pos ascending within a read.  `read.focus_bases` is left holding the read's motif hits."""
+    from .data_chunks import DeviceReads, _extract_device
 
+    if len(reads) == 0:
+        return []
     motifs = [Motif(*m) for m in model_metadata["motifs"]]
-    focus = find_focus_bases_batch(reads, motifs)
     refiner = model_metadata.get("sig_map_refiner")
     if refiner is not None and getattr(refiner, "is_loaded", False):
-        for err in refiner.refine_reads(reads):  # one GPU pass per DP round for the whole batch
+        for err in refiner.refine_reads(reads):  # host re-scaling per read + one GPU pass per DP round
             if err is not None:
                 raise err
-    for r, fb in zip(reads, focus):
+    dr = DeviceReads(reads, getattr(model, "engine", None))
+    focus, foc_off = dr.motif_focus_bases(motifs)
+    counts = np.diff(foc_off)
+    arrs, _ = _extract_device(dr, focus, foc_off, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
+                              model_metadata["base_start_justify"], model_metadata["offset"])
+    focus_host = focus.cpu().numpy() if int(foc_off[-1]) else np.zeros(0, np.int64)
+    for r, fb in zip(reads, np.split(focus_host, np.cumsum(counts)[:-1])):
         r.focus_bases = fb
-    arrs, _ = extract_chunk_arrays(reads, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
-                                   model_metadata["base_start_justify"], model_metadata["offset"])
-    counts = np.array([len(fb) for fb in focus], dtype=np.int64)
     if len(arrs) == 0:
         return [(np.array([]), np.array([]), np.array([])) for _ in reads]
     out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)

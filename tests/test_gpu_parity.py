@@ -784,3 +784,36 @@ def test_real_reads_reference_anchored(torch_cuda, O, tmp_path):
         fwd = str(g[f"r{i}_ra_ref_seq"])
         assert rec.query_sequence == (rio.revcomp(fwd) if rec.is_reverse else fwd)
         assert dict(rec.tags)["MM"] == str(g[f"r{i}_ra_mm"])
+
+
+def test_motif_scan_kernel_vs_host(torch_cuda):
+    """rmr_motif_flags (through DeviceReads.motif_focus_bases) against Motif.findall on every read: IUPAC
+    codes, several motifs, N bases in the reads, a focus position left of the motif after N-stripping, reads
+    shorter than the motif, and no hit may straddle two reads."""
+    from remora_amd.data_chunks import DeviceReads, RemoraRead
+    from remora_amd.util import Motif
+
+    rng = np.random.default_rng(12)
+    reads = []
+    for n in (3000, 1, 2, 777, 5, 1200, 64, 65, 4096):
+        seq = rng.integers(0, 4, n).astype(np.int64)
+        if n > 100:
+            seq[rng.integers(0, n, n // 50)] = -1
+        dw = rng.integers(1, 5, n)
+        m = np.concatenate([[0], np.cumsum(dw)]).astype(np.int64)
+        reads.append(RemoraRead(dacs=np.zeros(m[-1], np.int16), shift=0.0, scale=1.0, seq_to_sig_map=m, int_seq=seq))
+    dr = DeviceReads(reads)
+    for spec in ([("CG", 0)], [("C", 0)], [("DRACH", 2), ("CG", 1)], [("NCG", 0)], [("CHH", 0), ("CHG", 0), ("CG", 0)],
+                 [("ACGTACGTACGTAC", 5)], [("N", 0)]):
+        motifs = [Motif(*m) for m in spec]
+        focus, foc_off = dr.motif_focus_bases(motifs)
+        focus = focus.cpu().numpy()
+        for i, r in enumerate(reads):
+            want = set()
+            for mot in motifs:
+                for st in mot.findall(r.int_seq):
+                    fb = int(st) + mot.focus_pos
+                    if 0 <= fb < r.int_seq.size:
+                        want.add(fb)
+            got = focus[foc_off[i] : foc_off[i + 1]]
+            assert np.array_equal(got, np.array(sorted(want), dtype=np.int64)), (spec, i)
