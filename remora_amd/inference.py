@@ -75,11 +75,16 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
         return []
     motifs = [Motif(*m) for m in model_metadata["motifs"]]
     refiner = model_metadata.get("sig_map_refiner")
-    if refiner is not None and getattr(refiner, "is_loaded", False):
-        for err in refiner.refine_reads(reads):  # host re-scaling per read + one GPU pass per DP round
+    loaded = refiner is not None and getattr(refiner, "is_loaded", False)
+    if loaded and refiner.scale_iters > 0:
+        for err in refiner.refine_reads(reads):  # DP rounds interleaved with host re-scaling
             if err is not None:
                 raise err
     dr = DeviceReads(reads, getattr(model, "engine", None))
+    if loaded and refiner.scale_iters <= 0 and refiner.do_rough_rescale:
+        refiner.rough_rescale_device(dr, reads)  # sorts + gathers on the GPU, 19-point fits on the host
+    if loaded and refiner.scale_iters == 0:
+        refiner.refine_device_reads(dr, reads)  # one banded-DP pass on the resident arrays
     focus, foc_off = dr.motif_focus_bases(motifs)
     counts = np.diff(foc_off)
     arrs, _ = _extract_device(dr, focus, foc_off, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],

@@ -486,6 +486,101 @@ class SigMapRefiner:
                         errs[i] = e
         return errs
 
+    def rough_rescale_device(self, dr, reads, quants=np.arange(0.05, 1, 0.05), clip_bases=10):
+        """`rough_rescale` for all reads of a `DeviceReads` batch: the per-base level lookup, the centre-sample
+        gather, the normalisation and the two sorts run on the GPU (torch tensor ops on the resident arrays,
+        float64 / float32 exactly as numpy evaluates them), the 19-point line fit of every read stays numpy on
+        the host - so the new (shift, scale) equal the per-read host method bit for bit.  Updates the reads and
+        `dr`."""
+        import torch
+
+        dev = dr.s2s.device
+        nr = dr.n_reads
+        seq_off = dr.d_seq_off
+        n_i = seq_off[1:] - seq_off[:-1]
+        total = int(dr.seq_off[-1])
+        k = self.kmer_len
+        base = torch.arange(total, device=dev)
+        read_of = torch.searchsorted(seq_off, base, right=True) - 1
+        local = base - seq_off[read_of]
+        # levels (refine_signal_map_core.pyx:87-101): k-mer starting at local - center_idx, inside the read
+        pos = base - int(self.center_idx)
+        ok = (local >= int(self.center_idx)) & (local - int(self.center_idx) + k <= n_i[read_of])
+        idx = torch.zeros(total, dtype=torch.int64, device=dev)
+        seq = dr.iseq.to(torch.int64)
+        for j in range(k):
+            idx = idx * 4 + seq[(pos + j).clamp(0, total - 1)]
+        table = torch.from_numpy(np.ascontiguousarray(self.levels_array, np.float32)).to(dev)
+        levels = torch.where(ok, table[idx.clamp(0, table.numel() - 1)], torch.zeros((), dtype=torch.float32, device=dev))
+        # centre sample of every base, normalised in float64
+        mi = base + read_of  # index of the base's start in the concatenated maps (n + 1 entries per read)
+        mid = (dr.s2s[mi] + dr.s2s[mi + 1]) // 2
+        od = dr.dacs[dr.d_sig_off[read_of] + mid].to(torch.float64)
+        norm = (od - dr.shift[read_of]) / dr.scale[read_of]
+        # clip `clip_bases` at both ends of reads longer than 2 * clip_bases
+        clip = (n_i > 2 * clip_bases)[read_of] if clip_bases > 0 else torch.zeros(total, dtype=torch.bool, device=dev)
+        keep = ~clip | ((local >= clip_bases) & (local < n_i[read_of] - clip_bases))
+        cnt = torch.where(n_i > 2 * clip_bases, n_i - 2 * clip_bases, n_i) if clip_bases > 0 else n_i
+        col = torch.where(clip, local - clip_bases, local)
+        width = int(cnt.max().item())
+        q = torch.from_numpy(np.asarray(quants, np.float64)).to(dev)
+
+        def quantiles(vals, dtype):
+            mat = torch.full((nr, width), float("inf"), dtype=dtype, device=dev)
+            mat[read_of[keep], col[keep]] = vals[keep]
+            srt = torch.sort(mat, dim=1).values
+            vi = (cnt - 1).to(torch.float64)[:, None] * q[None, :]
+            prev = torch.floor(vi)
+            gamma = vi - prev
+            pi = prev.to(torch.int64)
+            ni = pi + 1
+            top = vi >= (cnt - 1).to(torch.float64)[:, None]
+            last = (cnt - 1)[:, None].expand_as(pi)
+            pi = torch.where(top, last, pi)
+            ni = torch.where(top, last, ni)
+            lo, hi = torch.gather(srt, 1, pi), torch.gather(srt, 1, ni)
+            diff = hi - lo  # in the array's own dtype, as numpy's subtract(b, a)
+            out = lo.to(torch.float64) + diff.to(torch.float64) * gamma
+            alt = hi.to(torch.float64) - diff.to(torch.float64) * (1 - gamma)
+            return torch.where(gamma >= 0.5, alt, out).cpu().numpy()
+
+        sig_q = quantiles(norm, torch.float64)
+        lvl_q = quantiles(levels, torch.float32)
+        shifts, scales = [], []
+        for i, r in enumerate(reads):
+            if self.rough_rescale_method == ROUGH_RESCALE_LEAST_SQUARES:
+                inter, slope = _fit_line(sig_q[i], lvl_q[i])
+                sh, sc = (r.shift, r.scale) if slope == 0 else (r.shift - (r.scale * inter / slope), r.scale / slope)
+            else:
+                sh, sc = theil_sen(sig_q[i], lvl_q[i], r.shift, r.scale)
+            r.shift, r.scale = sh, sc
+            r._sig = None
+            shifts.append(float(sh))
+            scales.append(float(sc))
+        dr.set_scaling(shifts, scales)
+
+    def refine_device_reads(self, dr, reads):
+        """One DP pass (scale_iters 0 or 1 round of it) on reads that are already resident (`DeviceReads`):
+        the refined mappings replace `dr.s2s` on the device and are copied back into the read objects.
+        Raises the RemoraError of the first read whose band is invalid."""
+        import torch
+
+        dev = self._device_refiner(dr.engine.device)
+        out = torch.empty_like(dr.s2s)
+        status = torch.zeros(max(dr.n_reads, 1), dtype=torch.int32, device=dr.s2s.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        L.check(dev._lib.rmr_refine_signal_maps(dev._h, dr.n_reads, p(dr.dacs), p(dr.d_sig_off), p(dr.s2s), p(dr.iseq),
+                                                 p(dr.d_seq_off), p(dr.shift), p(dr.scale), p(out), p(status), L.MEM_DEVICE))
+        for st in status[: dr.n_reads].cpu().numpy():
+            if st != 0:
+                raise RemoraError(dev.status_message(st))
+        dr.s2s = out
+        host = out.cpu().numpy()
+        mo = dr.seq_off + np.arange(dr.n_reads + 1)
+        for i, r in enumerate(reads):
+            r.seq_to_sig_map = host[mo[i] : mo[i + 1]].astype(np.asarray(r.seq_to_sig_map).dtype, copy=False)
+            r._sig = None
+
     # ---- (de)serialisation (:499-587) -----------------------------------------------------------
     def asdict(self):
         return {

@@ -294,3 +294,34 @@ def test_refine_tiny_reads_and_device_pointers(torch_cuda, O):
     for i in range(n):
         if status[i] == 0:
             np.testing.assert_array_equal(got[mo[i] : mo[i + 1]], want[i])
+
+
+@pytest.mark.parametrize("method", ["least_squares", "theil_sen"])
+def test_rough_rescale_device_equals_host(torch_cuda, G, method):
+    """The batched GPU-side rough re-scale (level lookup, centre samples, sorts, numpy's quantile arithmetic)
+    returns bit-identical (shift, scale) to the per-read host method, for reads shorter and longer than the
+    2 x 10 clipped bases, and to the reference's values for the golden reads."""
+    from remora_amd.data_chunks import DeviceReads, RemoraRead
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    ref = SigMapRefiner(_levels_array=G["kmer_levels"], center_idx=int(G["center_idx"]), do_rough_rescale=True,
+                        rough_rescale_method=method)
+    rng = np.random.default_rng(2)
+    reads = []
+    for n in READS:
+        reads.append(RemoraRead(dacs=G[f"{n}_dacs"], shift=505.0, scale=83.0, seq_to_sig_map=G[f"{n}_map"].copy(),
+                                int_seq=G[f"{n}_int_seq"], read_id=n))
+    for nb in (7, 20, 21, 33, 900):
+        seq = rng.integers(0, 4, nb)
+        m = np.concatenate([[0], np.cumsum(rng.integers(1, 9, nb))]).astype(np.int64)
+        d = np.round(500 + 80 * rng.standard_normal(m[-1])).astype(np.int16)
+        reads.append(RemoraRead(dacs=d, shift=498.0 + nb % 3, scale=79.5, seq_to_sig_map=m, int_seq=seq, read_id=f"x{nb}"))
+    want = [ref.rough_rescale(r.shift, r.scale, r.seq_to_sig_map, r.int_seq, r.dacs) for r in reads]
+    dr = DeviceReads(reads)
+    ref.rough_rescale_device(dr, reads)
+    for r, (sh, sc) in zip(reads, want):  # (a 7-base read has too few distinct quantiles for Theil-Sen: NaN on both sides)
+        np.testing.assert_array_equal(np.array([r.shift, r.scale]), np.array([sh, sc]), err_msg=r.read_id)
+    np.testing.assert_array_equal(dr.shift.cpu().numpy(), [w[0] for w in want])
+    if method == "theil_sen":  # setting 1 of the golden flow is exactly this (no DP pass)
+        for i, n in enumerate(READS):
+            np.testing.assert_allclose([reads[i].shift, reads[i].scale], G[f"s1_{n}_shift_scale"], rtol=1e-12)
