@@ -7,7 +7,7 @@
  * product path (remora_amd/, libremora_hip.so) never links, imports or calls it.
  *
  * Parity status: PINNED.  Every function here is checked against golden vectors produced
- * by running the reference itself (tools/gen_golden.py -> tests/golden/*.npz); see
+ * by running the reference itself (tools/gen_golden.py -> the .npz files under tests/golden); see
  * tests/test_oracle_golden.py.
  *
  * Each function cites the reference file:line it follows (paths relative to the

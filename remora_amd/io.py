@@ -166,40 +166,50 @@ def _parse_tags(buf, spans=None):
     return tags
 
 
+_NT16 = np.frombuffer(_SEQ_NT16.encode(), dtype="S1")
+
+
+def _read_exact(fh, n):
+    buf = fh.read(n)
+    if len(buf) != n:
+        raise RemoraError("truncated BAM file")
+    return buf
+
+
 def iter_bam_records(bam_path):
-    """Yield BamRecord for every alignment of an (unindexed read of a) BAM file."""
+    """Yield BamRecord for every alignment of a BAM file, streaming (one record in memory at a time)."""
     with gzip.open(bam_path, "rb") as fh:  # BGZF members are valid concatenated gzip members
-        data = fh.read()
-    if data[:4] != b"BAM\x01":
-        raise RemoraError(f"{bam_path} is not a BAM file")
-    l_text = struct.unpack_from("<i", data, 4)[0]
-    p = 8 + l_text
-    n_ref = struct.unpack_from("<i", data, p)[0]
-    p += 4
-    refs = []
-    for _ in range(n_ref):
-        l_name = struct.unpack_from("<i", data, p)[0]
-        refs.append(data[p + 4 : p + 4 + l_name - 1].decode())
-        p += 4 + l_name + 4
-    n = len(data)
-    while p < n:
-        block = struct.unpack_from("<i", data, p)[0]
-        rec = data[p + 4 : p + 4 + block]
-        p += 4 + block
-        ref_id, pos, l_read_name, mapq, _bin, n_cig, flag, l_seq, _nref, _npos, _tlen = struct.unpack_from(
-            "<iiBBHHHiiii", rec, 0)
-        q = 32
-        name = rec[q : q + l_read_name - 1].decode(); q += l_read_name
-        cig = np.frombuffer(rec, dtype="<u4", count=n_cig, offset=q); q += 4 * n_cig
-        cigartuples = [(int(c & 0xF), int(c >> 4)) for c in cig]
-        sb = np.frombuffer(rec, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q); q += (l_seq + 1) // 2
-        codes = np.empty(2 * sb.size, np.uint8)
-        codes[0::2], codes[1::2] = sb >> 4, sb & 0xF
-        seq = "".join(_SEQ_NT16[c] for c in codes[:l_seq])
-        qual = bytes(rec[q : q + l_seq]); q += l_seq
-        spans = []
-        yield BamRecord(name, flag, ref_id, refs[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq,
-                        qual, _parse_tags(rec[q:], spans), bytes(rec), q, spans)
+        if fh.read(4) != b"BAM\x01":
+            raise RemoraError(f"{bam_path} is not a BAM file")
+        l_text = struct.unpack("<i", _read_exact(fh, 4))[0]
+        _read_exact(fh, l_text)
+        n_ref = struct.unpack("<i", _read_exact(fh, 4))[0]
+        refs = []
+        for _ in range(n_ref):
+            l_name = struct.unpack("<i", _read_exact(fh, 4))[0]
+            refs.append(_read_exact(fh, l_name)[:-1].decode())
+            _read_exact(fh, 4)
+        while True:
+            head = fh.read(4)
+            if not head:
+                return
+            if len(head) != 4:
+                raise RemoraError("truncated BAM file")
+            rec = _read_exact(fh, struct.unpack("<i", head)[0])
+            ref_id, pos, l_read_name, mapq, _bin, n_cig, flag, l_seq, _nref, _npos, _tlen = struct.unpack_from(
+                "<iiBBHHHiiii", rec, 0)
+            q = 32
+            name = rec[q : q + l_read_name - 1].decode(); q += l_read_name
+            cig = np.frombuffer(rec, dtype="<u4", count=n_cig, offset=q); q += 4 * n_cig
+            cigartuples = [(int(c & 0xF), int(c >> 4)) for c in cig]
+            sb = np.frombuffer(rec, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q); q += (l_seq + 1) // 2
+            codes = np.empty(2 * sb.size, np.uint8)
+            codes[0::2], codes[1::2] = sb >> 4, sb & 0xF
+            seq = _NT16[codes[:l_seq]].tobytes().decode()
+            qual = bytes(rec[q : q + l_seq]); q += l_seq
+            spans = []
+            yield BamRecord(name, flag, ref_id, refs[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq,
+                            qual, _parse_tags(rec[q:], spans), bytes(rec), q, spans)
 
 
 def _vbz_decode(blob, n_samples):
@@ -229,55 +239,83 @@ class Pod5Read:
     calibration_scale: float
 
 
-def iter_pod5_reads(pod5_path, read_ids=None):
-    """Yield Pod5Read for every read of a POD5 file (Arrow tables located by their magic)."""
-    import uuid
+class Pod5File:
+    """Random access to the reads of a POD5 file without the pod5 package: the file is memory mapped, the
+    embedded Arrow IPC tables (signal rows, reads) are opened in place, a read's signal rows are VBZ-decoded
+    only when the read is asked for."""
 
-    import pyarrow as pa
-    import pyarrow.ipc as ipc
+    def __init__(self, pod5_path):
+        import mmap
+        import uuid
 
-    blob = open(pod5_path, "rb").read()
-    if blob[:8] != b"\x8bPOD\r\n\x1a\n":
-        raise RemoraError(f"{pod5_path} is not a POD5 file")
-    marks = []
-    i = blob.find(b"ARROW1")
-    while i >= 0:
-        marks.append(i)
-        i = blob.find(b"ARROW1", i + 1)
-    tables = {}
-    k = 0
-    while k + 1 < len(marks):  # files are [ARROW1\0\0 ... ARROW1] pairs
-        st = marks[k]
-        opened = False
-        for e in marks[k + 1 :]:
-            try:
-                t = ipc.open_file(pa.BufferReader(blob[st : e + 6])).read_all()
-            except (pa.ArrowInvalid, OSError):
-                continue
-            names = set(t.schema.names)
-            if {"signal", "samples"} <= names:
-                tables["signal"] = t
-            elif "calibration_offset" in names:
-                tables["reads"] = t
-            k = marks.index(e) + 1
-            opened = True
-            break
-        if not opened:
-            k += 1
-    if "signal" not in tables or "reads" not in tables:
-        raise RemoraError(f"could not locate the signal / reads tables in {pod5_path}")
-    sig_t, reads_t = tables["signal"], tables["reads"]
-    sig_rows, sig_n = sig_t.column("signal"), sig_t.column("samples")
-    want = None if read_ids is None else set(read_ids)
-    for r in range(reads_t.num_rows):
-        rid = str(uuid.UUID(bytes=reads_t.column("read_id")[r].as_py()))
-        if want is not None and rid not in want:
-            continue
-        parts = [_vbz_decode(sig_rows[i].as_py(), sig_n[i].as_py()) for i in reads_t.column("signal")[r].as_py()]
+        import pyarrow as pa
+        import pyarrow.ipc as ipc
+
+        self._fh = open(pod5_path, "rb")
+        self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        mm = self._mm
+        if mm[:8] != b"\x8bPOD\r\n\x1a\n":
+            raise RemoraError(f"{pod5_path} is not a POD5 file")
+        marks = []
+        i = mm.find(b"ARROW1")
+        while i >= 0:
+            marks.append(i)
+            i = mm.find(b"ARROW1", i + 1)
+        view = memoryview(mm)
+        tables = {}
+        k = 0
+        while k + 1 < len(marks):  # embedded files are [ARROW1\0\0 ... ARROW1] pairs
+            st = marks[k]
+            opened = False
+            for e in marks[k + 1 :]:
+                try:
+                    t = ipc.open_file(pa.BufferReader(pa.py_buffer(view[st : e + 6]))).read_all()
+                except (pa.ArrowInvalid, OSError):
+                    continue
+                names = set(t.schema.names)
+                if {"signal", "samples"} <= names:
+                    tables["signal"] = t
+                elif "calibration_offset" in names:
+                    tables["reads"] = t
+                k = marks.index(e) + 1
+                opened = True
+                break
+            if not opened:
+                k += 1
+        if "signal" not in tables or "reads" not in tables:
+            raise RemoraError(f"could not locate the signal / reads tables in {pod5_path}")
+        self._sig, self._reads = tables["signal"], tables["reads"]
+        ids = self._reads.column("read_id")
+        self.read_ids = [str(uuid.UUID(bytes=ids[r].as_py())) for r in range(self._reads.num_rows)]
+        self._row = {rid: r for r, rid in enumerate(self.read_ids)}
+
+    def __contains__(self, read_id):
+        return read_id in self._row
+
+    def __len__(self):
+        return len(self.read_ids)
+
+    def get(self, read_id):
+        r = self._row[read_id]
+        sig_rows, sig_n = self._sig.column("signal"), self._sig.column("samples")
+        parts = [_vbz_decode(sig_rows[i].as_py(), sig_n[i].as_py()) for i in self._reads.column("signal")[r].as_py()]
         # delta coding restarts in every signal row
-        yield Pod5Read(rid, np.concatenate(parts) if len(parts) > 1 else parts[0],
-                       float(reads_t.column("calibration_offset")[r].as_py()),
-                       float(reads_t.column("calibration_scale")[r].as_py()))
+        return Pod5Read(read_id, np.concatenate(parts) if len(parts) > 1 else parts[0],
+                        float(self._reads.column("calibration_offset")[r].as_py()),
+                        float(self._reads.column("calibration_scale")[r].as_py()))
+
+    def __iter__(self):
+        for rid in self.read_ids:
+            yield self.get(rid)
+
+
+def iter_pod5_reads(pod5_path, read_ids=None):
+    """Yield Pod5Read for every (requested) read of a POD5 file."""
+    f = Pod5File(pod5_path)
+    want = None if read_ids is None else set(read_ids)
+    for rid in f.read_ids:
+        if want is None or rid in want:
+            yield f.get(rid)
 
 
 _COMP = str.maketrans("ACGTBVDHKMRYacgt", "TGCAVBHDMKYRtgca")
@@ -462,7 +500,7 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
                                  skip_non_primary=True):
     """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
     read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519)."""
-    signals = {r.read_id: r for r in iter_pod5_reads(pod5_path)}
+    signals = Pod5File(pod5_path)  # signals are decoded when their alignment comes up
     for rec in iter_bam_records(bam_path):
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
@@ -470,7 +508,7 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
         rid = tags.get("pi", rec.query_name)
         if rid not in signals:
             continue
-        read = Read.from_pod5(signals[rid], reverse_signal=reverse_signal)
+        read = Read.from_pod5(signals.get(rid), reverse_signal=reverse_signal)
         try:
             read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling)
         except RemoraError as e:
@@ -491,15 +529,16 @@ _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000
 def read_bam_header_bytes(bam_path):
     """Everything before the first alignment record (magic, text header, reference list)."""
     with gzip.open(bam_path, "rb") as fh:
-        data = fh.read()
-    l_text = struct.unpack_from("<i", data, 4)[0]
-    p = 8 + l_text
-    n_ref = struct.unpack_from("<i", data, p)[0]
-    p += 4
-    for _ in range(n_ref):
-        l_name = struct.unpack_from("<i", data, p)[0]
-        p += 4 + l_name + 4
-    return data[:p]
+        out = bytearray(_read_exact(fh, 8))
+        if out[:4] != b"BAM\x01":
+            raise RemoraError(f"{bam_path} is not a BAM file")
+        out += _read_exact(fh, struct.unpack_from("<i", out, 4)[0])
+        nref = _read_exact(fh, 4)
+        out += nref
+        for _ in range(struct.unpack("<i", nref)[0]):
+            ln = _read_exact(fh, 4)
+            out += ln + _read_exact(fh, struct.unpack("<i", ln)[0] + 4)
+    return bytes(out)
 
 
 def _pack_seq(seq):
