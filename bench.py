@@ -345,6 +345,14 @@ def main():
                         "upload, GPU rough re-scale inputs (sorts) + host 19-point fits, GPU banded DP, motif scan, "
                         "extraction, inference"}
 
+    # ---- POD5 signal decompression: the VBZ layer below zstd on resident rows ----
+    vbz_leg = None
+    if rank == 0 and world == 1 and not args.no_refine:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_vbz
+
+        vbz_leg = bench_vbz.measure(n_rows=2048, row_samples=102400, steps=3, warmup=1, cpu_rows=8, device=local)
+
     # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
     alt, alt_head = None, None
     if rank == 0 and world == 1 and args.dtype == "fp32" and arch == "conv_lstm" and not args.no_alt:
@@ -419,6 +427,7 @@ def main():
         "alt_bf16x6": alt,
         "reads_pipeline": reads_leg,
         "refine_signal_map": refine_leg,
+        "vbz_decode": vbz_leg,
         "label_counts": [int(x) for x in counts.tolist()],
     }
     if world == 1 and not args.no_cpu_baseline:

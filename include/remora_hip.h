@@ -126,6 +126,17 @@ int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int
                     int64_t seq_len, int check, int reverse_signal, int64_t *q2s,
                     int64_t *n_out, int mem);
 
+/* ---- N1: POD5 signal decompression (the VBZ layer below zstd) ------------------------------ */
+/* replaces: the per-row signal decode that pod5's C++ reader performs for the records consumed by
+ * io.iter_signal (src/remora/io.py:441-474) / Read.from_pod5_and_alignment (:2086-2121):
+ * streamvbyte16 (ceil(n/8) key bytes, one bit per sample LSB first: 0 = one data byte, 1 = two; then the
+ * data bytes) -> zigzag -> running sum in int16.  `svb` holds the zstd-DEcompressed bytes of the rows back to
+ * back (row r = svb[row_off[r] : row_off[r+1]]), row_samples[r] its sample count; `out` receives the rows'
+ * samples back to back (sum(row_samples) int16).  The delta coding restarts in every row.
+ * Errors: RMR_ERR_INVALID "corrupt VBZ signal block" when a row's byte count disagrees with its keys. */
+int rmr_vbz_decode(rmr_engine *e, const uint8_t *svb, const int64_t *row_off, const int32_t *row_samples,
+                   int64_t n_rows, int16_t *out, int mem);
+
 /* ---- M3: motif scan ---------------------------------------------------------------------- */
 /* replaces: Motif.findall (src/remora/util.py:281-297) + find_focus_bases_in_int_sequence (:413-426) as
  * called by RemoraRead.set_motif_focus_bases (src/remora/data_chunks.py:310-317), for a batch of reads:

@@ -493,3 +493,32 @@ ORC_API int orc_seq_banded_dp(const float *signal, const float *levels, int n, c
     free(unpen); free(unpen_tb); free(spoof);
     return 0;
 }
+
+/* ====================================================================================
+ * N1  POD5 signal rows: the VBZ layer below zstd (streamvbyte16 -> zigzag -> running sum).
+ *     The algorithm lives in pod5's C++ library (pod5 >= 0.2, `svb16` + `decompress_signal`), a
+ *     dependency of the reference that is absent here; this restates its published format:
+ *     ceil(n/8) key bytes (bit j of byte i = sample 8i+j: 0 one data byte, 1 two, little endian),
+ *     then the data bytes; value -> (v >> 1) ^ -(v & 1); samples = prefix sums in int16.
+ *     Pinned on the reference's own tests/data/can_reads.pod5: the decoded signals feed the
+ *     reference's Read/call_read_mods golden (signal checksums in tests/golden/real_reads_can.npz).
+ *     returns 0, or -1 when the byte count disagrees with the keys.
+ * ==================================================================================== */
+ORC_API int orc_vbz_decode(const uint8_t *svb, int64_t nbytes, int32_t n, int16_t *out) {
+    const int64_t nkeys = ((int64_t)n + 7) / 8;
+    if (nbytes < nkeys) return -1;
+    const uint8_t *data = svb + nkeys;
+    int64_t p = 0;
+    const int64_t avail = nbytes - nkeys;
+    uint16_t acc = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int two = (svb[i >> 3] >> (i & 7)) & 1;
+        if (p + 1 + two > avail) return -1;
+        uint32_t v = data[p];
+        if (two) v |= (uint32_t)data[p + 1] << 8;
+        p += 1 + two;
+        acc = (uint16_t)(acc + (uint16_t)((v >> 1) ^ (0u - (v & 1u))));
+        out[i] = (int16_t)acc;
+    }
+    return p == avail ? 0 : -1;
+}

@@ -25,7 +25,7 @@ static const char *k_names[K_NUM] = {
     "encode_kmers", "trim_chunk_context", "parse_moves", "normalise_signal", "chunk_geometry",
     "chunk_fill", "front_sig", "front_seq", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
     "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
-    "count_labels", "motif_scan", "refine_band", "refine_dp", "refine_dp_rowwise"};
+    "count_labels", "motif_scan", "vbz_decode", "refine_band", "refine_dp", "refine_dp_rowwise"};
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
 
 }  // namespace rmr
@@ -952,6 +952,60 @@ int rmr_motif_flags(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off
     RMR_TRY(launch_motif(e, ds, d_off, (int)n_reads, total, *motifs, df));
     D2H(flags, df, (size_t)total);
     RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_vbz_decode(rmr_engine *e, const uint8_t *svb, const int64_t *row_off, const int32_t *row_samples,
+                   int64_t n_rows, int16_t *out, int mem) {
+    if (!e || !svb || !row_off || !row_samples || !out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_rows < 0 || n_rows > (int64_t)1 << 30) RMR_FAIL(RMR_ERR_INVALID, "bad n_rows");
+    if (n_rows == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    std::vector<int64_t> ro((size_t)n_rows + 1), oo((size_t)n_rows + 1);
+    std::vector<int32_t> rn((size_t)n_rows);
+    if (mem == RMR_MEM_HOST) {
+        memcpy(ro.data(), row_off, ro.size() * 8);
+        memcpy(rn.data(), row_samples, rn.size() * 4);
+    } else {
+        RMR_HIP(hipMemcpy(ro.data(), row_off, ro.size() * 8, hipMemcpyDeviceToHost));
+        RMR_HIP(hipMemcpy(rn.data(), row_samples, rn.size() * 4, hipMemcpyDeviceToHost));
+    }
+    oo[0] = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        if (rn[r] < 0 || ro[r + 1] < ro[r] || ro[r + 1] - ro[r] < ((int64_t)rn[r] + 7) / 8 + rn[r])
+            RMR_FAIL(RMR_ERR_INVALID, "corrupt VBZ signal block (row %lld)", (long long)r);
+        oo[r + 1] = oo[r] + rn[r];
+    }
+    const int64_t nbytes = ro[n_rows], nout = oo[n_rows];
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad((size_t)nbytes + 16) + 2 * Stage::pad((size_t)(n_rows + 1) * 8) + 2 * Stage::pad((size_t)n_rows * 4) +
+                    Stage::pad((size_t)nout * 2 + 16) + 8192));
+    int64_t *d_oo = st.take<int64_t>(n_rows + 1);
+    int32_t *d_st = st.take<int32_t>(n_rows);
+    H2D(d_oo, oo.data(), oo.size() * 8);
+    RMR_HIP(hipMemsetAsync(d_st, 0, (size_t)n_rows * 4, e->stream));
+    const uint8_t *d_svb = svb;
+    const int64_t *d_ro = row_off;
+    const int32_t *d_rn = row_samples;
+    int16_t *d_out = out;
+    if (mem == RMR_MEM_HOST) {
+        uint8_t *b = st.take<uint8_t>(nbytes + 16);
+        int64_t *o = st.take<int64_t>(n_rows + 1);
+        int32_t *c = st.take<int32_t>(n_rows);
+        d_out = st.take<int16_t>(nout + 8);
+        H2D(b, svb, (size_t)nbytes);
+        H2D(o, row_off, ro.size() * 8);
+        H2D(c, row_samples, rn.size() * 4);
+        d_svb = b; d_ro = o; d_rn = c;
+    }
+    RMR_TRY(launch_vbz(e, d_svb, d_ro, d_rn, d_oo, n_rows, d_out, d_st));
+    std::vector<int32_t> hst((size_t)n_rows);
+    D2H(hst.data(), d_st, (size_t)n_rows * 4);
+    if (mem == RMR_MEM_HOST) D2H(out, d_out, (size_t)nout * 2);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    for (int64_t r = 0; r < n_rows; ++r)
+        if (hst[r]) RMR_FAIL(RMR_ERR_INVALID, "corrupt VBZ signal block (row %lld)", (long long)r);
     return 0;
 }
 

@@ -231,6 +231,48 @@ def _vbz_decode(blob, n_samples):
     return np.cumsum(d, dtype=np.int16)
 
 
+def _zstd_decompress(blob):
+    import pyarrow as pa
+
+    return pa.CompressedInputStream(pa.BufferReader(blob), "zstd").read()
+
+
+def vbz_decode_batch(blobs, n_samples, engine=None, to_host=True):
+    """Decode many VBZ signal rows at once: zstd on the host (libzstd through pyarrow), then streamvbyte16 ->
+    zigzag -> running sum on the GPU (`rmr_vbz_decode`; one upload of 1..2 bytes per sample).  Returns the rows'
+    int16 samples back to back (numpy array, or a CUDA tensor with to_host=False) and the row offsets."""
+    import ctypes
+
+    import torch
+
+    from . import _lib as L
+    from .engine import get_engine
+
+    eng = engine if engine is not None else get_engine()
+    raws = [_zstd_decompress(b) for b in blobs]
+    n = len(raws)
+    row_off = np.zeros(n + 1, np.int64)
+    np.cumsum([len(r) for r in raws], out=row_off[1:])
+    out_off = np.zeros(n + 1, np.int64)
+    np.cumsum(np.asarray(n_samples, np.int64), out=out_off[1:])
+    buf = np.zeros(int(row_off[-1]) + 16, np.uint8)  # the kernel reads whole dwords: a little slack at the end
+    for r, st in zip(raws, row_off):
+        buf[st : st + len(r)] = np.frombuffer(r, np.uint8)
+    rn = np.ascontiguousarray(n_samples, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    if to_host:
+        out = np.empty(int(out_off[-1]), np.int16)
+        L.check(L.lib().rmr_vbz_decode(eng.handle, p(buf), p(row_off), p(rn), n, p(out), L.MEM_HOST))
+        return out, out_off
+    dev = eng.torch_device
+    d_buf, d_ro, d_rn = (torch.from_numpy(a).to(dev) for a in (buf, row_off, rn))
+    d_out = torch.empty(max(int(out_off[-1]), 1), dtype=torch.int16, device=dev)
+    L.check(L.lib().rmr_vbz_decode(eng.handle, d_buf.data_ptr(), d_ro.data_ptr(), d_rn.data_ptr(), n, d_out.data_ptr(),
+                                   L.MEM_DEVICE))
+    eng.synchronize()
+    return d_out[: int(out_off[-1])], out_off
+
+
 @dataclasses.dataclass
 class Pod5Read:
     read_id: str
@@ -303,6 +345,26 @@ class Pod5File:
         return Pod5Read(read_id, np.concatenate(parts) if len(parts) > 1 else parts[0],
                         float(self._reads.column("calibration_offset")[r].as_py()),
                         float(self._reads.column("calibration_scale")[r].as_py()))
+
+    def get_many(self, read_ids, engine=None):
+        """The signals of several reads decoded in one GPU call (see vbz_decode_batch); list of Pod5Read."""
+        sig_rows, sig_n = self._sig.column("signal"), self._sig.column("samples")
+        rows_of, blobs, ns = [], [], []
+        for rid in read_ids:
+            rows = self._reads.column("signal")[self._row[rid]].as_py()
+            rows_of.append(len(rows))
+            for i in rows:
+                blobs.append(sig_rows[i].as_py())
+                ns.append(sig_n[i].as_py())
+        flat, off = vbz_decode_batch(blobs, ns, engine)
+        out, k = [], 0
+        for rid, nrows in zip(read_ids, rows_of):
+            r = self._row[rid]
+            sig = flat[off[k] : off[k + nrows]]  # a read's rows are consecutive in the batch
+            k += nrows
+            out.append(Pod5Read(rid, sig, float(self._reads.column("calibration_offset")[r].as_py()),
+                                float(self._reads.column("calibration_scale")[r].as_py())))
+        return out
 
     def __iter__(self):
         for rid in self.read_ids:
@@ -497,24 +559,40 @@ class Read:
 
 
 def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_scaling=None,
-                                 skip_non_primary=True):
+                                 skip_non_primary=True, decode_batch=256):
     """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
-    read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519)."""
-    signals = Pod5File(pod5_path)  # signals are decoded when their alignment comes up
+    read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519).  The signals of
+    `decode_batch` consecutive records are decompressed together (zstd on the host, VBZ on the GPU);
+    decode_batch <= 1 decodes read by read on the host."""
+    signals = Pod5File(pod5_path)
+
+    def emit(recs):
+        if decode_batch > 1 and recs:
+            ids = list(dict.fromkeys(rid for _, rid in recs))
+            pods = dict(zip(ids, signals.get_many(ids)))
+        else:
+            pods = None
+        for rec, rid in recs:
+            read = Read.from_pod5(pods[rid] if pods is not None else signals.get(rid), reverse_signal=reverse_signal)
+            try:
+                read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling)
+            except RemoraError as e:
+                yield read, str(e)
+                continue
+            yield read, None
+
+    pending = []
     for rec in iter_bam_records(bam_path):
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
-        tags = dict(rec.tags)
-        rid = tags.get("pi", rec.query_name)
+        rid = dict(rec.tags).get("pi", rec.query_name)
         if rid not in signals:
             continue
-        read = Read.from_pod5(signals.get(rid), reverse_signal=reverse_signal)
-        try:
-            read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling)
-        except RemoraError as e:
-            yield read, str(e)
-            continue
-        yield read, None
+        pending.append((rec, rid))
+        if len(pending) >= max(decode_batch, 1):
+            yield from emit(pending)
+            pending = []
+    yield from emit(pending)
 
 
 # ---- BAM output (SURVEY §8f row N3): the reference writes `pysam.AlignedSegment.from_dict(

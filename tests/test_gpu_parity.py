@@ -817,3 +817,52 @@ def test_motif_scan_kernel_vs_host(torch_cuda):
                         want.add(fb)
             got = focus[foc_off[i] : foc_off[i + 1]]
             assert np.array_equal(got, np.array(sorted(want), dtype=np.int64)), (spec, i)
+
+
+def _svb16_encode(sig):
+    """Test-side encoder of the VBZ layer below zstd: int16 samples -> deltas -> zigzag -> streamvbyte16."""
+    sig = np.asarray(sig, np.int16)
+    d = np.diff(np.concatenate([[0], sig.astype(np.int64)])).astype(np.int16)  # wraps like the decoder's sum
+    zz = ((d.astype(np.int32) << 1) ^ (d.astype(np.int32) >> 15)).astype(np.uint32) & 0xFFFF
+    two = zz > 0xFF
+    keys = np.packbits(two, bitorder="little")
+    data = np.empty(sig.size + int(two.sum()), np.uint8)
+    offs = np.cumsum(two + 1) - (two + 1)
+    data[offs] = zz & 0xFF
+    data[offs[two] + 1] = zz[two] >> 8
+    return keys.tobytes() + data.tobytes()
+
+
+def test_vbz_decode_kernel(torch_cuda):
+    """rmr_vbz_decode against the numpy decoder (itself pinned on the reference's POD5 file through the signal
+    checksums of real_reads_can.npz): the rows of the real file, and synthetic rows from 1 sample to 150 k,
+    all-one-byte / all-two-byte deltas, int16 wrap-around; host and device pointer flavours; corrupt input."""
+    import pyarrow as pa
+
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    f = rio.Pod5File(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data", "can_reads.pod5"))
+    for batch in (f.read_ids, f.read_ids[:1], f.read_ids[3:9]):
+        got = f.get_many(batch)
+        for rid, g in zip(batch, got):
+            np.testing.assert_array_equal(g.signal, f.get(rid).signal)
+    rng = np.random.default_rng(8)
+    rows = []
+    for n in (1, 7, 8, 9, 255, 2048, 2049, 4096, 40000, 102400, 150001):
+        walk = np.cumsum(rng.integers(-40, 41, n)) + 500
+        rows.append(walk.astype(np.int16))
+    rows.append(np.full(5000, 77, np.int16))                                   # every delta fits one byte
+    rows.append((rng.integers(0, 2, 5000) * 20000 - 10000).astype(np.int16))    # every delta needs two bytes
+    rows.append(np.cumsum(rng.integers(-30000, 30000, 9000)).astype(np.int16))  # wraps around int16 many times
+    comp = [pa.compress(_svb16_encode(r), codec="zstd", asbytes=True) for r in rows]
+    for r, c in zip(rows[:6], comp[:6]):  # the encoder agrees with the host decoder
+        np.testing.assert_array_equal(rio._vbz_decode(c, r.size), r)
+    flat, off = rio.vbz_decode_batch(comp, [r.size for r in rows])
+    for i, r in enumerate(rows):
+        np.testing.assert_array_equal(flat[off[i] : off[i + 1]], r, err_msg=f"row {i}")
+    dflat, _ = rio.vbz_decode_batch(comp, [r.size for r in rows], to_host=False)
+    np.testing.assert_array_equal(dflat.cpu().numpy(), flat)
+    bad = pa.compress(_svb16_encode(rows[4])[:-3], codec="zstd", asbytes=True)
+    with pytest.raises(RemoraError, match="corrupt VBZ"):
+        rio.vbz_decode_batch([comp[0], bad], [rows[0].size, rows[4].size])

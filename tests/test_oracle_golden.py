@@ -258,3 +258,26 @@ def test_call_read_mods_with_refiner_golden():
         assert np.array_equal(pos, g[f"{rname}_pos"])
         assert pos.size and np.abs(nn_out - g[f"{rname}_nn_out"]).max() < 2e-5
     assert moved > 100  # the refinement really changed the mappings
+
+
+def test_vbz_oracle_on_the_reference_pod5_rows():
+    """orc_vbz_decode on every signal row of the reference's tests/data/can_reads.pod5 equals the numpy decoder
+    whose output feeds the reference-generated read golden (signal checksums in real_reads_can.npz)."""
+    import os
+
+    from conftest import GOLDEN
+    from remora_amd import io as rio
+
+    f = rio.Pod5File(os.path.join(GOLDEN, "data", "can_reads.pod5"))
+    rows, ns = f._sig.column("signal"), f._sig.column("samples")
+    total = 0
+    for i in range(f._sig.num_rows):
+        blob, n = rows[i].as_py(), ns[i].as_py()
+        np.testing.assert_array_equal(O.vbz_decode(bytes(rio._zstd_decompress(blob)), n), rio._vbz_decode(blob, n))
+        total += n
+    assert total > 500000
+    g = golden("real_reads_can.npz")
+    read = f.get(str(g["r0_name"]))
+    assert read.signal.dtype == np.int16 and read.signal.size >= int(g["r0_ndacs"])
+    with pytest.raises(O.OracleError):
+        O.vbz_decode(b"\x01\x02", 8)
