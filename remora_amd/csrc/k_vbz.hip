@@ -17,7 +17,7 @@ namespace rmr {
 namespace {
 
 constexpr int kVbzWaves = 4;          // rows per workgroup
-constexpr int kVbzPer = 16;           // samples per lane and step
+constexpr int kVbzPer = 16;           // samples per lane and step (a multiple of 8, at most 32)
 constexpr int kVbzStep = 64 * kVbzPer;
 
 // exclusive scan over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips); *total receives the sum
@@ -59,11 +59,10 @@ __global__ __launch_bounds__(64 * kVbzWaves) void vbz_decode_kernel(const uint8_
         const int64_t first = s0 + (int64_t)lane * kVbzPer;
         *nv = (int)min((int64_t)kVbzPer, max((int64_t)0, (int64_t)n - first));
         uint32_t k = 0;
-        if (*nv > 0) {
-            k = keys[first >> 3];
-            if (*nv > 8) k |= (uint32_t)keys[(first >> 3) + 1] << 8;
-            k &= (*nv >= 16) ? 0xffffu : ((1u << *nv) - 1u);
-        }
+#pragma unroll
+        for (int b = 0; b < kVbzPer / 8; ++b)
+            if (*nv > 8 * b) k |= (uint32_t)keys[(first >> 3) + b] << (8 * b);
+        k &= (*nv >= 32) ? 0xffffffffu : ((1u << *nv) - 1u);
         *key = k;
     };
     // the data bytes of a step, as aligned dwords in registers (they go to LDS when the slice is free)
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(64 * kVbzWaves) void vbz_decode_kernel(const uint8_
 #pragma unroll
         for (int j = 0; j < kVbzPer; ++j) {  // byte offset of sample j = j + (two-byte samples before it): independent reads
             const int pj = j + __popc(key_c & ((1u << j) - 1u));
-            const uint32_t b0 = sb[pj], b1 = sb[pj + 1];
+            const uint32_t b0 = sb[pj], b1 = sb[pj + 1];  // byte reads: unaligned 16-bit LDS reads measured 2x slower
             raw[j] = ((key_c >> j) & 1u) ? (b0 | (b1 << 8)) : b0;
         }
 #pragma unroll
@@ -125,13 +124,13 @@ __global__ __launch_bounds__(64 * kVbzWaves) void vbz_decode_kernel(const uint8_
         const uint32_t add = carry + (uint32_t)base;
         int16_t *o = dst + first;
         if (nv_c == kVbzPer && ((uintptr_t)o & 15) == 0) {
-            uint4 w[2];
+            uint4 w[kVbzPer / 8];
             uint32_t *wp = reinterpret_cast<uint32_t *>(w);
 #pragma unroll
             for (int j = 0; j < kVbzPer; j += 2)
                 wp[j >> 1] = ((uint32_t)(uint16_t)(vals[j] + add)) | ((uint32_t)(uint16_t)(vals[j + 1] + add) << 16);
-            reinterpret_cast<uint4 *>(o)[0] = w[0];
-            reinterpret_cast<uint4 *>(o)[1] = w[1];
+#pragma unroll
+            for (int q = 0; q < kVbzPer / 8; ++q) reinterpret_cast<uint4 *>(o)[q] = w[q];
         } else {
 #pragma unroll
             for (int j = 0; j < kVbzPer; ++j)
