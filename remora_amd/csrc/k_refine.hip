@@ -948,6 +948,7 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
         const int force_w = tune_int("RMR_REFINE_W", 0);
         for (int64_t r = 0; r < n_reads; ++r) {
             if (hstat[r] != 0) continue;
+            if (band_len[r] >= ((int64_t)1 << 31)) continue;  // 32-bit row offsets of the column kernel: row-wise instead
             if (maxwin[r] <= 16 && force_w != 64) l16.push_back((int32_t)r);
             else if (maxwin[r] <= 64) l64.push_back((int32_t)r);
         }
@@ -987,7 +988,7 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
         RMR_D2H(hstat.data(), w.status, (size_t)n_reads * 4);
         RMR_HIP(hipStreamSynchronize(e->stream));
         for (int64_t r = 0; r < n_reads; ++r)
-            if (maxwin[r] > 64 && hstat[r] == 0) hstat[r] = -1;  // too wide for the column kernel
+            if ((maxwin[r] > 64 || band_len[r] >= ((int64_t)1 << 31)) && hstat[r] == 0) hstat[r] = -1;  // not for the column kernel
     }
     // reads handed back by the column kernel (or all of them when forced) are evaluated row by row
     {
