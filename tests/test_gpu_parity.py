@@ -866,3 +866,49 @@ def test_vbz_decode_kernel(torch_cuda):
     bad = pa.compress(_svb16_encode(rows[4])[:-3], codec="zstd", asbytes=True)
     with pytest.raises(RemoraError, match="corrupt VBZ"):
         rio.vbz_decode_batch([comp[0], bad], [rows[0].size, rows[4].size])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_whole_read_pipeline_vs_oracle(torch_cuda, O, seed):
+    """Random model shapes (size 16/32/64, chunk length 40..260 with unequal contexts, k-mer contexts 0..6,
+    2..4 classes), random motifs (IUPAC, focus anywhere), base_start_justify / offset, and random reads with N
+    bases and zero-dwell bases: the batched GPU pipeline (upload, motif scan, extraction, fused inference) must
+    give the oracle's positions (as a set: the batch path is ascending) and logits for every read."""
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_reads_mods
+    from remora_amd.model_util import model_from_state
+
+    rng = np.random.default_rng(5000 + seed)
+    size = int(rng.choice([16, 32, 64]))
+    kb, ka = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+    cc = (int(rng.integers(20, 131)), int(rng.integers(20, 131)))
+    num_out = int(rng.integers(2, 5))
+    state = synth.synth_state("conv_lstm", size=size, kmer_len=kb + ka + 1, num_out=num_out, seed=seed)
+    motif = [("CG", 0), ("C", 0), ("DRACH", 2), ("GATC", 1), ("CHH", 0), ("NCG", 0)][seed % 6]
+    md = dict(chunk_context=cc, kmer_context_bases=(kb, ka), motifs=[motif], mod_bases=list("abc"[: num_out - 1]),
+              mod_long_names=list("xyz"[: num_out - 1]), can_base=motif[0][motif[1]] if motif[0][motif[1]] in "ACGT" else "C",
+              base_start_justify=bool(seed % 2), offset=int(rng.integers(0, 3)), sig_map_refiner=None)
+    model = model_from_state(state, md, device=0)
+    reads, raw = [], []
+    for i in range(5):
+        nb = int(rng.integers(3, 400))
+        seq = rng.integers(0, 4, nb).astype(np.int64)
+        if i % 2:
+            seq[rng.integers(0, nb, max(nb // 30, 1))] = -1
+        dw = rng.integers(0 if i == 2 else 1, 18, nb)
+        dw[-1] = max(dw[-1], 1)
+        m = np.concatenate([[0], np.cumsum(dw)]).astype(np.int64)
+        d = rng.integers(300, 700, m[-1]).astype(np.int16)
+        raw.append((d, m, seq))
+        reads.append(RemoraRead(dacs=d, shift=500.0 + i, scale=80.0 - i, seq_to_sig_map=m, int_seq=seq, read_id=f"f{i}"))
+    res = call_reads_mods(reads, model, md)
+    total = 0
+    for i, ((d, m, seq), (nn_out, _, pos)) in enumerate(zip(raw, res)):
+        want_out, _, want_pos = O.call_read_mods(d, 500.0 + i, 80.0 - i, m, seq, state, md)
+        assert sorted(np.asarray(want_pos).tolist()) == np.asarray(pos).tolist(), (seed, i)
+        if len(pos):
+            order = np.argsort(want_pos, kind="stable")
+            assert np.abs(nn_out - want_out[order]).max() <= 1e-4, (seed, i, float(np.abs(nn_out - want_out[order]).max()))
+        total += len(pos)
+    assert total > 0
