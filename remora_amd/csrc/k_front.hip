@@ -174,14 +174,14 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
         }
         wave_sync();
         if (live) {
-            for (int s = sub; s < a.L; s += 32) {  // first index in [0, len] with map[idx] > s
-                int lo = 0, hi = len + 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_map[mid] <= s) lo = mid + 1; else hi = mid;
-                }
-                const int p = lo - 1;
-                s_pidx[s] = (int16_t)((p >= 0 && p < len) ? p : a.maxlen);
+            // base covering every signal position: p(s) = last p with map[p] <= s < map[len] (the gather form of the
+            // reference's scatter loops).  Written as runs - base p owns [map[p], map[p+1]) - which needs no
+            // dependent LDS probes; positions no base owns keep the zero row `maxlen`
+            for (int s = sub; s < a.L; s += 32) s_pidx[s] = (int16_t)a.maxlen;
+            wave_sync();
+            for (int p = sub; p < len; p += 32) {
+                const int s0 = max((int)s_map[p], 0), s1 = min((int)s_map[p + 1], a.L);
+                for (int s = s0; s < s1; ++s) s_pidx[s] = (int16_t)p;
             }
             for (int p = sub; p < len; p += 32) {
                 unsigned long long wv = 0;
