@@ -351,7 +351,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_vbz
 
-        vbz_leg = bench_vbz.measure(n_rows=2048, row_samples=102400, steps=3, warmup=1, cpu_rows=8, device=local)
+        vbz_leg = bench_vbz.measure(n_rows=4096, row_samples=102400, steps=3, warmup=1, cpu_rows=8, device=local)
 
     # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
     alt, alt_head = None, None
