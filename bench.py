@@ -160,7 +160,7 @@ def cpu_baseline(state, data, kcb, budget_s=12.0):
         "kind": "port",
         "sample": f"{done} chunks in batches of {B}: C port of compute_encoded_kmer_batch (1 thread) + torch.nn "
                   f"restatement of the network, eager fp32, {threads} torch threads (best of {sorted(tuned)} on a "
-                  f"512-chunk probe; box has {cores} cores)",
+                  f"one-batch probe; box has {cores} cores)",
         "thread_probe_chunks_per_s": {str(k): v for k, v in tuned.items()},
         "encode_chunks_per_s": done / t_enc,
         "model_chunks_per_s": done / t_net,
