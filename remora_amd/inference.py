@@ -1,5 +1,8 @@
 """Python API of the hot path — drop-in for `remora.inference.call_read_mods`
 (src/remora/inference.py:661-712) and the per-label tally the multi-GPU runs reduce."""
+import queue as _queue
+from collections import defaultdict as _defaultdict
+
 import numpy as np
 
 from . import RemoraError
@@ -107,7 +110,7 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
 
 
 def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
-                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False):
+                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False, prefetch=2):
     """`remora infer from_pod5_and_bam` for one model, basecall-anchored by default or reference-anchored
     (`--reference-anchored`: calls at reference positions, output records rewritten to `<len>M` + reference
     sequence) (src/remora/inference.py:462-641): every input alignment is written to `out_bam_path` with
@@ -152,18 +155,55 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                 fwd = io_read.ref_seq if io_read.ref_reg.strand == "+" else rio.revcomp(io_read.ref_seq)
             writer.write(rio.record_with_mod_tags(io_read.record, mm, ml, ref_anchored_seq=fwd))
 
-    with rio.BamWriter(out_bam_path, header) as writer:
+    def batches():
         batch = []
         for i, item in enumerate(rio.iter_reads_from_pod5_and_bam(pod5_path, in_bam_path, reverse_signal=reverse_signal,
-                                                                  pa_scaling=pa_scaling, skip_non_primary=skip_non_primary)):
+                                                                  pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
+                                                                  decode_batch=reads_per_batch)):
             if num_reads is not None and i >= num_reads:
                 break
             batch.append(item)
             if len(batch) >= reads_per_batch:
-                flush(batch, writer)
+                yield batch
                 batch = []
         if batch:
-            flush(batch, writer)
+            yield batch
+
+    # ingest (BGZF inflate, zstd, record parsing) of the next batches runs in a thread while the GPU works on the
+    # current one - the role the reference gives to its reader / prepare processes (src/remora/inference.py:488-560)
+    import threading
+
+    q = _queue.Queue(maxsize=max(int(prefetch), 1))
+    stop = threading.Event()
+
+    def produce():
+        try:
+            for b in batches():
+                while not stop.is_set():
+                    try:
+                        q.put(b, timeout=0.1)
+                        break
+                    except _queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+            q.put(None)
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            q.put(e)
+
+    t = threading.Thread(target=produce, daemon=True)
+    t.start()
+    try:
+        with rio.BamWriter(out_bam_path, header) as writer:
+            while True:
+                b = q.get()
+                if b is None:
+                    break
+                if isinstance(b, BaseException):
+                    raise b
+                flush(b, writer)
+    finally:
+        stop.set()
     return dict(stats)
 
 
@@ -175,8 +215,6 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 # the dense one-hot `enc_kmers` (14,400 B per chunk): the one-hot is never materialised, the
 # fused kernels expand it in LDS.  `PackedKmers.dense()` gives the reference's array when wanted.
 # ---------------------------------------------------------------------------------------------
-import queue as _queue
-from collections import defaultdict as _defaultdict
 
 
 class PackedKmers:
