@@ -574,3 +574,79 @@ def test_cigar_mapping_errors_and_ref_anchored_record_bytes():
     assert back.reference_start == rec.reference_start and back.flag == rec.flag and back.query_name == rec.query_name
     t = dict(back.tags)
     assert t["MM"] == "C+m?,1,2;" and list(t["ML"]) == [7, 200] and t["NM"] == dict(rec.tags)["NM"]
+
+
+# ---- N4: dataset writer on the host (no GPU needed for write_batch / write_chunk / shuffle) -------
+def test_core_dataset_write_batch_roundtrip_and_shuffle(tmp_path):
+    """Rows read from the reference-written dataset, written back through write_batch / write_chunk, give the
+    same metadata.jsn text and the same valid bytes; shuffle applies one permutation to every array."""
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import Chunk, CoreRemoraDataset, dataset_metadata
+
+    ref_dir = os.path.join(ROOT, "tests", "golden", "data", "core_dataset")
+    src = CoreRemoraDataset(ref_dir)
+    n = src.size
+    md = dataset_metadata(allocate_size=n + 7, max_seq_len=20, mod_bases=["m"], mod_long_names=["5mC"],
+                          motif_sequences=["CG"], motif_offsets=[0], chunk_context=(50, 50), kmer_context_bases=(4, 4))
+    out = str(tmp_path / "w")
+    ds = CoreRemoraDataset(out, mode="w", metadata=md)
+    rows = {k: np.array(v[:n]) for k, v in src.arrays.items()}
+    half = n // 2
+    ds.write_batch({k: v[:half] for k, v in rows.items()})
+    for i in range(half, n):  # the rest chunk by chunk, as RemoraRead.iter_chunks would hand them over
+        sl = int(rows["sequence_lengths"][i])
+        ds.write_chunk(Chunk(signal=rows["signal"][i, 0], seq_w_context=rows["sequence"][i, : sl + 8],
+                             seq_to_sig_map=rows["sequence_to_signal_mapping"][i, : sl + 1], kmer_context_bases=(4, 4),
+                             chunk_sig_focus_idx=50, chunk_focus_base=0, read_focus_base=0, read_id="x",
+                             label=int(rows["labels"][i])))
+    ds.flush()
+    assert open(os.path.join(out, "metadata.jsn")).read() == open(os.path.join(ref_dir, "metadata.jsn")).read()
+    back = CoreRemoraDataset(out)
+    for k in ("signal", "sequence_lengths", "labels"):
+        np.testing.assert_array_equal(back.arrays[k][:n], rows[k])
+    for i in range(n):
+        sl = int(rows["sequence_lengths"][i])
+        np.testing.assert_array_equal(back.arrays["sequence"][i, : sl + 8], rows["sequence"][i, : sl + 8])
+        np.testing.assert_array_equal(back.arrays["sequence_to_signal_mapping"][i, : sl + 1],
+                                      rows["sequence_to_signal_mapping"][i, : sl + 1])
+    with pytest.raises(RemoraError, match="allocated"):
+        ds.write_batch({k: v[:20] for k, v in rows.items()})
+    with pytest.raises(RemoraError, match="Missing"):
+        ds.write_batch({"signal": rows["signal"][:1]})
+    with pytest.raises(RemoraError, match="mode"):
+        back.write_batch({k: v[:1] for k, v in rows.items()})
+    np.random.seed(5)
+    ds.shuffle(batch_size=37)
+    sig_after = np.array(ds.arrays["signal"][:n])
+    order = [int(np.flatnonzero((rows["signal"] == sig_after[i]).all(axis=(1, 2)))[0]) for i in range(n)]
+    assert sorted(order) == list(range(n)) and order != list(range(n))
+    np.testing.assert_array_equal(np.array(ds.arrays["labels"][:n]), rows["labels"][order])
+    np.testing.assert_array_equal(np.array(ds.arrays["sequence_lengths"][:n]), rows["sequence_lengths"][order])
+
+
+def test_batch_reads_widens_for_reads_with_longer_chunks():
+    """Reads whose widest chunk differs: the batch arrays grow and pad (sequence -1, mapping 0) without touching
+    rows already packed."""
+    import queue
+    from types import SimpleNamespace
+
+    from remora_amd.inference import PackedKmers, batch_reads
+
+    def chunks(n, w, fill):
+        return {"C": {"signal": np.full((n, 1, 10), fill, np.float32),
+                      "kmers": PackedKmers(np.full((n, w + 2), fill, np.int8), np.full((n, w + 1), fill, np.int16),
+                                           np.full(n, w, np.int16), (1, 1)),
+                      "read_focus_bases": np.arange(n) + 100 * fill}}
+
+    a, b = SimpleNamespace(read_id="a"), SimpleNamespace(read_id="b")
+    q = queue.Queue()
+    batch_reads(iter([[(a, chunks(3, 4, 1), None)], [(b, chunks(3, 9, 2), None)]]), q, 4,
+                [dict(can_base="C", chunk_len=10, kmer_len=3)])
+    first, second = q.get(), q.get()
+    assert q.get() is StopIteration
+    _, sig, km, pos, spans = first
+    assert sig.shape == (4, 1, 10) and km.sequence.shape == (4, 11) and km.mapping.shape == (4, 10)
+    assert (km.sequence[:3, :6] == 1).all() and (km.sequence[:3, 6:] == -1).all() and (km.mapping[:3, 5:] == 0).all()
+    assert (km.sequence[3] == 2).all() and list(km.lengths) == [4, 4, 4, 9]
+    assert [[r.read_id, s, e] for r, s, e, _ in spans] == [["a", 0, 3], ["b", 3, None]]
+    assert [[r.read_id, s, e] for r, s, e, _ in second[4]] == [["b", None, 2]] and len(second[2]) == 2
