@@ -259,11 +259,13 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);
-    const int abl = tune_int("RMR_LSTM_ABLATE", 0);  // timing experiments only (results are wrong)
+#ifdef RMR_TIMING_ABLATIONS  // experiment builds only (make CXXFLAGS+=-DRMR_TIMING_ABLATIONS): variants that skip work
+    const int abl = tune_int("RMR_LSTM_ABLATE", 0);
     if (abl == 1) hipLaunchKernelGGL((lstm_head_kernel<H, 1>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     else if (abl == 2) hipLaunchKernelGGL((lstm_head_kernel<H, 2>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     else if (abl == 3) hipLaunchKernelGGL((lstm_head_kernel<H, 3>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     else
+#endif
     hipLaunchKernelGGL((lstm_head_kernel<H, 0>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
