@@ -15,7 +15,8 @@ def main(argv=None):
     p = infer.add_parser("from_pod5_and_bam", help="Infer modified bases from POD5 + BAM on an MI355X")
     p.add_argument("pod5")
     p.add_argument("in_bam")
-    p.add_argument("--model", required=True, help="TorchScript model file (with meta.txt)")
+    p.add_argument("--model", required=True, action="append",
+                   help="TorchScript model file (with meta.txt); repeat for one model per canonical base")
     p.add_argument("--out-bam", required=True)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--num-reads", type=int, default=None)
@@ -29,7 +30,10 @@ def main(argv=None):
     from .model_util import load_torchscript_model
 
     try:
-        model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
+        loaded = [load_torchscript_model(m, device=args.device, eval_only=True, dtype=args.dtype) for m in args.model]
+        model, md = [x[0] for x in loaded], [x[1] for x in loaded]
+        if len({m["can_base"] for m in md}) != len(md):
+            raise RemoraError("Only one model per canonical base allowed.")
         stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
                                         reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored)
     except RemoraError as e:

@@ -111,7 +111,8 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
 
 def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
                             reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False, prefetch=2):
-    """`remora infer from_pod5_and_bam` for one model, basecall-anchored by default or reference-anchored
+    """`remora infer from_pod5_and_bam` for one model or a list of models (one per canonical base, with a list of
+    metadata dicts), basecall-anchored by default or reference-anchored
     (`--reference-anchored`: calls at reference positions, output records rewritten to `<len>M` + reference
     sequence) (src/remora/inference.py:462-641): every input alignment is written to `out_bam_path` with
     MM/ML tags from the model (records whose read cannot be called are written unchanged and
@@ -122,11 +123,17 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     from . import io as rio
 
+    md0 = model_metadata[0] if isinstance(model_metadata, (list, tuple)) else model_metadata
     if reverse_signal is None:
-        reverse_signal = bool(model_metadata.get("reverse_signal", False))
-    pa_scaling = model_metadata.get("pa_scaling")
+        reverse_signal = bool(md0.get("reverse_signal", False))
+    pa_scaling = md0.get("pa_scaling")
     stats = Counter()
     header = rio.read_bam_header_bytes(in_bam_path)
+
+    models = list(model) if isinstance(model, (list, tuple)) else [model]
+    mds = list(model_metadata) if isinstance(model_metadata, (list, tuple)) else [model_metadata]
+    if len(models) != len(mds):
+        raise RemoraError("one metadata dict per model is required")
 
     def flush(batch, writer):
         good = []
@@ -141,19 +148,34 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             writer.write(rio.record_with_mod_tags(io_read.record, None, None))
         if not good:
             return
-        results = call_reads_mods([rr for _, rr in good], model, model_metadata, return_mod_probs=True)
-        for (io_read, rr), (probs, _, pos) in zip(good, results):
-            if pos.size == 0:
-                stats[f"No {model_metadata['can_base']} mod calls"] += 1
+        # one pass per model (the reference runs one model per canonical base, src/remora/inference.py:277-316);
+        # every model works on its own copy of the reads because refinement rewrites their mappings
+        per_model = []
+        for mdl, md in zip(models, mds):
+            reads = [rr.copy() for _, rr in good] if len(models) > 1 else [rr for _, rr in good]
+            per_model.append(call_reads_mods(reads, mdl, md, return_mod_probs=True))
+        for k, (io_read, rr) in enumerate(good):
+            import array
+
+            mm_all, ml_all, errs = [], array.array("B"), []
+            for md, results in zip(mds, per_model):
+                probs, _, pos = results[k]
+                if pos.size == 0:
+                    errs.append(f"No {md['can_base']} mod calls")
+                    continue
+                mm, ml = format_mm_ml_tags(seq=io_read.ref_seq if ref_anchored else io_read.seq, poss=pos, probs=probs,
+                                           mod_bases=md["mod_bases"], can_base=md["can_base"])
+                mm_all.append(mm)
+                ml_all.extend(ml)
+            if not mm_all:
+                stats[",".join(sorted(errs))] += 1
                 writer.write(rio.record_with_mod_tags(io_read.record, None, None))
                 continue
-            mm, ml = format_mm_ml_tags(seq=io_read.ref_seq if ref_anchored else io_read.seq, poss=pos, probs=probs,
-                                       mod_bases=model_metadata["mod_bases"], can_base=model_metadata["can_base"])
             stats[None] += 1
             fwd = None
             if ref_anchored:
                 fwd = io_read.ref_seq if io_read.ref_reg.strand == "+" else rio.revcomp(io_read.ref_seq)
-            writer.write(rio.record_with_mod_tags(io_read.record, mm, ml, ref_anchored_seq=fwd))
+            writer.write(rio.record_with_mod_tags(io_read.record, "".join(mm_all), ml_all, ref_anchored_seq=fwd))
 
     def batches():
         batch = []

@@ -912,3 +912,30 @@ def test_fuzz_whole_read_pipeline_vs_oracle(torch_cuda, O, seed):
             assert np.abs(nn_out - want_out[order]).max() <= 1e-4, (seed, i, float(np.abs(nn_out - want_out[order]).max()))
         total += len(pos)
     assert total > 0
+
+
+def test_infer_with_two_models(torch_cuda, O, tmp_path):
+    """One model per canonical base (the reference's repeated --model): the 5mC CG model of the golden plus an
+    all-context adenine model; every record carries both MM entries in model order, each equal to what the
+    single-read API gives for that model alone (the C entry also equals the reference's)."""
+    from remora_amd import io as rio
+    from remora_amd import synth
+    from remora_amd.inference import call_read_mods, infer_from_pod5_and_bam
+    from remora_amd.model_util import load_model, model_from_state
+
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    pod5, bam = os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam")
+    g = golden("real_reads_can.npz")
+    model_c, md_c = load_model(_mint_pt(tmp_path, g, O), device=0)
+    md_a = dict(md_c, motifs=[("A", 0)], motif=("A", 0), can_base="A", mod_bases=["a"], mod_long_names=["6mA"],
+                chunk_context=(40, 60), chunk_len=100, kmer_context_bases=(2, 3), kmer_len=6)
+    model_a = model_from_state(synth.synth_state("conv_lstm", size=32, kmer_len=6, num_out=2, seed=9), md_a, device=0)
+    out = str(tmp_path / "two.bam")
+    stats = infer_from_pod5_and_bam(pod5, bam, [model_c, model_a], [md_c, md_a], out, reads_per_batch=6)
+    assert stats.get(None) == 14
+    reads = [r for r, _ in rio.iter_reads_from_pod5_and_bam(pod5, bam)]
+    for i, rec in enumerate(rio.iter_bam_records(out)):
+        mm = rec.get_tag("MM")
+        mm_a, ml_a = call_read_mods(reads[i].into_remora_read(False), model_a, md_a, return_mm_ml_tags=True)
+        assert mm == str(g[f"r{i}_mm"]) + mm_a
+        assert len(rec.get_tag("ML")) == g[f"r{i}_ml"].size + len(ml_a)
