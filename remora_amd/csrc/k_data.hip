@@ -202,17 +202,37 @@ int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_
 // (bit-exact with numpy); per chunk: focus clip, focus signal index, window with clipping,
 // the two binary searches on the read's seq_to_signal map.
 // ======================================================================================
-__global__ void normalise_kernel(const int16_t *dacs, const int64_t *sig_off, int64_t n_reads,
-                                 const double *shift, const double *scale, float *sig, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    // owning read: last r with sig_off[r] <= i (reads are concatenated; offsets ascend)
+// 8 consecutive samples per thread: one bisection of sig_off per thread (the read can only move forward inside
+// the 8), one 16-byte load and two 16-byte stores when the span is aligned and inside one read.
+__global__ __launch_bounds__(256) void normalise_kernel(const int16_t *__restrict__ dacs, const int64_t *__restrict__ sig_off,
+                                                        int64_t n_reads, const double *__restrict__ shift,
+                                                        const double *__restrict__ scale, float *__restrict__ sig, int64_t total) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i0 >= total) return;
+    // owning read of the first sample: last r with sig_off[r] <= i0 (reads are concatenated; offsets ascend)
     int64_t lo = 0, hi = n_reads;
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
-        if (sig_off[mid] <= i) lo = mid; else hi = mid;
+        if (sig_off[mid] <= i0) lo = mid; else hi = mid;
     }
-    sig[i] = (float)(((double)dacs[i] - shift[lo]) / scale[lo]);
+    int64_t r = lo, r_end = sig_off[r + 1];
+    double sh = shift[r], sc = scale[r];
+    const int nv = (int)min((int64_t)8, total - i0);
+    if (nv == 8 && i0 + 8 <= r_end) {  // aligned (i0 is a multiple of 8; the buffers are 16-byte aligned) and one read
+        const uint4 raw = *reinterpret_cast<const uint4 *>(dacs + i0);
+        const int16_t *d = reinterpret_cast<const int16_t *>(&raw);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)(((double)d[k] - sh) / sc);
+        reinterpret_cast<float4 *>(sig + i0)[0] = make_float4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<float4 *>(sig + i0)[1] = make_float4(o[4], o[5], o[6], o[7]);
+        return;
+    }
+    for (int k = 0; k < nv; ++k) {
+        const int64_t i = i0 + k;
+        while (i >= r_end) { ++r; r_end = sig_off[r + 1]; sh = shift[r]; sc = scale[r]; }  // empty reads are skipped too
+        sig[i] = (float)(((double)dacs[i] - sh) / sc);
+    }
 }
 
 struct GeoArgs {
@@ -271,7 +291,7 @@ int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const i
                     int *d_max_seq_len) {
     if (total_sig > 0) {
         ProfScope ps(e, K_NORMALISE);
-        hipLaunchKernelGGL(normalise_kernel, dim3((unsigned)((total_sig + 255) / 256)), dim3(256), 0,
+        hipLaunchKernelGGL(normalise_kernel, dim3((unsigned)((total_sig + 2047) / 2048)), dim3(256), 0,
                            e->stream, d.dacs, d.sig_off, d.n_reads, d.shift, d.scale, sig_out, total_sig);
         RMR_HIP(hipGetLastError());
     }
