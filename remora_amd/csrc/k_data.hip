@@ -406,39 +406,54 @@ __global__ __launch_bounds__(256) void count_kernel(const float *logits, int64_t
 }
 
 // ---- M3: motif scan ------------------------------------------------------------------------
-// One thread per base of the concatenated sequences; the read of a base is found by bisection of
-// seq_off (reads are thousands of bases, the table stays in L1/L2).  HBM traffic: 1 B read (+ the
-// motif window from cache) and 1 B written per base.
+// 16 consecutive bases per thread: one bisection of seq_off per thread (the read only moves forward inside the 16),
+// 16 flags leave as one 16-byte store when aligned.  HBM traffic: 1 B read (+ the motif window from cache) and 1 B
+// written per base.
 __global__ __launch_bounds__(256) void motif_kernel(const int8_t *__restrict__ seq, const int64_t *__restrict__ seq_off,
                                                     int n_reads, int64_t total, rmr_motif_set ms,
                                                     uint8_t *__restrict__ flags) {
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b >= total) return;
-    int lo = 0, hi = n_reads - 1;  // last read with seq_off[r] <= b
+    const int64_t b0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (b0 >= total) return;
+    int lo = 0, hi = n_reads - 1;  // last read with seq_off[r] <= b0
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (seq_off[mid] <= b) lo = mid; else hi = mid - 1;
+        if (seq_off[mid] <= b0) lo = mid; else hi = mid - 1;
     }
-    const int64_t rs = seq_off[lo], re = seq_off[lo + 1];
-    uint8_t hit = 0;
-    for (int m = 0; m < ms.n_motifs && !hit; ++m) {
-        const int64_t j = b - ms.focus_pos[m];  // start of the window whose focus base is b
-        if (j < rs || j + ms.len[m] > re) continue;
-        bool ok = true;
-        for (int k = 0; k < ms.len[m] && ok; ++k) {
-            const int c = seq[j + k];
-            ok = c >= 0 && ((ms.mask[m][k] >> c) & 1);
+    int r = lo;
+    int64_t rs = seq_off[r], re = seq_off[r + 1];
+    const int nv = (int)min((int64_t)16, total - b0);
+    uint8_t out[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        out[q] = 0;
+        if (q >= nv) continue;
+        const int64_t b = b0 + q;
+        while (b >= re) { ++r; rs = re; re = seq_off[r + 1]; }  // empty reads are skipped too
+        uint8_t hit = 0;
+        for (int m = 0; m < ms.n_motifs && !hit; ++m) {
+            const int64_t j = b - ms.focus_pos[m];  // start of the window whose focus base is b
+            if (j < rs || j + ms.len[m] > re) continue;
+            bool ok = true;
+            for (int k = 0; k < ms.len[m] && ok; ++k) {
+                const int c = seq[j + k];
+                ok = c >= 0 && ((ms.mask[m][k] >> c) & 1);
+            }
+            hit = ok;
         }
-        hit = ok;
+        out[q] = hit;
     }
-    flags[b] = hit;
+    if (nv == 16 && (reinterpret_cast<uintptr_t>(flags + b0) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(flags + b0) = *reinterpret_cast<const uint4 *>(out);
+    } else {
+        for (int q = 0; q < nv; ++q) flags[b0 + q] = out[q];
+    }
 }
 
 int launch_motif(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, int64_t total,
                  const rmr_motif_set &ms, uint8_t *flags) {
     if (total <= 0) return 0;
     ProfScope ps(e, K_MOTIF);
-    hipLaunchKernelGGL(motif_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, seq, seq_off,
+    hipLaunchKernelGGL(motif_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, e->stream, seq, seq_off,
                        n_reads, total, ms, flags);
     RMR_HIP(hipGetLastError());
     return 0;
