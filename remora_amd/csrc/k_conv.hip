@@ -167,7 +167,7 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     const int64_t iters = (n + cb - 1) / cb;
     const int threads = 64 * (c.oc / 16);
     // two 256-thread blocks per CU (or four 128-thread blocks for the 32-channel layer)
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 4) * (c.oc >= 64 ? 1 : 64 / c.oc);
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8) * (c.oc >= 64 ? 1 : 64 / c.oc);
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_mfma_kernel<IC, KW, STRIDE>;

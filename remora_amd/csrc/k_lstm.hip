@@ -255,7 +255,7 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
     a.a_ih2 = m->lstm.a_ih2; a.b2 = m->lstm.b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
     a.skew = tune_int("RMR_LSTM_SKEW", 0);
     const int64_t groups = (n + 15) / 16;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTM_BLOCKS_PER_CU", 2);
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTM_BLOCKS_PER_CU", 16);
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);
