@@ -259,7 +259,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
         const int Lp = (m->L + 3) & ~3;
         const size_t lds = (size_t)a.cb * (Lp + m->P1 * 4) * 4;
         const int64_t iters = (n + a.cb - 1) / a.cb;
-        int64_t grid = (int64_t)e->num_cus * 8;
+        int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SIG_BLOCKS_PER_CU", 8);
         if (grid > iters) grid = iters;
         ProfScope ps(e, K_FRONT_SIG, st, true);
         if (kw == 5) hipLaunchKernelGGL(front_sig_kernel<5>, dim3((unsigned)grid), dim3(256), lds, st, a);
@@ -298,7 +298,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
         attr_done[kw == 5 ? 0 : 1] = true;
     }
     const int64_t iters = (n + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * (direct ? 8 : 4);
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SEQ_BLOCKS_PER_CU", direct ? 8 : 4);
     if (grid > iters) grid = iters;
     ProfScope ps(e, K_FRONT_SEQ, st, true);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(32 * cb), lds, st, a);
