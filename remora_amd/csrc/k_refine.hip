@@ -6,22 +6,25 @@
 // validate_band (:686-737) + extract_levels (core.pyx:87-101) + seq_banded_dp
 // (core.pyx:403-473: forward steps :150-317 and traceback :119-148).
 //
-// Layout of the work: one 64-lane wave per read.
-//   * refine_band_kernel: bands in closed form from the base breakpoints, the two
-//     min-step recurrences as wave prefix/suffix scans, validation, row offsets, levels.
-//   * refine_dp_kernel: the forward pass walks the band COLUMN by column (signal sample by
-//     sample).  Cell (base i, sample s) only depends on cells of column < s, so all bases
-//     whose row contains s are evaluated together: lane (i mod 64) hosts base i, the value
-//     of row i-1 arrives with one DPP wave rotate, the history the dwell-penalty step needs
-//     (D previous-row scores, D squared residuals, D un-penalised scores) lives in
-//     registers.  Every cell executes exactly the reference's float32 operations in the
-//     reference's order (contraction is off in this file), so scores, traceback and paths
-//     are bit-identical.  The one non-local term of the dwell-penalty step
-//     (LARGE_SCORE + last score of the previous row) is speculated as "never wins" and
-//     verified when the previous row completes; reads that violate it, bands wider than 64
-//     rows per column, or bands that are not strictly increasing are re-run by
-//     refine_dp_rowwise_kernel, a row-by-row evaluation in global memory.
-//   * the traceback is a pointer chase over the int32 traceback band (L2 resident).
+// Layout of the work:
+//   * refine_band_kernel (one wave per read): bands in closed form from the base breakpoints, the two
+//     min-step recurrences as wave prefix/suffix scans, validation, row offsets, levels, widest column.
+//   * refine_dp_kernel<W, D, ALGO> (persistent waves, 64 / W reads per wave): the forward pass walks the band
+//     COLUMN by column (signal sample by sample).  Cell (base i, sample s) only depends on cells of column < s,
+//     so all bases whose row contains s are evaluated together: lane (i mod W) of a W-lane group hosts base i,
+//     the score of row i-1 arrives with one DPP rotate, the sample with a DPP row broadcast, the history the
+//     dwell-penalty step needs (D previous-row scores, D squared residuals, D un-penalised scores) lives in
+//     registers.  Every cell executes exactly the reference's float32 operations in the reference's order
+//     (contraction is off in this file), so scores, traceback and paths are bit-identical.  The one term of
+//     the dwell-penalty step that runs against the column order (LARGE_SCORE + last score of the previous
+//     row) is speculated as "never wins" and verified when the previous row completes; on a violation the
+//     now-known term is recorded in LDS and the wave replays from a checkpoint of its registers (one per 64
+//     samples, 8 kept).  Traceback values leave as packed int16, 16 bytes per row per 8 samples.
+//   * refine_dp_rowwise_kernel: row-by-row evaluation in global memory for what the column kernel does not
+//     take (more than 64 rows per column, rows wider than 32767 samples, rows that do not start at strictly
+//     increasing samples, penalty arrays longer than 6, replays out of checkpoint reach).
+//   * the traceback is a pointer chase over the traceback band; a lookup outside its row (possible only
+//     through "large score" cells) is mapped through the reference's flat band layout.
 #pragma clang fp contract(off)
 #include <algorithm>
 #include <cmath>
