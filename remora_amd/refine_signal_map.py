@@ -4,12 +4,14 @@ through `rmr_refine_signal_maps` (include/remora_hip.h; kernels in csrc/k_refine
 
 What runs where:
   * levels, bands, band adjustment/validation, signal normalisation, forward DP (Viterbi or
-    dwell penalty) and traceback: HIP kernels, one wave per read, any number of reads per call
-    (`SigMapRefiner.refine_reads` is the batched entry; `refine_sig_map` keeps the reference's
-    per-read signature).  No CPU fallback: without the library or a GPU the call raises.
-  * the scalar re-scaling estimators (`rough_rescale`, `rescale`: quantiles, a 2x2 least-squares
-    fit or Theil-Sen medians over <= 1000 points, float64) stay numpy on the host, as in the
-    reference; they are O(bases) bookkeeping around the DP."""
+    dwell penalty) and traceback: HIP kernels (`refine_maps` / `refine_reads` on host arrays,
+    `refine_device_reads` on a resident `DeviceReads` batch; `refine_sig_map` keeps the
+    reference's per-read signature).  No CPU fallback: without the library or a GPU the call raises.
+  * the scalar re-scaling estimators: `rough_rescale` / `rescale` are float64 numpy on the host as in
+    the reference (the quantiles through a one-sort replica of numpy's arithmetic);
+    `rough_rescale_device` does the per-base level lookup, the centre-sample gather and the two sorts
+    of a whole batch on the GPU and leaves only the 19-point line fit of every read on the host -
+    bit-identical results."""
 import ctypes
 import dataclasses
 from itertools import product
