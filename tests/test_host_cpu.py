@@ -650,3 +650,42 @@ def test_batch_reads_widens_for_reads_with_longer_chunks():
     assert (km.sequence[3] == 2).all() and list(km.lengths) == [4, 4, 4, 9]
     assert [[r.read_id, s, e] for r, s, e, _ in spans] == [["a", 0, 3], ["b", 3, None]]
     assert [[r.read_id, s, e] for r, s, e, _ in second[4]] == [["b", None, 2]] and len(second[2]) == 2
+
+
+def test_io_edge_cases_host():
+    """MD-less records, soft clips / insertions / deletions in get_reference_sequence, truncated BAM, POD5 index."""
+    import gzip
+    import tempfile
+
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    rec = rio.BamRecord("q", 0, 0, "chr", 10, 60, [(4, 2), (0, 3), (1, 2), (0, 2), (2, 3), (0, 1), (4, 1)], "TTACGGGTCAG"[:11],
+                        b"", [("MD", "2T2^ACG1")])
+    # columns: M3 = ACG ; I2 skipped (GG) ; M2 = TC ; D3 ; M1 = A  -> MD: 2 match, T mismatch, 2 match, ^ACG deletion, 1 match
+    assert rec.get_reference_sequence() == "ACtTCACGA"
+    assert rio.BamRecord("q", 0, 0, "chr", 0, 0, [(0, 3)], "ACG", b"", []).is_unmapped is False
+    with pytest.raises(ValueError):
+        rio.BamRecord("q", 0, 0, "chr", 0, 0, [(0, 3)], "ACG", b"", []).get_reference_sequence()
+    with pytest.raises(ValueError):
+        rio.BamRecord("q", 0, 0, "chr", 0, 0, [(0, 3)], "ACG", b"", [("MD", "5")]).get_reference_sequence()
+    assert rio.revcomp("ACGTN") == "NACGT"
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    with tempfile.TemporaryDirectory() as td:
+        raw = gzip.open(os.path.join(data, "can_mappings.bam"), "rb").read()
+        bad = os.path.join(td, "trunc.bam")
+        with gzip.open(bad, "wb") as fh:
+            fh.write(raw[: len(raw) // 2])
+        with pytest.raises(RemoraError, match="truncated"):
+            list(rio.iter_bam_records(bad))
+        notbam = os.path.join(td, "x.bam")
+        with gzip.open(notbam, "wb") as fh:
+            fh.write(b"nope")
+        with pytest.raises(RemoraError, match="not a BAM"):
+            list(rio.iter_bam_records(notbam))
+    f = rio.Pod5File(os.path.join(data, "can_reads.pod5"))
+    assert len(f) == len(f.read_ids) == 14 and f.read_ids[0] in f and "nope" not in f
+    r = f.get(f.read_ids[3])
+    assert r.signal.dtype == np.int16 and r.signal.size > 1000 and r.calibration_scale > 0
+    assert [x.read_id for x in rio.iter_pod5_reads(os.path.join(data, "can_reads.pod5"), read_ids=f.read_ids[:2])] == f.read_ids[:2]
+    assert rio._pack_seq("ACGTN") == bytes([0x12, 0x48, 0xF0])
