@@ -1,7 +1,9 @@
 """`python -m remora_amd infer from_pod5_and_bam POD5 BAM --model MODEL.pt --out-bam OUT.bam`
 — the sub-command of the reference CLI that sits on the hot path (src/remora/parsers.py:1294-1417,
 :1582-1612), same positional arguments and the same meaning of --model / --out-bam / --device /
---num-reads."""
+--num-reads; and `python -m remora_amd validate from_remora_dataset DATASET_DIR --model MODEL.pt`
+(:1800-1960): the stored chunks of an on-disk dataset through the model with the model's chunk / k-mer
+contexts, accuracy and confusion matrix against the stored labels."""
 import argparse
 import sys
 
@@ -24,7 +26,33 @@ def main(argv=None):
     p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")
     p.add_argument("--reference-anchored", action="store_true",
                    help="call at reference positions; output records become <len>M with the reference sequence")
+    val = sub.add_parser("validate").add_subparsers(dest="sub", required=True)
+    v = val.add_parser("from_remora_dataset", help="Validate a model on an on-disk Remora chunk dataset")
+    v.add_argument("remora_dataset_path")
+    v.add_argument("--model", required=True)
+    v.add_argument("--device", type=int, default=0)
+    v.add_argument("--batch-size", type=int, default=131072)
+    v.add_argument("--dtype", default=None)
     args = ap.parse_args(argv)
+    if args.cmd == "validate":
+        from .data_chunks import CoreRemoraDataset, validate_dataset
+        from .model_util import load_torchscript_model
+
+        try:
+            model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
+            ds = CoreRemoraDataset(args.remora_dataset_path, batch_size=args.batch_size,
+                                   override_metadata={"kmer_context_bases": md["kmer_context_bases"],
+                                                      "chunk_context": md["chunk_context"]})
+            res = validate_dataset(ds, model)
+        except RemoraError as e:
+            print(f"remora_amd: {e}", file=sys.stderr)
+            return 1
+        print(f"chunks {ds.size}\tacc {res['acc']:.6f}")
+        print("predicted label counts\t" + "\t".join(str(int(c)) for c in res["pred_counts"]))
+        print("confusion (rows = stored label, columns = call)")
+        for row in res["confusion"]:
+            print("\t".join(str(int(c)) for c in row))
+        return 0
 
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model

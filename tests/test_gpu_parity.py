@@ -939,3 +939,30 @@ def test_infer_with_two_models(torch_cuda, O, tmp_path):
         mm_a, ml_a = call_read_mods(reads[i].into_remora_read(False), model_a, md_a, return_mm_ml_tags=True)
         assert mm == str(g[f"r{i}_mm"]) + mm_a
         assert len(rec.get_tag("ML")) == g[f"r{i}_ml"].size + len(ml_a)
+
+
+def test_validate_from_remora_dataset_cli(torch_cuda, O, tmp_path):
+    """`python -m remora_amd validate from_remora_dataset` on the reference-written dataset with a model whose
+    contexts are smaller than the stored ones (so the trimming path runs): the printed tally equals
+    validate_dataset called directly."""
+    import subprocess
+    import sys
+
+    from remora_amd.data_chunks import CoreRemoraDataset, validate_dataset
+    from remora_amd.model_util import load_model
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ds_dir = os.path.join(root, "tests", "golden", "data", "core_dataset")
+    g = golden("call_read_mods_cg_5mc.npz")
+    pt = _mint_pt(tmp_path, g, O)
+    res = subprocess.run([sys.executable, "-m", "remora_amd", "validate", "from_remora_dataset", ds_dir, "--model", pt],
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    model, md = load_model(pt, device=0)
+    ds = CoreRemoraDataset(ds_dir, override_metadata={"kmer_context_bases": md["kmer_context_bases"],
+                                                      "chunk_context": md["chunk_context"]})
+    want = validate_dataset(ds, model)
+    lines = res.stdout.strip().splitlines()
+    assert lines[0].split("\t")[0] == f"chunks {ds.size}" and abs(float(lines[0].split("acc ")[1]) - want["acc"]) < 1e-6
+    assert [int(x) for x in lines[1].split("\t")[1:]] == [int(c) for c in want["pred_counts"]]
+    assert int(np.sum(want["confusion"])) == ds.size
