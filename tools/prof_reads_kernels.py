@@ -1,7 +1,7 @@
 """Per-kernel HIP-event times of one batched call_reads_mods (2048 reads x 5 kb, with a refiner)."""
 import ctypes, sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
-import numpy as np, torch
+import torch
 from remora_amd import synth, _lib as L
 from remora_amd.data_chunks import RemoraRead
 from remora_amd.engine import get_engine

@@ -1,6 +1,6 @@
 import sys, time, cProfile, pstats
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
-import numpy as np, torch
+import torch
 from remora_amd import synth
 from remora_amd.data_chunks import RemoraRead
 from remora_amd.inference import call_reads_mods

@@ -1,6 +1,6 @@
 """Repeated batched calls (refinement + motif scan + extraction + inference): device memory must stop shrinking."""
 import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
-import numpy as np, torch, gc
+import torch, gc
 from remora_amd import synth
 from remora_amd.data_chunks import RemoraRead
 from remora_amd.inference import call_reads_mods
