@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 
 #include "rmr_internal.h"
 
@@ -386,15 +387,18 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
         bool act = false, lknown = false;
         int my_i = 0, my_lo = 0, my_hi = 0, prev_hi = 0, fail = 0, ctb = 0;
         int my_toff = 0;  // traceback element offset of the row, minus (my_lo & ~7): sample s is stored at tbr[my_toff + s]
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // the row's traceback values of the current 8-sample group
+        uint32_t a[4] = {0, 0, 0, 0};  // the row's traceback values of the current 8-sample group (8 x int16)
         bool dirty = false;
-        float lvl = 0.f, cur = 0.f, L = INF, specmax = -INF;
-        float P[DD + 1], Q[DD], U[DD + 1];
-        int Ut[DD + 1];
+        float lvl = 0.f, cur = 0.f, L = INF;
+        // histories of the dwell-penalty step as rings of DD registers: slot (step mod DD) is rewritten every step, so
+        // nothing is shifted; "canonical" (at sub-block boundaries) = most recent value in slot DD-1
+        float Pa[DD], Qa[DD], Ua[DD];
+        int Uta[DD];
 #pragma unroll
-        for (int k = 0; k <= DD; ++k) { P[k] = 0.f; U[k] = 0.f; Ut[k] = 0; }
-#pragma unroll
-        for (int k = 0; k < DD; ++k) Q[k] = 0.f;
+        for (int k = 0; k < DD; ++k) { Pa[k] = 0.f; Qa[k] = 0.f; Ua[k] = 0.f; Uta[k] = 0; }
+        bool use_ovr = false;  // row 0: the spoofed previous row [0, inf, ...] replaces the neighbour's score
+        float ovr = INF;
+        uint32_t specbits = 0;  // max over the speculated cells of the row, as the bit pattern of a non-negative float
         int ib_next = 0, next_lo = IMAX, staged_hi = 0;  // uniform inside a lane group
         int dnext = 0, dnext_s = -1;                     // raw samples fetched ahead, and the sample they start at
         bool gfail = false;
@@ -430,12 +434,12 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                 int k = 0;
 #define CK_I(v) c[(k++) * 64] = (uint32_t)(v);
 #define CK_F(v) c[(k++) * 64] = __builtin_bit_cast(uint32_t, v);
-                CK_I((act ? 1 : 0) | (lknown ? 2 : 0))
+                CK_I((act ? 1 : 0) | (lknown ? 2 : 0) | (use_ovr ? 4 : 0))
                 CK_I(my_i) CK_I(my_lo) CK_I(my_hi) CK_I(prev_hi) CK_I(ctb) CK_I(ib_next) CK_I(next_lo)
                 CK_I(my_toff)
-                CK_F(lvl) CK_F(cur) CK_F(L) CK_F(specmax)
+                CK_F(lvl) CK_F(cur) CK_F(L) CK_I(specbits)
 #pragma unroll
-                for (int d = 1; d <= DD; ++d) { CK_F(P[d]) CK_F(U[d]) CK_I(Ut[d]) CK_F(Q[d - 1]) }
+                for (int d = 0; d < DD; ++d) { CK_F(Pa[d]) CK_F(Ua[d]) CK_I(Uta[d]) CK_F(Qa[d]) }
 #undef CK_I
 #undef CK_F
             }
@@ -453,9 +457,15 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                 dnext = (tq + SB < nsig) ? (int)dac[tq + SB] : 0;
                 dnext_s = sq + SB;
                 // one cell of every active row: sample sq + jj, whose value x is broadcast inside the lane group
-                auto step = [&](const int jj, const float x) {
+                // J >= 0: step number inside the sub-block as a compile-time constant (the ring slots and the traceback
+                // slot are then immediates); J < 0: run-time step number, the rings are brought back to canonical after
+                // every step
+                auto step = [&](auto jc, const int jj, const float x) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr bool ST = J >= 0;
+                    constexpr int r = ST ? (J % DD) : 0;  // slot written in this step
                     const int s = sq + jj;
-                    float pv = rot1<W>(cur);
+                    const float pv = rot1<W>(cur);
                     if (s == next_lo) {  // a new row starts (rows start at strictly increasing samples)
                         const int i = ib_next;
                         const int4 pr = ring[grp][i & (RN - 1)];
@@ -465,11 +475,13 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                             if (act && s < my_hi) fail = 1;                    // more than W rows in one column
                             if (i > 0 && (pr.x > ph || pr.y <= ph)) fail = 1;  // gap to / nested in the previous row
                             if (dirty) {  // the row this lane hosted before ended inside the current group: flush it
-                                for (int t = s & 7; t < 8; ++t) {
-                                    a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
-                                    a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 >>= 16;
+                                if (!ST) {
+                                    for (int t = s & 7; t < 8; ++t) {
+                                        a[0] = __builtin_amdgcn_alignbit(a[1], a[0], 16); a[1] = __builtin_amdgcn_alignbit(a[2], a[1], 16);
+                                        a[2] = __builtin_amdgcn_alignbit(a[3], a[2], 16); a[3] >>= 16;
+                                    }
                                 }
-                                *reinterpret_cast<uint4 *>(tbr + ((int64_t)my_toff + (s & ~7))) = make_uint4(a0, a1, a2, a3);
+                                *reinterpret_cast<uint4 *>(tbr + ((int64_t)my_toff + (s & ~7))) = make_uint4(a[0], a[1], a[2], a[3]);
                                 dirty = false;
                             }
                             act = true; my_i = i;
@@ -477,13 +489,13 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                             my_toff = pr.w - (pr.x & ~7);
                             prev_hi = ph;
                             lknown = (i == 0);
+                            use_ovr = (i == 0);
+                            ovr = 0.f;
                             L = (i == 0 && pr.y == 1) ? kLargeScore : INF;
-                            specmax = -INF;
+                            specbits = 0;
                             if (ALGO == 0) { cur = INF; ctb = -1; }  // the first cell can only be a move
 #pragma unroll
-                            for (int k = 1; k <= DD; ++k) { P[k] = INF; U[k] = INF; Ut[k] = -1; }
-#pragma unroll
-                            for (int k = 0; k < DD; ++k) Q[k] = 0.f;
+                            for (int k = 0; k < DD; ++k) { Pa[k] = INF; Ua[k] = INF; Uta[k] = -1; Qa[k] = 0.f; }
                             if (ALGO == 1 && have_known && i > 0 && Lrow[grp][i & (kLT - 1)] == i) {  // learnt in an earlier pass
                                 lknown = true;
                                 L = Ltab[grp][i & (kLT - 1)];
@@ -494,11 +506,12 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                         if (next_lo <= s) fail = 1;  // rows must start at strictly increasing samples
                     }
                     if (act && s < my_hi) {
-                        if (my_i == 0) pv = (s == 0) ? 0.f : INF;  // spoofed previous row [0, inf, ...] (core.pyx:360-362)
                         // score of row i-1 at sample s-1, +inf once that row has ended: a move from it, and every
                         // penalised candidate built on it, then loses all '<' tests exactly as the reference's
-                        // index checks skip them
-                        const float pvm = (s <= prev_hi) ? pv : INF;
+                        // index checks skip them.  Row 0 sees the spoofed row [0, inf, ...] (core.pyx:360-362).
+                        float pvm = (s <= prev_hi) ? pv : INF;
+                        pvm = use_ovr ? ovr : pvm;
+                        ovr = INF;
                         const float dlt = lvl - x;
                         const float qq = dlt * dlt;
                         float nc;
@@ -510,75 +523,97 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                             nc = c ? mv : sy;
                             nt = c ? 0 : ctb + 1;
                         } else {
-                            // un-penalised Viterbi row (core.pyx:183-190); U[1] = +inf, Ut[1] = -1 at the row start
-                            const float mv = pvm + qq, sy = U[1] + qq;
+                            constexpr int sU1 = ((r - 1) % DD + DD) % DD;  // un-penalised score one sample back
+                            // un-penalised Viterbi row (core.pyx:183-190); +inf / -1 at the row start
+                            const float mv = pvm + qq, sy = Ua[sU1] + qq;
                             const bool c = mv < sy;
                             const float un = c ? mv : sy;
-                            const int ut = c ? 0 : Ut[1] + 1;
+                            const int ut = c ? 0 : Uta[sU1] + 1;
                             if (!lknown && s == prev_hi) {  // the previous row just completed: pv is its last score
                                 L = kLargeScore + pv;
                                 lknown = true;
-                                if (!(specmax < L)) {  // a cell of this row should have taken L: replay from the row start
+                                if (!(specbits < __builtin_bit_cast(uint32_t, L))) {  // a cell of this row should have taken L
                                     viol = min(viol, my_lo);
                                     Ltab[grp][my_i & (kLT - 1)] = L;
                                     Lrow[grp][my_i & (kLT - 1)] = my_i;
                                 }
                             }
-                            // banded_forward_dwell_penalty_step (core.pyx:192-253).  P[k] = row i-1 at sample s-k
-                            // (+inf before this row started or after row i-1 ended), Q[k] = residual at s-k
-                            // (0 before the row started), U[k] = un-penalised score at s-k (+inf before the row
+                            // banded_forward_dwell_penalty_step (core.pyx:192-253).  P(k) = row i-1 at sample s-k
+                            // (+inf before this row started or after row i-1 ended), Q(k) = residual at s-k
+                            // (0 before the row started), U(k) = un-penalised score at s-k (+inf before the row
                             // started): candidates that the reference does not evaluate are +inf here
-#pragma unroll
-                            for (int k = DD; k >= 2; --k) P[k] = P[k - 1];
-                            P[1] = pvm;
-#pragma unroll
-                            for (int k = DD - 1; k >= 1; --k) Q[k] = Q[k - 1];
-                            Q[0] = qq;
+                            Pa[r] = pvm;
+                            Qa[r] = qq;
                             float best = lknown ? L : INF;
                             int bt = -1;
                             float run = 0.f;
 #pragma unroll
                             for (int di = 0; di < DD; ++di) {
-                                run += Q[di];
-                                const float ps = (P[di + 1] + run) + sdp[di];
+                                const int sl = ((r - di) % DD + DD) % DD;  // P(di + 1) and Q(di) share the slot
+                                run += Qa[sl];
+                                const float ps = (Pa[sl] + run) + sdp[di];
                                 const bool cc = ps < best;
                                 best = cc ? ps : best;
                                 bt = cc ? di : bt;
                             }
                             {
-                                const float ps = U[DD] + run;
+                                const float ps = Ua[r] + run;  // U(DD): the slot about to be rewritten
                                 const bool cc = ps < best;
                                 best = cc ? ps : best;
-                                bt = cc ? Ut[DD] + DD : bt;
+                                bt = cc ? Uta[r] + DD : bt;
                             }
                             const bool tail = (s - prev_hi >= DD);  // beyond the reach of row i-1: stay (core.pyx:201-209)
-                            if (!lknown && !tail) specmax = fmaxf(specmax, best);
+                            const uint32_t sp = (!lknown && !tail) ? __builtin_bit_cast(uint32_t, best) : 0u;
+                            specbits = max(specbits, sp);
                             nc = tail ? cur + qq : best;
                             nt = tail ? ctb + 1 : bt;
+                            Ua[r] = un; Uta[r] = ut;
+                            if (!ST && DD > 1) {  // back to canonical: most recent value in slot DD-1
+                                const float p0 = Pa[0], q0 = Qa[0], u0 = Ua[0];
+                                const int t0 = Uta[0];
 #pragma unroll
-                            for (int k = DD; k >= 2; --k) { U[k] = U[k - 1]; Ut[k] = Ut[k - 1]; }
-                            U[1] = un; Ut[1] = ut;
+                                for (int k = 0; k + 1 < DD; ++k) { Pa[k] = Pa[k + 1]; Qa[k] = Qa[k + 1]; Ua[k] = Ua[k + 1]; Uta[k] = Uta[k + 1]; }
+                                Pa[DD - 1] = p0; Qa[DD - 1] = q0; Ua[DD - 1] = u0; Uta[DD - 1] = t0;
+                            }
                         }
                         cur = nc; ctb = nt;
                         dirty = true;
                     }
-                    // traceback values travel through a 128-bit shift register and leave as one 16-byte store per
-                    // row every 8 samples (a 4-byte store per cell makes the kernel store-issue bound)
-                    a0 = __builtin_amdgcn_alignbit(a1, a0, 16); a1 = __builtin_amdgcn_alignbit(a2, a1, 16);
-                    a2 = __builtin_amdgcn_alignbit(a3, a2, 16); a3 = __builtin_amdgcn_alignbit((uint32_t)ctb, a3, 16);
+                    // traceback values leave as one 16-byte store per row every 8 samples (a 4-byte store per cell makes
+                    // the kernel store-issue bound): written into their 16-bit slot when the step number is an immediate,
+                    // through a 128-bit shift register otherwise
+                    if (ST) {
+                        constexpr int sl = (J >= 0 ? J : 0) & 7;
+                        if (sl & 1) a[sl >> 1] |= (uint32_t)ctb << 16;
+                        else a[sl >> 1] = (uint32_t)ctb & 0xffffu;
+                    } else {
+                        a[0] = __builtin_amdgcn_alignbit(a[1], a[0], 16); a[1] = __builtin_amdgcn_alignbit(a[2], a[1], 16);
+                        a[2] = __builtin_amdgcn_alignbit(a[3], a[2], 16); a[3] = __builtin_amdgcn_alignbit((uint32_t)ctb, a[3], 16);
+                    }
                     if ((jj & 7) == 7) {
-                        if (dirty) *reinterpret_cast<uint4 *>(tbr + ((int64_t)my_toff + (s & ~7))) = make_uint4(a0, a1, a2, a3);
+                        if (dirty) *reinterpret_cast<uint4 *>(tbr + ((int64_t)my_toff + (s & ~7))) = make_uint4(a[0], a[1], a[2], a[3]);
                         dirty = false;
                     }
                 };
                 if constexpr (W == 64) {
-                    for (int jj = 0; jj < 64; ++jj) step(jj, readlane_f(sv, jj));
+                    for (int jj = 0; jj < 64; ++jj) step(std::integral_constant<int, -1>{}, jj, readlane_f(sv, jj));
                 } else {
-                    // 16 steps with the broadcast lane as an immediate (DPP row_newbcast)
-#define RMR_STEP16(J) step(J, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x150 + J, 0xf, 0xf, false)));
+                    // 16 steps with the broadcast lane and the ring slots as immediates (DPP row_newbcast)
+#define RMR_STEP16(J) step(std::integral_constant<int, J>{}, J, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x150 + J, 0xf, 0xf, false)));
                     RMR_STEP16(0) RMR_STEP16(1) RMR_STEP16(2) RMR_STEP16(3) RMR_STEP16(4) RMR_STEP16(5) RMR_STEP16(6) RMR_STEP16(7)
                     RMR_STEP16(8) RMR_STEP16(9) RMR_STEP16(10) RMR_STEP16(11) RMR_STEP16(12) RMR_STEP16(13) RMR_STEP16(14) RMR_STEP16(15)
 #undef RMR_STEP16
+                    if (ALGO == 1 && 16 % DD != 0) {  // 16 steps later the rings are rotated by 16 mod DD: back to canonical
+                        float pn[DD], qn[DD], un_[DD];
+                        int tn[DD];
+#pragma unroll
+                        for (int m = 0; m < DD; ++m) {
+                            const int src = ((15 - m) % DD + DD) % DD;
+                            pn[DD - 1 - m] = Pa[src]; qn[DD - 1 - m] = Qa[src]; un_[DD - 1 - m] = Ua[src]; tn[DD - 1 - m] = Uta[src];
+                        }
+#pragma unroll
+                        for (int k = 0; k < DD; ++k) { Pa[k] = pn[k]; Qa[k] = qn[k]; Ua[k] = un_[k]; Uta[k] = tn[k]; }
+                    }
                 }
             }
             // a lane group that hit an unsupported band shape stops here (its read goes to the row-wise kernel)
@@ -618,12 +653,13 @@ __global__ __launch_bounds__(64) void refine_dp_kernel(RefineReads a, RefineScra
                     CK_I(fl)
                     CK_I(my_i) CK_I(my_lo) CK_I(my_hi) CK_I(prev_hi) CK_I(ctb) CK_I(ib_next) CK_I(next_lo)
                     CK_I(my_toff)
-                    CK_F(lvl) CK_F(cur) CK_F(L) CK_F(specmax)
+                    CK_F(lvl) CK_F(cur) CK_F(L)
+                    { int sb_; CK_I(sb_) specbits = (uint32_t)sb_; }
 #pragma unroll
-                    for (int d = 1; d <= DD; ++d) { CK_F(P[d]) CK_F(U[d]) CK_I(Ut[d]) CK_F(Q[d - 1]) }
+                    for (int d = 0; d < DD; ++d) { CK_F(Pa[d]) CK_F(Ua[d]) CK_I(Uta[d]) CK_F(Qa[d]) }
 #undef CK_I
 #undef CK_F
-                    act = (fl & 1) != 0; lknown = (fl & 2) != 0;
+                    act = (fl & 1) != 0; lknown = (fl & 2) != 0; use_ovr = (fl & 4) != 0; ovr = INF;
                     if (!gvalid) { act = false; next_lo = IMAX; }
                     staged_hi = max(ib_next - 1, 0) / W * W;  // re-stage the row parameters from there
                     dnext_s = -1;
