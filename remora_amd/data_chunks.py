@@ -128,6 +128,19 @@ class ChunkArrays:
         return iter(self.as_reference_batch())
 
 
+_PINNED = {}
+
+
+def _pinned(key, dt, count):
+    """Grow-only pinned host staging buffers, one per array kind (pinned allocation is too slow to do per batch)."""
+    torch = _torch()
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < count:
+        buf = torch.empty(max(int(count * 1.25), 1 << 16), dtype=getattr(torch, np.dtype(dt).name), pin_memory=True)
+        _PINNED[key] = buf
+    return buf
+
+
 class DeviceReads:
     """The arrays of a batch of reads, concatenated and resident in HBM (the rmr_reads layout of
     include/remora_hip.h) - uploaded once and shared by the motif scan, the signal-mapping refinement
@@ -146,12 +159,27 @@ class DeviceReads:
             self.seq_off[i + 1] = self.seq_off[i] + r.int_seq.size
             if r.seq_to_sig_map.size != r.int_seq.size + 1:
                 raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
-        cat = lambda arrs, dt: (np.concatenate([np.asarray(a).ravel() for a in arrs]).astype(dt, copy=False)
-                                if arrs else np.zeros(0, dt))
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self.dacs = to_dev(cat([r.dacs for r in reads], np.int16))
-        self.s2s = to_dev(cat([r.seq_to_sig_map for r in reads], np.int64))
-        self.iseq = to_dev(cat([r.int_seq for r in reads], np.int8))
+
+        def cat_to_dev(arrs, dt, total, key):
+            """Concatenate straight into a cached pinned staging buffer (no intermediate array, no bounce copy in the
+            driver) and upload from there."""
+            if total == 0:
+                return torch.zeros(0, dtype=getattr(torch, np.dtype(dt).name), device=dev)
+            buf = _pinned(key, dt, total)
+            host = buf.numpy()[:total]
+            o = 0
+            for a in arrs:
+                a = np.asarray(a).ravel()
+                host[o : o + a.size] = a  # casts to `dt` on the fly
+                o += a.size
+            out = buf[:total].to(dev, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()  # the staging buffer is reused by the next batch
+            return out
+
+        self.dacs = cat_to_dev([r.dacs for r in reads], np.int16, int(self.sig_off[-1]), "dacs")
+        self.s2s = cat_to_dev([r.seq_to_sig_map for r in reads], np.int64, int(self.seq_off[-1]) + nr, "s2s")
+        self.iseq = cat_to_dev([r.int_seq for r in reads], np.int8, int(self.seq_off[-1]), "iseq")
         self.d_sig_off, self.d_seq_off = to_dev(self.sig_off), to_dev(self.seq_off)
         self.set_scaling([float(r.shift) for r in reads], [float(r.scale) for r in reads])
 
