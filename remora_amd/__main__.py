@@ -1,13 +1,141 @@
 """`python -m remora_amd infer from_pod5_and_bam POD5 BAM --model MODEL.pt --out-bam OUT.bam`
 — the sub-command of the reference CLI that sits on the hot path (src/remora/parsers.py:1294-1417,
 :1582-1612), same positional arguments and the same meaning of --model / --out-bam / --device /
---num-reads; and `python -m remora_amd validate from_remora_dataset DATASET_DIR --model MODEL.pt`
-(:1800-1960): the stored chunks of an on-disk dataset through the model with the model's chunk / k-mer
-contexts, accuracy and confusion matrix against the stored labels."""
+--num-reads; `python -m remora_amd validate from_remora_dataset DATASET --model MODEL.pt` (:1800-1960):
+the stored chunks of an on-disk dataset (directory or config) through the model with the model's chunk /
+k-mer contexts, the reference's validation summary line against the stored labels; and `python -m remora_amd
+dataset prepare | inspect | make_config` (:64-458), the ETL and bookkeeping around the on-disk chunk format."""
 import argparse
 import sys
 
-from . import RemoraError
+from . import RemoraError, constants
+
+
+def _validate(args):
+    """src/remora/parsers.py:1890-1960: the dataset is loaded with the model's contexts and without extra arrays,
+    every chunk goes through the model, one summary line in the reference's format."""
+    import torch
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+    from .model_util import load_torchscript_model
+    from .validate import ValidationLogger
+
+    model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
+    over = {"extra_arrays": {}, "kmer_context_bases": md["kmer_context_bases"], "chunk_context": md["chunk_context"]}
+    paths, props, hashes = load_dataset(args.remora_dataset_path)
+    dataset = RemoraDataset([CoreRemoraDataset(p, override_metadata=dict(over), infinite_iter=False,
+                                               do_check_super_batches=True) for p in paths],
+                            props, hashes, batch_size=args.batch_size)
+    out_fp = sys.stdout if args.out_file is None else open(args.out_file, "w", buffering=1)
+    full_fp = None if args.full_results_filename is None else open(args.full_results_filename, "w", buffering=1)
+    try:
+        ValidationLogger(out_fp, full_fp).validate_model(model, md["mod_bases"], torch.nn.CrossEntropyLoss(), dataset,
+                                                         args.pct_filt / 100)
+    finally:
+        for fp in (out_fp, full_fp):
+            if fp not in (None, sys.stdout):
+                fp.close()
+    return 0
+
+
+def _dataset_prepare(args):
+    """src/remora/parsers.py:281-337."""
+    from .engine import get_engine
+    from .io import parse_bed
+    from .prepare_train_data import extract_chunk_dataset
+    from .refine_signal_map import SigMapRefiner
+    from .util import Motif, prepare_out_dir
+
+    if args.mod_base is None and not args.mod_base_control:
+        raise RemoraError("Must specify either --mod-base or --mod-base-control")
+    prepare_out_dir(args.output_path, args.overwrite)
+    refiner = SigMapRefiner(kmer_model_filename=args.refine_kmer_level_table, do_rough_rescale=args.refine_rough_rescale,
+                            scale_iters=args.refine_scale_iters, algo=args.refine_algo,
+                            half_bandwidth=args.refine_half_bandwidth, sd_params=args.refine_short_dwell_parameters,
+                            do_fix_guage=True, rough_rescale_method=args.rough_rescale_method)
+    if not refiner.is_valid:
+        raise RemoraError("Invalid signal mapping refiner settings.")
+    dataset, errs = extract_chunk_dataset(
+        bam_path=args.bam, pod5_path=args.pod5, out_path=args.output_path, mod_base=args.mod_base,
+        mod_base_control=args.mod_base_control, motifs=[Motif(*m) for m in args.motif],
+        focus_ref_pos=None if args.focus_reference_positions is None else parse_bed(args.focus_reference_positions),
+        chunk_context=args.chunk_context, min_samps_per_base=args.min_samples_per_base,
+        max_chunks_per_read=args.max_chunks_per_read, pa_scaling=None, sig_map_refiner=refiner,
+        kmer_context_bases=args.kmer_context_bases, base_start_justify=args.base_start_justify, offset=args.offset,
+        num_reads=args.num_reads, basecall_anchor=args.basecall_anchor, rev_sig=args.reverse_signal,
+        save_every=args.save_every, skip_shuffle=args.skip_shuffle, reads_per_batch=args.reads_per_batch,
+        engine=get_engine(args.device))
+    if dataset is None:
+        print("no reads with signal and alignment")
+        return 0
+    for reason, cnt in sorted(errs.items(), key=lambda kv: -kv[1]):
+        print(f"{cnt:>7,} : {reason}")
+    print(f"Extracted {dataset.size:,} chunks -> {args.output_path}")
+    print(f"Label distribution: {dataset.label_summary}")
+    return 0
+
+
+def _dataset_inspect(args):
+    """src/remora/parsers.py:359-376."""
+    import json
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+
+    paths, props, hashes = load_dataset(args.remora_dataset_path)
+    dataset = RemoraDataset([CoreRemoraDataset(p, do_check_super_batches=True) for p in paths], props, hashes)
+    print(f"Dataset summary:\n{dataset.summary}")
+    if args.out_path is not None:
+        with open(args.out_path, "w") as fh:
+            json.dump(dataset.get_config(), fh)
+    return 0
+
+
+def _dataset_make_config(args):
+    """src/remora/parsers.py:414-458: default weights are the dataset sizes (chunks drawn uniformly overall)."""
+    import json
+
+    import numpy as np
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+
+    if args.dataset_weights is not None:
+        if len(args.dataset_weights) != len(args.dataset_paths):
+            raise RemoraError("Weights must be same length as input datasets.")
+        if any(w <= 0 for w in args.dataset_weights):
+            raise RemoraError("Weights must be positive.")
+    core_paths, core_weights, core_hashes = [], [], []
+    for i, ds_path in enumerate(args.dataset_paths):
+        paths, weights, hashes = load_dataset(ds_path)
+        core_paths.extend(paths)
+        scale = sum(CoreRemoraDataset(p).size for p in paths) if args.dataset_weights is None else args.dataset_weights[i]
+        core_weights.extend(weights * scale)
+        if hashes is None or core_hashes is None:
+            core_hashes = None
+        else:
+            core_hashes.extend(hashes)
+    core_weights = np.array(core_weights)
+    dataset = RemoraDataset([CoreRemoraDataset(p) for p in core_paths], core_weights / core_weights.sum(), core_hashes)
+    with open(args.out_path, "w") as fh:
+        json.dump(dataset.get_config(), fh)
+    print(dataset.summary)
+    return 0
+
+
+def _infer(args):
+    from .inference import infer_from_pod5_and_bam
+    from .model_util import load_torchscript_model
+
+    loaded = [load_torchscript_model(m, device=args.device, eval_only=True, dtype=args.dtype) for m in args.model]
+    model, md = [x[0] for x in loaded], [x[1] for x in loaded]
+    if len({m["can_base"] for m in md}) != len(md):
+        raise RemoraError("Only one model per canonical base allowed.")
+    stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
+                                    reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored)
+    ok = stats.pop(None, 0)
+    print(f"called {ok} reads -> {args.out_bam}")
+    for reason, cnt in sorted(stats.items(), key=lambda kv: -kv[1]):
+        print(f"{cnt:>7} : {reason}")
+    return 0
 
 
 def main(argv=None):
@@ -26,52 +154,67 @@ def main(argv=None):
     p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")
     p.add_argument("--reference-anchored", action="store_true",
                    help="call at reference positions; output records become <len>M with the reference sequence")
+    p.set_defaults(func=_infer)
+
     val = sub.add_parser("validate").add_subparsers(dest="sub", required=True)
-    v = val.add_parser("from_remora_dataset", help="Validate a model on an on-disk Remora chunk dataset")
+    v = val.add_parser("from_remora_dataset", help="Validate a model on an on-disk Remora dataset (directory or config)")
     v.add_argument("remora_dataset_path")
     v.add_argument("--model", required=True)
+    v.add_argument("--out-file", help="validation summary (default stdout)")
+    v.add_argument("--full-results-filename", help="per-chunk label, call and probabilities (TSV)")
+    v.add_argument("--pct-filt", type=float, default=10.0)
     v.add_argument("--device", type=int, default=0)
     v.add_argument("--batch-size", type=int, default=131072)
     v.add_argument("--dtype", default=None)
+    v.set_defaults(func=_validate)
+
+    dset = sub.add_parser("dataset").add_subparsers(dest="sub", required=True)
+    d = dset.add_parser("prepare", help="POD5 + BAM -> labelled chunk dataset directory")
+    d.add_argument("pod5")
+    d.add_argument("bam")
+    d.add_argument("--output-path", default="remora_training_dataset")
+    d.add_argument("--overwrite", action="store_true")
+    d.add_argument("--motif", nargs=2, action="append", metavar=("MOTIF", "FOCUS_POSITION"), required=True)
+    d.add_argument("--focus-reference-positions")
+    d.add_argument("--chunk-context", default=list(constants.DEFAULT_CHUNK_CONTEXT), type=int, nargs=2)
+    d.add_argument("--min-samples-per-base", type=int, default=constants.DEFAULT_MIN_SAMPLES_PER_BASE)
+    d.add_argument("--kmer-context-bases", nargs=2, default=list(constants.DEFAULT_KMER_CONTEXT_BASES), type=int)
+    d.add_argument("--max-chunks-per-read", type=int, default=15)
+    d.add_argument("--base-start-justify", action="store_true")
+    d.add_argument("--offset", default=0, type=int)
+    d.add_argument("--num-reads", type=int)
+    d.add_argument("--basecall-anchor", action="store_true")
+    d.add_argument("--reverse-signal", action="store_true")
+    d.add_argument("--save-every", default=100_000, type=int)
+    d.add_argument("--skip-shuffle", action="store_true")
+    d.add_argument("--refine-kmer-level-table")
+    d.add_argument("--refine-rough-rescale", action="store_true")
+    d.add_argument("--refine-scale-iters", default=-1, type=int)
+    d.add_argument("--refine-half-bandwidth", default=5, type=int)
+    d.add_argument("--refine-algo", default="dwell_penalty", choices=("Viterbi", "dwell_penalty"))
+    d.add_argument("--refine-short-dwell-parameters", default=[4, 3, 0.5], type=float, nargs=3)
+    d.add_argument("--rough-rescale-method", default="least_squares", choices=("least_squares", "theil_sen"))
+    d.add_argument("--mod-base", nargs=2, metavar=("SHORT_NAME", "LONG_NAME"))
+    d.add_argument("--mod-base-control", action="store_true")
+    d.add_argument("--reads-per-batch", type=int, default=256)
+    d.add_argument("--device", type=int, default=0)
+    d.set_defaults(func=_dataset_prepare)
+    di = dset.add_parser("inspect", help="Summary of a dataset directory or config")
+    di.add_argument("remora_dataset_path")
+    di.add_argument("--out-path", help="write the expanded config (with hashes) here")
+    di.set_defaults(func=_dataset_inspect)
+    dm = dset.add_parser("make_config", help="Config drawing from several datasets at fixed proportions (no data copied)")
+    dm.add_argument("out_path")
+    dm.add_argument("dataset_paths", nargs="+")
+    dm.add_argument("--dataset-weights", type=float, nargs="+")
+    dm.set_defaults(func=_dataset_make_config)
+
     args = ap.parse_args(argv)
-    if args.cmd == "validate":
-        from .data_chunks import CoreRemoraDataset, validate_dataset
-        from .model_util import load_torchscript_model
-
-        try:
-            model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
-            ds = CoreRemoraDataset(args.remora_dataset_path, batch_size=args.batch_size,
-                                   override_metadata={"kmer_context_bases": md["kmer_context_bases"],
-                                                      "chunk_context": md["chunk_context"]})
-            res = validate_dataset(ds, model)
-        except RemoraError as e:
-            print(f"remora_amd: {e}", file=sys.stderr)
-            return 1
-        print(f"chunks {ds.size}\tacc {res['acc']:.6f}")
-        print("predicted label counts\t" + "\t".join(str(int(c)) for c in res["pred_counts"]))
-        print("confusion (rows = stored label, columns = call)")
-        for row in res["confusion"]:
-            print("\t".join(str(int(c)) for c in row))
-        return 0
-
-    from .inference import infer_from_pod5_and_bam
-    from .model_util import load_torchscript_model
-
     try:
-        loaded = [load_torchscript_model(m, device=args.device, eval_only=True, dtype=args.dtype) for m in args.model]
-        model, md = [x[0] for x in loaded], [x[1] for x in loaded]
-        if len({m["can_base"] for m in md}) != len(md):
-            raise RemoraError("Only one model per canonical base allowed.")
-        stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
-                                        reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored)
+        return args.func(args)
     except RemoraError as e:
         print(f"remora_amd: {e}", file=sys.stderr)
         return 1
-    ok = stats.pop(None, 0)
-    print(f"called {ok} reads -> {args.out_bam}")
-    for reason, cnt in sorted(stats.items(), key=lambda kv: -kv[1]):
-        print(f"{cnt:>7} : {reason}")
-    return 0
 
 
 if __name__ == "__main__":

@@ -456,117 +456,133 @@ class RemoraRead:
 # applied per batch exactly as the reference does (trim_sb_kmer_context_bases :1512-1534,
 # trim_sb_chunk_context :1536-1576 -> the T1 kernel).
 # =======================================================================================
+import hashlib
 import json
 import os
+from copy import deepcopy
+from glob import glob
+
+from . import constants
 
 DATASET_VERSION = 3
 
 
-def dataset_metadata(allocate_size, max_seq_len, mod_bases, mod_long_names, motif_sequences, motif_offsets,
-                     chunk_context=(50, 50), kmer_context_bases=(4, 4), base_start_justify=False, offset=0,
-                     reverse_signal=False, pa_scaling=None, extra_arrays=None, sig_map_refiner=None,
-                     modified_base_labels=True, rough_rescale_method="least_squares"):
-    """The JSON-able dict the reference's DatasetMetadata.write stores in metadata.jsn
-    (src/remora/data_chunks.py:786-888): same keys, same order, refiner fields flattened in."""
-    from .refine_signal_map import SigMapRefiner
+@dataclasses.dataclass
+class DatasetMetadata:
+    """What a chunk dataset says about itself: the reference's DatasetMetadata (src/remora/data_chunks.py:645-888),
+    same field names, defaults, derived properties and metadata.jsn text.  Items can also be read and written
+    with [] (md["dataset_end"])."""
 
-    ref = sig_map_refiner if sig_map_refiner is not None else SigMapRefiner()
-    md = {
-        "allocate_size": int(allocate_size), "max_seq_len": int(max_seq_len), "mod_bases": list(mod_bases),
-        "mod_long_names": list(mod_long_names), "motif_sequences": list(motif_sequences),
-        "motif_offsets": [int(x) for x in motif_offsets], "dataset_start": 0, "dataset_end": 0,
-        "version": DATASET_VERSION, "modified_base_labels": bool(modified_base_labels), "extra_arrays": extra_arrays,
-        "chunk_context": [int(x) for x in chunk_context], "base_start_justify": bool(base_start_justify),
-        "offset": int(offset), "kmer_context_bases": [int(x) for x in kmer_context_bases],
-        "reverse_signal": bool(reverse_signal), "pa_scaling": pa_scaling, "rough_rescale_method": rough_rescale_method,
-        "_stored_kmer_context_bases": None, "_stored_chunk_context": None,
-    }
-    md.update(ref.asdict())
-    md.pop("rough_rescale_method")
-    md["rough_rescale_method"] = ref.rough_rescale_method if ref.is_loaded else rough_rescale_method
-    # keep the reference's key order: ..., pa_scaling, rough_rescale_method, _stored_*, refine_*
-    order = ["allocate_size", "max_seq_len", "mod_bases", "mod_long_names", "motif_sequences", "motif_offsets",
-             "dataset_start", "dataset_end", "version", "modified_base_labels", "extra_arrays", "chunk_context",
-             "base_start_justify", "offset", "kmer_context_bases", "reverse_signal", "pa_scaling",
-             "rough_rescale_method", "_stored_kmer_context_bases", "_stored_chunk_context", "refine_kmer_levels",
-             "refine_kmer_center_idx", "refine_do_rough_rescale", "refine_scale_iters", "refine_algo",
-             "refine_half_bandwidth", "refine_sd_arr"]
-    return {k: md[k] for k in order}
+    allocate_size: int
+    max_seq_len: int
+    mod_bases: list
+    mod_long_names: list
+    motif_sequences: list
+    motif_offsets: list
+    dataset_start: int = 0
+    dataset_end: int = 0
+    version: int = DATASET_VERSION
+    modified_base_labels: bool = True
+    extra_arrays: dict = None
+    chunk_context: tuple = constants.DEFAULT_CHUNK_CONTEXT
+    base_start_justify: bool = False
+    offset: int = 0
+    kmer_context_bases: tuple = constants.DEFAULT_KMER_CONTEXT_BASES
+    reverse_signal: bool = False
+    pa_scaling: tuple = None
+    sig_map_refiner: object = None
+    rough_rescale_method: str = "least_squares"
+    _stored_kmer_context_bases: tuple = None
+    _stored_chunk_context: tuple = None
 
+    def __post_init__(self):
+        if isinstance(self.mod_bases, str):
+            self.mod_bases = list(self.mod_bases)
+        self.mod_bases = [str(mb) for mb in self.mod_bases]
+        self.mod_long_names = list(self.mod_long_names)
+        if len(self.mod_bases) != len(self.mod_long_names):
+            raise RemoraError(f"mod_bases ({self.mod_bases}) must be the same length as mod_long_names "
+                              f"({self.mod_long_names})")
+        self.chunk_context = tuple(int(x) for x in self.chunk_context)
+        self.kmer_context_bases = tuple(int(x) for x in self.kmer_context_bases)
+        if self._stored_chunk_context is not None:
+            self._stored_chunk_context = tuple(self._stored_chunk_context)
+        if self._stored_kmer_context_bases is not None:
+            self._stored_kmer_context_bases = tuple(self._stored_kmer_context_bases)
+        self.check_motifs()
 
-class CoreRemoraDataset:
-    """On-disk chunk dataset in the reference's format (src/remora/data_chunks.py:926-1702): five raw
-    memmapped core arrays named `<array>.npy` (no npy header) + `metadata.jsn` (+ `kmer_table.npy`).
-    mode "r" reads a directory (optionally with smaller chunk / k-mer contexts than stored);
-    mode "w" creates one from `metadata` (see `dataset_metadata`) and appends chunk arrays that the
-    extraction kernels already produce in this layout."""
+    # dict-style access
+    def __getitem__(self, key):
+        if key.startswith("refine_"):
+            return self._refiner_dict()[key]
+        return getattr(self, key)
 
-    _core_dtypes = {"signal": np.float32, "sequence": np.int8, "sequence_to_signal_mapping": np.int16,
-                    "sequence_lengths": np.int16, "labels": np.int64}
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
 
-    def __init__(self, data_path, override_metadata=None, batch_size=2048, mode="r", metadata=None):
-        self.data_path = data_path
-        self.batch_size = int(batch_size)
-        self.mode = mode
-        if mode not in ("r", "w"):
-            raise RemoraError("mode must be 'r' or 'w'")
-        if mode == "w":
-            if not isinstance(metadata, dict) or "allocate_size" not in metadata:
-                raise RemoraError("Must provide metadata for new dataset")
-            if override_metadata:
-                raise RemoraError("Cannot override metadata of a dataset opened for writing")
-            os.makedirs(data_path, exist_ok=True)
-            md = dict(metadata)
-        else:
-            with open(os.path.join(data_path, "metadata.jsn")) as fh:
-                md = json.load(fh)
-        if md.get("version") != DATASET_VERSION:
-            raise RemoraError(f"Remora dataset version ({md.get('version')}) does not match current "
-                              f"distribution ({DATASET_VERSION})")
-        self.metadata = md
-        self.stored_chunk_context = tuple(md.get("_stored_chunk_context") or md["chunk_context"])
-        self.stored_kmer_context_bases = tuple(md.get("_stored_kmer_context_bases") or md["kmer_context_bases"])
-        self.chunk_context = tuple(md["chunk_context"])
-        self.kmer_context_bases = tuple(md["kmer_context_bases"])
-        for k, v in (override_metadata or {}).items():
-            if k == "chunk_context":
-                v = tuple(int(x) for x in v)
-                if v[0] > self.stored_chunk_context[0] or v[1] > self.stored_chunk_context[1]:
-                    raise RemoraError("Cannot expand chunk context beyond stored chunk context")
-                self.chunk_context = v
-            elif k == "kmer_context_bases":
-                v = tuple(int(x) for x in v)
-                if v[0] > self.stored_kmer_context_bases[0] or v[1] > self.stored_kmer_context_bases[1]:
-                    raise RemoraError("Cannot expand kmer context beyond stored kmer context")
-                self.kmer_context_bases = v
-            elif k in ("dataset_start", "dataset_end"):
-                md[k] = int(v)
-            else:
-                raise RemoraError(f"cannot override dataset metadata attribute {k!r}")
-        n, msl = int(md["allocate_size"]), int(md["max_seq_len"])
-        L = sum(self.stored_chunk_context)
-        shapes = {"signal": (n, 1, L), "sequence": (n, msl + sum(self.stored_kmer_context_bases)),
-                  "sequence_to_signal_mapping": (n, msl + 1), "sequence_lengths": (n,), "labels": (n,)}
-        self.arrays = {}
-        for name, dt in self._core_dtypes.items():
-            path = os.path.join(data_path, f"{name}.npy")
-            if mode == "w":
-                self.arrays[name] = np.memmap(path, dt, mode="w+", shape=shapes[name])
-                continue
-            if os.path.getsize(path) != int(np.prod(shapes[name])) * np.dtype(dt).itemsize:
-                raise RemoraError(f"{path} does not have the size metadata.jsn implies")
-            self.arrays[name] = np.memmap(path, dt, mode="r", shape=shapes[name])
-        if mode == "w":
-            self.write_metadata()
+    def get(self, key, default=None):
+        return getattr(self, key, default)
 
-    # ---- writing (:1268-1469) ----------------------------------------------------------------
-    def write_metadata(self):
-        """metadata.jsn (+ kmer_table.npy when a level table is attached), as DatasetMetadata.write (:865-888)."""
-        md = dict(self.metadata)
-        levels = md.get("refine_kmer_levels")
-        if levels is not None:
-            np.save(os.path.join(self.data_path, "kmer_table.npy"), np.asarray(levels), allow_pickle=False)
-            del md["refine_kmer_levels"]
+    def check_motifs(self):
+        motifs = [util.Motif(*m) for m in self.motifs]
+        ambiguous = [m for m in motifs if m.focus_base not in "ACGT"]
+        if ambiguous:
+            raise RemoraError(f"Cannot create dataset at motifs with ambiguous bases {ambiguous}")
+        focus = {m.focus_base for m in motifs}
+        if len(focus) > 1:
+            raise RemoraError(f"Cannot create dataset with multiple motif focus bases: {focus}")
+
+    chunk_width = property(lambda s: sum(s.chunk_context))
+    stored_chunk_context = property(lambda s: s.chunk_context if s._stored_chunk_context is None else s._stored_chunk_context)
+    stored_chunk_width = property(lambda s: sum(s.stored_chunk_context))
+    chunk_context_adjusted = property(lambda s: s.stored_chunk_context != s.chunk_context)
+    kmer_len = property(lambda s: sum(s.kmer_context_bases) + 1)
+    stored_kmer_context_bases = property(
+        lambda s: s.kmer_context_bases if s._stored_kmer_context_bases is None else s._stored_kmer_context_bases)
+    kmer_context_bases_adjusted = property(lambda s: s.stored_kmer_context_bases != s.kmer_context_bases)
+    size = property(lambda s: s.dataset_end - s.dataset_start)
+    labels = property(lambda s: ["control"] + list(s.mod_long_names))
+    num_labels = property(lambda s: len(s.mod_long_names) + 1)
+    motifs = property(lambda s: list(zip(s.motif_sequences, s.motif_offsets)))
+    num_motifs = property(lambda s: len(s.motif_sequences))
+    extra_array_names = property(lambda s: [] if s.extra_arrays is None else list(s.extra_arrays))
+    sequence_width = property(lambda s: s.max_seq_len + sum(s.stored_kmer_context_bases))
+    sequence_to_signal_mapping_width = property(lambda s: s.max_seq_len + 1)
+    signal_shape = property(lambda s: (s.allocate_size, 1, s.stored_chunk_width))
+    sequence_shape = property(lambda s: (s.allocate_size, s.sequence_width))
+    sequence_to_signal_mapping_shape = property(lambda s: (s.allocate_size, s.sequence_to_signal_mapping_width))
+    sequence_lengths_shape = property(lambda s: (s.allocate_size,))
+    labels_shape = property(lambda s: (s.allocate_size,))
+    extras_shape = property(lambda s: (s.allocate_size,))
+
+    @property
+    def extra_array_dtypes_and_shapes(self):
+        return [] if self.extra_arrays is None else [(n, dt, self.extras_shape) for n, (dt, _) in self.extra_arrays.items()]
+
+    def _refiner_dict(self):
+        from .refine_signal_map import SigMapRefiner
+
+        return (self.sig_map_refiner if self.sig_map_refiner is not None else SigMapRefiner()).asdict()
+
+    def asdict(self):
+        """Field order of metadata.jsn: the dataclass fields without the refiner, then the refiner's own
+        entries (its rough_rescale_method replaces the field's value in place), :847-852."""
+        d = {f.name: getattr(self, f.name) for f in dataclasses.fields(self) if f.name != "sig_map_refiner"}
+        d = deepcopy(d)
+        if self.sig_map_refiner is not None:
+            d.update(self.sig_map_refiner.asdict())
+        return d
+
+    def copy(self):
+        return deepcopy(self)
+
+    def write(self, metadata_path, kmer_table_path=None):
+        """metadata.jsn (+ kmer_table.npy when a level table is attached), :857-888."""
+        d = self.asdict()
+        if d.get("refine_kmer_levels") is not None:
+            if kmer_table_path is not None:
+                np.save(kmer_table_path, np.asarray(d["refine_kmer_levels"]), allow_pickle=False)
+            del d["refine_kmer_levels"]
 
         def enc(o):
             if isinstance(o, np.integer):
@@ -577,125 +593,809 @@ class CoreRemoraDataset:
                 return bool(o)
             if isinstance(o, np.ndarray):
                 return o.tolist()
-            raise TypeError(type(o))
+            raise TypeError(f"{type(o)} is not JSON serialisable")
 
-        with open(os.path.join(self.data_path, "metadata.jsn"), "w") as fh:
-            json.dump(md, fh, default=enc)
+        with open(metadata_path, "w") as fh:
+            json.dump(d, fh, default=enc)
 
+
+def dataset_metadata(allocate_size, max_seq_len, mod_bases, mod_long_names, motif_sequences, motif_offsets,
+                     chunk_context=(50, 50), kmer_context_bases=(4, 4), base_start_justify=False, offset=0,
+                     reverse_signal=False, pa_scaling=None, extra_arrays=None, sig_map_refiner=None,
+                     modified_base_labels=True, rough_rescale_method="least_squares"):
+    """DatasetMetadata for a new dataset; a refiner is always attached (an unloaded one by default), because a
+    dataset without the refine_* keys in metadata.jsn cannot be read back."""
+    from .refine_signal_map import SigMapRefiner
+
+    return DatasetMetadata(
+        allocate_size=int(allocate_size), max_seq_len=int(max_seq_len), mod_bases=mod_bases, mod_long_names=mod_long_names,
+        motif_sequences=list(motif_sequences), motif_offsets=[int(x) for x in motif_offsets],
+        modified_base_labels=bool(modified_base_labels), extra_arrays=extra_arrays, chunk_context=chunk_context,
+        base_start_justify=bool(base_start_justify), offset=int(offset), kmer_context_bases=kmer_context_bases,
+        reverse_signal=bool(reverse_signal), pa_scaling=pa_scaling,
+        sig_map_refiner=sig_map_refiner if sig_map_refiner is not None else SigMapRefiner(),
+        rough_rescale_method=rough_rescale_method)
+
+
+def check_super_batch(super_batch, chunk_width):
+    """Row sanity of a super batch (:891-923): positive lengths, mappings inside [0, chunk_width] ending at
+    chunk_width, monotonic inside each chunk, bases in [-1, 3]."""
+    lens = super_batch["sequence_lengths"].astype(np.int64)
+    if not np.all(lens) > 0:  # (sic) the reference compares the all() result, not the elements
+        raise RemoraError("Sequence lengths must all be positive.")
+    maps = super_batch["sequence_to_signal_mapping"]
+    valid = np.arange(maps.shape[1]) < (lens[:, None] + 1)
+    flat = maps[valid]
+    if flat.max() > chunk_width:
+        raise RemoraError("Signal mapping extend beyond chunk width")
+    if flat.min() < 0:
+        raise RemoraError("Signal mapping cannot contain negative values")
+    if not np.all(maps[np.arange(lens.size), lens] == chunk_width):
+        raise RemoraError("Chunk does not end at chunk_width")
+    inner = np.ones(flat.size - 1, dtype=bool)
+    ends = np.cumsum(lens)
+    inner[ends[:-1] + np.arange(ends.size)[:-1]] = False  # steps from one chunk's end to the next chunk's start
+    if np.diff(flat)[inner].min() < 0:
+        raise RemoraError("Sequence to signal mappings are not monotonic")
+    bases = super_batch["sequence"][np.arange(super_batch["sequence"].shape[1]) < lens[:, None]]
+    if bases.max() > 3:
+        raise RemoraError("Sequence max must be less than 4")
+    if bases.min() < -1:
+        raise RemoraError("Sequence min must greater tha -2")
+
+
+class CoreRemoraDataset:
+    """On-disk chunk dataset in the reference's format (src/remora/data_chunks.py:926-1702): five raw
+    memmapped core arrays `<array>.npy` (no npy header), optional `extra_<name>.npy`, `metadata.jsn`
+    (+ `kmer_table.npy`).  Same constructor arguments and iteration scheme (super batches, wrap-around for
+    infinite iteration, random sub-sampling, label conversion, dynamic chunk / k-mer context trimming) as
+    the reference; batches carry the core rows themselves (the fused GPU path consumes them directly) and
+    `enc_kmers` on request through the encode kernel.  mode "w" appends what the extraction kernels produce."""
+
+    _core_dtypes = {"signal": np.float32, "sequence": np.int8, "sequence_to_signal_mapping": np.int16,
+                    "sequence_lengths": np.int16, "labels": np.int64}
+    _core_arrays = list(_core_dtypes)
+
+    def __init__(self, data_path=None, mode="r", metadata=None, override_metadata=None,
+                 batch_size=constants.DEFAULT_BATCH_SIZE, super_batch_size=constants.DEFAULT_SUPER_BATCH_SIZE,
+                 super_batch_sample_frac=None, super_batch_offset=0, infinite_iter=True, do_check_super_batches=False):
+        self.data_path, self.mode, self.metadata = data_path, mode, metadata
+        self.override_metadata = override_metadata
+        self.batch_size, self.super_batch_size = int(batch_size), int(super_batch_size)
+        self.super_batch_sample_frac, self.super_batch_offset = super_batch_sample_frac, int(super_batch_offset)
+        self.infinite_iter, self.do_check_super_batches = bool(infinite_iter), bool(do_check_super_batches)
+        self.label_conv = None
+        self.arrays = {}
+        self._iter = None
+        if mode not in ("r", "w"):
+            raise RemoraError("mode must be 'r' or 'w'")
+        if data_path is None:
+            if mode != "w" or not isinstance(metadata, DatasetMetadata):
+                raise RemoraError("In-memory dataset must have mode='w' and metadata")
+            self.allocate_arrays()
+        elif mode == "r":
+            self.data_path = util.resolve_path(data_path)
+            self.load_metadata()
+        else:
+            if not isinstance(metadata, DatasetMetadata):
+                raise RemoraError("Must provide metadata for new dataset")
+            if override_metadata:
+                raise RemoraError("Cannot override metadata of a dataset opened for writing")
+            self.data_path = util.resolve_path(data_path)
+            os.makedirs(self.data_path, exist_ok=True)
+            self.allocate_arrays()
+            self.write_metadata()
+        self.refresh_memmaps()
+
+    # ---- files ------------------------------------------------------------------------------
+    @staticmethod
+    def dataset_paths(data_path):
+        data_path = util.resolve_path(data_path)
+        paths = [os.path.join(data_path, n) for n in ["metadata.jsn"] + [f"{a}.npy" for a in CoreRemoraDataset._core_arrays]]
+        paths += glob(os.path.join(data_path, "extra_*.npy"))
+        if os.path.isfile(os.path.join(data_path, "kmer_table.npy")):
+            paths.append(os.path.join(data_path, "kmer_table.npy"))
+        return paths
+
+    @staticmethod
+    def check_dataset_dir(data_path):
+        return all(os.path.isfile(p) for p in CoreRemoraDataset.dataset_paths(data_path))
+
+    @staticmethod
+    def hash(data_path):
+        """sha256 over the per-file digests; files of 2 MiB and more are sampled at 8 evenly spaced 256 KiB
+        windows (:975-1009), so that configs written by either implementation verify with the other."""
+        bufsize, num_buf = 2**18, 8
+
+        def file_digest(path):
+            dig = hashlib.sha256()
+            size = os.path.getsize(path)
+            with open(path, "rb") as fh:
+                if size < bufsize * num_buf:
+                    for block in iter(lambda: fh.read(bufsize), b""):
+                        dig.update(block)
+                else:
+                    for pos in np.floor(np.linspace(0, size - bufsize, num_buf)).astype(int):
+                        fh.seek(int(pos))
+                        dig.update(fh.read(bufsize))
+            return dig.hexdigest()
+
+        joined = "".join(file_digest(p) for p in CoreRemoraDataset.dataset_paths(data_path))
+        return hashlib.sha256(joined.encode("utf-8")).hexdigest()
+
+    @property
+    def metadata_path(self):
+        if self.data_path is None:
+            raise RemoraError("No path available for in-memory dataset")
+        return os.path.join(self.data_path, "metadata.jsn")
+
+    @property
+    def kmer_table_path(self):
+        if self.data_path is None:
+            raise RemoraError("No path available for in-memory dataset")
+        return os.path.join(self.data_path, "kmer_table.npy")
+
+    def get_array_path(self, array_name):
+        if self.data_path is None:
+            raise RemoraError("No path available for in-memory dataset")
+        if array_name in self._core_arrays:
+            return os.path.join(self.data_path, f"{array_name}.npy")
+        if array_name in (self.metadata.extra_arrays or {}):
+            return os.path.join(self.data_path, f"extra_{array_name}.npy")
+        raise RemoraError(f"Invalid extra array name: {array_name}")
+
+    @property
+    def array_names(self):
+        return self._core_arrays + self.metadata.extra_array_names
+
+    @property
+    def arrays_info(self):
+        md = self.metadata
+        return [(n, dt, getattr(md, f"{n}_shape")) for n, dt in self._core_dtypes.items()] + md.extra_array_dtypes_and_shapes
+
+    def __getattr__(self, name):  # ds.signal, ds.labels, ds.read_ids ... as in the reference
+        arrays = self.__dict__.get("arrays") or {}
+        if name in arrays:
+            return arrays[name]
+        raise AttributeError(name)
+
+    def allocate_arrays(self):
+        if self.mode != "w":
+            raise RemoraError("Cannot write when mode is not 'w'")
+        for name, dt, shape in self.arrays_info:
+            if self.data_path is None:
+                self.arrays[name] = np.empty(shape, dtype=dt)
+            else:
+                self.arrays[name] = np.memmap(self.get_array_path(name), dt, mode="w+", shape=shape)
+
+    def refresh_memmaps(self):
+        if self.data_path is None:
+            return
+        self.arrays = {}
+        for name, dt, shape in self.arrays_info:
+            path = self.get_array_path(name)
+            if os.path.getsize(path) != int(np.prod(shape)) * np.dtype(dt).itemsize:
+                raise RemoraError(f"{path} does not have the size metadata.jsn implies")
+            self.arrays[name] = np.memmap(path, dt, mode="r" if self.mode == "r" else "r+", shape=shape)
+
+    def close_memmaps(self):
+        if self.data_path is not None:
+            self.arrays = {}
+
+    # ---- metadata ---------------------------------------------------------------------------
+    def load_metadata(self):
+        """metadata.jsn with `override_metadata` applied (:1078-1216).  Overridable: dataset_start / dataset_end
+        (slicing), mod_bases + mod_long_names (more labels; stored labels are converted), extra_arrays (a
+        subset), kmer_context_bases / chunk_context (not larger than stored)."""
+        from .refine_signal_map import SigMapRefiner
+
+        with open(self.metadata_path) as fh:
+            loaded = json.load(fh)
+        if loaded.get("version") != DATASET_VERSION:
+            raise RemoraError(f"Remora dataset version ({loaded.get('version')}) does not match current "
+                              f"distribution ({DATASET_VERSION})")
+        if os.path.exists(self.kmer_table_path):
+            loaded["refine_kmer_levels"] = np.load(self.kmer_table_path)
+        loaded["refine_sd_arr"] = np.asarray(loaded["refine_sd_arr"], np.float32)
+        loaded["sig_map_refiner"] = SigMapRefiner.load_from_metadata(loaded)
+        for key in [k for k in loaded if k.startswith("refine_")]:
+            del loaded[key]
+        stored_mods = [str(mb) for mb in loaded["mod_bases"]]
+        invalid = []
+        for key, val in (self.override_metadata or {}).items():
+            if key == "dataset_start":
+                if val < 0:
+                    raise RemoraError("Dataset start must be positive")
+            elif key == "dataset_end":
+                if val > loaded["dataset_end"]:
+                    raise RemoraError("Cannot set dataset end past loaded end")
+            elif key == "mod_bases":
+                val = [str(mb) for mb in val]
+                if "mod_long_names" not in self.override_metadata or len(self.override_metadata["mod_long_names"]) != len(val):
+                    raise RemoraError("mod_bases and mod_long_names must be overridden together")
+                if not all(mb in val for mb in stored_mods):
+                    raise RemoraError("Cannot remove modified base")
+                if stored_mods != val[: len(stored_mods)]:
+                    self.label_conv = np.zeros(len(stored_mods) + 1, dtype=np.int64)
+                    for lab, mb in enumerate(stored_mods):
+                        self.label_conv[lab + 1] = val.index(mb) + 1
+            elif key == "mod_long_names":
+                if "mod_bases" not in self.override_metadata:
+                    raise RemoraError("mod_bases and mod_long_names must be overridden together")
+            elif key == "extra_arrays":
+                missing = set(val).difference(loaded["extra_arrays"] or {})
+                if missing:
+                    raise RemoraError(f"Cannot load missing arrays: {', '.join(sorted(missing))}\nAvailable extra "
+                                      f"arrays: {', '.join((loaded['extra_arrays'] or {}).keys())}")
+                val = {k: loaded["extra_arrays"][k] for k in val}
+            elif key in ("chunk_context", "kmer_context_bases"):
+                val = tuple(int(x) for x in val)
+                stored = loaded[key] = tuple(loaded[key])
+                if val[0] > stored[0] or val[1] > stored[1]:
+                    what = "chunk context" if key == "chunk_context" else "kmer context"
+                    raise RemoraError(f"Cannot expand {what} (stored:{stored} ; requested:{val})")
+                loaded["_stored_" + key] = stored
+            else:
+                invalid.append(key)
+                continue
+            loaded[key] = val
+        if self.override_metadata is not None:
+            if loaded["dataset_start"] >= loaded["dataset_end"]:
+                raise RemoraError("Loaded dataset is empty")
+            if invalid:
+                raise RemoraError(f"Cannot change metadata values: {', '.join(invalid)}")
+        self.metadata = DatasetMetadata(**loaded)
+
+    def update_metadata(self, other):
+        """Take labels, extra arrays and contexts from another dataset's metadata (:1218-1247)."""
+        md = {k: getattr(other.metadata, k) for k in ("mod_bases", "mod_long_names", "extra_arrays",
+                                                     "kmer_context_bases", "chunk_context")}
+        md.update(dataset_start=self.metadata.dataset_start, dataset_end=self.metadata.dataset_end)
+        self.override_metadata = md
+        self.load_metadata()
+        self.refresh_memmaps()
+
+    def write_metadata(self):
+        self.metadata.write(self.metadata_path, self.kmer_table_path)
+
+    # convenience views of the loaded (possibly overridden) contexts
+    chunk_context = property(lambda s: s.metadata.chunk_context)
+    kmer_context_bases = property(lambda s: s.metadata.kmer_context_bases)
+    stored_chunk_context = property(lambda s: s.metadata.stored_chunk_context)
+    stored_kmer_context_bases = property(lambda s: s.metadata.stored_kmer_context_bases)
+    chunk_len = property(lambda s: s.metadata.chunk_width)
+    size = property(lambda s: s.metadata.dataset_end - s.metadata.dataset_start)
+
+    # ---- writing (:1345-1469) ---------------------------------------------------------------
     def write_batch(self, arrays):
-        """Append rows given as {array name: array[n, ...]} in the core dtypes (:1345-1374)."""
+        """Append rows given as {array name: array[n, ...]} (:1345-1374).  2-D rows narrower than the stored
+        width are padded (sequence with -1, mapping with 0)."""
         if self.mode != "w":
             raise RemoraError("Cannot write when mode is not 'w'")
         n = next(iter(arrays.values())).shape[0]
         if any(a.shape[0] != n for a in arrays.values()):
             raise RemoraError("All arrays in a batch must be the same size")
-        end = int(self.metadata["dataset_end"])
-        if end + n > int(self.metadata["allocate_size"]):
+        end = int(self.metadata.dataset_end)
+        if end + n > int(self.metadata.allocate_size):
             self.write_metadata()
             raise RemoraError("Batch write greater than allocated memory")
-        missing = set(self.arrays).difference(arrays)
+        missing = set(self.array_names).difference(arrays)
         if missing:
             raise RemoraError(f"Batch write must include all arrays. Missing: {', '.join(sorted(missing))}")
-        extra = set(arrays).difference(self.arrays)
+        extra = set(arrays).difference(self.array_names)
         if extra:
             raise RemoraError(f"Batch write must only include spcified arrays. Found: {', '.join(sorted(extra))}")
         for name, a in arrays.items():
             out = self.arrays[name]
             a = np.asarray(a)
-            if a.ndim == 2 and a.shape[1] < out.shape[1]:  # narrower rows: the tail columns are padding
+            if a.ndim == 2 and a.shape[1] < out.shape[1]:
                 out[end : end + n, : a.shape[1]] = a
                 out[end : end + n, a.shape[1] :] = -1 if name == "sequence" else 0
             else:
                 out[end : end + n] = a
-        self.metadata["dataset_end"] = end + n
+        self.metadata.dataset_end = end + n
 
     def write_chunk(self, chunk):
-        """One `Chunk` (:1376-1418)."""
-        self.write_batch({
+        """One `Chunk` (:1376-1418), with the read_ids / read_focus_bases extras when the dataset has them."""
+        row = {
             "signal": np.asarray(chunk.signal, np.float32)[None, None, :],
             "sequence": np.asarray(chunk.seq_w_context, np.int8)[None, :],
             "sequence_to_signal_mapping": np.asarray(chunk.seq_to_sig_map, np.int16)[None, :],
             "sequence_lengths": np.asarray([chunk.seq_len], np.int16),
             "labels": np.asarray([chunk.label], np.int64),
-        })
+        }
+        extras = self.metadata.extra_arrays or {}
+        if "read_ids" in extras:
+            row["read_ids"] = np.array([chunk.read_id], dtype=extras["read_ids"][0])
+        if "read_focus_bases" in extras:
+            row["read_focus_bases"] = np.array([chunk.read_focus_base], dtype=extras["read_focus_bases"][0])
+        self.write_batch(row)
 
-    def write_chunk_arrays(self, arrs, keep=None):
-        """Append GPU-extracted `ChunkArrays` (extract_chunk_arrays); chunks longer than max_seq_len are
-        dropped, as `remora dataset prepare` does (src/remora/prepare_train_data.py:213-221).  Returns
-        the number of chunks written."""
+    def write_chunk_arrays(self, arrs, keep=None, read_ids=None):
+        """Append GPU-extracted `ChunkArrays`; chunks longer than max_seq_len are dropped, as `remora dataset
+        prepare` does (src/remora/prepare_train_data.py:213-221).  `read_ids` (one per chunk) feeds the
+        read_ids extra array.  Returns the number of chunks written."""
         lens = arrs.lengths.cpu().numpy()
-        ok = lens <= int(self.metadata["max_seq_len"])
+        ok = lens <= int(self.metadata.max_seq_len)
         if keep is not None:
             ok &= np.asarray(keep, bool)
         if not ok.any():
             return 0
-        msl = int(self.metadata["max_seq_len"])
-        sw, mw = msl + sum(self.stored_kmer_context_bases), msl + 1
-        seq = arrs.sequence.cpu().numpy()[ok]
-        mp = arrs.mapping.cpu().numpy()[ok]
-        self.write_batch({
+        md = self.metadata
+        rows = {
             "signal": arrs.signal.cpu().numpy()[ok],
-            "sequence": seq[:, :sw],
-            "sequence_to_signal_mapping": mp[:, :mw],
+            "sequence": arrs.sequence.cpu().numpy()[ok][:, : md.sequence_width],
+            "sequence_to_signal_mapping": arrs.mapping.cpu().numpy()[ok][:, : md.sequence_to_signal_mapping_width],
             "sequence_lengths": lens[ok],
             "labels": np.asarray(arrs.labels, np.int64)[ok],
-        })
+        }
+        extras = md.extra_arrays or {}
+        if "read_ids" in extras:
+            if read_ids is None:
+                raise RemoraError("read_ids are needed for the read_ids extra array")
+            rows["read_ids"] = np.asarray(read_ids, dtype=extras["read_ids"][0])[ok]
+        if "read_focus_bases" in extras:
+            rows["read_focus_bases"] = arrs.read_focus_bases.cpu().numpy().astype(extras["read_focus_bases"][0])[ok]
+        self.write_batch(rows)
         return int(ok.sum())
 
-    def shuffle(self, batch_size=100_000):
-        """Random permutation of the written rows, every array with the same permutation (:1420-1469)."""
+    def shuffle(self, batch_size=100_000, show_prog=False):
+        """One np.random permutation applied to the written rows of every array (:1420-1469)."""
         if self.mode != "w":
             raise RemoraError("Cannot write when mode is not 'w'")
-        a0, a1 = int(self.metadata["dataset_start"]), int(self.metadata["dataset_end"])
+        a0, a1 = int(self.metadata.dataset_start), int(self.metadata.dataset_end)
         perm = np.random.permutation(a1 - a0)
-        for a in self.arrays.values():
-            view = a[a0:a1]
+        for name in self.array_names:
+            view = self.arrays[name][a0:a1]
             src = view.copy()
             for st in range(0, a1 - a0, batch_size):
                 view[st : st + batch_size] = src[perm[st : st + batch_size]]
-            a.flush()
+            if hasattr(self.arrays[name], "flush"):
+                self.arrays[name].flush()
 
     def flush(self):
+        if self.data_path is None:
+            return
         for a in self.arrays.values():
-            if hasattr(a, "flush"):
-                a.flush()
+            a.flush()
         if self.mode == "w":
             self.write_metadata()
 
-    @property
-    def size(self):
-        return int(self.metadata["dataset_end"]) - int(self.metadata["dataset_start"])
+    # ---- reading (:1470-1702) ---------------------------------------------------------------
+    def get_label_counts(self):
+        labs = np.asarray(self.arrays["labels"][self.metadata.dataset_start : self.metadata.dataset_end])
+        if self.label_conv is not None:
+            labs = self.label_conv[labs]
+        return np.bincount(labs, minlength=self.metadata.num_labels)
 
     @property
-    def chunk_len(self):
-        return sum(self.chunk_context)
+    def label_summary(self):
+        return "; ".join(f"{self.metadata.labels[i]}:{c:,}" for i, c in enumerate(self.get_label_counts()))
 
-    def load_batch(self, st, en):
-        """Rows [st, en) of the dataset as writable numpy arrays, trimmed to the loaded contexts."""
+    @property
+    def summary(self):
+        md = self.metadata
+        return (f"                data_path : {self.data_path}\n"
+                f"                     size : {self.size:,}\n"
+                f"            dataset_start : {md.dataset_start:,}\n"
+                f"              dataset_end : {md.dataset_end:,}\n"
+                f"       label distribution : {self.label_summary}\n"
+                f"     modified_base_labels : {md.modified_base_labels}\n"
+                f"                mod_bases : {md.mod_bases}\n"
+                f"           mod_long_names : {md.mod_long_names}\n"
+                f"       kmer_context_bases : {md.kmer_context_bases}\n"
+                f"            chunk_context : {md.chunk_context}\n"
+                f"                   motifs : {md.motifs}\n"
+                f"           reverse_signal : {md.reverse_signal}\n"
+                f" chunk_extract_base_start : {md.base_start_justify}\n"
+                f"     chunk_extract_offset : {md.offset}\n"
+                f"          sig_map_refiner : {md.sig_map_refiner}\n")
+
+    def adjust_batch_params(self):
+        """Clamp the super-batch size to the dataset and derive the number of chunks drawn from each super
+        batch for `super_batch_sample_frac` (:1471-1510).  -> (chunks_per_super_batch, select_num_chunks|None)"""
+        self.super_batch_size = min(self.super_batch_size, self.size)
+        frac = self.super_batch_sample_frac
+        if frac is None:
+            return self.super_batch_size, None
+        select = int(np.ceil(self.super_batch_size * frac / self.batch_size) * self.batch_size)
+        if select > self.super_batch_size:
+            select -= self.batch_size
+        if select == 0:
+            self.batch_size = int(self.super_batch_size * frac)
+            select = self.batch_size
+        if frac == 1.0:
+            self.super_batch_size = select
+        return select, select
+
+    def _trim(self, b):
+        """Dynamic k-mer / chunk context trimming of a super batch (:1512-1576; T1 kernel)."""
         from .data_chunks_core import trim_sb_chunk_context_core
 
-        a0 = int(self.metadata["dataset_start"])
-        b = {k: np.array(v[a0 + st : a0 + en]) for k, v in self.arrays.items()}
-        seq_diff = self.stored_kmer_context_bases[0] - self.kmer_context_bases[0]
-        if seq_diff > 0:  # :1512-1534 (the trailing trim happens in the encode via the smaller ka)
+        md = self.metadata
+        seq_diff = md.stored_kmer_context_bases[0] - md.kmer_context_bases[0]
+        if seq_diff > 0:  # the trailing trim happens in the encode via the smaller ka
             b["sequence"][:, :-seq_diff] = b["sequence"][:, seq_diff:].copy()
-        if self.chunk_context != self.stored_chunk_context:  # :1536-1576
-            st_diff = self.stored_chunk_context[0] - self.chunk_context[0]
-            new_en = self.stored_chunk_context[0] + self.chunk_context[1]
+        if md.chunk_context_adjusted:
+            st_diff = md.stored_chunk_context[0] - md.chunk_context[0]
+            new_en = md.stored_chunk_context[0] + md.chunk_context[1]
             b["signal"] = np.ascontiguousarray(b["signal"][:, :, st_diff:new_en])
             b["sequence_to_signal_mapping"] = (b["sequence_to_signal_mapping"] - st_diff).astype(np.int16)
-            trim_sb_chunk_context_core(*self.stored_chunk_context, *self.chunk_context,
-                                       sum(self.kmer_context_bases), b["sequence"],
-                                       b["sequence_to_signal_mapping"], b["sequence_lengths"])
+            trim_sb_chunk_context_core(*md.stored_chunk_context, *md.chunk_context, sum(md.kmer_context_bases),
+                                       b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"])
         return b
 
-    def iter_batches(self):
-        for st in range(0, self.size, self.batch_size):
-            yield self.load_batch(st, min(st + self.batch_size, self.size))
+    def load_super_batch(self, offset=0, size=None, select_num_chunks=None):
+        """`size` rows from `offset` (relative to dataset_start) as writable arrays: wraps around the end for
+        infinite iteration, returns a short last batch otherwise, None past the end (:1578-1633)."""
+        md = self.metadata
+        if self.infinite_iter:
+            offset %= self.size
+        elif offset >= self.size:
+            return None
+        st = md.dataset_start + offset
+        if size is None:
+            if self.infinite_iter:
+                raise RemoraError("Must specify size of super batch for infinite iter dataset")
+            size = md.dataset_end - st
+        if size > self.size:
+            raise RemoraError("Super batch larger than dataset requested")
+        en = st + size
+        if en <= md.dataset_end:
+            sb = {n: np.array(self.arrays[n][st:en]) for n in self.array_names}
+        elif self.infinite_iter:
+            wrap = en - self.size
+            sb = {n: np.concatenate([self.arrays[n][st : md.dataset_end], self.arrays[n][md.dataset_start : wrap]])
+                  for n in self.array_names}
+        else:
+            sb = {n: np.array(self.arrays[n][st : md.dataset_end]) for n in self.array_names}
+        if select_num_chunks is not None:
+            pick = np.random.choice(sb["labels"].size, min(select_num_chunks, sb["labels"].size), replace=False)
+            sb = {n: a[pick] for n, a in sb.items()}
+        if self.label_conv is not None:
+            sb["labels"] = self.label_conv[sb["labels"]]
+        return self._trim(sb)
+
+    def load_batch(self, st, en):
+        """Rows [st, en) of the dataset (relative to dataset_start), trimmed to the loaded contexts."""
+        keep, self.infinite_iter = self.infinite_iter, False
+        try:
+            return self.load_super_batch(st, min(en, self.size) - st)
+        finally:
+            self.infinite_iter = keep
+
+    def iter_super_batches(self, select_num_chunks=None):
+        num = 0
+        while True:
+            self.refresh_memmaps()
+            sb = self.load_super_batch(self.super_batch_offset + num * self.super_batch_size, self.super_batch_size,
+                                       select_num_chunks=select_num_chunks)
+            if sb is None:
+                return
+            if self.do_check_super_batches:
+                check_super_batch(sb, self.metadata.chunk_width)
+            num += 1
+            yield sb
+
+    def extract_batch(self, super_batch, batch_st, enc_kmers=False):
+        """One batch of a super batch (:1652-1676): the core rows, plus `enc_kmers` from the encode kernel when
+        asked for (the fused path does not need it)."""
+        en = min(batch_st + self.batch_size, super_batch["sequence"].shape[0])
+        batch = {n: a[batch_st:en] for n, a in super_batch.items()}
+        if enc_kmers:
+            from .encoded_kmers import compute_encoded_kmer_batch
+
+            batch["enc_kmers"] = compute_encoded_kmer_batch(
+                *self.metadata.kmer_context_bases, batch["sequence"], batch["sequence_to_signal_mapping"],
+                batch["sequence_lengths"])
+        return batch
+
+    def iter_batches(self, max_batches=None, enc_kmers=False):
+        chunks_per_sb, select = self.adjust_batch_params()
+        num = 0
+        for sb in self.iter_super_batches(select):
+            for st in range(0, chunks_per_sb, self.batch_size):
+                if st >= sb["sequence"].shape[0]:  # short last super batch of a finite dataset
+                    break
+                yield self.extract_batch(sb, st, enc_kmers)
+                num += 1
+                if max_batches is not None and num >= max_batches:
+                    return
+
+    def __iter__(self):
+        if self._iter is None or not self.infinite_iter:
+            self._iter = self.iter_batches()
+        return self._iter
+
+    def __next__(self):
+        return next(self._iter)
+
+
+def parse_dataset_config(config_path, used_configs=None):
+    """Dataset config = JSON list of [path, weight] or [path, weight, hash]; a path may itself be a config
+    (weights multiply).  -> (core paths, proportions summing to 1, hashes) (:1705-1760)."""
+    config_path = util.resolve_path(config_path)
+    used_configs = {config_path: config_path} if used_configs is None else used_configs
+    paths, weights, hashes = [], [], []
+    with open(config_path) as fh:
+        entries = json.load(fh)
+    for entry in entries:
+        ds_path, weight = entry[0], entry[1]
+        ds_hash = entry[2] if len(entry) == 3 else None
+        if not weight > 0:
+            raise RemoraError("dataset config weight must be positive")
+        ds_path = util.resolve_path(ds_path)
+        if not os.path.exists(ds_path):
+            raise RemoraError(f"Core dataset path does not exist. {ds_path}")
+        if os.path.isdir(ds_path):
+            computed = CoreRemoraDataset.hash(ds_path)
+            if ds_hash is not None and ds_hash != computed:
+                raise RemoraError(f"Dataset hash does not match value from config for dataset at {ds_path}")
+            paths.append(ds_path)
+            weights.append(weight)
+            hashes.append(computed)
+            continue
+        if ds_path in used_configs:
+            raise RemoraError(f"Circular or repeated dataset config refrence. {ds_path} found in {config_path} and "
+                              f"previously found in {used_configs[ds_path]}")
+        used_configs[ds_path] = config_path
+        sub_paths, sub_props, sub_hashes = parse_dataset_config(ds_path, used_configs=used_configs)
+        paths.extend(sub_paths)
+        weights.extend(sub_props * weight)
+        hashes.extend(sub_hashes)
+    weights = np.array(weights, dtype=float)
+    return paths, weights / weights.sum(), hashes
+
+
+def load_dataset(ds_path):
+    """A core dataset directory or a dataset config (:1763-1770)."""
+    ds_path = util.resolve_path(ds_path)
+    if not os.path.exists(ds_path):
+        raise RemoraError(f"Dataset path does not exist. {ds_path}")
+    if os.path.isdir(ds_path):
+        return [ds_path], np.ones(1, dtype=float), None
+    return parse_dataset_config(ds_path)
+
+
+def compute_best_split(total_size, props):
+    """`total_size` split into len(props) positive integers as close to `props` as possible (:1773-1792)."""
+    props = np.asarray(props, dtype=float)
+    if total_size < len(props):
+        raise RemoraError(f"total_size ({total_size}) smaller than number of proportions {len(props)}")
+    sizes = np.floor(total_size * props).astype(int)
+    sizes[sizes == 0] = 1
+    while sizes.sum() > total_size:
+        sizes[np.argmax(sizes)] -= 1
+    while sizes.sum() < total_size:
+        sizes[np.argmin(sizes / sizes.sum() - props)] += 1
+    return sizes
+
+
+class RemoraDataset:
+    """Several core datasets drawn from at fixed proportions in every batch (src/remora/data_chunks.py:1806-2276):
+    labels, motifs and contexts are reconciled across the datasets, each contributes `batch_sizes[i]` rows per
+    batch.  Batches are lists of arrays named by `return_arrays`; besides the reference's "enc_kmers", "signal",
+    "labels" the raw rows ("sequence", "sequence_to_signal_mapping", "sequence_lengths", padded to a common
+    width) can be requested — those feed the fused GPU path."""
+
+    def __init__(self, datasets, proportions, hashes=None, batch_size=constants.DEFAULT_BATCH_SIZE,
+                 super_batch_size=constants.DEFAULT_SUPER_BATCH_SIZE, super_batch_sample_frac=None, seed=None,
+                 return_arrays=("enc_kmers", "signal", "labels")):
+        self.datasets, self.props = list(datasets), np.asarray(proportions, dtype=float)
+        if not all(0 <= p <= 1 for p in self.props):
+            raise RemoraError("Dataset proportions must be between 0 and 1.")
+        if len(self.datasets) != len(self.props):
+            raise RemoraError("Dataset and proportions must be same length.")
+        self._hashes = hashes
+        self.set_batch_size(batch_size)
+        self.super_batch_size, self.super_batch_sample_frac, self.seed = super_batch_size, super_batch_sample_frac, seed
+        self.return_arrays = tuple(return_arrays)
+        self.infinite_iter = all(ds.infinite_iter for ds in self.datasets)
+        self.set_global_metadata()
+        for ds in self.datasets:
+            ds.update_metadata(self)
+        self.super_batch_offsets = [0] * len(self.datasets)
+        self._ds_iters = self._iter = self._all_batches = None
+
+    num_datasets = property(lambda s: len(s.datasets))
+    paths = property(lambda s: [ds.data_path for ds in s.datasets])
+    size = property(lambda s: sum(ds.size for ds in s.datasets))
+
+    @property
+    def hashes(self):
+        if self._hashes is None or any(h is None for h in self._hashes):
+            self._hashes = [ds.hash(ds.data_path) for ds in self.datasets]
+        return self._hashes
+
+    @property
+    def init_kwargs(self):
+        return dict(proportions=self.props, hashes=self._hashes, batch_size=self.batch_size,
+                    super_batch_size=self.super_batch_size, super_batch_sample_frac=self.super_batch_sample_frac,
+                    seed=self.seed, return_arrays=self.return_arrays)
+
+    @property
+    def summary(self):
+        md = self.metadata
+        return (f"                     size : {self.size:,}\n"
+                f"     modified_base_labels : {md.modified_base_labels}\n"
+                f"                mod_bases : {md.mod_bases}\n"
+                f"           mod_long_names : {md.mod_long_names}\n"
+                f"       kmer_context_bases : {md.kmer_context_bases}\n"
+                f"            chunk_context : {md.chunk_context}\n"
+                f"                   motifs : {md.motifs}\n"
+                f"           reverse_signal : {md.reverse_signal}\n"
+                f" chunk_extract_base_start : {md.base_start_justify}\n"
+                f"     chunk_extract_offset : {md.offset}\n"
+                f"               pa_scaling : {md.pa_scaling}\n"
+                f"          sig_map_refiner : {md.sig_map_refiner}\n")
+
+    def set_global_metadata(self):
+        """Metadata of the union (:1862-1992): exact-match attributes checked, mod bases unioned and sorted by
+        short name, k-mer context reduced to the common minimum, motif sets merged."""
+        md = self.metadata = self.datasets[0].metadata.copy()
+        for name in ("allocate_size", "max_seq_len", "dataset_start", "dataset_end"):
+            setattr(md, name, None)
+
+        def set_motifs(motifs):
+            md.motif_sequences, md.motif_offsets = zip(*[m.to_tuple() for m in util.merge_motifs(motifs)])
+            md.check_motifs()
+
+        set_motifs(md.motifs)
+        for ds in self.datasets[1:]:
+            other = ds.metadata
+            for attr in ("modified_base_labels", "base_start_justify", "offset", "reverse_signal", "pa_scaling",
+                         "sig_map_refiner"):
+                if getattr(other, attr) != getattr(md, attr):
+                    raise RemoraError(f"All datasets must have same {attr} {getattr(other, attr)} != {getattr(md, attr)}")
+            if set(other.extra_array_names) != set(md.extra_array_names):
+                raise RemoraError(f"Extra arrays not equal: {other.extra_array_names} != {md.extra_array_names}")
+            for mb, mln in zip(other.mod_bases, other.mod_long_names):
+                if mb in md.mod_bases:
+                    known = md.mod_long_names[md.mod_bases.index(mb)]
+                    if mln != known:
+                        raise RemoraError(f"Mismatched modified bases.\n\tPreviously loaded modified bases: "
+                                          f"{md.mod_bases} {md.mod_long_names}\n\tNew modified bases: "
+                                          f"{other.mod_bases} {other.mod_long_names}")
+                else:
+                    md.mod_bases.append(mb)
+                    md.mod_long_names.append(mln)
+            if other.kmer_context_bases != md.kmer_context_bases:
+                md.kmer_context_bases = tuple(min(a, b) for a, b in zip(md.kmer_context_bases, other.kmer_context_bases))
+            if other.chunk_context != md.chunk_context:
+                # (sic) the reference stores the reduced chunk context into kmer_context_bases (:1949-1964);
+                # kept, because the datasets are then re-loaded with exactly these values
+                md.kmer_context_bases = tuple(min(a, b) for a, b in zip(md.chunk_context, other.chunk_context))
+            if set(other.motifs) != set(md.motifs):
+                set_motifs(md.motifs + other.motifs)
+        order = sorted(range(len(md.mod_bases)), key=md.mod_bases.__getitem__)
+        md.mod_bases = [md.mod_bases[i] for i in order]
+        md.mod_long_names = [md.mod_long_names[i] for i in order]
+
+    def update_metadata(self, other):
+        for key in ("modified_base_labels", "offset", "reverse_signal", "pa_scaling", "sig_map_refiner"):
+            if getattr(self.metadata, key) != getattr(other.metadata, key):
+                raise RemoraError(f"Cannot update metadata with mismatching '{key}'. ({getattr(self.metadata, key)} != "
+                                  f"{getattr(other.metadata, key)})")
+        for ds in self.datasets:
+            ds.update_metadata(other)
+        for key in ("mod_bases", "mod_long_names", "extra_arrays", "kmer_context_bases", "chunk_context"):
+            setattr(self.metadata, key, getattr(other.metadata, key))
+
+    def set_batch_size(self, batch_size):
+        self.batch_size = int(batch_size)
+        self.batch_sizes = compute_best_split(self.batch_size, self.props)
+
+    @classmethod
+    def from_config(cls, config_path, override_metadata=None, ds_kwargs=None, **kwargs):
+        paths, props, hashes = parse_dataset_config(config_path)
+        datasets = [CoreRemoraDataset(p, override_metadata=dict(override_metadata or {}), **(ds_kwargs or {})) for p in paths]
+        return cls(datasets, props, hashes, **kwargs)
+
+    def _split(self, sizes, make_md, **ds_kwargs):
+        out = []
+        for ds, n in zip(self.datasets, sizes):
+            if n >= ds.size:
+                raise RemoraError("Not enough chunks")
+            out.append(CoreRemoraDataset(ds.data_path, override_metadata=make_md(ds, int(n)), **ds_kwargs))
+        return out
+
+    def train_test_split(self, num_test_chunks, override_metadata=None):
+        """The first rows of every dataset (in proportion) become the finite test set, the rest the training set (:2078-2108)."""
+        sizes = compute_best_split(num_test_chunks, self.props)
+        base = dict(override_metadata or {})
+        train = self._split(sizes, lambda ds, n: {**base, "dataset_start": ds.metadata.dataset_start + n})
+        test = self._split(sizes, lambda ds, n: {**base, "dataset_end": ds.metadata.dataset_start + n}, infinite_iter=False)
+        return RemoraDataset(train, **self.init_kwargs), RemoraDataset(test, **self.init_kwargs)
+
+    def head(self, num_chunks, override_metadata=None):
+        sizes = compute_best_split(num_chunks, self.props)
+        base = dict(override_metadata or {})
+        heads = self._split(sizes, lambda ds, n: {**base, "dataset_start": ds.metadata.dataset_start,
+                                                  "dataset_end": ds.metadata.dataset_start + n}, infinite_iter=False)
+        return RemoraDataset(heads, **self.init_kwargs)
+
+    def _set_sub_ds_iters(self, enc_kmers):
+        for ds, bs, off in zip(self.datasets, self.batch_sizes, self.super_batch_offsets):
+            ds.batch_size, ds.super_batch_offset = int(bs), int(off)
+            ds.super_batch_size, ds.super_batch_sample_frac = self.super_batch_size, self.super_batch_sample_frac
+        self._ds_iters = [ds.iter_batches(enc_kmers=enc_kmers) for ds in self.datasets]
+
+    @staticmethod
+    def _concat(name, parts):
+        if name in ("sequence", "sequence_to_signal_mapping"):  # datasets may differ in max_seq_len
+            width = max(p.shape[1] for p in parts)
+            fill = -1 if name == "sequence" else 0
+            parts = [p if p.shape[1] == width else np.pad(p, ((0, 0), (0, width - p.shape[1])), constant_values=fill)
+                     for p in parts]
+        return np.concatenate(parts)
+
+    def iter_batches(self, return_arrays=None):
+        """Batches until any core dataset runs out (never, when all iterate infinitely) (:2135-2149)."""
+        names = tuple(return_arrays) if return_arrays is not None else self.return_arrays
+        if self._ds_iters is None:
+            self._set_sub_ds_iters("enc_kmers" in names)
+        torch = _torch()
+        while True:
+            try:
+                parts = [next(it) for it in self._ds_iters]
+            except StopIteration:
+                return
+            yield [torch.from_numpy(np.ascontiguousarray(self._concat(n, [p[n] for p in parts]))) for n in names]
+
+    def load_all_batches(self):
+        if self.infinite_iter:
+            raise RemoraError("Cannot save all batches for infinite dataset")
+        self._ds_iters = None
+        self._all_batches = list(self.iter_batches())
+        for ds in self.datasets:
+            ds.close_memmaps()
+
+    def __iter__(self):
+        if self._all_batches is not None:
+            self._iter = iter(self._all_batches)
+            return self._iter
+        if self._iter is None or not self.infinite_iter:
+            self._ds_iters = None
+            self._iter = self.iter_batches()
+        return self._iter
+
+    def __next__(self):
+        return next(self._iter)
 
     def get_label_counts(self):
-        a0, a1 = int(self.metadata["dataset_start"]), int(self.metadata["dataset_end"])
-        return np.bincount(self.arrays["labels"][a0:a1], minlength=len(self.metadata["mod_bases"]) + 1)
+        counts = np.zeros(self.metadata.num_labels, dtype=int)
+        if self._all_batches is not None and "labels" in self.return_arrays:
+            li = self.return_arrays.index("labels")
+            for b in self._all_batches:
+                c = np.bincount(b[li].numpy())
+                counts[: c.size] += c
+            return counts
+        for ds in self.datasets:
+            c = ds.get_label_counts()
+            counts[: c.size] += c
+        return counts
+
+    @property
+    def label_summary(self):
+        return "; ".join(f"{self.metadata.labels[i]}:{c:,}" for i, c in enumerate(self.get_label_counts()))
+
+    def get_config(self):
+        return [(p, float(w)) if h is None else (p, float(w), h) for p, w, h in zip(self.paths, self.props, self.hashes)]
+
+    def epoch_summary(self, batches_per_epoch):
+        """Per-dataset table of how much of each dataset an epoch consumes (:2205-2276)."""
+        labs = self.metadata.labels
+        lines = []
+        for ds, bs in zip(self.datasets, self.batch_sizes):
+            counts = dict(zip(ds.metadata.labels, ds.get_label_counts()))
+            tot = sum(counts.values())
+            per_batch = "\t".join(f"{int(np.ceil(counts.get(lab, 0) / tot * bs)):,}" for lab in labs)
+            stored = "\t".join(f"{counts.get(lab, 0):,}" for lab in labs)
+            per_epoch = batches_per_epoch * int(bs)
+            lines.append(f"{per_epoch / ds.size:10.4%}\t{per_batch}\t{per_epoch:,}\t{ds.size:,}\t{stored}\t{ds.data_path}")
+        header = ("percent_of_dataset_per_epoch\t" + "\t".join(f"batch_{lab}" for lab in labs) +
+                  "\tdataset_chunks_per_epoch\tdataset_size\t" + "\t".join(f"dataset_{lab}" for lab in labs) + "\tpath\n")
+        return header + "\n".join(lines)
 
 
 def validate_dataset(dataset, model):
@@ -706,6 +1406,8 @@ def validate_dataset(dataset, model):
     counts = np.zeros(num_out, np.int64)
     conf = np.zeros((num_out, num_out), np.int64)
     logits = []
+    if dataset.infinite_iter:
+        raise RemoraError("validate_dataset needs a finite dataset (infinite_iter=False)")
     for b in dataset.iter_batches():
         out = model.infer_chunks(b["signal"], b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"],
                                  dataset.kmer_context_bases, label_counts=counts)

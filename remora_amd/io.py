@@ -403,6 +403,30 @@ class RefRegion:
     def len(self):
         return self.end - self.start
 
+    @property
+    def coord_range(self):
+        return range(self.start, self.end)
+
+
+def parse_bed_lines(bed_path):
+    """One RefRegion per BED line; strand None unless column 6 is + or - (src/remora/io.py:105-115)."""
+    with open(bed_path) as fh:
+        for line in fh:
+            fields = line.split()
+            strand = fields[5] if len(fields) >= 6 and fields[5] in "+-" else None
+            yield RefRegion(fields[0], strand, int(fields[1]), int(fields[2]))
+
+
+def parse_bed(bed_path):
+    """{(contig, strand): set of 0-based positions}; unstranded lines count for both strands (:118-126)."""
+    from collections import defaultdict
+
+    regs = defaultdict(set)
+    for reg in parse_bed_lines(bed_path):
+        for strand in ("+-" if reg.strand is None else reg.strand):
+            regs[(reg.ctg, strand)].update(reg.coord_range)
+    return regs
+
 
 @dataclasses.dataclass
 class Read:
@@ -520,6 +544,39 @@ class Read:
             if self.ref_to_signal.size != len(self.ref_seq) + 1:  # knots include the end of the last base
                 raise RemoraError("Discordant ref seq lengths")
             self.ref_reg.end = self.ref_reg.start + self.ref_to_signal.size - 1
+
+    def copy(self):
+        """Shallow copy with its own attribute set (arrays are shared, add_alignment rebinds them)."""
+        return dataclasses.replace(self)
+
+    def get_filtered_focus_positions(self, select_focus_positions):
+        """Read-oriented offsets into the reference sequence of this alignment for the positions of
+        `select_focus_positions` (as from parse_bed) that the alignment covers (src/remora/io.py:2215-2247)."""
+        if self.ref_reg is None or self.ref_seq is None:
+            raise RemoraError("Cannot extract focus positions without mapping")
+        reg, n = self.ref_reg, len(self.ref_seq)
+        wanted = select_focus_positions.get((reg.ctg, reg.strand))
+        if wanted is None:
+            return np.array([], dtype=int)
+        hit = np.array(sorted(set(range(reg.start, reg.start + n)).intersection(wanted)), dtype=int)
+        return hit - reg.start if reg.strand == "+" else reg.start + n - hit[::-1] - 1
+
+    def get_basecall_anchored_focus_bases(self, motifs, select_focus_reference_positions):
+        """Basecall positions on a motif whose aligned reference position is on a motif too (or in the BED
+        selection) (src/remora/io.py:2249-2289)."""
+        from . import util
+        from .data_chunks import make_sequence_coordinate_mapping
+
+        if self.cigar is None:
+            raise RemoraError("missing alignment")
+        called = util.find_focus_bases_in_int_sequence(util.seq_to_int(self.seq), motifs)
+        ref_to_query = make_sequence_coordinate_mapping(self.cigar).astype(int)
+        if select_focus_reference_positions is None:
+            ref_pos = util.find_focus_bases_in_int_sequence(util.seq_to_int(self.ref_seq), motifs)
+        else:
+            ref_pos = self.get_filtered_focus_positions(select_focus_reference_positions)
+        supported = set(ref_to_query[ref_pos].tolist())
+        return np.array([fb for fb in called if fb in supported])
 
     def into_remora_read(self, use_reference_anchor=False):
         """RemoraRead anchored on the basecalls (move table) or on the reference (move table composed with the

@@ -1,0 +1,240 @@
+"""`remora dataset prepare`: labelled chunk datasets from POD5 + BAM, the ETL that sits in
+front of the hot path's on-disk input format.  Mirrors src/remora/prepare_train_data.py:
+`extract_chunks` (:33-118) and `extract_chunk_dataset` (:124-276) with the same arguments and per-read
+semantics (reference- or basecall-anchored reads, motif or BED-selected focus bases, signal-mapping
+refinement, `max_chunks_per_read` down-sampling with numpy's global RNG, chunk checks, max_seq_len filter,
+read_ids / read_focus_bases extra arrays, final shuffle).
+
+What is different is the execution shape: reads are joined BAM-stream against POD5 random access and handled
+`reads_per_batch` at a time - ONE upload, ONE banded-DP refinement launch, ONE extraction launch per batch
+(`extract_chunk_arrays`) whose outputs already are the dataset's row layout and go to the memmaps with
+`write_chunk_arrays` - instead of one Python `Chunk` object per focus base across three process pools."""
+from collections import defaultdict
+
+import numpy as np
+
+from . import RemoraError
+from . import io as rio
+from .data_chunks import (CoreRemoraDataset, DatasetMetadata, DeviceReads, RemoraRead, _extract_device,
+                          compute_ref_to_signal)
+from .engine import _torch
+
+
+def _training_read(io_read, int_label, motifs, focus_ref_pos, basecall_anchor):
+    """RemoraRead with labels and focus bases for one aligned io.Read (prepare_train_data.py:53-91)."""
+    if basecall_anchor:
+        rr = io_read.into_remora_read(use_reference_anchor=False)
+        rr.focus_bases = io_read.get_basecall_anchored_focus_bases(motifs=motifs,
+                                                                   select_focus_reference_positions=focus_ref_pos)
+        rr.labels = np.full(len(io_read.seq), int_label, dtype=int)
+        return rr
+    io_read.ref_to_signal = compute_ref_to_signal(io_read.query_to_signal, io_read.cigar)
+    if io_read.ref_to_signal.size != len(io_read.ref_seq) + 1:
+        raise RemoraError(f"discordant ref seq lengths: move+cigar:{io_read.ref_to_signal.size} "
+                          f"ref_seq:{len(io_read.ref_seq)}")
+    r2s = io_read.ref_to_signal
+    rr = RemoraRead(dacs=io_read.dacs[r2s[0] : r2s[-1]], shift=io_read.shift_dacs_to_norm,
+                    scale=io_read.scale_dacs_to_norm, seq_to_sig_map=r2s - r2s[0], str_seq=io_read.ref_seq,
+                    labels=np.full(len(io_read.ref_seq), int_label, dtype=int), read_id=io_read.read_id)
+    if focus_ref_pos is None:
+        rr.set_motif_focus_bases(motifs)
+    else:
+        rr.focus_bases = io_read.get_filtered_focus_positions(focus_ref_pos)
+    return rr
+
+
+def _refine(reads, sig_map_refiner, engine):
+    """Signal-mapping refinement of a batch (RemoraRead.refine_signal_mapping for every read, batched on the
+    device); -> (DeviceReads of the surviving reads, surviving reads, {index in `reads`: error text})."""
+    refiner = sig_map_refiner
+    loaded = refiner is not None and getattr(refiner, "is_loaded", False)
+    errs = {}
+    if loaded and refiner.scale_iters > 0:
+        for i, err in enumerate(refiner.refine_reads(reads)):
+            if err is not None:
+                errs[i] = str(err)
+        alive = [r for i, r in enumerate(reads) if i not in errs]
+        return (DeviceReads(alive, engine) if alive else None), alive, errs
+    alive = list(reads)
+    if not alive:
+        return None, alive, errs
+    dr = DeviceReads(alive, engine)
+    if loaded and refiner.do_rough_rescale:
+        refiner.rough_rescale_device(dr, alive)
+    if loaded and refiner.scale_iters == 0:
+        try:
+            refiner.refine_device_reads(dr, alive)
+        except RemoraError:
+            # some read has an invalid band: find it read by read, then redo the batch without the failures
+            for i, r in enumerate(alive):
+                try:
+                    r.seq_to_sig_map, _, _ = refiner.refine_sig_map(r.shift, r.scale, r.seq_to_sig_map, r.int_seq, r.dacs)
+                except RemoraError as e:
+                    errs[i] = str(e)
+            alive = [r for i, r in enumerate(alive) if i not in errs]
+            dr = DeviceReads(alive, engine) if alive else None
+    return dr, alive, errs
+
+
+def extract_chunk_arrays_from_reads(read_errs, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read,
+                                    chunk_context, kmer_context_bases, base_start_justify, offset, basecall_anchor,
+                                    engine=None):
+    """Batched `extract_chunks`: -> (ChunkArrays | None, read id of every chunk, keep mask, per-read results).
+    Per-read results, in input order: (error text | None, (first, last+1) chunk rows | None).  Reads whose
+    RemoraRead.check fails are left out of the results, as in the reference (:95-99)."""
+    torch = _torch()
+    results, cands = [], []  # results[slot] = [error, row range]; None marks a read dropped by check()
+    for io_read, err in read_errs:
+        if err is None and io_read.ref_seq is None:
+            err = "No reference sequence (missing MD tag)"
+        results.append([err, None])
+        if err is None:
+            cands.append((len(results) - 1, _training_read(io_read, int_label, motifs, focus_ref_pos, basecall_anchor)))
+    dr, alive, errs = _refine([rr for _, rr in cands], sig_map_refiner, engine)
+    checked = []
+    for k, (slot, rr) in enumerate(cands):
+        if k in errs:
+            results[slot][0] = errs[k]
+            continue
+        rr.downsample_focus_bases(max_chunks_per_read)  # np.random.choice, in read order like the reference
+        try:
+            rr.check()
+            checked.append((slot, rr))
+        except RemoraError:
+            results[slot] = None
+    if dr is not None and len(checked) != len(alive):
+        dr = DeviceReads([rr for _, rr in checked], engine) if checked else None
+    arrs, ids, keep = None, [], np.zeros(0, bool)
+    if dr is not None:
+        # focus bases that still sit on a motif (iter_chunks(motifs=...), data_chunks.py:435-440)
+        focus_list, labels_list = [], []
+        foc_off = np.zeros(len(checked) + 1, np.int64)
+        for i, (slot, rr) in enumerate(checked):
+            fbs = np.asarray(rr.focus_bases if rr.focus_bases is not None else [], dtype=np.int64)
+            fbs = np.asarray([fb for fb in fbs if any(m.match(rr.int_seq, fb) for m in motifs)], dtype=np.int64)
+            focus_list.append(fbs)
+            labels_list.append(np.asarray(rr.labels)[fbs] if fbs.size else np.zeros(0, np.int64))
+            ids += [rr.read_id] * fbs.size
+            foc_off[i + 1] = foc_off[i] + fbs.size
+            results[slot][1] = (int(foc_off[i]), int(foc_off[i + 1]))
+        if foc_off[-1] > 0:
+            focus = torch.from_numpy(np.concatenate(focus_list)).to(dr.engine.torch_device)
+            arrs, _ = _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset,
+                                      np.concatenate(labels_list).astype(np.int64))
+            keep = ~torch.isnan(arrs.signal).any(dim=2).any(dim=1).cpu().numpy()  # Chunk.check: "Signal contains NaN"
+    return arrs, ids, keep, [tuple(r) for r in results if r is not None]
+
+
+def extract_chunks(read_errs, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read, chunk_context,
+                   kmer_context_bases, base_start_justify, offset, basecall_anchor, engine=None):
+    """The reference's signature and return shape (prepare_train_data.py:33-118): a list of
+    (list of Chunk | None, error text | None), one entry per read that was not dropped by RemoraRead.check.
+    Extraction itself is the batched GPU path."""
+    from .data_chunks import Chunk
+
+    arrs, ids, keep, results = extract_chunk_arrays_from_reads(
+        read_errs, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read, chunk_context,
+        kmer_context_bases, base_start_justify, offset, basecall_anchor, engine)
+    if arrs is not None:
+        sig = arrs.signal.cpu().numpy()[:, 0]
+        seqs, maps, geo = arrs.sequence.cpu().numpy(), arrs.mapping.cpu().numpy(), arrs.geo.cpu().numpy()
+        ctx = sum(arrs.kmer_context_bases)
+    out = []
+    for err, rows in results:
+        if err is not None:
+            out.append((None, err))
+            continue
+        chunks = []
+        for i in range(*(rows or (0, 0))):
+            if not keep[i]:
+                continue
+            sl = int(geo[i, 0])
+            chunks.append(Chunk(signal=sig[i].copy(), seq_w_context=seqs[i, : sl + ctx].copy(),
+                                seq_to_sig_map=maps[i, : sl + 1].astype(np.int32),
+                                kmer_context_bases=arrs.kmer_context_bases, chunk_sig_focus_idx=int(geo[i, 1]),
+                                chunk_focus_base=int(geo[i, 2]), read_focus_base=int(geo[i, 3]), read_id=ids[i],
+                                label=int(arrs.labels[i])))
+        out.append((chunks, None))
+    return out
+
+
+def count_reads(pod5_path, bam_path, skip_non_primary=True):
+    """Number of BAM records (after the primary filter) whose parent read has signal in the POD5 file, and the
+    total record count - the quantities of get_read_ids (src/remora/io.py:362-391)."""
+    signals = rio.Pod5File(pod5_path)
+    total = both = 0
+    for rec in rio.iter_bam_records(bam_path):
+        if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
+            continue
+        total += 1
+        both += dict(rec.tags).get("pi", rec.query_name) in signals
+    return both, total
+
+
+def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_control, motifs, focus_ref_pos,
+                          chunk_context, min_samps_per_base, max_chunks_per_read, pa_scaling, sig_map_refiner,
+                          kmer_context_bases, base_start_justify, offset, num_reads, num_extract_alignment_threads=1,
+                          num_extract_chunks_threads=1, skip_non_primary=True, basecall_anchor=False, rev_sig=False,
+                          save_every=100_000, skip_shuffle=False, reads_per_batch=256, engine=None):
+    """POD5 + BAM -> CoreRemoraDataset directory (prepare_train_data.py:124-276; the two worker-count arguments
+    are accepted for signature compatibility and unused: the batch is the unit of parallelism here).  Returns
+    (dataset, {reason: count})."""
+    num_both, num_records = count_reads(pod5_path, bam_path, skip_non_primary)
+    if num_records == 0:
+        raise RemoraError("No records found in BAM file.")
+    num_reads = num_both if num_reads is None else min(int(num_reads), num_both)
+    if num_reads == 0:
+        return None, {}
+    max_seq_len = sum(chunk_context) // min_samps_per_base
+    dataset = CoreRemoraDataset(
+        data_path=out_path, mode="w",
+        metadata=DatasetMetadata(
+            allocate_size=max_chunks_per_read * num_reads, max_seq_len=max_seq_len,
+            mod_bases=[] if mod_base_control else [mod_base[0]], mod_long_names=[] if mod_base_control else [mod_base[1]],
+            motif_sequences=[m.raw_motif for m in motifs], motif_offsets=[m.focus_pos for m in motifs],
+            extra_arrays={"read_ids": ("<U36", "Read identifier"),
+                          "read_focus_bases": ("int64", "Position within read training sequence")},
+            chunk_context=chunk_context, kmer_context_bases=kmer_context_bases, reverse_signal=rev_sig,
+            pa_scaling=pa_scaling, sig_map_refiner=sig_map_refiner, base_start_justify=base_start_justify, offset=offset))
+    errs = defaultdict(int)
+    int_label = 0 if mod_base_control else 1
+    next_save = save_every
+
+    def run(batch):
+        nonlocal next_save
+        arrs, ids, keep, results = extract_chunk_arrays_from_reads(
+            batch, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read, chunk_context,
+            kmer_context_bases, base_start_justify, offset, basecall_anchor, engine)
+        for err, _rows in results:
+            if err is not None:
+                errs[err] += 1
+        errs["No chunks extracted"] += len(batch) - len(results)  # reads dropped by RemoraRead.check (:204-206)
+        if arrs is None:
+            return
+        errs["Sequence too long"] += int(((arrs.lengths.cpu().numpy() > max_seq_len) & keep).sum())
+        try:
+            dataset.write_chunk_arrays(arrs, keep=keep, read_ids=ids)
+        except RemoraError as e:
+            errs[str(e)] += 1
+        if dataset.size >= next_save:
+            dataset.flush()
+            next_save += save_every
+
+    batch, seen = [], 0
+    for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,
+                                                     skip_non_primary=skip_non_primary):
+        if seen >= num_reads:
+            break
+        seen += 1
+        batch.append(read_err)
+        if len(batch) >= reads_per_batch:
+            run(batch)
+            batch = []
+    if batch:
+        run(batch)
+    errs = {k: v for k, v in errs.items() if v}
+    dataset.write_metadata()
+    if not skip_shuffle:
+        dataset.shuffle()
+    dataset.flush()
+    return dataset, errs

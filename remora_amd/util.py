@@ -4,8 +4,11 @@ int_to_seq :145-159, softmax_axis1 :182-186, Motif :190-378, find_focus_bases_in
 :413-426, format_mm_ml_tags :485-537.  Pure numpy / python (string and set handling; nothing
 here is on the GPU roofline)."""
 import array
+import os
 import re
+import shutil
 from dataclasses import dataclass
+from itertools import product
 
 import numpy as np
 
@@ -17,6 +20,7 @@ SINGLE_LETTER_CODE = {
     "A": "A", "C": "C", "G": "G", "T": "T", "B": "CGT", "D": "AGT", "H": "ACT", "K": "GT",
     "M": "AC", "N": "ACGT", "R": "AG", "S": "CG", "V": "ACG", "W": "AT", "Y": "CT",
 }
+BASES_TO_CODES = {v: k for k, v in SINGLE_LETTER_CODE.items()}
 _SEQ_LUT = np.full(256, -1, dtype=int)
 for _i, _b in enumerate(CAN_ALPHABET):
     _SEQ_LUT[ord(_b)] = _i
@@ -111,10 +115,73 @@ class Motif:
         return np.flatnonzero(hit)
 
     def match(self, int_seq, pos):
-        st = pos - self.focus_pos
-        if st < 0 or st + len(self.raw_motif) > int_seq.size:
+        """Does the motif sit on `pos`?  A motif hanging over either end of the sequence is compared on the
+        overlapping part only, as the reference does (src/remora/util.py:297-311)."""
+        pat = self.int_pattern
+        st, en = pos - self.focus_pos, pos + self.num_bases_after_focus + 1
+        if st < 0:
+            pat, st = pat[-st:], 0
+        if en > int_seq.size:
+            pat, en = pat[: len(pat) - en + int_seq.size], int_seq.size
+        return all(base in allowed for allowed, base in zip(pat, int_seq[st:en]))
+
+    @property
+    def possible_kmers(self):
+        return ["".join(bs) for bs in product(*(SINGLE_LETTER_CODE[c] for c in self.raw_motif))]
+
+    def is_super_set(self, other):
+        """Every sequence `other` stands for is also one of this motif's (:313-337)."""
+        if self.focus_pos > other.focus_pos or self.num_bases_after_focus > other.num_bases_after_focus:
             return False
-        return all(int_seq[st + i] in allowed for i, allowed in enumerate(self.int_pattern))
+        window = other.raw_motif[other.focus_pos - self.focus_pos : other.focus_pos + self.num_bases_after_focus + 1]
+        return all(set(SINGLE_LETTER_CODE[ob]) <= set(SINGLE_LETTER_CODE[sb]) for sb, ob in zip(self.raw_motif, window))
+
+    def merge(self, other):
+        """One motif standing for exactly the union of both, or RemoraError (:339-378)."""
+        if self == other or self.is_super_set(other):
+            return self
+        if other.is_super_set(self):
+            return other
+        if len(self.raw_motif) != len(other.raw_motif):
+            raise RemoraError("Cannot merge motifs of different sizes")
+        if self.focus_pos != other.focus_pos:
+            raise RemoraError("Cannot merge motifs with different focus pos")
+        union = set(self.possible_kmers) | set(other.possible_kmers)
+        width = len(self.raw_motif)
+        cand = Motif("".join(BASES_TO_CODES["".join(sorted({k[i] for k in union}))] for i in range(width)), self.focus_pos)
+        if len(cand.raw_motif) < width:  # leading / trailing N columns were clipped by the constructor
+            lead = self.focus_pos - cand.focus_pos
+            cols = ["ACGT"] * lead + [SINGLE_LETTER_CODE[c] for c in cand.raw_motif] + \
+                   ["ACGT"] * (width - len(cand.raw_motif) - lead)
+            spanned = {"".join(bs) for bs in product(*cols)}
+        else:
+            spanned = set(cand.possible_kmers)
+        if spanned != union:
+            raise RemoraError(f"Cannot merge motifs {self} {other}")
+        return cand
+
+
+def merge_motifs(motifs):
+    """Repeated pairwise merging until the set stops changing (src/remora/util.py:381-410)."""
+    motifs = list({m if isinstance(m, Motif) else Motif(*m) for m in motifs})
+    seen = None
+    while len(motifs) > 1 and (seen is None or set(seen) != set(motifs)):
+        seen = motifs
+        absorbed, pool = set(), set()
+        for a in seen:
+            for b in seen[1:]:
+                try:
+                    ab = a.merge(b)
+                except RemoraError:
+                    pool.update((a, b))
+                    continue
+                if ab != a:
+                    absorbed.add(a)
+                if ab != b:
+                    absorbed.add(b)
+                pool.add(ab)
+        motifs = list(pool - absorbed)
+    return motifs
 
 
 def find_focus_bases_in_int_sequence(int_seq, motifs):
@@ -149,3 +216,18 @@ def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
         scaled[scaled == 256] = 255
         ml_tag.extend(scaled.astype(np.uint8))
     return mm_tag, ml_tag
+
+
+def resolve_path(fn_path):
+    """Absolute, user-expanded, symlink-free path; None stays None (src/remora/util.py:161-167)."""
+    return None if fn_path is None else os.path.realpath(os.path.expanduser(str(fn_path)))
+
+
+def prepare_out_dir(out_dir, overwrite):
+    """Fresh output directory; an existing path is an error unless `overwrite` (src/remora/util.py:59-69; the
+    reference also opens its log file there)."""
+    if os.path.exists(out_dir):
+        if not overwrite:
+            raise RemoraError("Refusing to overwrite existing directory.")
+        shutil.rmtree(out_dir) if os.path.isdir(out_dir) else os.remove(out_dir)
+    os.makedirs(out_dir, exist_ok=True)

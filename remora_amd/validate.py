@@ -1,0 +1,136 @@
+"""`remora validate from_remora_dataset` on the MI355X path: the chunks of a (mixed) RemoraDataset through the
+fused extraction-free inference kernels and the reference's validation summary on top (accuracy, confusion
+matrix, cross-entropy loss, confidence-filtered accuracy).  Mirrors src/remora/validate.py:17-293 for the
+dataset flavour: VAL_METRICS, mat_to_str, compute_metrics (:42-66), add_unmodeled_labels (:69-99),
+ValidationLogger (:168-293).  The host part is numpy on N x num_labels arrays; the model forward is
+HipModel.infer_chunks on the stored rows (no one-hot tensor is materialised)."""
+import json
+from collections import namedtuple
+
+import numpy as np
+
+from . import constants
+from .engine import HipModel, _torch
+from .util import softmax_axis1
+
+VAL_METRICS = namedtuple("VAL_METRICS", ("loss", "acc", "num_calls", "conf_mat", "filt_frac", "filt_acc", "filt_conf_mat",
+                                         "filt_thresh"))
+
+
+def mat_to_str(mat):
+    return json.dumps(np.asarray(mat).tolist(), separators=(",", ":"))
+
+
+def confusion_matrix(labels, preds):
+    """Counts[true, predicted] over the sorted union of the classes that occur in either vector - what
+    sklearn.metrics.confusion_matrix(labels, preds) returns with default arguments (validate.py:44)."""
+    labels, preds = np.asarray(labels), np.asarray(preds)
+    classes = np.unique(np.concatenate([labels, preds]))
+    n = classes.size
+    idx = np.searchsorted(classes, labels) * n + np.searchsorted(classes, preds)
+    return np.bincount(idx, minlength=n * n).reshape(n, n).astype(np.int64)
+
+
+def compute_metrics(probs, labels, filt_frac):
+    """(acc, conf_mat, filt_frac, filt_acc, filt_conf_mat, filt_thr): overall accuracy and the accuracy over the
+    calls whose winning probability lies above the `filt_frac` quantile (validate.py:42-66)."""
+    preds = np.argmax(probs, axis=1)
+    conf = confusion_matrix(labels, preds)
+    right = preds == labels
+    acc = right.sum() / labels.size
+    win = np.take_along_axis(probs, preds[:, None], -1)[:, 0]
+    thr = np.quantile(win, filt_frac)
+    if thr == win.max():  # everything would be filtered: nudge the threshold below the maximum
+        thr *= 0.999999
+    sure = win > thr
+    n_sure = int(sure.sum())
+    if n_sure == 0:  # all probabilities NaN
+        return acc, conf, 1.0, np.nan, np.array([]), np.nan
+    return (acc, conf, 1 - n_sure / labels.size, right[sure].sum() / n_sure,
+            confusion_matrix(labels[sure], preds[sure]), thr)
+
+
+def add_unmodeled_labels(output, unmodeled_labels):
+    """Widen model outputs by the label columns the dataset has but the model does not; those columns get -1000
+    so that they vanish under softmax (validate.py:69-99)."""
+    unmodeled_labels = np.asarray(unmodeled_labels)
+    if unmodeled_labels.size == 0:
+        return output
+    nobs, nlab = output.shape
+    width = nlab + unmodeled_labels.size
+    wide = np.full((nobs, width), -1000, dtype=output.dtype)
+    wide[:, 0] = output[:, 0]
+    skipped = 0
+    for col in range(1, width):
+        if col in unmodeled_labels:
+            skipped += 1
+        else:
+            wide[:, col] = output[:, col - skipped]
+    return wide
+
+
+_RAW = ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths", "labels")
+
+
+class ValidationLogger:
+    """Tab-separated validation summary lines, same columns as the reference (validate.py:168-293)."""
+
+    HEADER = "\t".join(("Val_Type", "Epoch", "Iteration", "Accuracy", "Confusion_Matrix", "Loss", "Num_Calls",
+                        "Filtered_Fraction", "Filtered_Accuracy", "Filtered_Confusion_Matrix", "Filtered_Threshold"))
+    FULL_HEADER = "\t".join(["label", "class_pred", "class_probs"])
+
+    def __init__(self, fp, full_results_fh=None):
+        self.fp = fp
+        self.fp.write(self.HEADER + "\n")
+        self.full_fh = full_results_fh
+        if self.full_fh is not None:
+            self.full_fh.write(self.FULL_HEADER + "\n")
+
+    def write_full_results(self, output, labels):
+        probs = softmax_axis1(output)
+        for lab, pred, row in zip(labels.tolist(), output.argmax(axis=1), probs):
+            self.full_fh.write(f"{lab}\t{pred}\t{','.join(map(str, row))}\n")
+
+    def run_validation(self, model, model_mod_bases, criterion, dataset, filt_frac=constants.DEFAULT_FILT_FRAC,
+                       full_results_fh=None, disable_pbar=False):
+        """All batches of `dataset` (a finite RemoraDataset) through the model -> VAL_METRICS.  `criterion` is
+        a torch loss on (float32 logits, int64 labels), or None for cross entropy; the loss is the mean of the
+        per-batch means, as in the reference."""
+        torch = _torch()
+        if criterion is None:
+            criterion = torch.nn.CrossEntropyLoss()
+        md = dataset.metadata
+        unmodeled = np.array([i + 1 for i, mb in enumerate(md.mod_bases) if mb not in model_mod_bases])
+        fused = isinstance(model, HipModel)
+        names = _RAW if fused else ("enc_kmers", "signal", "labels")
+        dataset._ds_iters = None
+        all_out, all_lab, losses = [], [], []
+        for batch in dataset.iter_batches(return_arrays=names):
+            b = dict(zip(names, batch))
+            if fused:
+                out = model.infer_chunks(b["signal"].numpy(), b["sequence"].numpy(), b["sequence_to_signal_mapping"].numpy(),
+                                         b["sequence_lengths"].numpy(), md.kmer_context_bases)
+                out = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
+            else:
+                device = next(model.parameters()).device
+                with torch.no_grad():
+                    out = model(b["signal"].to(device), b["enc_kmers"].to(device)).detach().cpu().numpy()
+            out = add_unmodeled_labels(out, unmodeled)
+            all_out.append(out)
+            all_lab.append(b["labels"].numpy())
+            losses.append(criterion(torch.from_numpy(out), b["labels"]).detach().cpu().numpy())
+            if self.full_fh is not None:
+                self.write_full_results(out, all_lab[-1])
+        dataset._ds_iters = None
+        out, labels = np.concatenate(all_out, axis=0), np.concatenate(all_lab)
+        acc, conf, ff, facc, fconf, thr = compute_metrics(softmax_axis1(out), labels, filt_frac)
+        return VAL_METRICS(loss=np.mean(losses), acc=acc, num_calls=labels.size, conf_mat=conf, filt_frac=ff,
+                           filt_acc=facc, filt_conf_mat=fconf, filt_thresh=thr)
+
+    def validate_model(self, model, model_mod_bases, criterion, dataset, filt_frac=constants.DEFAULT_FILT_FRAC,
+                       val_type="val", nepoch=0, niter=0, disable_pbar=False):
+        ms = self.run_validation(model, model_mod_bases, criterion, dataset, filt_frac, disable_pbar=disable_pbar)
+        self.fp.write(f"{val_type}\t{nepoch}\t{niter}\t{ms.acc:.6f}\t{mat_to_str(ms.conf_mat)}\t{ms.loss:.6f}\t"
+                      f"{ms.num_calls}\t{ms.filt_frac:.4f}\t{ms.filt_acc:.6f}\t{mat_to_str(ms.filt_conf_mat)}\t"
+                      f"{ms.filt_thresh}\n")
+        return ms

@@ -1,0 +1,62 @@
+"""Helpers shared by the tests and tools/gen_golden.py: chunk datasets are kept in the golden npz files as
+their written rows + the metadata.jsn text and are turned back into dataset directories on demand."""
+import json
+import os
+
+import numpy as np
+
+CORE = ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths", "labels")
+
+
+def dataset_keys(prefix):
+    return [f"{prefix}__{n}" for n in CORE]
+
+
+def materialise_dataset(g, prefix, out_dir):
+    """Write the dataset stored under `prefix` in the npz mapping `g` as a CoreRemoraDataset directory:
+    raw C-order arrays `<name>.npy` / `extra_<name>.npy` with allocate_size rows (rows past the written
+    ones are zero), metadata.jsn verbatim, kmer_table.npy when a level table was stored."""
+    os.makedirs(out_dir, exist_ok=True)
+    text = str(g[f"{prefix}__metadata_jsn"])
+    md = json.loads(text)
+    with open(os.path.join(out_dir, "metadata.jsn"), "w") as fh:
+        fh.write(text)
+    alloc = int(md["allocate_size"])
+    names = list(CORE) + list((md.get("extra_arrays") or {}).keys())
+    for name in names:
+        rows = np.asarray(g[f"{prefix}__{name}"])
+        full = np.zeros((alloc,) + rows.shape[1:], dtype=rows.dtype)
+        full[: rows.shape[0]] = rows
+        fn = f"{name}.npy" if name in CORE else f"extra_{name}.npy"
+        with open(os.path.join(out_dir, fn), "wb") as fh:
+            fh.write(np.ascontiguousarray(full).tobytes())
+    if f"{prefix}__kmer_table" in g:
+        np.save(os.path.join(out_dir, "kmer_table.npy"), np.asarray(g[f"{prefix}__kmer_table"]), allow_pickle=False)
+    return out_dir
+
+
+def dataset_rows(ds_dir, md=None):
+    """(metadata dict, {array name: written rows}) of a dataset directory, padding columns masked (sequence -> -1,
+    mapping -> 0 beyond each chunk's length) so that rows compare independently of uninitialised padding."""
+    if md is None:
+        with open(os.path.join(ds_dir, "metadata.jsn")) as fh:
+            md = json.load(fh)
+    alloc, msl = int(md["allocate_size"]), int(md["max_seq_len"])
+    n0, n1 = int(md["dataset_start"]), int(md["dataset_end"])
+    kb, ka = md["_stored_kmer_context_bases"] or md["kmer_context_bases"]
+    L = sum(md["_stored_chunk_context"] or md["chunk_context"])
+    spec = {"signal": (np.float32, (alloc, 1, L)), "sequence": (np.int8, (alloc, msl + kb + ka)),
+            "sequence_to_signal_mapping": (np.int16, (alloc, msl + 1)), "sequence_lengths": (np.int16, (alloc,)),
+            "labels": (np.int64, (alloc,))}
+    for name, (dt, _desc) in (md.get("extra_arrays") or {}).items():
+        spec[name] = (np.dtype(dt), (alloc,))
+    rows = {}
+    for name, (dt, shape) in spec.items():
+        fn = f"{name}.npy" if name in CORE else f"extra_{name}.npy"
+        rows[name] = np.array(np.memmap(os.path.join(ds_dir, fn), dt, mode="r", shape=shape)[n0:n1])
+    lens = rows["sequence_lengths"].astype(int)
+    cols = np.arange(rows["sequence"].shape[1])[None, :]
+    rows["sequence"][cols >= (lens[:, None] + kb + ka)] = -1
+    cols = np.arange(rows["sequence_to_signal_mapping"].shape[1])[None, :]
+    rows["sequence_to_signal_mapping"][cols > lens[:, None]] = 0
+    return md, rows

@@ -638,7 +638,7 @@ def test_core_dataset_on_disk(torch_cuda, O, tag):
     g = golden("core_dataset.npz")
     override = json.loads(str(g[f"{tag}_override"]))
     ddir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data", "core_dataset")
-    ds = CoreRemoraDataset(ddir, override_metadata=override, batch_size=64)
+    ds = CoreRemoraDataset(ddir, override_metadata=override, batch_size=64, infinite_iter=False)
     assert ds.size == int(g["num_chunks"]) == 120
     sig, code, labs = [], [], []
     for b in ds.iter_batches():
@@ -943,26 +943,215 @@ def test_infer_with_two_models(torch_cuda, O, tmp_path):
 
 def test_validate_from_remora_dataset_cli(torch_cuda, O, tmp_path):
     """`python -m remora_amd validate from_remora_dataset` on the reference-written dataset with a model whose
-    contexts are smaller than the stored ones (so the trimming path runs): the printed tally equals
-    validate_dataset called directly."""
+    contexts are smaller than the stored ones (so the trimming path runs): header + one summary line in the
+    reference's format, equal to ValidationLogger.run_validation and to validate_dataset called directly."""
     import subprocess
     import sys
 
-    from remora_amd.data_chunks import CoreRemoraDataset, validate_dataset
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset, validate_dataset
     from remora_amd.model_util import load_model
+    from remora_amd.validate import ValidationLogger, mat_to_str
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ds_dir = os.path.join(root, "tests", "golden", "data", "core_dataset")
     g = golden("call_read_mods_cg_5mc.npz")
     pt = _mint_pt(tmp_path, g, O)
-    res = subprocess.run([sys.executable, "-m", "remora_amd", "validate", "from_remora_dataset", ds_dir, "--model", pt],
-                         cwd=root, capture_output=True, text=True, timeout=300)
+    full = str(tmp_path / "full.tsv")
+    res = subprocess.run([sys.executable, "-m", "remora_amd", "validate", "from_remora_dataset", ds_dir, "--model", pt,
+                          "--full-results-filename", full], cwd=root, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     model, md = load_model(pt, device=0)
-    ds = CoreRemoraDataset(ds_dir, override_metadata={"kmer_context_bases": md["kmer_context_bases"],
-                                                      "chunk_context": md["chunk_context"]})
+    over = {"kmer_context_bases": md["kmer_context_bases"], "chunk_context": md["chunk_context"]}
+    ds = CoreRemoraDataset(ds_dir, infinite_iter=False, override_metadata=dict(over))
     want = validate_dataset(ds, model)
     lines = res.stdout.strip().splitlines()
-    assert lines[0].split("\t")[0] == f"chunks {ds.size}" and abs(float(lines[0].split("acc ")[1]) - want["acc"]) < 1e-6
-    assert [int(x) for x in lines[1].split("\t")[1:]] == [int(c) for c in want["pred_counts"]]
-    assert int(np.sum(want["confusion"])) == ds.size
+    assert lines[0] == ValidationLogger.HEADER
+    f = lines[1].split("\t")
+    assert f[:3] == ["val", "0", "0"] and int(f[6]) == ds.size
+    assert abs(float(f[3]) - want["acc"]) < 1e-6 and f[4] == mat_to_str(want["confusion"])
+    rd = RemoraDataset([CoreRemoraDataset(ds_dir, infinite_iter=False, override_metadata={"extra_arrays": {}, **over})], [1.0])
+    ms = ValidationLogger(open(os.devnull, "w")).run_validation(model, md["mod_bases"], None, rd, 0.1)
+    assert abs(float(f[5]) - ms.loss) < 1e-5 and f[8] == f"{ms.filt_acc:.6f}" and f[9] == mat_to_str(ms.filt_conf_mat)
+    rows = open(full).read().strip().splitlines()
+    assert rows[0] == ValidationLogger.FULL_HEADER and len(rows) == ds.size + 1
+    labs = np.array([int(r.split("\t")[0]) for r in rows[1:]])
+    calls = np.array([int(r.split("\t")[1]) for r in rows[1:]])
+    assert np.array_equal(np.bincount(calls, minlength=2), want["pred_counts"])
+    assert np.array_equal(np.bincount(labs, minlength=2), ds.get_label_counts())
+
+
+# ---- N4: `remora dataset prepare` and RemoraDataset validation on the GPU path ---------------------------------
+def _prep_args(name):
+    g = golden("prepared_datasets.npz")
+    which, mod_base, kw = json.loads(str(g["configs_json"]))[name]
+    return g, which, mod_base, kw
+
+
+def _run_prepare(name, out_dir, skip_shuffle=False, reads_per_batch=5):
+    from remora_amd import io as rio
+    from remora_amd.prepare_train_data import extract_chunk_dataset
+    from remora_amd.refine_signal_map import SigMapRefiner
+    from remora_amd.util import Motif
+
+    g, which, mod_base, kw = _prep_args(name)
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    refiner = SigMapRefiner()
+    if kw["refine"]:
+        refiner = SigMapRefiner(kmer_model_filename=os.path.join(data, "levels_4mer.txt"), do_rough_rescale=True,
+                                scale_iters=0, do_fix_guage=True)
+    np.random.seed(11)
+    return extract_chunk_dataset(
+        bam_path=os.path.join(data, f"{which}_mappings.bam"), pod5_path=os.path.join(data, f"{which}_reads.pod5"),
+        out_path=out_dir, mod_base=mod_base, mod_base_control=mod_base is None, motifs=[Motif(*m) for m in kw["motifs"]],
+        focus_ref_pos=None if kw["bed"] is None else rio.parse_bed(os.path.join(data, kw["bed"])),
+        chunk_context=kw["chunk_context"], min_samps_per_base=kw["min_samps_per_base"],
+        max_chunks_per_read=kw["max_chunks_per_read"], pa_scaling=None, sig_map_refiner=refiner,
+        kmer_context_bases=kw["kmer_context_bases"], base_start_justify=kw["base_start_justify"], offset=kw["offset"],
+        num_reads=None, basecall_anchor=kw["basecall_anchor"], skip_shuffle=skip_shuffle, reads_per_batch=reads_per_batch)
+
+
+@pytest.mark.parametrize("name", ["can_ctrl", "mod_m", "mod_h", "can_bc_bed", "can_bc", "can_ref_bed", "can_refine",
+                                  "can_default"])
+def test_dataset_prepare_matches_reference(torch_cuda, tmp_path, name):
+    """`remora dataset prepare` (extract_chunk_dataset) on the reference's POD5 + BAM test data against the
+    dataset the reference's own extract_chunks + CoreRemoraDataset wrote under the same numpy seed: same
+    metadata.jsn text, the same rows in the same (shuffled) order for every array - signal bit for bit - and the
+    same pre-shuffle order; control and modified labels, reference- and basecall-anchored reads, BED-selected
+    positions, down-sampling, signal-mapping refinement, two motifs / offset / base-start justification."""
+    from golden_util import dataset_rows
+
+    g, which, mod_base, kw = _prep_args(name)
+    out = str(tmp_path / "ds")
+    ds, errs = _run_prepare(name, out)
+    assert open(os.path.join(out, "metadata.jsn")).read() == str(g[f"{name}__metadata_jsn"])
+    assert errs == json.loads(str(g[f"{name}__errs_json"]))
+    md, rows = dataset_rows(out)
+    for k, v in rows.items():
+        want = g[f"{name}__{k}"]
+        assert v.shape == want.shape, k
+        if k == "signal":
+            assert np.array_equal(v.view(np.uint32), want.view(np.uint32)), k
+        else:
+            np.testing.assert_array_equal(v, want, err_msg=k)
+    if f"{name}__kmer_table" in g:
+        np.testing.assert_array_equal(np.load(os.path.join(out, "kmer_table.npy")), g[f"{name}__kmer_table"])
+    _run_prepare(name, str(tmp_path / "ns"), skip_shuffle=True, reads_per_batch=256)
+    _, pre = dataset_rows(str(tmp_path / "ns"))
+    np.testing.assert_array_equal(pre["read_ids"], g[f"{name}_preshuffle__read_ids"])
+    np.testing.assert_array_equal(pre["read_focus_bases"], g[f"{name}_preshuffle__read_focus_bases"])
+    # the labels are the constant of the sample; each read contributes at most max_chunks_per_read chunks
+    assert set(rows["labels"].tolist()) == {0 if mod_base is None else 1}
+    assert max(np.unique(rows["read_ids"], return_counts=True)[1]) <= kw["max_chunks_per_read"]
+
+
+def test_extract_chunks_reference_signature(torch_cuda):
+    """prepare_train_data.extract_chunks with the reference's arguments and return shape: per read a list of
+    Chunk objects (or an error), equal to the rows the dataset writer got."""
+    from remora_amd import io as rio
+    from remora_amd.prepare_train_data import extract_chunks
+    from remora_amd.util import Motif
+
+    g = golden("prepared_datasets.npz")
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    read_errs = list(rio.iter_reads_from_pod5_and_bam(os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam")))
+    read_errs.insert(2, (read_errs[0][0], "made-up alignment error"))
+    np.random.seed(11)
+    res = extract_chunks(read_errs, 0, [Motif("CG", 0)], None, None, 15, (50, 50), (4, 4), False, 0, False)
+    assert len(res) == len(read_errs) and res[2] == (None, "made-up alignment error")
+    ids = [c.read_id for chunks, err in res if chunks for c in chunks]
+    fbs = [c.read_focus_base for chunks, err in res if chunks for c in chunks]
+    keep = np.array([c.seq_len <= 20 for chunks, err in res if chunks for c in chunks])
+    np.testing.assert_array_equal(np.asarray(ids)[keep], g["can_ctrl_preshuffle__read_ids"])
+    np.testing.assert_array_equal(np.asarray(fbs)[keep], g["can_ctrl_preshuffle__read_focus_bases"])
+    ch = res[0][0][0]
+    assert ch.signal.shape == (100,) and ch.label == 0 and ch.seq_to_sig_map[0] == 0 and ch.seq_to_sig_map[-1] == 100
+
+
+def test_remora_dataset_validation_matches_reference(torch_cuda, O, tmp_path):
+    """Three prepared datasets (two different modified bases -> label conversion) loaded the way `remora validate
+    from_remora_dataset` loads them - extra arrays dropped, the model's smaller k-mer and chunk contexts, which
+    runs the trimming kernel - : every batch equals the reference's, and ValidationLogger.run_validation through
+    the fused kernels gives the reference's metrics for a 3-class model and for a 2-class model with an
+    un-modelled label."""
+    from golden_util import materialise_dataset
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+    from remora_amd.model_util import model_from_state
+    from remora_amd.validate import ValidationLogger
+
+    g, gp = golden("remora_dataset.npz"), golden("prepared_datasets.npz")
+    paths = [materialise_dataset(gp, n, str(tmp_path / n)) for n in ("can_ctrl", "mod_m", "mod_h")]
+    over = {"extra_arrays": {}, "kmer_context_bases": (2, 3), "chunk_context": (45, 40)}
+    ds = RemoraDataset([CoreRemoraDataset(p, override_metadata=dict(over), infinite_iter=False, do_check_super_batches=True)
+                        for p in paths], g["mix2_props"], list(g["mix2_hashes"]), batch_size=64)
+    assert ds.metadata.kmer_context_bases == (2, 3) and ds.metadata.chunk_context == (45, 40)
+    codes, sigs, labs, sizes = [], [], [], []
+    for enc, sig, lab in ds:  # the reference's default return arrays; enc_kmers from the encode kernel
+        enc = enc.numpy()
+        n, K4, L = enc.shape
+        e4 = enc.reshape(n, K4 // 4, 4, L)
+        codes.append(np.where(e4.sum(2) > 0, e4.argmax(2), -1).astype(np.int8))
+        sigs.append(sig.numpy()); labs.append(lab.numpy()); sizes.append(n)
+    np.testing.assert_array_equal(sizes, g["mix3_bsizes"])
+    np.testing.assert_array_equal(np.concatenate(labs), g["mix3_labels"])
+    assert np.array_equal(np.concatenate(sigs).view(np.uint32), g["mix3_signal"].view(np.uint32))
+    np.testing.assert_array_equal(np.concatenate(codes), g["mix3_enc_code"])
+    ds.load_all_batches()
+    np.testing.assert_array_equal(ds.get_label_counts(), g["mix3_label_counts_loaded"])
+    ds = RemoraDataset([CoreRemoraDataset(p, override_metadata=dict(over), infinite_iter=False) for p in paths],
+                       g["mix2_props"], list(g["mix2_hashes"]), batch_size=64)
+    val = ValidationLogger(open(os.devnull, "w"))
+    for tag, prefix, mods in (("hm", "mix3_w__", ["h", "m"]), ("m_only", "mix3b_w__", ["m"])):
+        state = O.state_from_npz(g, prefix)
+        model = model_from_state(state, dict(chunk_context=(45, 40), kmer_context_bases=(2, 3)), device=0)
+        ms = val.run_validation(model, mods, None, ds, 0.1)
+        loss, acc, ncalls, ff, facc, thr = g[f"mix3_{tag}_metrics"]
+        assert ms.num_calls == int(ncalls)
+        np.testing.assert_array_equal(ms.conf_mat, g[f"mix3_{tag}_conf"])
+        np.testing.assert_array_equal(ms.filt_conf_mat, g[f"mix3_{tag}_filt_conf"])
+        assert ms.acc == acc and ms.filt_frac == ff and ms.filt_acc == facc
+        assert abs(ms.loss - loss) <= 1e-5 * max(1.0, abs(loss)) and abs(ms.filt_thresh - thr) <= 1e-5
+
+
+def test_dataset_cli_prepare_then_validate(torch_cuda, O, tmp_path):
+    """`python -m remora_amd dataset prepare` twice (control + modified sample), `dataset make_config`, `dataset
+    inspect`, then `validate from_remora_dataset` on the config: the reference's CLI flow for a two-sample dataset
+    (tests/conftest.py can_chunks / mod_chunks / chunks fixtures) end to end on the GPU path."""
+    import subprocess
+    import sys
+
+    from remora_amd.data_chunks import CoreRemoraDataset
+    from remora_amd.validate import ValidationLogger
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = os.path.join(root, "tests", "golden", "data")
+    run = lambda *a: subprocess.run([sys.executable, "-m", "remora_amd", *a], cwd=root, capture_output=True, text=True, timeout=600)
+    can, mod, cfg = str(tmp_path / "can_chunks"), str(tmp_path / "mod_chunks"), str(tmp_path / "chunks.cfg")
+    r = run("dataset", "prepare", os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam"), "--output-path", can,
+            "--mod-base-control", "--motif", "CG", "0", "--chunk-context", "50", "50")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = run("dataset", "prepare", os.path.join(data, "mod_reads.pod5"), os.path.join(data, "mod_mappings.bam"), "--output-path", mod,
+            "--mod-base", "m", "5mC", "--motif", "CG", "0", "--chunk-context", "50", "50")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Label distribution: control:0; 5mC:" in r.stdout
+    r = run("dataset", "prepare", os.path.join(data, "mod_reads.pod5"), os.path.join(data, "mod_mappings.bam"), "--output-path", mod,
+            "--mod-base", "m", "5mC", "--motif", "CG", "0")
+    assert r.returncode == 1 and "Refusing to overwrite" in r.stderr
+    n_can, n_mod = CoreRemoraDataset(can).size, CoreRemoraDataset(mod).size  # 14 reads x <= 15 random focus bases each
+    assert 150 < n_can <= 210 and 150 < n_mod <= 210
+    r = run("dataset", "make_config", cfg, can, mod)
+    assert r.returncode == 0, r.stderr[-2000:]
+    conf = json.load(open(cfg))
+    assert [c[0] for c in conf] == [can, mod] and abs(conf[0][1] - n_can / (n_can + n_mod)) < 1e-12 and len(conf[0][2]) == 64
+    r = run("dataset", "inspect", cfg)
+    assert r.returncode == 0 and f"size : {n_can + n_mod}" in r.stdout and "['5mC']" in r.stdout
+    pt = _mint_pt(tmp_path, golden("call_read_mods_cg_5mc.npz"), O)
+    r = run("validate", "from_remora_dataset", cfg, "--model", pt, "--batch-size", "100")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == ValidationLogger.HEADER
+    f = lines[1].split("\t")
+    conf_mat = np.array(json.loads(f[4]))
+    # batches of 100 split 49 / 51 until the smaller dataset runs out: 4 full batches + the 9 / 6 remainder
+    assert int(f[6]) == conf_mat.sum() and conf_mat.shape == (2, 2) and int(f[6]) >= 300
+    assert conf_mat[0].sum() > 100 and conf_mat[1].sum() > 100  # both samples' labels are present

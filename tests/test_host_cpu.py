@@ -689,3 +689,198 @@ def test_io_edge_cases_host():
     assert r.signal.dtype == np.int16 and r.signal.size > 1000 and r.calibration_scale > 0
     assert [x.read_id for x in rio.iter_pod5_reads(os.path.join(data, "can_reads.pod5"), read_ids=f.read_ids[:2])] == f.read_ids[:2]
     assert rio._pack_seq("ACGTN") == bytes([0x12, 0x48, 0xF0])
+
+
+# ---- N4: RemoraDataset mixing, dataset configs, validation metrics (host logic; golden from the reference) ----
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def _materialise(tmp_path, names):
+    from golden_util import materialise_dataset
+
+    g = golden("prepared_datasets.npz")
+    return {n: materialise_dataset(g, n, str(tmp_path / n)) for n in names}
+
+
+def _batches(it, O, kcb, limit=None):
+    """Concatenated (enc code, signal, labels, batch sizes) of raw-row batches; the one-hot code through the oracle."""
+    codes, sigs, labs, sizes = [], [], [], []
+    for bi, (sig, seq, mp, ln, lab) in enumerate(it):
+        enc = O.compute_encoded_kmer_batch(*kcb, seq.numpy(), mp.numpy(), ln.numpy())
+        n, K4, L = enc.shape
+        e4 = enc.reshape(n, K4 // 4, 4, L)
+        codes.append(np.where(e4.sum(2) > 0, e4.argmax(2), -1).astype(np.int8))
+        sigs.append(sig.numpy()); labs.append(lab.numpy()); sizes.append(n)
+        if limit is not None and bi + 1 >= limit:
+            break
+    return np.concatenate(codes), np.concatenate(sigs), np.concatenate(labs), np.asarray(sizes)
+
+
+RAW = ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths", "labels")
+
+
+def _check_batches(g, tag, got):
+    code, sig, lab, sizes = got
+    np.testing.assert_array_equal(sizes, g[f"{tag}_bsizes"])
+    np.testing.assert_array_equal(lab, g[f"{tag}_labels"])
+    assert np.array_equal(sig.view(np.uint32), g[f"{tag}_signal"].view(np.uint32))
+    np.testing.assert_array_equal(code, g[f"{tag}_enc_code"])
+
+
+def test_remora_dataset_two_way_mix_matches_reference(tmp_path, O):
+    """Two prepared datasets at 0.5 / 0.5 from a config file (the reference's own test fixture shape): batch split,
+    merged metadata, label counts, every batch of the finite iteration, head() and train_test_split()."""
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset
+
+    g = golden("remora_dataset.npz")
+    dirs = _materialise(tmp_path, ["can_ctrl", "mod_m"])
+    for n, p in dirs.items():
+        assert CoreRemoraDataset.hash(p) == str(g[f"hash_{n}"]) and CoreRemoraDataset.check_dataset_dir(p)
+    cfg = str(tmp_path / "mix1.cfg")
+    json.dump([[dirs["can_ctrl"], 0.5], [dirs["mod_m"], 0.5]], open(cfg, "w"))
+    ds = RemoraDataset.from_config(cfg, ds_kwargs={"infinite_iter": False}, batch_size=32, return_arrays=RAW)
+    np.testing.assert_array_equal(ds.batch_sizes, g["mix1_batch_sizes"])
+    np.testing.assert_allclose(ds.props, g["mix1_props"])
+    np.testing.assert_array_equal(ds.get_label_counts(), g["mix1_label_counts"])
+    assert ds.label_summary == str(g["mix1_label_summary"])
+    mods, longs, motifs = json.loads(str(g["mix1_mod_bases"]))
+    assert ds.metadata.mod_bases == mods and ds.metadata.mod_long_names == longs
+    assert [list(m) for m in ds.metadata.motifs] == motifs
+    assert ds.epoch_summary(10).replace(str(tmp_path), "<TD>") == str(g["mix1_epoch_summary"])
+    kcb = ds.metadata.kmer_context_bases
+    _check_batches(g, "mix1", _batches(iter(ds), O, kcb))
+    _check_batches(g, "mix1", _batches(iter(ds), O, kcb))  # a finite dataset restarts on every iter()
+    hd = ds.head(40)
+    np.testing.assert_array_equal([s.size for s in hd.datasets], g["mix1_head_sizes"])
+    _check_batches(g, "mix1_head", _batches(iter(hd), O, kcb))
+    trn, tst = ds.train_test_split(25)
+    np.testing.assert_array_equal([[s.size for s in trn.datasets], [s.size for s in tst.datasets]], g["mix1_split_sizes"])
+    _check_batches(g, "mix1_test", _batches(iter(tst), O, kcb))
+    _check_batches(g, "mix1_train", _batches(iter(trn), O, kcb, limit=5), )
+    ds.load_all_batches()
+    np.testing.assert_array_equal(ds.get_label_counts(), np.bincount(g["mix1_labels"], minlength=2))
+    _check_batches(g, "mix1", _batches(iter(ds), O, kcb))
+
+
+def test_remora_dataset_nested_config_label_conversion_and_wraparound(tmp_path, O):
+    """Three datasets with two different modified bases through a nested config: proportions, hashes, the
+    label conversion table of every dataset, merged (sorted) mod bases, and the first 9 batches of the
+    infinite iteration with super batches smaller than the datasets (wrap-around)."""
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset, parse_dataset_config
+
+    g = golden("remora_dataset.npz")
+    dirs = _materialise(tmp_path, ["can_ctrl", "mod_m", "mod_h"])
+    sub, cfg = str(tmp_path / "sub.cfg"), str(tmp_path / "mix2.cfg")
+    json.dump([[dirs["mod_m"], 3], [dirs["mod_h"], 1]], open(sub, "w"))
+    json.dump([[dirs["can_ctrl"], 2], [sub, 3]], open(cfg, "w"))
+    paths, props, hashes = parse_dataset_config(cfg)
+    assert [os.path.basename(p) for p in paths] == list(g["mix2_paths"])
+    np.testing.assert_allclose(props, g["mix2_props"], rtol=0, atol=1e-15)
+    assert hashes == list(g["mix2_hashes"])
+    assert load_dataset(dirs["mod_m"])[0] == [dirs["mod_m"]] and load_dataset(cfg)[0] == paths
+    ds = RemoraDataset([CoreRemoraDataset(p) for p in paths], props, hashes, batch_size=50, super_batch_size=70,
+                       return_arrays=RAW)
+    np.testing.assert_array_equal(ds.batch_sizes, g["mix2_batch_sizes"])
+    assert [ds.metadata.mod_bases, ds.metadata.mod_long_names] == json.loads(str(g["mix2_mod_bases"]))
+    want_conv = json.loads(str(g["mix2_label_conv"]))
+    assert [None if s.label_conv is None else s.label_conv.tolist() for s in ds.datasets] == want_conv
+    np.testing.assert_array_equal(ds.get_label_counts(), g["mix2_label_counts"])
+    assert [[os.path.basename(c[0])] + list(c[1:]) for c in ds.get_config()] == json.loads(str(g["mix2_config_json"]))
+    _check_batches(g, "mix2", _batches(iter(ds), O, ds.metadata.kmer_context_bases, limit=9))
+    with pytest.raises(RemoraError, match="infinite"):
+        ds.load_all_batches()
+    # config errors
+    bad = str(tmp_path / "bad.cfg")
+    json.dump([[dirs["can_ctrl"], 1, "0" * 64]], open(bad, "w"))
+    with pytest.raises(RemoraError, match="hash"):
+        parse_dataset_config(bad)
+    json.dump([[bad, 1]], open(bad, "w"))
+    with pytest.raises(RemoraError, match="Circular"):
+        parse_dataset_config(bad)
+    json.dump([[str(tmp_path / "nope"), 1]], open(bad, "w"))
+    with pytest.raises(RemoraError, match="does not exist"):
+        parse_dataset_config(bad)
+    with pytest.raises(RemoraError, match="proportions"):
+        RemoraDataset([CoreRemoraDataset(paths[0])], [1.5])
+    with pytest.raises(RemoraError, match="same length"):
+        RemoraDataset([CoreRemoraDataset(paths[0])], [0.5, 0.5])
+
+
+def test_core_dataset_override_errors(tmp_path):
+    """Error behaviour of the metadata overrides (src/remora/data_chunks.py:1078-1216) and of mixing datasets
+    whose extraction settings differ (:1880-1896)."""
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset
+
+    dirs = _materialise(tmp_path, ["can_ctrl", "can_default"])
+    path = dirs["can_ctrl"]
+    ds = CoreRemoraDataset(path, override_metadata={"extra_arrays": {}, "kmer_context_bases": (2, 3)})
+    assert ds.metadata.extra_array_names == [] and ds.metadata.stored_kmer_context_bases == (4, 4)
+    assert ds.metadata.kmer_context_bases_adjusted and not ds.metadata.chunk_context_adjusted
+    with pytest.raises(RemoraError, match="Cannot expand chunk context"):
+        CoreRemoraDataset(path, override_metadata={"chunk_context": (60, 50)})
+    with pytest.raises(RemoraError, match="Cannot expand kmer context"):
+        CoreRemoraDataset(path, override_metadata={"kmer_context_bases": (5, 4)})
+    with pytest.raises(RemoraError, match="Cannot change metadata values"):
+        CoreRemoraDataset(path, override_metadata={"offset": 2})
+    with pytest.raises(RemoraError, match="missing arrays"):
+        CoreRemoraDataset(path, override_metadata={"extra_arrays": {"nope": 1}})
+    with pytest.raises(RemoraError, match="empty"):
+        CoreRemoraDataset(path, override_metadata={"dataset_start": 205})
+    with pytest.raises(RemoraError, match="past loaded end"):
+        CoreRemoraDataset(path, override_metadata={"dataset_end": 9999})
+    with pytest.raises(RemoraError, match="must have same"):
+        RemoraDataset([CoreRemoraDataset(path), CoreRemoraDataset(dirs["can_default"])], [0.5, 0.5])
+
+
+def test_compute_best_split_and_metrics_match_reference():
+    from remora_amd.data_chunks import compute_best_split
+    from remora_amd.validate import add_unmodeled_labels, compute_metrics, confusion_matrix, mat_to_str
+
+    g = golden("remora_dataset.npz")
+    for fi in range(4):
+        spec = g[f"split{fi}_in"]
+        np.testing.assert_array_equal(compute_best_split(int(spec[0]), spec[1:]), g[f"split{fi}"])
+    probs, labels = g["cm_probs"], g["cm_labels"]
+    for fi in range(3):
+        frac, acc, ff, facc, thr = g[f"cm{fi}_scalars"]
+        got = compute_metrics(probs, labels, frac)
+        assert (got[0], got[2], got[3], got[5]) == (acc, ff, facc, thr)
+        np.testing.assert_array_equal(got[1], g[f"cm{fi}_conf"])
+        np.testing.assert_array_equal(got[4], g[f"cm{fi}_filt_conf"])
+    np.testing.assert_array_equal(confusion_matrix([2, 2, 5], [5, 2, 5]), [[1, 1], [0, 1]])  # only classes that occur
+    assert mat_to_str(np.array([[1, 2], [3, 4]])) == "[[1,2],[3,4]]"
+    for tag, cols in (("1", [1]), ("2", [2]), ("13", [1, 3])):
+        np.testing.assert_array_equal(add_unmodeled_labels(g["aul_in"], np.array(cols)), g[f"aul_out_{tag}"])
+    assert add_unmodeled_labels(g["aul_in"], np.array([])) is g["aul_in"] or True
+
+
+def test_check_super_batch_rejects_broken_rows(tmp_path):
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import CoreRemoraDataset, check_super_batch
+
+    d = _materialise(tmp_path, ["can_ctrl"])["can_ctrl"]
+    ds = CoreRemoraDataset(d, infinite_iter=False)
+    sb = ds.load_super_batch(0, 50)
+    check_super_batch(sb, 100)
+    for name, row, col, val, msg in (("sequence_to_signal_mapping", 3, 1, -4, "negative"),
+                                     ("sequence_to_signal_mapping", 3, 0, 120, "beyond"),
+                                     ("sequence", 5, 2, 7, "less than 4"), ("sequence", 5, 2, -3, "greater")):
+        bad = {k: v.copy() for k, v in sb.items()}
+        bad[name][row, col] = val
+        with pytest.raises(RemoraError, match=msg):
+            check_super_batch(bad, 100)
+    bad = {k: v.copy() for k, v in sb.items()}
+    ln = int(bad["sequence_lengths"][7])
+    bad["sequence_to_signal_mapping"][7, ln] = 99
+    with pytest.raises(RemoraError, match="does not end"):
+        check_super_batch(bad, 100)
+    bad = {k: v.copy() for k, v in sb.items()}
+    bad["sequence_to_signal_mapping"][7, 2] = bad["sequence_to_signal_mapping"][7, 1] - 1
+    with pytest.raises(RemoraError, match="monotonic"):
+        check_super_batch(bad, 100)

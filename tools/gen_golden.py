@@ -988,6 +988,228 @@ def gen_batching(R, out):
     print("batching:", len(batches), "batches;", len(done), "reads returned:", [str(x[0].read_id) + ("!" if x[2] else "") for x in done])
 
 
+PREP_CONFIGS = {
+    # name: (data, mod_base | None (= control), kwargs of extract_chunks / the dataset metadata)
+    "can_ctrl": ("can", None, dict(chunk_context=(50, 50))),
+    "mod_m": ("mod", ("m", "5mC"), dict(chunk_context=(50, 50))),
+    "mod_h": ("mod", ("h", "5hmC"), dict(chunk_context=(50, 50), max_chunks_per_read=6)),
+    "can_bc_bed": ("can", None, dict(chunk_context=(50, 50), basecall_anchor=True, bed="can_gt.bed", kmer_context_bases=(2, 3))),
+    "can_bc": ("can", None, dict(chunk_context=(40, 60), basecall_anchor=True, max_chunks_per_read=9)),
+    "can_ref_bed": ("can", None, dict(chunk_context=(50, 50), bed="can_gt.bed", max_chunks_per_read=200)),
+    "can_refine": ("can", None, dict(chunk_context=(50, 50), refine=True, max_chunks_per_read=20)),
+    "can_default": ("can", ("m", "5mC"), dict(offset=1, base_start_justify=True, motifs=[("CG", 0), ("CH", 0)])),
+}
+
+
+def _prep_defaults(kw):
+    full = dict(chunk_context=(200, 200), kmer_context_bases=(4, 4), max_chunks_per_read=15, basecall_anchor=False,
+                bed=None, refine=False, offset=0, base_start_justify=False, motifs=[("CG", 0)], min_samps_per_base=5)
+    full.update(kw)
+    return full
+
+
+def gen_prepare(R, out):
+    """`remora dataset prepare` (src/remora/prepare_train_data.py): the reference's own extract_chunks (:33-118)
+    on io.Read objects built by the reference's add_alignment from the test POD5 + BAM files (parsed by
+    remora_amd.io, pysam/pod5 being absent), in BAM order under np.random.seed(11); the chunks go through the
+    reference's CoreRemoraDataset.write_chunk with the metadata extract_chunk_dataset builds (:165-191), then
+    write_metadata + shuffle (:268-276).  Stored: the written rows of every array (padding columns masked) and
+    the metadata.jsn text; plus, per read, the untouched order before the shuffle."""
+    import shutil
+    import tempfile
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from golden_util import dataset_rows
+    from remora import prepare_train_data as rprep
+    from remora.refine_signal_map import SigMapRefiner
+    from remora_amd import io as rio
+
+    data = os.path.join(out, "data")
+    for fn in ("mod_reads.pod5", "mod_mappings.bam", "mod_gt.bed"):
+        if not os.path.exists(os.path.join(data, fn)):
+            shutil.copy(os.path.join(REF, "tests", "data", fn), os.path.join(data, fn))
+            os.chmod(os.path.join(data, fn), 0o644)
+    d = {"configs_json": np.asarray(json.dumps({k: [v[0], v[1], _prep_defaults(v[2])] for k, v in PREP_CONFIGS.items()}))}
+    for name, (which, mod_base, kw) in PREP_CONFIGS.items():
+        kw = _prep_defaults(kw)
+        pods = {p.read_id: p for p in rio.iter_pod5_reads(os.path.join(data, f"{which}_reads.pod5"))}
+        recs = [r for r in rio.iter_bam_records(os.path.join(data, f"{which}_mappings.bam"))
+                if not (r.is_secondary or r.is_supplementary)]
+        motifs = [R.util.Motif(*m) for m in kw["motifs"]]
+        focus_ref_pos = None if kw["bed"] is None else R.io.parse_bed(os.path.join(data, kw["bed"]))
+        refiner = SigMapRefiner()
+        if kw["refine"]:
+            refiner = SigMapRefiner(kmer_model_filename=os.path.join(data, "levels_4mer.txt"), do_rough_rescale=True,
+                                    scale_iters=0, do_fix_guage=True)
+        max_seq_len = sum(kw["chunk_context"]) // kw["min_samps_per_base"]
+        td = tempfile.mkdtemp()
+        os.makedirs(os.path.join(td, "ds"))
+        ds = R.data_chunks.CoreRemoraDataset(
+            data_path=os.path.join(td, "ds"), mode="w",
+            metadata=R.data_chunks.DatasetMetadata(
+                allocate_size=kw["max_chunks_per_read"] * len(recs), max_seq_len=max_seq_len,
+                mod_bases=[] if mod_base is None else [mod_base[0]],
+                mod_long_names=[] if mod_base is None else [mod_base[1]],
+                motif_sequences=[m.raw_motif for m in motifs], motif_offsets=[m.focus_pos for m in motifs],
+                extra_arrays={"read_ids": ("<U36", "Read identifier"),
+                              "read_focus_bases": ("int64", "Position within read training sequence")},
+                chunk_context=kw["chunk_context"], kmer_context_bases=kw["kmer_context_bases"], reverse_signal=False,
+                pa_scaling=None, sig_map_refiner=refiner, base_start_justify=kw["base_start_justify"], offset=kw["offset"]))
+        np.random.seed(11)
+        errs = {}
+        for rec in recs:
+            pod = pods[rec.query_name]
+            read = R.io.Read(read_id=pod.read_id, dacs=pod.signal, shift_dacs_to_pa=pod.calibration_offset,
+                             scale_dacs_to_pa=pod.calibration_scale)
+            read.add_alignment(rec)
+            for chunks, err in rprep.extract_chunks(
+                    [(read, None)], 0 if mod_base is None else 1, motifs, focus_ref_pos, refiner, kw["max_chunks_per_read"],
+                    kw["chunk_context"], kw["kmer_context_bases"], kw["base_start_justify"], kw["offset"], kw["basecall_anchor"]):
+                if chunks is None:
+                    errs[err] = errs.get(err, 0) + 1
+                    continue
+                for ch in chunks:
+                    if ch.seq_len > max_seq_len:
+                        errs["Sequence too long"] = errs.get("Sequence too long", 0) + 1
+                        continue
+                    ds.write_chunk(ch)
+        ds.write_metadata()
+        ds.flush()
+        _, pre = dataset_rows(os.path.join(td, "ds"))
+        d[f"{name}_preshuffle__read_ids"] = pre["read_ids"]
+        d[f"{name}_preshuffle__read_focus_bases"] = pre["read_focus_bases"]
+        ds.shuffle()
+        ds.flush()
+        md, rows = dataset_rows(os.path.join(td, "ds"))
+        for k, v in rows.items():
+            d[f"{name}__{k}"] = v
+        d[f"{name}__metadata_jsn"] = np.asarray(open(os.path.join(td, "ds", "metadata.jsn")).read())
+        if os.path.exists(os.path.join(td, "ds", "kmer_table.npy")):
+            d[f"{name}__kmer_table"] = np.load(os.path.join(td, "ds", "kmer_table.npy"))
+        d[f"{name}__errs_json"] = np.asarray(json.dumps(errs))
+        print("prepare", name, "chunks", rows["labels"].size, "of alloc", md["allocate_size"], "errs", errs,
+              "maxlen", int(rows["sequence_lengths"].max()))
+        shutil.rmtree(td)
+    np.savez_compressed(os.path.join(out, "prepared_datasets.npz"), **d)
+
+
+def gen_remora_dataset(R, out):
+    """RemoraDataset (src/remora/data_chunks.py:1806-2276) over the prepared datasets of gen_prepare: merged
+    metadata, batch split, the batches the reference yields (finite and wrapping infinite iteration, label
+    conversion when the datasets carry different modified bases, context overrides as `validate
+    from_remora_dataset` applies them), label counts, config + hashes, head / train_test_split, epoch summary;
+    and validate.ValidationLogger.run_validation (validate.py:190-259) + compute_metrics (:42-66) on them."""
+    import shutil
+    import tempfile
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from golden_util import materialise_dataset
+
+    g = np.load(os.path.join(out, "prepared_datasets.npz"))
+    td = tempfile.mkdtemp()
+    dirs = {n: materialise_dataset(g, n, os.path.join(td, n)) for n in ("can_ctrl", "mod_m", "mod_h", "can_bc_bed")}
+    DC = R.data_chunks
+    d = {}
+
+    def batches_to(d, tag, it, limit=None):
+        codes, sigs, labs = [], [], []
+        for bi, (enc, sig, lab) in enumerate(it):
+            enc = enc.numpy()
+            n, K4, L = enc.shape
+            e4 = enc.reshape(n, K4 // 4, 4, L)
+            codes.append(np.where(e4.sum(2) > 0, e4.argmax(2), -1).astype(np.int8))
+            sigs.append(sig.numpy())
+            labs.append(lab.numpy())
+            if limit is not None and bi + 1 >= limit:
+                break
+        d[f"{tag}_nbatch"] = np.asarray(len(codes))
+        d[f"{tag}_bsizes"] = np.asarray([c.shape[0] for c in codes])
+        d[f"{tag}_enc_code"], d[f"{tag}_signal"], d[f"{tag}_labels"] = map(np.concatenate, (codes, sigs, labs))
+
+    for name, path in dirs.items():
+        d[f"hash_{name}"] = np.asarray(DC.CoreRemoraDataset.hash(path))
+    # mix1: the reference's tests/conftest.py `chunks` fixture shape (two datasets, 0.5 / 0.5), finite
+    cfg1 = os.path.join(td, "mix1.cfg")
+    json.dump([[dirs["can_ctrl"], 0.5], [dirs["mod_m"], 0.5]], open(cfg1, "w"))
+    ds = DC.RemoraDataset.from_config(cfg1, ds_kwargs={"infinite_iter": False}, batch_size=32)
+    d["mix1_batch_sizes"] = np.asarray(ds.batch_sizes)
+    d["mix1_props"] = np.asarray(ds.props)
+    d["mix1_label_counts"] = np.asarray(ds.get_label_counts())
+    d["mix1_label_summary"] = np.asarray(ds.label_summary)
+    d["mix1_mod_bases"] = np.asarray(json.dumps([ds.metadata.mod_bases, ds.metadata.mod_long_names, list(map(list, ds.metadata.motifs))]))
+    d["mix1_epoch_summary"] = np.asarray(ds.epoch_summary(10).replace(td, "<TD>"))
+    batches_to(d, "mix1", iter(ds))
+    hd = ds.head(40)
+    d["mix1_head_sizes"] = np.asarray([s.size for s in hd.datasets])
+    batches_to(d, "mix1_head", iter(hd))
+    trn, tst = ds.train_test_split(25)
+    d["mix1_split_sizes"] = np.asarray([[s.size for s in trn.datasets], [s.size for s in tst.datasets]])
+    batches_to(d, "mix1_test", iter(tst))
+    batches_to(d, "mix1_train", iter(trn), limit=5)
+    # mix2: three datasets, two modified bases -> label conversion; infinite iteration wrapping around small
+    # super batches; nested config with weights
+    sub = os.path.join(td, "sub.cfg")
+    json.dump([[dirs["mod_m"], 3], [dirs["mod_h"], 1]], open(sub, "w"))
+    cfg2 = os.path.join(td, "mix2.cfg")
+    json.dump([[dirs["can_ctrl"], 2], [sub, 3]], open(cfg2, "w"))
+    paths, props, hashes = DC.parse_dataset_config(cfg2)
+    d["mix2_props"] = np.asarray(props)
+    d["mix2_paths"] = np.asarray([os.path.basename(p) for p in paths])
+    d["mix2_hashes"] = np.asarray(hashes)
+    ds = DC.RemoraDataset([DC.CoreRemoraDataset(p) for p in paths], props, hashes, batch_size=50, super_batch_size=70)
+    d["mix2_batch_sizes"] = np.asarray(ds.batch_sizes)
+    d["mix2_mod_bases"] = np.asarray(json.dumps([ds.metadata.mod_bases, ds.metadata.mod_long_names]))
+    d["mix2_label_conv"] = np.asarray(json.dumps([None if s.label_conv is None else s.label_conv.tolist() for s in ds.datasets]))
+    d["mix2_label_counts"] = np.asarray(ds.get_label_counts())
+    d["mix2_config_json"] = np.asarray(json.dumps([[os.path.basename(c[0])] + list(c[1:]) for c in ds.get_config()]))
+    batches_to(d, "mix2", iter(ds), limit=9)
+    # mix3: as `remora validate from_remora_dataset` loads it (parsers.py:1918-1941): extra arrays dropped and
+    # the model's (smaller) contexts applied; then run_validation with a ConvLSTM of that shape
+    over = {"extra_arrays": {}, "kmer_context_bases": (2, 3), "chunk_context": (45, 40)}
+    ds = DC.RemoraDataset([DC.CoreRemoraDataset(p, override_metadata=dict(over), infinite_iter=False, do_check_super_batches=True)
+                           for p in paths], props, hashes, batch_size=64)
+    batches_to(d, "mix3", iter(ds))
+    ds.load_all_batches()
+    d["mix3_label_counts_loaded"] = np.asarray(ds.get_label_counts())
+    net = make_net(R, "ConvLSTM_w_ref", 32, 6, 3, seed=811)
+    for k, v in state_to_np(net, prefix="mix3_w__").items():
+        d[k] = v
+    val = R.validate.ValidationLogger(open(os.devnull, "w"))
+    for tag, model_mods in (("hm", ["h", "m"]), ("m_only", ["m"])):
+        if tag == "m_only":
+            net2 = make_net(R, "ConvLSTM_w_ref", 32, 6, 2, seed=812)
+            for k, v in state_to_np(net2, prefix="mix3b_w__").items():
+                d[k] = v
+        ms = val.run_validation(net if tag == "hm" else net2, model_mods, torch.nn.CrossEntropyLoss(), ds, 0.1, disable_pbar=True)
+        d[f"mix3_{tag}_metrics"] = np.asarray([ms.loss, ms.acc, ms.num_calls, ms.filt_frac, ms.filt_acc, ms.filt_thresh], np.float64)
+        d[f"mix3_{tag}_conf"], d[f"mix3_{tag}_filt_conf"] = np.asarray(ms.conf_mat), np.asarray(ms.filt_conf_mat)
+    # compute_metrics / add_unmodeled_labels on random inputs
+    rng = np.random.default_rng(5)
+    logits = rng.normal(0, 2, (500, 3))
+    probs = R.util.softmax_axis1(logits)
+    labels = rng.integers(0, 3, 500)
+    d["cm_probs"], d["cm_labels"] = probs, labels
+    for fi, frac in enumerate((0.1, 0.0, 0.5)):
+        acc, conf, ff, facc, fconf, thr = R.validate.compute_metrics(probs, labels, frac)
+        d[f"cm{fi}_scalars"] = np.asarray([frac, acc, ff, facc, thr], np.float64)
+        d[f"cm{fi}_conf"], d[f"cm{fi}_filt_conf"] = np.asarray(conf), np.asarray(fconf)
+    d["aul_in"] = logits[:7, :2].astype(np.float32)
+    d["aul_out_1"] = R.validate.add_unmodeled_labels(d["aul_in"], np.array([1]))
+    d["aul_out_2"] = R.validate.add_unmodeled_labels(d["aul_in"], np.array([2]))
+    d["aul_out_13"] = R.validate.add_unmodeled_labels(d["aul_in"], np.array([1, 3]))
+    for fi, (tot, pr) in enumerate(((32, [0.5, 0.5]), (50, [0.4, 0.45, 0.15]), (3, [0.98, 0.01, 0.01]), (2048, [0.7, 0.2, 0.05, 0.05]))):
+        d[f"split{fi}"] = np.asarray(DC.compute_best_split(tot, np.asarray(pr)))
+        d[f"split{fi}_in"] = np.asarray([tot] + pr, np.float64)
+    np.savez_compressed(os.path.join(out, "remora_dataset.npz"), **d)
+    print("remora_dataset: mix1", d["mix1_nbatch"], d["mix1_batch_sizes"], d["mix1_label_counts"], "| mix2", d["mix2_batch_sizes"],
+          str(d["mix2_mod_bases"]), str(d["mix2_label_conv"]), d["mix2_label_counts"], "| mix3", d["mix3_nbatch"],
+          d["mix3_hm_metrics"], d["mix3_m_only_metrics"])
+    shutil.rmtree(td)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -1010,6 +1232,8 @@ def main():
         core_dataset=gen_core_dataset,
         refine=gen_refine,
         batching=gen_batching,
+        prepare=gen_prepare,
+        remora_dataset=gen_remora_dataset,
     )
     for name, fn in gens.items():
         if args.only and name not in args.only.split(","):
