@@ -353,6 +353,13 @@ def main():
 
         vbz_leg = bench_vbz.measure(n_rows=4096, row_samples=102400, steps=3, warmup=1, cpu_rows=8, device=local)
 
+    # ---- dataset ETL: validate from an on-disk dataset, dataset prepare from aligned reads ----
+    dataset_leg = None
+    if rank == 0 and world == 1 and not args.no_refine:
+        import bench_dataset
+
+        dataset_leg = bench_dataset.measure(n_chunks=1 << 20, n_reads=2048, n_bases=5000, device=local)
+
     # ---- comparison leg: same job on the bf16 matrix cores with 3-part split operands (bf16x6) ----
     alt, alt_head = None, None
     if rank == 0 and world == 1 and args.dtype == "fp32" and arch == "conv_lstm" and not args.no_alt:
@@ -428,6 +435,7 @@ def main():
         "reads_pipeline": reads_leg,
         "refine_signal_map": refine_leg,
         "vbz_decode": vbz_leg,
+        "dataset_etl": dataset_leg,
         "label_counts": [int(x) for x in counts.tolist()],
     }
     if world == 1 and not args.no_cpu_baseline:

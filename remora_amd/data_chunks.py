@@ -823,6 +823,7 @@ class CoreRemoraDataset:
                 if "mod_bases" not in self.override_metadata:
                     raise RemoraError("mod_bases and mod_long_names must be overridden together")
             elif key == "extra_arrays":
+                val = {} if val is None else val  # (the reference needs a dict here; None = no extra arrays)
                 missing = set(val).difference(loaded["extra_arrays"] or {})
                 if missing:
                     raise RemoraError(f"Cannot load missing arrays: {', '.join(sorted(missing))}\nAvailable extra "
@@ -1025,9 +1026,11 @@ class CoreRemoraDataset:
                                        b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"])
         return b
 
-    def load_super_batch(self, offset=0, size=None, select_num_chunks=None):
-        """`size` rows from `offset` (relative to dataset_start) as writable arrays: wraps around the end for
-        infinite iteration, returns a short last batch otherwise, None past the end (:1578-1633)."""
+    def load_super_batch(self, offset=0, size=None, select_num_chunks=None, copy=True):
+        """`size` rows from `offset` (relative to dataset_start): wraps around the end for infinite iteration,
+        returns a short last batch otherwise, None past the end (:1578-1633).  With copy=False arrays that need
+        no rewriting (trimming, label conversion) stay read-only views of the memmaps - the fused GPU path
+        uploads straight from them."""
         md = self.metadata
         if self.infinite_iter:
             offset %= self.size
@@ -1041,14 +1044,20 @@ class CoreRemoraDataset:
         if size > self.size:
             raise RemoraError("Super batch larger than dataset requested")
         en = st + size
+        rewritten = set()
+        if md.kmer_context_bases_adjusted and md.stored_kmer_context_bases[0] > md.kmer_context_bases[0]:
+            rewritten.add("sequence")
+        if md.chunk_context_adjusted:
+            rewritten.update(("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths"))
+        take = (lambda n, a: np.array(a)) if copy else (lambda n, a: np.array(a) if n in rewritten else a)
         if en <= md.dataset_end:
-            sb = {n: np.array(self.arrays[n][st:en]) for n in self.array_names}
+            sb = {n: take(n, self.arrays[n][st:en]) for n in self.array_names}
         elif self.infinite_iter:
             wrap = en - self.size
             sb = {n: np.concatenate([self.arrays[n][st : md.dataset_end], self.arrays[n][md.dataset_start : wrap]])
                   for n in self.array_names}
         else:
-            sb = {n: np.array(self.arrays[n][st : md.dataset_end]) for n in self.array_names}
+            sb = {n: take(n, self.arrays[n][st : md.dataset_end]) for n in self.array_names}
         if select_num_chunks is not None:
             pick = np.random.choice(sb["labels"].size, min(select_num_chunks, sb["labels"].size), replace=False)
             sb = {n: a[pick] for n, a in sb.items()}
@@ -1064,12 +1073,12 @@ class CoreRemoraDataset:
         finally:
             self.infinite_iter = keep
 
-    def iter_super_batches(self, select_num_chunks=None):
+    def iter_super_batches(self, select_num_chunks=None, copy=True):
         num = 0
         while True:
             self.refresh_memmaps()
             sb = self.load_super_batch(self.super_batch_offset + num * self.super_batch_size, self.super_batch_size,
-                                       select_num_chunks=select_num_chunks)
+                                       select_num_chunks=select_num_chunks, copy=copy)
             if sb is None:
                 return
             if self.do_check_super_batches:
@@ -1090,10 +1099,10 @@ class CoreRemoraDataset:
                 batch["sequence_lengths"])
         return batch
 
-    def iter_batches(self, max_batches=None, enc_kmers=False):
+    def iter_batches(self, max_batches=None, enc_kmers=False, copy=True):
         chunks_per_sb, select = self.adjust_batch_params()
         num = 0
-        for sb in self.iter_super_batches(select):
+        for sb in self.iter_super_batches(select, copy=copy):
             for st in range(0, chunks_per_sb, self.batch_size):
                 if st >= sb["sequence"].shape[0]:  # short last super batch of a finite dataset
                     break
@@ -1314,14 +1323,16 @@ class RemoraDataset:
                                                   "dataset_end": ds.metadata.dataset_start + n}, infinite_iter=False)
         return RemoraDataset(heads, **self.init_kwargs)
 
-    def _set_sub_ds_iters(self, enc_kmers):
+    def _set_sub_ds_iters(self, enc_kmers, copy=True):
         for ds, bs, off in zip(self.datasets, self.batch_sizes, self.super_batch_offsets):
             ds.batch_size, ds.super_batch_offset = int(bs), int(off)
             ds.super_batch_size, ds.super_batch_sample_frac = self.super_batch_size, self.super_batch_sample_frac
-        self._ds_iters = [ds.iter_batches(enc_kmers=enc_kmers) for ds in self.datasets]
+        self._ds_iters = [ds.iter_batches(enc_kmers=enc_kmers, copy=copy) for ds in self.datasets]
 
     @staticmethod
     def _concat(name, parts):
+        if len(parts) == 1:
+            return parts[0]
         if name in ("sequence", "sequence_to_signal_mapping"):  # datasets may differ in max_seq_len
             width = max(p.shape[1] for p in parts)
             fill = -1 if name == "sequence" else 0
@@ -1329,18 +1340,25 @@ class RemoraDataset:
                      for p in parts]
         return np.concatenate(parts)
 
-    def iter_batches(self, return_arrays=None):
-        """Batches until any core dataset runs out (never, when all iterate infinitely) (:2135-2149)."""
+    def iter_numpy_batches(self, return_arrays=None, copy=False):
+        """Batches as lists of numpy arrays until any core dataset runs out.  With copy=False (default here) a
+        single-dataset batch whose rows need no rewriting is a read-only view of the memmaps: nothing is copied
+        on the host between the page cache and the upload."""
         names = tuple(return_arrays) if return_arrays is not None else self.return_arrays
         if self._ds_iters is None:
-            self._set_sub_ds_iters("enc_kmers" in names)
-        torch = _torch()
+            self._set_sub_ds_iters("enc_kmers" in names, copy=copy)
         while True:
             try:
                 parts = [next(it) for it in self._ds_iters]
             except StopIteration:
                 return
-            yield [torch.from_numpy(np.ascontiguousarray(self._concat(n, [p[n] for p in parts]))) for n in names]
+            yield [self._concat(n, [p[n] for p in parts]) for n in names]
+
+    def iter_batches(self, return_arrays=None):
+        """Batches as lists of torch tensors, the reference's element type (:2135-2149)."""
+        torch = _torch()
+        for arrays in self.iter_numpy_batches(return_arrays, copy=True):
+            yield [torch.from_numpy(np.ascontiguousarray(a)) for a in arrays]
 
     def load_all_batches(self):
         if self.infinite_iter:

@@ -51,6 +51,32 @@ def softmax_axis1(x):
         return e_x / e_x.sum(axis=1, keepdims=True)
 
 
+_PATTERNS = {}
+
+
+def _int_pattern(raw_motif):
+    """Per motif position the array of allowed base codes (cached per motif string)."""
+    if raw_motif not in _PATTERNS:
+        pats = [np.array([CAN_ALPHABET.index(b) for b in SINGLE_LETTER_CODE[c]]) for c in raw_motif]
+        luts = []
+        for p in pats:
+            lut = np.zeros(5, dtype=bool)
+            lut[p] = True
+            luts.append(lut)
+        _PATTERNS[raw_motif] = (pats, luts, [frozenset(p.tolist()) for p in pats])
+    return _PATTERNS[raw_motif][0]
+
+
+def _allowed_lut(raw_motif):
+    _int_pattern(raw_motif)
+    return _PATTERNS[raw_motif][1]
+
+
+def _allowed_sets(raw_motif):
+    _int_pattern(raw_motif)
+    return _PATTERNS[raw_motif][2]
+
+
 @dataclass
 class Motif:
     """IUPAC motif + focus position (src/remora/util.py:190-378, the subset the hot path
@@ -101,7 +127,7 @@ class Motif:
 
     @property
     def int_pattern(self):
-        return [np.array([CAN_ALPHABET.index(b) for b in SINGLE_LETTER_CODE[c]]) for c in self.raw_motif]
+        return _int_pattern(self.raw_motif)
 
     def findall(self, int_seq):
         """Start index of every (overlapping) hit in an integer sequence."""
@@ -110,20 +136,20 @@ class Motif:
         if nwin <= 0:
             return np.zeros(0, dtype=np.int64)
         hit = np.ones(nwin, dtype=bool)
-        for po, allowed in enumerate(self.int_pattern):
-            hit &= np.isin(int_seq[po : po + nwin], allowed)
+        for po, allowed in enumerate(_allowed_lut(self.raw_motif)):
+            hit &= allowed[int_seq[po : po + nwin]]  # 5-entry table; index -1 (= N) is never allowed
         return np.flatnonzero(hit)
 
     def match(self, int_seq, pos):
         """Does the motif sit on `pos`?  A motif hanging over either end of the sequence is compared on the
         overlapping part only, as the reference does (src/remora/util.py:297-311)."""
-        pat = self.int_pattern
+        pat = _allowed_sets(self.raw_motif)
         st, en = pos - self.focus_pos, pos + self.num_bases_after_focus + 1
         if st < 0:
             pat, st = pat[-st:], 0
         if en > int_seq.size:
             pat, en = pat[: len(pat) - en + int_seq.size], int_seq.size
-        return all(base in allowed for allowed, base in zip(pat, int_seq[st:en]))
+        return all(base in allowed for allowed, base in zip(pat, int_seq[st:en].tolist()))
 
     @property
     def possible_kmers(self):

@@ -105,22 +105,24 @@ class ValidationLogger:
         names = _RAW if fused else ("enc_kmers", "signal", "labels")
         dataset._ds_iters = None
         all_out, all_lab, losses = [], [], []
-        for batch in dataset.iter_batches(return_arrays=names):
+        for batch in dataset.iter_numpy_batches(return_arrays=names, copy=not fused):
             b = dict(zip(names, batch))
-            if fused:
-                out = model.infer_chunks(b["signal"].numpy(), b["sequence"].numpy(), b["sequence_to_signal_mapping"].numpy(),
-                                         b["sequence_lengths"].numpy(), md.kmer_context_bases)
+            labels = np.asarray(b["labels"])
+            if fused:  # stored rows straight into the fused kernels (uploaded from the memmaps when untouched)
+                out = model.infer_chunks(b["signal"], b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"],
+                                         md.kmer_context_bases)
                 out = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
             else:
                 device = next(model.parameters()).device
                 with torch.no_grad():
-                    out = model(b["signal"].to(device), b["enc_kmers"].to(device)).detach().cpu().numpy()
+                    out = model(torch.from_numpy(b["signal"]).to(device), torch.from_numpy(b["enc_kmers"]).to(device))
+                out = out.detach().cpu().numpy()
             out = add_unmodeled_labels(out, unmodeled)
             all_out.append(out)
-            all_lab.append(b["labels"].numpy())
-            losses.append(criterion(torch.from_numpy(out), b["labels"]).detach().cpu().numpy())
+            all_lab.append(labels)
+            losses.append(criterion(torch.from_numpy(out), torch.from_numpy(np.array(labels))).detach().cpu().numpy())
             if self.full_fh is not None:
-                self.write_full_results(out, all_lab[-1])
+                self.write_full_results(out, labels)
         dataset._ds_iters = None
         out, labels = np.concatenate(all_out, axis=0), np.concatenate(all_lab)
         acc, conf, ff, facc, fconf, thr = compute_metrics(softmax_axis1(out), labels, filt_frac)
