@@ -215,10 +215,9 @@ def find_focus_bases_in_int_sequence(int_seq, motifs):
     it (src/remora/util.py:413-426); chunk order downstream follows that iteration order, so
     it is reproduced here the same way."""
     hits = set()
-    for mot in motifs:
-        for pos in mot.findall(int_seq):
-            hits.add(pos + mot.focus_pos)
-    return np.fromiter(hits, int)
+    for mot in motifs:  # list -> set.update inserts one by one in list order, like the reference's generator
+        hits.update((mot.findall(int_seq) + mot.focus_pos).tolist())
+    return np.fromiter(hits, int, len(hits))
 
 
 def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
