@@ -884,3 +884,23 @@ def test_check_super_batch_rejects_broken_rows(tmp_path):
     bad["sequence_to_signal_mapping"][7, 2] = bad["sequence_to_signal_mapping"][7, 1] - 1
     with pytest.raises(RemoraError, match="monotonic"):
         check_super_batch(bad, 100)
+
+
+def test_map_ref_to_signal_known_answers_of_the_reference_tests():
+    """The known-answer vectors the reference's own tests hold for data_chunks.map_ref_to_signal
+    (tests/test_duplex.py:57-251; query_to_signal = arange(len(simplex)), knots = the duplex-to-simplex map):
+    (simplex length, first knot, number of knots) -> expected signal coordinates."""
+    from remora_amd.data_chunks import map_ref_to_signal
+
+    cases = [
+        (16, 5, 12, [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 15]),    # extra simplex sequence at the 5' end
+        (11, 0, 12, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10]),         # simplex missing sequence at the 5' end
+        (11, 2, 10, [2, 3, 4, 5, 6, 7, 8, 9, 10, 10]),               # ... and starting with unpaired sequence
+        (11, 0, 12, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10]),         # missing sequence at the 3' end
+        (13, 0, 12, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]),         # ... with unaligned simplex sequence after it
+        (22, 5, 12, [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]),    # ragged ends, simplex longer
+        (11, 0, 12, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10]),         # ragged ends, duplex longer
+    ]
+    for n, first, count, want in cases:
+        got = map_ref_to_signal(query_to_signal=np.arange(n), ref_to_query_knots=np.arange(first, first + count))
+        np.testing.assert_array_equal(got, want)
