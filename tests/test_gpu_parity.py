@@ -1155,3 +1155,60 @@ def test_dataset_cli_prepare_then_validate(torch_cuda, O, tmp_path):
     # batches of 100 split 49 / 51 until the smaller dataset runs out: 4 full batches + the 9 / 6 remainder
     assert int(f[6]) == conf_mat.sum() and conf_mat.shape == (2, 2) and int(f[6]) >= 300
     assert conf_mat[0].sum() > 100 and conf_mat[1].sum() > 100  # both samples' labels are present
+
+
+def test_reference_etl_tests_known_sizes(torch_cuda, tmp_path):
+    """The reference's own ETL tests, same command lines and the same expected numbers (tests/conftest.py:251-403,
+    tests/test_main.py:23-136): `dataset prepare` on the canonical sample gives 205 chunks all labelled 0, on the
+    modified sample 210 chunks all labelled 1 (also with ChEBI codes as short names); the two-dataset config has
+    label counts [205, 210]; `make_config` over the four datasets has four labels with 205 / 210 / 210 / 210; `dataset
+    inspect --out-path` writes the expanded config."""
+    import subprocess
+    import sys
+
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset
+
+    EXPECTED_CAN_SIZE, EXPECTED_MOD_SIZE = 205, 210
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = os.path.join(root, "tests", "golden", "data")
+
+    def remora(*a):
+        r = subprocess.run([sys.executable, "-m", "remora_amd", *a], cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+
+    def prepare(name, sample, *label_args):
+        out = str(tmp_path / name)
+        remora("dataset", "prepare", os.path.join(data, f"{sample}_reads.pod5"), os.path.join(data, f"{sample}_mappings.bam"),
+               "--output-path", out, *label_args, "--motif", "CG", "0")
+        return out
+
+    can_chunks = prepare("can_chunks", "can", "--mod-base-control")
+    mod_chunks = prepare("mod_chunks", "mod", "--mod-base", "m", "5mC")
+    mod_chebi_chunks = prepare("mod_chebi_chunks", "mod", "--mod-base", "27551", "5-methylcytosine")
+    mod_chebi2_chunks = prepare("mod_chebi2_chunks", "mod", "--mod-base", "76792", "5-hydroxymethylcytosine")
+    ds = CoreRemoraDataset(can_chunks, batch_size=10)  # test_prep_can
+    assert ds.size == EXPECTED_CAN_SIZE and ds.get_label_counts()[0] == EXPECTED_CAN_SIZE
+    assert ds.metadata.chunk_context == (200, 200) and ds.metadata.max_seq_len == 80
+    for path in (mod_chunks, mod_chebi_chunks):  # test_prep_mod, test_prep_mod_chebi
+        ds = CoreRemoraDataset(path, batch_size=10)
+        assert ds.size == EXPECTED_MOD_SIZE and ds.get_label_counts()[1] == EXPECTED_MOD_SIZE
+    chunks = str(tmp_path / "chunks.cfg")  # the `chunks` fixture
+    json.dump([[can_chunks, 0.5], [mod_chunks, 0.5]], open(chunks, "w"))
+    dataset = RemoraDataset.from_config(chunks, batch_size=10)  # test_remora_dataset
+    counts = dataset.get_label_counts()
+    assert counts.size == 2 and dataset.size == EXPECTED_CAN_SIZE + EXPECTED_MOD_SIZE
+    assert counts[0] == EXPECTED_CAN_SIZE and counts[1] == EXPECTED_MOD_SIZE
+    chebi_chunks = str(tmp_path / "chebi.cfg")  # the `chebi_chunks` fixture
+    remora("dataset", "make_config", chebi_chunks, can_chunks, mod_chunks, mod_chebi_chunks, mod_chebi2_chunks)
+    dataset = RemoraDataset.from_config(chebi_chunks, batch_size=10)  # test_remora_dataset_chebi
+    counts = dataset.get_label_counts()
+    assert counts.size == 4 and dataset.size == EXPECTED_CAN_SIZE + 3 * EXPECTED_MOD_SIZE
+    assert list(counts) == [EXPECTED_CAN_SIZE] + [EXPECTED_MOD_SIZE] * 3
+    assert dataset.metadata.mod_bases == ["27551", "76792", "m"]
+    batch = next(iter(dataset))  # every dataset contributes to every batch of 10
+    assert batch[0].shape == (10, 36, 400) and batch[1].shape == (10, 1, 400) and batch[2].shape == (10,)
+    for cfg in (chunks, chebi_chunks):  # test_dataset_inspect, test_chebi_dataset_inspect
+        out_cfg = str(tmp_path / "dataset_inspect.cfg")
+        assert "Dataset summary" in remora("dataset", "inspect", cfg, "--out-path", out_cfg)
+        assert len(json.load(open(out_cfg))) == (2 if cfg == chunks else 4)
