@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <thread>
+#include <algorithm>
 
 #include "rmr_internal.h"
 
@@ -35,6 +37,24 @@ using namespace rmr;
 // =========================================================================================
 // engine
 // =========================================================================================
+int rmr_engine::ensure_pinned(size_t bytes) {
+    if (bytes <= pinned_cap) return 0;
+    if (pinned) {
+        RMR_HIP(hipStreamSynchronize(aux));
+        RMR_HIP(hipHostFree(pinned));
+        pinned = nullptr;
+        pinned_cap = 0;
+    }
+    hipError_t err = hipHostMalloc(&pinned, bytes, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        pinned = nullptr;
+        set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return RMR_ERR_HIP;
+    }
+    pinned_cap = bytes;
+    return 0;
+}
+
 int rmr_engine::ensure(Arena &a, size_t bytes) {
     if (bytes <= a.cap) return 0;
     if (a.ptr) {
@@ -119,6 +139,7 @@ int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
     for (int k = 0; k < 2; ++k) {
         RMR_HIP(hipEventCreateWithFlags(&e->ev_front[k], hipEventDisableTiming));
         RMR_HIP(hipEventCreateWithFlags(&e->ev_done[k], hipEventDisableTiming));
+        RMR_HIP(hipEventCreateWithFlags(&e->ev_h2d[k], hipEventDisableTiming));
     }
     *out = e.release();
     return 0;
@@ -133,7 +154,9 @@ void rmr_engine_destroy(rmr_engine *e) {
     for (int k = 0; k < 2; ++k) {
         if (e->ev_front[k]) (void)hipEventDestroy(e->ev_front[k]);
         if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
+        if (e->ev_h2d[k]) (void)hipEventDestroy(e->ev_h2d[k]);
     }
+    if (e->pinned) (void)hipHostFree(e->pinned);
     for (auto &r : e->recs) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->act.ptr) (void)hipFree(e->act.ptr);
@@ -1057,11 +1080,50 @@ int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int 
     int16_t *dl = st.take<int16_t>(n);
     float *dlog = st.take<float>((size_t)n * no);
     int64_t *dc = st.take<int64_t>(16);
-    H2D(dsig, signal, n * L * 4);
-    H2D(ds, seqs, (size_t)n * seq_w);
-    H2D(dm, maps, (size_t)n * map_w * 2);
-    H2D(dl, lens, (size_t)n * 2);
-    RMR_TRY(run_pipeline(m, dsig, nullptr, ds, seq_w, dm, map_w, dl, kb, ka, n, dlog));
+    const int64_t hsb = tune_int("RMR_HOST_SUBBATCH", 131072);
+    if (hsb > 0 && n > hsb) {
+        // pipelined upload: the CPU copies sub-batch i+1 into a pinned slot and the aux stream uploads it
+        // while the kernels of sub-batch i run on the main stream
+        const size_t o_seq = Stage::pad((size_t)hsb * L * 4), o_map = o_seq + Stage::pad((size_t)hsb * seq_w);
+        const size_t o_len = o_map + Stage::pad((size_t)hsb * map_w * 2), slot_b = o_len + Stage::pad((size_t)hsb * 2);
+        RMR_TRY(e->ensure_pinned(2 * slot_b));
+        const int nthr = (int)tune_int("RMR_HOST_COPY_THREADS", 4);
+        int64_t idx = 0;
+        for (int64_t c0 = 0; c0 < n; c0 += hsb, ++idx) {
+            const int64_t nb = (n - c0) < hsb ? (n - c0) : hsb;
+            const int slot = (int)(idx & 1);
+            char *pb = reinterpret_cast<char *>(e->pinned) + (size_t)slot * slot_b;
+            if (idx >= 2) RMR_HIP(hipEventSynchronize(e->ev_h2d[slot]));  // the upload that used this slot is done
+            {
+                const char *src = reinterpret_cast<const char *>(signal + (size_t)c0 * L);
+                const size_t bytes = (size_t)nb * L * 4, part = (bytes / nthr + 4095) & ~(size_t)4095;
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nthr; ++t) {
+                    const size_t b0 = (size_t)t * part;
+                    if (b0 < bytes) pool.emplace_back([=] { memcpy(pb + b0, src + b0, std::min(part, bytes - b0)); });
+                }
+                memcpy(pb, src, std::min(part, bytes));
+                memcpy(pb + o_seq, seqs + (size_t)c0 * seq_w, (size_t)nb * seq_w);
+                memcpy(pb + o_map, maps + (size_t)c0 * map_w, (size_t)nb * map_w * 2);
+                memcpy(pb + o_len, lens + c0, (size_t)nb * 2);
+                for (auto &th : pool) th.join();
+            }
+            RMR_HIP(hipMemcpyAsync(dsig + (size_t)c0 * L, pb, (size_t)nb * L * 4, hipMemcpyHostToDevice, e->aux));
+            RMR_HIP(hipMemcpyAsync(ds + (size_t)c0 * seq_w, pb + o_seq, (size_t)nb * seq_w, hipMemcpyHostToDevice, e->aux));
+            RMR_HIP(hipMemcpyAsync(dm + (size_t)c0 * map_w, pb + o_map, (size_t)nb * map_w * 2, hipMemcpyHostToDevice, e->aux));
+            RMR_HIP(hipMemcpyAsync(dl + c0, pb + o_len, (size_t)nb * 2, hipMemcpyHostToDevice, e->aux));
+            RMR_HIP(hipEventRecord(e->ev_h2d[slot], e->aux));
+            RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_h2d[slot], 0));
+            RMR_TRY(run_pipeline(m, dsig + (size_t)c0 * L, nullptr, ds + (size_t)c0 * seq_w, seq_w, dm + (size_t)c0 * map_w,
+                                 map_w, dl + c0, kb, ka, nb, dlog + (size_t)c0 * no));
+        }
+    } else {
+        H2D(dsig, signal, n * L * 4);
+        H2D(ds, seqs, (size_t)n * seq_w);
+        H2D(dm, maps, (size_t)n * map_w * 2);
+        H2D(dl, lens, (size_t)n * 2);
+        RMR_TRY(run_pipeline(m, dsig, nullptr, ds, seq_w, dm, map_w, dl, kb, ka, n, dlog));
+    }
     if (label_counts) {
         H2D(dc, label_counts, (size_t)no * 8);
         RMR_TRY(launch_count(e, dlog, n, no, dc));

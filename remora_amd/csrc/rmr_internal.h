@@ -89,6 +89,12 @@ struct rmr_engine {
     Arena act;      // activations of the fused pipeline
     Arena staging;  // host<->device staging for RMR_MEM_HOST calls
     int ensure(Arena &a, size_t bytes);
+    // pinned host bounce buffers (two slots) + copy-done events: large RMR_MEM_HOST batches are uploaded
+    // sub-batch by sub-batch on the aux stream under the kernels of the previous sub-batch
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    int ensure_pinned(size_t bytes);
 
     // profiling
     bool profiling = false;

@@ -1212,3 +1212,30 @@ def test_reference_etl_tests_known_sizes(torch_cuda, tmp_path):
         out_cfg = str(tmp_path / "dataset_inspect.cfg")
         assert "Dataset summary" in remora("dataset", "inspect", cfg, "--out-path", out_cfg)
         assert len(json.load(open(out_cfg))) == (2 if cfg == chunks else 4)
+
+
+def test_host_buffer_path_pipelined_upload_matches_device_path(torch_cuda):
+    """rmr_infer_chunks with HOST buffers larger than the upload sub-batch (pinned double-buffered copies on the
+    aux stream under the kernels of the previous sub-batch, ragged last sub-batch): logits bit-identical to the
+    device-resident call, label counts equal; also with a tiny sub-batch so that many slots are recycled."""
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    n = 300_001
+    data = synth.synth_chunks(n, 100, 20, (4, 4), seed=77)
+    model = model_from_state(synth.synth_state("conv_lstm", 64, 9, 2, seed=3), dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0)
+    host = [data[k] for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+    dev = [torch.from_numpy(a).cuda() for a in host]
+    dc = torch.zeros(2, dtype=torch.int64, device="cuda")
+    want = model.infer_chunks(*dev, (4, 4), label_counts=dc).cpu().numpy()
+    for sub in (None, "4096"):
+        if sub is not None:
+            os.environ["RMR_HOST_SUBBATCH"] = sub
+        try:
+            hc = np.zeros(2, np.int64)
+            got = model.infer_chunks(*host, (4, 4), label_counts=hc)
+        finally:
+            os.environ.pop("RMR_HOST_SUBBATCH", None)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(hc, dc.cpu().numpy()) and hc.sum() == n
