@@ -4,7 +4,7 @@
 --num-reads; `python -m remora_amd validate from_remora_dataset DATASET --model MODEL.pt` (:1800-1960):
 the stored chunks of an on-disk dataset (directory or config) through the model with the model's chunk /
 k-mer contexts, the reference's validation summary line against the stored labels; and `python -m remora_amd
-dataset prepare | inspect | make_config` (:64-458), the ETL and bookkeeping around the on-disk chunk format."""
+dataset prepare | inspect | make_config | merge | head | copy` (:64-727), the ETL and bookkeeping around the on-disk chunk format."""
 import argparse
 import sys
 
@@ -121,6 +121,89 @@ def _dataset_make_config(args):
     return 0
 
 
+def _dataset_merge(args):
+    """src/remora/parsers.py:493-572: all rows of several datasets (labels converted to the merged label set)
+    copied into one new dataset, optionally capped at --max-size in proportion, then shuffled."""
+    import numpy as np
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, compute_best_split, load_dataset
+    from .util import prepare_out_dir
+
+    prepare_out_dir(args.out_path, args.overwrite)
+    paths = [sub for ds_path in args.dataset_paths for sub in load_dataset(ds_path)[0]]
+    dataset = RemoraDataset([CoreRemoraDataset(p, infinite_iter=False, do_check_super_batches=True) for p in paths],
+                            np.ones(len(paths)) / len(paths))
+    sizes = np.array([ds.size for ds in dataset.datasets])
+    if args.max_size is not None and sizes.sum() > args.max_size:
+        sizes = compute_best_split(args.max_size, sizes / sizes.sum())
+    md = dataset.metadata.copy()
+    md.allocate_size, md.max_seq_len = int(sizes.sum()), max(ds.metadata.max_seq_len for ds in dataset.datasets)
+    md.dataset_start = md.dataset_end = 0
+    merged = CoreRemoraDataset(data_path=args.out_path, mode="w", metadata=md)
+    for ds, size in zip(dataset.datasets, sizes):
+        ds.metadata.dataset_end = ds.metadata.dataset_start + int(size)
+        ds.adjust_batch_params()
+        for sb in ds.iter_super_batches():
+            merged.write_batch(sb)
+        merged.flush()
+    merged.shuffle()
+    merged.flush()
+    print(f"Saved core dataset:\n{merged.summary}")
+    return 0
+
+
+def _dataset_head(args):
+    """src/remora/parsers.py:604-655: the first `num_chunks` rows of a core dataset as a new (shuffled) dataset."""
+    from .data_chunks import CoreRemoraDataset
+    from .util import prepare_out_dir
+
+    prepare_out_dir(args.out_path, args.overwrite)
+    src = CoreRemoraDataset(args.in_path, infinite_iter=False, do_check_super_batches=True)
+    md = src.metadata.copy()
+    md.allocate_size, md.dataset_start, md.dataset_end = args.num_chunks, 0, 0
+    head = CoreRemoraDataset(data_path=args.out_path, mode="w", metadata=md)
+    src.adjust_batch_params()
+    for sb in src.iter_super_batches():
+        room = args.num_chunks - head.metadata.dataset_end
+        if sb["labels"].size >= room:
+            head.write_batch({n: a[:room] for n, a in sb.items()})
+            break
+        head.write_batch(sb)
+    head.flush()
+    head.shuffle()
+    head.flush()
+    print(f"Saved core dataset:\n{head.summary}")
+    return 0
+
+
+def _dataset_copy(args):
+    """src/remora/parsers.py:684-727: every core dataset of a dataset / config copied to OUT/dataset_NNN, with
+    OUT/dataset.cfg pointing at the copies and OUT/sources.txt recording where they came from."""
+    import json
+    import os
+    import shutil
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+    from .util import prepare_out_dir
+
+    prepare_out_dir(args.out_path, args.overwrite)
+    paths, props, hashes = load_dataset(args.in_path)
+    out_dirs = []
+    with open(os.path.join(args.out_path, "sources.txt"), "w") as src_fh:
+        for i, src in enumerate(paths):
+            if any(os.path.isdir(os.path.join(src, item)) for item in os.listdir(src)):
+                raise RemoraError(f"Source dataset has nested directory: {src}")
+            dst = os.path.join(args.out_path, f"dataset_{i:03}")
+            src_fh.write(f"{src}\t{dst}\n")
+            shutil.copytree(src, dst)
+            out_dirs.append(dst)
+    dataset = RemoraDataset([CoreRemoraDataset(d) for d in out_dirs], props, hashes)
+    with open(os.path.join(args.out_path, "dataset.cfg"), "w") as fh:
+        json.dump(dataset.get_config(), fh)
+    print(dataset.summary)
+    return 0
+
+
 def _infer(args):
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model
@@ -208,6 +291,24 @@ def main(argv=None):
     dm.add_argument("dataset_paths", nargs="+")
     dm.add_argument("--dataset-weights", type=float, nargs="+")
     dm.set_defaults(func=_dataset_make_config)
+
+    dg = dset.add_parser("merge", help="Copy several datasets into one new core dataset (shuffled)")
+    dg.add_argument("out_path")
+    dg.add_argument("dataset_paths", nargs="+")
+    dg.add_argument("--max-size", type=int)
+    dg.add_argument("--overwrite", action="store_true")
+    dg.set_defaults(func=_dataset_merge)
+    dh = dset.add_parser("head", help="New core dataset from the first chunks of another")
+    dh.add_argument("out_path")
+    dh.add_argument("in_path")
+    dh.add_argument("num_chunks", type=int)
+    dh.add_argument("--overwrite", action="store_true")
+    dh.set_defaults(func=_dataset_head)
+    dc = dset.add_parser("copy", help="Copy a dataset (all its core datasets + a new config) to a new location")
+    dc.add_argument("in_path")
+    dc.add_argument("out_path")
+    dc.add_argument("--overwrite", action="store_true")
+    dc.set_defaults(func=_dataset_copy)
 
     args = ap.parse_args(argv)
     try:
