@@ -322,8 +322,21 @@ def main():
         for r in rs[:32]:
             call_read_mods(r, model, mdr)
         t1b = time.perf_counter()
+        # the same reads as a stream of 8 batches of 512: staging of batch k+1 under the GPU work of batch k
+        from remora_amd.inference import iter_call_reads_mods
+
+        stream_batches = [rs[i : i + 512] for i in range(0, nreads, 512)] * 2
+        for _ in iter_call_reads_mods(stream_batches[:2], model, mdr):
+            pass
+        torch.cuda.synchronize()
+        tsa = time.perf_counter()
+        for _ in iter_call_reads_mods(stream_batches, model, mdr):
+            pass
+        torch.cuda.synchronize()
+        tsb = time.perf_counter()
         reads_leg = {"reads": nreads, "bases_per_read": 5000, "chunks_per_read": nchunks / nreads,
                      "batched_reads_per_s": 3 * nreads / (tb - ta), "batched_chunks_per_s": 3 * nchunks / (tb - ta),
+                     "streamed_reads_per_s": 512 * len(stream_batches) / (tsb - tsa),
                      "single_read_api_reads_per_s": 32 / (t1b - t1a),
                      "note": f"call_reads_mods: one upload of the reads, GPU motif scan + geometry/fill + fused inference, logits back on "
                              f"the host, per batch of {nreads} reads"}

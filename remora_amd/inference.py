@@ -7,6 +7,7 @@ import numpy as np
 
 from . import RemoraError
 from .constants import DEFAULT_BATCH_SIZE
+from .engine import _torch
 from .util import Motif, format_mm_ml_tags, softmax_axis1
 
 
@@ -66,7 +67,52 @@ def find_focus_bases_batch(reads, motifs):
     return np.split(local, np.cumsum(counts)[:-1]) if len(reads) else []
 
 
-def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
+def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=False):
+    """call_reads_mods over a stream of read batches with the host staging of batch k+1 (concatenation into pinned
+    buffers + upload, on its own HIP stream in a worker thread) running under the GPU work of batch k.  Yields
+    (reads, results) per batch, results as call_reads_mods returns them.  Batches whose refiner re-scales
+    iteratively (scale_iters > 0) are staged inline, because that refinement rewrites the reads first."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .data_chunks import DeviceReads
+
+    torch = _torch()
+    refiner = model_metadata.get("sig_map_refiner")
+    inline = refiner is not None and getattr(refiner, "is_loaded", False) and refiner.scale_iters > 0
+    engine = getattr(model, "engine", None)
+    upload_stream = None
+
+    def stage(reads):
+        nonlocal upload_stream
+        if inline or len(reads) == 0:
+            return None
+        if upload_stream is None:
+            upload_stream = torch.cuda.Stream(device=(engine.torch_device if engine is not None else None))
+        with torch.cuda.stream(upload_stream):
+            dr = DeviceReads(reads, engine)  # synchronises the upload stream before returning
+        return dr
+
+    it = iter(read_batches)
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        fut = pool.submit(stage, cur)
+        while True:
+            dr = fut.result()
+            try:
+                nxt = next(it)
+                fut = pool.submit(stage, nxt)
+            except StopIteration:
+                nxt, fut = None, None
+            yield cur, call_reads_mods(cur, model, model_metadata, return_mod_probs, device_reads=dr)
+            if fut is None:
+                return
+            cur = nxt
+
+
+def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device_reads=None):
     """Batched form of call_read_mods for a list of RemoraRead objects: the reads are uploaded once, then the
     (optional) signal-mapping refinement, the motif scan, the chunk extraction and the fused inference all run
     on the resident arrays (the reference processes reads one by one in Python,
@@ -83,7 +129,8 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False):
         for err in refiner.refine_reads(reads):  # DP rounds interleaved with host re-scaling
             if err is not None:
                 raise err
-    dr = DeviceReads(reads, getattr(model, "engine", None))
+    dr = device_reads if device_reads is not None and not (loaded and refiner.scale_iters > 0) else \
+        DeviceReads(reads, getattr(model, "engine", None))
     if loaded and refiner.scale_iters <= 0 and refiner.do_rough_rescale:
         refiner.rough_rescale_device(dr, reads)  # sorts + gathers on the GPU, 19-point fits on the host
     if loaded and refiner.scale_iters == 0:

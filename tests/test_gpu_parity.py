@@ -1239,3 +1239,44 @@ def test_host_buffer_path_pipelined_upload_matches_device_path(torch_cuda):
             os.environ.pop("RMR_HOST_SUBBATCH", None)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert np.array_equal(hc, dc.cpu().numpy()) and hc.sum() == n
+
+
+def test_streamed_read_batches_equal_batched_calls(torch_cuda):
+    """iter_call_reads_mods (staging of the next batch in a worker thread on its own stream) returns, batch by
+    batch, exactly what call_reads_mods returns - without a refiner and with one (rough re-scale + banded DP)."""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+
+    sys.path.insert(0, sys_path)
+    import bench_refine
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_reads_mods, iter_call_reads_mods
+    from remora_amd.model_util import model_from_state
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)], mod_bases=["m"], mod_long_names=["5mC"],
+              can_base="C", base_start_justify=False, offset=0, sig_map_refiner=None)
+    model = model_from_state(synth.synth_state(seed=4), md, device=0)
+    table, center, base = bench_refine.synth_reads(40, 1500, seed=9)
+    refiner = SigMapRefiner(_levels_array=table, center_idx=center, do_rough_rescale=True, scale_iters=0)
+
+    def fresh():
+        return [RemoraRead(dacs=b[0], shift=400.0, scale=60.0, seq_to_sig_map=b[1].copy(), int_seq=b[2], read_id=f"r{i}")
+                for i, b in enumerate(base)]
+
+    for mdx in (md, dict(md, sig_map_refiner=refiner)):
+        want_reads = fresh()
+        sizes = [7, 1, 0, 20, 12]
+        cuts = np.cumsum([0] + sizes)
+        want = [call_reads_mods(want_reads[a:b], model, mdx) for a, b in zip(cuts[:-1], cuts[1:])]
+        got_reads = fresh()
+        got = list(iter_call_reads_mods([got_reads[a:b] for a, b in zip(cuts[:-1], cuts[1:])], model, mdx))
+        assert len(got) == len(want)
+        for (reads, res), exp, (a, b) in zip(got, want, zip(cuts[:-1], cuts[1:])):
+            assert [r.read_id for r in reads] == [r.read_id for r in got_reads[a:b]] and len(res) == len(exp)
+            for (o1, l1, p1), (o2, l2, p2) in zip(res, exp):
+                assert np.array_equal(p1, p2) and np.array_equal(np.asarray(o1).view(np.uint32), np.asarray(o2).view(np.uint32))
+        for r1, r2 in zip(got_reads, want_reads):
+            assert np.array_equal(r1.seq_to_sig_map, r2.seq_to_sig_map) and (r1.shift, r1.scale) == (r2.shift, r2.scale)
+    assert list(iter_call_reads_mods([], model, md)) == []
