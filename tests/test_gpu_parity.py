@@ -429,7 +429,7 @@ def test_errors_surface_as_remora_error(torch_cuda):
 
 
 # ---- bf16-MFMA modes (split operands): own tolerances ---------------------------------------------
-# bf16x6 is fp32-class (as close to a float64 evaluation as the fp32-MFMA path, tools/err_check2.py);
+# bf16x6 is fp32-class (as close to a float64 evaluation as the fp32-MFMA path, tests/manual/precision_vs_float64.py);
 # bf16x3 and bf16 are reduced-precision modes with their own tolerances
 SPLIT_TOL = {"bf16x6": 1e-4, "bf16x3": 5e-4, "bf16": 3e-2}
 
