@@ -1091,7 +1091,10 @@ class CoreRemoraDataset:
         asked for (the fused path does not need it)."""
         en = min(batch_st + self.batch_size, super_batch["sequence"].shape[0])
         batch = {n: a[batch_st:en] for n, a in super_batch.items()}
-        if enc_kmers:
+        if enc_kmers and en <= batch_st:
+            md = self.metadata
+            batch["enc_kmers"] = np.zeros((0, 4 * md.kmer_len, md.chunk_width), np.float32)
+        elif enc_kmers:
             from .encoded_kmers import compute_encoded_kmer_batch
 
             batch["enc_kmers"] = compute_encoded_kmer_batch(
@@ -1104,8 +1107,8 @@ class CoreRemoraDataset:
         num = 0
         for sb in self.iter_super_batches(select, copy=copy):
             for st in range(0, chunks_per_sb, self.batch_size):
-                if st >= sb["sequence"].shape[0]:  # short last super batch of a finite dataset
-                    break
+                # (a short last super batch of a finite dataset yields short and then EMPTY batches, as in the
+                # reference; consumers that cannot take an empty batch skip it)
                 yield self.extract_batch(sb, st, enc_kmers)
                 num += 1
                 if max_batches is not None and num >= max_batches:

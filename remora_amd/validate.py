@@ -108,6 +108,8 @@ class ValidationLogger:
         for batch in dataset.iter_numpy_batches(return_arrays=names, copy=not fused):
             b = dict(zip(names, batch))
             labels = np.asarray(b["labels"])
+            if labels.size == 0:  # trailing empty batch of a short last super batch (the reference's loss turns NaN on it)
+                continue
             if fused:  # stored rows straight into the fused kernels (uploaded from the memmaps when untouched)
                 out = model.infer_chunks(b["signal"], b["sequence"], b["sequence_to_signal_mapping"], b["sequence_lengths"],
                                          md.kmer_context_bases)

@@ -951,3 +951,30 @@ def test_dataset_cli_merge_head_copy(tmp_path):
     back = RemoraDataset.from_config(os.path.join(copied, "dataset.cfg"), batch_size=50)  # hashes are verified on load
     np.testing.assert_allclose(back.props, [0.4, 0.3, 0.3])
     assert back.size == 499 and list(back.get_label_counts()) == [205, 84, 210]
+
+
+def test_batch_params_and_seeded_subsampling_match_reference(tmp_path):
+    """adjust_batch_params over a grid of batch / super-batch sizes and sample fractions, and the batches of a
+    seeded iteration with super_batch_sample_frac (np.random.choice inside every super batch), finite (including
+    the reference's short and empty trailing batches) and infinite."""
+    from remora_amd.data_chunks import CoreRemoraDataset
+
+    g = golden("dataset_batch_params.npz")
+    path = _materialise(tmp_path, ["can_ctrl"])["can_ctrl"]
+    for bs, sbs, frac, cps, sel, new_bs, new_sbs in g["grid"]:
+        ds = CoreRemoraDataset(path, batch_size=int(bs), super_batch_size=int(sbs),
+                               super_batch_sample_frac=None if frac < 0 else float(frac), infinite_iter=False)
+        got = ds.adjust_batch_params()
+        assert (got[0], -1 if got[1] is None else got[1], ds.batch_size, ds.super_batch_size) == (cps, sel, new_bs, new_sbs), \
+            (bs, sbs, frac)
+    for tag, inf in (("finite", False), ("infinite", True)):
+        ds = CoreRemoraDataset(path, batch_size=16, super_batch_size=64, super_batch_sample_frac=0.5, infinite_iter=inf)
+        np.random.seed(5)
+        sizes, fbs, ids = [], [], []
+        for bi, b in enumerate(ds):
+            sizes.append(b["labels"].size); fbs.append(b["read_focus_bases"]); ids.append(b["read_ids"])
+            if bi >= 9:
+                break
+        np.testing.assert_array_equal(sizes, g[f"frac_{tag}_sizes"])
+        np.testing.assert_array_equal(np.concatenate(fbs), g[f"frac_{tag}_read_focus_bases"])
+        np.testing.assert_array_equal(np.concatenate(ids), g[f"frac_{tag}_read_ids"])

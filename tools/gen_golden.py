@@ -1210,6 +1210,46 @@ def gen_remora_dataset(R, out):
     shutil.rmtree(td)
 
 
+def gen_batch_params(R, out):
+    """CoreRemoraDataset.adjust_batch_params (src/remora/data_chunks.py:1471-1510) over a grid of dataset /
+    batch / super-batch sizes and sample fractions, and one seeded iteration with super_batch_sample_frac
+    (np.random.choice inside load_super_batch, :1618-1626) over a prepared dataset."""
+    import shutil
+    import tempfile
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from golden_util import materialise_dataset
+
+    g = np.load(os.path.join(out, "prepared_datasets.npz"))
+    td = tempfile.mkdtemp()
+    path = materialise_dataset(g, "can_ctrl", os.path.join(td, "can_ctrl"))
+    rows = []
+    for bs in (1, 7, 16, 64, 300):
+        for sbs in (10, 64, 100, 205, 1000):
+            for frac in (None, 0.01, 0.1, 0.5, 0.99, 1.0):
+                ds = R.data_chunks.CoreRemoraDataset(path, batch_size=bs, super_batch_size=sbs, super_batch_sample_frac=frac,
+                                                     infinite_iter=False)
+                cps, sel = ds.adjust_batch_params()
+                rows.append([bs, sbs, -1.0 if frac is None else frac, cps, -1 if sel is None else sel, ds.batch_size,
+                             ds.super_batch_size])
+    d = {"grid": np.asarray(rows, np.float64)}
+    for tag, inf in (("finite", False), ("infinite", True)):
+        ds = R.data_chunks.CoreRemoraDataset(path, batch_size=16, super_batch_size=64, super_batch_sample_frac=0.5,
+                                             infinite_iter=inf)
+        np.random.seed(5)
+        labs, fbs, ids, sizes = [], [], [], []
+        for bi, b in enumerate(ds):
+            labs.append(b["labels"]); fbs.append(b["read_focus_bases"]); ids.append(b["read_ids"]); sizes.append(b["labels"].size)
+            if bi >= 9:
+                break
+        d[f"frac_{tag}_sizes"] = np.asarray(sizes)
+        d[f"frac_{tag}_read_focus_bases"] = np.concatenate(fbs)
+        d[f"frac_{tag}_read_ids"] = np.concatenate(ids)
+    np.savez_compressed(os.path.join(out, "dataset_batch_params.npz"), **d)
+    print("batch_params:", len(rows), "grid rows; frac iteration sizes", d["frac_finite_sizes"], d["frac_infinite_sizes"])
+    shutil.rmtree(td)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -1234,6 +1274,7 @@ def main():
         batching=gen_batching,
         prepare=gen_prepare,
         remora_dataset=gen_remora_dataset,
+        batch_params=gen_batch_params,
     )
     for name, fn in gens.items():
         if args.only and name not in args.only.split(","):
