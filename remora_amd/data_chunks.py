@@ -128,23 +128,26 @@ class ChunkArrays:
         return iter(self.as_reference_batch())
 
 
-_PINNED = {}
+import threading
+
+_PINNED = threading.local()  # one staging buffer per thread (the streaming API stages in a worker thread)
 
 
-def _pinned(key, dt, count):
-    """Grow-only pinned host staging buffers, one per array kind (pinned allocation is too slow to do per batch)."""
+def _pinned_bytes(count):
+    """Grow-only pinned host staging buffer of this thread (pinned allocation is too slow to do per batch)."""
     torch = _torch()
-    buf = _PINNED.get(key)
+    buf = getattr(_PINNED, "buf", None)
     if buf is None or buf.numel() < count:
-        buf = torch.empty(max(int(count * 1.25), 1 << 16), dtype=getattr(torch, np.dtype(dt).name), pin_memory=True)
-        _PINNED[key] = buf
+        buf = torch.empty(max(int(count * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
+        _PINNED.buf = buf
     return buf
 
 
 class DeviceReads:
     """The arrays of a batch of reads, concatenated and resident in HBM (the rmr_reads layout of
     include/remora_hip.h) - uploaded once and shared by the motif scan, the signal-mapping refinement
-    and the chunk extraction."""
+    and the chunk extraction.  All arrays travel in ONE pinned buffer / ONE copy (256-byte aligned segments);
+    the device tensors are typed views of that allocation."""
 
     def __init__(self, reads, engine=None):
         torch = _torch()
@@ -159,29 +162,36 @@ class DeviceReads:
             self.seq_off[i + 1] = self.seq_off[i] + r.int_seq.size
             if r.seq_to_sig_map.size != r.int_seq.size + 1:
                 raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
-        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-
-        def cat_to_dev(arrs, dt, total, key):
-            """Concatenate straight into a cached pinned staging buffer (no intermediate array, no bounce copy in the
-            driver) and upload from there."""
-            if total == 0:
-                return torch.zeros(0, dtype=getattr(torch, np.dtype(dt).name), device=dev)
-            buf = _pinned(key, dt, total)
-            host = buf.numpy()[:total]
-            o = 0
-            for a in arrs:
-                a = np.asarray(a).ravel()
-                host[o : o + a.size] = a  # casts to `dt` on the fly
-                o += a.size
-            out = buf[:total].to(dev, non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()  # the staging buffer is reused by the next batch
-            return out
-
-        self.dacs = cat_to_dev([r.dacs for r in reads], np.int16, int(self.sig_off[-1]), "dacs")
-        self.s2s = cat_to_dev([r.seq_to_sig_map for r in reads], np.int64, int(self.seq_off[-1]) + nr, "s2s")
-        self.iseq = cat_to_dev([r.int_seq for r in reads], np.int8, int(self.seq_off[-1]), "iseq")
-        self.d_sig_off, self.d_seq_off = to_dev(self.sig_off), to_dev(self.seq_off)
-        self.set_scaling([float(r.shift) for r in reads], [float(r.scale) for r in reads])
+        n_sig, n_seq = int(self.sig_off[-1]), int(self.seq_off[-1])
+        segs = [("s2s", np.int64, n_seq + nr), ("d_sig_off", np.int64, nr + 1), ("d_seq_off", np.int64, nr + 1),
+                ("shift", np.float64, nr), ("scale", np.float64, nr), ("dacs", np.int16, n_sig), ("iseq", np.int8, n_seq)]
+        offs, total = {}, 0
+        for name, dt, cnt in segs:
+            offs[name] = total
+            total += (cnt * np.dtype(dt).itemsize + 255) & ~255
+        buf = _pinned_bytes(max(total, 256))
+        host = buf.numpy()
+        view = {name: host[offs[name] : offs[name] + cnt * np.dtype(dt).itemsize].view(dt) for name, dt, cnt in segs}
+        o_sig = o_seq = o_map = 0
+        for r in reads:  # numpy casts to the segment dtype on the fly
+            a = np.asarray(r.dacs).ravel()
+            view["dacs"][o_sig : o_sig + a.size] = a
+            o_sig += a.size
+            a = np.asarray(r.seq_to_sig_map).ravel()
+            view["s2s"][o_map : o_map + a.size] = a
+            o_map += a.size
+            a = np.asarray(r.int_seq).ravel()
+            view["iseq"][o_seq : o_seq + a.size] = a
+            o_seq += a.size
+        view["d_sig_off"][:] = self.sig_off
+        view["d_seq_off"][:] = self.seq_off
+        view["shift"][:] = [float(r.shift) for r in reads]
+        view["scale"][:] = [float(r.scale) for r in reads]
+        dbuf = buf[: max(total, 256)].to(dev, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()  # the staging buffer is reused by the next batch
+        for name, dt, cnt in segs:
+            nbytes = cnt * np.dtype(dt).itemsize
+            setattr(self, name, dbuf[offs[name] : offs[name] + nbytes].view(getattr(torch, np.dtype(dt).name)))
 
     def set_scaling(self, shift, scale):
         torch = _torch()
