@@ -107,6 +107,7 @@ class ChunkArrays:
                  kmer_context_bases, chunk_context):
         self.signal, self.sequence, self.mapping, self.lengths = signal, sequence, mapping, lengths
         self.read_focus_bases, self.labels, self.geo = read_focus_bases, labels, geo
+        self.read_focus_bases_host = None  # filled in when the caller already knows them (saves a device read-back)
         self.kmer_context_bases = tuple(int(x) for x in kmer_context_bases)
         self.chunk_context = tuple(int(x) for x in chunk_context)
 
@@ -234,9 +235,14 @@ def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_
     eng, lib = dr.engine, L.lib()
     dev = eng.torch_device
     n_chunks = int(foc_off[-1])
-    d_foc_off = torch.from_numpy(np.ascontiguousarray(foc_off)).to(dev)
-    if focus.numel() == 0:
-        focus = torch.zeros(1, dtype=torch.int64, device=dev)
+    if isinstance(focus, np.ndarray):  # host focus bases: one upload for focus + offsets
+        packed = torch.from_numpy(np.concatenate([np.ascontiguousarray(foc_off, np.int64),
+                                                  focus.astype(np.int64, copy=False), np.zeros(1, np.int64)])).to(dev)
+        d_foc_off, focus = packed[: foc_off.size], packed[foc_off.size :]
+    else:
+        d_foc_off = torch.from_numpy(np.ascontiguousarray(foc_off)).to(dev)
+        if focus.numel() == 0:
+            focus = torch.zeros(1, dtype=torch.int64, device=dev)
     rs = L.Reads(dr.n_reads, dr.dacs.data_ptr(), dr.d_sig_off.data_ptr(), dr.s2s.data_ptr(), dr.iseq.data_ptr(),
                  dr.d_seq_off.data_ptr(), dr.shift.data_ptr(), dr.scale.data_ptr(), focus.data_ptr(),
                  d_foc_off.data_ptr(), int(chunk_context[0]), int(chunk_context[1]),
@@ -287,8 +293,12 @@ def extract_chunk_arrays(reads, chunk_context, kmer_context_bases, base_start_ju
     for i, r in enumerate(reads):
         if r.labels is not None and foc_off[i + 1] > foc_off[i]:
             labels[foc_off[i] : foc_off[i + 1]] = np.asarray(r.labels)[np.asarray(r.focus_bases)]
-    d_focus = torch.from_numpy(np.ascontiguousarray(focus)).to(dr.engine.torch_device)
-    return _extract_device(dr, d_focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset, labels)
+    arrs, sig = _extract_device(dr, focus[:n_chunks] if n_chunks else np.zeros(0, np.int64), foc_off, chunk_context,
+                                kmer_context_bases, base_start_justify, offset, labels)
+    if n_chunks:  # focus base after the offset, clipped into the read (data_chunks.py:443-446): known on the host
+        last = np.repeat(np.diff(dr.seq_off) - 1, np.diff(foc_off))
+        arrs.read_focus_bases_host = np.clip(focus[:n_chunks] + int(offset), 0, last)
+    return arrs, sig
 
 
 @dataclasses.dataclass
@@ -453,7 +463,8 @@ class RemoraRead:
                 out = model(arrs.signal.to(device), arrs.enc_kmers().to(device)).detach()
             outs.append(out.cpu().numpy())
             labs.append(arrs.labels)
-            poss.append(arrs.read_focus_bases.cpu().numpy())
+            poss.append(arrs.read_focus_bases_host if arrs.read_focus_bases_host is not None
+                        else arrs.read_focus_bases.cpu().numpy())
         return np.concatenate(outs, axis=0), np.concatenate(labs), np.concatenate(poss)
 
 
