@@ -12,7 +12,9 @@
  *     The Python host turns non-zero into remora_amd.RemoraError — the one exception type
  *     the reference's callers catch (src/remora/__init__.py:4-7, inference.py:88).
  *   - `mem` says where the caller's data buffers live: RMR_MEM_HOST (numpy / malloc; the
- *     engine stages them through device scratch and copies results back before returning)
+ *     engine stages them through device scratch and copies results back before returning;
+ *     rmr_infer_chunks uploads large batches sub-batch by sub-batch through pinned slots on
+ *     a second stream, under the kernels of the previous sub-batch)
  *     or RMR_MEM_DEVICE (hipMalloc / torch `data_ptr()`; work is enqueued on the engine
  *     stream and the call returns without synchronising — call rmr_engine_synchronize).
  *   - the caller owns every input and output buffer; the engine owns only weights,
