@@ -127,6 +127,15 @@ int rmr_trim_chunk_context(rmr_engine *e, int stored_before, int stored_after, i
 int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_t sig_len,
                     int64_t seq_len, int check, int reverse_signal, int64_t *q2s,
                     int64_t *n_out, int mem);
+/* The same for a batch of reads in one launch (one block per move table): `mv_tags` is the concatenation of
+ * the tables, table i at [mv_off[i], mv_off[i+1]); its coordinates are written to q2s[mv_off[i] ...] (a table of
+ * m entries yields at most m), counts[i] of them; status[i] = 0 or the code rmr_parse_moves would return for
+ * that read (RMR_ERR_DISCORDANT_SEQ / _SIG when `check`, RMR_ERR_INVALID for an empty table or stride <= 0).
+ * The call itself fails only on argument errors.  Used by the POD5+BAM ingest, which parses the move tables of
+ * a whole batch of alignments at once instead of one kernel launch per read. */
+int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off,
+                          const int64_t *sig_len, const int64_t *seq_len, int64_t n_reads, int check,
+                          int reverse_signal, int64_t *q2s, int64_t *counts, int32_t *status, int mem);
 
 /* ---- N1: POD5 signal decompression (the VBZ layer below zstd) ------------------------------ */
 /* replaces: the per-row signal decode that pod5's C++ reader performs for the records consumed by

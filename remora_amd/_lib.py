@@ -52,6 +52,7 @@ SIGNATURES = {
     "rmr_encode_kmers": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_int]),
     "rmr_trim_chunk_context": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int]),
     "rmr_parse_moves": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, ctypes.POINTER(c_i64), c_int]),
+    "rmr_parse_moves_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int]),
     "rmr_vbz_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
     "rmr_motif_flags": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),

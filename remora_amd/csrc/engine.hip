@@ -775,6 +775,39 @@ int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int
     return 0;
 }
 
+int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off, const int64_t *sig_len,
+                          const int64_t *seq_len, int64_t n_reads, int check, int reverse_signal, int64_t *q2s,
+                          int64_t *counts, int32_t *status, int mem) {
+    if (!e || !mv_tags || !mv_off || !sig_len || !seq_len || !q2s || !counts || !status)
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_reads <= 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    if (mem == RMR_MEM_DEVICE)
+        return launch_moves_batch(e, mv_tags, mv_off, sig_len, seq_len, n_reads, check, reverse_signal, q2s, counts, status);
+    const int64_t total = mv_off[n_reads];
+    if (mv_off[0] != 0 || total < n_reads) RMR_FAIL(RMR_ERR_INVALID, "bad move table offsets");
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad(total) + Stage::pad((size_t)total * 8) + 4 * Stage::pad((size_t)(n_reads + 1) * 8) + 4096));
+    int8_t *dmv = st.take<int8_t>(total);
+    int64_t *doff = st.take<int64_t>(n_reads + 1);
+    int64_t *dsl = st.take<int64_t>(n_reads);
+    int64_t *dql = st.take<int64_t>(n_reads);
+    int64_t *dq = st.take<int64_t>(total);
+    int64_t *dcnt = st.take<int64_t>(n_reads);
+    int32_t *dst = st.take<int32_t>(n_reads);
+    H2D(dmv, mv_tags, (size_t)total);
+    H2D(doff, mv_off, (size_t)(n_reads + 1) * 8);
+    H2D(dsl, sig_len, (size_t)n_reads * 8);
+    H2D(dql, seq_len, (size_t)n_reads * 8);
+    RMR_TRY(launch_moves_batch(e, dmv, doff, dsl, dql, n_reads, check, reverse_signal, dq, dcnt, dst));
+    D2H(q2s, dq, (size_t)total * 8);
+    D2H(counts, dcnt, (size_t)n_reads * 8);
+    D2H(status, dst, (size_t)n_reads * 4);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 }  // extern "C"
 
 // ---- chunk extraction ------------------------------------------------------------------------

@@ -197,6 +197,81 @@ int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_
     return 0;
 }
 
+// batch form: block b expands table b of a concatenation (tables at mv_off[b]..mv_off[b+1], outputs at the
+// same offsets: a table of m entries yields at most m coordinates); per-table status as rmr_parse_moves returns it
+__global__ __launch_bounds__(1024) void moves_batch_kernel(const int8_t *mv_tags, const int64_t *mv_off,
+                                                            const int64_t *sig_len, const int64_t *seq_len, int check,
+                                                            int reverse, int64_t *q2s, int64_t *counts, int32_t *status) {
+    __shared__ int wave_tot[16];
+    __shared__ long long base_sh;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int8_t *mv_tag = mv_tags + mv_off[b];
+    const int64_t mv_tag_len = mv_off[b + 1] - mv_off[b];
+    int64_t *out = q2s + mv_off[b];
+    if (mv_tag_len < 1) {
+        if (tid == 0) { counts[b] = 0; status[b] = RMR_ERR_INVALID; }
+        return;
+    }
+    const int64_t stride = mv_tag[0], nmv = mv_tag_len - 1, slen = sig_len[b];
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    int64_t total = 0;
+    if (reverse) {
+        int cnt = 0;
+        for (int64_t i = tid; i < nmv; i += blockDim.x) cnt += (mv_tag[1 + i] != 0);
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) wave_tot[wv] = cnt;
+        __syncthreads();
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) total += wave_tot[k];
+        __syncthreads();
+    }
+    for (int64_t start = 0; start < nmv; start += blockDim.x) {
+        const int64_t i = start + tid;
+        const bool nz = (i < nmv) && (mv_tag[1 + i] != 0);
+        const unsigned long long bal = __ballot(nz);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int wave_off = 0, blk = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+            if (k < wv) wave_off += wave_tot[k];
+            blk += wave_tot[k];
+        }
+        const long long base = base_sh;
+        if (nz) {
+            const int64_t k = base + wave_off + before;
+            if (!reverse) out[k] = i * stride;
+            else out[total - k] = slen - i * stride;
+        }
+        __syncthreads();
+        if (tid == 0) base_sh = base + blk;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int64_t cnt = base_sh;
+        if (!reverse) out[cnt] = slen;
+        else out[0] = 0;
+        counts[b] = cnt + 1;
+        int st = 0;
+        if (stride <= 0) st = RMR_ERR_INVALID;
+        else if (check && seq_len[b] >= 0 && cnt != seq_len[b]) st = RMR_ERR_DISCORDANT_SEQ;
+        else if (check && nmv != slen / stride) st = RMR_ERR_DISCORDANT_SIG;
+        status[b] = st;
+    }
+}
+
+int launch_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off, const int64_t *sig_len,
+                       const int64_t *seq_len, int64_t n, int check, int reverse, int64_t *q2s, int64_t *counts,
+                       int32_t *status) {
+    if (n <= 0) return 0;
+    ProfScope ps(e, K_MOVES);
+    hipLaunchKernelGGL(moves_batch_kernel, dim3((unsigned)n), dim3(1024), 0, e->stream, mv_tags, mv_off, sig_len,
+                       seq_len, check, reverse, q2s, counts, status);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 // ======================================================================================
 // X1 + X2/X3 geometry.  Signal normalisation in float64 then one rounding to float32
 // (bit-exact with numpy); per chunk: focus clip, focus signal index, window with clipping,

@@ -184,6 +184,9 @@ int launch_trim(rmr_engine *e, int sb, int sa, int cb, int ca, int tsc, int8_t *
                 int16_t *maps, int map_w, int16_t *lens, int64_t n);
 int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_t sig_len,
                  int reverse, int64_t *q2s, int64_t *d_count);
+int launch_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off, const int64_t *sig_len,
+                       const int64_t *seq_len, int64_t n, int check, int reverse, int64_t *q2s, int64_t *counts,
+                       int32_t *status);
 int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
                     float *sig_out, int64_t total_sig, const int32_t *sig_read, int64_t *geo,
                     int *d_max_seq_len);

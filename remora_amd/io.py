@@ -27,6 +27,37 @@ def parse_move_tag(mv_tag, sig_len, seq_len=None, check=True, reverse_signal=Fal
     return q2s[: n_out.value].copy(), mv[1:].astype(np.int64), stride
 
 
+_MOVE_ERRORS = {-4: "Move table discordant with basecalls", -5: "Move table discordant with signal"}
+
+
+def parse_move_tags(mv_tags, sig_lens, seq_lens=None, check=True, reverse_signal=False, engine=None):
+    """parse_move_tag for a batch of reads in ONE launch (rmr_parse_moves_batch): per read either the tuple
+    parse_move_tag returns or the RemoraError it would raise (returned, not raised)."""
+    eng = engine if engine is not None else get_engine()
+    n = len(mv_tags)
+    if n == 0:
+        return []
+    mvs = [np.ascontiguousarray(m, dtype=np.int8) for m in mv_tags]
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum([m.size for m in mvs], out=off[1:])
+    cat = np.concatenate(mvs) if off[-1] else np.zeros(1, np.int8)
+    sl = np.ascontiguousarray(sig_lens, np.int64)
+    ql = np.full(n, -1, np.int64) if seq_lens is None else np.asarray([-1 if x is None else int(x) for x in seq_lens], np.int64)
+    q2s = np.empty(max(int(off[-1]), 1), np.int64)
+    counts, status = np.zeros(n, np.int64), np.zeros(n, np.int32)
+    L.check(L.lib().rmr_parse_moves_batch(eng.handle, cat.ctypes.data, off.ctypes.data, sl.ctypes.data, ql.ctypes.data, n,
+                                          int(bool(check)), int(bool(reverse_signal)), q2s.ctypes.data, counts.ctypes.data,
+                                          status.ctypes.data, L.MEM_HOST))
+    out = []
+    for i, m in enumerate(mvs):
+        if status[i] != 0:
+            out.append(RemoraError(_MOVE_ERRORS.get(int(status[i]), "empty move tag" if m.size < 1 else
+                                                    f"move table stride {int(m[0])}")))
+        else:
+            out.append((q2s[off[i] : off[i] + counts[i]].copy(), m[1:].astype(np.int64), int(m[0])))
+    return out
+
+
 # =======================================================================================
 # POD5 + BAM ingest without pysam / pod5 (SURVEY §8f row N1): the reference reads these with
 # pod5.DatasetReader (src/remora/io.py:441-474) and pysam (:184-358); both formats are simple
@@ -485,7 +516,7 @@ class Read:
             sh, sc = -pod5_read.calibration_offset, 1 / pod5_read.calibration_scale
         return cls(read_id=pod5_read.read_id, dacs=dacs, shift_dacs_to_pa=sh, scale_dacs_to_pa=sc)
 
-    def add_alignment(self, rec, parse_ref_align=True, reverse_signal=False, pa_scaling=None):
+    def add_alignment(self, rec, parse_ref_align=True, reverse_signal=False, pa_scaling=None, parsed_moves=None):
         """Signal trimming by sp/ts/ns, read-id checks, strand-aware sequence, move table ->
         query_to_signal, sm/sd (or median/MAD) norm scaling composed with the pA calibration, and - for
         mapped records when `parse_ref_align` - the reference region, the reference sequence (MD tag),
@@ -514,7 +545,11 @@ class Read:
                 raise RemoraError("Split read IDs mismatch")
             self._child_read_id = rec.query_name
         self.seq = revcomp(rec.query_sequence) if rec.is_reverse else rec.query_sequence
-        if "mv" in tags:
+        if "mv" in tags and parsed_moves is not None:  # expanded together with the rest of the batch (parse_move_tags)
+            if isinstance(parsed_moves, Exception):
+                raise parsed_moves
+            self.query_to_signal, self.mv_table, self.stride = parsed_moves
+        elif "mv" in tags:
             self.query_to_signal, self.mv_table, self.stride = parse_move_tag(
                 tags["mv"], sig_len=self.sig_len, seq_len=len(self.seq), reverse_signal=reverse_signal)
         else:
@@ -629,10 +664,24 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
             pods = dict(zip(ids, signals.get_many(ids)))
         else:
             pods = None
-        for rec, rid in recs:
-            read = Read.from_pod5(pods[rid] if pods is not None else signals.get(rid), reverse_signal=reverse_signal)
+        reads = [Read.from_pod5(pods[rid] if pods is not None else signals.get(rid), reverse_signal=reverse_signal)
+                 for _rec, rid in recs]
+        moves = [None] * len(recs)
+        if decode_batch > 1:  # the move tables of the whole batch in one launch
+            have, mvs, sls, qls = [], [], [], []
+            for k, ((rec, _rid), read) in enumerate(zip(recs, reads)):
+                tags = dict(rec.tags)
+                if "mv" in tags and read.dacs is not None:
+                    # signal length after the sp / ts / ns trimming add_alignment applies (same slicing rules)
+                    sls.append(len(range(read.dacs.size)[tags.get("sp", 0) :][tags.get("ts", 0) : tags.get("ns", None)]))
+                    mvs.append(tags["mv"])
+                    qls.append(len(rec.query_sequence))
+                    have.append(k)
+            for k, res in zip(have, parse_move_tags(mvs, sls, qls, reverse_signal=reverse_signal)):
+                moves[k] = res
+        for (rec, rid), read, mv in zip(recs, reads, moves):
             try:
-                read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling)
+                read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling, parsed_moves=mv)
             except RemoraError as e:
                 yield read, str(e)
                 continue

@@ -123,6 +123,46 @@ def test_parse_move_tag_golden(torch_cuda):
             assert stride == mv[0] and np.array_equal(mvt, mv[1:])
 
 
+def test_parse_move_tags_batch_golden(torch_cuda, O):
+    """rmr_parse_moves_batch (one launch for the move tables of a whole batch, as the POD5+BAM ingest uses it): per
+    read the golden result or the reference's error, for the golden cases grouped by (check, reverse) and for a
+    ragged random batch against the oracle."""
+    from remora_amd import RemoraError
+    from remora_amd.io import parse_move_tags
+
+    g = golden("parse_move_tag.npz")
+    groups = {}
+    for i in range(int(g["num_cases"])):
+        sig_len, seq_len, rev, check = (int(x) for x in g[f"c{i}_args"])
+        groups.setdefault((check, rev), []).append((i, sig_len, None if seq_len < 0 else seq_len))
+    for (check, rev), cases in groups.items():
+        res = parse_move_tags([g[f"c{i}_mv"] for i, _, _ in cases], [sl for _, sl, _ in cases], [ql for _, _, ql in cases],
+                              check=bool(check), reverse_signal=bool(rev))
+        for (i, _, _), r in zip(cases, res):
+            err = str(g[f"c{i}_err"])
+            if err:
+                assert isinstance(r, RemoraError) and err in str(r)
+            else:
+                q2s, mvt, stride = r
+                assert np.array_equal(q2s, g[f"c{i}_q2s"]) and q2s.dtype == np.int64
+                assert stride == g[f"c{i}_mv"][0] and np.array_equal(mvt, g[f"c{i}_mv"][1:])
+    rng = np.random.default_rng(8)
+    for rev in (False, True):
+        tags, sls, qls = [], [], []
+        for n in (1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 70_001):
+            mv = (rng.random(n) < 0.35).astype(np.int8)
+            mv[0] = 1
+            stride = int(rng.integers(1, 13))
+            tags.append(np.concatenate([[stride], mv]).astype(np.int8))
+            sls.append(n * stride + int(rng.integers(0, stride)))
+            qls.append(int(mv.sum()))
+        res = parse_move_tags(tags, sls, qls, reverse_signal=rev)
+        for t, sl, ql, r in zip(tags, sls, qls, res):
+            qo, _, _ = O.parse_move_tag(t, sl, seq_len=ql, reverse_signal=rev)
+            assert np.array_equal(r[0], qo)
+    assert parse_move_tags([], []) == []
+
+
 def test_parse_move_tag_large_vs_oracle(torch_cuda, O):
     from remora_amd.io import parse_move_tag
 
