@@ -228,7 +228,8 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         batch = []
         for i, item in enumerate(rio.iter_reads_from_pod5_and_bam(pod5_path, in_bam_path, reverse_signal=reverse_signal,
                                                                   pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
-                                                                  decode_batch=reads_per_batch)):
+                                                                  decode_batch=reads_per_batch,
+                                                                  parse_ref_align=ref_anchored)):
             if num_reads is not None and i >= num_reads:
                 break
             batch.append(item)

@@ -71,6 +71,10 @@ import dataclasses
 import gzip
 import struct
 
+import re
+
+_MD_TOKEN = re.compile(r"(\d+)|(\^[A-Za-z]+)|([A-Za-z])")
+_MD_VALID = re.compile(r"(?:\d+|\^[A-Za-z]+|[A-Za-z])*")
 _SEQ_NT16 = "=ACMGRSVTWYHKDBN"
 _CIGAR_OPS = "MIDNSHP=XB"
 
@@ -124,38 +128,30 @@ class BamRecord:
         except KeyError:
             raise ValueError("MD tag not present")
         # reference-consuming columns of the alignment: query base for M/=/X, placeholder for D/N
-        cols, q = [], 0
+        parts, q = [], 0
         for op, ln in self.cigartuples:
             if op in (0, 7, 8):
-                cols.extend(self.query_sequence[q : q + ln])
+                parts.append(self.query_sequence[q : q + ln])
                 q += ln
             elif op in (1, 4):
                 q += ln
             elif op in (2, 3):
-                cols.extend("-" * ln)
-        out, i, p, n = [], 0, 0, len(md)
-        while p < n:
-            c = md[p]
-            if c.isdigit():
-                e = p
-                while e < n and md[e].isdigit():
-                    e += 1
-                run = int(md[p:e])
-                out.extend(cols[i : i + run])
-                i += run
-                p = e
-            elif c == "^":
-                e = p + 1
-                while e < n and md[e].isalpha():
-                    e += 1
-                out.extend(md[p + 1 : e].upper())
-                i += e - p - 1
-                p = e
+                parts.append("-" * ln)
+        cols = "".join(parts)
+        out, i = [], 0
+        tokens = _MD_TOKEN.findall(md)
+        for run, deleted, mismatch in tokens:
+            if run:
+                n = int(run)
+                out.append(cols[i : i + n])
+                i += n
+            elif deleted:
+                out.append(deleted[1:].upper())
+                i += len(deleted) - 1
             else:
-                out.append(c.lower())
+                out.append(mismatch.lower())
                 i += 1
-                p += 1
-        if i != len(cols):
+        if i != len(cols) or _MD_VALID.fullmatch(md) is None:
             raise ValueError("MD tag and CIGAR disagree about the reference span")
         return "".join(out)
 
@@ -185,10 +181,11 @@ def _parse_tags(buf, spans=None):
             sub = chr(buf[p]); cnt = struct.unpack_from("<i", buf, p + 1)[0]; p += 5
             dt = {"c": np.int8, "C": np.uint8, "s": np.int16, "S": np.uint16, "i": np.int32, "I": np.uint32,
                   "f": np.float32}[sub]
-            arr = np.frombuffer(buf, dtype=np.dtype(dt).newbyteorder("<"), count=cnt, offset=p)
-            # pysam hands B tags over as array.array: same here
-            val = array.array({"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub], arr.tolist())
-            p += cnt * np.dtype(dt).itemsize
+            nbytes = cnt * np.dtype(dt).itemsize
+            # pysam hands B tags over as array.array: same here (BAM is little-endian, as are the hosts this runs on)
+            val = array.array({"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub])
+            val.frombytes(bytes(buf[p : p + nbytes]))
+            p += nbytes
         else:
             raise RemoraError(f"unknown BAM tag type {t!r}")
         tags.append((name, val))
@@ -232,7 +229,7 @@ def iter_bam_records(bam_path):
             q = 32
             name = rec[q : q + l_read_name - 1].decode(); q += l_read_name
             cig = np.frombuffer(rec, dtype="<u4", count=n_cig, offset=q); q += 4 * n_cig
-            cigartuples = [(int(c & 0xF), int(c >> 4)) for c in cig]
+            cigartuples = list(zip((cig & 0xF).tolist(), (cig >> 4).tolist()))
             sb = np.frombuffer(rec, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q); q += (l_seq + 1) // 2
             codes = np.empty(2 * sb.size, np.uint8)
             codes[0::2], codes[1::2] = sb >> 4, sb & 0xF
@@ -651,11 +648,12 @@ class Read:
 
 
 def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_scaling=None,
-                                 skip_non_primary=True, decode_batch=256):
+                                 skip_non_primary=True, decode_batch=256, parse_ref_align=True):
     """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
     read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519).  The signals of
-    `decode_batch` consecutive records are decompressed together (zstd on the host, VBZ on the GPU);
-    decode_batch <= 1 decodes read by read on the host."""
+    `decode_batch` consecutive records are decompressed together (zstd on the host, VBZ on the GPU) and their
+    move tables are expanded in one launch; decode_batch <= 1 works read by read.  `parse_ref_align=False` skips the
+    reference side of the alignment (MD reconstruction, ref_to_signal) when only basecall-anchored reads are needed."""
     signals = Pod5File(pod5_path)
 
     def emit(recs):
@@ -681,7 +679,8 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
                 moves[k] = res
         for (rec, rid), read, mv in zip(recs, reads, moves):
             try:
-                read.add_alignment(rec, reverse_signal=reverse_signal, pa_scaling=pa_scaling, parsed_moves=mv)
+                read.add_alignment(rec, parse_ref_align=parse_ref_align, reverse_signal=reverse_signal,
+                                   pa_scaling=pa_scaling, parsed_moves=mv)
             except RemoraError as e:
                 yield read, str(e)
                 continue
