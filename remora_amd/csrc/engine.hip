@@ -788,7 +788,7 @@ int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *m
     const int64_t total = mv_off[n_reads];
     if (mv_off[0] != 0 || total < n_reads) RMR_FAIL(RMR_ERR_INVALID, "bad move table offsets");
     Stage st{e};
-    RMR_TRY(st.init(Stage::pad(total) + Stage::pad((size_t)total * 8) + 4 * Stage::pad((size_t)(n_reads + 1) * 8) + 4096));
+    RMR_TRY(st.init(Stage::pad(total) + Stage::pad((size_t)total * 8) + 5 * Stage::pad((size_t)(n_reads + 1) * 8) + 4096));
     int8_t *dmv = st.take<int8_t>(total);
     int64_t *doff = st.take<int64_t>(n_reads + 1);
     int64_t *dsl = st.take<int64_t>(n_reads);

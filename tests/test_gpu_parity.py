@@ -1320,3 +1320,31 @@ def test_streamed_read_batches_equal_batched_calls(torch_cuda):
         for r1, r2 in zip(got_reads, want_reads):
             assert np.array_equal(r1.seq_to_sig_map, r2.seq_to_sig_map) and (r1.shift, r1.scale) == (r2.shift, r2.scale)
     assert list(iter_call_reads_mods([], model, md)) == []
+
+
+def test_infer_pipeline_repeated_calls_and_large_move_batches(torch_cuda, O, tmp_path):
+    """infer_from_pod5_and_bam several times in one process (a fresh ingest thread per call) gives the same output
+    file every time; and rmr_parse_moves_batch with far more tables than one ingest batch (staging sized per read)."""
+    from remora_amd.inference import infer_from_pod5_and_bam
+    from remora_amd.io import parse_move_tags
+    from remora_amd.model_util import load_model
+
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    model, md = load_model(_mint_pt(tmp_path, golden("real_reads_can.npz"), O), device=0)
+    outs = []
+    for k in range(4):
+        out = str(tmp_path / f"o{k}.bam")
+        stats = infer_from_pod5_and_bam(os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam"), model, md,
+                                        out, reads_per_batch=5)
+        assert stats[None] == 14
+        outs.append(open(out, "rb").read())
+    assert all(o == outs[0] for o in outs[1:])
+    rng = np.random.default_rng(2)
+    tags, sls, qls = [], [], []
+    for _ in range(3000):
+        n = int(rng.integers(1, 40))
+        mv = (rng.random(n) < 0.5).astype(np.int8)
+        mv[0] = 1
+        tags.append(np.concatenate([[5], mv]).astype(np.int8)); sls.append(5 * n + 2); qls.append(int(mv.sum()))
+    for t, sl, ql, r in zip(tags, sls, qls, parse_move_tags(tags, sls, qls)):
+        assert np.array_equal(r[0], O.parse_move_tag(t, sl, seq_len=ql)[0])

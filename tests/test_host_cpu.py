@@ -978,3 +978,33 @@ def test_batch_params_and_seeded_subsampling_match_reference(tmp_path):
         np.testing.assert_array_equal(sizes, g[f"frac_{tag}_sizes"])
         np.testing.assert_array_equal(np.concatenate(fbs), g[f"frac_{tag}_read_focus_bases"])
         np.testing.assert_array_equal(np.concatenate(ids), g[f"frac_{tag}_read_ids"])
+
+
+def test_zstd_rows_inflate_from_short_lived_threads():
+    """POD5 signal rows are inflated in the ingest thread of every infer call: the zstd layer must survive being
+    used from many short-lived threads (pyarrow's stream reader does not) and give the same bytes everywhere."""
+    import threading
+
+    from remora_amd import io as rio
+
+    path = os.path.join(ROOT, "tests", "golden", "data", "can_reads.pod5")
+    f0 = rio.Pod5File(path)
+    rows = f0._sig.column("signal")
+    ref = [rio._zstd_decompress(rows[i].as_py()) for i in range(f0._sig.num_rows)]
+    assert len(ref) == 17 and all(len(r) > 1000 for r in ref)
+    bad = []
+
+    def work():
+        f = rio.Pod5File(path)
+        sr = f._sig.column("signal")
+        for i in range(f._sig.num_rows):
+            if rio._zstd_decompress(sr[i].as_py()) != ref[i]:
+                bad.append(i)
+
+    for _ in range(12):
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+    assert not bad
+    with pytest.raises(Exception):
+        rio._zstd_decompress(b"\x28\xb5\x2f\xfd\x20\x10garbage")
