@@ -240,25 +240,6 @@ def iter_bam_records(bam_path):
                             qual, _parse_tags(rec[q:], spans), bytes(rec), q, spans)
 
 
-def _vbz_decode(blob, n_samples):
-    """zstd -> streamvbyte16 (1 key bit per value: 0 = one byte, 1 = two bytes; keys first) ->
-    zigzag -> running sum, int16."""
-    import pyarrow as pa
-
-    raw = np.frombuffer(pa.CompressedInputStream(pa.BufferReader(blob), "zstd").read(), np.uint8)
-    nkeys = (n_samples + 7) // 8
-    keys = np.unpackbits(raw[:nkeys], bitorder="little")[:n_samples].astype(np.int64)
-    data = raw[nkeys:]
-    if data.size != n_samples + int(keys.sum()):
-        raise RemoraError("corrupt VBZ signal block")
-    offs = np.cumsum(keys + 1) - (keys + 1)
-    lo = data[offs].astype(np.uint16)
-    hi = np.where(keys == 1, data[np.minimum(offs + 1, data.size - 1)], 0).astype(np.uint16)
-    v = lo | (hi << 8)
-    d = (v >> 1).astype(np.int16) ^ (-(v & 1).astype(np.int16))
-    return np.cumsum(d, dtype=np.int16)
-
-
 _ZSTD = None
 
 
@@ -348,7 +329,7 @@ class Pod5Read:
 class Pod5File:
     """Random access to the reads of a POD5 file without the pod5 package: the file is memory mapped, the
     embedded Arrow IPC tables (signal rows, reads) are opened in place, a read's signal rows are VBZ-decoded
-    only when the read is asked for."""
+    (zstd on the host, the streamvbyte / zigzag / running-sum layer on the GPU) only when the read is asked for."""
 
     def __init__(self, pod5_path):
         import mmap
@@ -401,14 +382,19 @@ class Pod5File:
     def __len__(self):
         return len(self.read_ids)
 
-    def get(self, read_id):
-        r = self._row[read_id]
+    def signal_rows(self, read_id):
+        """[(zstd-compressed VBZ bytes, number of samples)] of a read's signal rows, in order (table access only)."""
         sig_rows, sig_n = self._sig.column("signal"), self._sig.column("samples")
-        parts = [_vbz_decode(sig_rows[i].as_py(), sig_n[i].as_py()) for i in self._reads.column("signal")[r].as_py()]
-        # delta coding restarts in every signal row
-        return Pod5Read(read_id, np.concatenate(parts) if len(parts) > 1 else parts[0],
-                        float(self._reads.column("calibration_offset")[r].as_py()),
-                        float(self._reads.column("calibration_scale")[r].as_py()))
+        return [(sig_rows[i].as_py(), sig_n[i].as_py()) for i in self._reads.column("signal")[self._row[read_id]].as_py()]
+
+    def calibration(self, read_id):
+        r = self._row[read_id]
+        return (float(self._reads.column("calibration_offset")[r].as_py()),
+                float(self._reads.column("calibration_scale")[r].as_py()))
+
+    def get(self, read_id, engine=None):
+        """One read (signal decoded on the GPU like a batch of one)."""
+        return self.get_many([read_id], engine)[0]
 
     def get_many(self, read_ids, engine=None):
         """The signals of several reads decoded in one GPU call (see vbz_decode_batch); list of Pod5Read."""
@@ -688,7 +674,7 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
     """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
     read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519).  The signals of
     `decode_batch` consecutive records are decompressed together (zstd on the host, VBZ on the GPU) and their
-    move tables are expanded in one launch; decode_batch <= 1 works read by read.  `parse_ref_align=False` skips the
+    move tables are expanded in one launch; decode_batch <= 1 works read by read (one launch per read).  `parse_ref_align=False` skips the
     reference side of the alignment (MD reconstruction, ref_to_signal) when only basecall-anchored reads are needed."""
     signals = Pod5File(pod5_path)
 

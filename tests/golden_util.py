@@ -60,3 +60,25 @@ def dataset_rows(ds_dir, md=None):
     cols = np.arange(rows["sequence_to_signal_mapping"].shape[1])[None, :]
     rows["sequence_to_signal_mapping"][cols > lens[:, None]] = 0
     return md, rows
+
+
+def pod5_reads_cpu(pod5_path, read_ids=None):
+    """The reads of a POD5 file decoded WITHOUT a GPU: table access and zstd from remora_amd.io, the VBZ layer from
+    the C oracle.  For CPU-side tests and for tools/gen_golden.py only (the product decodes on the GPU)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import oracle as O
+    from remora_amd import io as rio
+
+    f = rio.Pod5File(pod5_path)
+    out = []
+    for rid in f.read_ids:
+        if read_ids is not None and rid not in read_ids:
+            continue
+        parts = [O.vbz_decode(bytes(rio._zstd_decompress(blob)), n) for blob, n in f.signal_rows(rid)]
+        off, scale = f.calibration(rid)
+        out.append(rio.Pod5Read(rid, np.concatenate(parts) if len(parts) > 1 else parts[0], off, scale))
+    return out

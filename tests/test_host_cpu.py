@@ -271,7 +271,9 @@ def test_bam_and_pod5_parsers_on_reference_test_data():
     from remora_amd import io as rio
 
     recs = list(rio.iter_bam_records(os.path.join(DATA, "can_mappings.bam")))
-    pods = {p.read_id: p for p in rio.iter_pod5_reads(os.path.join(DATA, "can_reads.pod5"))}
+    from golden_util import pod5_reads_cpu
+
+    pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(DATA, "can_reads.pod5"))}
     g = golden("real_reads_can.npz")
     assert len(recs) == len(pods) == int(g["num_records"]) == 14
     assert sum(r.is_reverse for r in recs) == 4 and all(r.reference_name == "chr13" for r in recs)
@@ -685,9 +687,13 @@ def test_io_edge_cases_host():
             list(rio.iter_bam_records(notbam))
     f = rio.Pod5File(os.path.join(data, "can_reads.pod5"))
     assert len(f) == len(f.read_ids) == 14 and f.read_ids[0] in f and "nope" not in f
-    r = f.get(f.read_ids[3])
+    from golden_util import pod5_reads_cpu
+
+    r = pod5_reads_cpu(os.path.join(data, "can_reads.pod5"), read_ids=f.read_ids[3:4])[0]
     assert r.signal.dtype == np.int16 and r.signal.size > 1000 and r.calibration_scale > 0
-    assert [x.read_id for x in rio.iter_pod5_reads(os.path.join(data, "can_reads.pod5"), read_ids=f.read_ids[:2])] == f.read_ids[:2]
+    assert sum(n for _, n in f.signal_rows(f.read_ids[3])) == r.signal.size and f.calibration(f.read_ids[3])[1] == r.calibration_scale
+    with pytest.raises(RemoraError, match="no GPU|GPU"):
+        f.get(f.read_ids[3])  # decoding a read is a GPU call: no CPU fallback in the product
     assert rio._pack_seq("ACGTN") == bytes([0x12, 0x48, 0xF0])
 
 

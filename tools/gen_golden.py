@@ -691,7 +691,10 @@ def gen_real_reads(R, out):
     from remora_amd import io as rio
 
     data = os.path.join(out, "data")
-    pods = {p.read_id: p for p in rio.iter_pod5_reads(os.path.join(data, "can_reads.pod5"))}
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from golden_util import pod5_reads_cpu
+
+    pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(data, "can_reads.pod5"))}
     recs = list(rio.iter_bam_records(os.path.join(data, "can_mappings.bam")))
     net = make_net(R, "ConvLSTM_w_ref", 64, 9, 2, seed=300)
     ckpt = _ckpt((4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 64, 9, 2)
@@ -1033,7 +1036,9 @@ def gen_prepare(R, out):
     d = {"configs_json": np.asarray(json.dumps({k: [v[0], v[1], _prep_defaults(v[2])] for k, v in PREP_CONFIGS.items()}))}
     for name, (which, mod_base, kw) in PREP_CONFIGS.items():
         kw = _prep_defaults(kw)
-        pods = {p.read_id: p for p in rio.iter_pod5_reads(os.path.join(data, f"{which}_reads.pod5"))}
+        from golden_util import pod5_reads_cpu
+
+        pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(data, f"{which}_reads.pod5"))}
         recs = [r for r in rio.iter_bam_records(os.path.join(data, f"{which}_mappings.bam"))
                 if not (r.is_secondary or r.is_supplementary)]
         motifs = [R.util.Motif(*m) for m in kw["motifs"]]
