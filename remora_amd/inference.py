@@ -34,39 +34,6 @@ def call_read_mods(read, model, model_metadata, batch_size=DEFAULT_BATCH_SIZE, f
     return probs, labels, pos
 
 
-def find_focus_bases_batch(reads, motifs):
-    """Motif hits for many reads at once (sorted ascending per read).  Vectorised restatement of
-    Motif.findall (src/remora/util.py:281-297) over the concatenated sequences; unlike
-    find_focus_bases_in_int_sequence (:413-426) the per-read order is ascending, not python-set
-    order (downstream consumers sort by position anyway, src/remora/util.py:506,518)."""
-    lens = np.array([r.int_seq.size for r in reads], dtype=np.int64)
-    offs = np.concatenate([[0], np.cumsum(lens)])
-    cat = np.concatenate([np.asarray(r.int_seq, dtype=np.int64) for r in reads]) if len(reads) else np.zeros(0, np.int64)
-    read_of = np.repeat(np.arange(len(reads)), lens)
-    hit_any = np.zeros(cat.size, dtype=bool)
-    cat1 = (cat + 1).astype(np.intp)  # -1 (N) -> 0
-    for mot in motifs:
-        m = len(mot.raw_motif)
-        nwin = cat.size - m + 1
-        if nwin <= 0:
-            continue
-        hit = np.ones(nwin, dtype=bool)
-        for po, allowed in enumerate(mot.int_pattern):
-            lut = np.zeros(5, dtype=bool)
-            lut[np.asarray(allowed) + 1] = True
-            hit &= lut[cat1[po : po + nwin]]
-        # a window must not straddle two reads
-        hit &= read_of[:nwin] == read_of[m - 1 : m - 1 + nwin]
-        focus = np.flatnonzero(hit) + mot.focus_pos
-        focus = focus[(focus >= 0) & (focus < cat.size)]
-        hit_any[focus] = True
-    pos = np.flatnonzero(hit_any)
-    owner = read_of[pos]
-    counts = np.bincount(owner, minlength=len(reads))
-    local = pos - offs[owner]
-    return np.split(local, np.cumsum(counts)[:-1]) if len(reads) else []
-
-
 def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=False):
     """call_reads_mods over a stream of read batches with the host staging of batch k+1 (concatenation into pinned
     buffers + upload, on its own HIP stream in a worker thread) running under the GPU work of batch k.  Yields
