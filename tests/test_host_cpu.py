@@ -1014,3 +1014,26 @@ def test_zstd_rows_inflate_from_short_lived_threads():
     assert not bad
     with pytest.raises(Exception):
         rio._zstd_decompress(b"\x28\xb5\x2f\xfd\x20\x10garbage")
+
+
+def test_bam_writer_thread_pool_is_deterministic(tmp_path):
+    """BGZF blocks are deflated by a thread pool and written in order: the file does not depend on the number of
+    threads or on how many blocks may be in flight, and reads back record for record."""
+    import struct
+
+    from remora_amd import io as rio
+
+    bam = os.path.join(ROOT, "tests", "golden", "data", "mod_mappings.bam")
+    hdr = rio.read_bam_header_bytes(bam)
+    recs = list(rio.iter_bam_records(bam))
+    outs = []
+    for k, (threads, pending) in enumerate(((1, 1), (4, 32), (3, 2))):
+        path = str(tmp_path / f"w{k}.bam")
+        with rio.BamWriter(path, hdr, threads=threads, max_pending=pending) as w:
+            for _ in range(5):
+                for r in recs:
+                    w.write(struct.pack("<i", len(r.raw)) + r.raw)
+        outs.append(open(path, "rb").read())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 500_000
+    back = list(rio.iter_bam_records(str(tmp_path / "w1.bam")))
+    assert len(back) == 5 * len(recs) and all(b.raw == recs[i % len(recs)].raw for i, b in enumerate(back))
