@@ -886,8 +886,8 @@ def test_vbz_decode_kernel(torch_cuda):
     from golden_util import pod5_reads_cpu
     from oracle import oracle as OR
 
-    cpu = {r.read_id: r for r in pod5_reads_cpu(f._path if hasattr(f, "_path") else os.path.join(
-        os.path.dirname(os.path.abspath(__file__)), "golden", "data", "can_reads.pod5"))}
+    cpu = {r.read_id: r for r in pod5_reads_cpu(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data",
+                                                             "can_reads.pod5"))}
     for batch in (f.read_ids, f.read_ids[:1], f.read_ids[3:9]):
         got = f.get_many(batch)
         for rid, g in zip(batch, got):
