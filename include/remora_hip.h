@@ -137,6 +137,41 @@ int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *m
                           const int64_t *sig_len, const int64_t *seq_len, int64_t n_reads, int check,
                           int reverse_signal, int64_t *q2s, int64_t *counts, int32_t *status, int mem);
 
+/* ---- N1: BAM records for the POD5+BAM ingest (host code: BGZF inflate + record / tag decode) ---------- */
+/* replaces: what ReadIndexedBam / pysam hand to io.Read.add_alignment (src/remora/io.py:184-358, :1972-2084):
+ * per alignment the flag, reference id / start, mapping quality, name, CIGAR, sequence, the tags mv, ts, ns, sp,
+ * sm, sd, pi, MD, the record bytes as stored (for writing the record back with MM/ML tags), and - when
+ * `want_ref` - the reference bases spanned by the alignment rebuilt from query + CIGAR + MD
+ * (pysam.AlignedSegment.get_reference_sequence: mismatches lower case; ref_ok = 0 without MD / when MD and
+ * CIGAR disagree).  Records arrive `max_records` at a time as flat arrays with [n+1] offset tables; every
+ * pointer of the batch stays valid until the next rmr_bam_read_batch / rmr_bam_close on the same handle.
+ * `has` bit i set = tag present: 0 mv (B:c), 1 ts, 2 ns, 3 sp, 4 sm, 5 sd, 6 pi, 7 MD.  `mv` excludes nothing:
+ * [stride, m0, m1, ...] as stored.  n_records < max_records means end of file. */
+typedef struct rmr_bam rmr_bam;
+typedef struct rmr_bam_batch {
+    int64_t n_records;
+    const int32_t *flag, *ref_id, *pos, *mapq, *l_seq, *n_cigar;
+    const int64_t *raw_off;   const uint8_t *raw;      /* record bytes (without the leading block_size) */
+    const int64_t *name_off;  const char *names;
+    const int64_t *seq_off;   const char *seq;         /* ASCII bases */
+    const int64_t *cigar_off; const uint32_t *cigar;   /* BAM CIGAR words: len << 4 | op */
+    const int64_t *tags_off;                           /* [n] offset of the tag region inside the record */
+    const uint8_t *has;
+    const int64_t *mv_off;    const int8_t *mv;
+    const int32_t *ts, *ns, *sp;
+    const float *sm, *sd;
+    const int64_t *pi_off;    const char *pi;
+    const int64_t *md_off;    const char *md;
+    const uint8_t *ref_ok;
+    const int64_t *refseq_off; const char *refseq;
+} rmr_bam_batch;
+int rmr_bam_open(const char *path, rmr_bam **out);
+void rmr_bam_close(rmr_bam *b);
+/* everything before the first record (magic, header text, reference dictionary), uncompressed */
+int rmr_bam_header(rmr_bam *b, const uint8_t **bytes, int64_t *n_bytes, int64_t *n_refs);
+const char *rmr_bam_ref_name(rmr_bam *b, int64_t ref_id); /* NULL when out of range */
+int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_batch *out);
+
 /* ---- N1: POD5 signal decompression (the VBZ layer below zstd) ------------------------------ */
 /* replaces: the per-row signal decode that pod5's C++ reader performs for the records consumed by
  * io.iter_signal (src/remora/io.py:441-474) / Read.from_pod5_and_alignment (:2086-2121):

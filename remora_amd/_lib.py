@@ -23,6 +23,15 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("arch", "size", "kmer_len", "num_out", "chunk_len", "dtype")]
 
 
+class BamBatch(ctypes.Structure):
+    """rmr_bam_batch of include/remora_hip.h."""
+
+    _fields_ = [("n_records", c_i64)] + [(n, c_vp) for n in (
+        "flag", "ref_id", "pos", "mapq", "l_seq", "n_cigar", "raw_off", "raw", "name_off", "names", "seq_off", "seq",
+        "cigar_off", "cigar", "tags_off", "has", "mv_off", "mv", "ts", "ns", "sp", "sm", "sd", "pi_off", "pi", "md_off",
+        "md", "ref_ok", "refseq_off", "refseq")]
+
+
 class MotifSet(ctypes.Structure):
     _fields_ = [("n_motifs", ctypes.c_int32), ("len", ctypes.c_int32 * 8), ("focus_pos", ctypes.c_int32 * 8),
                 ("mask", (ctypes.c_uint8 * 16) * 8)]
@@ -53,6 +62,11 @@ SIGNATURES = {
     "rmr_trim_chunk_context": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int]),
     "rmr_parse_moves": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, ctypes.POINTER(c_i64), c_int]),
     "rmr_parse_moves_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int]),
+    "rmr_bam_open": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "rmr_bam_close": (None, [c_vp]),
+    "rmr_bam_header": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "rmr_bam_ref_name": (ctypes.c_char_p, [c_vp, c_i64]),
+    "rmr_bam_read_batch": (c_int, [c_vp, c_i64, c_int, c_vp]),
     "rmr_vbz_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
     "rmr_motif_flags": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),

@@ -1,0 +1,467 @@
+// Native BGZF / BAM record reader for the POD5+BAM ingest.
+//
+// The reference reads alignments through pysam / htslib (src/remora/io.py:184-358, ReadIndexedBam, and
+// Read.add_alignment :1972-2084 for what it takes from a record).  Here the same fields are produced a batch
+// of records at a time: BGZF members are inflated with zlib, records are split and their fixed fields, name,
+// CIGAR, 4-bit sequence and the tags the hot path needs (mv, ts, ns, sp, sm, sd, pi, MD) are decoded into flat
+// arrays the Python host wraps without a per-record parse; optionally the reference bases of the alignment
+// are rebuilt from query + CIGAR + MD (what pysam's get_reference_sequence returns, mismatches in lower case).
+//
+// Host code only (no device work): plain C++17 + zlib, part of libremora_hip.so.
+#include <zlib.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/remora_hip.h"
+#include "rmr_internal.h"
+
+using rmr::set_error;
+
+struct rmr_bam {
+    FILE *fh = nullptr;
+    std::vector<uint8_t> cbuf;    // compressed block
+    std::vector<uint8_t> ubuf;    // inflated, not yet consumed bytes
+    size_t upos = 0;              // consumed prefix of ubuf
+    bool eof = false;
+    // BGZF members are independent deflate streams: kSlots of them are read ahead and inflated by as many threads
+    static constexpr int kSlots = 8;
+    struct Slot {
+        std::vector<uint8_t> cbuf, out;
+        uint32_t crc = 0, isize = 0;
+        int clen = 0;
+        z_stream zs{};
+        bool zs_init = false;
+        int rc = 0;
+    } slot[kSlots];
+    // persistent inflate workers (creating threads per batch of members costs more than the inflate itself in a
+    // process that carries the HIP runtime's thread-local state)
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    uint64_t generation = 0;
+    int n_active = 0, n_pending = 0;
+    bool stop = false;
+    std::vector<uint8_t> header;  // everything before the first record (magic, text, references)
+    std::vector<std::string> refs;
+    // batch arenas (valid until the next read_batch call)
+    std::vector<int32_t> flag, ref_id, pos, mapq, l_seq, n_cigar, ts, ns, sp;
+    std::vector<float> sm, sd;
+    std::vector<uint8_t> has;  // bit0 mv, 1 ts, 2 ns, 3 sp, 4 sm, 5 sd, 6 pi, 7 MD
+    std::vector<uint8_t> ref_ok;
+    std::vector<int64_t> raw_off, name_off, seq_off, cigar_off, tags_off, mv_off, pi_off, md_off, refseq_off;
+    std::vector<uint8_t> raw;
+    std::vector<char> names, seq, pi, md, refseq;
+    std::vector<uint32_t> cigar;
+    std::vector<int8_t> mv;
+};
+
+namespace {
+
+// ---- BGZF ---------------------------------------------------------------------------------
+// reads the next BGZF member (compressed) into slot k; returns 1 = read, 0 = clean EOF, negative = error
+int read_member(rmr_bam *b, rmr_bam::Slot &sl) {
+    uint8_t hd[12];
+    const size_t got = fread(hd, 1, 12, b->fh);
+    if (got == 0) return 0;
+    if (got != 12 || hd[0] != 0x1f || hd[1] != 0x8b || hd[2] != 8 || !(hd[3] & 4)) {
+        set_error("not a BAM file: not a BGZF block (truncated or plain gzip)");
+        return RMR_ERR_INVALID;
+    }
+    const int xlen = hd[10] | (hd[11] << 8);
+    uint8_t extra[65536];
+    if (fread(extra, 1, (size_t)xlen, b->fh) != (size_t)xlen) {
+        set_error("truncated BAM file");
+        return RMR_ERR_INVALID;
+    }
+    int bsize = -1;
+    for (int p = 0; p + 4 <= xlen;) {
+        const int slen = extra[p + 2] | (extra[p + 3] << 8);
+        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
+        p += 4 + slen;
+    }
+    if (bsize < 0) {
+        set_error("BGZF block without BC field");
+        return RMR_ERR_INVALID;
+    }
+    sl.clen = bsize - xlen - 19;  // deflate payload
+    if (sl.clen < 0) {
+        set_error("corrupt BGZF block size");
+        return RMR_ERR_INVALID;
+    }
+    sl.cbuf.resize((size_t)sl.clen + 8);
+    if (fread(sl.cbuf.data(), 1, (size_t)sl.clen + 8, b->fh) != (size_t)sl.clen + 8) {
+        set_error("truncated BAM file");
+        return RMR_ERR_INVALID;
+    }
+    const uint8_t *tail = sl.cbuf.data() + sl.clen;
+    sl.crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+    sl.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+    return 1;
+}
+
+// inflates slot's member into slot.out (thread-safe: touches the slot only); rc in slot.rc: 0 ok, 1 inflate, 2 crc
+void inflate_member(rmr_bam::Slot &sl) {
+    sl.out.resize(sl.isize);
+    sl.rc = 0;
+    if (sl.isize == 0) return;  // empty member (e.g. the EOF marker)
+    if (!sl.zs_init) {
+        if (inflateInit2(&sl.zs, -15) != Z_OK) { sl.rc = 1; return; }
+        sl.zs_init = true;
+    } else {
+        inflateReset(&sl.zs);
+    }
+    sl.zs.next_in = sl.cbuf.data();
+    sl.zs.avail_in = (uInt)sl.clen;
+    sl.zs.next_out = sl.out.data();
+    sl.zs.avail_out = sl.isize;
+    if (inflate(&sl.zs, Z_FINISH) != Z_STREAM_END || sl.zs.avail_out != 0) { sl.rc = 1; return; }
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), sl.out.data(), sl.isize) != sl.crc) sl.rc = 2;
+}
+
+// worker w inflates slot w of every generation that has that many members
+void worker_loop(rmr_bam *b, int w) {
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            b->cv_work.wait(lk, [&] { return b->stop || b->generation != seen; });
+            if (b->stop) return;
+            seen = b->generation;
+            if (w >= b->n_active) continue;
+        }
+        inflate_member(b->slot[w]);
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            --b->n_pending;
+        }
+        b->cv_done.notify_one();
+    }
+}
+
+// reads up to kSlots members, inflates them in parallel, appends the bytes to b->ubuf in file order;
+// returns the number of members read (0 = clean EOF) or a negative error
+int next_blocks(rmr_bam *b) {
+    int n = 0, rc = 1;
+    while (n < rmr_bam::kSlots) {
+        rc = read_member(b, b->slot[n]);
+        if (rc <= 0) break;
+        ++n;
+    }
+    if (rc < 0) return rc;
+    if (n == 0) return 0;
+    if (n > 1) {
+        if (b->workers.empty()) {
+            for (int w = 1; w < rmr_bam::kSlots; ++w) b->workers.emplace_back(worker_loop, b, w);
+        }
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            b->n_active = n;
+            b->n_pending = n - 1;
+            ++b->generation;
+        }
+        b->cv_work.notify_all();
+        inflate_member(b->slot[0]);
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv_done.wait(lk, [&] { return b->n_pending == 0; });
+    } else {
+        inflate_member(b->slot[0]);
+    }
+    if (b->upos > 0 && b->upos >= b->ubuf.size() / 2) {  // compact the consumed prefix before growing
+        b->ubuf.erase(b->ubuf.begin(), b->ubuf.begin() + (ptrdiff_t)b->upos);
+        b->upos = 0;
+    }
+    for (int k = 0; k < n; ++k) {
+        if (b->slot[k].rc != 0) {
+            set_error(b->slot[k].rc == 1 ? "corrupt BGZF block (inflate)" : "corrupt BGZF block (crc)");
+            return RMR_ERR_INVALID;
+        }
+        b->ubuf.insert(b->ubuf.end(), b->slot[k].out.begin(), b->slot[k].out.end());
+    }
+    return n;
+}
+
+// makes at least n unread bytes available; returns 1, 0 (EOF before n bytes; *avail says how many there are) or <0
+int ensure(rmr_bam *b, size_t n) {
+    while (b->ubuf.size() - b->upos < n) {
+        if (b->eof) return 0;
+        const int rc = next_blocks(b);
+        if (rc < 0) return rc;
+        if (rc == 0) b->eof = true;
+    }
+    return 1;
+}
+
+inline int32_t rd_i32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+inline uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+const char NT16[] = "=ACMGRSVTWYHKDBN";
+
+// size in bytes of a tag value at p (type t); -1 on error / overrun
+int64_t tag_value_size(char t, const uint8_t *p, const uint8_t *end) {
+    switch (t) {
+        case 'A': case 'c': case 'C': return 1;
+        case 's': case 'S': return 2;
+        case 'i': case 'I': case 'f': return 4;
+        case 'Z': case 'H': {
+            const void *z = memchr(p, 0, (size_t)(end - p));
+            return z ? (const uint8_t *)z - p + 1 : -1;
+        }
+        case 'B': {
+            if (end - p < 5) return -1;
+            const char sub = (char)p[0];
+            const int64_t cnt = rd_i32(p + 1);
+            int w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : -1;
+            if (w < 0 || cnt < 0) return -1;
+            return 5 + cnt * w;
+        }
+        default: return -1;
+    }
+}
+
+bool tag_int(char t, const uint8_t *p, int32_t *out) {
+    switch (t) {
+        case 'c': *out = (int8_t)p[0]; return true;
+        case 'C': *out = p[0]; return true;
+        case 's': { int16_t v; memcpy(&v, p, 2); *out = v; return true; }
+        case 'S': { uint16_t v; memcpy(&v, p, 2); *out = v; return true; }
+        case 'i': *out = rd_i32(p); return true;
+        case 'I': *out = (int32_t)rd_u32(p); return true;
+        default: return false;
+    }
+}
+
+// reference bases of the alignment from query + CIGAR + MD; false when MD and CIGAR disagree / MD malformed
+bool rebuild_reference(const char *query, const uint32_t *cig, int n_cig, const char *md, size_t md_len,
+                       std::string &cols, std::vector<char> &out) {
+    cols.clear();
+    size_t q = 0;
+    for (int k = 0; k < n_cig; ++k) {
+        const uint32_t op = cig[k] & 0xF, ln = cig[k] >> 4;
+        if (op == 0 || op == 7 || op == 8) { cols.append(query + q, ln); q += ln; }
+        else if (op == 1 || op == 4) q += ln;
+        else if (op == 2 || op == 3) cols.append(ln, '-');
+    }
+    const size_t start = out.size();
+    size_t i = 0, p = 0;
+    while (p < md_len) {
+        const unsigned char c = (unsigned char)md[p];
+        if (isdigit(c)) {
+            size_t run = 0;
+            while (p < md_len && isdigit((unsigned char)md[p])) { run = run * 10 + (size_t)(md[p] - '0'); ++p; }
+            const size_t take = (i < cols.size()) ? ((run < cols.size() - i) ? run : cols.size() - i) : 0;
+            out.insert(out.end(), cols.begin() + (ptrdiff_t)i, cols.begin() + (ptrdiff_t)(i + take));
+            i += run;
+        } else if (c == '^') {
+            size_t e = p + 1;
+            while (e < md_len && isalpha((unsigned char)md[e])) ++e;
+            if (e == p + 1) { out.resize(start); return false; }
+            for (size_t k = p + 1; k < e; ++k) out.push_back((char)toupper((unsigned char)md[k]));
+            i += e - p - 1;
+            p = e;
+        } else if (isalpha(c)) {
+            out.push_back((char)tolower(c));
+            ++i;
+            ++p;
+        } else {
+            out.resize(start);
+            return false;
+        }
+    }
+    if (i != cols.size()) { out.resize(start); return false; }
+    return true;
+}
+
+void stop_workers(rmr_bam *b) {
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->stop = true;
+    }
+    b->cv_work.notify_all();
+    for (auto &t : b->workers) t.join();
+    b->workers.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmr_bam_open(const char *path, rmr_bam **out) {
+    if (!path || !out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    std::unique_ptr<rmr_bam> b(new rmr_bam());
+    b->fh = fopen(path, "rb");
+    if (!b->fh) RMR_FAIL(RMR_ERR_INVALID, "cannot open %s", path);
+    auto fail = [&](int rc) {
+        stop_workers(b.get());
+        fclose(b->fh);
+        b->fh = nullptr;
+        for (auto &sl : b->slot) if (sl.zs_init) { inflateEnd(&sl.zs); sl.zs_init = false; }
+        return rc;
+    };
+    int rc = ensure(b.get(), 12);
+    if (rc < 0) return fail(rc);
+    if (rc == 0 || memcmp(b->ubuf.data(), "BAM\x01", 4) != 0) { set_error("%s is not a BAM file", path); return fail(RMR_ERR_INVALID); }
+    const int64_t l_text = rd_i32(b->ubuf.data() + 4);
+    if (l_text < 0) { set_error("corrupt BAM header"); return fail(RMR_ERR_INVALID); }
+    rc = ensure(b.get(), 12 + (size_t)l_text);
+    if (rc <= 0) { if (rc == 0) set_error("truncated BAM file"); return fail(rc < 0 ? rc : RMR_ERR_INVALID); }
+    size_t p = 8 + (size_t)l_text;
+    const int64_t n_ref = rd_i32(b->ubuf.data() + p);
+    p += 4;
+    for (int64_t r = 0; r < n_ref; ++r) {
+        rc = ensure(b.get(), p + 4);
+        if (rc <= 0) { if (rc == 0) set_error("truncated BAM file"); return fail(rc < 0 ? rc : RMR_ERR_INVALID); }
+        const int64_t l_name = rd_i32(b->ubuf.data() + p);
+        rc = ensure(b.get(), p + 4 + (size_t)l_name + 4);
+        if (rc <= 0 || l_name < 1) { if (rc >= 0) set_error("truncated BAM file"); return fail(rc < 0 ? rc : RMR_ERR_INVALID); }
+        b->refs.emplace_back(reinterpret_cast<const char *>(b->ubuf.data() + p + 4), (size_t)l_name - 1);
+        p += 4 + (size_t)l_name + 4;
+    }
+    b->header.assign(b->ubuf.begin(), b->ubuf.begin() + (ptrdiff_t)p);
+    b->upos = p;
+    *out = b.release();
+    return 0;
+}
+
+void rmr_bam_close(rmr_bam *b) {
+    if (!b) return;
+    stop_workers(b);
+    if (b->fh) fclose(b->fh);
+    for (auto &sl : b->slot) if (sl.zs_init) inflateEnd(&sl.zs);
+    delete b;
+}
+
+int rmr_bam_header(rmr_bam *b, const uint8_t **bytes, int64_t *n_bytes, int64_t *n_refs) {
+    if (!b || !bytes || !n_bytes) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    *bytes = b->header.data();
+    *n_bytes = (int64_t)b->header.size();
+    if (n_refs) *n_refs = (int64_t)b->refs.size();
+    return 0;
+}
+
+const char *rmr_bam_ref_name(rmr_bam *b, int64_t ref_id) {
+    if (!b || ref_id < 0 || ref_id >= (int64_t)b->refs.size()) return nullptr;
+    return b->refs[(size_t)ref_id].c_str();
+}
+
+int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_batch *out) {
+    if (!b || !out || max_records < 0) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    auto clr = [](auto &v) { v.clear(); };
+    clr(b->flag); clr(b->ref_id); clr(b->pos); clr(b->mapq); clr(b->l_seq); clr(b->n_cigar); clr(b->ts); clr(b->ns);
+    clr(b->sp); clr(b->sm); clr(b->sd); clr(b->has); clr(b->ref_ok); clr(b->raw); clr(b->names); clr(b->seq); clr(b->pi);
+    clr(b->md); clr(b->refseq); clr(b->cigar); clr(b->mv);
+    for (auto *v : {&b->raw_off, &b->name_off, &b->seq_off, &b->cigar_off, &b->tags_off, &b->mv_off, &b->pi_off, &b->md_off,
+                    &b->refseq_off}) { v->clear(); }
+    for (auto *v : {&b->raw_off, &b->name_off, &b->seq_off, &b->cigar_off, &b->mv_off, &b->pi_off, &b->md_off, &b->refseq_off})
+        v->push_back(0);
+    std::string cols;
+    int64_t n = 0;
+    while (n < max_records) {
+        int rc = ensure(b, 4);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            if (b->ubuf.size() - b->upos != 0) RMR_FAIL(RMR_ERR_INVALID, "truncated BAM file");
+            break;
+        }
+        const int64_t bs = rd_i32(b->ubuf.data() + b->upos);
+        if (bs < 32) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM record");
+        rc = ensure(b, 4 + (size_t)bs);
+        if (rc < 0) return rc;
+        if (rc == 0) RMR_FAIL(RMR_ERR_INVALID, "truncated BAM file");
+        const uint8_t *rec = b->ubuf.data() + b->upos + 4;
+        const uint8_t *end = rec + bs;
+        const int32_t ref_id = rd_i32(rec), pos = rd_i32(rec + 4);
+        const int l_read_name = rec[8], mapq = rec[9];
+        const int n_cig = rec[12] | (rec[13] << 8), flag = rec[14] | (rec[15] << 8);
+        const int64_t l_seq = rd_i32(rec + 16);
+        const uint8_t *p = rec + 32;
+        if (l_seq < 0 || l_read_name < 1 || p + l_read_name + 4 * (int64_t)n_cig + (l_seq + 1) / 2 + l_seq > end)
+            RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM record");
+        b->flag.push_back(flag); b->ref_id.push_back(ref_id); b->pos.push_back(pos); b->mapq.push_back(mapq);
+        b->l_seq.push_back((int32_t)l_seq); b->n_cigar.push_back(n_cig);
+        b->raw.insert(b->raw.end(), rec, end);
+        b->raw_off.push_back((int64_t)b->raw.size());
+        b->names.insert(b->names.end(), (const char *)p, (const char *)p + l_read_name - 1);
+        b->name_off.push_back((int64_t)b->names.size());
+        p += l_read_name;
+        const size_t cig0 = b->cigar.size();
+        for (int k = 0; k < n_cig; ++k) b->cigar.push_back(rd_u32(p + 4 * k));
+        b->cigar_off.push_back((int64_t)b->cigar.size());
+        p += 4 * (size_t)n_cig;
+        const size_t seq0 = b->seq.size();
+        b->seq.resize(seq0 + (size_t)l_seq);
+        for (int64_t k = 0; k < l_seq; ++k) {
+            const uint8_t byte = p[k >> 1];
+            b->seq[seq0 + (size_t)k] = NT16[(k & 1) ? (byte & 0xF) : (byte >> 4)];
+        }
+        b->seq_off.push_back((int64_t)b->seq.size());
+        p += (l_seq + 1) / 2 + l_seq;  // packed bases + qualities
+        b->tags_off.push_back((int64_t)(p - rec));
+        // ---- tags ----
+        uint8_t has = 0;
+        int32_t ts = 0, ns = 0, sp = 0;
+        float sm = 0.f, sd = 0.f;
+        const char *md = nullptr;
+        size_t md_len = 0;
+        while (p + 3 <= end) {
+            const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
+            const uint8_t *val = p + 3;
+            const int64_t sz = tag_value_size(ty, val, end);
+            if (sz < 0 || val + sz > end) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM tag %c%c", t0, t1);
+            if (t0 == 'm' && t1 == 'v' && ty == 'B' && (val[0] == 'c' || val[0] == 'C')) {
+                const int64_t cnt = rd_i32(val + 1);
+                b->mv.insert(b->mv.end(), (const int8_t *)val + 5, (const int8_t *)val + 5 + cnt);
+                has |= 1;
+            } else if (t0 == 't' && t1 == 's' && tag_int(ty, val, &ts)) has |= 2;
+            else if (t0 == 'n' && t1 == 's' && tag_int(ty, val, &ns)) has |= 4;
+            else if (t0 == 's' && t1 == 'p' && tag_int(ty, val, &sp)) has |= 8;
+            else if (t0 == 's' && t1 == 'm' && ty == 'f') { memcpy(&sm, val, 4); has |= 16; }
+            else if (t0 == 's' && t1 == 'd' && ty == 'f') { memcpy(&sd, val, 4); has |= 32; }
+            else if (t0 == 'p' && t1 == 'i' && ty == 'Z') { b->pi.insert(b->pi.end(), (const char *)val, (const char *)val + sz - 1); has |= 64; }
+            else if (t0 == 'M' && t1 == 'D' && ty == 'Z') {
+                md = (const char *)val; md_len = (size_t)sz - 1;
+                b->md.insert(b->md.end(), md, md + md_len);
+                has |= 128;
+            }
+            p = val + sz;
+        }
+        if (p != end) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM tag region");
+        b->mv_off.push_back((int64_t)b->mv.size());
+        b->pi_off.push_back((int64_t)b->pi.size());
+        b->md_off.push_back((int64_t)b->md.size());
+        b->ts.push_back(ts); b->ns.push_back(ns); b->sp.push_back(sp); b->sm.push_back(sm); b->sd.push_back(sd);
+        b->has.push_back(has);
+        uint8_t ok = 0;
+        if (want_ref && md && !(flag & 4))
+            ok = rebuild_reference(b->seq.data() + seq0, b->cigar.data() + cig0, n_cig, md, md_len, cols, b->refseq) ? 1 : 0;
+        b->ref_ok.push_back(ok);
+        b->refseq_off.push_back((int64_t)b->refseq.size());
+        b->upos += 4 + (size_t)bs;
+        ++n;
+    }
+    out->n_records = n;
+    out->flag = b->flag.data(); out->ref_id = b->ref_id.data(); out->pos = b->pos.data(); out->mapq = b->mapq.data();
+    out->l_seq = b->l_seq.data(); out->n_cigar = b->n_cigar.data();
+    out->raw_off = b->raw_off.data(); out->raw = b->raw.data();
+    out->name_off = b->name_off.data(); out->names = b->names.data();
+    out->seq_off = b->seq_off.data(); out->seq = b->seq.data();
+    out->cigar_off = b->cigar_off.data(); out->cigar = b->cigar.data();
+    out->tags_off = b->tags_off.data();
+    out->has = b->has.data();
+    out->mv_off = b->mv_off.data(); out->mv = b->mv.data();
+    out->ts = b->ts.data(); out->ns = b->ns.data(); out->sp = b->sp.data(); out->sm = b->sm.data(); out->sd = b->sd.data();
+    out->pi_off = b->pi_off.data(); out->pi = b->pi.data();
+    out->md_off = b->md_off.data(); out->md = b->md.data();
+    out->ref_ok = b->ref_ok.data(); out->refseq_off = b->refseq_off.data(); out->refseq = b->refseq.data();
+    return 0;
+}
+
+}  // extern "C"

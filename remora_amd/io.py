@@ -204,8 +204,127 @@ def _read_exact(fh, n):
     return buf
 
 
-def iter_bam_records(bam_path):
-    """Yield BamRecord for every alignment of a BAM file, streaming (one record in memory at a time)."""
+class _NativeBamRecord(BamRecord):
+    """BamRecord filled from a native batch (rmr_bam_read_batch): the hot fields are there at once, everything else
+    (full tag list, tag byte spans, CIGAR tuples, qualities) is decoded from the record bytes on first use."""
+
+    def __init__(self, query_name, flag, reference_id, reference_name, reference_start, mapping_quality, query_sequence,
+                 raw, tags_offset, n_cigar, hot, ref_seq):
+        self.query_name, self.flag, self.reference_id, self.reference_name = query_name, flag, reference_id, reference_name
+        self.reference_start, self.mapping_quality, self.query_sequence = reference_start, mapping_quality, query_sequence
+        self.raw, self.tags_offset, self._n_cigar, self._hot, self._ref_seq = raw, tags_offset, n_cigar, hot, ref_seq
+
+    def _parse_all_tags(self):
+        spans = []
+        self._tags = _parse_tags(self.raw[self.tags_offset :], spans)
+        self._tag_spans = spans
+
+    @property
+    def tags(self):
+        if "_tags" not in self.__dict__:
+            self._parse_all_tags()
+        return self._tags
+
+    @property
+    def tag_spans(self):
+        if "_tag_spans" not in self.__dict__:
+            self._parse_all_tags()
+        return self._tag_spans
+
+    @property
+    def cigartuples(self):
+        if "_cigartuples" not in self.__dict__:
+            cig = np.frombuffer(self.raw, dtype="<u4", count=self._n_cigar, offset=32 + self.raw[8])
+            self._cigartuples = list(zip((cig & 0xF).tolist(), (cig >> 4).tolist()))
+        return self._cigartuples
+
+    @property
+    def query_qualities(self):
+        l_seq = len(self.query_sequence)
+        q = 32 + self.raw[8] + 4 * self._n_cigar + (l_seq + 1) // 2
+        return bytes(self.raw[q : q + l_seq])
+
+    def hot_tags(self):
+        """{name: value} of the tags Read.add_alignment looks at (mv, ts, ns, sp, sm, sd, pi), without parsing the
+        whole tag region; mv as an int8 numpy array."""
+        return self._hot
+
+    def get_reference_sequence(self):
+        if self._ref_seq is None:  # no MD tag, unmapped, or not requested from the native reader: python path decides
+            return BamRecord.get_reference_sequence(self)
+        return self._ref_seq
+
+
+def _iter_bam_records_native(bam_path, want_ref, batch):
+    lib = L.lib()
+    h = ctypes.c_void_p()
+    L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+    try:
+        refs = {}
+        bb = L.BamBatch()
+        arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,))
+                                      if count else np.zeros(0, dt))  # noqa: E731
+        while True:
+            L.check(lib.rmr_bam_read_batch(h, batch, int(bool(want_ref)), ctypes.byref(bb)))
+            n = int(bb.n_records)
+            if n == 0:
+                return
+            i32 = lambda f: arr(getattr(bb, f), ctypes.c_int32, n).tolist()  # noqa: E731
+            off = lambda f: arr(getattr(bb, f), ctypes.c_int64, n + 1).tolist()  # noqa: E731
+            flag, ref_id, pos, mapq, n_cig = i32("flag"), i32("ref_id"), i32("pos"), i32("mapq"), i32("n_cigar")
+            ts, ns, sp = i32("ts"), i32("ns"), i32("sp")
+            sm, sd = arr(bb.sm, ctypes.c_float, n).tolist(), arr(bb.sd, ctypes.c_float, n).tolist()
+            has, ref_ok = arr(bb.has, ctypes.c_uint8, n).tolist(), arr(bb.ref_ok, ctypes.c_uint8, n).tolist()
+            raw_off, name_off, seq_off, mv_off, pi_off, rs_off = (off(f) for f in (
+                "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off"))
+            tags_off = arr(bb.tags_off, ctypes.c_int64, n).tolist()
+            blob = lambda ptr, total: ctypes.string_at(ptr, total) if total else b""  # noqa: E731
+            raw, names, seq = blob(bb.raw, raw_off[n]), blob(bb.names, name_off[n]).decode(), blob(bb.seq, seq_off[n]).decode()
+            pi, refseq = blob(bb.pi, pi_off[n]).decode(), blob(bb.refseq, rs_off[n]).decode()
+            mv = np.frombuffer(blob(bb.mv, mv_off[n]), np.int8)
+            for i in range(n):
+                h_i = has[i]
+                hot = {}
+                if h_i & 1:
+                    hot["mv"] = mv[mv_off[i] : mv_off[i + 1]]
+                if h_i & 2:
+                    hot["ts"] = ts[i]
+                if h_i & 4:
+                    hot["ns"] = ns[i]
+                if h_i & 8:
+                    hot["sp"] = sp[i]
+                if h_i & 16:
+                    hot["sm"] = sm[i]
+                if h_i & 32:
+                    hot["sd"] = sd[i]
+                if h_i & 64:
+                    hot["pi"] = pi[pi_off[i] : pi_off[i + 1]]
+                rid = ref_id[i]
+                if rid >= 0 and rid not in refs:
+                    nm = lib.rmr_bam_ref_name(h, rid)
+                    refs[rid] = nm.decode() if nm is not None else None
+                yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
+                                       pos[i], mapq[i], seq[seq_off[i] : seq_off[i + 1]], raw[raw_off[i] : raw_off[i + 1]],
+                                       tags_off[i], n_cig[i], hot,
+                                       refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None)
+            if n < batch:
+                return
+    finally:
+        lib.rmr_bam_close(h)
+
+
+def iter_bam_records(bam_path, want_ref=False, batch=512, native=True):
+    """Yield a BamRecord for every alignment of a BAM file, streaming.  By default the records come from the native
+    reader (rmr_bam_read_batch: BGZF inflate, record split, hot tags and - with want_ref - the MD reconstruction in
+    C++, `batch` records per call); native=False is the pure-Python reader the native one is tested against."""
+    if native:
+        yield from _iter_bam_records_native(bam_path, want_ref, batch)
+        return
+    yield from _iter_bam_records_py(bam_path)
+
+
+def _iter_bam_records_py(bam_path):
+    """Pure-Python BGZF/BAM reader (gzip + struct), one record in memory at a time."""
     with gzip.open(bam_path, "rb") as fh:  # BGZF members are valid concatenated gzip members
         if fh.read(4) != b"BAM\x01":
             raise RemoraError(f"{bam_path} is not a BAM file")
@@ -548,7 +667,7 @@ class Read:
             raise RemoraError("Must add signal to io.Read before alignment.")
         self.full_align = rec.to_dict()
         self.record = rec
-        tags = dict(rec.tags)
+        tags = rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)
         if reverse_signal:
             self.dacs = self.dacs[::-1]
         self.dacs = self.dacs[tags.get("sp", 0) :]
@@ -690,7 +809,7 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
         if decode_batch > 1:  # the move tables of the whole batch in one launch
             have, mvs, sls, qls = [], [], [], []
             for k, ((rec, _rid), read) in enumerate(zip(recs, reads)):
-                tags = dict(rec.tags)
+                tags = rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)
                 if "mv" in tags and read.dacs is not None:
                     # signal length after the sp / ts / ns trimming add_alignment applies (same slicing rules)
                     sls.append(len(range(read.dacs.size)[tags.get("sp", 0) :][tags.get("ts", 0) : tags.get("ns", None)]))
@@ -709,10 +828,10 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
             yield read, None
 
     pending = []
-    for rec in iter_bam_records(bam_path):
+    for rec in iter_bam_records(bam_path, want_ref=parse_ref_align):
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
-        rid = dict(rec.tags).get("pi", rec.query_name)
+        rid = (rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)).get("pi", rec.query_name)
         if rid not in signals:
             continue
         pending.append((rec, rid))
