@@ -100,6 +100,10 @@ def lib():
                     f"{LIB_PATH} not found: build the HIP extension first "
                     "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
                 )
+            # PyTorch-ROCm ships its own HIP runtime: it has to be in the process before this library pulls in
+            # /opt/rocm's, otherwise the second runtime to initialise finds "no ROCm-capable device"
+            import torch  # noqa: F401
+
             try:
                 L = ctypes.CDLL(LIB_PATH)
             except OSError as e:

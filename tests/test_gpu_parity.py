@@ -1354,3 +1354,21 @@ def test_infer_pipeline_repeated_calls_and_large_move_batches(torch_cuda, O, tmp
         tags.append(np.concatenate([[5], mv]).astype(np.int8)); sls.append(5 * n + 2); qls.append(int(mv.sum()))
     for t, sl, ql, r in zip(tags, sls, qls, parse_move_tags(tags, sls, qls)):
         assert np.array_equal(r[0], O.parse_move_tag(t, sl, seq_len=ql)[0])
+
+
+def test_library_can_be_touched_before_torch(torch_cuda):
+    """A fresh process that reads a BAM file through the native reader (which loads libremora_hip.so) before
+    anything imported torch can still create an engine afterwards: the loader brings PyTorch's HIP runtime in
+    first (two HIP runtimes in the wrong order end in "no ROCm-capable device")."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from remora_amd import io as rio\n"
+            "n = sum(1 for _ in rio.iter_bam_records(%r))\n"
+            "assert 'torch' in sys.modules\n"
+            "from remora_amd.engine import get_engine\n"
+            "get_engine().synchronize(); print('ok', n)\n") % (root, os.path.join(root, "tests", "golden", "data", "can_mappings.bam"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok 14", r.stderr[-1500:]
