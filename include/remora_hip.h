@@ -172,6 +172,16 @@ int rmr_bam_header(rmr_bam *b, const uint8_t **bytes, int64_t *n_bytes, int64_t 
 const char *rmr_bam_ref_name(rmr_bam *b, int64_t ref_id); /* NULL when out of range */
 int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_batch *out);
 
+/* ---- N1: POD5 signal rows, the zstd layer (host code, parallel over rows) ----------------------------- */
+/* replaces: the zstd step of pod5's signal reader under io.iter_signal (src/remora/io.py:441-474).  `src[i]`
+ * points at row i's compressed bytes (one zstd frame, src_len[i] bytes).  rmr_zstd_frame_sizes reads the
+ * decompressed size of every frame from its header; rmr_zstd_rows inflates row i into out[out_off[i] ..
+ * out_off[i+1]) (that span must equal the frame's content size) with `n_threads` threads.  libzstd.so.1 is
+ * loaded from the system at run time. */
+int rmr_zstd_frame_sizes(const uint8_t *const *src, const int64_t *src_len, int64_t n_rows, int64_t *sizes);
+int rmr_zstd_rows(const uint8_t *const *src, const int64_t *src_len, int64_t n_rows, uint8_t *out,
+                  const int64_t *out_off, int n_threads);
+
 /* ---- N1: POD5 signal decompression (the VBZ layer below zstd) ------------------------------ */
 /* replaces: the per-row signal decode that pod5's C++ reader performs for the records consumed by
  * io.iter_signal (src/remora/io.py:441-474) / Read.from_pod5_and_alignment (:2086-2121):

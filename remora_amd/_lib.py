@@ -67,6 +67,8 @@ SIGNATURES = {
     "rmr_bam_header": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "rmr_bam_ref_name": (ctypes.c_char_p, [c_vp, c_i64]),
     "rmr_bam_read_batch": (c_int, [c_vp, c_i64, c_int, c_vp]),
+    "rmr_zstd_frame_sizes": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "rmr_zstd_rows": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_vbz_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
     "rmr_motif_flags": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),

@@ -1,5 +1,6 @@
 """Read-side helper of the hot path: move-table expansion (src/remora/io.py:394-407)."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -413,17 +414,21 @@ def vbz_decode_batch(blobs, n_samples, engine=None, to_host=True):
     from .engine import get_engine
 
     eng = engine if engine is not None else get_engine()
-    raws = [_zstd_decompress(b) for b in blobs]
-    n = len(raws)
+    # the zstd layer of all rows, inflated by native threads straight into the buffer the kernel uploads
+    n = len(blobs)
+    blobs = [b if isinstance(b, bytes) else bytes(b) for b in blobs]
+    src = (ctypes.c_char_p * max(n, 1))(*blobs)
+    src_len = np.asarray([len(b) for b in blobs], np.int64)
+    sizes = np.zeros(max(n, 1), np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.check(L.lib().rmr_zstd_frame_sizes(src, p(src_len), n, p(sizes)))
     row_off = np.zeros(n + 1, np.int64)
-    np.cumsum([len(r) for r in raws], out=row_off[1:])
+    np.cumsum(sizes[:n], out=row_off[1:])
     out_off = np.zeros(n + 1, np.int64)
     np.cumsum(np.asarray(n_samples, np.int64), out=out_off[1:])
     buf = np.zeros(int(row_off[-1]) + 16, np.uint8)  # the kernel reads whole dwords: a little slack at the end
-    for r, st in zip(raws, row_off):
-        buf[st : st + len(r)] = np.frombuffer(r, np.uint8)
+    L.check(L.lib().rmr_zstd_rows(src, p(src_len), n, p(buf), p(row_off), min(8, os.cpu_count() or 1)))
     rn = np.ascontiguousarray(n_samples, np.int32)
-    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     if to_host:
         out = np.empty(int(out_off[-1]), np.int16)
         L.check(L.lib().rmr_vbz_decode(eng.handle, p(buf), p(row_off), p(rn), n, p(out), L.MEM_HOST))
