@@ -1097,3 +1097,46 @@ def test_native_bam_reader_equals_python_reader(tmp_path):
         list(rio.iter_bam_records(notbam))
     with pytest.raises(RemoraError, match="cannot open"):
         list(rio.iter_bam_records(str(tmp_path / "missing.bam")))
+
+
+def test_native_zstd_rows_equal_libzstd_one_shot():
+    """rmr_zstd_frame_sizes / rmr_zstd_rows (native threads, one zstd context each) on the signal rows of the
+    reference's POD5 files: the same bytes as the one-shot decompression, for 1 and 8 threads; corrupt frames and
+    a wrong output span are refused."""
+    import ctypes
+
+    from remora_amd import RemoraError
+    from remora_amd import _lib as L
+    from remora_amd import io as rio
+
+    blobs = []
+    for which in ("can", "mod"):
+        f = rio.Pod5File(os.path.join(ROOT, "tests", "golden", "data", f"{which}_reads.pod5"))
+        rows = f._sig.column("signal")
+        blobs += [rows[i].as_py() for i in range(f._sig.num_rows)]
+    ref = [rio._zstd_decompress(b) for b in blobs]
+    n = len(blobs)
+    src = (ctypes.c_char_p * n)(*blobs)
+    src_len = np.asarray([len(b) for b in blobs], np.int64)
+    sizes = np.zeros(n, np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.check(L.lib().rmr_zstd_frame_sizes(src, p(src_len), n, p(sizes)))
+    assert sizes.tolist() == [len(r) for r in ref]
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    for threads in (1, 8):
+        buf = np.zeros(int(off[-1]), np.uint8)
+        L.check(L.lib().rmr_zstd_rows(src, p(src_len), n, p(buf), p(off), threads))
+        assert all(bytes(buf[off[i] : off[i + 1]]) == ref[i] for i in range(n))
+    bad = [bytearray(b) for b in blobs[:3]]
+    bad[1][len(bad[1]) // 2] ^= 0xFF
+    bsrc = (ctypes.c_char_p * 3)(*[bytes(b) for b in bad])
+    with pytest.raises(RemoraError, match="corrupt zstd frame"):
+        L.check(L.lib().rmr_zstd_rows(bsrc, p(src_len), 3, p(np.zeros(int(off[3]), np.uint8)), p(off), 2))
+    short = off.copy()
+    short[1:] -= 1
+    with pytest.raises(RemoraError, match="corrupt zstd frame"):
+        L.check(L.lib().rmr_zstd_rows(src, p(src_len), 2, p(np.zeros(int(off[2]), np.uint8)), p(short), 1))
+    with pytest.raises(RemoraError, match="not a zstd frame"):
+        junk = (ctypes.c_char_p * 1)(b"not zstd at all")
+        L.check(L.lib().rmr_zstd_frame_sizes(junk, p(np.asarray([15], np.int64)), 1, p(np.zeros(1, np.int64))))
