@@ -258,7 +258,7 @@ bool rebuild_reference(const char *query, const uint32_t *cig, int n_cig, const 
             size_t run = 0;
             while (p < md_len && isdigit((unsigned char)md[p])) { run = run * 10 + (size_t)(md[p] - '0'); ++p; }
             const size_t take = (i < cols.size()) ? ((run < cols.size() - i) ? run : cols.size() - i) : 0;
-            out.insert(out.end(), cols.begin() + (ptrdiff_t)i, cols.begin() + (ptrdiff_t)(i + take));
+            if (take) out.insert(out.end(), cols.begin() + (ptrdiff_t)i, cols.begin() + (ptrdiff_t)(i + take));
             i += run;
         } else if (c == '^') {
             size_t e = p + 1;
