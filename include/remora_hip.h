@@ -164,6 +164,7 @@ typedef struct rmr_bam_batch {
     const int64_t *md_off;    const char *md;
     const uint8_t *ref_ok;
     const int64_t *refseq_off; const char *refseq;
+    const int64_t *voffset;                            /* [n] BGZF virtual offset of the record (for rmr_bam_seek) */
 } rmr_bam_batch;
 int rmr_bam_open(const char *path, rmr_bam **out);
 void rmr_bam_close(rmr_bam *b);
@@ -171,6 +172,10 @@ void rmr_bam_close(rmr_bam *b);
 int rmr_bam_header(rmr_bam *b, const uint8_t **bytes, int64_t *n_bytes, int64_t *n_refs);
 const char *rmr_bam_ref_name(rmr_bam *b, int64_t ref_id); /* NULL when out of range */
 int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_batch *out);
+/* continue reading at a record's virtual offset (compressed block offset << 16 | offset inside the inflated block),
+ * as returned in rmr_bam_batch.voffset - the random access ReadIndexedBam.get_alignments needs
+ * (src/remora/io.py:303-325) */
+int rmr_bam_seek(rmr_bam *b, int64_t voffset);
 
 /* ---- N1: POD5 signal rows, the zstd layer (host code, parallel over rows) ----------------------------- */
 /* replaces: the zstd step of pod5's signal reader under io.iter_signal (src/remora/io.py:441-474).  `src[i]`

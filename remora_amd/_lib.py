@@ -29,7 +29,7 @@ class BamBatch(ctypes.Structure):
     _fields_ = [("n_records", c_i64)] + [(n, c_vp) for n in (
         "flag", "ref_id", "pos", "mapq", "l_seq", "n_cigar", "raw_off", "raw", "name_off", "names", "seq_off", "seq",
         "cigar_off", "cigar", "tags_off", "has", "mv_off", "mv", "ts", "ns", "sp", "sm", "sd", "pi_off", "pi", "md_off",
-        "md", "ref_ok", "refseq_off", "refseq")]
+        "md", "ref_ok", "refseq_off", "refseq", "voffset")]
 
 
 class MotifSet(ctypes.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "rmr_bam_header": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "rmr_bam_ref_name": (ctypes.c_char_p, [c_vp, c_i64]),
     "rmr_bam_read_batch": (c_int, [c_vp, c_i64, c_int, c_vp]),
+    "rmr_bam_seek": (c_int, [c_vp, c_i64]),
     "rmr_zstd_frame_sizes": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "rmr_zstd_rows": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_vbz_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),

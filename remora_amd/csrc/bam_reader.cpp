@@ -31,6 +31,9 @@ struct rmr_bam {
     std::vector<uint8_t> cbuf;    // compressed block
     std::vector<uint8_t> ubuf;    // inflated, not yet consumed bytes
     size_t upos = 0;              // consumed prefix of ubuf
+    struct Seg { size_t begin; int64_t file_off; uint32_t isize; };  // ubuf[begin, begin+isize) came from the member at file_off
+    std::vector<Seg> segs;
+    std::vector<int64_t> voff;    // per record of the batch: BGZF virtual offset (file_off << 16 | offset in block)
     bool eof = false;
     // BGZF members are independent deflate streams: kSlots of them are read ahead and inflated by as many threads
     static constexpr int kSlots = 8;
@@ -38,6 +41,7 @@ struct rmr_bam {
         std::vector<uint8_t> cbuf, out;
         uint32_t crc = 0, isize = 0;
         int clen = 0;
+        int64_t file_off = 0;
         z_stream zs{};
         bool zs_init = false;
         int rc = 0;
@@ -70,6 +74,7 @@ namespace {
 // reads the next BGZF member (compressed) into slot k; returns 1 = read, 0 = clean EOF, negative = error
 int read_member(rmr_bam *b, rmr_bam::Slot &sl) {
     uint8_t hd[12];
+    sl.file_off = (int64_t)ftello(b->fh);
     const size_t got = fread(hd, 1, 12, b->fh);
     if (got == 0) return 0;
     if (got != 12 || hd[0] != 0x1f || hd[1] != 0x8b || hd[2] != 8 || !(hd[3] & 4)) {
@@ -176,14 +181,24 @@ int next_blocks(rmr_bam *b) {
         inflate_member(b->slot[0]);
     }
     if (b->upos > 0 && b->upos >= b->ubuf.size() / 2) {  // compact the consumed prefix before growing
-        b->ubuf.erase(b->ubuf.begin(), b->ubuf.begin() + (ptrdiff_t)b->upos);
+        const size_t cut = b->upos;
+        b->ubuf.erase(b->ubuf.begin(), b->ubuf.begin() + (ptrdiff_t)cut);
         b->upos = 0;
+        size_t keep = 0;
+        for (auto &sg : b->segs) {  // drop fully consumed members, shift the rest (begin may become "negative")
+            if (sg.begin + sg.isize <= cut) continue;
+            rmr_bam::Seg t = sg;
+            t.begin = sg.begin - cut;  // size_t wrap-around is fine: only begin + offset sums are used
+            b->segs[keep++] = t;
+        }
+        b->segs.resize(keep);
     }
     for (int k = 0; k < n; ++k) {
         if (b->slot[k].rc != 0) {
             set_error(b->slot[k].rc == 1 ? "corrupt BGZF block (inflate)" : "corrupt BGZF block (crc)");
             return RMR_ERR_INVALID;
         }
+        if (b->slot[k].isize) b->segs.push_back({b->ubuf.size(), b->slot[k].file_off, b->slot[k].isize});
         b->ubuf.insert(b->ubuf.end(), b->slot[k].out.begin(), b->slot[k].out.end());
     }
     return n;
@@ -357,7 +372,7 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
     auto clr = [](auto &v) { v.clear(); };
     clr(b->flag); clr(b->ref_id); clr(b->pos); clr(b->mapq); clr(b->l_seq); clr(b->n_cigar); clr(b->ts); clr(b->ns);
     clr(b->sp); clr(b->sm); clr(b->sd); clr(b->has); clr(b->ref_ok); clr(b->raw); clr(b->names); clr(b->seq); clr(b->pi);
-    clr(b->md); clr(b->refseq); clr(b->cigar); clr(b->mv);
+    clr(b->md); clr(b->refseq); clr(b->cigar); clr(b->mv); clr(b->voff);
     for (auto *v : {&b->raw_off, &b->name_off, &b->seq_off, &b->cigar_off, &b->tags_off, &b->mv_off, &b->pi_off, &b->md_off,
                     &b->refseq_off}) { v->clear(); }
     for (auto *v : {&b->raw_off, &b->name_off, &b->seq_off, &b->cigar_off, &b->mv_off, &b->pi_off, &b->md_off, &b->refseq_off})
@@ -373,6 +388,11 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         }
         const int64_t bs = rd_i32(b->ubuf.data() + b->upos);
         if (bs < 32) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM record");
+        int64_t vo = -1;
+        for (const auto &sg : b->segs) {  // few entries: the members currently buffered
+            const size_t rel = b->upos - sg.begin;  // wraps for members that start before the buffer
+            if (rel < sg.isize) { vo = (sg.file_off << 16) | (int64_t)rel; break; }
+        }
         rc = ensure(b, 4 + (size_t)bs);
         if (rc < 0) return rc;
         if (rc == 0) RMR_FAIL(RMR_ERR_INVALID, "truncated BAM file");
@@ -385,6 +405,7 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         const uint8_t *p = rec + 32;
         if (l_seq < 0 || l_read_name < 1 || p + l_read_name + 4 * (int64_t)n_cig + (l_seq + 1) / 2 + l_seq > end)
             RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM record");
+        b->voff.push_back(vo);
         b->flag.push_back(flag); b->ref_id.push_back(ref_id); b->pos.push_back(pos); b->mapq.push_back(mapq);
         b->l_seq.push_back((int32_t)l_seq); b->n_cigar.push_back(n_cig);
         b->raw.insert(b->raw.end(), rec, end);
@@ -461,6 +482,22 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
     out->pi_off = b->pi_off.data(); out->pi = b->pi.data();
     out->md_off = b->md_off.data(); out->md = b->md.data();
     out->ref_ok = b->ref_ok.data(); out->refseq_off = b->refseq_off.data(); out->refseq = b->refseq.data();
+    out->voffset = b->voff.data();
+    return 0;
+}
+
+int rmr_bam_seek(rmr_bam *b, int64_t voffset) {
+    if (!b || voffset < 0) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    if (fseeko(b->fh, (off_t)(voffset >> 16), SEEK_SET) != 0) RMR_FAIL(RMR_ERR_INVALID, "seek failed");
+    b->ubuf.clear();
+    b->segs.clear();
+    b->upos = 0;
+    b->eof = false;
+    const size_t within = (size_t)(voffset & 0xFFFF);
+    const int rc = ensure(b, within + 1);
+    if (rc < 0) return rc;
+    if (rc == 0) RMR_FAIL(RMR_ERR_INVALID, "virtual offset beyond the end of the file");
+    b->upos = within;
     return 0;
 }
 

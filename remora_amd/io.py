@@ -210,10 +210,11 @@ class _NativeBamRecord(BamRecord):
     (full tag list, tag byte spans, CIGAR tuples, qualities) is decoded from the record bytes on first use."""
 
     def __init__(self, query_name, flag, reference_id, reference_name, reference_start, mapping_quality, query_sequence,
-                 raw, tags_offset, n_cigar, hot, ref_seq):
+                 raw, tags_offset, n_cigar, hot, ref_seq, voffset=-1):
         self.query_name, self.flag, self.reference_id, self.reference_name = query_name, flag, reference_id, reference_name
         self.reference_start, self.mapping_quality, self.query_sequence = reference_start, mapping_quality, query_sequence
         self.raw, self.tags_offset, self._n_cigar, self._hot, self._ref_seq = raw, tags_offset, n_cigar, hot, ref_seq
+        self.voffset = voffset  # BGZF virtual offset of the record in its file
 
     def _parse_all_tags(self):
         spans = []
@@ -256,62 +257,183 @@ class _NativeBamRecord(BamRecord):
         return self._ref_seq
 
 
-def _iter_bam_records_native(bam_path, want_ref, batch):
+def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None):
+    """Records of a BAM file from the native reader; with `voffsets` only the records at those virtual offsets
+    (one seek + one record each), otherwise the whole file in order."""
     lib = L.lib()
     h = ctypes.c_void_p()
     L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
     try:
-        refs = {}
-        bb = L.BamBatch()
-        arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,))
-                                      if count else np.zeros(0, dt))  # noqa: E731
-        while True:
-            L.check(lib.rmr_bam_read_batch(h, batch, int(bool(want_ref)), ctypes.byref(bb)))
-            n = int(bb.n_records)
-            if n == 0:
-                return
-            i32 = lambda f: arr(getattr(bb, f), ctypes.c_int32, n).tolist()  # noqa: E731
-            off = lambda f: arr(getattr(bb, f), ctypes.c_int64, n + 1).tolist()  # noqa: E731
-            flag, ref_id, pos, mapq, n_cig = i32("flag"), i32("ref_id"), i32("pos"), i32("mapq"), i32("n_cigar")
-            ts, ns, sp = i32("ts"), i32("ns"), i32("sp")
-            sm, sd = arr(bb.sm, ctypes.c_float, n).tolist(), arr(bb.sd, ctypes.c_float, n).tolist()
-            has, ref_ok = arr(bb.has, ctypes.c_uint8, n).tolist(), arr(bb.ref_ok, ctypes.c_uint8, n).tolist()
-            raw_off, name_off, seq_off, mv_off, pi_off, rs_off = (off(f) for f in (
-                "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off"))
-            tags_off = arr(bb.tags_off, ctypes.c_int64, n).tolist()
-            blob = lambda ptr, total: ctypes.string_at(ptr, total) if total else b""  # noqa: E731
-            raw, names, seq = blob(bb.raw, raw_off[n]), blob(bb.names, name_off[n]).decode(), blob(bb.seq, seq_off[n]).decode()
-            pi, refseq = blob(bb.pi, pi_off[n]).decode(), blob(bb.refseq, rs_off[n]).decode()
-            mv = np.frombuffer(blob(bb.mv, mv_off[n]), np.int8)
-            for i in range(n):
-                h_i = has[i]
-                hot = {}
-                if h_i & 1:
-                    hot["mv"] = mv[mv_off[i] : mv_off[i + 1]]
-                if h_i & 2:
-                    hot["ts"] = ts[i]
-                if h_i & 4:
-                    hot["ns"] = ns[i]
-                if h_i & 8:
-                    hot["sp"] = sp[i]
-                if h_i & 16:
-                    hot["sm"] = sm[i]
-                if h_i & 32:
-                    hot["sd"] = sd[i]
-                if h_i & 64:
-                    hot["pi"] = pi[pi_off[i] : pi_off[i + 1]]
-                rid = ref_id[i]
-                if rid >= 0 and rid not in refs:
-                    nm = lib.rmr_bam_ref_name(h, rid)
-                    refs[rid] = nm.decode() if nm is not None else None
-                yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
-                                       pos[i], mapq[i], seq[seq_off[i] : seq_off[i + 1]], raw[raw_off[i] : raw_off[i + 1]],
-                                       tags_off[i], n_cig[i], hot,
-                                       refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None)
-            if n < batch:
-                return
+        if voffsets is not None:
+            for vo in voffsets:
+                L.check(lib.rmr_bam_seek(h, int(vo)))
+                yield from _native_batches(lib, h, want_ref, 1, once=True)
+            return
+        yield from _native_batches(lib, h, want_ref, batch)
     finally:
         lib.rmr_bam_close(h)
+
+
+def _native_batches(lib, h, want_ref, batch, once=False):
+    refs = {}
+    bb = L.BamBatch()
+    arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,))
+                                  if count else np.zeros(0, dt))  # noqa: E731
+    while True:
+        L.check(lib.rmr_bam_read_batch(h, batch, int(bool(want_ref)), ctypes.byref(bb)))
+        n = int(bb.n_records)
+        if n == 0:
+            return
+        i32 = lambda f: arr(getattr(bb, f), ctypes.c_int32, n).tolist()  # noqa: E731
+        off = lambda f: arr(getattr(bb, f), ctypes.c_int64, n + 1).tolist()  # noqa: E731
+        flag, ref_id, pos, mapq, n_cig = i32("flag"), i32("ref_id"), i32("pos"), i32("mapq"), i32("n_cigar")
+        ts, ns, sp = i32("ts"), i32("ns"), i32("sp")
+        sm, sd = arr(bb.sm, ctypes.c_float, n).tolist(), arr(bb.sd, ctypes.c_float, n).tolist()
+        has, ref_ok = arr(bb.has, ctypes.c_uint8, n).tolist(), arr(bb.ref_ok, ctypes.c_uint8, n).tolist()
+        raw_off, name_off, seq_off, mv_off, pi_off, rs_off = (off(f) for f in (
+            "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off"))
+        tags_off = arr(bb.tags_off, ctypes.c_int64, n).tolist()
+        voff = arr(bb.voffset, ctypes.c_int64, n).tolist()
+        blob = lambda ptr, total: ctypes.string_at(ptr, total) if total else b""  # noqa: E731
+        raw, names, seq = blob(bb.raw, raw_off[n]), blob(bb.names, name_off[n]).decode(), blob(bb.seq, seq_off[n]).decode()
+        pi, refseq = blob(bb.pi, pi_off[n]).decode(), blob(bb.refseq, rs_off[n]).decode()
+        mv = np.frombuffer(blob(bb.mv, mv_off[n]), np.int8)
+        for i in range(n):
+            h_i = has[i]
+            hot = {}
+            if h_i & 1:
+                hot["mv"] = mv[mv_off[i] : mv_off[i + 1]]
+            if h_i & 2:
+                hot["ts"] = ts[i]
+            if h_i & 4:
+                hot["ns"] = ns[i]
+            if h_i & 8:
+                hot["sp"] = sp[i]
+            if h_i & 16:
+                hot["sm"] = sm[i]
+            if h_i & 32:
+                hot["sd"] = sd[i]
+            if h_i & 64:
+                hot["pi"] = pi[pi_off[i] : pi_off[i + 1]]
+            rid = ref_id[i]
+            if rid >= 0 and rid not in refs:
+                nm = lib.rmr_bam_ref_name(h, rid)
+                refs[rid] = nm.decode() if nm is not None else None
+            yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
+                                   pos[i], mapq[i], seq[seq_off[i] : seq_off[i + 1]], raw[raw_off[i] : raw_off[i + 1]],
+                                   tags_off[i], n_cig[i], hot,
+                                   refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None, voff[i])
+        if n < batch or once:
+            return
+
+
+def read_is_primary(read):
+    """Not secondary and not supplementary (src/remora/io.py:147-154)."""
+    return not (read.is_supplementary or read.is_secondary)
+
+
+def get_parent_id(bam_read):
+    """The `pi` tag of a split read's child record, else the record's own name (src/remora/io.py:176-182)."""
+    hot = bam_read.hot_tags() if hasattr(bam_read, "hot_tags") else dict(bam_read.tags)
+    return hot.get("pi", bam_read.query_name)
+
+
+class ReadIndexedBam:
+    """BAM file indexed by (parent) read id, the reference's ReadIndexedBam (src/remora/io.py:184-358) without
+    pysam: one streaming pass of the native reader records the BGZF virtual offset of every kept record,
+    `get_alignments(read_id)` seeks to them.  Same constructor arguments and attributes: num_records, num_reads,
+    read_ids, skip_reasons, `in`, [] (-> offsets), get_alignments, get_first_alignment, iteration over all records."""
+
+    def __init__(self, bam_path, skip_non_primary=True, req_tags=None, read_id_converter=None, parent_read_id_subset=None,
+                 child_read_id_subset=None):
+        self.bam_path, self.skip_non_primary, self.req_tags = bam_path, skip_non_primary, req_tags
+        self.read_id_converter = read_id_converter
+        self.parent_read_id_subset, self.child_read_id_subset = parent_read_id_subset, child_read_id_subset
+        self.num_reads = self.num_records = None
+        self._bam_idx = None
+        self.compute_read_index()
+
+    reference_filename = property(lambda s: s.bam_path)
+    filename = property(lambda s: s.bam_path)
+
+    def compute_read_index(self):
+        from collections import defaultdict
+
+        idx = defaultdict(list)
+        self.num_records = 0
+        self.skip_reasons = defaultdict(int)
+        for rec in iter_bam_records(self.bam_path):
+            if self.child_read_id_subset is not None and rec.query_name not in self.child_read_id_subset:
+                self.skip_reasons["Child read ID filtered"] += 1
+                continue
+            rid = get_parent_id(rec)
+            if self.parent_read_id_subset is not None and rid not in self.parent_read_id_subset:
+                self.skip_reasons["Parent read ID filtered"] += 1
+                continue
+            if self.read_id_converter is not None:
+                rid = self.read_id_converter(rid)
+            if self.req_tags is not None and set(self.req_tags).difference(k for k, _ in rec.tags):
+                self.skip_reasons["Missing BAM tags"] += 1
+                continue
+            if self.skip_non_primary and not read_is_primary(rec):
+                self.skip_reasons["Non-primary alignment"] += 1
+                continue
+            self.num_records += 1
+            idx[rid].append(rec.voffset)
+        self._bam_idx = dict(idx)
+        self.num_reads = len(self._bam_idx)
+
+    def get_alignments(self, read_id, want_ref=True):
+        if self._bam_idx is None:
+            raise RemoraError("Bam index not yet computed")
+        try:
+            offsets = self._bam_idx[read_id]
+        except KeyError:
+            raise RemoraError(f"Could not find {read_id} in {self.bam_path}")
+        yield from _iter_bam_records_native(self.bam_path, want_ref, 1, voffsets=offsets)
+
+    def get_first_alignment(self, read_id):
+        return next(self.get_alignments(read_id))
+
+    def __contains__(self, read_id):
+        return read_id in self._bam_idx
+
+    def __getitem__(self, read_id):
+        return self._bam_idx[read_id]
+
+    @property
+    def read_ids(self):
+        return list(self._bam_idx.keys())
+
+    def __iter__(self):
+        return iter_bam_records(self.bam_path)
+
+
+def get_read_ids(bam_idx, pod5_file, num_reads, return_num_bam_reads=False):
+    """Read ids present in both the BAM index and the POD5 file, and how many to process (src/remora/io.py:362-391):
+    the number of parent reads, or - `return_num_bam_reads` - of BAM records under those parents, capped at num_reads."""
+    both = list(set(pod5_file.read_ids).intersection(bam_idx.read_ids))
+    count = sum(len(bam_idx[r]) for r in both) if return_num_bam_reads else len(both)
+    return both, count if num_reads is None else min(num_reads, count)
+
+
+def extract_alignments(read_err, bam_idx, rev_sig=False, pa_scaling=None):
+    """Every alignment of a signal read as its own io.Read (src/remora/io.py:489-511): [(read, error | None)]."""
+    io_read, err = read_err
+    if io_read is None:
+        return [read_err]
+    out = []
+    try:
+        for rec in bam_idx.get_alignments(io_read.read_id):
+            aligned = io_read.copy()
+            try:
+                aligned.add_alignment(rec, reverse_signal=rev_sig, pa_scaling=pa_scaling)
+                out.append((aligned, None))
+            except RemoraError as e:
+                out.append((aligned, str(e)))
+    except RemoraError as e:
+        return [(io_read, str(e))]
+    return out
 
 
 def iter_bam_records(bam_path, want_ref=False, batch=512, native=True):

@@ -1223,3 +1223,67 @@ def test_native_bam_reader_fuzz_all_tag_types(tmp_path):
             except ValueError as e:
                 rec._r = "ValueError"
         assert x._r == y._r
+
+
+def test_read_indexed_bam(tmp_path):
+    """ReadIndexedBam on the reference's BAM files and on a file with secondary / supplementary / split-read
+    records: counts, skip reasons, read ids, random access through BGZF virtual offsets (records equal the streamed
+    ones), filters, get_read_ids."""
+    import struct
+
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    bam = os.path.join(ROOT, "tests", "golden", "data", "can_mappings.bam")
+    streamed = list(rio.iter_bam_records(bam, want_ref=True))
+    idx = rio.ReadIndexedBam(bam)
+    assert idx.num_records == idx.num_reads == 14 and dict(idx.skip_reasons) == {}
+    assert idx.read_ids == [r.query_name for r in streamed] and streamed[3].query_name in idx and "nope" not in idx
+    for k in (13, 0, 7, 7, 2):  # any order, repeated
+        got = list(idx.get_alignments(streamed[k].query_name))
+        assert len(got) == 1 and got[0].raw == streamed[k].raw and got[0].voffset == streamed[k].voffset == idx[streamed[k].query_name][0]
+        assert got[0].get_reference_sequence() == streamed[k].get_reference_sequence()
+    assert idx.get_first_alignment(streamed[5].query_name).query_name == streamed[5].query_name
+    with pytest.raises(RemoraError, match="Could not find"):
+        list(idx.get_alignments("nope"))
+    assert sum(1 for _ in idx) == 14
+    # a file with non-primary records and split reads (pi tag): written from modified copies of real records
+    recs = list(rio.iter_bam_records(bam, native=False))
+    hdr = rio.read_bam_header_bytes(bam)
+    path = str(tmp_path / "mix.bam")
+
+    def with_flag(r, flag, extra=b""):
+        raw = bytearray(r.raw)
+        raw[14:16] = struct.pack("<H", flag)
+        return bytes(raw) + extra
+
+    out = []
+    for k, r in enumerate(recs * 30):  # many blocks
+        flag = r.flag | (256 if k % 5 == 1 else 0) | (2048 if k % 7 == 3 else 0)
+        extra = b"piZ" + f"parent-{k % 11}".encode() + b"\x00" if k % 3 == 0 else b""
+        out.append(with_flag(r, flag, extra))
+    with rio.BamWriter(path, hdr) as w:
+        for raw in out:
+            w.write(struct.pack("<i", len(raw)) + raw)
+    idx = rio.ReadIndexedBam(path)
+    primary = [k for k in range(len(out)) if not (k % 5 == 1 or k % 7 == 3)]
+    assert idx.num_records == len(primary) and idx.skip_reasons["Non-primary alignment"] == len(out) - len(primary)
+    want = {}
+    for k in primary:
+        want.setdefault(f"parent-{k % 11}" if k % 3 == 0 else recs[k % 14].query_name, []).append(out[k])
+    assert set(idx.read_ids) == set(want) and idx.num_reads == len(want)
+    for rid in list(want)[::3]:
+        assert [a.raw for a in idx.get_alignments(rid, want_ref=False)] == want[rid]
+    everything = rio.ReadIndexedBam(path, skip_non_primary=False)
+    assert everything.num_records == len(out)
+    some = rio.ReadIndexedBam(path, parent_read_id_subset={"parent-3", recs[1].query_name}, req_tags={"mv", "MD"})
+    assert set(some.read_ids) <= {"parent-3", recs[1].query_name} and some.skip_reasons["Parent read ID filtered"] > 0
+    assert rio.ReadIndexedBam(path, req_tags={"zz"}).num_records == 0
+
+    class P5:
+        read_ids = [recs[0].query_name, recs[1].query_name, "only-in-pod5"]
+
+    both, n = rio.get_read_ids(idx, P5, None)
+    assert set(both) == {recs[0].query_name, recs[1].query_name} & set(idx.read_ids) and n == len(both)
+    both, n = rio.get_read_ids(idx, P5, 1, return_num_bam_reads=True)
+    assert n == 1
