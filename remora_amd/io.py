@@ -572,6 +572,44 @@ class Pod5Read:
     calibration_scale: float
 
 
+def _pod5_embedded_files(buf):
+    """[(offset, length)] of the Arrow files embedded in a POD5 container, from its footer: the file ends with
+    b"FOOTER\0\0" + flatbuffer(Footer{..., contents:[EmbeddedFile{offset, length, format, content_type}]}) + padding +
+    int64 footer length + 16-byte section marker + 8-byte signature."""
+    n = len(buf)
+    if n < 64 or bytes(buf[n - 8 : n]) != b"\x8bPOD\r\n\x1a\n":
+        raise RemoraError("no POD5 signature at the end of the file")
+    flen = struct.unpack_from("<q", buf, n - 32)[0]
+    fb = n - 32 - flen
+    if flen <= 0 or fb < 16 or bytes(buf[fb - 8 : fb]) != b"FOOTER\x00\x00":
+        raise RemoraError("POD5 footer not found")
+    u32 = lambda p: struct.unpack_from("<I", buf, p)[0]  # noqa: E731
+
+    def field(table, k):  # flatbuffers: table -> vtable -> offset of field k (0 = absent)
+        vt = table - struct.unpack_from("<i", buf, table)[0]
+        if 4 + 2 * k >= struct.unpack_from("<H", buf, vt)[0]:
+            return None
+        off = struct.unpack_from("<H", buf, vt + 4 + 2 * k)[0]
+        return table + off if off else None
+
+    root = fb + u32(fb)
+    cp = field(root, 3)
+    if cp is None:
+        raise RemoraError("POD5 footer without contents")
+    vec = cp + u32(cp)
+    files = []
+    for k in range(u32(vec)):
+        e = vec + 4 + 4 * k
+        tab = e + u32(e)
+        po, pl = field(tab, 0), field(tab, 1)
+        off = struct.unpack_from("<q", buf, po)[0] if po else 0
+        length = struct.unpack_from("<q", buf, pl)[0] if pl else 0
+        if off < 0 or length <= 0 or off + length > n:
+            raise RemoraError("POD5 footer entry out of range")
+        files.append((off, length))
+    return files
+
+
 class Pod5File:
     """Random access to the reads of a POD5 file without the pod5 package: the file is memory mapped, the
     embedded Arrow IPC tables (signal rows, reads) are opened in place, a read's signal rows are VBZ-decoded
@@ -589,32 +627,43 @@ class Pod5File:
         mm = self._mm
         if mm[:8] != b"\x8bPOD\r\n\x1a\n":
             raise RemoraError(f"{pod5_path} is not a POD5 file")
-        marks = []
-        i = mm.find(b"ARROW1")
-        while i >= 0:
-            marks.append(i)
-            i = mm.find(b"ARROW1", i + 1)
         view = memoryview(mm)
         tables = {}
-        k = 0
-        while k + 1 < len(marks):  # embedded files are [ARROW1\0\0 ... ARROW1] pairs
-            st = marks[k]
-            opened = False
-            for e in marks[k + 1 :]:
-                try:
-                    t = ipc.open_file(pa.BufferReader(pa.py_buffer(view[st : e + 6]))).read_all()
-                except (pa.ArrowInvalid, OSError):
-                    continue
-                names = set(t.schema.names)
-                if {"signal", "samples"} <= names:
-                    tables["signal"] = t
-                elif "calibration_offset" in names:
-                    tables["reads"] = t
-                k = marks.index(e) + 1
-                opened = True
-                break
-            if not opened:
-                k += 1
+
+        def classify(t):
+            names = set(t.schema.names)
+            if {"signal", "samples"} <= names:
+                tables["signal"] = t
+            elif "calibration_offset" in names:
+                tables["reads"] = t
+
+        try:  # the footer lists the embedded Arrow files: O(1) whatever the file size
+            for off, length in _pod5_embedded_files(mm):
+                classify(ipc.open_file(pa.BufferReader(pa.py_buffer(view[off : off + length]))).read_all())
+        except (RemoraError, pa.ArrowInvalid, OSError, struct.error, IndexError, ValueError):
+            tables = {}
+        if "signal" not in tables or "reads" not in tables:  # damaged / missing footer: look for the Arrow magic
+            tables = {}
+            marks = []
+            i = mm.find(b"ARROW1")
+            while i >= 0:
+                marks.append(i)
+                i = mm.find(b"ARROW1", i + 1)
+            k = 0
+            while k + 1 < len(marks):  # embedded files are [ARROW1\0\0 ... ARROW1] pairs
+                st = marks[k]
+                opened = False
+                for e in marks[k + 1 :]:
+                    try:
+                        t = ipc.open_file(pa.BufferReader(pa.py_buffer(view[st : e + 6]))).read_all()
+                    except (pa.ArrowInvalid, OSError):
+                        continue
+                    classify(t)
+                    k = marks.index(e) + 1
+                    opened = True
+                    break
+                if not opened:
+                    k += 1
         if "signal" not in tables or "reads" not in tables:
             raise RemoraError(f"could not locate the signal / reads tables in {pod5_path}")
         self._sig, self._reads = tables["signal"], tables["reads"]

@@ -1287,3 +1287,34 @@ def test_read_indexed_bam(tmp_path):
     assert set(both) == {recs[0].query_name, recs[1].query_name} & set(idx.read_ids) and n == len(both)
     both, n = rio.get_read_ids(idx, P5, 1, return_num_bam_reads=True)
     assert n == 1
+
+
+def test_pod5_tables_are_located_through_the_footer(tmp_path):
+    """Pod5File finds the embedded Arrow tables from the container's footer (flatbuffer at the end of the file)
+    and only scans for the Arrow magic when the footer is unusable: both ways give the same tables."""
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    for which, n_rows in (("can", 17), ("mod", None)):
+        path = os.path.join(ROOT, "tests", "golden", "data", f"{which}_reads.pod5")
+        raw = open(path, "rb").read()
+        files = rio._pod5_embedded_files(raw)
+        assert len(files) == 3 and all(raw[o : o + 6] == b"ARROW1" and raw[o + ln - 6 : o + ln] == b"ARROW1" for o, ln in files)
+        good = rio.Pod5File(path)
+        assert len(good) == 14 and (n_rows is None or good._sig.num_rows == n_rows)
+        broken = bytearray(raw)
+        broken[-40:-32] = b"\\x00" * 8  # inside the footer flatbuffer's padding / tail
+        broken[-32:-24] = (10**9).to_bytes(8, "little")  # absurd footer length
+        bad = str(tmp_path / f"{which}_badfooter.pod5")
+        open(bad, "wb").write(bytes(broken))
+        with pytest.raises(RemoraError):
+            rio._pod5_embedded_files(bytes(broken))
+        scanned = rio.Pod5File(bad)  # falls back to the magic scan
+        assert scanned.read_ids == good.read_ids and scanned._sig.equals(good._sig)
+        assert scanned._reads.schema.equals(good._reads.schema)
+        for col in ("read_id", "signal", "calibration_offset", "calibration_scale"):  # (other columns hold NaNs)
+            assert scanned._reads.column(col).equals(good._reads.column(col)), col
+    with pytest.raises(RemoraError, match="not a POD5"):
+        junk = str(tmp_path / "junk.pod5")
+        open(junk, "wb").write(b"x" * 200)
+        rio.Pod5File(junk)
