@@ -667,9 +667,26 @@ class Pod5File:
         if "signal" not in tables or "reads" not in tables:
             raise RemoraError(f"could not locate the signal / reads tables in {pod5_path}")
         self._sig, self._reads = tables["signal"], tables["reads"]
-        ids = self._reads.column("read_id")
-        self.read_ids = [str(uuid.UUID(bytes=ids[r].as_py())) for r in range(self._reads.num_rows)]
+        self.read_ids = [str(uuid.UUID(bytes=b)) for b in self._reads.column("read_id").to_pylist()]
         self._row = {rid: r for r, rid in enumerate(self.read_ids)}
+        # per-read columns once (small), per-row access into the big signal table by (chunk, index): indexing a
+        # chunked column by a global row number walks its chunks every time
+        self._cal_off = self._reads.column("calibration_offset").to_numpy()
+        self._cal_scale = self._reads.column("calibration_scale").to_numpy()
+        self._read_rows = self._reads.column("signal")
+        self._read_rows_starts = np.cumsum([0] + [len(c) for c in self._read_rows.chunks])
+        sig_col, n_col = self._sig.column("signal"), self._sig.column("samples")
+        self._sig_chunks, self._n_chunks = sig_col.chunks, n_col.chunks
+        self._sig_starts = np.cumsum([0] + [len(c) for c in self._sig_chunks])
+        self._n_starts = np.cumsum([0] + [len(c) for c in self._n_chunks])
+
+    @staticmethod
+    def _cell(chunks, starts, i):
+        k = int(np.searchsorted(starts, i, side="right")) - 1
+        return chunks[k][int(i - starts[k])].as_py()
+
+    def _rows_of(self, read_id):
+        return self._cell(self._read_rows.chunks, self._read_rows_starts, self._row[read_id])
 
     def __contains__(self, read_id):
         return read_id in self._row
@@ -679,13 +696,12 @@ class Pod5File:
 
     def signal_rows(self, read_id):
         """[(zstd-compressed VBZ bytes, number of samples)] of a read's signal rows, in order (table access only)."""
-        sig_rows, sig_n = self._sig.column("signal"), self._sig.column("samples")
-        return [(sig_rows[i].as_py(), sig_n[i].as_py()) for i in self._reads.column("signal")[self._row[read_id]].as_py()]
+        return [(self._cell(self._sig_chunks, self._sig_starts, i), self._cell(self._n_chunks, self._n_starts, i))
+                for i in self._rows_of(read_id)]
 
     def calibration(self, read_id):
         r = self._row[read_id]
-        return (float(self._reads.column("calibration_offset")[r].as_py()),
-                float(self._reads.column("calibration_scale")[r].as_py()))
+        return float(self._cal_off[r]), float(self._cal_scale[r])
 
     def get(self, read_id, engine=None):
         """One read (signal decoded on the GPU like a batch of one)."""
@@ -693,22 +709,19 @@ class Pod5File:
 
     def get_many(self, read_ids, engine=None):
         """The signals of several reads decoded in one GPU call (see vbz_decode_batch); list of Pod5Read."""
-        sig_rows, sig_n = self._sig.column("signal"), self._sig.column("samples")
         rows_of, blobs, ns = [], [], []
         for rid in read_ids:
-            rows = self._reads.column("signal")[self._row[rid]].as_py()
+            rows = self.signal_rows(rid)
             rows_of.append(len(rows))
-            for i in rows:
-                blobs.append(sig_rows[i].as_py())
-                ns.append(sig_n[i].as_py())
+            for blob, n in rows:
+                blobs.append(blob)
+                ns.append(n)
         flat, off = vbz_decode_batch(blobs, ns, engine)
         out, k = [], 0
         for rid, nrows in zip(read_ids, rows_of):
-            r = self._row[rid]
             sig = flat[off[k] : off[k + nrows]]  # a read's rows are consecutive in the batch
             k += nrows
-            out.append(Pod5Read(rid, sig, float(self._reads.column("calibration_offset")[r].as_py()),
-                                float(self._reads.column("calibration_scale")[r].as_py())))
+            out.append(Pod5Read(rid, sig, *self.calibration(rid)))
         return out
 
     def __iter__(self):
