@@ -255,15 +255,24 @@ bool tag_int(char t, const uint8_t *p, int32_t *out) {
 }
 
 // reference bases of the alignment from query + CIGAR + MD; false when MD and CIGAR disagree / MD malformed
-bool rebuild_reference(const char *query, const uint32_t *cig, int n_cig, const char *md, size_t md_len,
+// (also when the CIGAR consumes more query bases than SEQ holds: SEQ '*' on a secondary record, or a corrupt record)
+bool rebuild_reference(const char *query, size_t l_seq, const uint32_t *cig, size_t n_cig, const char *md, size_t md_len,
                        std::string &cols, std::vector<char> &out) {
     cols.clear();
     size_t q = 0;
-    for (int k = 0; k < n_cig; ++k) {
-        const uint32_t op = cig[k] & 0xF, ln = cig[k] >> 4;
-        if (op == 0 || op == 7 || op == 8) { cols.append(query + q, ln); q += ln; }
-        else if (op == 1 || op == 4) q += ln;
-        else if (op == 2 || op == 3) cols.append(ln, '-');
+    for (size_t k = 0; k < n_cig; ++k) {
+        const uint32_t op = cig[k] & 0xF;
+        const size_t ln = cig[k] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            if (ln > l_seq - q) return false;  // q <= l_seq is an invariant of this loop
+            cols.append(query + q, ln);
+            q += ln;
+        } else if (op == 1 || op == 4) {
+            if (ln > l_seq - q) return false;
+            q += ln;
+        } else if (op == 2 || op == 3) {
+            cols.append(ln, '-');
+        }
     }
     const size_t start = out.size();
     size_t i = 0, p = 0;
@@ -415,7 +424,6 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         p += l_read_name;
         const size_t cig0 = b->cigar.size();
         for (int k = 0; k < n_cig; ++k) b->cigar.push_back(rd_u32(p + 4 * k));
-        b->cigar_off.push_back((int64_t)b->cigar.size());
         p += 4 * (size_t)n_cig;
         const size_t seq0 = b->seq.size();
         b->seq.resize(seq0 + (size_t)l_seq);
@@ -432,6 +440,8 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         float sm = 0.f, sd = 0.f;
         const char *md = nullptr;
         size_t md_len = 0;
+        const uint8_t *cg = nullptr;  // CG:B,I — the real CIGAR of a record with more than 65535 operations
+        int64_t cg_n = 0;
         while (p + 3 <= end) {
             const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
             const uint8_t *val = p + 3;
@@ -451,10 +461,21 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
                 md = (const char *)val; md_len = (size_t)sz - 1;
                 b->md.insert(b->md.end(), md, md + md_len);
                 has |= 128;
+            } else if (t0 == 'C' && t1 == 'G' && ty == 'B' && val[0] == 'I') {
+                cg = val + 5;
+                cg_n = rd_i32(val + 1);
             }
             p = val + sz;
         }
         if (p != end) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM tag region");
+        // SAM spec 4.2.2: a CIGAR that does not fit the 16-bit count is stored in CG and the record carries the
+        // placeholder <l_seq>S<ref_len>N (htslib / pysam resolve this transparently)
+        if (cg && cg_n > 0 && n_cig == 2 && (b->cigar[cig0] & 0xF) == 4 && (int64_t)(b->cigar[cig0] >> 4) == l_seq &&
+            (b->cigar[cig0 + 1] & 0xF) == 3) {
+            b->cigar.resize(cig0);
+            for (int64_t k = 0; k < cg_n; ++k) b->cigar.push_back(rd_u32(cg + 4 * k));  // n_cigar keeps the record's own count (byte offsets)
+        }
+        b->cigar_off.push_back((int64_t)b->cigar.size());
         b->mv_off.push_back((int64_t)b->mv.size());
         b->pi_off.push_back((int64_t)b->pi.size());
         b->md_off.push_back((int64_t)b->md.size());
@@ -462,7 +483,8 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         b->has.push_back(has);
         uint8_t ok = 0;
         if (want_ref && md && !(flag & 4))
-            ok = rebuild_reference(b->seq.data() + seq0, b->cigar.data() + cig0, n_cig, md, md_len, cols, b->refseq) ? 1 : 0;
+            ok = rebuild_reference(b->seq.data() + seq0, (size_t)l_seq, b->cigar.data() + cig0, b->cigar.size() - cig0, md,
+                                   md_len, cols, b->refseq) ? 1 : 0;
         b->ref_ok.push_back(ok);
         b->refseq_off.push_back((int64_t)b->refseq.size());
         b->upos += 4 + (size_t)bs;

@@ -144,6 +144,23 @@ def _pinned_bytes(count):
     return buf
 
 
+def _validated_int16_dacs(r):
+    """dacs of a read as the int16 values the device layout (rmr_reads.dacs) holds.  The reference's RemoraRead.sig
+    (data_chunks.py:191-197) takes any dtype; here anything int16 represents exactly goes through (e.g. the float
+    zeros of RemoraRead.test_read), anything else would be truncated or wrapped silently and is refused."""
+    a = np.asarray(r.dacs).ravel()
+    if a.dtype == np.int16:
+        return a
+    with np.errstate(invalid="ignore", over="ignore"):
+        ai = a.astype(np.int16)
+    if not np.array_equal(ai, a):
+        raise RemoraError(
+            f"read {getattr(r, 'read_id', '?')}: dacs ({a.dtype}) are not int16-representable (non-integer or out "
+            "of range); pass raw int16 ADC values with shift/scale - already-normalised float signal is not "
+            "supported by the GPU extraction path")
+    return ai
+
+
 class DeviceReads:
     """The arrays of a batch of reads, concatenated and resident in HBM (the rmr_reads layout of
     include/remora_hip.h) - uploaded once and shared by the motif scan, the signal-mapping refinement
@@ -175,7 +192,7 @@ class DeviceReads:
         view = {name: host[offs[name] : offs[name] + cnt * np.dtype(dt).itemsize].view(dt) for name, dt, cnt in segs}
         o_sig = o_seq = o_map = 0
         for r in reads:  # numpy casts to the segment dtype on the fly
-            a = np.asarray(r.dacs).ravel()
+            a = _validated_int16_dacs(r)
             view["dacs"][o_sig : o_sig + a.size] = a
             o_sig += a.size
             a = np.asarray(r.seq_to_sig_map).ravel()

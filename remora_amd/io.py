@@ -71,6 +71,7 @@ import array
 import dataclasses
 import gzip
 import struct
+import threading
 
 import re
 
@@ -198,6 +199,17 @@ def _parse_tags(buf, spans=None):
 _NT16 = np.frombuffer(_SEQ_NT16.encode(), dtype="S1")
 
 
+def _resolve_long_cigar(cig, l_seq, get_tags):
+    """SAM spec 4.2.2: a CIGAR with more than 65535 operations lives in the CG:B,I tag and the record itself holds
+    the placeholder <l_seq>S<ref_len>N; htslib (hence pysam, which the reference reads alignments with) resolves it
+    when the record is read.  `cig`: uint32 operations as stored; returns the operations to use."""
+    if cig.size == 2 and (int(cig[0]) & 0xF) == 4 and (int(cig[0]) >> 4) == l_seq and (int(cig[1]) & 0xF) == 3:
+        for k, v in get_tags():
+            if k == "CG" and isinstance(v, array.array) and v.typecode == "I" and len(v):
+                return np.frombuffer(v.tobytes(), dtype="<u4")
+    return cig
+
+
 def _read_exact(fh, n):
     buf = fh.read(n)
     if len(buf) != n:
@@ -210,11 +222,12 @@ class _NativeBamRecord(BamRecord):
     (full tag list, tag byte spans, CIGAR tuples, qualities) is decoded from the record bytes on first use."""
 
     def __init__(self, query_name, flag, reference_id, reference_name, reference_start, mapping_quality, query_sequence,
-                 raw, tags_offset, n_cigar, hot, ref_seq, voffset=-1):
+                 raw, tags_offset, n_cigar, hot, ref_seq, voffset=-1, cigar=None):
         self.query_name, self.flag, self.reference_id, self.reference_name = query_name, flag, reference_id, reference_name
         self.reference_start, self.mapping_quality, self.query_sequence = reference_start, mapping_quality, query_sequence
         self.raw, self.tags_offset, self._n_cigar, self._hot, self._ref_seq = raw, tags_offset, n_cigar, hot, ref_seq
         self.voffset = voffset  # BGZF virtual offset of the record in its file
+        self._cigar = cigar  # uint32 operations from the native reader (the CG tag's when the record holds a placeholder)
 
     def _parse_all_tags(self):
         spans = []
@@ -236,7 +249,10 @@ class _NativeBamRecord(BamRecord):
     @property
     def cigartuples(self):
         if "_cigartuples" not in self.__dict__:
-            cig = np.frombuffer(self.raw, dtype="<u4", count=self._n_cigar, offset=32 + self.raw[8])
+            cig = self._cigar
+            if cig is None:
+                cig = _resolve_long_cigar(np.frombuffer(self.raw, dtype="<u4", count=self._n_cigar, offset=32 + self.raw[8]),
+                                          len(self.query_sequence), lambda: self.tags)
             self._cigartuples = list(zip((cig & 0xF).tolist(), (cig >> 4).tolist()))
         return self._cigartuples
 
@@ -290,13 +306,16 @@ def _native_batches(lib, h, want_ref, batch, once=False):
         ts, ns, sp = i32("ts"), i32("ns"), i32("sp")
         sm, sd = arr(bb.sm, ctypes.c_float, n).tolist(), arr(bb.sd, ctypes.c_float, n).tolist()
         has, ref_ok = arr(bb.has, ctypes.c_uint8, n).tolist(), arr(bb.ref_ok, ctypes.c_uint8, n).tolist()
-        raw_off, name_off, seq_off, mv_off, pi_off, rs_off = (off(f) for f in (
-            "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off"))
+        raw_off, name_off, seq_off, mv_off, pi_off, rs_off, cig_off = (off(f) for f in (
+            "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off", "cigar_off"))
+        cigar = arr(bb.cigar, ctypes.c_uint32, cig_off[n]).copy()
         tags_off = arr(bb.tags_off, ctypes.c_int64, n).tolist()
         voff = arr(bb.voffset, ctypes.c_int64, n).tolist()
         blob = lambda ptr, total: ctypes.string_at(ptr, total) if total else b""  # noqa: E731
-        raw, names, seq = blob(bb.raw, raw_off[n]), blob(bb.names, name_off[n]).decode(), blob(bb.seq, seq_off[n]).decode()
-        pi, refseq = blob(bb.pi, pi_off[n]).decode(), blob(bb.refseq, rs_off[n]).decode()
+        # latin-1 is one character per byte: offsets stay valid whatever the bytes are (one odd record cannot
+        # take the whole batch down with a UnicodeDecodeError)
+        raw, names, seq = blob(bb.raw, raw_off[n]), blob(bb.names, name_off[n]).decode("latin-1"), blob(bb.seq, seq_off[n]).decode("latin-1")
+        pi, refseq = blob(bb.pi, pi_off[n]).decode("latin-1"), blob(bb.refseq, rs_off[n]).decode("latin-1")
         mv = np.frombuffer(blob(bb.mv, mv_off[n]), np.int8)
         for i in range(n):
             h_i = has[i]
@@ -322,7 +341,8 @@ def _native_batches(lib, h, want_ref, batch, once=False):
             yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
                                    pos[i], mapq[i], seq[seq_off[i] : seq_off[i + 1]], raw[raw_off[i] : raw_off[i + 1]],
                                    tags_off[i], n_cig[i], hot,
-                                   refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None, voff[i])
+                                   refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None, voff[i],
+                                   cigar[cig_off[i] : cig_off[i + 1]])
         if n < batch or once:
             return
 
@@ -351,6 +371,8 @@ class ReadIndexedBam:
         self.parent_read_id_subset, self.child_read_id_subset = parent_read_id_subset, child_read_id_subset
         self.num_reads = self.num_records = None
         self._bam_idx = None
+        self._handle = None
+        self._lock = threading.Lock()
         self.compute_read_index()
 
     reference_filename = property(lambda s: s.bam_path)
@@ -390,10 +412,44 @@ class ReadIndexedBam:
             offsets = self._bam_idx[read_id]
         except KeyError:
             raise RemoraError(f"Could not find {read_id} in {self.bam_path}")
-        yield from _iter_bam_records_native(self.bam_path, want_ref, 1, voffsets=offsets)
+        # one native handle for the lifetime of the index (the reference keeps its pysam handle open the same way):
+        # a seek + one record per offset instead of a header parse and an inflate pool per look-up
+        lib = L.lib()
+        with self._lock:
+            if self._handle is None:
+                h = ctypes.c_void_p()
+                L.check(lib.rmr_bam_open(str(self.bam_path).encode(), ctypes.byref(h)))
+                self._handle = h
+            recs = []
+            for vo in offsets:
+                L.check(lib.rmr_bam_seek(self._handle, int(vo)))
+                recs.extend(_native_batches(lib, self._handle, want_ref, 1, once=True))
+        return iter(recs)
 
     def get_first_alignment(self, read_id):
         return next(self.get_alignments(read_id))
+
+    def close(self):
+        with self._lock:
+            if self._handle is not None:
+                L.lib().rmr_bam_close(self._handle)
+                self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def __getstate__(self):  # handles do not travel to worker processes; each re-opens on first use
+        d = dict(self.__dict__)
+        d["_handle"] = None
+        d.pop("_lock", None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._lock = threading.Lock()
 
     def __contains__(self, read_id):
         return read_id in self._bam_idx
@@ -471,15 +527,17 @@ def _iter_bam_records_py(bam_path):
             q = 32
             name = rec[q : q + l_read_name - 1].decode(); q += l_read_name
             cig = np.frombuffer(rec, dtype="<u4", count=n_cig, offset=q); q += 4 * n_cig
-            cigartuples = list(zip((cig & 0xF).tolist(), (cig >> 4).tolist()))
             sb = np.frombuffer(rec, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q); q += (l_seq + 1) // 2
             codes = np.empty(2 * sb.size, np.uint8)
             codes[0::2], codes[1::2] = sb >> 4, sb & 0xF
             seq = _NT16[codes[:l_seq]].tobytes().decode()
             qual = bytes(rec[q : q + l_seq]); q += l_seq
             spans = []
+            tags = _parse_tags(rec[q:], spans)
+            cig = _resolve_long_cigar(cig, l_seq, lambda: tags)
+            cigartuples = list(zip((cig & 0xF).tolist(), (cig >> 4).tolist()))
             yield BamRecord(name, flag, ref_id, refs[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq,
-                            qual, _parse_tags(rec[q:], spans), bytes(rec), q, spans)
+                            qual, tags, bytes(rec), q, spans)
 
 
 _ZSTD = None

@@ -1318,3 +1318,101 @@ def test_pod5_tables_are_located_through_the_footer(tmp_path):
         junk = str(tmp_path / "junk.pod5")
         open(junk, "wb").write(b"x" * 200)
         rio.Pod5File(junk)
+
+
+def _tiny_bam(path, records):
+    """records: [(name, flag, seq, cigar [(op, len)], [tag bytes])] -> BAM file with one reference."""
+    import struct
+
+    from remora_amd import io as rio
+
+    text = b"@HD\tVN:1.6\n@SQ\tSN:chrA\tLN:1000000\n"
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1)
+    hdr += struct.pack("<i", 5) + b"chrA\x00" + struct.pack("<i", 1000000)
+    with rio.BamWriter(str(path), hdr, threads=1) as w:
+        for name, flag, seq, cigar, tags in records:
+            rname = name.encode()
+            body = struct.pack("<iiBBHHHiiii", 0, 100, len(rname) + 1, 60, 4680, len(cigar), flag, len(seq), -1, -1, 0)
+            body += rname + b"\x00" + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar)
+            body += rio._pack_seq(seq) + bytes(len(seq)) + b"".join(tags)
+            w.write(struct.pack("<i", len(body)) + body)
+    return hdr
+
+
+def test_native_bam_reader_seq_less_secondary_with_md(tmp_path):
+    """A mapped secondary record with SEQ '*' (l_seq = 0, as minimap2 / dorado write them) whose CIGAR and MD still
+    describe 200 matched bases: the MD reconstruction must refuse it (ref_seq None -> the python path raises
+    ValueError for that record only) instead of reading past the sequence arena; the records around it are
+    unaffected.  Same for a CIGAR that consumes more query bases than SEQ holds."""
+    from remora_amd import io as rio
+
+    md = lambda s: b"MDZ" + s.encode() + b"\x00"  # noqa: E731
+    recs = [("prim", 0, "ACGT" * 50, [(0, 200)], [md("200")]),
+            ("prim", 256, "", [(0, 200)], [md("200")]),
+            ("long", 0, "ACGTACGT", [(4, 2), (0, 20), (1, 3)], [md("20")]),
+            ("next", 16, "TTGCA", [(0, 5)], [md("2a2")])]
+    path = tmp_path / "secondary.bam"
+    _tiny_bam(path, recs)
+    nat = list(rio.iter_bam_records(str(path), want_ref=True, batch=8))
+    py = list(rio.iter_bam_records(str(path), native=False))
+    assert [r.query_name for r in nat] == ["prim", "prim", "long", "next"]
+    got = []
+    for x, y in zip(nat, py):
+        outs = []
+        for rec in (x, y):
+            try:
+                outs.append(rec.get_reference_sequence())
+            except ValueError:
+                outs.append(None)
+        assert outs[0] == outs[1]
+        got.append(outs[0])
+    assert got == ["ACGT" * 50, None, None, "TTaCA"]
+    idx = rio.ReadIndexedBam(str(path), skip_non_primary=True)
+    assert idx.num_records == 3 and [r.query_name for r in idx.get_alignments("next")] == ["next"]
+    assert idx.get_first_alignment("prim").get_reference_sequence() == "ACGT" * 50
+    idx.close()
+
+
+def test_bam_long_cigar_in_cg_tag(tmp_path):
+    """More than 65535 CIGAR operations: the record holds <l_seq>S<ref_len>N and the real CIGAR sits in CG:B,I
+    (SAM spec 4.2.2; htslib/pysam resolve it on read).  Both readers hand out the CG operations, and the MD
+    reconstruction uses them."""
+    import struct
+
+    from remora_amd import io as rio
+
+    real = [(0, 3), (2, 1), (0, 2), (1, 1), (0, 2)]  # 3M1D2M1I2M: query 8, reference 8
+    cg = b"CGBI" + struct.pack("<i", len(real)) + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in real)
+    md = b"MDZ3^G4\x00"
+    _tiny_bam(tmp_path / "cg.bam", [("ultra", 0, "ACGTTACA", [(4, 8), (3, 8)], [md, cg]),
+                                    ("plain", 0, "ACGT", [(4, 4), (3, 9)], [])])
+    for native in (True, False):
+        a, b = list(rio.iter_bam_records(str(tmp_path / "cg.bam"), want_ref=True, native=native))
+        assert a.cigartuples == real, native
+        assert a.get_reference_sequence() == "ACGGTTCA", native  # I base (index 5, 'A') dropped, deleted G inserted
+        assert b.cigartuples == [(4, 4), (3, 9)]  # no CG tag: the record's own CIGAR stands
+        assert len(a.query_qualities) == 8
+
+
+def test_device_reads_refuse_dacs_that_int16_cannot_hold():
+    """rmr_reads.dacs is int16: float / wide-integer dacs go through only when every value is exactly
+    representable (RemoraRead.test_read's float zeros); otherwise RemoraError instead of silent truncation."""
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import RemoraRead
+
+    mk = lambda d: RemoraRead(dacs=d, shift=0.0, scale=1.0, seq_to_sig_map=np.array([0, 2, 4]),  # noqa: E731
+                              int_seq=np.array([1, 2]), read_id="r")
+    for bad in (np.array([0.5, 1.0, 2.0, 3.0]), np.array([0, 1, 2, 40000]), np.array([0.0, np.nan, 1.0, 2.0])):
+        with pytest.raises(RemoraError, match="int16"):
+            _check_dacs_only([mk(bad)])
+    from remora_amd import data_chunks as dc
+
+    assert dc._validated_int16_dacs(mk(np.zeros(4))).dtype == np.int16  # float zeros: exact
+    assert np.array_equal(dc._validated_int16_dacs(mk(np.array([-32768, 5, 6, 32767], np.int64))), [-32768, 5, 6, 32767])
+
+
+def _check_dacs_only(reads):
+    """The validation DeviceReads applies, without a GPU: mirrors its staging loop on a plain buffer."""
+    from remora_amd import data_chunks as dc
+
+    dc._validated_int16_dacs(reads[0])
