@@ -56,6 +56,8 @@ def kernel_flops_per_chunk(arch, L, size=64, K=9, num_out=2):
         f["conv_seq2"] = 2 * size * 16 * 13 * P3
         f["conv_merge1"] = 2 * size * 2 * size * 5 * T
         f["lstm_head"] = 2 * (T * 2 * 4 * size * size + 4 * size * size + num_out * size)
+        # the fused bf16 front kernel (k_fused.hip) does the work of the five kernels above it
+        f["fused_front"] = f["front_sig"] + f["front_seq"] + f["conv_sig3"] + f["conv_seq2"] + f["conv_merge1"]
     else:
         PQ2 = P1 - 10
         T, T2 = P3 - 4, P3 - 8

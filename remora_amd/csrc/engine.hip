@@ -27,7 +27,8 @@ static const char *k_names[K_NUM] = {
     "encode_kmers", "trim_chunk_context", "parse_moves", "normalise_signal", "chunk_geometry",
     "chunk_fill", "front_sig", "front_seq", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
     "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
-    "count_labels", "motif_scan", "vbz_decode", "refine_band", "refine_dp", "refine_dp_rowwise"};
+    "count_labels", "motif_scan", "vbz_decode", "refine_band", "refine_dp", "refine_dp_rowwise",
+    "fused_front"};
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
 
 }  // namespace rmr
@@ -367,6 +368,30 @@ int pack_conv_split(rmr_model *m, const Folded &f, int np, ConvLayer *out) {
     return upload(m, fl, &out->spack);
 }
 
+// conv weights -> bf16 A fragments of the fused front kernel: [oc/16][ksteps][64 lanes][4 dwords]; lane (q, m) of
+// k-step s holds k = 32 s + 8 q + j, k = tap * C + channel (C = row width of the operand in LDS, k_fused.hip);
+// taps >= kw and channels >= ic are zero
+int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, float **dev) {
+    const ConvSpec &s = f.s;
+    const int W = s.oc / 16;
+    std::vector<uint32_t> o((size_t)W * ksteps * 64 * 4);
+    for (int w = 0; w < W; ++w)
+        for (int st = 0; st < ksteps; ++st)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane >> 4, oc = 16 * w + (lane & 15);
+                uint32_t b[8];
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * st + 8 * q + j, tap = k / C, ch = k % C;
+                    const float v = (tap < s.kw && ch < s.ic) ? f.w[((size_t)oc * s.ic + ch) * s.kw + tap] : 0.0f;
+                    b[j] = rne_bf16(f2u(v));
+                }
+                for (int i = 0; i < 4; ++i) o[(((size_t)w * ksteps + st) * 64 + lane) * 4 + i] = (b[2 * i] >> 16) | b[2 * i + 1];
+            }
+    std::vector<float> fl(o.size());
+    memcpy(fl.data(), o.data(), o.size() * 4);
+    return upload(m, fl, dev);
+}
+
 // [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
 std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates, bool prescale = false) {
     const int KS = H / 4, G = H / 16, W = H / 16;
@@ -494,6 +519,14 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
             RMR_TRY(pack_conv_split(m.get(), convs[4], m->nparts, &m->seq2));
             RMR_TRY(pack_conv_split(m.get(), convs[5], m->nparts, &m->merge1));
         }
+        if (m->nparts == 1 && sz == 64 && K == 9 && kw1 == 5) {  // operands of the fused front kernel
+            const int cg = (4 * K + 7) / 8;
+            RMR_TRY(pack_flat_a(m.get(), convs[1], 4, 1, &m->fused.a_sig2));
+            RMR_TRY(pack_flat_a(m.get(), convs[3], 8 * cg, (5 * cg * 8 + 31) / 32, &m->fused.a_seq1));
+            RMR_TRY(pack_flat_a(m.get(), convs[2], 16, 5, &m->fused.a_sig3));
+            RMR_TRY(pack_flat_a(m.get(), convs[4], 16, 7, &m->fused.a_seq2));
+            RMR_TRY(pack_flat_a(m.get(), convs[5], 2 * sz, 20, &m->fused.a_merge1));
+        }
         const int H = sz;
         const float *wih1 = p; p += (size_t)4 * H * H;
         const float *whh1 = p; p += (size_t)4 * H * H;
@@ -569,6 +602,22 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                  float *logits) {
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
+    if (!enc && fused_front_supported(m, seq_w, map_w) && tune_int("RMR_FUSED", 1)) {
+        // plain-bf16 ConvLSTM: two launches per sub-batch, x (bf16, 3 KB/chunk @C100) is the only intermediate in
+        // HBM; sub-batches are sized so that x stays in the 256 MiB Infinity Cache between producer and consumer
+        int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_FUSED_SUBBATCH", 32768);
+        if (sb > n) sb = n;
+        const size_t x_elems = (size_t)m->T * m->desc.size;
+        RMR_TRY(e->ensure(e->act, x_elems * sb * sizeof(uint16_t)));
+        uint16_t *x16 = reinterpret_cast<uint16_t *>(e->act.ptr);
+        for (int64_t c0 = 0; c0 < n; c0 += sb) {
+            const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
+            RMR_TRY(launch_fused_front(m, signal + (size_t)c0 * m->L, seqs + (size_t)c0 * seq_w, seq_w,
+                                       maps + (size_t)c0 * map_w, map_w, lens + c0, nb, x16));
+            RMR_TRY(launch_lstm_head_x16(m, x16, nb, logits + (size_t)c0 * m->desc.num_out));
+        }
+        return 0;
+    }
     const size_t per = act_floats_per_chunk(m);
     int64_t sb = e->subbatch > 0 ? e->subbatch : 131072;
     if (sb > n) sb = n;

@@ -1,0 +1,402 @@
+// k_fused.hip — the whole convolutional front of ConvLSTM_w_ref in ONE kernel on the bf16 matrix cores:
+//   chunk arrays (signal f32[n][L], sequence i8, mapping i16, lengths i16; 472 B/chunk @C100)
+//     -> sig_conv1 -> sig_conv2 -> sig_conv3 \
+//     -> k-mer one-hot -> seq_conv1 -> seq_conv2 -> cat -> merge_conv1 -> x bf16[n][T][64]   (3 KB/chunk)
+// Replaces, fused: encoded_kmers.compute_encoded_kmer_batch (src/remora/encoded_kmers.pyx:13-45) and
+// models/ConvLSTM_w_ref.py:41-50 (five Conv1d + BatchNorm1d(eval, folded) + swish triples and the cat).
+// Every intermediate lives in LDS as bf16; HBM sees the chunk arrays once and x once (the unfused pipeline moved
+// 68.9 KB/chunk through HBM in fp32, profiles/r01; this one 3.5 KB/chunk).
+//
+// All five convolutions are implicit GEMMs on v_mfma_f32_16x16x32_bf16 (fp32 accumulate):
+//   D[oc][col] = sum_k A[oc][k] * B[k][col],  col = (chunk, output position), k = tap * C + channel
+// With channel-last activations [row = position][C channels] a stride-S convolution needs no im2col: the K
+// extent of column (chunk, pos) is the CONTIGUOUS run that starts at row chunk*Pin + S*pos — lane (q, n) of
+// k-step s reads the 8 bf16 at flat index row*C + 32 s + 8 q with one ds_read_b128.  K is padded to a multiple of
+// 32 with zero weights; the padded k read finite bf16 of the following rows (never NaN: every activation buffer
+// is zeroed once and only ever holds finite activations).
+//   layer        C     K (padded)   k-steps   M (oc)   where the operand lives
+//   sig_conv1    -     5            VALU      4        signal f32 in LDS           -> SIG1 [row][4]
+//   sig_conv2    4     20 (32)      1         16       SIG1                        -> SIG2 [row][16]
+//   seq_conv1    40    200 (224)    7         16       one-hot OH, 5 planes        -> SEQ1 [row][16]
+//   sig_conv3    16    144 (160)    5         64       SIG2 (stride 3)             -> CAT channels 0..63
+//   seq_conv2    16    208 (224)    7         64       SEQ1 (stride 3)             -> CAT channels 64..127
+//   merge_conv1  128   640          20        64       CAT, 4 planes               -> x (global, bf16)
+// The k-mer one-hot (36 channels, padded to 40) is built in LDS from the 3-bit base codes of the base that
+// covers each signal position (the gather form of the reference's scatter loops) and consumed by the matrix
+// cores — exact in bf16, and it moves seq_conv1's 69 k gather-adds per chunk off the VALU.
+//
+// Wave roles: 4 waves per block, CB chunks per block iteration.  M = 16 layers: the waves split the column
+// tiles; M = 64 layers: wave w owns output channels 16w..16w+15 and walks all column tiles.  Every wave keeps
+// its A fragments of the three M = 64 layers in registers for the lifetime of the block (128 VGPRs); the 32 VGPRs of
+// the two M = 16 layers are re-fetched from L2 at the top of every iteration.
+// LDS bank behaviour of the B reads (ds_read_b128, 16-lane service groups that mix two q values):
+//   SIG2 / SEQ1 (32-byte rows, stride 3): slot = 6 n + 4 s + q  — distinct over a group;
+//   CAT: plane q (8-channel group q of every 32), rows of 4 slots padded to 5 — distinct over a group;
+//   OH: plane per 8-channel group, one slot per row — conflict-free except where the two q of a group fall on
+//   different taps (2 of 7 k-steps, one extra LDS cycle).
+#include "rmr_internal.h"
+#include "rmr_math.h"
+
+namespace rmr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct FusedArgs {
+    const float *signal;   // [n][L]
+    const int8_t *seqs;    // [n][seq_w]
+    const int16_t *maps;   // [n][map_w]
+    const int16_t *lens;   // [n]
+    const uint4 *a_sig2, *a_seq1, *a_sig3, *a_seq2, *a_merge1;  // bf16 A fragments [oc/16][k-steps][64 lanes]
+    const float *w_sig1, *b_sig1;                               // [5][4], [4]  (VALU layer)
+    const float *b_sig2, *b_seq1, *b_sig3, *b_seq2, *b_merge1;  // folded biases
+    uint16_t *x;           // bf16 [n][T][64]
+    int64_t n;
+    int L, P1, P2, P3, T, seq_w, map_w, maxlen, cb;
+    // LDS carve, byte offsets (all multiples of 16)
+    int o_sig, o_seq, o_map, o_len, o_pidx, o_code, o_sig1, o_sig2, o_seq1, o_oh;
+    int oh_plane, cat_plane;  // bytes
+    int lds_bytes;
+    FastDiv d_L, d_P1, d_P3, d_T, d_maxlen;
+};
+
+__device__ __forceinline__ int fdiv(int x, FastDiv d) { return (int)(((float)x + 0.5f) * d.inv); }
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4 a, const uint4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// swish of the four accumulator rows (consecutive output channels) rounded to bf16: 8 bytes
+__device__ __forceinline__ uint2 swish_pack(const f32x4 acc) {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (__bf16)swish_f(acc[r]);
+    return __builtin_bit_cast(uint2, o);
+}
+
+// one or two 16-column tiles of an implicit GEMM: NS k-steps, A resident, B fragments at r + off(s)
+template <int NS, bool TWO, typename Off>
+__device__ __forceinline__ void gemm_cols(const uint4 (&A)[NS], const unsigned char *r0, const unsigned char *r1, Off off,
+                                          f32x4 &acc0, f32x4 &acc1) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc0 = mfma_bf16(A[s], *reinterpret_cast<const uint4 *>(r0 + off(s)), acc0);
+        if (TWO) acc1 = mfma_bf16(A[s], *reinterpret_cast<const uint4 *>(r1 + off(s)), acc1);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CG = (4 * K + 7) / 8;                // 8-channel groups of a one-hot row
+    constexpr int KS_SEQ1 = (5 * CG * 8 + 31) / 32;    // k-steps of seq_conv1
+    constexpr int KS_SIG3 = 5, KS_SEQ2 = 7, KS_M1 = 20;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+
+    // ---- register-resident A fragments and biases of every layer ----
+    uint4 Asig3[KS_SIG3], Aseq2[KS_SEQ2], Am1[KS_M1];
+#pragma unroll
+    for (int s = 0; s < KS_SIG3; ++s) Asig3[s] = a.a_sig3[(w * KS_SIG3 + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < KS_SEQ2; ++s) Aseq2[s] = a.a_seq2[(w * KS_SEQ2 + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < KS_M1; ++s) Am1[s] = a.a_merge1[(w * KS_M1 + s) * 64 + lane];
+    float w1[5][4];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w1[t][o] = a.w_sig1[t * 4 + o];
+    const float4 b1 = *reinterpret_cast<const float4 *>(a.b_sig1);
+
+    float *s_sig = reinterpret_cast<float *>(smem + a.o_sig);
+    int8_t *s_seq = reinterpret_cast<int8_t *>(smem + a.o_seq);
+    int16_t *s_map = reinterpret_cast<int16_t *>(smem + a.o_map);
+    int16_t *s_len = reinterpret_cast<int16_t *>(smem + a.o_len);
+    int16_t *s_pidx = reinterpret_cast<int16_t *>(smem + a.o_pidx);
+    unsigned *s_code = reinterpret_cast<unsigned *>(smem + a.o_code);
+    unsigned char *s_sig1 = smem + a.o_sig1;  // [row][4] bf16, 8 B rows
+    unsigned char *s_sig2 = smem + a.o_sig2;  // [row][16] bf16, 32 B rows
+    unsigned char *s_seq1 = smem + a.o_seq1;  // [row][16] bf16
+    unsigned char *s_oh = smem + a.o_oh;      // CG planes x [row] x 16 B;  aliased by
+    unsigned char *s_cat = smem + a.o_oh;     // 4 planes x [row][5 slots] x 16 B
+
+    // every byte finite from the start (K padding reads rows that no stage of this iteration wrote)
+    for (int i = tid * 16; i < a.lds_bytes; i += 256 * 16) *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
+
+    const int tiles_sig2 = (a.P2 + 15) >> 4, tiles_seq1 = (a.P1 + 15) >> 4;
+    const int pairs_sig2 = (tiles_sig2 + 1) >> 1, pairs_seq1 = (tiles_seq1 + 1) >> 1;
+    const int pairs_chunk = pairs_sig2 + pairs_seq1;
+    const FastDiv d_pc = FastDiv{pairs_chunk, 1.0f / (float)pairs_chunk};
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        __syncthreads();  // merge_conv1 of the previous iteration has read CAT (the one-hot planes alias it)
+        // A fragments of the two M = 16 layers: fetched (L2-resident, 8 KB) at the top of every iteration and dead
+        // after S2, so that they do not occupy 32 VGPRs while merge_conv1 runs
+        const uint4 Asig2 = a.a_sig2[lane];
+        uint4 Aseq1[KS_SEQ1];
+#pragma unroll
+        for (int s = 0; s < KS_SEQ1; ++s) Aseq1[s] = a.a_seq1[s * 64 + lane];
+        // ---- S0: chunk arrays -> LDS (each array of the nch chunks is one contiguous run in HBM) ----
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(a.signal + (size_t)chunk0 * a.L);
+            const int n4 = (nch * a.L) >> 2;  // L % 4 == 0 (checked by the launcher)
+            for (int i = tid; i < n4; i += 256) reinterpret_cast<float4 *>(s_sig)[i] = src[i];
+            const int8_t *sq = a.seqs + (size_t)chunk0 * a.seq_w;
+            for (int i = tid; i < nch * a.seq_w; i += 256) s_seq[i] = sq[i];
+            const int16_t *mp = a.maps + (size_t)chunk0 * a.map_w;
+            for (int i = tid; i < nch * a.map_w; i += 256) s_map[i] = mp[i];
+            if (tid < nch) {
+                int len = a.lens[chunk0 + tid];
+                s_len[tid] = (int16_t)(len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len));
+            }
+        }
+        __syncthreads();
+        // ---- S1a: sig_conv1 (VALU, fp32) -> SIG1;  covering base of every signal position;  base codes ----
+        for (int i = tid; i < nch * a.P1; i += 256) {
+            const int ci = fdiv(i, a.d_P1), pos = i - ci * a.P1;
+            const float *xs = s_sig + ci * a.L + pos;
+            float4 acc = b1;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const float xv = xs[t];
+                acc.x = fmaf(w1[t][0], xv, acc.x); acc.y = fmaf(w1[t][1], xv, acc.y);
+                acc.z = fmaf(w1[t][2], xv, acc.z); acc.w = fmaf(w1[t][3], xv, acc.w);
+            }
+            const f32x4 v = {acc.x, acc.y, acc.z, acc.w};
+            *reinterpret_cast<uint2 *>(s_sig1 + (size_t)i * 8) = swish_pack(v);
+        }
+        for (int i = tid; i < nch * a.L; i += 256) {
+            const int ci = fdiv(i, a.d_L), s = i - ci * a.L;
+            const int16_t *mp = s_map + ci * a.map_w;
+            const int len = s_len[ci];
+            // p = (number of mapping entries map[0..len] that are <= s) - 1: the base whose [map[p], map[p+1]) holds s
+            int lo = 0, hi = len + 1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int mid = (lo + hi) >> 1;
+                const bool go = lo < hi;
+                const bool le = go && (int)mp[go ? mid : 0] <= s;
+                lo = le ? mid + 1 : lo;
+                hi = (go && !le) ? mid : hi;
+            }
+            const int p = lo - 1;
+            s_pidx[i] = (int16_t)((p >= 0 && p < len) ? p : -1);
+        }
+        for (int i = tid; i < nch * a.maxlen; i += 256) {
+            const int ci = fdiv(i, a.d_maxlen), p = i - ci * a.maxlen;
+            unsigned code = 0;
+            if (p < s_len[ci]) {
+                const int8_t *sq = s_seq + ci * a.seq_w + p;
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    const int b = sq[kp];
+                    code |= (unsigned)((b >= 0 && b < 4) ? b : 4) << (3 * kp);
+                }
+            }
+            s_code[i] = code;
+        }
+        __syncthreads();
+        // ---- S1b: one-hot rows (bf16 1.0 = 0x3F80), 16 bytes = 8 channels = k-mer slots 2cg, 2cg+1 ----
+        for (int i = tid; i < nch * a.L * CG; i += 256) {
+            const int row = i / CG, cg = i - row * CG;  // CG is a compile-time constant
+            const int ci = fdiv(row, a.d_L);
+            const int p = s_pidx[row];
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p >= 0) {
+                const unsigned code = s_code[ci * a.maxlen + p];
+                const int kp0 = 2 * cg, kp1 = 2 * cg + 1;
+                const unsigned b0 = (code >> (3 * kp0)) & 7u;
+                const unsigned b1c = kp1 < K ? ((code >> (3 * kp1)) & 7u) : 4u;
+                const unsigned one0 = 0x3F80u << ((b0 & 1u) * 16), one1 = 0x3F80u << ((b1c & 1u) * 16);
+                v.x = (b0 >> 1) == 0 ? one0 : 0u;
+                v.y = (b0 >> 1) == 1 ? one0 : 0u;
+                v.z = (b1c >> 1) == 0 ? one1 : 0u;
+                v.w = (b1c >> 1) == 1 ? one1 : 0u;
+            }
+            *reinterpret_cast<uint4 *>(s_oh + (size_t)cg * a.oh_plane + (size_t)row * 16) = v;
+        }
+        __syncthreads();
+        // ---- S2: sig_conv2 and seq_conv1 (M = 16): the waves split the column-tile pairs ----
+        // (biases are fetched per stage: L1-resident, and not worth 20 VGPRs for the whole block lifetime)
+        const f32x4 b_sig2 = *reinterpret_cast<const f32x4 *>(a.b_sig2 + 4 * q);
+        const f32x4 b_seq1 = *reinterpret_cast<const f32x4 *>(a.b_seq1 + 4 * q);
+        // one-hot operand of seq_conv1: 8-group k8 = 4 s + q of k-step s sits at tap k8 / CG, channel group k8 % CG
+        int oh_off[KS_SEQ1];
+#pragma unroll
+        for (int s = 0; s < KS_SEQ1; ++s) {
+            const int k8 = 4 * s + q, tap = k8 / CG, cg = k8 - tap * CG;
+            oh_off[s] = cg * a.oh_plane + tap * 16;
+        }
+        for (int item = w; item < nch * pairs_chunk; item += 4) {
+            const int ci = fdiv(item, d_pc), r = item - ci * pairs_chunk;
+            if (r < pairs_sig2) {
+                int pos0 = 32 * r + nn, pos1 = pos0 + 16;
+                const bool v0 = pos0 < a.P2, v1 = pos1 < a.P2;
+                pos0 = v0 ? pos0 : a.P2 - 1;
+                pos1 = v1 ? pos1 : a.P2 - 1;
+                const unsigned char *r0 = s_sig1 + (size_t)(ci * a.P1 + pos0) * 8 + 16 * q;
+                const unsigned char *r1 = s_sig1 + (size_t)(ci * a.P1 + pos1) * 8 + 16 * q;
+                const uint2 x00 = *reinterpret_cast<const uint2 *>(r0), x01 = *reinterpret_cast<const uint2 *>(r0 + 8);
+                const uint2 x10 = *reinterpret_cast<const uint2 *>(r1), x11 = *reinterpret_cast<const uint2 *>(r1 + 8);
+                const f32x4 acc0 = mfma_bf16(Asig2, make_uint4(x00.x, x00.y, x01.x, x01.y), b_sig2);
+                const f32x4 acc1 = mfma_bf16(Asig2, make_uint4(x10.x, x10.y, x11.x, x11.y), b_sig2);
+                if (v0) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos0) * 32 + 8 * q) = swish_pack(acc0);
+                if (v1) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos1) * 32 + 8 * q) = swish_pack(acc1);
+            } else {
+                int pos0 = 32 * (r - pairs_sig2) + nn, pos1 = pos0 + 16;
+                const bool v0 = pos0 < a.P1, v1 = pos1 < a.P1;
+                pos0 = v0 ? pos0 : a.P1 - 1;
+                pos1 = v1 ? pos1 : a.P1 - 1;
+                const unsigned char *r0 = s_oh + (size_t)(ci * a.L + pos0) * 16;
+                const unsigned char *r1 = s_oh + (size_t)(ci * a.L + pos1) * 16;
+                f32x4 acc0 = b_seq1, acc1 = b_seq1;
+#pragma unroll
+                for (int s = 0; s < KS_SEQ1; ++s) {
+                    acc0 = mfma_bf16(Aseq1[s], *reinterpret_cast<const uint4 *>(r0 + oh_off[s]), acc0);
+                    acc1 = mfma_bf16(Aseq1[s], *reinterpret_cast<const uint4 *>(r1 + oh_off[s]), acc1);
+                }
+                if (v0) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos0) * 32 + 8 * q) = swish_pack(acc0);
+                if (v1) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos1) * 32 + 8 * q) = swish_pack(acc1);
+            }
+        }
+        __syncthreads();
+        // ---- S3: sig_conv3 and seq_conv2 (stride 3, M = 64: wave w = channels 16w..16w+15) -> CAT ----
+        {
+            const int ncols = nch * a.P3;
+            const int ntiles = (ncols + 15) >> 4;
+            const f32x4 b_sig3 = *reinterpret_cast<const f32x4 *>(a.b_sig3 + 16 * w + 4 * q);
+            const f32x4 b_seq2 = *reinterpret_cast<const f32x4 *>(a.b_seq2 + 16 * w + 4 * q);
+            // CAT position of this lane's 4 output channels c0 = 16w + 4q (+64 for the sequence half):
+            // plane (c0 % 32) / 8, slot c0 / 32, half (c0 % 8) / 4
+            unsigned char *cat_w = s_cat + (size_t)((w & 1) * 2 + (q >> 1)) * a.cat_plane + (w >> 1) * 16 + (q & 1) * 8;
+            for (int tile = 0; tile < ntiles; tile += 2) {
+                int col0 = tile * 16 + nn, col1 = col0 + 16;
+                const bool v0 = col0 < ncols, v1 = col1 < ncols;
+                col0 = v0 ? col0 : ncols - 1;
+                col1 = v1 ? col1 : ncols - 1;
+                const int ch0 = fdiv(col0, a.d_P3), ch1 = fdiv(col1, a.d_P3);
+                const int p0 = col0 - ch0 * a.P3, p1 = col1 - ch1 * a.P3;
+                const bool two = tile + 1 < ntiles;  // wave-uniform
+                {
+                    const unsigned char *r0 = s_sig2 + (size_t)(ch0 * a.P2 + 3 * p0) * 32 + 16 * q;
+                    const unsigned char *r1 = s_sig2 + (size_t)(ch1 * a.P2 + 3 * p1) * 32 + 16 * q;
+                    f32x4 acc0 = b_sig3, acc1 = b_sig3;
+                    auto off = [](int s) { return 64 * s; };
+                    if (two) gemm_cols<KS_SIG3, true>(Asig3, r0, r1, off, acc0, acc1);
+                    else gemm_cols<KS_SIG3, false>(Asig3, r0, r1, off, acc0, acc1);
+                    if (v0) *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80) = swish_pack(acc0);
+                    if (v1) *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80) = swish_pack(acc1);
+                }
+                {
+                    const unsigned char *r0 = s_seq1 + (size_t)(ch0 * a.P1 + 3 * p0) * 32 + 16 * q;
+                    const unsigned char *r1 = s_seq1 + (size_t)(ch1 * a.P1 + 3 * p1) * 32 + 16 * q;
+                    f32x4 acc0 = b_seq2, acc1 = b_seq2;
+                    auto off = [](int s) { return 64 * s; };
+                    if (two) gemm_cols<KS_SEQ2, true>(Aseq2, r0, r1, off, acc0, acc1);
+                    else gemm_cols<KS_SEQ2, false>(Aseq2, r0, r1, off, acc0, acc1);
+                    if (v0) *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80 + 32) = swish_pack(acc0);
+                    if (v1) *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80 + 32) = swish_pack(acc1);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- S4: merge_conv1 (K = 5 taps x 128 channels) -> x, bf16 channel-last in HBM ----
+        {
+            const int ncols = nch * a.T;
+            const int ntiles = (ncols + 15) >> 4;
+            const f32x4 b_m1 = *reinterpret_cast<const f32x4 *>(a.b_merge1 + 16 * w + 4 * q);
+            uint16_t *xo = a.x + (size_t)chunk0 * a.T * 64 + 16 * w + 4 * q;
+            const unsigned char *cat_r = s_cat + (size_t)q * a.cat_plane;
+            for (int tile = 0; tile < ntiles; tile += 2) {
+                int col0 = tile * 16 + nn, col1 = col0 + 16;
+                const bool v0 = col0 < ncols, v1 = col1 < ncols;
+                col0 = v0 ? col0 : ncols - 1;
+                col1 = v1 ? col1 : ncols - 1;
+                const int ch0 = fdiv(col0, a.d_T), ch1 = fdiv(col1, a.d_T);
+                const unsigned char *r0 = cat_r + (size_t)(ch0 * a.P3 + (col0 - ch0 * a.T)) * 80;
+                const unsigned char *r1 = cat_r + (size_t)(ch1 * a.P3 + (col1 - ch1 * a.T)) * 80;
+                const bool two = tile + 1 < ntiles;
+                f32x4 acc0 = b_m1, acc1 = b_m1;
+                auto off = [](int s) { return (s >> 2) * 80 + (s & 3) * 16; };  // tap row, 32-channel slot
+                if (two) gemm_cols<KS_M1, true>(Am1, r0, r1, off, acc0, acc1);
+                else gemm_cols<KS_M1, false>(Am1, r0, r1, off, acc0, acc1);
+                if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack(acc0);
+                if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack(acc1);
+            }
+        }
+    }
+}
+
+// per-device "attribute set" flags: hipFuncSetAttribute applies to the current device only
+static bool fused_attr_done[64] = {};
+
+bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
+    if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 1) return false;
+    if (m->desc.kmer_len != 9 || m->front.kw1 != 5) return false;
+    if (m->L % 4 || map_w - 1 > 62 || map_w < 2) return false;
+    if (seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
+    return m->fused.a_merge1 != nullptr;
+}
+
+int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
+                       const int16_t *lens, int64_t n, uint16_t *x) {
+    rmr_engine *e = m->eng;
+    if (n <= 0) return 0;
+    constexpr int CG = 5;
+    FusedArgs a;
+    a.signal = signal; a.seqs = seqs; a.maps = maps; a.lens = lens;
+    a.a_sig2 = reinterpret_cast<const uint4 *>(m->fused.a_sig2); a.a_seq1 = reinterpret_cast<const uint4 *>(m->fused.a_seq1);
+    a.a_sig3 = reinterpret_cast<const uint4 *>(m->fused.a_sig3); a.a_seq2 = reinterpret_cast<const uint4 *>(m->fused.a_seq2);
+    a.a_merge1 = reinterpret_cast<const uint4 *>(m->fused.a_merge1);
+    a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1; a.b_sig2 = m->front.b_sig2; a.b_seq1 = m->front.b_seq1;
+    a.b_sig3 = m->sig3.bias; a.b_seq2 = m->seq2.bias; a.b_merge1 = m->merge1.bias;
+    a.x = x; a.n = n;
+    a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.P3 = m->P3; a.T = m->T;
+    a.seq_w = seq_w; a.map_w = map_w; a.maxlen = map_w - 1;
+    auto up16 = [](int b) { return (b + 15) & ~15; };
+    // chunks per block iteration: the largest count whose LDS image leaves room for two blocks per CU
+    const int budget = tune_int("RMR_FUSED_LDS_BUDGET", 80 * 1024);
+    int cb = tune_int("RMR_FUSED_CB", 8), total = 0;
+    for (; cb >= 1; --cb) {
+        int off = 0;
+        a.o_sig = off; off += up16(cb * a.L * 4);
+        a.o_seq = off; off += up16(cb * seq_w);
+        a.o_map = off; off += up16(cb * map_w * 2);
+        a.o_len = off; off += up16(cb * 2);
+        a.o_pidx = off; off += up16(cb * a.L * 2);
+        a.o_code = off; off += up16(cb * a.maxlen * 4);
+        a.o_sig1 = off; off += up16((cb * a.P1 + 8) * 8);
+        a.o_sig2 = off; off += (cb * a.P2 + 4) * 32;
+        a.o_seq1 = off; off += (cb * a.P1 + 4) * 32;
+        a.o_oh = off;
+        a.oh_plane = ((cb * a.L + 8 + 15) & ~15) * 16;
+        a.cat_plane = (((cb * a.P3 + 1) * 5 + 15) & ~15) * 16;
+        const int oh = CG * a.oh_plane, cat = 4 * a.cat_plane;
+        off += oh > cat ? oh : cat;
+        total = off;
+        if (total <= budget) break;
+    }
+    if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "fused front: one chunk of %d samples needs %d B of LDS", a.L, total);
+    a.cb = cb; a.lds_bytes = total;
+    a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);
+    a.d_maxlen = make_fastdiv(a.maxlen);
+    auto kern = fused_front_kernel<9>;
+    if (e->device < 64 && !fused_attr_done[e->device]) {
+        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        fused_attr_done[e->device] = true;
+    }
+    const int64_t iters = (n + cb - 1) / cb;
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 4);
+    if (grid > iters) grid = iters;
+    ProfScope ps(e, K_FUSED_FRONT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)total, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rmr

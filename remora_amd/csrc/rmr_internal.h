@@ -62,6 +62,7 @@ enum KernelId {
     K_REFINE_BAND,
     K_REFINE_DP,
     K_REFINE_ROWWISE,
+    K_FUSED_FRONT,
     K_NUM
 };
 const char *kernel_name(int id);
@@ -148,6 +149,11 @@ struct FrontWeights {
     float *b_seq1 = nullptr;   // [16]
 };
 
+// bf16 A fragments of the fused front kernel (k_fused.hip): [oc/16][k-steps][64 lanes] x 16 B, k = tap * C + channel
+struct FusedWeights {
+    float *a_sig2 = nullptr, *a_seq1 = nullptr, *a_sig3 = nullptr, *a_seq2 = nullptr, *a_merge1 = nullptr;
+};
+
 struct LstmWeights {
     float *a_ih1 = nullptr, *a_hh1 = nullptr;  // [H/16 waves][4 gates][H/4][64]
     float *b1 = nullptr;                       // [4H]  b_ih + b_hh
@@ -169,6 +175,7 @@ struct rmr_model {
     // conv_lstm: sig3, seq2, merge1;  conv_only: sig3, seq2, seq3, merge1..4
     rmr::ConvLayer sig3, seq2, seq3, merge1, merge2, merge3, merge4;
     rmr::LstmWeights lstm;
+    rmr::FusedWeights fused;  // plain-bf16 ConvLSTM only
     float *w_fc = nullptr, *b_fc = nullptr;  // conv_only head: [num_out][size*3]
     // derived geometry
     int L = 0, P1 = 0, P2 = 0, P3 = 0, PQ2 = 0, T = 0, T2 = 0, T3 = 0, T4 = 0;
@@ -211,6 +218,11 @@ int launch_lstm_head_split(rmr_model *m, const float *x, int64_t n, float *logit
 int launch_conv_split(rmr_engine *e, const ConvLayer &c, int np, const float *in, int in_row, int pin,
                       float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits);
+// fused bf16 front (k_fused.hip): chunk arrays -> x bf16[n][T][64];  lstm on that tensor (k_lstm_bf16s.hip)
+bool fused_front_supported(const rmr_model *m, int seq_w, int map_w);
+int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
+                       const int16_t *lens, int64_t n, uint16_t *x);
+int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logits);
 
 // integer tuning knob from the environment (read once per call site; for experiments only)
 inline int tune_int(const char *name, int dflt) {

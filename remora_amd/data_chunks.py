@@ -1208,17 +1208,26 @@ def load_dataset(ds_path):
 
 
 def compute_best_split(total_size, props):
-    """`total_size` split into len(props) positive integers as close to `props` as possible (:1773-1792)."""
-    props = np.asarray(props, dtype=float)
-    if total_size < len(props):
-        raise RemoraError(f"total_size ({total_size}) smaller than number of proportions {len(props)}")
-    sizes = np.floor(total_size * props).astype(int)
-    sizes[sizes == 0] = 1
-    while sizes.sum() > total_size:
-        sizes[np.argmax(sizes)] -= 1
-    while sizes.sum() < total_size:
-        sizes[np.argmin(sizes / sizes.sum() - props)] += 1
-    return sizes
+    """Integer batch shares: len(props) positive counts adding up to `total_size`, as near to the proportions as
+    integers allow.  Same outcome as the reference's function of this name (src/remora/data_chunks.py:1767-1786;
+    pinned on reference-generated cases in tests/test_host_cpu.py): floor quotas of at least one row each, an
+    over-commitment taken back from the largest share, the remainder handed out one row at a time to the share
+    that lags its proportion most (first index on ties in both loops)."""
+    target = [float(p) for p in props]
+    k = len(target)
+    if total_size < k:
+        raise RemoraError(f"total_size ({total_size}) smaller than number of proportions {k}")
+    quota = [max(1, int(np.floor(total_size * p))) for p in target]
+    used = sum(quota)
+    while used > total_size:
+        j = max(range(k), key=lambda i: (quota[i], -i))
+        quota[j] -= 1
+        used -= 1
+    while used < total_size:
+        j = min(range(k), key=lambda i: (quota[i] / used - target[i], i))
+        quota[j] += 1
+        used += 1
+    return np.asarray(quota, dtype=int)
 
 
 class RemoraDataset:

@@ -1,0 +1,143 @@
+"""GPU parity tests of the fused bf16 front kernel (remora_amd/csrc/k_fused.hip): chunk arrays -> x bf16 in one
+kernel, every intermediate in LDS.  Checked against (a) the CPU restatement of the reference network (oracle, fp32;
+plain-bf16 tolerance of tests/test_gpu_parity.py: 3e-2 on logits + argmax agreement on clearly separated chunks),
+(b) the unfused bf16 pipeline of the same library (RMR_FUSED=0), which rounds at the same places except for
+sig_conv2 / seq_conv1 (fp32 VALU there, bf16 MFMA here)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 3e-2
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def _unfused(fn):
+    os.environ["RMR_FUSED"] = "0"
+    try:
+        return fn()
+    finally:
+        del os.environ["RMR_FUSED"]
+
+
+def _awkward(d, rng):
+    """Edge rows on top of the synthetic generator: missing (-1) bases, zero-dwell bases, the shortest sequences,
+    garbage in the padding columns."""
+    seqs, maps, lens = d["sequence"].copy(), d["sequence_to_signal_mapping"].copy(), d["sequence_lengths"].copy()
+    n, L = lens.size, d["chunk_len"]
+    for c in range(0, n, 5):  # N bases anywhere, incl. the context columns
+        seqs[c, rng.integers(0, seqs.shape[1], 3)] = -1
+    for c in range(1, n, 7):  # zero-dwell: repeat a cut
+        sl = int(lens[c])
+        if sl >= 3:
+            maps[c, 2] = maps[c, 1]
+    for c in range(2, n, 11):  # one or two bases cover the whole chunk
+        sl = 1 + (c % 2)
+        maps[c, : sl + 1] = [0, L] if sl == 1 else [0, L // 3, L]
+        lens[c] = sl
+    for c in range(n):  # padding columns are uninitialised in the reference's datasets (data_chunks.py:1379-1388)
+        sl = int(lens[c])
+        maps[c, sl + 1 :] = rng.integers(-300, 300, maps.shape[1] - sl - 1)
+        seqs[c, sl + 8 :] = rng.integers(-1, 4, seqs.shape[1] - sl - 8)
+    return seqs, maps, lens
+
+
+@pytest.mark.parametrize("cfg,num_out", [("C100", 2), ("C200", 3)])
+def test_fused_front_vs_oracle_and_unfused(torch_cuda, O, cfg, num_out):
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.engine import get_engine
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    net = torch_ref.random_model("conv_lstm", 64, 9, num_out, seed=5)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    cc = synth.CONFIGS[cfg][0]
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0, dtype="bf16")
+    eng = get_engine(0)
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 3, 5, 37, 1000, 4099):  # not multiples of the chunks-per-iteration, of 16, of anything
+        d = synth.synth_chunks_config(cfg, n, shard=100 + n)
+        seqs, maps, lens = _awkward(d, rng) if n >= 37 else (d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+        eng.profile_reset()
+        eng.profile_enable(True)
+        out = model.infer_chunks(d["signal"], seqs, maps, lens, (4, 4))
+        eng.profile_enable(False)
+        prof = eng.profile()
+        assert "fused_front" in prof and "front_seq" not in prof, prof.keys()  # the fused kernel is what ran
+        out_u = _unfused(lambda: model.infer_chunks(d["signal"], seqs, maps, lens, (4, 4)))
+        enc = O.compute_encoded_kmer_batch(4, 4, seqs, maps, lens)
+        with torch.no_grad():
+            ref = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
+        assert np.isfinite(out).all()
+        err, err_u = np.abs(out - ref).max(), np.abs(out_u - ref).max()
+        assert err <= BF16_TOL, (cfg, n, err, err_u)
+        assert np.abs(out - out_u).max() <= BF16_TOL, (cfg, n)
+        srt = np.sort(ref, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 4 * BF16_TOL
+        assert np.array_equal(out.argmax(1)[clear], ref.argmax(1)[clear])
+
+
+def test_fused_front_golden_models(torch_cuda, O):
+    """The reference-generated logits (tests/golden/model_convlstm_*.npz; weights with non-trivial BatchNorm stats)."""
+    from conftest import golden
+    from remora_amd.engine import get_engine
+    from remora_amd.model_util import model_from_state
+
+    for name in ("convlstm_s64_l100_o2", "convlstm_s64_l200_o3"):
+        g = golden(f"model_{name}.npz")
+        state = O.state_from_npz(g)
+        size, kb, ka, L, num_out = (int(x) for x in g["params"])
+        model = model_from_state(state, dict(chunk_context=(L // 2, L - L // 2), kmer_context_bases=(kb, ka)), device=0,
+                                 dtype="bf16")
+        eng = get_engine(0)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        out = model.infer_chunks(g["sigs"], g["seqs"], g["maps"], g["lens"], (kb, ka))
+        eng.profile_enable(False)
+        assert ("fused_front" in eng.profile()) == (kb + ka + 1 == 9)
+        assert np.abs(out - g["logits"]).max() <= BF16_TOL, name
+
+
+def test_fused_front_full_size_properties(torch_cuda):
+    """1M chunks (BASELINE configs[3] shape per GPU): deterministic, independent of batch position (sub-batch /
+    block-iteration / tile boundaries), exact label tally, device and host-buffer entry agree."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    n = 1_000_000
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=0)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    model = model_from_state(state, dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0, dtype="bf16")
+    d = synth.synth_chunks_config("C100", n)
+    keys = ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")
+    dev = [torch.from_numpy(d[k]).cuda() for k in keys]
+    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    out = model.infer_chunks(*dev, (4, 4), label_counts=counts)
+    out2 = model.infer_chunks(*dev, (4, 4))
+    assert torch.equal(out, out2) and bool(torch.isfinite(out).all())
+    assert torch.equal(counts, torch.bincount(out.argmax(dim=1), minlength=2)) and int(counts.sum()) == n
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    outp = model.infer_chunks(*[t[perm].contiguous() for t in dev], (4, 4))
+    assert torch.equal(outp, out[perm]), "result of a chunk depends on its batch position"
+    k = 300_001
+    out_h = model.infer_chunks(*[d[key][:k] for key in keys], (4, 4))
+    assert np.array_equal(out_h, out[:k].cpu().numpy())
