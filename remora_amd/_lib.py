@@ -7,7 +7,8 @@ import threading
 from . import RemoraError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libremora_hip.so")
+# REMORA_HIP_LIB: another build of the same library (experiment builds such as `make abl`); never a fallback
+LIB_PATH = os.environ.get("REMORA_HIP_LIB") or os.path.join(_HERE, "libremora_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 ARCH_CONV_LSTM, ARCH_CONV_ONLY = 0, 1

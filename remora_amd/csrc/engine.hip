@@ -371,7 +371,7 @@ int pack_conv_split(rmr_model *m, const Folded &f, int np, ConvLayer *out) {
 // conv weights -> bf16 A fragments of the fused front kernel: [oc/16][ksteps][64 lanes][4 dwords]; lane (q, m) of
 // k-step s holds k = 32 s + 8 q + j, k = tap * C + channel (C = row width of the operand in LDS, k_fused.hip);
 // taps >= kw and channels >= ic are zero
-int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, float **dev) {
+int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, double scale, float **dev) {
     const ConvSpec &s = f.s;
     const int W = s.oc / 16;
     std::vector<uint32_t> o((size_t)W * ksteps * 64 * 4);
@@ -382,7 +382,7 @@ int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, float **dev) {
                 uint32_t b[8];
                 for (int j = 0; j < 8; ++j) {
                     const int k = 32 * st + 8 * q + j, tap = k / C, ch = k % C;
-                    const float v = (tap < s.kw && ch < s.ic) ? f.w[((size_t)oc * s.ic + ch) * s.kw + tap] : 0.0f;
+                    const float v = (tap < s.kw && ch < s.ic) ? (float)(scale * (double)f.w[((size_t)oc * s.ic + ch) * s.kw + tap]) : 0.0f;
                     b[j] = rne_bf16(f2u(v));
                 }
                 for (int i = 0; i < 4; ++i) o[(((size_t)w * ksteps + st) * 64 + lane) * 4 + i] = (b[2 * i] >> 16) | b[2 * i + 1];
@@ -521,11 +521,27 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
         }
         if (m->nparts == 1 && sz == 64 && K == 9 && kw1 == 5) {  // operands of the fused front kernel
             const int cg = (4 * K + 7) / 8;
-            RMR_TRY(pack_flat_a(m.get(), convs[1], 4, 1, &m->fused.a_sig2));
-            RMR_TRY(pack_flat_a(m.get(), convs[3], 8 * cg, (5 * cg * 8 + 31) / 32, &m->fused.a_seq1));
-            RMR_TRY(pack_flat_a(m.get(), convs[2], 16, 5, &m->fused.a_sig3));
-            RMR_TRY(pack_flat_a(m.get(), convs[4], 16, 7, &m->fused.a_seq2));
-            RMR_TRY(pack_flat_a(m.get(), convs[5], 2 * sz, 20, &m->fused.a_merge1));
+            const double log2e = 1.4426950408889634;
+            RMR_TRY(pack_flat_a(m.get(), convs[1], 4, 1, 1.0, &m->fused.a_sig2));
+            RMR_TRY(pack_flat_a(m.get(), convs[3], 8 * cg, (5 * cg * 8 + 31) / 32, log2e, &m->fused.a_seq1));
+            RMR_TRY(pack_flat_a(m.get(), convs[2], 16, 5, 1.0, &m->fused.a_sig3));
+            RMR_TRY(pack_flat_a(m.get(), convs[4], 16, 7, 1.0, &m->fused.a_seq2));
+            RMR_TRY(pack_flat_a(m.get(), convs[5], 2 * sz, 20, 1.0, &m->fused.a_merge1));
+            auto scaled = [&](const std::vector<float> &v) {
+                std::vector<float> o(v.size());
+                for (size_t i = 0; i < v.size(); ++i) o[i] = (float)((double)v[i] * log2e);
+                return o;
+            };
+            std::vector<float> w1s((size_t)kw1 * 4);
+            for (int t = 0; t < kw1; ++t)
+                for (int o = 0; o < 4; ++o) w1s[t * 4 + o] = (float)((double)convs[0].w[(size_t)o * kw1 + t] * log2e);
+            RMR_TRY(upload(m.get(), w1s, &m->fused.w_sig1));
+            RMR_TRY(upload(m.get(), scaled(convs[0].b), &m->fused.b_sig1));
+            RMR_TRY(upload(m.get(), scaled(convs[1].b), &m->fused.b_sig2));
+            RMR_TRY(upload(m.get(), scaled(convs[3].b), &m->fused.b_seq1));
+            RMR_TRY(upload(m.get(), scaled(convs[2].b), &m->fused.b_sig3));
+            RMR_TRY(upload(m.get(), scaled(convs[4].b), &m->fused.b_seq2));
+            RMR_TRY(upload(m.get(), scaled(convs[5].b), &m->fused.b_merge1));
         }
         const int H = sz;
         const float *wih1 = p; p += (size_t)4 * H * H;

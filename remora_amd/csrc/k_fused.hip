@@ -27,8 +27,8 @@
 //
 // Wave roles: 4 waves per block, CB chunks per block iteration.  M = 16 layers: the waves split the column
 // tiles; M = 64 layers: wave w owns output channels 16w..16w+15 and walks all column tiles.  Every wave keeps
-// its A fragments of the three M = 64 layers in registers for the lifetime of the block (128 VGPRs); the 32 VGPRs of
-// the two M = 16 layers are re-fetched from L2 at the top of every iteration.
+// the A fragments of merge_conv1 in registers for the lifetime of the block (80 VGPRs); the fragments of the other
+// layers are re-fetched from L2 where their stage begins (their VGPRs hold B fragments in flight during the other stages).
 // LDS bank behaviour of the B reads (ds_read_b128, 16-lane service groups that mix two q values):
 //   SIG2 / SEQ1 (32-byte rows, stride 3): slot = 6 n + 4 s + q  — distinct over a group;
 //   CAT: plane q (8-channel group q of every 32), rows of 4 slots padded to 5 — distinct over a group;
@@ -49,8 +49,8 @@ struct FusedArgs {
     const int16_t *maps;   // [n][map_w]
     const int16_t *lens;   // [n]
     const uint4 *a_sig2, *a_seq1, *a_sig3, *a_seq2, *a_merge1;  // bf16 A fragments [oc/16][k-steps][64 lanes]
-    const float *w_sig1, *b_sig1;                               // [5][4], [4]  (VALU layer)
-    const float *b_sig2, *b_seq1, *b_sig3, *b_seq2, *b_merge1;  // folded biases
+    const float *w_sig1, *b_sig1;                               // [5][4], [4]  (VALU layer), scaled by log2(e)
+    const float *b_sig2, *b_seq1, *b_sig3, *b_seq2, *b_merge1;  // folded biases, scaled by log2(e)
     uint16_t *x;           // bf16 [n][T][64]
     int64_t n;
     int L, P1, P2, P3, T, seq_w, map_w, maxlen, cb;
@@ -59,7 +59,17 @@ struct FusedArgs {
     int oh_plane, cat_plane;  // bytes
     int lds_bytes;
     FastDiv d_L, d_P1, d_P3, d_T, d_maxlen;
+    int abl;  // experiment builds only (-DRMR_TIMING_ABLATIONS): bit mask of stages to skip, see ABL() below
 };
+
+// Timing ablations (which stage costs what): compiled in only with -DRMR_TIMING_ABLATIONS (make abl ->
+// libremora_hip_abl.so, selected with REMORA_HIP_LIB); the shipped library has no way to skip work.
+// bits: 1 S0 loads, 2 S1a (sig_conv1 / covering base / codes), 4 S1b one-hot, 8 S2, 16 S3, 32 S4, 64 swish -> identity
+#ifdef RMR_TIMING_ABLATIONS
+#define ABL(bit) (a.abl & (bit))
+#else
+#define ABL(bit) 0
+#endif
 
 __device__ __forceinline__ int fdiv(int x, FastDiv d) { return (int)(((float)x + 0.5f) * d.inv); }
 
@@ -67,24 +77,102 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4 a, const uint4 b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// swish of the four accumulator rows (consecutive output channels) rounded to bf16: 8 bytes
-__device__ __forceinline__ uint2 swish_pack(const f32x4 acc) {
+// Activations are carried SCALED by log2(e): every layer's weights/bias are prepared on the host so that the
+// accumulator holds z = log2(e) * y (y = the reference's pre-activation), and the stored activation is
+//   a' = z / (1 + 2^-z) = log2(e) * swish(y)          (src/remora/activations.py:4-18: swish(y) = y * sigmoid(y))
+// which saves the multiply by -log2(e) in front of every v_exp_f32; the next layer's weights are unchanged (its bias
+// is scaled by log2(e)), and the last layer multiplies by POST = 1 / log2(e) to hand over the true activation.
+// Four accumulator rows (consecutive output channels) -> four bf16: 8 bytes.
+__device__ __forceinline__ uint2 swish_pack(const f32x4 acc, const int no_swish = 0, const float post = 1.0f) {
     bf16x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (__bf16)swish_f(acc[r]);
+    for (int r = 0; r < 4; ++r) {
+        const float z = acc[r];
+        const float y = z * fast_rcp(1.0f + __builtin_amdgcn_exp2f(-z));
+        o[r] = (__bf16)(no_swish ? z : y * post);
+    }
     return __builtin_bit_cast(uint2, o);
 }
 
-// one or two 16-column tiles of an implicit GEMM: NS k-steps, A resident, B fragments at r + off(s)
+// B fragments (8 bf16 per lane) of NS k-steps of one or two 16-column tiles, read ahead of the MFMAs that use them
 template <int NS, bool TWO, typename Off>
-__device__ __forceinline__ void gemm_cols(const uint4 (&A)[NS], const unsigned char *r0, const unsigned char *r1, Off off,
-                                          f32x4 &acc0, f32x4 &acc1) {
+__device__ __forceinline__ void load_b(uint4 (&b0)[NS], uint4 (&b1)[NS], const unsigned char *r0, const unsigned char *r1, Off off) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        acc0 = mfma_bf16(A[s], *reinterpret_cast<const uint4 *>(r0 + off(s)), acc0);
-        if (TWO) acc1 = mfma_bf16(A[s], *reinterpret_cast<const uint4 *>(r1 + off(s)), acc1);
+        b0[s] = *reinterpret_cast<const uint4 *>(r0 + off(s));
+        if (TWO) b1[s] = *reinterpret_cast<const uint4 *>(r1 + off(s));
     }
 }
+template <int NS, bool TWO, int A0 = 0, int NA>
+__device__ __forceinline__ void mma_b(const uint4 (&A)[NA], const uint4 (&b0)[NS], const uint4 (&b1)[NS], f32x4 &acc0, f32x4 &acc1) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc0 = mfma_bf16(A[A0 + s], b0[s], acc0);
+        if (TWO) acc1 = mfma_bf16(A[A0 + s], b1[s], acc1);
+    }
+}
+
+// sig_conv3 + seq_conv2 of one or two column tiles: the B fragments of sig_conv3 are all in flight before its first
+// MFMA; those of seq_conv2 are read one per MFMA from then on, so that ~10 reads stay ahead of the matrix pipe
+template <bool TWO>
+__device__ __forceinline__ void s3_pair(const uint4 (&Asig3)[5], const uint4 (&Aseq2)[7], const unsigned char *g0, const unsigned char *g1,
+                                        const unsigned char *q0, const unsigned char *q1, f32x4 &as0, f32x4 &as1, f32x4 &aq0,
+                                        f32x4 &aq1) {
+    uint4 bs0[5], bs1[5], bq0[7], bq1[7];
+    load_b<5, TWO>(bs0, bs1, g0, g1, [](int s) { return 64 * s; });
+    load_b<7, TWO>(bq0, bq1, q0, q1, [](int s) { return 64 * s; });
+    mma_b<5, TWO, 0>(Asig3, bs0, bs1, as0, as1);
+    mma_b<7, TWO, 0>(Aseq2, bq0, bq1, aq0, aq1);
+    // pin the issue order (hipcc otherwise sinks every ds_read next to its MFMA: no read in flight under the MFMAs)
+    constexpr int T = TWO ? 2 : 1;
+    __builtin_amdgcn_sched_group_barrier(0x100, 5 * T, 0);
+#pragma unroll
+    for (int i = 0; i < 7 * T; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 5 * T, 0);
+}
+
+// merge_conv1 of one or two column tiles: the four 32-channel slots of tap t+1 are read while the MFMAs of tap t run
+template <bool TWO>
+__device__ __forceinline__ void s4_pair(const uint4 (&Am1)[20], const unsigned char *r0, const unsigned char *r1, f32x4 &acc0, f32x4 &acc1) {
+    uint4 ba0[4], ba1[4], bb0[4], bb1[4];
+    load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 16 * s; });
+    load_b<4, TWO>(bb0, bb1, r0, r1, [](int s) { return 80 + 16 * s; });
+    mma_b<4, TWO, 0>(Am1, ba0, ba1, acc0, acc1);
+    load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 160 + 16 * s; });
+    mma_b<4, TWO, 4>(Am1, bb0, bb1, acc0, acc1);
+    load_b<4, TWO>(bb0, bb1, r0, r1, [](int s) { return 240 + 16 * s; });
+    mma_b<4, TWO, 8>(Am1, ba0, ba1, acc0, acc1);
+    load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 320 + 16 * s; });
+    mma_b<4, TWO, 12>(Am1, bb0, bb1, acc0, acc1);
+    mma_b<4, TWO, 16>(Am1, ba0, ba1, acc0, acc1);
+    // pin: two taps of reads up front, then one read issued per MFMA, so that a tap's reads are a tap ahead of its MFMAs
+    constexpr int T = TWO ? 2 : 1;
+    __builtin_amdgcn_sched_group_barrier(0x100, 8 * T, 0);
+#pragma unroll
+    for (int i = 0; i < 12 * T; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * T, 0);
+}
+
+// the chunk arrays of one block iteration, one element per thread and array, on their way from HBM to LDS
+struct InRegs {
+    float4 sig;
+    int8_t seq;
+    int16_t map, len;
+};
+
+// which A fragments stay in registers for the lifetime of the block (the rest is re-fetched from L2 per iteration)
+#ifndef RMR_FUSED_RES_SMALL
+#define RMR_FUSED_RES_SMALL 0  // sig_conv2 + seq_conv1 (32 VGPRs)
+#endif
+#ifndef RMR_FUSED_RES_MID
+#define RMR_FUSED_RES_MID 0    // sig_conv3 + seq_conv2 (48 VGPRs)
+#endif
 
 template <int K>
 __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
@@ -92,17 +180,38 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
     constexpr int CG = (4 * K + 7) / 8;                // 8-channel groups of a one-hot row
     constexpr int KS_SEQ1 = (5 * CG * 8 + 31) / 32;    // k-steps of seq_conv1
     constexpr int KS_SIG3 = 5, KS_SEQ2 = 7, KS_M1 = 20;
+    static_assert(K <= 10, "base codes of a k-mer are packed 3 bits each into 32 bits");
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
 
-    // ---- register-resident A fragments and biases of every layer ----
-    uint4 Asig3[KS_SIG3], Aseq2[KS_SEQ2], Am1[KS_M1];
+    // ---- register-resident A fragments of merge_conv1 (80 VGPRs); the other layers' fragments (L2-resident, 60 KB in
+    //      all) are fetched where their stage begins, so that each stage has room for its B fragments in flight ----
+    // fragment loads go through buffer descriptors: wave-uniform base + scalar fragment offset + ONE per-lane offset
+    // VGPR (lane * 16), instead of one 64-bit address VGPR pair per fragment that the compiler hoists and spills
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int lane16 = lane * 16;
+    auto frag = [&](const uint4 *base, int nfrag, int idx) -> uint4 {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(base), 0, nfrag * 1024, 0x00020000);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, idx * 1024, 0);
+        return __builtin_bit_cast(uint4, v);
+    };
+    uint4 Am1[KS_M1];
 #pragma unroll
-    for (int s = 0; s < KS_SIG3; ++s) Asig3[s] = a.a_sig3[(w * KS_SIG3 + s) * 64 + lane];
+    for (int s = 0; s < KS_M1; ++s) Am1[s] = frag(a.a_merge1, 4 * KS_M1, wu * KS_M1 + s);
+    uint4 Asig2, Aseq1[KS_SEQ1], Asig3[KS_SIG3], Aseq2[KS_SEQ2];
+    auto load_small = [&]() {
+        Asig2 = frag(a.a_sig2, 1, 0);
 #pragma unroll
-    for (int s = 0; s < KS_SEQ2; ++s) Aseq2[s] = a.a_seq2[(w * KS_SEQ2 + s) * 64 + lane];
+        for (int s = 0; s < KS_SEQ1; ++s) Aseq1[s] = frag(a.a_seq1, KS_SEQ1, s);
+    };
+    auto load_mid = [&]() {
 #pragma unroll
-    for (int s = 0; s < KS_M1; ++s) Am1[s] = a.a_merge1[(w * KS_M1 + s) * 64 + lane];
+        for (int s = 0; s < KS_SIG3; ++s) Asig3[s] = frag(a.a_sig3, 4 * KS_SIG3, wu * KS_SIG3 + s);
+#pragma unroll
+        for (int s = 0; s < KS_SEQ2; ++s) Aseq2[s] = frag(a.a_seq2, 4 * KS_SEQ2, wu * KS_SEQ2 + s);
+    };
+    if (RMR_FUSED_RES_SMALL) load_small();
+    if (RMR_FUSED_RES_MID) load_mid();
     float w1[5][4];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
@@ -114,8 +223,6 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
     int8_t *s_seq = reinterpret_cast<int8_t *>(smem + a.o_seq);
     int16_t *s_map = reinterpret_cast<int16_t *>(smem + a.o_map);
     int16_t *s_len = reinterpret_cast<int16_t *>(smem + a.o_len);
-    int16_t *s_pidx = reinterpret_cast<int16_t *>(smem + a.o_pidx);
-    unsigned *s_code = reinterpret_cast<unsigned *>(smem + a.o_code);
     unsigned char *s_sig1 = smem + a.o_sig1;  // [row][4] bf16, 8 B rows
     unsigned char *s_sig2 = smem + a.o_sig2;  // [row][16] bf16, 32 B rows
     unsigned char *s_seq1 = smem + a.o_seq1;  // [row][16] bf16
@@ -129,35 +236,43 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
     const int pairs_sig2 = (tiles_sig2 + 1) >> 1, pairs_seq1 = (tiles_seq1 + 1) >> 1;
     const int pairs_chunk = pairs_sig2 + pairs_seq1;
     const FastDiv d_pc = FastDiv{pairs_chunk, 1.0f / (float)pairs_chunk};
+    int nsearch = 1;  // bisection steps that cover maxlen + 1 mapping entries
+    while ((1 << nsearch) < a.maxlen + 2) ++nsearch;
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    // S0: each array of the chunks of an iteration is ONE contiguous run in HBM; the launcher keeps every run within
+    // 256 elements (float4 / byte / int16), so a thread carries one element of each from HBM to LDS
+    auto fetch_inputs = [&](int64_t it) -> InRegs {
+        InRegs r;
+        r.sig = make_float4(0.f, 0.f, 0.f, 0.f); r.seq = 0; r.map = 0; r.len = 0;
+        if (it >= n_iters || ABL(1)) return r;
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        if (tid < ((nch * a.L) >> 2)) r.sig = reinterpret_cast<const float4 *>(a.signal + (size_t)chunk0 * a.L)[tid];
+        if (tid < nch * a.seq_w) r.seq = a.seqs[(size_t)chunk0 * a.seq_w + tid];
+        if (tid < nch * a.map_w) r.map = a.maps[(size_t)chunk0 * a.map_w + tid];
+        if (tid < nch) r.len = a.lens[chunk0 + tid];
+        return r;
+    };
+    auto store_inputs = [&](const InRegs &r) {
+        reinterpret_cast<float4 *>(s_sig)[tid] = r.sig;  // the regions are 256 elements wide (launcher)
+        s_seq[tid] = r.seq;
+        s_map[tid] = r.map;
+        if (tid < a.cb) s_len[tid] = (int16_t)(r.len < 0 ? 0 : (r.len > a.maxlen ? a.maxlen : r.len));
+    };
+    __syncthreads();  // the zero fill is done before the first inputs land
+    store_inputs(fetch_inputs(blockIdx.x));
+
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
-        __syncthreads();  // merge_conv1 of the previous iteration has read CAT (the one-hot planes alias it)
+        __syncthreads();  // inputs of this iteration are in LDS; merge_conv1 of the previous one has read CAT (OH aliases it)
         // A fragments of the two M = 16 layers: fetched (L2-resident, 8 KB) at the top of every iteration and dead
         // after S2, so that they do not occupy 32 VGPRs while merge_conv1 runs
-        const uint4 Asig2 = a.a_sig2[lane];
-        uint4 Aseq1[KS_SEQ1];
-#pragma unroll
-        for (int s = 0; s < KS_SEQ1; ++s) Aseq1[s] = a.a_seq1[s * 64 + lane];
-        // ---- S0: chunk arrays -> LDS (each array of the nch chunks is one contiguous run in HBM) ----
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(a.signal + (size_t)chunk0 * a.L);
-            const int n4 = (nch * a.L) >> 2;  // L % 4 == 0 (checked by the launcher)
-            for (int i = tid; i < n4; i += 256) reinterpret_cast<float4 *>(s_sig)[i] = src[i];
-            const int8_t *sq = a.seqs + (size_t)chunk0 * a.seq_w;
-            for (int i = tid; i < nch * a.seq_w; i += 256) s_seq[i] = sq[i];
-            const int16_t *mp = a.maps + (size_t)chunk0 * a.map_w;
-            for (int i = tid; i < nch * a.map_w; i += 256) s_map[i] = mp[i];
-            if (tid < nch) {
-                int len = a.lens[chunk0 + tid];
-                s_len[tid] = (int16_t)(len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len));
-            }
-        }
-        __syncthreads();
-        // ---- S1a: sig_conv1 (VALU, fp32) -> SIG1;  covering base of every signal position;  base codes ----
-        for (int i = tid; i < nch * a.P1; i += 256) {
+        if (!RMR_FUSED_RES_SMALL) load_small();
+        // ---- S1: sig_conv1 (VALU, fp32) -> SIG1;  k-mer one-hot rows -> OH ----
+        const int n_s1a = ABL(2) ? 0 : nch;
+        for (int i = tid; i < n_s1a * a.P1; i += 256) {
             const int ci = fdiv(i, a.d_P1), pos = i - ci * a.P1;
             const float *xs = s_sig + ci * a.L + pos;
             float4 acc = b1;
@@ -168,16 +283,17 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
                 acc.z = fmaf(w1[t][2], xv, acc.z); acc.w = fmaf(w1[t][3], xv, acc.w);
             }
             const f32x4 v = {acc.x, acc.y, acc.z, acc.w};
-            *reinterpret_cast<uint2 *>(s_sig1 + (size_t)i * 8) = swish_pack(v);
+            *reinterpret_cast<uint2 *>(s_sig1 + (size_t)i * 8) = swish_pack(v, ABL(64));
         }
-        for (int i = tid; i < nch * a.L; i += 256) {
-            const int ci = fdiv(i, a.d_L), s = i - ci * a.L;
+        // one thread per signal position: the base p that covers it (the gather form of the reference's scatter loops:
+        // p = #{mapping entries map[0..len] <= s} - 1, valid when 0 <= p < len), the K bases p..p+K-1 as 3-bit codes
+        // (4 = missing), and the row of CG 16-byte pieces (bf16 1.0 = 0x3F80; piece cg = k-mer slots 2cg, 2cg+1)
+        for (int row = tid; row < (ABL(4) ? 0 : nch) * a.L; row += 256) {
+            const int ci = fdiv(row, a.d_L), s = row - ci * a.L;
             const int16_t *mp = s_map + ci * a.map_w;
             const int len = s_len[ci];
-            // p = (number of mapping entries map[0..len] that are <= s) - 1: the base whose [map[p], map[p+1]) holds s
             int lo = 0, hi = len + 1;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < nsearch; ++k) {
                 const int mid = (lo + hi) >> 1;
                 const bool go = lo < hi;
                 const bool le = go && (int)mp[go ? mid : 0] <= s;
@@ -185,90 +301,85 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
                 hi = (go && !le) ? mid : hi;
             }
             const int p = lo - 1;
-            s_pidx[i] = (int16_t)((p >= 0 && p < len) ? p : -1);
-        }
-        for (int i = tid; i < nch * a.maxlen; i += 256) {
-            const int ci = fdiv(i, a.d_maxlen), p = i - ci * a.maxlen;
+            const bool valid = p >= 0 && p < len;
+            const int8_t *sq = s_seq + ci * a.seq_w + (valid ? p : 0);
             unsigned code = 0;
-            if (p < s_len[ci]) {
-                const int8_t *sq = s_seq + ci * a.seq_w + p;
 #pragma unroll
-                for (int kp = 0; kp < K; ++kp) {
-                    const int b = sq[kp];
-                    code |= (unsigned)((b >= 0 && b < 4) ? b : 4) << (3 * kp);
-                }
+            for (int kp = 0; kp < K; ++kp) {
+                const int b = sq[kp];
+                code |= (unsigned)((valid && b >= 0 && b < 4) ? b : 4) << (3 * kp);
             }
-            s_code[i] = code;
-        }
-        __syncthreads();
-        // ---- S1b: one-hot rows (bf16 1.0 = 0x3F80), 16 bytes = 8 channels = k-mer slots 2cg, 2cg+1 ----
-        for (int i = tid; i < nch * a.L * CG; i += 256) {
-            const int row = i / CG, cg = i - row * CG;  // CG is a compile-time constant
-            const int ci = fdiv(row, a.d_L);
-            const int p = s_pidx[row];
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p >= 0) {
-                const unsigned code = s_code[ci * a.maxlen + p];
-                const int kp0 = 2 * cg, kp1 = 2 * cg + 1;
-                const unsigned b0 = (code >> (3 * kp0)) & 7u;
-                const unsigned b1c = kp1 < K ? ((code >> (3 * kp1)) & 7u) : 4u;
+            unsigned char *dst = s_oh + (size_t)row * 16;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+                const unsigned b0 = (code >> (6 * cg)) & 7u;
+                const unsigned b1c = 2 * cg + 1 < K ? ((code >> (6 * cg + 3)) & 7u) : 4u;
                 const unsigned one0 = 0x3F80u << ((b0 & 1u) * 16), one1 = 0x3F80u << ((b1c & 1u) * 16);
+                uint4 v;
                 v.x = (b0 >> 1) == 0 ? one0 : 0u;
                 v.y = (b0 >> 1) == 1 ? one0 : 0u;
                 v.z = (b1c >> 1) == 0 ? one1 : 0u;
                 v.w = (b1c >> 1) == 1 ? one1 : 0u;
+                *reinterpret_cast<uint4 *>(dst + (size_t)cg * a.oh_plane) = v;
             }
-            *reinterpret_cast<uint4 *>(s_oh + (size_t)cg * a.oh_plane + (size_t)row * 16) = v;
         }
         __syncthreads();
         // ---- S2: sig_conv2 and seq_conv1 (M = 16): the waves split the column-tile pairs ----
-        // (biases are fetched per stage: L1-resident, and not worth 20 VGPRs for the whole block lifetime)
-        const f32x4 b_sig2 = *reinterpret_cast<const f32x4 *>(a.b_sig2 + 4 * q);
-        const f32x4 b_seq1 = *reinterpret_cast<const f32x4 *>(a.b_seq1 + 4 * q);
-        // one-hot operand of seq_conv1: 8-group k8 = 4 s + q of k-step s sits at tap k8 / CG, channel group k8 % CG
-        int oh_off[KS_SEQ1];
+        {
+            // (biases are fetched per stage: L1-resident, and not worth 20 VGPRs for the whole block lifetime)
+            const f32x4 b_sig2 = *reinterpret_cast<const f32x4 *>(a.b_sig2 + 4 * q);
+            const f32x4 b_seq1 = *reinterpret_cast<const f32x4 *>(a.b_seq1 + 4 * q);
+            // one-hot operand of seq_conv1: 8-group k8 = 4 s + q of k-step s sits at tap k8 / CG, channel group k8 % CG
+            int oh_off[KS_SEQ1];
 #pragma unroll
-        for (int s = 0; s < KS_SEQ1; ++s) {
-            const int k8 = 4 * s + q, tap = k8 / CG, cg = k8 - tap * CG;
-            oh_off[s] = cg * a.oh_plane + tap * 16;
-        }
-        for (int item = w; item < nch * pairs_chunk; item += 4) {
-            const int ci = fdiv(item, d_pc), r = item - ci * pairs_chunk;
-            if (r < pairs_sig2) {
-                int pos0 = 32 * r + nn, pos1 = pos0 + 16;
-                const bool v0 = pos0 < a.P2, v1 = pos1 < a.P2;
-                pos0 = v0 ? pos0 : a.P2 - 1;
-                pos1 = v1 ? pos1 : a.P2 - 1;
-                const unsigned char *r0 = s_sig1 + (size_t)(ci * a.P1 + pos0) * 8 + 16 * q;
-                const unsigned char *r1 = s_sig1 + (size_t)(ci * a.P1 + pos1) * 8 + 16 * q;
-                const uint2 x00 = *reinterpret_cast<const uint2 *>(r0), x01 = *reinterpret_cast<const uint2 *>(r0 + 8);
-                const uint2 x10 = *reinterpret_cast<const uint2 *>(r1), x11 = *reinterpret_cast<const uint2 *>(r1 + 8);
-                const f32x4 acc0 = mfma_bf16(Asig2, make_uint4(x00.x, x00.y, x01.x, x01.y), b_sig2);
-                const f32x4 acc1 = mfma_bf16(Asig2, make_uint4(x10.x, x10.y, x11.x, x11.y), b_sig2);
-                if (v0) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos0) * 32 + 8 * q) = swish_pack(acc0);
-                if (v1) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos1) * 32 + 8 * q) = swish_pack(acc1);
-            } else {
-                int pos0 = 32 * (r - pairs_sig2) + nn, pos1 = pos0 + 16;
-                const bool v0 = pos0 < a.P1, v1 = pos1 < a.P1;
-                pos0 = v0 ? pos0 : a.P1 - 1;
-                pos1 = v1 ? pos1 : a.P1 - 1;
-                const unsigned char *r0 = s_oh + (size_t)(ci * a.L + pos0) * 16;
-                const unsigned char *r1 = s_oh + (size_t)(ci * a.L + pos1) * 16;
-                f32x4 acc0 = b_seq1, acc1 = b_seq1;
+            for (int s = 0; s < KS_SEQ1; ++s) {
+                const int k8 = 4 * s + q, tap = k8 / CG, cg = k8 - tap * CG;
+                oh_off[s] = cg * a.oh_plane + tap * 16;
+            }
+            for (int item = w; item < (ABL(8) ? 0 : nch) * pairs_chunk; item += 4) {
+                const int ci = fdiv(item, d_pc), r = item - ci * pairs_chunk;
+                if (r < pairs_sig2) {
+                    int pos0 = 32 * r + nn, pos1 = pos0 + 16;
+                    const bool v0 = pos0 < a.P2, v1 = pos1 < a.P2;
+                    pos0 = v0 ? pos0 : a.P2 - 1;
+                    pos1 = v1 ? pos1 : a.P2 - 1;
+                    const unsigned char *r0 = s_sig1 + (size_t)(ci * a.P1 + pos0) * 8 + 16 * q;
+                    const unsigned char *r1 = s_sig1 + (size_t)(ci * a.P1 + pos1) * 8 + 16 * q;
+                    const uint2 x00 = *reinterpret_cast<const uint2 *>(r0), x01 = *reinterpret_cast<const uint2 *>(r0 + 8);
+                    const uint2 x10 = *reinterpret_cast<const uint2 *>(r1), x11 = *reinterpret_cast<const uint2 *>(r1 + 8);
+                    const f32x4 acc0 = mfma_bf16(Asig2, make_uint4(x00.x, x00.y, x01.x, x01.y), b_sig2);
+                    const f32x4 acc1 = mfma_bf16(Asig2, make_uint4(x10.x, x10.y, x11.x, x11.y), b_sig2);
+                    if (v0) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos0) * 32 + 8 * q) = swish_pack(acc0, ABL(64));
+                    if (v1) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos1) * 32 + 8 * q) = swish_pack(acc1, ABL(64));
+                } else {
+                    int pos0 = 32 * (r - pairs_sig2) + nn, pos1 = pos0 + 16;
+                    const bool v0 = pos0 < a.P1, v1 = pos1 < a.P1;
+                    pos0 = v0 ? pos0 : a.P1 - 1;
+                    pos1 = v1 ? pos1 : a.P1 - 1;
+                    const unsigned char *r0 = s_oh + (size_t)(ci * a.L + pos0) * 16;
+                    const unsigned char *r1 = s_oh + (size_t)(ci * a.L + pos1) * 16;
+                    f32x4 acc0 = b_seq1, acc1 = b_seq1;
+                    uint4 b0[KS_SEQ1], b1v[KS_SEQ1];  // all 14 B reads in flight before the first MFMA
 #pragma unroll
-                for (int s = 0; s < KS_SEQ1; ++s) {
-                    acc0 = mfma_bf16(Aseq1[s], *reinterpret_cast<const uint4 *>(r0 + oh_off[s]), acc0);
-                    acc1 = mfma_bf16(Aseq1[s], *reinterpret_cast<const uint4 *>(r1 + oh_off[s]), acc1);
+                    for (int s = 0; s < KS_SEQ1; ++s) {
+                        b0[s] = *reinterpret_cast<const uint4 *>(r0 + oh_off[s]);
+                        b1v[s] = *reinterpret_cast<const uint4 *>(r1 + oh_off[s]);
+                    }
+                    mma_b<KS_SEQ1, true, 0>(Aseq1, b0, b1v, acc0, acc1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS_SEQ1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * KS_SEQ1, 0);
+                    if (v0) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos0) * 32 + 8 * q) = swish_pack(acc0, ABL(64));
+                    if (v1) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos1) * 32 + 8 * q) = swish_pack(acc1, ABL(64));
                 }
-                if (v0) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos0) * 32 + 8 * q) = swish_pack(acc0);
-                if (v1) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos1) * 32 + 8 * q) = swish_pack(acc1);
             }
         }
+        // A fragments of sig_conv3 / seq_conv2 (this wave's 16 output channels): on their way while the block gathers
+        if (!RMR_FUSED_RES_MID) load_mid();
         __syncthreads();
         // ---- S3: sig_conv3 and seq_conv2 (stride 3, M = 64: wave w = channels 16w..16w+15) -> CAT ----
         {
             const int ncols = nch * a.P3;
-            const int ntiles = (ncols + 15) >> 4;
+            const int ntiles = ABL(16) ? 0 : (ncols + 15) >> 4;
             const f32x4 b_sig3 = *reinterpret_cast<const f32x4 *>(a.b_sig3 + 16 * w + 4 * q);
             const f32x4 b_seq2 = *reinterpret_cast<const f32x4 *>(a.b_seq2 + 16 * w + 4 * q);
             // CAT position of this lane's 4 output channels c0 = 16w + 4q (+64 for the sequence half):
@@ -281,35 +392,34 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
                 col1 = v1 ? col1 : ncols - 1;
                 const int ch0 = fdiv(col0, a.d_P3), ch1 = fdiv(col1, a.d_P3);
                 const int p0 = col0 - ch0 * a.P3, p1 = col1 - ch1 * a.P3;
-                const bool two = tile + 1 < ntiles;  // wave-uniform
-                {
-                    const unsigned char *r0 = s_sig2 + (size_t)(ch0 * a.P2 + 3 * p0) * 32 + 16 * q;
-                    const unsigned char *r1 = s_sig2 + (size_t)(ch1 * a.P2 + 3 * p1) * 32 + 16 * q;
-                    f32x4 acc0 = b_sig3, acc1 = b_sig3;
-                    auto off = [](int s) { return 64 * s; };
-                    if (two) gemm_cols<KS_SIG3, true>(Asig3, r0, r1, off, acc0, acc1);
-                    else gemm_cols<KS_SIG3, false>(Asig3, r0, r1, off, acc0, acc1);
-                    if (v0) *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80) = swish_pack(acc0);
-                    if (v1) *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80) = swish_pack(acc1);
+                const unsigned char *g0 = s_sig2 + (size_t)(ch0 * a.P2 + 3 * p0) * 32 + 16 * q;
+                const unsigned char *g1 = s_sig2 + (size_t)(ch1 * a.P2 + 3 * p1) * 32 + 16 * q;
+                const unsigned char *q0 = s_seq1 + (size_t)(ch0 * a.P1 + 3 * p0) * 32 + 16 * q;
+                const unsigned char *q1 = s_seq1 + (size_t)(ch1 * a.P1 + 3 * p1) * 32 + 16 * q;
+                f32x4 as0 = b_sig3, as1 = b_sig3, aq0 = b_seq2, aq1 = b_seq2;
+                if (tile + 1 < ntiles) s3_pair<true>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);  // wave-uniform
+                else s3_pair<false>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);
+                if (v0) {
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80) = swish_pack(as0, ABL(64));
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80 + 32) = swish_pack(aq0, ABL(64));
                 }
-                {
-                    const unsigned char *r0 = s_seq1 + (size_t)(ch0 * a.P1 + 3 * p0) * 32 + 16 * q;
-                    const unsigned char *r1 = s_seq1 + (size_t)(ch1 * a.P1 + 3 * p1) * 32 + 16 * q;
-                    f32x4 acc0 = b_seq2, acc1 = b_seq2;
-                    auto off = [](int s) { return 64 * s; };
-                    if (two) gemm_cols<KS_SEQ2, true>(Aseq2, r0, r1, off, acc0, acc1);
-                    else gemm_cols<KS_SEQ2, false>(Aseq2, r0, r1, off, acc0, acc1);
-                    if (v0) *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80 + 32) = swish_pack(acc0);
-                    if (v1) *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80 + 32) = swish_pack(acc1);
+                if (v1) {
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80) = swish_pack(as1, ABL(64));
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80 + 32) = swish_pack(aq1, ABL(64));
                 }
             }
         }
+        // the chunk arrays of the block's next iteration leave HBM now and land in LDS after merge_conv1 (their LDS
+        // regions were last read in S1)
+        // (vmcnt retires in order: the bias of S4 is requested BEFORE the prefetch so that waiting for it does not wait
+        //  for the prefetch)
+        const f32x4 b_m1 = *reinterpret_cast<const f32x4 *>(a.b_merge1 + 16 * w + 4 * q);
+        const InRegs next_in = fetch_inputs(it + gridDim.x);
         __syncthreads();
         // ---- S4: merge_conv1 (K = 5 taps x 128 channels) -> x, bf16 channel-last in HBM ----
         {
             const int ncols = nch * a.T;
-            const int ntiles = (ncols + 15) >> 4;
-            const f32x4 b_m1 = *reinterpret_cast<const f32x4 *>(a.b_merge1 + 16 * w + 4 * q);
+            const int ntiles = ABL(32) ? 0 : (ncols + 15) >> 4;
             uint16_t *xo = a.x + (size_t)chunk0 * a.T * 64 + 16 * w + 4 * q;
             const unsigned char *cat_r = s_cat + (size_t)q * a.cat_plane;
             for (int tile = 0; tile < ntiles; tile += 2) {
@@ -320,15 +430,14 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
                 const int ch0 = fdiv(col0, a.d_T), ch1 = fdiv(col1, a.d_T);
                 const unsigned char *r0 = cat_r + (size_t)(ch0 * a.P3 + (col0 - ch0 * a.T)) * 80;
                 const unsigned char *r1 = cat_r + (size_t)(ch1 * a.P3 + (col1 - ch1 * a.T)) * 80;
-                const bool two = tile + 1 < ntiles;
                 f32x4 acc0 = b_m1, acc1 = b_m1;
-                auto off = [](int s) { return (s >> 2) * 80 + (s & 3) * 16; };  // tap row, 32-channel slot
-                if (two) gemm_cols<KS_M1, true>(Am1, r0, r1, off, acc0, acc1);
-                else gemm_cols<KS_M1, false>(Am1, r0, r1, off, acc0, acc1);
-                if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack(acc0);
-                if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack(acc1);
+                if (tile + 1 < ntiles) s4_pair<true>(Am1, r0, r1, acc0, acc1);  // wave-uniform
+                else s4_pair<false>(Am1, r0, r1, acc0, acc1);
+                if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack(acc0, ABL(64), 0.6931471805599453f);
+                if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack(acc1, ABL(64), 0.6931471805599453f);
             }
         }
+        store_inputs(next_in);
     }
 }
 
@@ -353,23 +462,23 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     a.a_sig2 = reinterpret_cast<const uint4 *>(m->fused.a_sig2); a.a_seq1 = reinterpret_cast<const uint4 *>(m->fused.a_seq1);
     a.a_sig3 = reinterpret_cast<const uint4 *>(m->fused.a_sig3); a.a_seq2 = reinterpret_cast<const uint4 *>(m->fused.a_seq2);
     a.a_merge1 = reinterpret_cast<const uint4 *>(m->fused.a_merge1);
-    a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1; a.b_sig2 = m->front.b_sig2; a.b_seq1 = m->front.b_seq1;
-    a.b_sig3 = m->sig3.bias; a.b_seq2 = m->seq2.bias; a.b_merge1 = m->merge1.bias;
+    a.w_sig1 = m->fused.w_sig1; a.b_sig1 = m->fused.b_sig1; a.b_sig2 = m->fused.b_sig2; a.b_seq1 = m->fused.b_seq1;
+    a.b_sig3 = m->fused.b_sig3; a.b_seq2 = m->fused.b_seq2; a.b_merge1 = m->fused.b_merge1;
     a.x = x; a.n = n;
     a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.P3 = m->P3; a.T = m->T;
     a.seq_w = seq_w; a.map_w = map_w; a.maxlen = map_w - 1;
     auto up16 = [](int b) { return (b + 15) & ~15; };
-    // chunks per block iteration: the largest count whose LDS image leaves room for two blocks per CU
+    // chunks per block iteration: the largest count whose LDS image leaves room for two blocks per CU and whose
+    // input runs fit one element per thread (S0)
     const int budget = tune_int("RMR_FUSED_LDS_BUDGET", 80 * 1024);
     int cb = tune_int("RMR_FUSED_CB", 8), total = 0;
     for (; cb >= 1; --cb) {
+        if (cb * a.L > 1024 || cb * seq_w > 256 || cb * map_w > 256) continue;
         int off = 0;
-        a.o_sig = off; off += up16(cb * a.L * 4);
-        a.o_seq = off; off += up16(cb * seq_w);
-        a.o_map = off; off += up16(cb * map_w * 2);
-        a.o_len = off; off += up16(cb * 2);
-        a.o_pidx = off; off += up16(cb * a.L * 2);
-        a.o_code = off; off += up16(cb * a.maxlen * 4);
+        a.o_sig = off; off += 256 * 16;  // input regions: one element per thread
+        a.o_seq = off; off += 256;
+        a.o_map = off; off += 512;
+        a.o_len = off; off += 16;
         a.o_sig1 = off; off += up16((cb * a.P1 + 8) * 8);
         a.o_sig2 = off; off += (cb * a.P2 + 4) * 32;
         a.o_seq1 = off; off += (cb * a.P1 + 4) * 32;
@@ -382,9 +491,11 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
         if (total <= budget) break;
     }
     if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "fused front: one chunk of %d samples needs %d B of LDS", a.L, total);
+    a.o_pidx = a.o_code = 0;
     a.cb = cb; a.lds_bytes = total;
     a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);
     a.d_maxlen = make_fastdiv(a.maxlen);
+    a.abl = tune_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
     auto kern = fused_front_kernel<9>;
     if (e->device < 64 && !fused_attr_done[e->device]) {
         RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -150,8 +150,12 @@ struct FrontWeights {
 };
 
 // bf16 A fragments of the fused front kernel (k_fused.hip): [oc/16][k-steps][64 lanes] x 16 B, k = tap * C + channel
+// Activations travel scaled by log2(e) inside that kernel: sig_conv1 / seq_conv1 (raw inputs) have weights AND bias
+// scaled, the other layers only the bias.
 struct FusedWeights {
     float *a_sig2 = nullptr, *a_seq1 = nullptr, *a_sig3 = nullptr, *a_seq2 = nullptr, *a_merge1 = nullptr;
+    float *w_sig1 = nullptr, *b_sig1 = nullptr, *b_sig2 = nullptr, *b_seq1 = nullptr, *b_sig3 = nullptr, *b_seq2 = nullptr,
+          *b_merge1 = nullptr;
 };
 
 struct LstmWeights {
