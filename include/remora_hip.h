@@ -274,6 +274,23 @@ int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int 
 int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
                      int64_t *counts, int mem);
 
+/* ---- (e) multi-GPU: the ONE collective of the path, RCCL over xGMI called from the library ------- */
+/* replaces, in distributed form: the per-label tally of a run summed over the workers —
+ * validate.compute_metrics' confusion/label tally (src/remora/validate.py:42-45) and get_label_counts
+ * (src/remora/data_chunks.py:1074-1082); the reference itself is single-process.  One process per GPU; chunks /
+ * reads shard embarrassingly, so this int64[num_out] all-reduce(sum) is the only exchange of a job.
+ * Bootstrap as RCCL's own: rank 0 calls rmr_comm_unique_id and hands the 128 bytes to every rank by ANY channel
+ * (file, socket, MPI, torch.distributed ...); every rank then calls rmr_comm_init (collective: all ranks must
+ * call it) with the same id.  librccl is dlopen'ed on first use: a single-GPU caller never needs it.
+ * rmr_allreduce_counts: in place; world 1 (or no communicator) = identity.  RMR_MEM_DEVICE: enqueued on the
+ * engine stream (ordered after the kernels that produced the counts; rmr_engine_synchronize to read them on the
+ * host); RMR_MEM_HOST: staged through the engine, synchronous. */
+#define RMR_COMM_ID_BYTES 128
+int rmr_comm_unique_id(uint8_t id[RMR_COMM_ID_BYTES]);
+int rmr_comm_init(rmr_engine *e, const uint8_t id[RMR_COMM_ID_BYTES], int rank, int world);
+int rmr_comm_destroy(rmr_engine *e);
+int rmr_allreduce_counts(rmr_engine *e, int64_t *counts, int n, int mem);
+
 /* ---- N2: signal-mapping refinement (banded dynamic programming) --------------------------- */
 /* replaces, for a batch of reads, the body of refine_signal_mapping
  * (src/remora/refine_signal_map.py:780-840) as called by SigMapRefiner.refine_sig_map (:472-497):

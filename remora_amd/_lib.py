@@ -78,6 +78,10 @@ SIGNATURES = {
     "rmr_forward": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
     "rmr_infer_chunks": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_int]),
     "rmr_count_labels": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int]),
+    "rmr_comm_unique_id": (c_int, [c_vp]),
+    "rmr_comm_init": (c_int, [c_vp, c_vp, c_int, c_int]),
+    "rmr_comm_destroy": (c_int, [c_vp]),
+    "rmr_allreduce_counts": (c_int, [c_vp, c_vp, c_int, c_int]),
     "rmr_refiner_create": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "rmr_refiner_destroy": (None, [c_vp]),
     "rmr_refine_status_message": (ctypes.c_char_p, [c_int]),

@@ -2,6 +2,8 @@
 // MFMA-fragment packing of the weights, the C ABI entry points and the per-kernel HIP-event
 // profiler.  See include/remora_hip.h for the contract of every entry point and the
 // reference interface (file:line) each one replaces.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -32,6 +34,8 @@ static const char *k_names[K_NUM] = {
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
 
 }  // namespace rmr
+
+namespace rmr { void rccl_comm_free(void *comm); }  // defined with the collective at the end of this file
 
 using namespace rmr;
 
@@ -156,6 +160,10 @@ void rmr_engine_destroy(rmr_engine *e) {
         if (e->ev_front[k]) (void)hipEventDestroy(e->ev_front[k]);
         if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
         if (e->ev_h2d[k]) (void)hipEventDestroy(e->ev_h2d[k]);
+    }
+    if (e->comm) {
+        rmr::rccl_comm_free(e->comm);
+        e->comm = nullptr;
     }
     if (e->pinned) (void)hipHostFree(e->pinned);
     for (auto &r : e->recs) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
@@ -1042,6 +1050,125 @@ int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
     H2D(dc, counts, (size_t)num_out * 8);
     RMR_TRY(launch_count(e, dl, n, num_out, dc));
     D2H(counts, dc, (size_t)num_out * 8);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ---- the one collective: RCCL, loaded on first use (a single-GPU process never touches it) ----------------
+namespace {
+struct NcclId { char internal[RMR_COMM_ID_BYTES]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt64 = 4, kNcclSum = 0;  // rccl.h ncclDataType_t / ncclRedOp_t
+
+int rccl_api(Rccl **out) {
+    static Rccl api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!api.lib) {
+        // the RCCL already in the process (PyTorch-ROCm ships one bound to the HIP runtime this process uses), else ROCm's
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *nm : names)
+            if ((h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
+        for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!h) RMR_FAIL(RMR_ERR_INVALID, "cannot load librccl (%s)", dlerror());
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.GetErrorString)
+            RMR_FAIL(RMR_ERR_INVALID, "librccl lacks an expected symbol");
+        api.lib = h;
+    }
+    *out = &api;
+    return 0;
+}
+#define RMR_NCCL(api, expr)                                                                  \
+    do {                                                                                     \
+        const int _r = (expr);                                                               \
+        if (_r != 0) RMR_FAIL(RMR_ERR_HIP, "RCCL error %s (%s)", (api)->GetErrorString(_r), #expr); \
+    } while (0)
+}  // namespace
+
+}  // extern "C"
+namespace rmr {
+void rccl_comm_free(void *comm) {
+    Rccl *r;
+    if (comm && rccl_api(&r) == 0) (void)r->CommDestroy(comm);
+}
+}  // namespace rmr
+extern "C" {
+
+int rmr_comm_unique_id(uint8_t id[RMR_COMM_ID_BYTES]) {
+    if (!id) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    Rccl *r;
+    RMR_TRY(rccl_api(&r));
+    NcclId u;
+    RMR_NCCL(r, r->GetUniqueId(&u));
+    memcpy(id, u.internal, RMR_COMM_ID_BYTES);
+    return 0;
+}
+
+int rmr_comm_init(rmr_engine *e, const uint8_t id[RMR_COMM_ID_BYTES], int rank, int world) {
+    if (!e || !id) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) RMR_FAIL(RMR_ERR_INVALID, "rank %d / world %d", rank, world);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->comm) RMR_FAIL(RMR_ERR_INVALID, "engine already has a communicator (rmr_comm_destroy first)");
+    Rccl *r;
+    RMR_TRY(rccl_api(&r));
+    RMR_HIP(hipSetDevice(e->device));
+    NcclId u;
+    memcpy(u.internal, id, RMR_COMM_ID_BYTES);
+    void *comm = nullptr;
+    RMR_NCCL(r, r->CommInitRank(&comm, world, u, rank));
+    e->comm = comm;
+    e->comm_rank = rank;
+    e->comm_world = world;
+    return 0;
+}
+
+int rmr_comm_destroy(rmr_engine *e) {
+    if (!e) RMR_FAIL(RMR_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->comm) return 0;
+    Rccl *r;
+    RMR_TRY(rccl_api(&r));
+    RMR_HIP(hipSetDevice(e->device));
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    void *c = e->comm;
+    e->comm = nullptr;
+    e->comm_world = 1;
+    e->comm_rank = 0;
+    RMR_NCCL(r, r->CommDestroy(c));
+    return 0;
+}
+
+int rmr_allreduce_counts(rmr_engine *e, int64_t *counts, int n, int mem) {
+    if (!e || !counts) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n < 1 || n > 4096) RMR_FAIL(RMR_ERR_INVALID, "n %d not in [1,4096]", n);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->comm || e->comm_world == 1) return 0;  // one process: the sum over ranks is the input
+    Rccl *r;
+    RMR_TRY(rccl_api(&r));
+    RMR_HIP(hipSetDevice(e->device));
+    if (mem == RMR_MEM_DEVICE) {
+        RMR_NCCL(r, r->AllReduce(counts, counts, (size_t)n, kNcclInt64, kNcclSum, e->comm, e->stream));
+        return 0;
+    }
+    Stage st{e};
+    RMR_TRY(st.init(Stage::pad((size_t)n * 8) + 1024));
+    int64_t *dc = st.take<int64_t>(n);
+    H2D(dc, counts, (size_t)n * 8);
+    RMR_NCCL(r, r->AllReduce(dc, dc, (size_t)n, kNcclInt64, kNcclSum, e->comm, e->stream));
+    D2H(counts, dc, (size_t)n * 8);
     RMR_HIP(hipStreamSynchronize(e->stream));
     return 0;
 }

@@ -81,6 +81,9 @@ struct rmr_engine {
     int num_cus = 256;
     std::mutex mu;
     int64_t subbatch = 0;
+    // RCCL communicator of rmr_comm_init (opaque ncclComm_t), this rank and the job size
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
 
     // grow-only device scratch arenas
     struct Arena {

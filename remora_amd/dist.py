@@ -73,3 +73,102 @@ def allreduce_max_float(x):
         t = t.cuda()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def allgather_counts(counts):
+    """Per-rank label counts as an int64 numpy array [world, num_out] (rank order) on every rank; one row for a
+    single process.  Used to check the all-reduce: the rows must add up to the reduced counts."""
+    import torch
+    import torch.distributed as dist
+
+    t = counts if hasattr(counts, "is_cuda") else torch.from_numpy(np.ascontiguousarray(counts, np.int64))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t.detach().cpu().numpy()[None, :].copy()
+    if dist.get_backend() == "nccl":
+        t = t.cuda() if not t.is_cuda else t
+    else:
+        t = t.cpu()
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t.contiguous())
+    return torch.stack(out).cpu().numpy()
+
+
+# ---- the C-ABI collective (include/remora_hip.h: rmr_comm_unique_id / rmr_comm_init / rmr_allreduce_counts) -----------
+# RCCL called from inside libremora_hip.so: what a non-torch host (the C/C++ caller of INTEGRATION.md) uses.  The
+# 128-byte unique id travels from rank 0 to the other ranks by whatever channel the job has; here torch.distributed.
+def init_cabi_comm(engine, rank=None, world=None):
+    """Create the library's own RCCL communicator on `engine` (collective over all ranks).  Returns True when a
+    communicator exists afterwards (False for a single process without torch.distributed, where none is needed)."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib as L
+
+    lib = L.lib()
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    ident = (ctypes.c_uint8 * 128)()
+    if rank == 0:
+        L.check(lib.rmr_comm_unique_id(ident))
+    if world > 1:
+        t = torch.tensor(list(ident), dtype=torch.uint8)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+    L.check(lib.rmr_comm_init(engine.handle, ident, int(rank), int(world)))
+    return True
+
+
+def cabi_allreduce_counts(engine, counts):
+    """All-reduce(sum) of an int64 device tensor / numpy array through the library's RCCL communicator, in place."""
+    from . import _lib as L
+
+    lib = L.lib()
+    if isinstance(counts, np.ndarray):
+        assert counts.dtype == np.int64 and counts.flags.c_contiguous
+        L.check(lib.rmr_allreduce_counts(engine.handle, counts.ctypes.data, counts.size, L.MEM_HOST))
+        return counts
+    assert counts.is_cuda and counts.dtype.is_floating_point is False and counts.element_size() == 8
+    L.check(lib.rmr_allreduce_counts(engine.handle, counts.data_ptr(), counts.numel(), L.MEM_DEVICE))
+    engine.synchronize()
+    return counts
+
+
+def cabi_allreduce_check(engine, per_rank, rank, world, timeout_s=60.0):
+    """bench.py's cross-check of the C-ABI collective against torch.distributed's result on the same counts: every rank
+    contributes its own row of `per_rank`; the reduced vector must equal the column sums.  Runs in a worker thread with a
+    deadline (a collective that cannot complete must not hang the bench line); never raises."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1 and (not dist.is_initialized() or dist.get_backend() != "nccl"):
+        return {"status": "skipped", "reason": "ranks do not own distinct GPUs (backend is not nccl)"}
+    res = {}
+
+    def work():
+        try:
+            init_cabi_comm(engine, rank, world)
+            mine = torch.from_numpy(np.ascontiguousarray(per_rank[rank], np.int64)).to(engine.torch_device)
+            cabi_allreduce_counts(engine, mine)
+            got = mine.cpu().numpy()
+            want = np.sum(per_rank, axis=0)
+            res.update(status="ok" if np.array_equal(got, want) else "mismatch", got=[int(x) for x in got], world=world,
+                       via="rmr_comm_unique_id / rmr_comm_init / rmr_allreduce_counts (RCCL inside libremora_hip.so)")
+            from . import _lib as L
+
+            L.check(L.lib().rmr_comm_destroy(engine.handle))
+        except Exception as e:  # noqa: BLE001
+            res.update(status="error", error=f"{type(e).__name__}: {e}")
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"status": "timeout", "timeout_s": timeout_s}
+    return res

@@ -1,0 +1,88 @@
+"""bench.py as a multi-rank program, and the C-ABI collective — on one GPU.
+
+The 8-GPU scaling run belongs to the driver; what can be proven on a 1-GPU box is that (a) `bench.py --gpus 2` launches
+two ranks by itself, shards the data, and its one collective reduces the per-rank label counts exactly (two ranks on
+the same GPU over gloo: the data path is the real one, only the transport of the 16-byte reduction differs), (b) a
+world size that differs from --gpus is refused, (c) rmr_allreduce_counts runs through RCCL (a communicator of one rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ["--steps", "2", "--warmup", "1", "--chunks", "20000", "--no-cpu-baseline", "--no-encode", "--no-reads", "--no-others",
+        "--no-refine"]
+
+
+def _bench(extra, env_extra=None, expect_rc=0):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == expect_rc, (p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return (json.loads(lines[-1]) if lines else None), p
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bench_two_ranks_shard_and_reduce_exactly(dtype):
+    two, _ = _bench(["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--dtype", dtype] + FAST)
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["chunks_per_step_all_gpus"] == 40000
+    assert sum(two["label_counts"]) == 2 * 20000 * 2
+    per_rank = np.asarray(two["label_counts_per_rank"])
+    assert per_rank.shape == (2, 2) and np.array_equal(per_rank.sum(0), two["label_counts"])
+    assert all(int(r.sum()) == 20000 * 2 for r in per_rank)
+    for r in range(2):  # each rank's tally = a single-rank run over that rank's shard of the data
+        one, _ = _bench(["--gpus", "1", "--shard-base", str(r), "--dtype", dtype] + FAST)
+        assert one["n_gpus"] == 1 and one["label_counts"] == [int(x) for x in per_rank[r]], (r, one["label_counts"], per_rank)
+    assert per_rank[0].tolist() != per_rank[1].tolist()  # the ranks really worked on different chunks
+
+
+def test_bench_strong_sharding_partitions_the_same_data_set():
+    """configs[3] shape (bf16, one data set sharded over the ranks) at a small size: the global label tally does not
+    depend on the number of ranks."""
+    args = ["--workload", "convlstm_c100_bf16_10m", "--steps", "1", "--warmup", "1", "--chunks", "30001", "--no-cpu-baseline",
+            "--no-encode", "--no-reads", "--no-others", "--no-refine"]
+    one, _ = _bench(["--gpus", "1"] + args)
+    two, _ = _bench(["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo"] + args)
+    assert one["scaling"] == two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert sum(one["label_counts"]) == 30001 and one["label_counts"] == two["label_counts"]
+    assert [sum(r) for r in two["label_counts_per_rank"]] == [15001, 15000]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    _, p = _bench(["--gpus", "2"] + FAST, env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_rc=2)
+    assert "refusing" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_cabi_allreduce_counts_through_rccl():
+    """rmr_comm_unique_id -> rmr_comm_init (1 rank) -> rmr_allreduce_counts on a device and on a host buffer -> destroy:
+    the library's own RCCL path (dlopen, communicator on the engine's device and stream) end to end; identity for one rank.
+    Before a communicator exists the call is the documented no-op."""
+    import torch
+
+    from remora_amd import dist as rdist
+    from remora_amd import _lib as L
+    from remora_amd.engine import get_engine
+
+    eng = get_engine(0)
+    c = torch.tensor([5, 7, 11], dtype=torch.int64, device="cuda:0")
+    rdist.cabi_allreduce_counts(eng, c)
+    assert c.tolist() == [5, 7, 11]
+    assert rdist.init_cabi_comm(eng, 0, 1)
+    try:
+        rdist.cabi_allreduce_counts(eng, c)
+        assert c.tolist() == [5, 7, 11]
+        h = np.array([1, 2, 3, 4], np.int64)
+        rdist.cabi_allreduce_counts(eng, h)
+        assert h.tolist() == [1, 2, 3, 4]
+        with pytest.raises(Exception, match="already has a communicator"):
+            rdist.init_cabi_comm(eng, 0, 1)
+    finally:
+        L.check(L.lib().rmr_comm_destroy(eng.handle))
+    chk = rdist.cabi_allreduce_check(eng, np.array([[3, 4]], np.int64), 0, 1)
+    assert chk["status"] == "ok" and chk["got"] == [3, 4], chk

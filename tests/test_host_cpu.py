@@ -241,8 +241,10 @@ total = rdist.allreduce_counts(counts.copy())
 t = torch.from_numpy(counts.copy())
 total_t = rdist.allreduce_counts(t)
 mx = rdist.allreduce_max_float(float(rank + 1))
+rows = rdist.allgather_counts(counts)        # what bench.py reports as label_counts_per_rank
 if rank == 0:
-    print(json.dumps({"total": total.tolist(), "total_t": total_t.tolist(), "max": mx, "n": [int(lo), int(hi)]}))
+    print(json.dumps({"total": total.tolist(), "total_t": total_t.tolist(), "max": mx, "n": [int(lo), int(hi)],
+                      "rows": rows.tolist(), "mine": counts.tolist()}))
 torch.distributed.destroy_process_group()
 '''
 
@@ -260,6 +262,8 @@ def test_count_allreduce_gloo_world2(tmp_path):
     g = golden("post_process.npz")
     assert res["total"] == g["tally_pred_counts"].tolist() == res["total_t"]
     assert res["max"] == 2.0 and res["n"] == [0, 500]
+    rows = np.asarray(res["rows"])
+    assert rows.shape == (2, 3) and rows[0].tolist() == res["mine"] and rows.sum(0).tolist() == res["total"]
 
 
 # ---- POD5 / BAM ingest on the reference's own test data (next row N1) ------------------------------
