@@ -400,6 +400,45 @@ int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, double scale, 
     return upload(m, fl, dev);
 }
 
+// LSTM weights for k_lstm_x16.hip (H = 64): 16-row MFMA tiles with UNIT-MAJOR rows — row r of tile (wave wv, t) is
+// (unit 8 wv + 2 (r >> 2) + t, gate r & 3) — as bf16 A fragments [8][2][2 k-steps][64 lanes][4 dwords]; gate rows
+// pre-scaled (lstm1_gate_scale); `skip_f` zeroes the f rows (lstm2: c0 = 0)
+std::vector<float> pack_lstm_x16(const float *w, bool skip_f) {
+    const int H = 64;
+    std::vector<uint32_t> o((size_t)8 * 2 * 2 * 64 * 4);
+    for (int wv = 0; wv < 8; ++wv)
+        for (int t = 0; t < 2; ++t)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int ql = lane >> 4, mm = lane & 15, gate = mm & 3, unit = 8 * wv + 2 * (mm >> 2) + t;
+                    uint32_t b[8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * ks + 8 * ql + j;
+                        const double v = (skip_f && gate == 1) ? 0.0 : (double)w[(size_t)(gate * H + unit) * H + k] * lstm1_gate_scale(gate);
+                        b[j] = rne_bf16(f2u((float)v));
+                    }
+                    for (int i = 0; i < 4; ++i)
+                        o[((((size_t)wv * 2 + t) * 2 + ks) * 64 + lane) * 4 + i] = (b[2 * i] >> 16) | b[2 * i + 1];
+                }
+    std::vector<float> f(o.size());
+    memcpy(f.data(), o.data(), o.size() * 4);
+    return f;
+}
+// matching biases [8][2][4 q][4 gates]: (b_ih + b_hh) of unit 8 wv + 2 q + t, pre-scaled
+std::vector<float> pack_bias_x16(const float *bih, const float *bhh, bool skip_f) {
+    const int H = 64;
+    std::vector<float> o((size_t)8 * 2 * 4 * 4);
+    for (int wv = 0; wv < 8; ++wv)
+        for (int t = 0; t < 2; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int gate = 0; gate < 4; ++gate) {
+                    const int unit = 8 * wv + 2 * q + t;
+                    o[(((size_t)wv * 2 + t) * 4 + q) * 4 + gate] =
+                        (skip_f && gate == 1) ? 0.0f : (float)(((double)bih[gate * H + unit] + (double)bhh[gate * H + unit]) * lstm1_gate_scale(gate));
+                }
+    return o;
+}
+
 // [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
 std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates, bool prescale = false) {
     const int KS = H / 4, G = H / 16, W = H / 16;
@@ -576,6 +615,13 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
             const int rb[4] = {0, H, 2 * H, 3 * H};
             RMR_TRY(upload(m.get(), pack_split_a(si, H, H / 16, rb, 4, m->nparts), &m->lstm.s_ih1));
             RMR_TRY(upload(m.get(), pack_split_a(sh, H, H / 16, rb, 4, m->nparts), &m->lstm.s_hh1));
+        }
+        if (m->nparts == 1 && H == 64) {
+            RMR_TRY(upload(m.get(), pack_lstm_x16(wih1, false), &m->lstm.x_ih));
+            RMR_TRY(upload(m.get(), pack_lstm_x16(whh1, false), &m->lstm.x_hh));
+            RMR_TRY(upload(m.get(), pack_lstm_x16(wih2, true), &m->lstm.x_ih2));
+            RMR_TRY(upload(m.get(), pack_bias_x16(bih1, bhh1, false), &m->lstm.x_b1));
+            RMR_TRY(upload(m.get(), pack_bias_x16(bih2, bhh2, true), &m->lstm.x_b2));
         }
         std::vector<float> b1(4 * H), b2(3 * H);
         for (int i = 0; i < 4 * H; ++i)

@@ -77,7 +77,7 @@ __device__ __forceinline__ void mm_split(const uint4 (&img)[NP][4][16][SL], int 
 }
 
 struct LstmSArgs {
-    const void *x;        // [n][T][H] channel-last: fp32, or bf16 (XB16: output of the fused front kernel)
+    const float *x;       // [n][T][H] fp32, channel-last
     float *logits;        // [n][num_out]
     const uint4 *a_ih, *a_hh;  // [H/16 waves][4 gates][H/32 ks][NP][64 lanes] bf16x8 fragments (pre-scaled)
     const float *b1;           // [4H] pre-scaled b_ih + b_hh
@@ -86,9 +86,8 @@ struct LstmSArgs {
     int T, num_out;
 };
 
-template <int H, int NP, bool XB16>
+template <int H, int NP>
 __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
-    static_assert(!XB16 || NP == 1, "bf16 activations carry one part");
     constexpr int NW = H / 16;
     constexpr int KS32 = H / 32;                 // bf16 k-steps of 32 channels
     constexpr int SL = (KS32 % 2 == 0) ? KS32 + 1 : KS32;  // 16-byte slots per row per plane (odd)
@@ -125,20 +124,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
     const int st_grp = st_c4 >> 1;                 // 8-channel group
     const int st_q = st_grp & 3, st_ks = st_grp >> 2, st_half = st_c4 & 1;
 
-    // x values of one staging role (4 channels): float4, or the 4 bf16 as they are
-    struct XV { float4 f; uint2 h; };
-    auto load_x = [&](const void *base, size_t row) -> XV {  // row = (chunk * T + t)
-        XV v;
-        if (XB16) v.h = *(reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(base) + row * H) + st_c4);
-        else v.f = *(reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + row * H) + st_c4);
-        return v;
-    };
-    auto stage_x = [&](int buf, const XV xv) {
-        if (XB16) {
-            *(reinterpret_cast<uint2 *>(&xs[buf][0][st_q][st_row][st_ks]) + st_half) = xv.h;
-            return;
-        }
-        const float4 v = xv.f;
+    auto stage_x = [&](int buf, const float4 v) {
         unsigned e[4][NP];
         split_parts<NP>(v.x, e[0]); split_parts<NP>(v.y, e[1]);
         split_parts<NP>(v.z, e[2]); split_parts<NP>(v.w, e[3]);
@@ -154,10 +140,10 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         const int64_t chunk0 = grp * 16;
         int64_t st_chunk = chunk0 + st_row;
         if (st_chunk >= a.n) st_chunk = a.n - 1;
-        const size_t xrow = (size_t)st_chunk * a.T;
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.x + (size_t)st_chunk * a.T * H) + st_c4;
         __syncthreads();
-        stage_x(0, load_x(a.x, xrow));
-        stage_x(1, load_x(a.x, xrow + (a.T > 1 ? 1 : 0)));
+        stage_x(0, xsrc[0]);
+        stage_x(1, xsrc[(size_t)(a.T > 1 ? 1 : 0) * (H / 4)]);
         __syncthreads();
 
         // Software pipeline as in k_lstm.hip: accN = b + W_ih x_{t+1} is issued in slices between
@@ -168,7 +154,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         mm_split<KS32, NP, SL>(xs[0], q, nn, Aih, accN);
         for (int t = 0; t < a.T; ++t) {
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
-            const XV xnext = load_x(a.x, xrow + tf);
+            const float4 xnext = xsrc[(size_t)tf * (H / 4)];
             f32x4 acc[4] = {accN[0], accN[1], accN[2], accN[3]};
             bf16x8 bxn[KS32][NP];
 #pragma unroll
@@ -269,8 +255,8 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
     }
 }
 
-template <int H, int NP, bool XB16 = false>
-static int launch_lstm_s_t(rmr_model *m, const void *x, int64_t n, float *logits) {
+template <int H, int NP>
+static int launch_lstm_s_t(rmr_model *m, const float *x, int64_t n, float *logits) {
     rmr_engine *e = m->eng;
     LstmSArgs a;
     a.x = x; a.logits = logits; a.n = n; a.T = m->T; a.num_out = m->desc.num_out;
@@ -281,14 +267,9 @@ static int launch_lstm_s_t(rmr_model *m, const void *x, int64_t n, float *logits
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);
-    hipLaunchKernelGGL((lstm_bf16s_kernel<H, NP, XB16>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    hipLaunchKernelGGL((lstm_bf16s_kernel<H, NP>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
-}
-
-int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logits) {
-    if (m->desc.size != 64 || m->nparts != 1) RMR_FAIL(RMR_ERR_INVALID, "bf16-activation LSTM: size 64, plain bf16 only");
-    return launch_lstm_s_t<64, 1, true>(m, x, n, logits);
 }
 
 int launch_lstm_head_split(rmr_model *m, const float *x, int64_t n, float *logits) {

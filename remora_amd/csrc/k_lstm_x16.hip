@@ -1,0 +1,189 @@
+// k_lstm_x16.hip — lstm1 (T steps) + lstm2 (ONE step) + fc head of ConvLSTM_w_ref (size 64) on the bf16 matrix
+// cores, for the bf16 x tensor the fused front kernel writes (k_fused.hip): x bf16[n][T][64] -> logits f32[n][num_out].
+// Replaces models/ConvLSTM_w_ref.py:51-56 (same algebra as k_lstm.hip: after the two flips z[-1] is the first output of
+// lstm2 on the reversed sequence, i.e. ONE lstm2 step on swish(h1[T-1]) with zero state).
+//
+// The gate non-linearities (5 exp + 5 rcp + ~12 plain VALU per hidden unit, chunk and step) outweigh the matrix work
+// (8 MFMAs per wave and step), and one wave issues at most one VALU instruction per ~4.5 cycles (tools/ubench):
+// the kernel is built for FOUR waves per SIMD so that the VALU pipe always has a second wave to issue from.
+//   block = 8 waves x 16 chunks; wave w owns hidden units 8w..8w+7 as two 16-row MFMA tiles whose rows are
+//   UNIT-MAJOR: row r of tile t = (unit 8w + 2(r>>2) + t, gate r&3).  The D fragment of lane (q, n) is then the four
+//   gates i,f,g,o of ONE unit for ONE chunk: the cell update is lane-local, c stays in a register, and the lane's two
+//   units (tiles 0/1) are neighbours 8w+2q, 8w+2q+1 -> h leaves as ONE packed 4-byte LDS store.
+//   Per wave: 32 VGPRs of A fragments (W_ih, W_hh), ~90 VGPRs in all -> 2 blocks (16 waves) per CU.
+// The input projection of step t+1 (W_ih x_{t+1}, independent of h_t) is issued before the gate math of step t, so only
+// W_hh h_{t-1} (4 MFMAs) sits on the recurrent critical path.  x_{t+2} is fetched from HBM while step t runs.
+// Gate rows of W and b are pre-scaled on the host (i,f,o by -log2 e, g by 2 log2 e): sigmoid(a) = 1/(1+2^a'),
+// tanh(a) = 1 - 2/(1+2^a').  bf16 operands, fp32 accumulation, fp32 cell state.
+#include "rmr_internal.h"
+#include "rmr_math.h"
+
+namespace rmr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct LstmXArgs {
+    const uint16_t *x;     // bf16 [n][T][64]
+    float *logits;         // [n][num_out]
+    const uint4 *a_ih, *a_hh, *a_ih2;  // bf16 A fragments [8 waves][2 tiles][2 k-steps][64 lanes]
+    const float *b1, *b2;  // [8 waves][2 tiles][4 q][4 gates] pre-scaled b_ih + b_hh (lstm2: the f row is unused)
+    const float *w_fc, *b_fc;  // [num_out][64], [num_out]
+    int64_t n;
+    int T, num_out;
+};
+
+__device__ __forceinline__ f32x4 mfma16(const uint4 a, const uint4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc rows are pre-scaled: [0] i, [1] f, [3] o by -log2(e); [2] g by 2 log2(e)
+__device__ __forceinline__ float lstm_cell(const f32x4 acc, float &c) {
+    const float ig = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0]));
+    const float fg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[1]));
+    const float gg = fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[2])), 1.0f);
+    const float og = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[3]));
+    c = fmaf(fg, c, ig * gg);
+    const float tc = fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(c * 2.8853900817779268f)), 1.0f);
+    return og * tc;
+}
+
+__global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
+    // B-operand images (8 bf16 = 16 B per slot): plane p = 8-channel group (channel / 8) % 4, slot = channel / 32,
+    // rows = chunks; 3 slots per row (2 used) keep the 16-lane ds_read_b128 groups on distinct bank slots
+    __shared__ uint4 xs[2][4][16][3];
+    __shared__ uint4 hs[2][4][16][3];
+    __shared__ float part[8][16][16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+
+    uint4 Aih[2][2], Ahh[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Aih[t][ks] = a.a_ih[((w * 2 + t) * 2 + ks) * 64 + lane];
+            Ahh[t][ks] = a.a_hh[((w * 2 + t) * 2 + ks) * 64 + lane];
+        }
+    f32x4 bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4 *>(a.b1 + ((w * 2 + t) * 4 + q) * 4);
+
+    // x staging role (threads 0..127): chunk row = tid >> 3, 8-channel group c8 = tid & 7 -> plane c8 & 3, slot c8 >> 2
+    const bool stager = tid < 128;
+    const int st_row = tid >> 3, st_c8 = tid & 7;
+    // this lane's two hidden units 8w + 2q, 8w + 2q + 1 sit in 8-channel group w: plane w & 3, slot w >> 2, bytes 4q..4q+3
+    const int h_plane = w & 3, h_slot = w >> 2;
+
+    const int64_t n_groups = (a.n + 15) / 16;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t chunk0 = grp * 16;
+        int64_t st_chunk = chunk0 + st_row;
+        if (st_chunk >= a.n) st_chunk = a.n - 1;  // ragged tail: clamp (results masked)
+        const uint4 *xsrc = reinterpret_cast<const uint4 *>(a.x + (size_t)st_chunk * a.T * 64) + st_c8;
+        __syncthreads();  // the previous group's LDS traffic is done
+        if (stager) {
+            xs[0][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[0];
+            xs[1][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[(size_t)(a.T > 1 ? 1 : 0) * 8];
+        }
+        __syncthreads();
+
+        float c[2] = {0.f, 0.f};
+        f32x4 accN[2];  // bias + W_ih x_t of the step about to run
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            accN[t] = bias[t];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) accN[t] = mfma16(Aih[t][ks], xs[0][q][nn][ks], accN[t]);
+        }
+        for (int t = 0; t < a.T; ++t) {
+            const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;  // x_{t+2} (the last two fetches are redundant re-reads)
+            uint4 xnext = make_uint4(0, 0, 0, 0);
+            if (stager) xnext = xsrc[(size_t)tf * 8];
+            f32x4 acc[2] = {accN[0], accN[1]};
+            const uint4 bx0 = xs[(t + 1) & 1][q][nn][0], bx1 = xs[(t + 1) & 1][q][nn][1];
+            if (t > 0) {  // recurrent critical path: W_hh h_{t-1}
+                const uint4 bh0 = hs[(t - 1) & 1][q][nn][0], bh1 = hs[(t - 1) & 1][q][nn][1];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[u] = mfma16(Ahh[u][0], bh0, acc[u]);
+                    acc[u] = mfma16(Ahh[u][1], bh1, acc[u]);
+                }
+            }
+            // input projection of the next step (in the last step it projects a stale, finite tile: dropped)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                accN[u] = mfma16(Aih[u][0], bx0, bias[u]);
+                accN[u] = mfma16(Aih[u][1], bx1, accN[u]);
+            }
+            float h0 = lstm_cell(acc[0], c[0]);
+            float h1 = lstm_cell(acc[1], c[1]);
+            if (t + 1 == a.T) {  // lstm2 consumes swish(h1[T-1]) (models/ConvLSTM_w_ref.py:52)
+                h0 = swish_f(h0);
+                h1 = swish_f(h1);
+            }
+            bf16x2 hp;
+            hp[0] = (__bf16)h0;
+            hp[1] = (__bf16)h1;
+            reinterpret_cast<unsigned *>(&hs[t & 1][h_plane][nn][h_slot])[q] = __builtin_bit_cast(unsigned, hp);
+            if (stager) xs[t & 1][st_c8 & 3][st_row][st_c8 >> 2] = xnext;  // the buffer whose last reader was step t-1
+            __syncthreads();
+        }
+        // ---- lstm2: one step on swish(h1[T-1]) with zero state (the f gate meets c0 = 0) ----
+        f32x4 acc2[2];
+        {
+            const uint4 bh0 = hs[(a.T - 1) & 1][q][nn][0], bh1 = hs[(a.T - 1) & 1][q][nn][1];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc2[u] = *reinterpret_cast<const f32x4 *>(a.b2 + ((w * 2 + u) * 4 + q) * 4);
+                acc2[u] = mfma16(a.a_ih2[((w * 2 + u) * 2 + 0) * 64 + lane], bh0, acc2[u]);
+                acc2[u] = mfma16(a.a_ih2[((w * 2 + u) * 2 + 1) * 64 + lane], bh1, acc2[u]);
+            }
+        }
+        float y[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float c2 = 0.f;
+            y[u] = swish_f(lstm_cell(acc2[u], c2));  // c2 = sig(i) tanh(g); h2 = sig(o) tanh(c2)
+        }
+        // ---- fc: this lane's two hidden units, reduced over q (lanes) then over the 8 waves (LDS) ----
+        const int u0 = 8 * w + 2 * q;
+        for (int o = 0; o < a.num_out; ++o) {
+            float p = a.w_fc[(size_t)o * 64 + u0] * y[0] + a.w_fc[(size_t)o * 64 + u0 + 1] * y[1];
+            p += __shfl_xor(p, 16);
+            p += __shfl_xor(p, 32);
+            if (q == 0) part[w][nn][o] = p;
+        }
+        __syncthreads();
+        if (tid < 16 * a.num_out) {
+            const int ch = tid / a.num_out, o = tid - ch * a.num_out;
+            if (chunk0 + ch < a.n) {
+                float s = a.b_fc[o];
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) s += part[ww][ch][o];
+                a.logits[(size_t)(chunk0 + ch) * a.num_out + o] = s;
+            }
+        }
+    }
+}
+
+int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logits) {
+    rmr_engine *e = m->eng;
+    if (m->desc.size != 64 || m->nparts != 1 || !m->lstm.x_ih) RMR_FAIL(RMR_ERR_INVALID, "bf16-activation LSTM: size 64, plain bf16 only");
+    if (n <= 0) return 0;
+    LstmXArgs a;
+    a.x = x; a.logits = logits; a.n = n; a.T = m->T; a.num_out = m->desc.num_out;
+    a.a_ih = reinterpret_cast<const uint4 *>(m->lstm.x_ih); a.a_hh = reinterpret_cast<const uint4 *>(m->lstm.x_hh);
+    a.a_ih2 = reinterpret_cast<const uint4 *>(m->lstm.x_ih2);
+    a.b1 = m->lstm.x_b1; a.b2 = m->lstm.x_b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
+    const int64_t groups = (n + 15) / 16;
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTMX_BLOCKS_PER_CU", 4);
+    if (grid > groups) grid = groups;
+    ProfScope ps(e, K_LSTM_HEAD);
+    hipLaunchKernelGGL(lstm_x16_kernel, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rmr

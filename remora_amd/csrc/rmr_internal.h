@@ -169,6 +169,9 @@ struct LstmWeights {
     float *w_fc = nullptr, *b_fc = nullptr;    // [num_out][H], [num_out]
     // split-bf16 fragments (dtype != 0): [H/16][4 gates][H/32][nparts][64 lanes] x 16 B
     float *s_ih1 = nullptr, *s_hh1 = nullptr;
+    // k_lstm_x16.hip (plain bf16, size 64): unit-major tiles [8 waves][2 tiles][2 k-steps][64 lanes] x 16 B, biases
+    // [8][2][4 q][4 gates]; lstm2 with a zero f row
+    float *x_ih = nullptr, *x_hh = nullptr, *x_ih2 = nullptr, *x_b1 = nullptr, *x_b2 = nullptr;
 };
 
 }  // namespace rmr
