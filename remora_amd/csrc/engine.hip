@@ -675,7 +675,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     if (!enc && fused_front_supported(m, seq_w, map_w) && tune_int("RMR_FUSED", 1)) {
         // plain-bf16 ConvLSTM: two launches per sub-batch, x (bf16, 3 KB/chunk @C100) is the only intermediate in
         // HBM; sub-batches are sized so that x stays in the 256 MiB Infinity Cache between producer and consumer
-        int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_FUSED_SUBBATCH", 32768);
+        int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_FUSED_SUBBATCH", 65536);
         if (sb > n) sb = n;
         const size_t x_elems = (size_t)m->T * m->desc.size;
         RMR_TRY(e->ensure(e->act, x_elems * sb * sizeof(uint16_t)));

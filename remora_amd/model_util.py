@@ -95,8 +95,12 @@ def load_model(model_filename=None, *, pore=None, basecall_model_type=None, base
             raise RemoraError("Failed loading torchscript model.")
     if pore is None:
         raise RemoraError("Must specify a pore.")
-    raise RemoraError("pretrained-model lookup/download is outside the hot path: pass model_filename "
-                      "(a TorchScript .pt with meta.txt, e.g. one fetched with `remora model download`)")
+    raise RemoraError(
+        f"load_model(pore={pore!r}, basecall_model_type={basecall_model_type!r}, ..., modified_bases={modified_bases!r}): the "
+        "reference resolves these through its pretrained-model registry and downloads the file "
+        "(remora.model_util.load_model, src/remora/model_util.py:592-699 -> get_pretrained_models / ModelDownload); that "
+        "registry is outside this engine's scope - pass model_filename= (the TorchScript .pt with meta.txt that "
+        "`remora model download` or the reference's load_model caches under its models directory)")
 
 
 def model_from_state(state, model_metadata, device=None, engine=None, dtype="fp32"):

@@ -507,20 +507,34 @@ def test_split_bf16_rejects_unsupported(torch_cuda, O):
 
 
 # ---- BASELINE configs[0] shape: the reference's own POD5 + BAM test data end to end ------------------
-def test_real_reads_pod5_bam_end_to_end(torch_cuda, O, tmp_path):
-    """tests/data/can_reads.pod5 + can_mappings.bam (copied under tests/golden/data) ->
-    remora_amd.io ingest -> Read.add_alignment -> into_remora_read -> call_read_mods, against the
+def _real_reads_golden(prefix):
+    """Per-read results of the reference on tests/data/<prefix>_reads.pod5 + <prefix>_mappings.bam; the CG 5mC model's
+    weights travel once, in the `can` file (tools/gen_golden.py: the same network calls both halves of configs[0])."""
+    class G(dict):
+        files = property(lambda self: list(self.keys()))
+
+    g = G(golden(f"real_reads_{prefix}.npz"))
+    if prefix != "can":
+        w = golden("real_reads_can.npz")
+        g.update({k: w[k] for k in w.files if k.startswith("w__")})
+    return g
+
+
+@pytest.mark.parametrize("prefix,n_chunks", [("can", 922), ("mod", 1264)])
+def test_real_reads_pod5_bam_end_to_end(torch_cuda, O, tmp_path, prefix, n_chunks):
+    """BASELINE configs[0], both halves: tests/data/{can,mod}_reads.pod5 + {can,mod}_mappings.bam (copied under
+    tests/golden/data) -> remora_amd.io ingest -> Read.add_alignment -> into_remora_read -> call_read_mods, against the
     reference's own Read / call_read_mods run on the same parsed records (tools/gen_golden.py)."""
     from remora_amd import io as rio
     from remora_amd.inference import call_read_mods
     from remora_amd.model_util import load_model
 
     data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
-    g = golden("real_reads_can.npz")
+    g = _real_reads_golden(prefix)
     model, md = load_model(_mint_pt(tmp_path, g, O), device=0)
     n = 0
-    for i, (read, err) in enumerate(rio.iter_reads_from_pod5_and_bam(os.path.join(data, "can_reads.pod5"),
-                                                                     os.path.join(data, "can_mappings.bam"))):
+    for i, (read, err) in enumerate(rio.iter_reads_from_pod5_and_bam(os.path.join(data, f"{prefix}_reads.pod5"),
+                                                                     os.path.join(data, f"{prefix}_mappings.bam"))):
         assert err is None and read.read_id == str(g[f"r{i}_name"])
         rr = read.into_remora_read(False)
         assert [rr.shift, rr.scale] == list(g[f"r{i}_shift_scale"]), "scaling composition must match bit for bit"
@@ -535,7 +549,7 @@ def test_real_reads_pod5_bam_end_to_end(torch_cuda, O, tmp_path):
         assert mm == str(g[f"r{i}_mm"])
         assert np.abs(np.asarray(list(ml), np.uint8).astype(int) - g[f"r{i}_ml"].astype(int)).max() <= 1
         n += pos.size
-    assert i == 13 and n == 922
+    assert i == 13 and n == n_chunks
 
 
 def test_batched_call_reads_mods_matches_single_read_api(torch_cuda, O):
@@ -636,9 +650,10 @@ def test_concurrent_calls_from_threads(torch_cuda, O):
             assert np.array_equal(got[i][rep], expect[i])
 
 
-def test_infer_from_pod5_and_bam_cli(torch_cuda, O, tmp_path):
-    """`python -m remora_amd infer from_pod5_and_bam` on the reference's test data: every input record
-    comes back with the MM/ML tags the reference's call_read_mods produces for that read."""
+@pytest.mark.parametrize("prefix", ["can", "mod"])
+def test_infer_from_pod5_and_bam_cli(torch_cuda, O, tmp_path, prefix):
+    """`python -m remora_amd infer from_pod5_and_bam` on the reference's test data (both halves of BASELINE configs[0]):
+    every input record comes back with the MM/ML tags the reference's call_read_mods produces for that read."""
     import subprocess
     import sys
 
@@ -646,11 +661,11 @@ def test_infer_from_pod5_and_bam_cli(torch_cuda, O, tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     data = os.path.join(root, "tests", "golden", "data")
-    g = golden("real_reads_can.npz")
+    g = _real_reads_golden(prefix)
     pt = _mint_pt(tmp_path, g, O)
     out = str(tmp_path / "out.bam")
-    res = subprocess.run([sys.executable, "-m", "remora_amd", "infer", "from_pod5_and_bam", os.path.join(data, "can_reads.pod5"),
-                          os.path.join(data, "can_mappings.bam"), "--model", pt, "--out-bam", out, "--reads-per-batch", "5"],
+    res = subprocess.run([sys.executable, "-m", "remora_amd", "infer", "from_pod5_and_bam", os.path.join(data, f"{prefix}_reads.pod5"),
+                          os.path.join(data, f"{prefix}_mappings.bam"), "--model", pt, "--out-bam", out, "--reads-per-batch", "5"],
                          cwd=root, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "called 14 reads" in res.stdout
@@ -786,7 +801,8 @@ def test_core_dataset_writer_matches_reference_files(torch_cuda, tmp_path):
         ds.write_batch({"signal": np.zeros((100, 1, 100), np.float32)})  # beyond the allocation / missing arrays
 
 
-def test_real_reads_reference_anchored(torch_cuda, O, tmp_path):
+@pytest.mark.parametrize("prefix,n_chunks", [("can", 847), ("mod", 1060)])
+def test_real_reads_reference_anchored(torch_cuda, O, tmp_path, prefix, n_chunks):
     """Reference-anchored flavour of the same reads: Read.add_alignment(parse_ref_align=True) ->
     ref_to_signal / ref region / ref_seq -> into_remora_read(True) -> call_read_mods, and the
     `--reference-anchored` pipeline output (records rewritten to <len>M + reference sequence + MM/ML),
@@ -796,8 +812,8 @@ def test_real_reads_reference_anchored(torch_cuda, O, tmp_path):
     from remora_amd.model_util import load_model
 
     data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
-    pod5, bam = os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam")
-    g = golden("real_reads_can.npz")
+    pod5, bam = os.path.join(data, f"{prefix}_reads.pod5"), os.path.join(data, f"{prefix}_mappings.bam")
+    g = _real_reads_golden(prefix)
     model, md = load_model(_mint_pt(tmp_path, g, O), device=0)
     n = 0
     for i, (read, err) in enumerate(rio.iter_reads_from_pod5_and_bam(pod5, bam)):
@@ -814,7 +830,7 @@ def test_real_reads_reference_anchored(torch_cuda, O, tmp_path):
         mm, _ = call_read_mods(read.into_remora_read(True), model, md, return_mm_ml_tags=True)
         assert mm == str(g[f"r{i}_ra_mm"])
         n += pos.size
-    assert n == 847
+    assert n == n_chunks
     out_bam = str(tmp_path / "ra.bam")
     stats = infer_from_pod5_and_bam(pod5, bam, model, md, out_bam, ref_anchored=True)
     assert stats.get(None) == 14

@@ -1420,3 +1420,65 @@ def _check_dacs_only(reads):
     from remora_amd import data_chunks as dc
 
     dc._validated_int16_dacs(reads[0])
+
+
+def test_bam_writer_output_is_valid_bgzf_and_bam_by_independent_readers(tmp_path):
+    """The BGZF/BAM writer is otherwise only read back by this repo's own readers; here its output is held to the SAM/BAM
+    specification with Python's zlib / gzip as the independent implementation (pysam / htslib are not installed):
+      * every BGZF member: gzip magic, CM 8, FLG.FEXTRA, XLEN 6, the 'BC' subfield with SLEN 2 and BSIZE = member size - 1,
+        a raw-deflate payload that zlib inflates to ISIZE bytes (<= 65536) whose CRC32 is the trailer's;
+      * the file ends with the 28-byte BGZF EOF marker of the specification;
+      * gzip.open reads the concatenated members as one stream: 'BAM\\1', l_text, text, n_ref, references, then records
+        whose block_size fields walk exactly to the end of the stream; l_read_name / n_cigar_op / l_seq are consistent
+        with each record's size, every tag parses, and the records equal what was written."""
+    import gzip
+    import struct
+    import zlib
+
+    from remora_amd import io as rio
+
+    rng = np.random.default_rng(23)
+    recs = []
+    for k in range(60):
+        n = int(rng.integers(1, 300)) if k % 9 else 40000  # some records span several 64 KiB blocks
+        seq = "".join(rng.choice(list("ACGT"), n))
+        mv = [5] + rng.integers(0, 2, 2 * n).tolist()
+        tags = [b"mvBc" + struct.pack("<i", len(mv)) + struct.pack(f"<{len(mv)}b", *mv), b"NMi" + struct.pack("<i", k),
+                b"MMZ" + b"C+m,1,2;" + b"\x00"]
+        recs.append((f"r{k}", 16 if k % 2 else 0, seq, [(0, n)], tags))
+    path = tmp_path / "w.bam"
+    hdr = _tiny_bam(path, recs)
+    raw = open(path, "rb").read()
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    assert raw.endswith(eof)
+    p, payload, members = 0, bytearray(), 0
+    while p < len(raw):
+        magic, cm, flg, _mtime, _xfl, _os, xlen = struct.unpack_from("<HBBIBBH", raw, p)
+        assert (magic, cm, flg, xlen) == (0x8B1F, 8, 4, 6)
+        si1, si2, slen, bsize = struct.unpack_from("<BBHH", raw, p + 12)
+        assert (si1, si2, slen) == (66, 67, 2)
+        end = p + bsize + 1
+        crc, isize = struct.unpack_from("<II", raw, end - 8)
+        data = zlib.decompress(raw[p + 18 : end - 8], wbits=-15)
+        assert len(data) == isize <= 65536 and zlib.crc32(data) == crc
+        payload += data
+        p = end
+        members += 1
+    assert p == len(raw) and members >= 3
+    stream = gzip.open(path, "rb").read()
+    assert stream == bytes(payload) and stream.startswith(hdr)
+    q, out = len(hdr), []
+    while q < len(stream):
+        (bs,) = struct.unpack_from("<i", stream, q)
+        rec = stream[q + 4 : q + 4 + bs]
+        assert len(rec) == bs
+        _ref, _pos, l_name, _mq, _bin, n_cig, _flag, l_seq = struct.unpack_from("<iiBBHHHi", rec, 0)
+        body = 32 + l_name + 4 * n_cig + (l_seq + 1) // 2 + l_seq
+        assert body <= bs and rec[32 + l_name - 1] == 0
+        tags = rio._parse_tags(rec[body:])  # every tag of the region parses to its end
+        assert [t for t, _ in tags] == ["mv", "NM", "MM"]
+        out.append(rec)
+        q += 4 + bs
+    assert q == len(stream) and len(out) == len(recs)
+    back = list(rio.iter_bam_records(str(path)))
+    assert [r.query_name for r in back] == [r[0] for r in recs] and [r.query_sequence for r in back] == [r[2] for r in recs]

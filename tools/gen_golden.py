@@ -694,8 +694,17 @@ def gen_real_reads(R, out):
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
     from golden_util import pod5_reads_cpu
 
-    pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(data, "can_reads.pod5"))}
-    recs = list(rio.iter_bam_records(os.path.join(data, "can_mappings.bam")))
+    for prefix in ("can", "mod"):  # both halves of BASELINE configs[0]; the same CG 5mC model calls both
+        _gen_real_reads_one(R, out, data, prefix, rio, pod5_reads_cpu)
+
+
+def _gen_real_reads_one(R, out, data, prefix, rio, pod5_reads_cpu):
+    import tempfile
+
+    import torch
+
+    pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(data, f"{prefix}_reads.pod5"))}
+    recs = list(rio.iter_bam_records(os.path.join(data, f"{prefix}_mappings.bam")))
     net = make_net(R, "ConvLSTM_w_ref", 64, 9, 2, seed=300)
     ckpt = _ckpt((4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 64, 9, 2)
     with tempfile.TemporaryDirectory() as td:
@@ -704,7 +713,8 @@ def gen_real_reads(R, out):
         extra = {"meta.txt": ""}
         torch.jit.load(pt, _extra_files=extra, map_location="cpu")
         model, md = R.model_util.load_model(pt, quiet=True, eval_only=True)
-    d = state_to_np(net)
+    # the weights travel once (real_reads_can.npz); the mod file holds the per-read results of the same model
+    d = state_to_np(net) if prefix == "can" else {}
     d["meta_txt"] = np.asarray(extra["meta.txt"] if isinstance(extra["meta.txt"], str) else extra["meta.txt"].decode())
     d["num_records"] = np.asarray(len(recs))
     for i, rec in enumerate(recs):
@@ -743,8 +753,9 @@ def gen_real_reads(R, out):
         d[f"r{i}_ra_pos"] = np.asarray(pos, np.int64)
         mm, ml = R.inference.call_read_mods(read.into_remora_read(True), model, md, return_mm_ml_tags=True)
         d[f"r{i}_ra_mm"] = np.asarray(mm)
-    np.savez_compressed(os.path.join(out, "real_reads_can.npz"), **d)
-    print("real_reads:", len(recs), "records,", sum(int(d[f"r{i}_pos"].size) for i in range(len(recs))), "chunks")
+    np.savez_compressed(os.path.join(out, f"real_reads_{prefix}.npz"), **d)
+    print(f"real_reads {prefix}:", len(recs), "records,", sum(int(d[f"r{i}_pos"].size) for i in range(len(recs))), "chunks,",
+          sum(int(d[f"r{i}_ra_pos"].size) for i in range(len(recs))), "reference-anchored chunks")
 
 
 def gen_core_dataset(R, out):
