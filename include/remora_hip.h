@@ -213,6 +213,24 @@ typedef struct {
 } rmr_motif_set;
 int rmr_motif_flags(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads,
                     const rmr_motif_set *motifs, uint8_t *flags, int mem);
+/* The same scan for a batch of device-resident reads without the flag array (DEVICE pointers only): pass 1 counts the
+ * hits of every read (counts i64[n_reads]); the caller turns them into offsets foc_off i64[n_reads+1] (exclusive
+ * prefix sum) and sizes `focus`; pass 2 writes the read-local focus positions of read r, ascending, at
+ * focus[foc_off[r] .. foc_off[r+1]).  One wavefront per read, ballot + prefix-popcount compaction. */
+int rmr_motif_focus_counts(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads,
+                           const rmr_motif_set *motifs, int64_t *counts);
+int rmr_motif_focus_fill(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads,
+                         const rmr_motif_set *motifs, const int64_t *foc_off, int64_t *focus);
+
+/* Host-side gather of a batch of reads into the concatenated rmr_reads layout (no GPU involved; native threads): read i
+ * contributes sig_n[i] int16 dacs, seq_n[i]+1 int64 mapping entries and seq_n[i] bases (integers of seq_itemsize[i]
+ * bytes, narrowed to int8).  dst_* are caller buffers (typically the pinned staging buffer that is uploaded next);
+ * sig_off / seq_off i64[n_reads+1] receive the offsets; the mapping of read i starts at dst_maps[seq_off[i] + i].
+ * replaces: nothing in the reference (it handles one read at a time, src/remora/inference.py:62-137). */
+int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
+                   const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
+                   int64_t *dst_maps, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads);
+
 
 /* ---- X1 + X2 + X3 (+X6): chunk extraction for a batch of reads --------------------------- */
 /* replaces: RemoraRead.sig (src/remora/data_chunks.py:191-197), iter_chunks (:425-466),

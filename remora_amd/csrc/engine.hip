@@ -1100,6 +1100,34 @@ int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
     return 0;
 }
 
+static int check_motifs(const rmr_motif_set *motifs) {
+    if (motifs->n_motifs < 1 || motifs->n_motifs > 8) RMR_FAIL(RMR_ERR_INVALID, "1..8 motifs supported");
+    for (int m = 0; m < motifs->n_motifs; ++m)
+        if (motifs->len[m] < 1 || motifs->len[m] > 16 || motifs->focus_pos[m] >= motifs->len[m] || motifs->focus_pos[m] < -64)
+            RMR_FAIL(RMR_ERR_INVALID, "motif %d: length %d / focus %d unsupported", m, motifs->len[m], motifs->focus_pos[m]);
+    return 0;
+}
+
+int rmr_motif_focus_counts(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads, const rmr_motif_set *motifs,
+                           int64_t *counts) {
+    if (!e || !int_seq || !seq_off || !motifs || !counts) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_reads < 0 || n_reads > (int64_t)1 << 30) RMR_FAIL(RMR_ERR_INVALID, "bad n_reads");
+    RMR_TRY(check_motifs(motifs));
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    return launch_motif_focus(e, int_seq, seq_off, (int)n_reads, *motifs, counts, nullptr, nullptr);
+}
+
+int rmr_motif_focus_fill(rmr_engine *e, const int8_t *int_seq, const int64_t *seq_off, int64_t n_reads, const rmr_motif_set *motifs,
+                         const int64_t *foc_off, int64_t *focus) {
+    if (!e || !int_seq || !seq_off || !motifs || !foc_off || !focus) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_reads < 0 || n_reads > (int64_t)1 << 30) RMR_FAIL(RMR_ERR_INVALID, "bad n_reads");
+    RMR_TRY(check_motifs(motifs));
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    return launch_motif_focus(e, int_seq, seq_off, (int)n_reads, *motifs, nullptr, foc_off, focus);
+}
+
 // ---- the one collective: RCCL, loaded on first use (a single-GPU process never touches it) ----------------
 namespace {
 struct NcclId { char internal[RMR_COMM_ID_BYTES]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value

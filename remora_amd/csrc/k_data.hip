@@ -534,6 +534,53 @@ int launch_motif(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n
     return 0;
 }
 
+// ---- M3 for batches, without a flag array: one wavefront per read walks its bases 64 at a time, tests the motifs,
+// and either counts the hits (FILL = false) or writes their read-local positions in ascending order at
+// focus[foc_off[read] ...] (FILL = true; wave ballot + prefix popcount compaction).  Replaces the
+// nonzero / searchsorted / bincount passes over a 1-byte-per-base flag array of the first version.
+template <bool FILL>
+__global__ __launch_bounds__(256) void motif_focus_kernel(const int8_t *__restrict__ seq, const int64_t *__restrict__ seq_off,
+                                                          int n_reads, rmr_motif_set ms, int64_t *__restrict__ counts,
+                                                          const int64_t *__restrict__ foc_off, int64_t *__restrict__ focus) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const int64_t rs = seq_off[r], re = seq_off[r + 1];
+    int64_t base = FILL ? foc_off[r] : 0, found = 0;
+    for (int64_t b0 = rs; b0 < re; b0 += 64) {
+        const int64_t b = b0 + lane;
+        bool hit = false;
+        if (b < re) {
+            for (int m = 0; m < ms.n_motifs && !hit; ++m) {
+                const int64_t j = b - ms.focus_pos[m];  // start of the window whose focus base is b
+                if (j < rs || j + ms.len[m] > re) continue;
+                bool ok = true;
+                for (int k = 0; k < ms.len[m] && ok; ++k) {
+                    const int c = seq[j + k];
+                    ok = c >= 0 && ((ms.mask[m][k] >> c) & 1);
+                }
+                hit = ok;
+            }
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (FILL && hit) focus[base + found + __popcll(mask & ((1ull << lane) - 1ull))] = b - rs;
+        found += __popcll(mask);
+    }
+    if (!FILL && lane == 0) counts[r] = found;
+}
+
+int launch_motif_focus(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, const rmr_motif_set &ms,
+                       int64_t *counts, const int64_t *foc_off, int64_t *focus) {
+    if (n_reads <= 0) return 0;
+    ProfScope ps(e, K_MOTIF);
+    if (focus) hipLaunchKernelGGL(motif_focus_kernel<true>, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, e->stream, seq, seq_off,
+                                  n_reads, ms, counts, foc_off, focus);
+    else hipLaunchKernelGGL(motif_focus_kernel<false>, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, e->stream, seq, seq_off,
+                            n_reads, ms, counts, foc_off, focus);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts) {
     if (n <= 0) return 0;
     if (num_out > 16) RMR_FAIL(RMR_ERR_INVALID, "num_out %d > 16", num_out);

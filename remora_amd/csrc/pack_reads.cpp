@@ -1,0 +1,69 @@
+// pack_reads.cpp — host side of the batched reads path: the arrays of a batch of reads (each read its own numpy arrays)
+// gathered into the concatenated rmr_reads layout (include/remora_hip.h) inside the caller's pinned staging buffer, by a
+// few native threads.  The reference has no counterpart (it processes reads one at a time in Python,
+// src/remora/inference.py:62-137); in this engine the per-read Python copies of this step were 55 of the 83 ms that a
+// batch of 2048 x 5 kb reads took end to end.
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "rmr_internal.h"
+
+namespace {
+
+template <typename T>
+void narrow_to_i8(const void *src, int64_t n, int8_t *dst) {
+    const T *s = static_cast<const T *>(src);
+    for (int64_t i = 0; i < n; ++i) dst[i] = (int8_t)s[i];
+}
+
+}  // namespace
+
+extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
+                              const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
+                              int64_t *dst_maps, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads) {
+    if (n_reads < 0 || !dacs || !sig_n || !maps || !seqs || !seq_n || !seq_itemsize || !dst_dacs || !dst_maps || !dst_seq ||
+        !sig_off || !seq_off)
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    sig_off[0] = seq_off[0] = 0;
+    for (int64_t i = 0; i < n_reads; ++i) {
+        if (sig_n[i] < 0 || seq_n[i] < 0) RMR_FAIL(RMR_ERR_INVALID, "read %lld: negative size", (long long)i);
+        const int sz = seq_itemsize[i];
+        if (sz != 1 && sz != 2 && sz != 4 && sz != 8) RMR_FAIL(RMR_ERR_INVALID, "read %lld: int_seq itemsize %d", (long long)i, sz);
+        sig_off[i + 1] = sig_off[i] + sig_n[i];
+        seq_off[i + 1] = seq_off[i] + seq_n[i];
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 32) threads = 32;
+    // reads are dealt to the threads in contiguous ranges of about equal signal volume
+    auto work = [&](int64_t r0, int64_t r1) {
+        for (int64_t i = r0; i < r1; ++i) {
+            memcpy(dst_dacs + sig_off[i], dacs[i], (size_t)sig_n[i] * sizeof(int16_t));
+            memcpy(dst_maps + seq_off[i] + i, maps[i], (size_t)(seq_n[i] + 1) * sizeof(int64_t));  // n + 1 entries per read
+            int8_t *d = dst_seq + seq_off[i];
+            switch (seq_itemsize[i]) {
+                case 1: memcpy(d, seqs[i], (size_t)seq_n[i]); break;
+                case 2: narrow_to_i8<int16_t>(seqs[i], seq_n[i], d); break;
+                case 4: narrow_to_i8<int32_t>(seqs[i], seq_n[i], d); break;
+                default: narrow_to_i8<int64_t>(seqs[i], seq_n[i], d); break;
+            }
+        }
+    };
+    if (threads == 1 || n_reads < 2 * threads) {
+        work(0, n_reads);
+        return 0;
+    }
+    std::vector<std::thread> pool;
+    const int64_t total = sig_off[n_reads];
+    int64_t r0 = 0;
+    for (int t = 0; t < threads && r0 < n_reads; ++t) {
+        int64_t r1 = r0;
+        const int64_t want = total * (t + 1) / threads;
+        while (r1 < n_reads && (sig_off[r1 + 1] <= want || r1 == r0)) ++r1;
+        if (t == threads - 1) r1 = n_reads;
+        pool.emplace_back(work, r0, r1);
+        r0 = r1;
+    }
+    for (auto &th : pool) th.join();
+    return 0;
+}

@@ -213,6 +213,8 @@ int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts);
 int launch_vbz(rmr_engine *e, const uint8_t *svb, const int64_t *row_off, const int32_t *row_n, const int64_t *out_off,
                int64_t n_rows, int16_t *out, int32_t *status);
+int launch_motif_focus(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, const rmr_motif_set &ms,
+                       int64_t *counts, const int64_t *foc_off, int64_t *focus);
 int launch_motif(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, int64_t total,
                  const rmr_motif_set &ms, uint8_t *flags);
 

@@ -9,6 +9,8 @@ layout (:786-816) and feed `HipModel.infer_chunks` without ever materialising th
 import ctypes
 import dataclasses
 
+import os
+
 import numpy as np
 
 from . import RemoraError
@@ -190,17 +192,30 @@ class DeviceReads:
         buf = _pinned_bytes(max(total, 256))
         host = buf.numpy()
         view = {name: host[offs[name] : offs[name] + cnt * np.dtype(dt).itemsize].view(dt) for name, dt, cnt in segs}
-        o_sig = o_seq = o_map = 0
-        for r in reads:  # numpy casts to the segment dtype on the fly
-            a = _validated_int16_dacs(r)
-            view["dacs"][o_sig : o_sig + a.size] = a
-            o_sig += a.size
-            a = np.asarray(r.seq_to_sig_map).ravel()
-            view["s2s"][o_map : o_map + a.size] = a
-            o_map += a.size
-            a = np.asarray(r.int_seq).ravel()
-            view["iseq"][o_seq : o_seq + a.size] = a
-            o_seq += a.size
+        # the per-read arrays are gathered into the pinned buffer by native threads (rmr_pack_reads): the python loop
+        # only collects pointers (a per-read numpy slice copy cost 25-30 us: two thirds of a batch's wall time)
+        keep, p_d, p_m, p_s, isz = [], [], [], [], []
+        for r in reads:
+            d = np.ascontiguousarray(_validated_int16_dacs(r))
+            mp = np.ascontiguousarray(r.seq_to_sig_map, dtype=np.int64).ravel()
+            sq = np.ascontiguousarray(r.int_seq).ravel()
+            if sq.dtype.kind not in "iu" or sq.dtype.itemsize not in (1, 2, 4, 8):
+                sq = sq.astype(np.int64)
+            keep.append((d, mp, sq))
+            p_d.append(d.__array_interface__["data"][0])
+            p_m.append(mp.__array_interface__["data"][0])
+            p_s.append(sq.__array_interface__["data"][0])
+            isz.append(sq.dtype.itemsize)
+        lib = L.lib()
+        vp = lambda lst: (ctypes.c_void_p * max(len(lst), 1))(*lst)  # noqa: E731
+        sig_n = np.diff(self.sig_off)
+        seq_n = np.diff(self.seq_off)
+        isz = np.asarray(isz, np.int32)
+        so, qo = np.empty(nr + 1, np.int64), np.empty(nr + 1, np.int64)
+        L.check(lib.rmr_pack_reads(nr, vp(p_d), sig_n.ctypes.data, vp(p_m), vp(p_s), seq_n.ctypes.data, isz.ctypes.data,
+                                   view["dacs"].ctypes.data, view["s2s"].ctypes.data, view["iseq"].ctypes.data,
+                                   so.ctypes.data, qo.ctypes.data, int(os.environ.get("RMR_PACK_THREADS", "8"))))
+        del keep
         view["d_sig_off"][:] = self.sig_off
         view["d_seq_off"][:] = self.seq_off
         view["shift"][:] = [float(r.shift) for r in reads]
@@ -234,16 +249,25 @@ class DeviceReads:
             for k, allowed in enumerate(mot.int_pattern):
                 ms.mask[m][k] = int(sum(1 << int(b) for b in allowed))
         total = int(self.seq_off[-1])
-        flags = torch.zeros(max(total, 1), dtype=torch.uint8, device=self.engine.torch_device)
-        if total:
-            L.check(L.lib().rmr_motif_flags(self.engine.handle, self.iseq.data_ptr(), self.d_seq_off.data_ptr(),
-                                            self.n_reads, ctypes.byref(ms), flags.data_ptr(), L.MEM_DEVICE))
-        pos = torch.nonzero(flags[:total]).flatten()  # ascending
-        read_of = torch.searchsorted(self.d_seq_off, pos, right=True) - 1
-        counts = torch.bincount(read_of, minlength=self.n_reads)[: self.n_reads]
+        dev = self.engine.torch_device
         foc_off = np.zeros(self.n_reads + 1, np.int64)
+        if not total:
+            return torch.zeros(0, dtype=torch.int64, device=dev), foc_off
+        lib = L.lib()
+        # pass 1: hits per read (one wavefront per read); offsets on the host (they are needed there anyway: the results
+        # are split per read); pass 2: read-local positions, ascending, compacted by wave ballots
+        counts = torch.empty(self.n_reads, dtype=torch.int64, device=dev)
+        L.check(lib.rmr_motif_focus_counts(self.engine.handle, self.iseq.data_ptr(), self.d_seq_off.data_ptr(), self.n_reads,
+                                           ctypes.byref(ms), counts.data_ptr()))
+        self.engine.synchronize()
         np.cumsum(counts.cpu().numpy(), out=foc_off[1:])
-        return pos - self.d_seq_off[read_of], foc_off
+        n_hits = int(foc_off[-1])
+        focus = torch.empty(max(n_hits, 1), dtype=torch.int64, device=dev)
+        if n_hits:
+            self.d_foc_off = torch.from_numpy(foc_off).to(dev)
+            L.check(lib.rmr_motif_focus_fill(self.engine.handle, self.iseq.data_ptr(), self.d_seq_off.data_ptr(), self.n_reads,
+                                             ctypes.byref(ms), self.d_foc_off.data_ptr(), focus.data_ptr()))
+        return focus[:n_hits], foc_off
 
 
 def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset, labels=None):

@@ -1482,3 +1482,41 @@ def test_bam_writer_output_is_valid_bgzf_and_bam_by_independent_readers(tmp_path
     assert q == len(stream) and len(out) == len(recs)
     back = list(rio.iter_bam_records(str(path)))
     assert [r.query_name for r in back] == [r[0] for r in recs] and [r.query_sequence for r in back] == [r[2] for r in recs]
+
+
+def test_pack_reads_native_gather_equals_numpy():
+    """rmr_pack_reads (host-only C++: the per-read arrays of a batch gathered into the concatenated rmr_reads layout by
+    native threads) against numpy concatenation: every int_seq itemsize, empty reads, any thread count."""
+    import ctypes
+
+    from remora_amd import _lib as L
+
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    nr = 37
+    dts = [np.int8, np.int16, np.int32, np.int64, np.uint8]
+    reads = []
+    for i in range(nr):
+        nb = 0 if i == 11 else int(rng.integers(1, 400))
+        ns = 0 if nb == 0 else int(rng.integers(nb, 12 * nb))
+        reads.append((rng.integers(-3000, 3000, ns).astype(np.int16), np.sort(rng.integers(0, ns + 1, nb + 1)).astype(np.int64),
+                      rng.integers(-1, 4, nb).astype(dts[i % len(dts)] if dts[i % len(dts)] != np.uint8 else np.int8)))
+    sig_n = np.asarray([r[0].size for r in reads], np.int64)
+    seq_n = np.asarray([r[2].size for r in reads], np.int64)
+    isz = np.asarray([r[2].dtype.itemsize for r in reads], np.int32)
+    vp = lambda k: (ctypes.c_void_p * nr)(*[r[k].ctypes.data for r in reads])  # noqa: E731
+    for threads in (1, 3, 8):
+        dacs = np.full(int(sig_n.sum()) + 1, 7777, np.int16)
+        maps = np.full(int(seq_n.sum()) + nr + 1, -5, np.int64)
+        seq = np.full(int(seq_n.sum()) + 1, 99, np.int8)
+        so, qo = np.empty(nr + 1, np.int64), np.empty(nr + 1, np.int64)
+        L.check(lib.rmr_pack_reads(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, isz.ctypes.data, dacs.ctypes.data,
+                                   maps.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, threads))
+        assert np.array_equal(so, np.concatenate([[0], np.cumsum(sig_n)])) and np.array_equal(qo, np.concatenate([[0], np.cumsum(seq_n)]))
+        assert np.array_equal(dacs[:-1], np.concatenate([r[0] for r in reads])) and dacs[-1] == 7777
+        assert np.array_equal(maps[:-1], np.concatenate([r[1] for r in reads])) and maps[-1] == -5
+        assert np.array_equal(seq[:-1], np.concatenate([r[2].astype(np.int8) for r in reads])) and seq[-1] == 99
+    bad = isz.copy()
+    bad[3] = 3
+    assert lib.rmr_pack_reads(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, bad.ctypes.data, dacs.ctypes.data,
+                              maps.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, 2) != 0
