@@ -35,10 +35,11 @@ BENCH_NAME = [("conv_mfma_kernel<128, 5, 1>", "conv_merge1"), ("conv_mfma_kernel
               ("conv_mfma_kernel<16, 9, 3>", "conv_sig3"), ("lstm_head_kernel", "lstm_head"),
               ("conv_bf16s_kernel<128, 5, 1", "conv_merge1"), ("conv_bf16s_kernel<16, 13, 3", "conv_seq2"),
               ("conv_bf16s_kernel<16, 9, 3", "conv_sig3"), ("lstm_bf16s_kernel", "lstm_head"),
-              ("front_sig_kernel", "front_sig"), ("front_seq_kernel", "front_seq")]
+              ("front_sig_kernel", "front_sig"), ("front_seq_kernel", "front_seq"), ("fused_front_kernel", "fused_front"),
+              ("lstm_x16_kernel", "lstm_head"), ("encode_kernel", "encode_kmers")]
 
 
-def write_traffic(d, dtype, chunks_per_launch, path):
+def write_traffic(d, dtype, chunks_per_launch, path, commit=None, per_kernel_chunks=None):
     """profiles/traffic.json: corrected HBM bytes per chunk per kernel (2 x FETCH_SIZE + WRITE_SIZE, KiB)."""
     import json
 
@@ -56,21 +57,31 @@ def write_traffic(d, dtype, chunks_per_launch, path):
         fv, fn = fetch.get(k, {}).get("FETCH_SIZE", (0, 0))
         wv, wn = write.get(k, {}).get("WRITE_SIZE", (0, 0))
         per_launch = 2 * fv * 1024 / max(fn, 1) + wv * 1024 / max(wn, 1)
-        ent[name] = {"bytes_per_chunk": per_launch / chunks_per_launch, "source": os.path.basename(d.rstrip("/")),
+        cpl = (per_kernel_chunks or {}).get(name, chunks_per_launch)
+        if name in ent and ent[name]["launches"] >= max(fn, wn):
+            continue  # two kernels share a bench name (e.g. the one-launch fp32 probe model of a bf16 run): keep the main one
+        ent[name] = {"bytes_per_chunk": per_launch / cpl, "source": os.path.basename(d.rstrip("/")),
                      "fetch_raw_kib_per_launch": fv / max(fn, 1), "write_kib_per_launch": wv / max(wn, 1),
-                     "chunks_per_launch": chunks_per_launch}
+                     "chunks_per_launch": cpl, "launches": max(fn, wn), "commit": commit}
     tj[dtype] = ent
     json.dump(tj, open(path, "w"), indent=1, sort_keys=True)
 
 
 def main():
     if len(sys.argv) > 2 and sys.argv[2] == "--traffic":
-        write_traffic(sys.argv[1], sys.argv[3], float(sys.argv[4]), sys.argv[5])
+        # <dir> --traffic <dtype key> <chunks per launch> <traffic.json> [commit] [kernel=chunks_per_launch ...]
+        extra = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[7:])
+        write_traffic(sys.argv[1], sys.argv[3], float(sys.argv[4]), sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else None, extra)
         return
     d = sys.argv[1]
     tag = os.path.basename(d.rstrip("/"))
+    cmd = ""
+    try:
+        cmd = open(os.path.join(d, "command.txt")).read().strip()
+    except OSError:
+        pass
     lines = [f"# rocprofv3 summary — {tag}", "",
-             "Command per pass: `rocprofv3 <flags> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
+             f"Command per pass: `rocprofv3 <flags> -- {cmd or 'python bench.py --steps 3 --warmup 1 --no-cpu-baseline'}` "
              "(tools/profile_gpu.sh); 1 x MI355X, 1M chunks/step.", ""]
     stats = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
     if stats:
@@ -110,7 +121,8 @@ def main():
         lines.append("")
         if sub == "pmc_mfma":
             lines += ["MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs) "
-                      "(GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x #v_mfma_f32_16x16x4_f32, summed over all SIMDs):", ""]
+                      "(GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES = busy cycles of the matrix pipe - 32 per "
+                      "v_mfma_f32_16x16x4_f32, 16 per v_mfma_f32_16x16x32_bf16 - summed over all SIMDs):", ""]
             for k in sorted(c):
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in c[k] and "GRBM_GUI_ACTIVE" in c[k] and c[k]["GRBM_GUI_ACTIVE"][0] > 0:
                     u = c[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (c[k]["GRBM_GUI_ACTIVE"][0] / 8 * 1024)
