@@ -79,6 +79,15 @@ int rmr_engine::ensure(Arena &a, size_t bytes) {
     return 0;
 }
 
+int rmr_engine::allow_big_lds(const void *kernel) {
+    for (const void *k : lds_attr_set)
+        if (k == kernel) return 0;
+    RMR_HIP(hipSetDevice(device));
+    RMR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_attr_set.push_back(kernel);
+    return 0;
+}
+
 int rmr_engine::prof_begin(int id, hipEvent_t *t1, hipStream_t s) {
     hipEvent_t ev[2];
     for (int k = 0; k < 2; ++k) {

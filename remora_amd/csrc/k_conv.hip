@@ -171,12 +171,7 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_mfma_kernel<IC, KW, STRIDE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     ProfScope ps(e, c.kid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, e->stream, a);
     RMR_HIP(hipGetLastError());

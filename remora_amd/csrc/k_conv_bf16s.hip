@@ -191,11 +191,7 @@ static int launch_conv_s_t(rmr_engine *e, const ConvLayer &c, const float *in, i
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_bf16s_kernel<IC, KW, STRIDE, NP>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     ProfScope ps(e, c.kid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (c.oc / 16)), lds, e->stream, a);
     RMR_HIP(hipGetLastError());

@@ -291,12 +291,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "front_seq: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
     a.cb = cb;
     auto kern = (kw == 5) ? front_seq_kernel<5, false> : front_seq_kernel<11, true>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[kw == 5 ? 0 : 1]) {
-        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done[kw == 5 ? 0 : 1] = true;
-    }
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SEQ_BLOCKS_PER_CU", direct ? 8 : 4);
     if (grid > iters) grid = iters;
@@ -356,12 +351,7 @@ int launch_seq1_dense(rmr_model *m, const float *enc, int64_t n, float *seq1) {
     // wt_seq1 layout [kw][K][4][16] == [kw][EC][16] with ic = 4*kp + base: same table
     const size_t lds = ((size_t)a.kw * a.EC * 16 + (size_t)a.EC * a.L) * 4;
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "dense seq_conv1 needs %zu B LDS", lds);
-    static bool attr_done = false;
-    if (!attr_done) {
-        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(seq1_dense_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(seq1_dense_kernel)));
     int64_t grid = (int64_t)e->num_cus * 2;
     if (grid > n) grid = n;
     ProfScope ps(e, K_SEQ1_DENSE);

@@ -441,9 +441,6 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
     }
 }
 
-// per-device "attribute set" flags: hipFuncSetAttribute applies to the current device only
-static bool fused_attr_done[64] = {};
-
 bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
     if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 1) return false;
     if (m->desc.kmer_len != 9 || m->front.kw1 != 5) return false;
@@ -497,10 +494,7 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     a.d_maxlen = make_fastdiv(a.maxlen);
     a.abl = tune_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
     auto kern = fused_front_kernel<9>;
-    if (e->device < 64 && !fused_attr_done[e->device]) {
-        RMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        fused_attr_done[e->device] = true;
-    }
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 4);
     if (grid > iters) grid = iters;

@@ -100,6 +100,11 @@ struct rmr_engine {
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};
     int ensure_pinned(size_t bytes);
 
+    // kernels whose dynamic-LDS limit was raised ON THIS DEVICE (hipFuncSetAttribute is per device: a flag per
+    // process would skip the second engine of a multi-GPU process); guarded by `mu` like every launch
+    std::vector<const void *> lds_attr_set;
+    int allow_big_lds(const void *kernel);
+
     // profiling
     bool profiling = false;
     struct Rec {

@@ -3,6 +3,8 @@
 import queue as _queue
 from collections import defaultdict as _defaultdict
 
+import os
+
 import numpy as np
 
 from . import RemoraError
@@ -92,6 +94,17 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     motifs = [Motif(*m) for m in model_metadata["motifs"]]
     refiner = model_metadata.get("sig_map_refiner")
     loaded = refiner is not None and getattr(refiner, "is_loaded", False)
+    sub = int(os.environ.get("RMR_READS_SUBBATCH", "512"))
+    if device_reads is None and not loaded and sub > 0 and len(reads) >= 2 * sub:
+        # a large batch is walked in sub-batches whose host staging (gather into pinned memory + upload, worker thread,
+        # own stream) runs under the GPU work of the previous sub-batch: same results, the upload leaves the critical path.
+        # (With a signal-mapping refiner the batch stays whole: the banded DP of a call costs one read's latency whatever
+        # the batch size.)
+        out = []
+        for _, res in iter_call_reads_mods((reads[i : i + sub] for i in range(0, len(reads), sub)), model, model_metadata,
+                                           return_mod_probs):
+            out.extend(res)
+        return out
     if loaded and refiner.scale_iters > 0:
         for err in refiner.refine_reads(reads):  # DP rounds interleaved with host re-scaling
             if err is not None:

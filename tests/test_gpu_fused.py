@@ -141,3 +141,32 @@ def test_fused_front_full_size_properties(torch_cuda):
     k = 300_001
     out_h = model.infer_chunks(*[d[key][:k] for key in keys], (4, 4))
     assert np.array_equal(out_h, out[:k].cpu().numpy())
+
+
+def test_call_reads_mods_subbatch_pipeline_equals_one_batch(torch_cuda):
+    """A large call_reads_mods batch is walked in sub-batches with the staging of the next one under the kernels of the
+    current one (RMR_READS_SUBBATCH); the per-read results must be those of the one-batch path, bit for bit."""
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_reads_mods
+    from remora_amd.model_util import model_from_state
+
+    md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)], mod_bases=["m"], mod_long_names=["5mC"],
+              can_base="C", base_start_justify=False, offset=0, sig_map_refiner=None)
+    model = model_from_state(synth.synth_state("conv_lstm", 64, 9, 2, seed=2), md, device=0)
+    reads = []
+    for i in range(700):
+        r = synth.synth_read(300 + (i % 7) * 50, idx=i)
+        reads.append(RemoraRead(dacs=r["dacs"], shift=r["shift"], scale=r["scale"], seq_to_sig_map=r["seq_to_sig_map"],
+                                int_seq=r["int_seq"], read_id=f"r{i}"))
+    os.environ["RMR_READS_SUBBATCH"] = "0"
+    try:
+        whole = call_reads_mods(reads, model, md)
+        os.environ["RMR_READS_SUBBATCH"] = "128"
+        piped = call_reads_mods(reads, model, md)
+    finally:
+        del os.environ["RMR_READS_SUBBATCH"]
+    assert len(whole) == len(piped) == 700
+    for a, b in zip(whole, piped):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert sum(r[2].size for r in whole) > 5000
