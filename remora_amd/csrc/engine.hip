@@ -575,7 +575,7 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
             RMR_TRY(pack_conv_split(m.get(), convs[4], m->nparts, &m->seq2));
             RMR_TRY(pack_conv_split(m.get(), convs[5], m->nparts, &m->merge1));
         }
-        if (m->nparts == 1 && sz == 64 && K == 9 && kw1 == 5) {  // operands of the fused front kernel
+        if (m->nparts == 1 && sz == 64 && (K == 9 || K == 6) && kw1 == 5) {  // operands of the fused front kernel
             const int cg = (4 * K + 7) / 8;
             const double log2e = 1.4426950408889634;
             RMR_TRY(pack_flat_a(m.get(), convs[1], 4, 1, 1.0, &m->fused.a_sig2));

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
 
 bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
     if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 1) return false;
-    if (m->desc.kmer_len != 9 || m->front.kw1 != 5) return false;
+    if ((m->desc.kmer_len != 9 && m->desc.kmer_len != 6) || m->front.kw1 != 5) return false;  // the instantiated k-mer lengths
     if (m->L % 4 || map_w - 1 > 62 || map_w < 2) return false;
     if (seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
     return m->fused.a_merge1 != nullptr;
@@ -453,7 +453,7 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
                        const int16_t *lens, int64_t n, uint16_t *x) {
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
-    constexpr int CG = 5;
+    const int CG = (4 * m->desc.kmer_len + 7) / 8;
     FusedArgs a;
     a.signal = signal; a.seqs = seqs; a.maps = maps; a.lens = lens;
     a.a_sig2 = reinterpret_cast<const uint4 *>(m->fused.a_sig2); a.a_seq1 = reinterpret_cast<const uint4 *>(m->fused.a_seq1);
@@ -493,7 +493,7 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);
     a.d_maxlen = make_fastdiv(a.maxlen);
     a.abl = tune_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
-    auto kern = fused_front_kernel<9>;
+    auto kern = m->desc.kmer_len == 9 ? fused_front_kernel<9> : fused_front_kernel<6>;  // (4,4) and (2,3)-style contexts
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 4);
