@@ -592,11 +592,23 @@ def main():
     except (OSError, ValueError):
         traffic_table = {}
     # the C-ABI collective (rmr_allreduce_counts: RCCL called from the library, no torch) cross-checked against the
-    # torch.distributed result on the same counts — outside the timed region, never fatal for the bench line
-    cabi = rdist.cabi_allreduce_check(job.eng, per_rank, rank, world) if hasattr(rdist, "cabi_allreduce_check") else None
-    if rank != 0:
-        if cabi and cabi.get("status") == "timeout":
+    # torch.distributed result on the same counts — outside the timed region.  One process: before the result line (it is
+    # part of it).  Several ranks: AFTER rank 0 has printed the result line, reported on stderr — whatever a second
+    # communicator does on a node this code has never seen, it cannot cost the measurement.
+    cabi = rdist.cabi_allreduce_check(job.eng, per_rank, rank, world) if world == 1 else None
+
+    def cabi_after():
+        if world == 1:
+            return
+        res = rdist.cabi_allreduce_check(job_eng, per_rank, rank, world)
+        if rank == 0:
+            print(json.dumps({"allreduce_counts_c_abi": res}), file=sys.stderr, flush=True)
+        if res.get("status") == "timeout":
             os._exit(0)  # a worker thread is stuck inside a collective: do not wait for it at interpreter exit
+
+    job_eng = job.eng
+    if rank != 0:
+        cabi_after()
         return
     rep = job.report(args.steps, args.warmup, elapsed, prof, traffic_table)
     total = job.total_chunks_per_step * args.steps
@@ -611,7 +623,7 @@ def main():
         "roofline": rep["roofline"], "whole_pipeline": rep["whole_pipeline"], "kernels": rep["kernels"],
         "label_counts": rep["label_counts"],
         "label_counts_per_rank": [[int(x) for x in r] for r in per_rank] if per_rank is not None else None,
-        "allreduce_counts_c_abi": cabi,
+        "allreduce_counts_c_abi": cabi if world == 1 else "run after this line; result on stderr (see bench.py)",
     }
     if world == 1:
         legs = side_legs(job, args, job.logits)
@@ -658,6 +670,7 @@ def main():
         if not args.no_cpu_baseline:
             out["precision"] = precision_check(primary_state, primary_sample, primary_kcb, head_logits)
     os.write(result_fd, (json.dumps(out) + "\n").encode())
+    cabi_after()
     if cabi and cabi.get("status") == "timeout":
         os._exit(0)
 

@@ -116,7 +116,7 @@ def init_cabi_comm(engine, rank=None, world=None):
     if world > 1:
         t = torch.tensor(list(ident), dtype=torch.uint8)
         if dist.get_backend() == "nccl":
-            t = t.cuda()
+            t = t.to(engine.torch_device)  # the rank's own GPU (the current device is per thread)
         dist.broadcast(t, src=0)
         ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
     L.check(lib.rmr_comm_init(engine.handle, ident, int(rank), int(world)))
@@ -153,6 +153,7 @@ def cabi_allreduce_check(engine, per_rank, rank, world, timeout_s=60.0):
 
     def work():
         try:
+            torch.cuda.set_device(engine.torch_device)  # a new thread starts on device 0
             init_cabi_comm(engine, rank, world)
             mine = torch.from_numpy(np.ascontiguousarray(per_rank[rank], np.int64)).to(engine.torch_device)
             cabi_allreduce_counts(engine, mine)

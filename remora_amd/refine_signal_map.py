@@ -101,6 +101,36 @@ def _fit_line(x, y):
     return np.linalg.lstsq(np.column_stack([np.ones_like(x), x]), y, rcond=None)[0]
 
 
+_BATCHED_LSTSQ_OK = None
+
+
+def _fit_lines(X, Y):
+    """`_fit_line` for every row of X, Y ([n, m] float64): (intercept, slope) [n, 2], bit for bit what the per-row
+    np.linalg.lstsq calls return.  numpy's lstsq is a thin wrapper around a LAPACK gufunc that broadcasts over leading
+    dimensions; calling it once on the stacked systems removes 16 us of Python per read (32 of the 106 ms a batch of
+    2048 reads with a refiner took).  The gufunc is private to numpy, so it is checked against the public function
+    on the first rows of the first call and abandoned for good if it ever disagrees."""
+    global _BATCHED_LSTSQ_OK
+    X, Y = np.asarray(X, np.float64), np.asarray(Y, np.float64)
+    n, m = X.shape
+    per_row = lambda lo: np.asarray([_fit_line(X[i], Y[i]) for i in range(lo, n)]).reshape(-1, 2)  # noqa: E731
+    if _BATCHED_LSTSQ_OK is False or n == 0:
+        return per_row(0)
+    try:
+        from numpy.linalg import _umath_linalg
+
+        A = np.stack([np.ones_like(X), X], axis=-1)
+        sol = _umath_linalg.lstsq(A, Y[..., None], np.finfo(np.float64).eps * max(m, 2), signature="ddd->ddid")[0][:, :2, 0]
+        if _BATCHED_LSTSQ_OK is None:
+            k = min(n, 4)
+            _BATCHED_LSTSQ_OK = bool(np.array_equal(sol[:k], np.asarray([_fit_line(X[i], Y[i]) for i in range(k)])))
+        if _BATCHED_LSTSQ_OK:
+            return sol
+    except Exception:  # noqa: BLE001 - a numpy without this private entry point: the public path is always there
+        _BATCHED_LSTSQ_OK = False
+    return per_row(0)
+
+
 def rescale_lstsq(dacs, levels, shift, scale):
     inter, slope = _fit_line((dacs - shift) / scale, levels)
     if slope == 0:
@@ -549,9 +579,10 @@ class SigMapRefiner:
         sig_q = quantiles(norm, torch.float64)
         lvl_q = quantiles(levels, torch.float32)
         shifts, scales = [], []
+        fits = _fit_lines(sig_q, lvl_q) if self.rough_rescale_method == ROUGH_RESCALE_LEAST_SQUARES else None
         for i, r in enumerate(reads):
-            if self.rough_rescale_method == ROUGH_RESCALE_LEAST_SQUARES:
-                inter, slope = _fit_line(sig_q[i], lvl_q[i])
+            if fits is not None:
+                inter, slope = fits[i]
                 sh, sc = (r.shift, r.scale) if slope == 0 else (r.shift - (r.scale * inter / slope), r.scale / slope)
             else:
                 sh, sc = theil_sen(sig_q[i], lvl_q[i], r.shift, r.scale)
