@@ -350,6 +350,17 @@ int rmr_refine_signal_maps(rmr_refiner *r, int64_t n_reads, const int16_t *dacs,
                            const int64_t *seq_to_sig, const int8_t *int_seq, const int64_t *seq_off,
                            const double *shift, const double *scale, int64_t *out_map, int32_t *status,
                            int mem);
+/* The two quantile vectors the rough re-scale fits its line through (SigMapRefiner.rough_rescale,
+ * src/remora/refine_signal_map.py:330-420: np.quantile of the normalised centre sample of every base and of the
+ * expected k-mer levels, clip_bases dropped at both ends of reads longer than 2 * clip_bases).  Reads laid out as
+ * above, DEVICE pointers; quants is a HOST array f64[n_quants] in [0, 1].  sig_q / lvl_q: device f64[n_reads][n_quants],
+ * bit-identical to numpy's "linear" quantiles of the float64 / float32 arrays.  status i32[n_reads] (device): 0 ok,
+ * 1 = read longer than the in-LDS sort holds (16384 kept bases; max_read_bases, the longest read of the batch or 0
+ * if unknown, sizes the sort), 2 = read without bases; rows of such reads are not written. */
+int rmr_rescale_quantiles(rmr_refiner *r, int64_t n_reads, const int16_t *dacs, const int64_t *sig_off,
+                          const int64_t *seq_to_sig, const int8_t *int_seq, const int64_t *seq_off,
+                          const double *shift, const double *scale, int64_t max_read_bases, int clip_bases,
+                          int n_quants, const double *quants, double *sig_q, double *lvl_q, int32_t *status);
 
 /* ---- measurement: HIP-event timing of every kernel launch on the engine stream ----------- */
 int rmr_profile_enable(rmr_engine *e, int on);

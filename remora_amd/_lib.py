@@ -89,6 +89,8 @@ SIGNATURES = {
     "rmr_refiner_destroy": (None, [c_vp]),
     "rmr_refine_status_message": (ctypes.c_char_p, [c_int]),
     "rmr_refine_signal_maps": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
+    "rmr_rescale_quantiles": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp,
+                                      c_vp, c_vp]),
     "rmr_profile_enable": (c_int, [c_vp, c_int]),
     "rmr_profile_reset": (c_int, [c_vp]),
     "rmr_profile_num_kernels": (c_int, []),

@@ -30,7 +30,7 @@ static const char *k_names[K_NUM] = {
     "chunk_fill", "front_sig", "front_seq", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
     "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
     "count_labels", "motif_scan", "vbz_decode", "refine_band", "refine_dp", "refine_dp_rowwise",
-    "fused_front"};
+    "fused_front", "rescale_quantiles"};
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
 
 }  // namespace rmr

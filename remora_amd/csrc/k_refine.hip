@@ -825,6 +825,107 @@ int launch_dp(rmr_refiner *rf, const RefineReads &dr, const RefineScratch &w, co
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// rough re-scale: the 19 quantiles of the normalised centre samples and of the expected levels of one read
+// (RemoraRead-level caller: src/remora/refine_signal_map.py:330-420, rough_rescale; np.quantile "linear")
+// ---------------------------------------------------------------------------------------
+// One block per read.  The kept bases (all of a read <= 2*clip bases long, else the middle n - 2*clip) are evaluated
+// into LDS, sorted there (bitonic network, +inf padding to a power of two) and the quantiles interpolated with
+// numpy's own two-sided formula (numpy/lib/_function_base_impl.py _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where
+// t >= 0.5; the difference b - a in the array's dtype).  Every product and sum is rounded on its own (fp contract
+// off: no FMAs) so the values equal numpy's bit for bit.
+template <typename T>
+__device__ __forceinline__ void lds_bitonic_sort(T *buf, int n_pad, int tid, int nt) {
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n_pad >> 1); t += nt) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // insert a 0 bit at position log2(j)
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const T a = buf[lo], b = buf[hi];
+                if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void lerp_quantiles(const T *buf, int cnt, const double *quants, int nq, double *out, int tid) {
+    if (tid < nq) {
+#pragma clang fp contract(off)  // hipcc contracts a * b + c into an FMA by default (and __dmul_rn / __dadd_rn are plain operators)
+        const double top = (double)(cnt - 1);
+        const double vi = top * quants[tid];
+        const double prev = floor(vi);
+        const double gamma = vi - prev;
+        int pi = (int)prev, ni = pi + 1;
+        if (vi >= top) pi = ni = cnt - 1;
+        const T lo = buf[pi], hi = buf[ni];
+        const T diff = hi - lo;  // in the array's own dtype, as numpy's subtract(b, a)
+        const double scaled_lo = (double)diff * gamma, scaled_hi = (double)diff * (1.0 - gamma);
+        const double res = gamma >= 0.5 ? (double)hi - scaled_hi : (double)lo + scaled_lo;
+        out[tid] = res;
+    }
+}
+
+__global__ __launch_bounds__(256) void rescale_quantiles_kernel(RefineReads a, const float *__restrict__ levels, int kmer_len,
+                                                                int center, int clip, int nq,
+                                                                const double *__restrict__ quants, int max_pad,
+                                                                double *__restrict__ sig_q, double *__restrict__ lvl_q,
+                                                                int32_t *__restrict__ status) {
+    extern __shared__ double rq_lds[];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int64_t q0 = a.seq_off[r];
+    const int n = (int)(a.seq_off[r + 1] - q0);
+    const bool clipped = clip > 0 && n > 2 * clip;
+    const int off = clipped ? clip : 0, cnt = clipped ? n - 2 * clip : n;
+    int n_pad = 2;
+    while (n_pad < cnt) n_pad <<= 1;
+    if (cnt < 1 || n_pad > max_pad) {  // empty read / longer than the LDS sort holds: the caller's general path
+        if (tid == 0) status[r] = cnt < 1 ? 2 : 1;
+        return;
+    }
+    if (tid == 0) status[r] = 0;
+    const int64_t *m = a.s2s + q0 + r;
+    const int16_t *dacs = a.dacs + a.sig_off[r];
+    const double shift = a.shift[r], scale = a.scale[r];
+    // normalised centre sample of every kept base, float64 ((dacs - shift) / scale as RemoraRead.sig evaluates it
+    // in float64 here: rough_rescale works on the float64 normalisation, refine_signal_map.py:330-352)
+    for (int j = tid; j < n_pad; j += 256) {
+        double v = __builtin_inf();
+        if (j < cnt) {
+            const int64_t mid = (m[off + j] + m[off + j + 1]) / 2;
+            v = ((double)dacs[mid] - shift) / scale;
+        }
+        rq_lds[j] = v;
+    }
+    __syncthreads();
+    lds_bitonic_sort(rq_lds, n_pad, tid, 256);
+    lerp_quantiles(rq_lds, cnt, quants, nq, sig_q + (size_t)r * nq, tid);
+    __syncthreads();
+    // expected level of every kept base (core.pyx:87-101), float32
+    float *lv = reinterpret_cast<float *>(rq_lds);
+    const int8_t *seq = a.int_seq + q0;
+    const int64_t kmax = ((int64_t)1 << (2 * kmer_len)) - 1;
+    for (int j = tid; j < n_pad; j += 256) {
+        float v = __builtin_inff();
+        if (j < cnt) {
+            const int pos = off + j - center;
+            v = 0.f;
+            if (pos >= 0 && pos + kmer_len <= n) {
+                int64_t idx = 0;
+                for (int k = 0; k < kmer_len; ++k) idx = idx * 4 + seq[pos + k];
+                v = levels[idx < 0 ? 0 : (idx > kmax ? kmax : idx)];
+            }
+        }
+        lv[j] = v;
+    }
+    __syncthreads();
+    lds_bitonic_sort(lv, n_pad, tid, 256);
+    lerp_quantiles(lv, cnt, quants, nq, lvl_q + (size_t)r * nq, tid);
+}
+
 }  // namespace
 }  // namespace rmr
 
@@ -1070,6 +1171,43 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
     RMR_HIP(hipStreamSynchronize(e->stream));
 #undef RMR_H2D
 #undef RMR_D2H
+    return 0;
+}
+
+
+int rmr_rescale_quantiles(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs, const int64_t *sig_off,
+                          const int64_t *seq_to_sig, const int8_t *int_seq, const int64_t *seq_off, const double *shift,
+                          const double *scale, int64_t max_read_bases, int clip_bases, int n_quants, const double *quants,
+                          double *sig_q, double *lvl_q, int32_t *status) {
+    if (!rf || !dacs || !sig_off || !seq_to_sig || !int_seq || !seq_off || !shift || !scale || !quants || !sig_q || !lvl_q ||
+        !status)
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_reads < 0 || n_reads > (int64_t)1 << 30) RMR_FAIL(RMR_ERR_INVALID, "bad n_reads");
+    if (n_quants < 1 || n_quants > 256 || clip_bases < 0) RMR_FAIL(RMR_ERR_INVALID, "bad n_quants / clip_bases");
+    for (int q = 0; q < n_quants; ++q)
+        if (!(quants[q] >= 0.0 && quants[q] <= 1.0)) RMR_FAIL(RMR_ERR_INVALID, "quantile %d outside [0, 1]", q);
+    if (n_reads == 0) return 0;
+    rmr_engine *e = rf->e;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    RMR_TRY(e->ensure(e->staging, 4096));
+    double *d_q = reinterpret_cast<double *>(e->staging.ptr);
+    RMR_HIP(hipMemcpyAsync(d_q, quants, (size_t)n_quants * 8, hipMemcpyHostToDevice, e->stream));
+    // LDS holds the kept bases of one read as float64, padded to a power of two: sized for the longest read the caller
+    // names (0: unknown), at most 16384 (128 KB); longer reads come back with status 1
+    const int cap = std::min(16384, std::max(64, tune_int("RMR_RESCALE_MAX_BASES", 16384)));
+    int max_pad = 64;
+    while (max_pad < cap && (max_read_bases <= 0 || max_pad < max_read_bases)) max_pad <<= 1;
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(rmr::rescale_quantiles_kernel)));
+    rmr::RefineReads dr{dacs, sig_off, seq_to_sig, seq_off, int_seq, shift, scale};
+    {
+        ProfScope ps(e, K_RESCALE_Q);
+        hipLaunchKernelGGL(rmr::rescale_quantiles_kernel, dim3((unsigned)n_reads), dim3(256), (size_t)max_pad * 8, e->stream,
+                           dr, rf->d_levels, rf->kmer_len, rf->center_idx, clip_bases, n_quants, d_q, max_pad, sig_q, lvl_q,
+                           status);
+        RMR_HIP(hipGetLastError());
+    }
+    RMR_HIP(hipStreamSynchronize(e->stream));
     return 0;
 }
 

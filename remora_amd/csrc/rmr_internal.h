@@ -63,6 +63,7 @@ enum KernelId {
     K_REFINE_DP,
     K_REFINE_ROWWISE,
     K_FUSED_FRONT,
+    K_RESCALE_Q,
     K_NUM
 };
 const char *kernel_name(int id);

@@ -14,6 +14,7 @@ What runs where:
     bit-identical results."""
 import ctypes
 import dataclasses
+import os
 from itertools import product
 
 import numpy as np
@@ -520,10 +521,51 @@ class SigMapRefiner:
 
     def rough_rescale_device(self, dr, reads, quants=np.arange(0.05, 1, 0.05), clip_bases=10):
         """`rough_rescale` for all reads of a `DeviceReads` batch: the per-base level lookup, the centre-sample
-        gather, the normalisation and the two sorts run on the GPU (torch tensor ops on the resident arrays,
-        float64 / float32 exactly as numpy evaluates them), the 19-point line fit of every read stays numpy on
-        the host - so the new (shift, scale) equal the per-read host method bit for bit.  Updates the reads and
-        `dr`."""
+        gather, the float64 normalisation, the two sorts and numpy's quantile interpolation run in one hand-written
+        kernel (one block per read, `rmr_rescale_quantiles`, csrc/k_refine.hip), the 19-point line fit of every
+        read stays LAPACK / numpy on the host - so the new (shift, scale) equal the per-read host method bit for
+        bit.  Updates the reads and `dr`."""
+        sig_q, lvl_q = self._device_quantiles(dr, np.asarray(quants, np.float64), int(clip_bases))
+        shifts, scales = [], []
+        fits = _fit_lines(sig_q, lvl_q) if self.rough_rescale_method == ROUGH_RESCALE_LEAST_SQUARES else None
+        for i, r in enumerate(reads):
+            if fits is not None:
+                inter, slope = fits[i]
+                sh, sc = (r.shift, r.scale) if slope == 0 else (r.shift - (r.scale * inter / slope), r.scale / slope)
+            else:
+                sh, sc = theil_sen(sig_q[i], lvl_q[i], r.shift, r.scale)
+            r.shift, r.scale = sh, sc
+            r._sig = None
+            shifts.append(float(sh))
+            scales.append(float(sc))
+        dr.set_scaling(shifts, scales)
+
+    def _device_quantiles(self, dr, quants, clip_bases):
+        """(sig_q, lvl_q) f64[n_reads][len(quants)] of a resident batch.  Reads longer than the kernel's in-LDS sort
+        holds (16384 kept bases) send the batch through `_device_quantiles_general`."""
+        import torch
+
+        nr = dr.n_reads
+        longest = int(np.diff(dr.seq_off).max()) if nr else 0
+        if nr == 0 or longest < 1 or os.environ.get("RMR_RESCALE_GENERAL") == "1":
+            return self._device_quantiles_general(dr, quants, clip_bases)
+        dev = self._device_refiner(dr.engine.device)
+        tdev = dr.s2s.device
+        sig_q = torch.empty((nr, quants.size), dtype=torch.float64, device=tdev)
+        lvl_q = torch.empty_like(sig_q)
+        status = torch.empty(nr, dtype=torch.int32, device=tdev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        q = np.ascontiguousarray(quants, np.float64)
+        L.check(dev._lib.rmr_rescale_quantiles(dev._h, nr, p(dr.dacs), p(dr.d_sig_off), p(dr.s2s), p(dr.iseq), p(dr.d_seq_off),
+                                                p(dr.shift), p(dr.scale), longest, clip_bases, q.size,
+                                                q.ctypes.data_as(ctypes.c_void_p), p(sig_q), p(lvl_q), p(status)))
+        if bool(status.any()):
+            return self._device_quantiles_general(dr, quants, clip_bases)
+        return sig_q.cpu().numpy(), lvl_q.cpu().numpy()
+
+    def _device_quantiles_general(self, dr, quants, clip_bases):
+        """The same quantiles with torch tensor ops on the resident arrays (float64 / float32 exactly as numpy
+        evaluates them): no bound on the read length; used for batches holding a read the kernel cannot sort in LDS."""
         import torch
 
         dev = dr.s2s.device
@@ -576,21 +618,7 @@ class SigMapRefiner:
             alt = hi.to(torch.float64) - diff.to(torch.float64) * (1 - gamma)
             return torch.where(gamma >= 0.5, alt, out).cpu().numpy()
 
-        sig_q = quantiles(norm, torch.float64)
-        lvl_q = quantiles(levels, torch.float32)
-        shifts, scales = [], []
-        fits = _fit_lines(sig_q, lvl_q) if self.rough_rescale_method == ROUGH_RESCALE_LEAST_SQUARES else None
-        for i, r in enumerate(reads):
-            if fits is not None:
-                inter, slope = fits[i]
-                sh, sc = (r.shift, r.scale) if slope == 0 else (r.shift - (r.scale * inter / slope), r.scale / slope)
-            else:
-                sh, sc = theil_sen(sig_q[i], lvl_q[i], r.shift, r.scale)
-            r.shift, r.scale = sh, sc
-            r._sig = None
-            shifts.append(float(sh))
-            scales.append(float(sc))
-        dr.set_scaling(shifts, scales)
+        return quantiles(norm, torch.float64), quantiles(levels, torch.float32)
 
     def refine_device_reads(self, dr, reads):
         """One DP pass (scale_iters 0 or 1 round of it) on reads that are already resident (`DeviceReads`):

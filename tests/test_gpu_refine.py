@@ -296,14 +296,28 @@ def test_refine_tiny_reads_and_device_pointers(torch_cuda, O):
             np.testing.assert_array_equal(got[mo[i] : mo[i + 1]], want[i])
 
 
+def _plain_read(rng, nb, idx=0):
+    from remora_amd.data_chunks import RemoraRead
+
+    seq = rng.integers(0, 4, nb)
+    m = np.concatenate([[0], np.cumsum(rng.integers(1 if nb > 3 else 2, 9, nb))]).astype(np.int64)
+    d = np.round(500 + 80 * rng.standard_normal(m[-1])).astype(np.int16)
+    return RemoraRead(dacs=d, shift=498.0 + nb % 3, scale=79.5, seq_to_sig_map=m, int_seq=seq, read_id=f"x{nb}_{idx}")
+
+
+@pytest.mark.parametrize("path", ["kernel", "general"])
 @pytest.mark.parametrize("method", ["least_squares", "theil_sen"])
-def test_rough_rescale_device_equals_host(torch_cuda, G, method):
-    """The batched GPU-side rough re-scale (level lookup, centre samples, sorts, numpy's quantile arithmetic)
+def test_rough_rescale_device_equals_host(torch_cuda, G, method, path, monkeypatch):
+    """The batched GPU-side rough re-scale (level lookup, centre samples, sorts, numpy's quantile arithmetic: the
+    hand-written rmr_rescale_quantiles kernel, and the torch formulation kept for reads too long for its LDS sort)
     returns bit-identical (shift, scale) to the per-read host method, for reads shorter and longer than the
-    2 x 10 clipped bases, and to the reference's values for the golden reads."""
+    2 x 10 clipped bases and at the powers of two of the sort, and to the reference's values for the golden reads."""
     from remora_amd.data_chunks import DeviceReads, RemoraRead
+    from remora_amd.engine import get_engine
     from remora_amd.refine_signal_map import SigMapRefiner
 
+    if path == "general":
+        monkeypatch.setenv("RMR_RESCALE_GENERAL", "1")
     ref = SigMapRefiner(_levels_array=G["kmer_levels"], center_idx=int(G["center_idx"]), do_rough_rescale=True,
                         rough_rescale_method=method)
     rng = np.random.default_rng(2)
@@ -311,17 +325,40 @@ def test_rough_rescale_device_equals_host(torch_cuda, G, method):
     for n in READS:
         reads.append(RemoraRead(dacs=G[f"{n}_dacs"], shift=505.0, scale=83.0, seq_to_sig_map=G[f"{n}_map"].copy(),
                                 int_seq=G[f"{n}_int_seq"], read_id=n))
-    for nb in (7, 20, 21, 33, 900):
-        seq = rng.integers(0, 4, nb)
-        m = np.concatenate([[0], np.cumsum(rng.integers(1, 9, nb))]).astype(np.int64)
-        d = np.round(500 + 80 * rng.standard_normal(m[-1])).astype(np.int16)
-        reads.append(RemoraRead(dacs=d, shift=498.0 + nb % 3, scale=79.5, seq_to_sig_map=m, int_seq=seq, read_id=f"x{nb}"))
+    # (2- and 3-base reads have no k-mer level at all: a zero Theil-Sen slope, which that method refuses on the host too)
+    for nb in ((2, 3) if method == "least_squares" else ()) + (7, 20, 21, 22, 33, 84, 85, 900, 1044, 1045, 5000, 8212, 8213):
+        reads.append(_plain_read(rng, nb))
+    eng = get_engine(0)
+    eng.profile_reset()
+    eng.profile_enable(True)
     want = [ref.rough_rescale(r.shift, r.scale, r.seq_to_sig_map, r.int_seq, r.dacs) for r in reads]
     dr = DeviceReads(reads)
     ref.rough_rescale_device(dr, reads)
+    eng.profile_enable(False)
+    assert ("rescale_quantiles" in eng.profile()) == (path == "kernel")
     for r, (sh, sc) in zip(reads, want):  # (a 7-base read has too few distinct quantiles for Theil-Sen: NaN on both sides)
         np.testing.assert_array_equal(np.array([r.shift, r.scale]), np.array([sh, sc]), err_msg=r.read_id)
     np.testing.assert_array_equal(dr.shift.cpu().numpy(), [w[0] for w in want])
     if method == "theil_sen":  # setting 1 of the golden flow is exactly this (no DP pass)
         for i, n in enumerate(READS):
             np.testing.assert_allclose([reads[i].shift, reads[i].scale], G[f"s1_{n}_shift_scale"], rtol=1e-12)
+
+
+def test_rough_rescale_device_long_read_takes_general_path(torch_cuda, G):
+    """A read with more kept bases than the kernel sorts in LDS (16384) is reported by status and the batch is
+    evaluated by the general formulation: same bits as the host method."""
+    from remora_amd.data_chunks import DeviceReads
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    ref = SigMapRefiner(_levels_array=G["kmer_levels"], center_idx=int(G["center_idx"]), do_rough_rescale=True)
+    rng = np.random.default_rng(5)
+    reads = [_plain_read(rng, nb, i) for i, nb in enumerate((16404, 300, 16405, 40000))]
+    want = [ref.rough_rescale(r.shift, r.scale, r.seq_to_sig_map, r.int_seq, r.dacs) for r in reads]
+    for keep in (slice(0, 2), slice(0, 4)):  # the first pair fits the kernel exactly (16404 - 20 = 2^14), the rest does not
+        sub = reads[keep]
+        for r in sub:
+            r.shift, r.scale = 498.0 + r.int_seq.size % 3, 79.5
+        dr = DeviceReads(sub)
+        ref.rough_rescale_device(dr, sub)
+        for r, (sh, sc) in zip(sub, want[keep]):
+            np.testing.assert_array_equal(np.array([r.shift, r.scale]), np.array([sh, sc]), err_msg=r.read_id)
