@@ -486,8 +486,22 @@ def side_legs(job, args, model_logits):
             pass
         torch.cuda.synchronize()
         tsb = time.perf_counter()
-        reads_leg = {"reads": nreads, "bases_per_read": 5000, "chunks_per_read": nchunks / nreads,
+        bf16_rate = None
+        if job.dtype == "fp32":  # the same reads through the plain-bf16 model of the same weights (3e-2 logit tolerance)
+            from remora_amd.model_util import model_from_state
+
+            mb = model_from_state(job.state, md, device=local, dtype="bf16")
+            call_reads_mods(rs, mb, mdr)
+            torch.cuda.synchronize()
+            tba = time.perf_counter()
+            for _ in range(3):
+                call_reads_mods(rs, mb, mdr)
+            torch.cuda.synchronize()
+            bf16_rate = 3 * nreads / (time.perf_counter() - tba)
+            del mb
+        reads_leg = {"reads": nreads, "bases_per_read": 5000, "chunks_per_read": nchunks / nreads, "model_dtype": job.dtype,
                      "batched_reads_per_s": 3 * nreads / (tb - ta), "batched_chunks_per_s": 3 * nchunks / (tb - ta),
+                     "batched_reads_per_s_bf16_model": bf16_rate,
                      "streamed_reads_per_s": 512 * len(stream_batches) / (tsb - tsa),
                      "single_read_api_reads_per_s": 32 / (t1b - t1a),
                      "note": f"call_reads_mods: one upload of the reads, GPU motif scan + geometry/fill + fused inference, logits back "
@@ -633,6 +647,7 @@ def main():
         # reads/sec: MEASURED from whole reads when that leg ran; the chunks/312 figure BASELINE.md §3.4 prescribes is kept beside it
         out["reads_per_sec_derived"] = rep["value"] / 312.0
         out["reads_per_sec"] = rl["batched_reads_per_s"] if rl else None
+        out["reads_per_sec_bf16_model"] = rl.get("batched_reads_per_s_bf16_model") if rl else None
         out["reads_per_sec_note"] = ("measured: call_reads_mods on 2048 synthetic 5 kb reads per call (reads_pipeline); "
                                      "reads_per_sec_derived = chunks/s / 312 CG sites per read (BASELINE.md §3.4)")
         if not args.no_cpu_baseline:

@@ -175,7 +175,10 @@ struct InRegs {
 #endif
 
 template <int K>
-__global__ __launch_bounds__(256, 2) void fused_front_kernel(FusedArgs a) {
+#ifndef RMR_FUSED_WAVES_EU
+#define RMR_FUSED_WAVES_EU 2
+#endif
+__global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CG = (4 * K + 7) / 8;                // 8-channel groups of a one-hot row
     constexpr int KS_SEQ1 = (5 * CG * 8 + 31) / 32;    // k-steps of seq_conv1

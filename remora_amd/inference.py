@@ -116,12 +116,12 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     if loaded and refiner.scale_iters == 0:
         refiner.refine_device_reads(dr, reads)  # one banded-DP pass on the resident arrays
     focus, foc_off = dr.motif_focus_bases(motifs)
-    counts = np.diff(foc_off)
     arrs, _ = _extract_device(dr, focus, foc_off, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
                               model_metadata["base_start_justify"], model_metadata["offset"])
     focus_host = focus.cpu().numpy() if int(foc_off[-1]) else np.zeros(0, np.int64)
-    for r, fb in zip(reads, np.split(focus_host, np.cumsum(counts)[:-1])):
-        r.focus_bases = fb
+    bounds = [int(x) for x in foc_off]  # per-read slices of the concatenated results (np.split costs 5 us a piece)
+    for i, r in enumerate(reads):
+        r.focus_bases = focus_host[bounds[i] : bounds[i + 1]]
     if len(arrs) == 0:
         return [(np.array([]), np.array([]), np.array([])) for _ in reads]
     out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
@@ -129,10 +129,10 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     pos = arrs.read_focus_bases.cpu().numpy()
     if return_mod_probs:
         out = softmax_axis1(out)[:, 1:].astype(np.float64)
-    cuts = np.cumsum(counts)[:-1]
-    res = []
-    for o, l, p in zip(np.split(out, cuts), np.split(arrs.labels, cuts), np.split(pos, cuts)):
-        res.append((o, l, p) if p.size else (np.array([]), np.array([]), np.array([])))
+    labels, res = arrs.labels, []
+    for i in range(len(reads)):
+        a, b = bounds[i], bounds[i + 1]
+        res.append((out[a:b], labels[a:b], pos[a:b]) if b > a else (np.array([]), np.array([]), np.array([])))
     return res
 
 

@@ -559,7 +559,7 @@ class SigMapRefiner:
         L.check(dev._lib.rmr_rescale_quantiles(dev._h, nr, p(dr.dacs), p(dr.d_sig_off), p(dr.s2s), p(dr.iseq), p(dr.d_seq_off),
                                                 p(dr.shift), p(dr.scale), longest, clip_bases, q.size,
                                                 q.ctypes.data_as(ctypes.c_void_p), p(sig_q), p(lvl_q), p(status)))
-        if bool(status.any()):
+        if status.cpu().numpy().any():
             return self._device_quantiles_general(dr, quants, clip_bases)
         return sig_q.cpu().numpy(), lvl_q.cpu().numpy()
 
@@ -628,7 +628,7 @@ class SigMapRefiner:
 
         dev = self._device_refiner(dr.engine.device)
         out = torch.empty_like(dr.s2s)
-        status = torch.zeros(max(dr.n_reads, 1), dtype=torch.int32, device=dr.s2s.device)
+        status = torch.empty(max(dr.n_reads, 1), dtype=torch.int32, device=dr.s2s.device)  # written for every read
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         L.check(dev._lib.rmr_refine_signal_maps(dev._h, dr.n_reads, p(dr.dacs), p(dr.d_sig_off), p(dr.s2s), p(dr.iseq),
                                                  p(dr.d_seq_off), p(dr.shift), p(dr.scale), p(out), p(status), L.MEM_DEVICE))
