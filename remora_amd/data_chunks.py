@@ -136,14 +136,32 @@ import threading
 _PINNED = threading.local()  # one staging buffer per thread (the streaming API stages in a worker thread)
 
 
-def _pinned_bytes(count):
-    """Grow-only pinned host staging buffer of this thread (pinned allocation is too slow to do per batch)."""
+def _pinned_bytes(count, slot=0):
+    """Grow-only pinned host staging buffer `slot` of this thread (pinned allocation is too slow to do per batch)."""
     torch = _torch()
-    buf = getattr(_PINNED, "buf", None)
+    bufs = getattr(_PINNED, "bufs", None)
+    if bufs is None:
+        bufs = _PINNED.bufs = {}
+    buf = bufs.get(slot)
     if buf is None or buf.numel() < count:
-        buf = torch.empty(max(int(count * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
-        _PINNED.buf = buf
+        buf = bufs[slot] = torch.empty(max(int(count * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
     return buf
+
+
+def _pinned_slot_async():
+    """(slot, event) for an upload that is NOT waited for by its issuer: two staging buffers of this thread take turns;
+    the event of a slot is that of the last upload out of it, to be waited for before the buffer is written again."""
+    torch = _torch()
+    st = getattr(_PINNED, "turn", None)
+    if st is None:
+        st = _PINNED.turn = {"next": 1, "events": {}}
+    slot = st["next"]
+    st["next"] = 3 - slot  # 1 <-> 2 (slot 0 is the synchronous buffer)
+    ev = st["events"].get(slot)
+    if ev is not None:
+        ev.synchronize()
+    ev = st["events"][slot] = torch.cuda.Event()
+    return slot, ev
 
 
 def _validated_int16_dacs(r):
@@ -169,8 +187,12 @@ class DeviceReads:
     and the chunk extraction.  All arrays travel in ONE pinned buffer / ONE copy (256-byte aligned segments);
     the device tensors are typed views of that allocation."""
 
-    def __init__(self, reads, engine=None):
+    def __init__(self, reads, engine=None, async_upload=False):
+        """`async_upload`: return once the copy is queued on the current torch stream (the staging buffer is one of two
+        that take turns); whoever uses the arrays calls `wait_ready()` first.  Lets a staging thread gather batch k+1
+        while batch k is still crossing PCIe."""
         torch = _torch()
+        self._ready = None
         self.engine = engine if engine is not None else get_engine()
         dev = self.engine.torch_device
         nr = len(reads)
@@ -189,7 +211,8 @@ class DeviceReads:
         for name, dt, cnt in segs:
             offs[name] = total
             total += (cnt * np.dtype(dt).itemsize + 255) & ~255
-        buf = _pinned_bytes(max(total, 256))
+        slot, ready = _pinned_slot_async() if async_upload else (0, None)
+        buf = _pinned_bytes(max(total, 256), slot)
         host = buf.numpy()
         view = {name: host[offs[name] : offs[name] + cnt * np.dtype(dt).itemsize].view(dt) for name, dt, cnt in segs}
         # the per-read arrays are gathered into the pinned buffer by native threads (rmr_pack_reads): the python loop
@@ -221,10 +244,20 @@ class DeviceReads:
         view["shift"][:] = [float(r.shift) for r in reads]
         view["scale"][:] = [float(r.scale) for r in reads]
         dbuf = buf[: max(total, 256)].to(dev, non_blocking=True)
-        torch.cuda.current_stream(dev).synchronize()  # the staging buffer is reused by the next batch
+        if ready is not None:
+            ready.record(torch.cuda.current_stream(dev))
+            self._ready = ready
+        else:
+            torch.cuda.current_stream(dev).synchronize()  # the staging buffer is reused by the next batch
         for name, dt, cnt in segs:
             nbytes = cnt * np.dtype(dt).itemsize
             setattr(self, name, dbuf[offs[name] : offs[name] + nbytes].view(getattr(torch, np.dtype(dt).name)))
+
+    def wait_ready(self):
+        """Host wait for an asynchronous upload (no-op otherwise)."""
+        if self._ready is not None:
+            self._ready.synchronize()
+            self._ready = None
 
     def set_scaling(self, shift, scale):
         torch = _torch()

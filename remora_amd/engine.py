@@ -27,11 +27,14 @@ class Engine:
         if not torch.cuda.is_available():
             raise RemoraError("no GPU visible: remora_amd has no CPU fallback")
         self.device = int(device)
+        self.stream_ptr = None  # the borrowed HIP stream (None: the engine owns a private one)
         h = ctypes.c_void_p()
         if stream is not None:
+            self.stream_ptr = int(stream)
             L.check(lib.rmr_engine_create(self.device, ctypes.c_void_p(stream), L.ENGINE_USE_STREAM, ctypes.byref(h)))
         elif use_torch_stream:
             s = torch.cuda.current_stream(self.device).cuda_stream
+            self.stream_ptr = int(s)
             L.check(lib.rmr_engine_create(self.device, ctypes.c_void_p(s), L.ENGINE_USE_STREAM, ctypes.byref(h)))
         else:
             L.check(lib.rmr_engine_create(self.device, None, L.ENGINE_OWN_STREAM, ctypes.byref(h)))
@@ -56,6 +59,18 @@ class Engine:
 
     def synchronize(self):
         L.check(self._lib.rmr_engine_synchronize(self._h))
+
+    def wait_submitted(self):
+        """Block until the work submitted to the engine's stream SO FAR is done (an event, not a stream drain: work
+        another thread queues behind it is not waited for).  A caller whose torch current stream is not the engine's
+        needs this before it copies an asynchronous result."""
+        torch = _torch()
+        if self.stream_ptr is None:
+            return self.synchronize()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(self.stream_ptr, device=self.torch_device) if self.stream_ptr else
+                  torch.cuda.default_stream(self.torch_device))
+        ev.synchronize()
 
     def set_subbatch(self, chunks):
         L.check(self._lib.rmr_engine_set_subbatch(self._h, int(chunks)))
@@ -96,6 +111,19 @@ def get_engine(device=None):
         if idx not in _engines:
             _engines[idx] = Engine(idx, use_torch_stream=True)
         return _engines[idx]
+
+
+_prep_engines = {}
+
+
+def get_prep_engine(device):
+    """A second engine (own non-blocking stream) on the GPU of `device`'s process-wide engine: read staging, motif scan
+    and chunk extraction of one sub-batch run on it while the inference of another occupies the main engine's stream."""
+    idx = get_engine(device).device
+    with _engines_lock:
+        if idx not in _prep_engines:
+            _prep_engines[idx] = Engine(idx, use_torch_stream=False)
+        return _prep_engines[idx]
 
 
 def _ptr(x):

@@ -81,6 +81,66 @@ def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=F
             cur = nxt
 
 
+def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
+    """A large batch walked in sub-batches on three threads: one stages (gather into pinned memory + upload on its own
+    stream), two alternate over the staged sub-batches (motif scan, extraction, inference, per-read split), so that the
+    kernels of one sub-batch run under the host work of its neighbours.  The engine serialises the GPU calls (one
+    mutex per engine); every C call and every copy releases the GIL.  Results are those of the one-batch path, in
+    read order.  At most four sub-batches are resident at a time.  (With a signal-mapping refiner the batch stays
+    whole: the banded DP of a call costs one read's latency whatever the batch size.)"""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .data_chunks import DeviceReads
+    from .engine import get_prep_engine
+
+    torch = _torch()
+    engine = getattr(model, "engine", None)
+    tdev = engine.torch_device if engine is not None else None
+    # extraction runs on a second engine (own stream): its small kernels and their host round trips do not queue behind
+    # the inference of the neighbouring sub-batch on the model's stream
+    prep = get_prep_engine(engine.device if engine is not None else None)
+    slots = threading.BoundedSemaphore(4)
+    upload = []
+
+    def stage(part):
+        slots.acquire()
+        if not upload:
+            upload.append(torch.cuda.Stream(device=tdev))
+        with torch.cuda.stream(upload[0]):
+            return DeviceReads(part, prep)  # synchronises the upload stream before returning
+
+    streams = {}
+
+    def work(part, staged):
+        try:
+            # a torch stream per worker: its copies (.cpu() / .to(device)) then wait for this sub-batch's work only, not
+            # for the neighbour's inference on the model's stream
+            me = threading.get_ident()
+            if me not in streams:
+                streams[me] = torch.cuda.Stream(device=tdev)
+            with torch.cuda.stream(streams[me]):
+                return call_reads_mods(part, model, model_metadata, return_mod_probs, device_reads=staged.result())
+        finally:
+            slots.release()
+
+    # short first sub-batches: the GPU starts after the staging of `sub / 4` reads instead of `sub`
+    cuts, pos = [], 0
+    for size in (max(1, sub // 4), max(1, sub // 2)):
+        cuts.append((pos, pos + size))
+        pos += size
+    while pos < len(reads):
+        cuts.append((pos, min(pos + sub, len(reads))))
+        pos += sub
+    parts = [reads[a:b] for a, b in cuts]
+    out = []
+    with ThreadPoolExecutor(max_workers=1) as stager, ThreadPoolExecutor(max_workers=2) as workers:
+        done = [workers.submit(work, part, stager.submit(stage, part)) for part in parts]
+        for f in done:
+            out.extend(f.result())
+    return out
+
+
 def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device_reads=None):
     """Batched form of call_read_mods for a list of RemoraRead objects: the reads are uploaded once, then the
     (optional) signal-mapping refinement, the motif scan, the chunk extraction and the fused inference all run
@@ -96,21 +156,14 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     loaded = refiner is not None and getattr(refiner, "is_loaded", False)
     sub = int(os.environ.get("RMR_READS_SUBBATCH", "512"))
     if device_reads is None and not loaded and sub > 0 and len(reads) >= 2 * sub:
-        # a large batch is walked in sub-batches whose host staging (gather into pinned memory + upload, worker thread,
-        # own stream) runs under the GPU work of the previous sub-batch: same results, the upload leaves the critical path.
-        # (With a signal-mapping refiner the batch stays whole: the banded DP of a call costs one read's latency whatever
-        # the batch size.)
-        out = []
-        for _, res in iter_call_reads_mods((reads[i : i + sub] for i in range(0, len(reads), sub)), model, model_metadata,
-                                           return_mod_probs):
-            out.extend(res)
-        return out
+        return _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs)
     if loaded and refiner.scale_iters > 0:
         for err in refiner.refine_reads(reads):  # DP rounds interleaved with host re-scaling
             if err is not None:
                 raise err
     dr = device_reads if device_reads is not None and not (loaded and refiner.scale_iters > 0) else \
         DeviceReads(reads, getattr(model, "engine", None))
+    dr.wait_ready()
     if loaded and refiner.scale_iters <= 0 and refiner.do_rough_rescale:
         refiner.rough_rescale_device(dr, reads)  # sorts + gathers on the GPU, 19-point fits on the host
     if loaded and refiner.scale_iters == 0:
@@ -125,6 +178,8 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     if len(arrs) == 0:
         return [(np.array([]), np.array([]), np.array([])) for _ in reads]
     out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
+    if hasattr(model, "engine"):
+        model.engine.wait_submitted()  # the copies below may run on another stream than the engine's (pipelined callers)
     out = out.cpu().numpy()
     pos = arrs.read_focus_bases.cpu().numpy()
     if return_mod_probs:
