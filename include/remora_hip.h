@@ -260,6 +260,10 @@ typedef struct {
     const int64_t *focus_bases; /* concatenated, read-local */
     const int64_t *focus_off;   /* [n_reads+1] */
     int32_t cc_before, cc_after, kb, ka, base_start_justify, offset;
+    /* optional (all three or NULL): HOST copies of sig_off / seq_off / focus_off for callers whose arrays are device
+     * memory - the library needs the offsets on the host (launch sizes, staging) and otherwise fetches them with three
+     * small device-to-host copies per call (about 60 us of a single-read call) */
+    const int64_t *host_sig_off, *host_seq_off, *host_focus_off;
 } rmr_reads;
 
 int rmr_chunk_geometry(rmr_engine *e, const rmr_reads *reads, float *sig_out, int64_t *geo,

@@ -45,6 +45,7 @@ class Reads(ctypes.Structure):
         ("focus_bases", c_vp), ("focus_off", c_vp),
         ("cc_before", ctypes.c_int32), ("cc_after", ctypes.c_int32), ("kb", ctypes.c_int32),
         ("ka", ctypes.c_int32), ("base_start_justify", ctypes.c_int32), ("offset", ctypes.c_int32),
+        ("host_sig_off", c_vp), ("host_seq_off", c_vp), ("host_focus_off", c_vp),  # optional, see include/remora_hip.h
     ]
 
 

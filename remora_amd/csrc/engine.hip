@@ -957,17 +957,25 @@ int read_offsets_host(rmr_engine *e, const rmr_reads *r, int mem, std::vector<in
         memcpy(sig_off.data(), r->sig_off, n1 * 8);
         memcpy(seq_off.data(), r->seq_off, n1 * 8);
         memcpy(foc_off.data(), r->focus_off, n1 * 8);
+    } else if (r->host_sig_off && r->host_seq_off && r->host_focus_off) {
+        // the caller kept host copies of the offsets: three small device-to-host copies (and their syncs) saved per call
+        memcpy(sig_off.data(), r->host_sig_off, n1 * 8);
+        memcpy(seq_off.data(), r->host_seq_off, n1 * 8);
+        memcpy(foc_off.data(), r->host_focus_off, n1 * 8);
     } else {
         RMR_HIP(hipMemcpy(sig_off.data(), r->sig_off, n1 * 8, hipMemcpyDeviceToHost));
         RMR_HIP(hipMemcpy(seq_off.data(), r->seq_off, n1 * 8, hipMemcpyDeviceToHost));
         RMR_HIP(hipMemcpy(foc_off.data(), r->focus_off, n1 * 8, hipMemcpyDeviceToHost));
     }
+    for (size_t i = 0; i + 1 < n1; ++i)
+        if (sig_off[i + 1] < sig_off[i] || seq_off[i + 1] < seq_off[i] || foc_off[i + 1] < foc_off[i])
+            RMR_FAIL(RMR_ERR_INVALID, "offsets of read %zu are not increasing", i);
+    if (sig_off[0] != 0 || seq_off[0] != 0 || foc_off[0] != 0) RMR_FAIL(RMR_ERR_INVALID, "offsets must start at 0");
     return 0;
 }
 
-int stage_reads(rmr_engine *e, Stage &st, const rmr_reads *r, int mem, bool need_dacs, DevReads *o) {
-    std::vector<int64_t> sig_off, seq_off, foc_off;
-    RMR_TRY(read_offsets_host(e, r, mem, sig_off, seq_off, foc_off));
+int stage_reads(rmr_engine *e, Stage &st, const rmr_reads *r, int mem, bool need_dacs, const std::vector<int64_t> &sig_off,
+                const std::vector<int64_t> &seq_off, const std::vector<int64_t> &foc_off, DevReads *o) {
     const int64_t nr = r->n_reads;
     o->total_sig = sig_off[nr];
     o->total_bases = seq_off[nr];
@@ -1027,7 +1035,7 @@ int rmr_chunk_geometry(rmr_engine *e, const rmr_reads *reads, float *sig_out, in
     Stage st{e};
     RMR_TRY(st.init(reads_stage_bytes(reads, ts, tb, nc) + Stage::pad(ts * 4) + Stage::pad(nc * 48) + 4096));
     DevReads dr;
-    RMR_TRY(stage_reads(e, st, reads, mem, true, &dr));
+    RMR_TRY(stage_reads(e, st, reads, mem, true, so, qo, fo, &dr));
     int *dmax = st.take<int>(4);
     RMR_HIP(hipMemsetAsync(dmax, 0, 16, e->stream));
     float *dsig = sig_out;
@@ -1066,7 +1074,7 @@ int rmr_chunk_fill(rmr_engine *e, const rmr_reads *reads, const float *sig, cons
                     Stage::pad((size_t)nc * L * 4) + Stage::pad((size_t)nc * seq_w) +
                     Stage::pad((size_t)nc * map_w * 2) + Stage::pad(nc * 2) + Stage::pad(nc * 8) + 8192));
     DevReads dr;
-    RMR_TRY(stage_reads(e, st, reads, mem, false, &dr));
+    RMR_TRY(stage_reads(e, st, reads, mem, false, so, qo, fo, &dr));
     if (mem == RMR_MEM_DEVICE)
         return launch_fill(e, dr.d, nc, dr.chunk_read, sig, geo, signal, seqs, seq_w, maps, map_w, lens,
                            read_focus_bases);

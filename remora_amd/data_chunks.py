@@ -321,6 +321,9 @@ def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_
                  dr.d_seq_off.data_ptr(), dr.shift.data_ptr(), dr.scale.data_ptr(), focus.data_ptr(),
                  d_foc_off.data_ptr(), int(chunk_context[0]), int(chunk_context[1]),
                  int(kmer_context_bases[0]), int(kmer_context_bases[1]), int(bool(base_start_justify)), int(offset))
+    h_foc = np.ascontiguousarray(foc_off, np.int64)
+    if dr.sig_off.dtype == np.int64 and dr.seq_off.dtype == np.int64:  # host copies of the offsets: no fetch per call
+        rs.host_sig_off, rs.host_seq_off, rs.host_focus_off = dr.sig_off.ctypes.data, dr.seq_off.ctypes.data, h_foc.ctypes.data
     L_chunk = int(chunk_context[0]) + int(chunk_context[1])
     sig = torch.empty(max(int(dr.sig_off[-1]), 1), dtype=torch.float32, device=dev)
     geo = torch.empty((max(n_chunks, 1), 6), dtype=torch.int64, device=dev)

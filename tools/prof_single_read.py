@@ -34,3 +34,16 @@ for r in rs:
     call_read_mods(r, model, md)
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+from remora_amd.engine import get_engine
+
+eng = get_engine(0)
+eng.profile_reset()
+eng.profile_enable(True)
+for r in rs[:32]:
+    call_read_mods(r, model, md)
+eng.profile_enable(False)
+tot = 0.0
+for k, (ms, n) in eng.profile().items():
+    print(f"  {k:18s} {ms / 32 * 1e3:8.1f} us per read  x{n / 32:.1f}")
+    tot += ms
+print("  kernel sum per read (us)", tot / 32 * 1e3)
