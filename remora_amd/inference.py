@@ -81,13 +81,19 @@ def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=F
             cur = nxt
 
 
+_PIPE = {}  # GPU index -> the pipeline's torch streams (upload, 2 workers) and its two thread pools
+_PIPE_LOCK = __import__("threading").Lock()
+
+
 def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
     """A large batch walked in sub-batches on three threads: one stages (gather into pinned memory + upload on its own
     stream), two alternate over the staged sub-batches (motif scan, extraction, inference, per-read split), so that the
     kernels of one sub-batch run under the host work of its neighbours.  The engine serialises the GPU calls (one
     mutex per engine); every C call and every copy releases the GIL.  Results are those of the one-batch path, in
-    read order.  At most four sub-batches are resident at a time.  (With a signal-mapping refiner the batch stays
-    whole: the banded DP of a call costs one read's latency whatever the batch size.)"""
+    read order.  At most four sub-batches are resident at a time.  A single-pass signal-mapping refiner (scale_iters
+    <= 0) can run per sub-batch inside the workers (opt-in, see call_reads_mods); iterative re-scaling (scale_iters > 0)
+    rewrites the reads on the host first and keeps the batch whole."""
+    import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
 
@@ -100,28 +106,39 @@ def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_pro
     # extraction runs on a second engine (own stream): its small kernels and their host round trips do not queue behind
     # the inference of the neighbouring sub-batch on the model's stream
     prep = get_prep_engine(engine.device if engine is not None else None)
+    refiner = model_metadata.get("sig_map_refiner")
+    if refiner is not None and getattr(refiner, "is_loaded", False):
+        refiner._device_refiner(prep.device)  # created once, here, not by whichever worker comes first
     slots = threading.BoundedSemaphore(4)
-    upload = []
+    # the three torch streams and the threads are made once per GPU: torch's caching allocator keeps its free blocks per
+    # stream (fresh streams on every call would turn every allocation of the call into a hipMalloc) and the stager's
+    # pinned buffers belong to its thread
+    key = prep.device
+    with _PIPE_LOCK:
+        if key not in _PIPE:
+            _PIPE[key] = dict(streams=[torch.cuda.Stream(device=tdev) for _ in range(3)],
+                              stager=ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmr-stage"),
+                              workers=ThreadPoolExecutor(max_workers=2, thread_name_prefix="rmr-work"))
+        pipe = _PIPE[key]
+    upload = pipe["streams"][0]
+    free_streams = queue.SimpleQueue()
+    for st in pipe["streams"][1:]:
+        free_streams.put(st)
 
     def stage(part):
         slots.acquire()
-        if not upload:
-            upload.append(torch.cuda.Stream(device=tdev))
-        with torch.cuda.stream(upload[0]):
-            return DeviceReads(part, prep)  # synchronises the upload stream before returning
-
-    streams = {}
+        with torch.cuda.stream(upload):
+            return DeviceReads(part, prep, async_upload=True)  # the worker waits for the copy (wait_ready)
 
     def work(part, staged):
+        # a torch stream per worker: its copies (.cpu() / .to(device)) then wait for this sub-batch's work only, not
+        # for the neighbour's inference on the model's stream
+        mine = free_streams.get()
         try:
-            # a torch stream per worker: its copies (.cpu() / .to(device)) then wait for this sub-batch's work only, not
-            # for the neighbour's inference on the model's stream
-            me = threading.get_ident()
-            if me not in streams:
-                streams[me] = torch.cuda.Stream(device=tdev)
-            with torch.cuda.stream(streams[me]):
+            with torch.cuda.stream(mine):
                 return call_reads_mods(part, model, model_metadata, return_mod_probs, device_reads=staged.result())
         finally:
+            free_streams.put(mine)
             slots.release()
 
     # short first sub-batches: the GPU starts after the staging of `sub / 4` reads instead of `sub`
@@ -134,10 +151,15 @@ def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_pro
         pos += sub
     parts = [reads[a:b] for a, b in cuts]
     out = []
-    with ThreadPoolExecutor(max_workers=1) as stager, ThreadPoolExecutor(max_workers=2) as workers:
-        done = [workers.submit(work, part, stager.submit(stage, part)) for part in parts]
-        for f in done:
+    done = [pipe["workers"].submit(work, part, pipe["stager"].submit(stage, part)) for part in parts]
+    err = None
+    for f in done:  # every sub-batch is waited for, also after a failure: nothing of this call keeps running behind it
+        try:
             out.extend(f.result())
+        except Exception as e:  # noqa: BLE001
+            err = err or e
+    if err is not None:
+        raise err
     return out
 
 
@@ -155,7 +177,10 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     refiner = model_metadata.get("sig_map_refiner")
     loaded = refiner is not None and getattr(refiner, "is_loaded", False)
     sub = int(os.environ.get("RMR_READS_SUBBATCH", "512"))
-    if device_reads is None and not loaded and sub > 0 and len(reads) >= 2 * sub:
+    # with a loaded refiner the batch stays whole by default: the banded DP of a call costs one read's latency whatever the
+    # batch size (18 ms for 2048 or for 512 reads of 5 kb), so sub-batches multiply it (RMR_READS_PIPELINE_REFINER=1 opts in)
+    piped_refiner = loaded and refiner.scale_iters <= 0 and os.environ.get("RMR_READS_PIPELINE_REFINER") == "1"
+    if device_reads is None and (not loaded or piped_refiner) and sub > 0 and len(reads) >= 2 * sub:
         return _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs)
     if loaded and refiner.scale_iters > 0:
         for err in refiner.refine_reads(reads):  # DP rounds interleaved with host re-scaling

@@ -362,3 +362,41 @@ def test_rough_rescale_device_long_read_takes_general_path(torch_cuda, G):
         ref.rough_rescale_device(dr, sub)
         for r, (sh, sc) in zip(sub, want[keep]):
             np.testing.assert_array_equal(np.array([r.shift, r.scale]), np.array([sh, sc]), err_msg=r.read_id)
+
+
+def test_call_reads_mods_pipelined_with_refiner_equals_one_batch(torch_cuda, monkeypatch):
+    """With a single-pass refiner (rough re-scale + one DP pass) a large batch can be walked in sub-batches by worker
+    threads (inference._call_reads_mods_pipelined, opt-in: the DP is latency-bound, see call_reads_mods); calls, refined mappings and new scalings must be those of the
+    one-batch path, bit for bit."""
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_reads_mods
+    from remora_amd.model_util import model_from_state
+    from remora_amd.refine_signal_map import SigMapRefiner
+
+    rng = np.random.default_rng(77)
+    k, center = 5, 2
+    table = rng.normal(0, 1, 4**k).astype(np.float32)
+    base = [_random_read(rng, table, k, center, int(rng.integers(200, 900))) for i in range(40)]
+    refiner = SigMapRefiner(_levels_array=table, center_idx=center, do_rough_rescale=True, scale_iters=0)
+    md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)], mod_bases=["m"], mod_long_names=["5mC"],
+              can_base="C", base_start_justify=False, offset=0, sig_map_refiner=refiner)
+    model = model_from_state(synth.synth_state("conv_lstm", 64, 9, 2, seed=3), md, device=0)
+
+    def fresh():
+        return [RemoraRead(dacs=base[i % 40][0], shift=400.0 + i % 3, scale=60.0, seq_to_sig_map=base[i % 40][1].copy(),
+                           int_seq=base[i % 40][2], read_id=f"p{i}") for i in range(300)]
+
+    monkeypatch.setenv("RMR_READS_SUBBATCH", "0")
+    ra = fresh()
+    whole = call_reads_mods(ra, model, md)
+    monkeypatch.setenv("RMR_READS_SUBBATCH", "64")
+    monkeypatch.setenv("RMR_READS_PIPELINE_REFINER", "1")
+    rb = fresh()
+    piped = call_reads_mods(rb, model, md)
+    assert len(whole) == len(piped) == 300 and sum(r[2].size for r in whole) > 1000
+    assert sum(not np.array_equal(x.seq_to_sig_map, base[i % 40][1]) for i, x in enumerate(ra)) > 200  # the DP moved the maps
+    for a, b, x, y in zip(whole, piped, ra, rb):
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+        assert (x.shift, x.scale) == (y.shift, y.scale)
+        np.testing.assert_array_equal(x.seq_to_sig_map, y.seq_to_sig_map)
