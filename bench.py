@@ -527,14 +527,15 @@ def side_legs(job, args, model_logits):
                                    int_seq=base[i % 64][2], read_id=f"lv{i}") for i in range(nref)]
 
             call_reads_mods(fresh(), model, mdf)  # warm-up (also creates the device refiner)
-            rs2 = fresh()
+            batches = [fresh() for _ in range(3)]  # refinement rewrites the reads: a fresh copy per timed call
             torch.cuda.synchronize()
             ta = time.perf_counter()
-            call_reads_mods(rs2, model, mdf)
+            for rs2 in batches:
+                call_reads_mods(rs2, model, mdf)
             torch.cuda.synchronize()
             tb = time.perf_counter()
             refine_leg["reads_pipeline_with_refiner"] = {
-                "reads": nref, "batched_reads_per_s": nref / (tb - ta),
+                "reads": nref, "calls": 3, "batched_reads_per_s": 3 * nref / (tb - ta),
                 "note": "call_reads_mods with a loaded SigMapRefiner (do_rough_rescale, scale_iters=0, dwell_penalty)"}
         out["refine_signal_map"] = refine_leg
         out["vbz_decode"] = bench_vbz.measure(n_rows=4096, row_samples=102400, steps=3, warmup=1, cpu_rows=8, device=local)

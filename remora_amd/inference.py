@@ -169,7 +169,7 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     on the resident arrays (the reference processes reads one by one in Python,
     src/remora/inference.py:62-137, 661-712).  Returns a list of per-read (nn_out | probs, labels, pos) tuples;
     pos ascending within a read.  `read.focus_bases` is left holding the read's motif hits."""
-    from .data_chunks import DeviceReads, _extract_device
+    from .data_chunks import DeviceReads, _extract_device, device_to_numpy
 
     if len(reads) == 0:
         return []
@@ -196,7 +196,7 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     focus, foc_off = dr.motif_focus_bases(motifs)
     arrs, _ = _extract_device(dr, focus, foc_off, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
                               model_metadata["base_start_justify"], model_metadata["offset"])
-    focus_host = focus.cpu().numpy() if int(foc_off[-1]) else np.zeros(0, np.int64)
+    focus_host = device_to_numpy(focus) if int(foc_off[-1]) else np.zeros(0, np.int64)
     bounds = [int(x) for x in foc_off]  # per-read slices of the concatenated results (np.split costs 5 us a piece)
     for i, r in enumerate(reads):
         r.focus_bases = focus_host[bounds[i] : bounds[i + 1]]
@@ -205,8 +205,8 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
     if hasattr(model, "engine"):
         model.engine.wait_submitted()  # the copies below may run on another stream than the engine's (pipelined callers)
-    out = out.cpu().numpy()
-    pos = arrs.read_focus_bases.cpu().numpy()
+    out = device_to_numpy(out)
+    pos = device_to_numpy(arrs.read_focus_bases)
     if return_mod_probs:
         out = softmax_axis1(out)[:, 1:].astype(np.float64)
     labels, res = arrs.labels, []

@@ -635,8 +635,10 @@ class SigMapRefiner:
         for st in status[: dr.n_reads].cpu().numpy():
             if st != 0:
                 raise RemoraError(dev.status_message(st))
+        from .data_chunks import device_to_numpy
+
         dr.s2s = out
-        host = out.cpu().numpy()
+        host = device_to_numpy(out)
         mo = dr.seq_off + np.arange(dr.n_reads + 1)
         for i, r in enumerate(reads):
             r.seq_to_sig_map = host[mo[i] : mo[i + 1]].astype(np.asarray(r.seq_to_sig_map).dtype, copy=False)

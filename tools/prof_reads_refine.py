@@ -14,11 +14,11 @@ md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)],
           can_base="C", base_start_justify=False, offset=0, sig_map_refiner=refiner)
 model = model_from_state(st, md, device=0)
 def fresh():
-    return [RemoraRead(dacs=base[i % 64][0], shift=400.0, scale=60.0, seq_to_sig_map=base[i % 64][1].copy(), int_seq=base[i % 64][2]) for i in range(512)]
+    return [RemoraRead(dacs=base[i % 64][0], shift=400.0, scale=60.0, seq_to_sig_map=base[i % 64][1].copy(), int_seq=base[i % 64][2]) for i in range(2048)]
 call_reads_mods(fresh(), model, md)
 torch.cuda.synchronize()
 rs = fresh()
 t = time.perf_counter(); call_reads_mods(rs, model, md); torch.cuda.synchronize(); print("one batch", time.perf_counter() - t)
 rs = fresh()
 pr = cProfile.Profile(); pr.enable(); call_reads_mods(rs, model, md); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
