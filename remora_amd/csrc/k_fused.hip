@@ -67,8 +67,17 @@ struct FusedArgs {
 // bits: 1 S0 loads, 2 S1a (sig_conv1 / covering base / codes), 4 S1b one-hot, 8 S2, 16 S3, 32 S4, 64 swish -> identity
 #ifdef RMR_TIMING_ABLATIONS
 #define ABL(bit) (a.abl & (bit))
+// stage clock of the experiment build (RMR_FUSED_STAGE_CLOCK=1): shader-clock time every wave spends between the
+// marks of an iteration, summed over iterations and blocks per wave index -> g_stage_clock[wave][mark]
+__device__ unsigned long long g_stage_clock[4][16];
+#define TS_DECL unsigned long long ts_prev = __builtin_readcyclecounter(), ts_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define TS(i) do { if (a.abl & 0x1000) { const unsigned long long t_ = __builtin_readcyclecounter(); ts_acc[i] += t_ - ts_prev; ts_prev = t_; } } while (0)
+#define TS_FLUSH do { if ((a.abl & 0x1000) && lane == 0) for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_stage_clock[w][i_], ts_acc[i_]); } while (0)
 #else
 #define ABL(bit) 0
+#define TS_DECL
+#define TS(i)
+#define TS_FLUSH
 #endif
 
 __device__ __forceinline__ int fdiv(int x, FastDiv d) { return (int)(((float)x + 0.5f) * d.inv); }
@@ -266,12 +275,15 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     __syncthreads();  // the zero fill is done before the first inputs land
     store_inputs(fetch_inputs(blockIdx.x));
 
+    TS_DECL;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        TS(9);
         __syncthreads();  // inputs of this iteration are in LDS; merge_conv1 of the previous one has read CAT (OH aliases it)
         // A fragments of the two M = 16 layers: fetched (L2-resident, 8 KB) at the top of every iteration and dead
         // after S2, so that they do not occupy 32 VGPRs while merge_conv1 runs
+        TS(0);
         if (!RMR_FUSED_RES_SMALL) load_small();
         // ---- S1: sig_conv1 (VALU, fp32) -> SIG1;  k-mer one-hot rows -> OH ----
         const int n_s1a = ABL(2) ? 0 : nch;
@@ -326,7 +338,9 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 *reinterpret_cast<uint4 *>(dst + (size_t)cg * a.oh_plane) = v;
             }
         }
+        TS(1);
         __syncthreads();
+        TS(2);
         // ---- S2: sig_conv2 and seq_conv1 (M = 16): the waves split the column-tile pairs ----
         {
             // (biases are fetched per stage: L1-resident, and not worth 20 VGPRs for the whole block lifetime)
@@ -377,8 +391,10 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             }
         }
         // A fragments of sig_conv3 / seq_conv2 (this wave's 16 output channels): on their way while the block gathers
+        TS(3);
         if (!RMR_FUSED_RES_MID) load_mid();
         __syncthreads();
+        TS(4);
         // ---- S3: sig_conv3 and seq_conv2 (stride 3, M = 64: wave w = channels 16w..16w+15) -> CAT ----
         {
             const int ncols = nch * a.P3;
@@ -416,9 +432,11 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         // regions were last read in S1)
         // (vmcnt retires in order: the bias of S4 is requested BEFORE the prefetch so that waiting for it does not wait
         //  for the prefetch)
+        TS(5);
         const f32x4 b_m1 = *reinterpret_cast<const f32x4 *>(a.b_merge1 + 16 * w + 4 * q);
         const InRegs next_in = fetch_inputs(it + gridDim.x);
         __syncthreads();
+        TS(6);
         // ---- S4: merge_conv1 (K = 5 taps x 128 channels) -> x, bf16 channel-last in HBM ----
         {
             const int ncols = nch * a.T;
@@ -440,8 +458,11 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack(acc1, ABL(64), 0.6931471805599453f);
             }
         }
+        TS(7);
         store_inputs(next_in);
+        TS(8);
     }
+    TS_FLUSH;
 }
 
 bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
@@ -496,6 +517,14 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);
     a.d_maxlen = make_fastdiv(a.maxlen);
     a.abl = tune_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+#ifdef RMR_TIMING_ABLATIONS
+    const bool stage_clock = tune_int("RMR_FUSED_STAGE_CLOCK", 0) != 0;
+    if (stage_clock) {
+        a.abl |= 0x1000;
+        static const unsigned long long zeros[4][16] = {};
+        RMR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stage_clock), zeros, sizeof(zeros)));
+    }
+#endif
     auto kern = m->desc.kmer_len == 9 ? fused_front_kernel<9> : fused_front_kernel<6>;  // (4,4) and (2,3)-style contexts
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
@@ -504,6 +533,22 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     ProfScope ps(e, K_FUSED_FRONT);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)total, e->stream, a);
     RMR_HIP(hipGetLastError());
+#ifdef RMR_TIMING_ABLATIONS
+    if (stage_clock) {
+        unsigned long long h[4][16];
+        RMR_HIP(hipStreamSynchronize(e->stream));
+        RMR_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_clock), sizeof(h)));
+        static const char *names[10] = {"barrier top", "S1 (+A fetch)", "barrier", "S2", "A fetch + barrier", "S3", "bias, prefetch, barrier", "S4",
+                                        "store inputs", "loop"};
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 10; ++i) tot += h[w][i];
+            fprintf(stderr, "[stage clock] wave %d:", w);
+            for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.1f%%;", names[i], 100.0 * (double)h[w][i] / (double)(tot ? tot : 1));
+            fprintf(stderr, " total %.3g clocks over %lld blocks, cb %d\n", (double)tot, (long long)grid, cb);
+        }
+    }
+#endif
     return 0;
 }
 
