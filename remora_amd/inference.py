@@ -37,17 +37,23 @@ def call_read_mods(read, model, model_metadata, batch_size=DEFAULT_BATCH_SIZE, f
 
 
 def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=False):
-    """call_reads_mods over a stream of read batches with the host staging of batch k+1 (concatenation into pinned
-    buffers + upload, on its own HIP stream in a worker thread) running under the GPU work of batch k.  Yields
-    (reads, results) per batch, results as call_reads_mods returns them.  Batches whose refiner re-scales
-    iteratively (scale_iters > 0) are staged inline, because that refinement rewrites the reads first."""
+    """call_reads_mods over a stream of read batches.  Yields (reads, results) per batch, in order, results as
+    call_reads_mods returns them.  Without a loaded refiner the batches go through the three-thread pipeline of
+    `_pipelined_parts` (staging, extraction and the per-read split of neighbouring batches run under each other's
+    inference); with one, the host staging of batch k+1 (own thread, own HIP stream) runs under the GPU work of batch
+    k; batches whose refiner re-scales iteratively (scale_iters > 0) are staged inline, because that refinement
+    rewrites the reads first."""
     from concurrent.futures import ThreadPoolExecutor
 
     from .data_chunks import DeviceReads
 
     torch = _torch()
     refiner = model_metadata.get("sig_map_refiner")
-    inline = refiner is not None and getattr(refiner, "is_loaded", False) and refiner.scale_iters > 0
+    loaded = refiner is not None and getattr(refiner, "is_loaded", False)
+    if not loaded and os.environ.get("RMR_READS_SUBBATCH", "512") != "0":
+        yield from _pipelined_parts(read_batches, model, model_metadata, return_mod_probs)
+        return
+    inline = loaded and refiner.scale_iters > 0
     engine = getattr(model, "engine", None)
     upload_stream = None
 
@@ -85,14 +91,16 @@ _PIPE = {}  # GPU index -> the pipeline's torch streams (upload, 2 workers) and 
 _PIPE_LOCK = __import__("threading").Lock()
 
 
-def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
-    """A large batch walked in sub-batches on three threads: one stages (gather into pinned memory + upload on its own
-    stream), two alternate over the staged sub-batches (motif scan, extraction, inference, per-read split), so that the
-    kernels of one sub-batch run under the host work of its neighbours.  The engine serialises the GPU calls (one
-    mutex per engine); every C call and every copy releases the GIL.  Results are those of the one-batch path, in
-    read order.  At most four sub-batches are resident at a time.  A single-pass signal-mapping refiner (scale_iters
-    <= 0) can run per sub-batch inside the workers (opt-in, see call_reads_mods); iterative re-scaling (scale_iters > 0)
-    rewrites the reads on the host first and keeps the batch whole."""
+def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
+    """call_reads_mods for every batch of reads of the iterable `parts`, on three threads: one stages (gather into
+    pinned memory + upload on its own stream, two pinned buffers taking turns), two alternate over the staged batches
+    (motif scan, extraction, inference, per-read split), so that the kernels of one batch run under the host work of
+    its neighbours.  Each engine serialises its GPU calls (one mutex per engine: extraction runs on a second engine
+    with its own stream); every C call and every copy releases the GIL.  Yields (batch, results) in order, results
+    identical to the unpipelined call.  At most four batches are resident and six in flight at a time.  A single-pass
+    signal-mapping refiner (scale_iters <= 0) can run per batch inside the workers (opt-in, see call_reads_mods);
+    iterative re-scaling (scale_iters > 0) rewrites the reads on the host first and never comes here."""
+    import collections
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -104,7 +112,7 @@ def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_pro
     engine = getattr(model, "engine", None)
     tdev = engine.torch_device if engine is not None else None
     # extraction runs on a second engine (own stream): its small kernels and their host round trips do not queue behind
-    # the inference of the neighbouring sub-batch on the model's stream
+    # the inference of the neighbouring batch on the model's stream
     prep = get_prep_engine(engine.device if engine is not None else None)
     refiner = model_metadata.get("sig_map_refiner")
     if refiner is not None and getattr(refiner, "is_loaded", False):
@@ -127,21 +135,46 @@ def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_pro
 
     def stage(part):
         slots.acquire()
+        if len(part) == 0:
+            return None
         with torch.cuda.stream(upload):
             return DeviceReads(part, prep, async_upload=True)  # the worker waits for the copy (wait_ready)
 
     def work(part, staged):
-        # a torch stream per worker: its copies (.cpu() / .to(device)) then wait for this sub-batch's work only, not
-        # for the neighbour's inference on the model's stream
+        # a torch stream per worker: its copies (.cpu() / .to(device)) then wait for this batch's work only, not for
+        # the neighbour's inference on the model's stream
         mine = free_streams.get()
         try:
+            dr = staged.result()
+            if dr is None:
+                return []
             with torch.cuda.stream(mine):
-                return call_reads_mods(part, model, model_metadata, return_mod_probs, device_reads=staged.result())
+                return call_reads_mods(part, model, model_metadata, return_mod_probs, device_reads=dr)
         finally:
             free_streams.put(mine)
             slots.release()
 
-    # short first sub-batches: the GPU starts after the staging of `sub / 4` reads instead of `sub`
+    flight = collections.deque()
+    try:
+        for part in parts:
+            flight.append((part, pipe["workers"].submit(work, part, pipe["stager"].submit(stage, part))))
+            if len(flight) >= 6:
+                done, fut = flight.popleft()
+                yield done, fut.result()
+        while flight:
+            done, fut = flight.popleft()
+            yield done, fut.result()
+    finally:
+        for _, fut in flight:  # a failure or an abandoned generator: nothing of this call keeps running behind it
+            try:
+                fut.result()
+            except Exception:  # noqa: BLE001
+                pass
+
+
+def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
+    """One large batch through `_pipelined_parts`, cut into sub-batches of `sub` reads after two short ones (the GPU
+    starts after the staging of `sub / 4` reads instead of `sub`)."""
     cuts, pos = [], 0
     for size in (max(1, sub // 4), max(1, sub // 2)):
         cuts.append((pos, pos + size))
@@ -149,17 +182,9 @@ def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_pro
     while pos < len(reads):
         cuts.append((pos, min(pos + sub, len(reads))))
         pos += sub
-    parts = [reads[a:b] for a, b in cuts]
     out = []
-    done = [pipe["workers"].submit(work, part, pipe["stager"].submit(stage, part)) for part in parts]
-    err = None
-    for f in done:  # every sub-batch is waited for, also after a failure: nothing of this call keeps running behind it
-        try:
-            out.extend(f.result())
-        except Exception as e:  # noqa: BLE001
-            err = err or e
-    if err is not None:
-        raise err
+    for _, res in _pipelined_parts((reads[a:b] for a, b in cuts), model, model_metadata, return_mod_probs):
+        out.extend(res)
     return out
 
 
