@@ -281,16 +281,17 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     a.o_seq = off; off += up4((seq_w + 3) / 4);
     a.o_code = off; off += up4(a.maxlen * 2);
     a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
-    const bool direct = (kw == 11);
+    const bool direct = (kw == 11) && tune_int("RMR_FRONT_SEQ_DIRECT", 1) != 0;
     a.o_u = off; if (!direct) off += (a.maxlen + 1) * kw * 16;
     a.per_chunk = up4(off);
     const size_t fixed = (size_t)kw * K * 80 * 4;
     int cb = 8;
-    while (cb > 1 && fixed + (size_t)cb * a.per_chunk * 4 > 78 * 1024) cb >>= 1;
+    const size_t lds_cap = (size_t)tune_int("RMR_FRONT_SEQ_LDS_KB", 78) * 1024;
+    while (cb > 1 && fixed + (size_t)cb * a.per_chunk * 4 > lds_cap) cb >>= 1;
     const size_t lds = fixed + (size_t)cb * a.per_chunk * 4;
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "front_seq: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
     a.cb = cb;
-    auto kern = (kw == 5) ? front_seq_kernel<5, false> : front_seq_kernel<11, true>;
+    auto kern = (kw == 5) ? front_seq_kernel<5, false> : (direct ? front_seq_kernel<11, true> : front_seq_kernel<11, false>);
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SEQ_BLOCKS_PER_CU", direct ? 8 : 4);
