@@ -1,9 +1,9 @@
 """Python API of the hot path — drop-in for `remora.inference.call_read_mods`
 (src/remora/inference.py:661-712) and the per-label tally the multi-GPU runs reduce."""
-import queue as _queue
-from collections import defaultdict as _defaultdict
-
 import os
+import queue as _queue
+import threading
+from collections import defaultdict as _defaultdict
 
 import numpy as np
 
@@ -88,7 +88,7 @@ def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=F
 
 
 _PIPE = {}  # GPU index -> the pipeline's torch streams (upload, 2 workers) and its two thread pools
-_PIPE_LOCK = __import__("threading").Lock()
+_PIPE_LOCK = threading.Lock()
 
 
 def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
@@ -102,7 +102,6 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
     iterative re-scaling (scale_iters > 0) rewrites the reads on the host first and never comes here."""
     import collections
     import queue
-    import threading
     from concurrent.futures import ThreadPoolExecutor
 
     from .data_chunks import DeviceReads
