@@ -84,6 +84,9 @@ def kernel_flops_per_chunk(arch, L, size=64, K=9, num_out=2):
         f["lstm_head"] = 2 * (T * 2 * 4 * size * size + 4 * size * size + num_out * size)
         # the fused bf16 front kernel (k_fused.hip) does the work of the five kernels above it
         f["fused_front"] = f["front_sig"] + f["front_seq"] + f["conv_sig3"] + f["conv_seq2"] + f["conv_merge1"]
+        # fp32: the producers folded into the staging of their consumer (k_conv_front.hip)
+        f["sig3_front"] = f["front_sig"] + f["conv_sig3"]
+        f["seq2_front"] = f["front_seq"] + f["conv_seq2"]
     else:
         PQ2 = P1 - 10
         T, T2 = P3 - 4, P3 - 8
@@ -109,6 +112,8 @@ def kernel_alg_bytes_per_chunk(arch, L, dtype, size=64, num_out=2, seq_w=28, map
         b["conv_seq2"] = P1 * 16 * 4 + P3 * size * 4
         b["lstm_head"] = T * size * (2 if dtype == "bf16" else 4) + 4 * num_out
         b["fused_front"] = L * 4 + seq_w + 2 * map_w + 2 + T * size * 2
+        b["sig3_front"] = L * 4 + P3 * size * 4
+        b["seq2_front"] = seq_w + 2 * map_w + 2 + P3 * size * 4
     return b
 
 
@@ -393,7 +398,7 @@ class Job:
         }
         gpu_ms = sum(k["ms_total"] for k in kern.values())
         # necessary flops of the whole network (the fused kernel's entry already contains its five layers)
-        net_flops = sum(v for k, v in flops.items() if k != "fused_front")
+        net_flops = sum(v for k, v in flops.items() if k not in ("fused_front", "sig3_front", "seq2_front"))
         return {
             "value": total / elapsed, "unit": "chunks/s", "ms_per_step": elapsed / steps * 1e3, "dtype": DTYPE_OUT.get(self.dtype, self.dtype),
             "scaling": self.w["scaling"],

@@ -30,7 +30,7 @@ static const char *k_names[K_NUM] = {
     "chunk_fill", "front_sig", "front_seq", "seq_conv1_dense", "conv_sig3", "conv_seq2", "conv_seq3",
     "conv_merge1", "conv_merge2", "conv_merge3", "conv_merge4", "lstm_head", "fc_head",
     "count_labels", "motif_scan", "vbz_decode", "refine_band", "refine_dp", "refine_dp_rowwise",
-    "fused_front", "rescale_quantiles"};
+    "fused_front", "rescale_quantiles", "sig3_front", "seq2_front"};
 const char *kernel_name(int id) { return (id >= 0 && id < K_NUM) ? k_names[id] : "?"; }
 
 }  // namespace rmr
@@ -705,7 +705,11 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     // can run on the aux stream while the matrix kernels of sub-batch i run on the main stream
     const size_t front_fl = (size_t)(m->P1 + m->P2) * 16;
     RMR_TRY(e->ensure(e->act, (per + front_fl) * sb * sizeof(float)));
-    const bool two_stream = tune_int("RMR_TWO_STREAM", 0) && n > sb;
+    // RMR_TWO_STREAM: 1 = front kernels of sub-batch i+1 on the aux stream from the start of sub-batch i (they then share
+    // the CUs with conv_sig3: no gain measured); 2 = released when merge_conv1 of sub-batch i is done, i.e. under its
+    // LSTM kernel (2 blocks of 4 waves per CU, half of the register file and 112 KB of LDS free)
+    const int ts_mode = n > sb ? tune_int("RMR_TWO_STREAM", 0) : 0;
+    const bool two_stream = ts_mode != 0, under_lstm = ts_mode == 2;
     hipStream_t fs = two_stream ? e->aux : e->stream;
     float *arena = reinterpret_cast<float *>(e->act.ptr);
     float *front_buf[2] = {arena, arena + front_fl * sb};
@@ -731,13 +735,16 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         }
         return 0;
     };
+    // fp32 ConvLSTM size 64 straight from the chunk arrays: sig_conv1/2 and seq_conv1 are produced inside the staging of
+    // sig_conv3 / seq_conv2 (k_conv_front.hip); sig2 / seq1 never exist in HBM
+    const bool fold = !enc && !two_stream && tune_int("RMR_CONV_FRONT", 1) && conv_front_supported(m, kb, ka, seq_w, map_w);
     int64_t idx = 0;
-    if (n > 0) RMR_TRY(front(0, n < sb ? n : sb, 0));
+    if (n > 0 && !fold) RMR_TRY(front(0, n < sb ? n : sb, 0));
     for (int64_t c0 = 0; c0 < n; c0 += sb, ++idx) {
         const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
         const int slot = (int)(idx & 1);
         // launch the NEXT sub-batch's front kernels before this sub-batch's matrix kernels
-        if (c0 + sb < n) {
+        if (c0 + sb < n && !under_lstm) {
             const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
             if (two_stream && idx >= 1) RMR_HIP(hipStreamWaitEvent(fs, e->ev_done[slot ^ 1], 0));
             if (two_stream) RMR_TRY(front(c0 + sb, nn, slot ^ 1));
@@ -747,11 +754,15 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         float *base = rest;
         float *cat = base; base += (size_t)nb * m->P3 * 2 * sz;
         const bool split_conv = m->nparts > 0 && tune_int("RMR_SPLIT_CONV", 1);
-        if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
+        if (fold) RMR_TRY(launch_conv_front(m, signal + (size_t)c0 * L, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
+                                            map_w, lens + c0, nb, cat));
+        else if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
         else RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
         if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
             float *x = base; base += (size_t)nb * m->T * sz;
-            if (split_conv) {
+            if (fold) {
+                RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
+            } else if (split_conv) {
                 RMR_TRY(launch_conv_split(e, m->seq2, m->nparts, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
                 RMR_TRY(launch_conv_split(e, m->merge1, m->nparts, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
             } else {
@@ -759,6 +770,11 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                 RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
             }
             if (two_stream) RMR_HIP(hipEventRecord(e->ev_done[slot], e->stream));  // seq1/sig2[slot] consumed
+            if (under_lstm && c0 + sb < n) {  // the other slot was consumed a sub-batch ago (stream order)
+                const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
+                RMR_HIP(hipStreamWaitEvent(fs, e->ev_done[slot], 0));
+                RMR_TRY(front(c0 + sb, nn, slot ^ 1));
+            }
             if (m->nparts > 0) RMR_TRY(launch_lstm_head_split(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
             else RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
         } else {
@@ -776,7 +792,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             RMR_TRY(launch_conv(e, m->merge4, m3, sz, m->T3, m4, sz, 0, m->T4, nb));
             RMR_TRY(launch_fc_head(m, m4, nb, logits + (size_t)c0 * m->desc.num_out));
         }
-        if (!two_stream && c0 + sb < n) {
+        if (!two_stream && !fold && c0 + sb < n) {
             const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
             RMR_TRY(front(c0 + sb, nn, slot ^ 1));
         }

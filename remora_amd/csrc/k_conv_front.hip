@@ -1,0 +1,424 @@
+// k_conv_front.hip — fp32 ConvLSTM_w_ref, size 64: sig_conv3 and seq_conv2 with their producers folded in.
+//
+//   sig3_front_kernel : signal -> sig_conv1 -> sig_conv2 (VALU, packed fp32) -> LDS planes -> sig_conv3 (fp32 MFMA)
+//   seq2_front_kernel : (sequence, mapping, length) -> seq_conv1 as the two-level gather-sum -> LDS planes
+//                       -> seq_conv2 (fp32 MFMA)
+//
+// Replaces, for this model shape, the pairs front_sig_kernel + conv_mfma_kernel<16,9,3> and front_seq_kernel +
+// conv_mfma_kernel<16,13,3> (k_front.hip, k_conv.hip; models/ConvLSTM_w_ref.py:41-46 and
+// src/remora/encoded_kmers.pyx:13-45).  The standalone front kernels were bound by HBM, not by their arithmetic:
+// 12 KB per chunk of fp32 sig2 / seq1 written (3.9 and 2.2 TB/s) only to be read back by the next launch, 10 % of
+// the fp32 step.  Here the 16-channel rows are produced straight into the four-plane LDS image the MFMA tiles read
+// (k_conv.hip: plane q = channels 4q..4q+3 of every row), so they never exist in HBM.
+//
+// Block = 4 waves.  Producer phase: wave w makes the rows of chunks w, w+4, ... of the iteration on its own (every
+// per-chunk LDS region is private to one wave: wave-level ordering only, as in k_front.hip).  After one block
+// barrier the matrix phase is conv_mfma_kernel's: wave w owns output channels 16w..16w+15 with its weight slice in
+// registers.  The arithmetic is that of the separate kernels, operation for operation (same results bit for bit).
+//
+// Measured (1 M chunks, MI355X): sig 0.20 + 0.60 -> 0.72 ms, seq 0.365 + 0.776 -> 1.12 ms per 131 k chunks; headline
+// 22.5 -> 23.2 M chunks/s.  Timing ablations (make abl, RMR_CONV_FRONT_ABLATE): producer phase alone 0.20 / 0.34 ms,
+// matrix phase alone 0.53 / 0.82 ms - the two add up; starting every second block of a CU half an iteration late
+// (per-CU arrival counters) changed nothing, nor did four accumulator chains per wave: a producer phase running under
+// the other block's matrix phase is slowed by exactly what it saves (shared fp32 datapath).
+#include "rmr_internal.h"
+#include "rmr_math.h"
+
+namespace rmr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct ConvFrontArgs {
+    // producer side
+    const float *signal;                      // [n][L]                     (sig)
+    const float *w_sig1, *b_sig1, *w_sig2, *b_sig2;
+    const int8_t *seqs;                       // [n][seq_w]                 (seq)
+    const int16_t *maps;                      // [n][map_w]
+    const int16_t *lens;                      // [n]
+    const float *wt5;                         // [5][K][5][16] gather table (row 4 of a slot = zeros)
+    const float *b_seq1;                      // [16]
+    int L, P1, seq_w, map_w, K, maxlen;
+    int o_front;                              // LDS offset (floats) of the producer scratch
+    int per_chunk;                            // producer scratch per chunk (floats)
+    int o_map, o_seq, o_code, o_pidx, o_u;    // seq: offsets inside a chunk's scratch (floats)
+    // matrix side (as ConvArgs)
+    float *out;
+    const float *apack, *bias;
+    int64_t n;
+    int pin, pout, out_row, out_coff, cb, plane;
+    FastDiv div_pout;
+    int abl;  // experiment builds only (-DRMR_TIMING_ABLATIONS): 1 = skip the producer phase, 2 = skip the matrix phase
+};
+
+#ifdef RMR_TIMING_ABLATIONS
+#define CF_ABL(bit) (a.abl & (bit))
+#else
+#define CF_ABL(bit) 0
+#endif
+
+// the matrix phase of conv_mfma_kernel<16, KW, 3> on the staged planes (RS = 4 floats per row and plane), FOUR column
+// tiles at a time: four independent accumulator chains let ONE wave keep the matrix pipe busy (a dependent
+// v_mfma_f32_16x16x4_f32 issues every ~64 cycles, the pipe takes one every 32: with two chains per wave a SIMD needs
+// both of its waves in this phase to fill the pipe, and then a producer phase can never run in the shadow of the
+// other block's matrix phase - the two phases were measured to add up exactly)
+template <int KW>
+__device__ __forceinline__ void mfma_phase(const ConvFrontArgs &a, const float *smem, const float (&A)[KW * 4], f32x4 b4,
+                                           int64_t chunk0, int nch, int w, int q, int nn) {
+    constexpr int RS = 4, STRIDE = 3, NS = KW, NT = 4;
+    const int ncols = nch * a.pout;
+    const int ntiles = (ncols + 15) >> 4;
+    for (int tile = 0; tile < ntiles; tile += NT) {
+        bool valid[NT];
+        const float *r[NT];
+        int chn[NT], pp[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            int col = (tile + k) * 16 + nn;
+            valid[k] = col < ncols;
+            col = valid[k] ? col : ncols - 1;
+            chn[k] = (int)(((float)col + 0.5f) * a.div_pout.inv);
+            pp[k] = col - chn[k] * a.pout;
+            r[k] = smem + (size_t)q * a.plane + (size_t)(chn[k] * a.pin + pp[k] * STRIDE) * RS;
+        }
+        const bool four = tile + 2 < ntiles;  // wave-uniform: the last group of an iteration may hold one or two tiles
+        f32x4 acc[NT], x[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            acc[k] = b4;
+            x[k] = *reinterpret_cast<const f32x4 *>(r[k]);
+        }
+        if (four) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                f32x4 y[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) y[k] = st + 1 < NS ? *reinterpret_cast<const f32x4 *>(r[k] + (st + 1) * RS) : x[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[k][j], acc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) x[k] = y[k];
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                f32x4 y0 = x[0], y1 = x[1];
+                if (st + 1 < NS) {
+                    y0 = *reinterpret_cast<const f32x4 *>(r[0] + (st + 1) * RS);
+                    y1 = *reinterpret_cast<const f32x4 *>(r[1] + (st + 1) * RS);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[0][j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[1][j], acc[1], 0, 0, 0);
+                }
+                x[0] = y0;
+                x[1] = y1;
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            if (valid[k] && (four || k < 2)) {
+                f32x4 y;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) y[rr] = swish_f(acc[k][rr]);
+                float *dst = a.out + ((size_t)(chunk0 + chn[k]) * a.pout + pp[k]) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                *reinterpret_cast<f32x4 *>(dst) = y;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// signal branch
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KW = 9, KW1 = 5, S = KW * 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15, quad = lane & 3;
+
+    float A[S];
+    {
+        const float *ap = a.apack + (size_t)w * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) A[s] = ap[(size_t)s * 64];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
+    // producer weights as channel pairs (front_sig_kernel)
+    f32x2 w1[KW1][2];
+#pragma unroll
+    for (int t = 0; t < KW1; ++t)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) w1[t][o] = f32x2{a.w_sig1[t * 4 + 2 * o], a.w_sig1[t * 4 + 2 * o + 1]};
+    const f32x2 b1lo = f32x2{a.b_sig1[0], a.b_sig1[1]}, b1hi = f32x2{a.b_sig1[2], a.b_sig1[3]};
+    f32x2 w2[KW1][4][2];
+#pragma unroll
+    for (int t = 0; t < KW1; ++t)
+#pragma unroll
+        for (int ic = 0; ic < 4; ++ic) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.w_sig2 + (t * 4 + ic) * 16 + 4 * quad);
+            w2[t][ic][0] = f32x2{v.x, v.y};
+            w2[t][ic][1] = f32x2{v.z, v.w};
+        }
+    const f32x2 b2lo = f32x2{a.b_sig2[4 * quad], a.b_sig2[4 * quad + 1]}, b2hi = f32x2{a.b_sig2[4 * quad + 2], a.b_sig2[4 * quad + 3]};
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        __syncthreads();  // the matrix phase of the previous iteration has read the planes
+        for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
+            float *s_sig = smem + a.o_front + (size_t)c * a.per_chunk;
+            float *s_sig1 = s_sig + ((a.L + 3) & ~3);
+            const float *src = a.signal + (size_t)(chunk0 + c) * a.L;
+            for (int s = lane; s < a.L; s += 64) s_sig[s] = src[s];
+            wave_sync();
+            for (int pos = lane; pos < a.P1; pos += 64) {
+                f32x2 lo = b1lo, hi = b1hi;
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    const f32x2 xv = pk_splat(s_sig[pos + t]);
+                    lo = pk_fma(w1[t][0], xv, lo);
+                    hi = pk_fma(w1[t][1], xv, hi);
+                }
+                swish_pk(lo, hi);
+                *reinterpret_cast<float4 *>(s_sig1 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            wave_sync();
+            float *row0 = smem + (size_t)quad * a.plane + (size_t)c * a.pin * 4;  // plane of this lane's channel quad
+            for (int i = lane; i < a.pin * 4; i += 64) {  // i & 3 == quad
+                const int pos = i >> 2;
+                f32x2 lo = b2lo, hi = b2hi;
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(s_sig1 + (pos + t) * 4);
+                    const float x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int ic = 0; ic < 4; ++ic) {
+                        const f32x2 xs = pk_splat(x4[ic]);
+                        lo = pk_fma(w2[t][ic][0], xs, lo);
+                        hi = pk_fma(w2[t][ic][1], xs, hi);
+                    }
+                }
+                swish_pk(lo, hi);
+                *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+        __syncthreads();
+        if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sequence branch (two-level gather of k_front.hip's front_seq_kernel<5, false>, 64 lanes per chunk)
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KW = 13, KW1 = 5, S = KW * 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15, quad = lane & 3;
+
+    float A[S];
+    {
+        const float *ap = a.apack + (size_t)w * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) A[s] = ap[(size_t)s * 64];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
+    constexpr int wt_words = KW1 * K * 80;
+    float *s_wt = smem + a.o_front;  // [KW1][K][5][16]
+    for (int i = tid; i < wt_words; i += 256) s_wt[i] = a.wt5[i];
+    const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        __syncthreads();  // planes free again; (first iteration) gather table visible
+        for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
+            const int64_t chunk = chunk0 + c;
+            float *cbase = smem + a.o_front + wt_words + (size_t)c * a.per_chunk;
+            int16_t *s_map = reinterpret_cast<int16_t *>(cbase + a.o_map);
+            int8_t *s_seq = reinterpret_cast<int8_t *>(cbase + a.o_seq);
+            unsigned long long *s_code = reinterpret_cast<unsigned long long *>(cbase + a.o_code);
+            int16_t *s_pidx = reinterpret_cast<int16_t *>(cbase + a.o_pidx);
+            float *s_u = cbase + a.o_u;  // [(maxlen+1)][KW1][16], row `maxlen` = zeros
+            int len = a.lens[chunk];
+            len = len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len);
+            const int16_t *mp = a.maps + (size_t)chunk * a.map_w;
+            for (int j = lane; j < a.map_w; j += 64) s_map[j] = mp[j];
+            const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
+            for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = sq[j];
+            for (int i = lane; i < KW1 * 16; i += 64) s_u[(size_t)a.maxlen * KW1 * 16 + i] = 0.0f;
+            for (int s = lane; s < a.L; s += 64) s_pidx[s] = (int16_t)a.maxlen;
+            wave_sync();
+            // base covering every signal position, written as runs (base p owns [map[p], map[p+1])); positions no base
+            // owns keep the zero row `maxlen` (the gather form of the reference's scatter loops, encoded_kmers.pyx:33-44)
+            for (int p = lane; p < len; p += 64) {
+                const int s0 = max((int)s_map[p], 0), s1 = min((int)s_map[p + 1], a.L);
+                for (int s = s0; s < s1; ++s) s_pidx[s] = (int16_t)p;
+                unsigned long long wv = 0;
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    const int b = s_seq[p + kp];
+                    wv |= (unsigned long long)((b >= 0 && b < 4) ? b : 4) << (3 * kp);
+                }
+                s_code[p] = wv;
+            }
+            wave_sync();
+            // U[p][tap][oc] = sum over the K k-mer slots of the table rows of base p's k-mer
+            const int items = len * KW1 * 4;
+            for (int i = lane; i < items; i += 64) {  // i & 3 == quad
+                const int pt = i >> 2;
+                const int p = pt / KW1, t = pt - p * KW1;
+                unsigned long long wv = s_code[p];
+                const float *wt = s_wt + (size_t)t * K * 80 + 4 * quad;
+                // K known at compile time: the K gathers of an item are all in flight before the first add (two or three
+                // waves per SIMD here, not the eight of the standalone front kernel, so the loop must not serialise them)
+                float4 v[K];
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    const int b = (int)((wv >> (3 * kp)) & 7ull);
+                    v[kp] = *reinterpret_cast<const float4 *>(wt + (kp * 5 + b) * 16);
+                }
+                f32x2 lo = pk_splat(0.f), hi = pk_splat(0.f);
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    lo += f32x2{v[kp].x, v[kp].y};
+                    hi += f32x2{v[kp].z, v[kp].w};
+                }
+                *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            wave_sync();
+            float *row0 = smem + (size_t)quad * a.plane + (size_t)c * a.pin * 4;
+            for (int i = lane; i < a.pin * 4; i += 64) {
+                const int pos = i >> 2;
+                f32x2 lo = bq_lo, hi = bq_hi;
+                int pb[KW1];
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) pb[t] = s_pidx[pos + t];
+                float4 v[KW1];
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) v[t] = *reinterpret_cast<const float4 *>(s_u + ((size_t)pb[t] * KW1 + t) * 16 + 4 * quad);
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    lo += f32x2{v[t].x, v[t].y};
+                    hi += f32x2{v[t].z, v[t].w};
+                }
+                swish_pk(lo, hi);
+                *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+        __syncthreads();
+        if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
+    }
+}
+
+}  // namespace
+
+bool conv_front_supported(const rmr_model *m, int kb, int ka, int seq_w, int map_w) {
+    if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 0 || m->front.kw1 != 5) return false;
+    if (m->sig3.ic != 16 || m->sig3.kw != 9 || m->sig3.stride != 3 || m->sig3.oc != 64) return false;
+    if (m->seq2.ic != 16 || m->seq2.kw != 13 || m->seq2.stride != 3 || m->seq2.oc != 64) return false;
+    if (kb + ka + 1 != m->desc.kmer_len || m->desc.kmer_len != 9) return false;  // the instantiated k-mer length
+    if (map_w < 2 || seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
+    return true;
+}
+
+// sig_conv3 (+ sig_conv1/2) and seq_conv2 (+ seq_conv1) of `n` chunks into the two halves of cat [n][P3][128]
+int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
+                      const int16_t *lens, int64_t n, float *cat) {
+    rmr_engine *e = m->eng;
+    if (n <= 0) return 0;
+    const int sz = m->desc.size, K = m->desc.kmer_len;
+    const int budget = tune_int("RMR_CONV_FRONT_LDS_BUDGET", 73728);
+    auto up4 = [](int words) { return (words + 3) & ~3; };
+    {   // ---- signal branch ----
+        ConvFrontArgs a{};
+        a.signal = signal; a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1; a.w_sig2 = m->front.w_sig2; a.b_sig2 = m->front.b_sig2;
+        a.L = m->L; a.P1 = m->P1;
+        a.out = cat; a.apack = m->sig3.apack; a.bias = m->sig3.bias; a.n = n;
+        a.pin = m->P2; a.pout = m->P3; a.out_row = 2 * sz; a.out_coff = 0; a.div_pout = make_fastdiv(m->P3);
+        a.per_chunk = up4(((m->L + 3) & ~3) + m->P1 * 4);
+        int cb = 8;
+        size_t lds = 0;
+        for (; cb >= 1; --cb) {
+            a.plane = ((cb * a.pin * 4) + 63) & ~63;
+            a.o_front = 4 * a.plane + 16;
+            lds = ((size_t)a.o_front + (size_t)cb * a.per_chunk) * sizeof(float);
+            if (lds <= (size_t)budget) break;
+        }
+        if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples needs %zu B of LDS", m->L, lds);
+        a.cb = cb;
+        a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+        const int64_t iters = (n + cb - 1) / cb;
+        int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
+        if (grid > iters) grid = iters;
+        RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(sig3_front_kernel)));
+        ProfScope ps(e, K_SIG3_FRONT);
+        hipLaunchKernelGGL(sig3_front_kernel, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        RMR_HIP(hipGetLastError());
+    }
+    {   // ---- sequence branch ----
+        ConvFrontArgs a{};
+        a.seqs = seqs; a.maps = maps; a.lens = lens; a.wt5 = m->front.wt5_seq1; a.b_seq1 = m->front.b_seq1;
+        a.L = m->L; a.P1 = m->P1; a.seq_w = seq_w; a.map_w = map_w; a.K = K; a.maxlen = map_w - 1;
+        a.out = cat; a.apack = m->seq2.apack; a.bias = m->seq2.bias; a.n = n;
+        a.pin = m->P1; a.pout = m->P3; a.out_row = 2 * sz; a.out_coff = sz; a.div_pout = make_fastdiv(m->P3);
+        int off = 0;
+        a.o_map = off; off += up4((map_w * 2 + 3) / 4);
+        a.o_seq = off; off += up4((seq_w + 3) / 4);
+        a.o_code = off; off += up4(a.maxlen * 2);
+        a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
+        a.o_u = off; off += (a.maxlen + 1) * 5 * 16;
+        a.per_chunk = up4(off);
+        const int wt_words = 5 * K * 80;
+        int cb = 8;
+        size_t lds = 0;
+        for (; cb >= 1; --cb) {
+            a.plane = ((cb * a.pin * 4) + 63) & ~63;
+            a.o_front = 4 * a.plane + 16;
+            lds = ((size_t)a.o_front + wt_words + (size_t)cb * a.per_chunk) * sizeof(float);
+            if (lds <= (size_t)budget) break;
+        }
+        if (cb < 1) {
+            cb = 1;
+            if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "seq2_front: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
+        }
+        a.cb = cb;
+        a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+        const int64_t iters = (n + cb - 1) / cb;
+        int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
+        if (grid > iters) grid = iters;
+        RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(seq2_front_kernel<9>)));
+        ProfScope ps(e, K_SEQ2_FRONT);
+        hipLaunchKernelGGL(seq2_front_kernel<9>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        RMR_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace rmr

@@ -52,19 +52,23 @@ __global__ __launch_bounds__(256) void front_sig_kernel(FrontSigArgs a) {
     float *s_sig = smem + (size_t)c * Lp;
     float *s_sig1 = smem + (size_t)a.cb * Lp + (size_t)c * a.P1 * 4;
 
-    float w1[KW][4];
+    // weights as channel PAIRS: every multiply-add below is a v_pk_fma_f32 (two output channels per instruction)
+    f32x2 w1[KW][2];
 #pragma unroll
     for (int t = 0; t < KW; ++t)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) w1[t][o] = a.w_sig1[t * 4 + o];
-    const float4 b1 = *reinterpret_cast<const float4 *>(a.b_sig1);
-    float4 w2[KW][4];  // [tap][ic] -> 4 oc of this thread's quad
+        for (int o = 0; o < 2; ++o) w1[t][o] = f32x2{a.w_sig1[t * 4 + 2 * o], a.w_sig1[t * 4 + 2 * o + 1]};
+    const f32x2 b1lo = f32x2{a.b_sig1[0], a.b_sig1[1]}, b1hi = f32x2{a.b_sig1[2], a.b_sig1[3]};
+    f32x2 w2[KW][4][2];  // [tap][ic] -> the 4 oc of this thread's quad as two pairs
 #pragma unroll
     for (int t = 0; t < KW; ++t)
 #pragma unroll
-        for (int ic = 0; ic < 4; ++ic)
-            w2[t][ic] = *reinterpret_cast<const float4 *>(a.w_sig2 + (t * 4 + ic) * 16 + 4 * quad);
-    const float4 b2 = *reinterpret_cast<const float4 *>(a.b_sig2 + 4 * quad);
+        for (int ic = 0; ic < 4; ++ic) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.w_sig2 + (t * 4 + ic) * 16 + 4 * quad);
+            w2[t][ic][0] = f32x2{v.x, v.y};
+            w2[t][ic][1] = f32x2{v.z, v.w};
+        }
+    const f32x2 b2lo = f32x2{a.b_sig2[4 * quad], a.b_sig2[4 * quad + 1]}, b2hi = f32x2{a.b_sig2[4 * quad + 2], a.b_sig2[4 * quad + 3]};
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
@@ -78,16 +82,15 @@ __global__ __launch_bounds__(256) void front_sig_kernel(FrontSigArgs a) {
         wave_sync();
         if (live) {
             for (int pos = sub; pos < a.P1; pos += 32) {
-                float4 acc = b1;
+                f32x2 lo = b1lo, hi = b1hi;
 #pragma unroll
                 for (int t = 0; t < KW; ++t) {
-                    const float xv = s_sig[pos + t];
-                    acc.x += w1[t][0] * xv; acc.y += w1[t][1] * xv;
-                    acc.z += w1[t][2] * xv; acc.w += w1[t][3] * xv;
+                    const f32x2 xv = pk_splat(s_sig[pos + t]);
+                    lo = pk_fma(w1[t][0], xv, lo);
+                    hi = pk_fma(w1[t][1], xv, hi);
                 }
-                acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
-                acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
-                *reinterpret_cast<float4 *>(s_sig1 + pos * 4) = acc;
+                swish_pk(lo, hi);
+                *reinterpret_cast<float4 *>(s_sig1 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
         wave_sync();
@@ -95,18 +98,20 @@ __global__ __launch_bounds__(256) void front_sig_kernel(FrontSigArgs a) {
             float *dst = a.sig2 + (size_t)chunk * a.P2 * 16;
             for (int i = sub; i < a.P2 * 4; i += 32) {  // i & 3 == quad
                 const int pos = i >> 2;
-                float4 acc = b2;
+                f32x2 lo = b2lo, hi = b2hi;
 #pragma unroll
                 for (int t = 0; t < KW; ++t) {
                     const float4 xv = *reinterpret_cast<const float4 *>(s_sig1 + (pos + t) * 4);
-                    acc.x += w2[t][0].x * xv.x + w2[t][1].x * xv.y + w2[t][2].x * xv.z + w2[t][3].x * xv.w;
-                    acc.y += w2[t][0].y * xv.x + w2[t][1].y * xv.y + w2[t][2].y * xv.z + w2[t][3].y * xv.w;
-                    acc.z += w2[t][0].z * xv.x + w2[t][1].z * xv.y + w2[t][2].z * xv.z + w2[t][3].z * xv.w;
-                    acc.w += w2[t][0].w * xv.x + w2[t][1].w * xv.y + w2[t][2].w * xv.z + w2[t][3].w * xv.w;
+                    const float x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int ic = 0; ic < 4; ++ic) {
+                        const f32x2 xs = pk_splat(x4[ic]);
+                        lo = pk_fma(w2[t][ic][0], xs, lo);
+                        hi = pk_fma(w2[t][ic][1], xs, hi);
+                    }
                 }
-                acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
-                acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
-                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = acc;
+                swish_pk(lo, hi);
+                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
     }
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     for (int i = tid; i < wt_words; i += blockDim.x) s_wt[i] = a.wt5[i];
     if (!DIRECT)
         for (int i = sub; i < KW * 16; i += 32) s_u[(size_t)a.maxlen * KW * 16 + i] = 0.0f;
-    const float4 bq = *reinterpret_cast<const float4 *>(a.b_seq1 + 4 * quad);
+    const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
     __syncthreads();  // gather table visible to every wave
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
@@ -200,14 +205,15 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
                 const int p = pt / KW, t = pt - p * KW;
                 unsigned long long wv = s_code[p];
                 const float *wt = s_wt + (size_t)t * a.K * 80 + 4 * quad;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x2 lo = pk_splat(0.f), hi = pk_splat(0.f);  // gather-adds as v_pk_add_f32: two channels per instruction
                 for (int kp = 0; kp < a.K; ++kp) {
                     const int b = (int)(wv & 7ull);
                     wv >>= 3;
                     const float4 v = *reinterpret_cast<const float4 *>(wt + (kp * 5 + b) * 16);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    lo += f32x2{v.x, v.y};
+                    hi += f32x2{v.z, v.w};
                 }
-                *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = acc;
+                *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
         if (!DIRECT) wave_sync();
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
             float *dst = a.seq1 + (size_t)chunk * a.P1 * 16;
             for (int i = sub; i < a.P1 * 4; i += 32) {
                 const int pos = i >> 2;
-                float4 acc = bq;
+                f32x2 lo = bq_lo, hi = bq_hi;
 #pragma unroll
                 for (int t = 0; t < KW; ++t) {
                     const int p = s_pidx[pos + t];
@@ -227,17 +233,18 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
                                 const int b = (int)(wv & 7ull);
                                 wv >>= 3;
                                 const float4 v = *reinterpret_cast<const float4 *>(wt + (kp * 5 + b) * 16);
-                                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                                lo += f32x2{v.x, v.y};
+                                hi += f32x2{v.z, v.w};
                             }
                         }
                         continue;
                     }
                     const float4 v = *reinterpret_cast<const float4 *>(s_u + ((size_t)p * KW + t) * 16 + 4 * quad);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    lo += f32x2{v.x, v.y};
+                    hi += f32x2{v.z, v.w};
                 }
-                acc.x = swish_f(acc.x); acc.y = swish_f(acc.y);
-                acc.z = swish_f(acc.z); acc.w = swish_f(acc.w);
-                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = acc;
+                swish_pk(lo, hi);
+                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
     }

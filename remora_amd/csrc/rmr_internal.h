@@ -64,6 +64,8 @@ enum KernelId {
     K_REFINE_ROWWISE,
     K_FUSED_FRONT,
     K_RESCALE_Q,
+    K_SIG3_FRONT,
+    K_SEQ2_FRONT,
     K_NUM
 };
 const char *kernel_name(int id);
@@ -229,6 +231,10 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
                  const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
                  float *sig2, float *seq1 /* nullptr: skip seq path */);
 int launch_seq1_dense(rmr_model *m, const float *enc, int64_t n, float *seq1);
+// k_conv_front.hip: fp32 sig_conv3 / seq_conv2 with their producers (sig_conv1/2, seq_conv1) folded into the staging
+bool conv_front_supported(const rmr_model *m, int kb, int ka, int seq_w, int map_w);
+int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
+                      const int16_t *lens, int64_t n, float *cat);
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                 float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);

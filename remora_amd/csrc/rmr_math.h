@@ -17,4 +17,20 @@ __device__ __forceinline__ float tanh_f(float x) { return fmaf(-2.0f, fast_rcp(1
 // x * sigmoid(x)   (src/remora/activations.py:4-18)
 __device__ __forceinline__ float swish_f(float x) { return x * sigmoid_f(x); }
 
+// Packed fp32 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per lane and instruction, same
+// rounding as the scalar forms).  v_mfma_f32_16x16x4_f32 shares the SIMD's fp32 datapath with the VALU, so every
+// VALU instruction saved in the fp32 pipeline is matrix time gained.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_splat(float x) { return f32x2{x, x}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// swish of four values: the multiplies and the add packed, the four exp / rcp stay scalar (no packed transcendentals);
+// element for element the same operations as swish_f
+__device__ __forceinline__ void swish_pk(f32x2 &a, f32x2 &b) {
+    const f32x2 ta = a * pk_splat(-1.4426950408889634f), tb = b * pk_splat(-1.4426950408889634f);
+    const f32x2 da = f32x2{__builtin_amdgcn_exp2f(ta.x), __builtin_amdgcn_exp2f(ta.y)} + pk_splat(1.0f);
+    const f32x2 db = f32x2{__builtin_amdgcn_exp2f(tb.x), __builtin_amdgcn_exp2f(tb.y)} + pk_splat(1.0f);
+    a = a * f32x2{__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
+    b = b * f32x2{__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+}
+
 }  // namespace rmr
