@@ -698,12 +698,18 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         return 0;
     }
     const size_t per = act_floats_per_chunk(m);
-    int64_t sb = e->subbatch > 0 ? e->subbatch : 131072;
+    // 262144 chunks per sub-batch: the tail of every persistent-block kernel is paid half as often as with 131072
+    // (+1.2 % measured; 524288: +0.2 % more for twice the 5.5 GB arena)
+    int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_SUBBATCH", 262144);
     if (sb > n) sb = n;
     const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;
     // front outputs (seq1, sig2) are double-buffered so that the front kernels of sub-batch i+1
     // can run on the aux stream while the matrix kernels of sub-batch i run on the main stream
-    const size_t front_fl = (size_t)(m->P1 + m->P2) * 16;
+    // fp32 ConvLSTM size 64 straight from the chunk arrays: sig_conv1/2 and seq_conv1 are produced inside the staging of
+    // sig_conv3 / seq_conv2 (k_conv_front.hip); sig2 / seq1 never exist in HBM
+    const bool fold = !enc && tune_int("RMR_TWO_STREAM", 0) == 0 && tune_int("RMR_CONV_FRONT", 1) &&
+                      conv_front_supported(m, kb, ka, seq_w, map_w);
+    const size_t front_fl = fold ? 0 : (size_t)(m->P1 + m->P2) * 16;
     RMR_TRY(e->ensure(e->act, (per + front_fl) * sb * sizeof(float)));
     // RMR_TWO_STREAM: 1 = front kernels of sub-batch i+1 on the aux stream from the start of sub-batch i (they then share
     // the CUs with conv_sig3: no gain measured); 2 = released when merge_conv1 of sub-batch i is done, i.e. under its
@@ -735,9 +741,6 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         }
         return 0;
     };
-    // fp32 ConvLSTM size 64 straight from the chunk arrays: sig_conv1/2 and seq_conv1 are produced inside the staging of
-    // sig_conv3 / seq_conv2 (k_conv_front.hip); sig2 / seq1 never exist in HBM
-    const bool fold = !enc && !two_stream && tune_int("RMR_CONV_FRONT", 1) && conv_front_supported(m, kb, ka, seq_w, map_w);
     int64_t idx = 0;
     if (n > 0 && !fold) RMR_TRY(front(0, n < sb ? n : sb, 0));
     for (int64_t c0 = 0; c0 < n; c0 += sb, ++idx) {

@@ -64,90 +64,69 @@ struct ConvFrontArgs {
 #define CF_ABL(bit) 0
 #endif
 
-// the matrix phase of conv_mfma_kernel<16, KW, 3> on the staged planes (RS = 4 floats per row and plane), FOUR column
-// tiles at a time: four independent accumulator chains let ONE wave keep the matrix pipe busy (a dependent
-// v_mfma_f32_16x16x4_f32 issues every ~64 cycles, the pipe takes one every 32: with two chains per wave a SIMD needs
-// both of its waves in this phase to fill the pipe, and then a producer phase can never run in the shadow of the
-// other block's matrix phase - the two phases were measured to add up exactly)
+// the matrix phase of conv_mfma_kernel<16, KW, 3> on the staged planes (RS = 4 floats per row and plane): groups of up
+// to four column tiles with one accumulator chain each; the last group of an iteration holds what is left (1-4 tiles,
+// wave-uniform) so that no MFMA is spent on padding tiles
+template <int KW, int NT>
+__device__ __forceinline__ void mfma_group(const ConvFrontArgs &a, const float *smem, const float (&A)[KW * 4], f32x4 b4,
+                                           int64_t chunk0, int ncols, int tile, int w, int q, int nn) {
+    constexpr int RS = 4, STRIDE = 3, NS = KW;
+    const float *r[NT];
+    int chn[NT], pp[NT];
+    bool valid[NT];
+    f32x4 acc[NT], x[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        int col = (tile + k) * 16 + nn;
+        valid[k] = col < ncols;
+        col = valid[k] ? col : ncols - 1;
+        chn[k] = (int)(((float)col + 0.5f) * a.div_pout.inv);
+        pp[k] = col - chn[k] * a.pout;
+        r[k] = smem + (size_t)q * a.plane + (size_t)(chn[k] * a.pin + pp[k] * STRIDE) * RS;
+        acc[k] = b4;
+        x[k] = *reinterpret_cast<const f32x4 *>(r[k]);
+    }
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        f32x4 y[NT];  // B fragments are fetched one tap ahead of the MFMAs that consume them
+#pragma unroll
+        for (int k = 0; k < NT; ++k) y[k] = st + 1 < NS ? *reinterpret_cast<const f32x4 *>(r[k] + (st + 1) * RS) : x[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[k][j], acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) x[k] = y[k];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        if (valid[k]) {
+            f32x4 y;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) y[rr] = swish_f(acc[k][rr]);
+            float *dst = a.out + ((size_t)(chunk0 + chn[k]) * a.pout + pp[k]) * a.out_row + a.out_coff + 16 * w + 4 * q;
+            *reinterpret_cast<f32x4 *>(dst) = y;
+        }
+    }
+}
+
 template <int KW>
 __device__ __forceinline__ void mfma_phase(const ConvFrontArgs &a, const float *smem, const float (&A)[KW * 4], f32x4 b4,
                                            int64_t chunk0, int nch, int w, int q, int nn) {
-    constexpr int RS = 4, STRIDE = 3, NS = KW, NT = 4;
     const int ncols = nch * a.pout;
     const int ntiles = (ncols + 15) >> 4;
-    for (int tile = 0; tile < ntiles; tile += NT) {
-        bool valid[NT];
-        const float *r[NT];
-        int chn[NT], pp[NT];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            int col = (tile + k) * 16 + nn;
-            valid[k] = col < ncols;
-            col = valid[k] ? col : ncols - 1;
-            chn[k] = (int)(((float)col + 0.5f) * a.div_pout.inv);
-            pp[k] = col - chn[k] * a.pout;
-            r[k] = smem + (size_t)q * a.plane + (size_t)(chn[k] * a.pin + pp[k] * STRIDE) * RS;
-        }
-        const bool four = tile + 2 < ntiles;  // wave-uniform: the last group of an iteration may hold one or two tiles
-        f32x4 acc[NT], x[NT];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            acc[k] = b4;
-            x[k] = *reinterpret_cast<const f32x4 *>(r[k]);
-        }
-        if (four) {
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                f32x4 y[NT];
-#pragma unroll
-                for (int k = 0; k < NT; ++k) y[k] = st + 1 < NS ? *reinterpret_cast<const f32x4 *>(r[k] + (st + 1) * RS) : x[k];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[k][j], acc[k], 0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < NT; ++k) x[k] = y[k];
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
-            }
-        } else {
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                f32x4 y0 = x[0], y1 = x[1];
-                if (st + 1 < NS) {
-                    y0 = *reinterpret_cast<const f32x4 *>(r[0] + (st + 1) * RS);
-                    y1 = *reinterpret_cast<const f32x4 *>(r[1] + (st + 1) * RS);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[0][j], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x[1][j], acc[1], 0, 0, 0);
-                }
-                x[0] = y0;
-                x[1] = y1;
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            if (valid[k] && (four || k < 2)) {
-                f32x4 y;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) y[rr] = swish_f(acc[k][rr]);
-                float *dst = a.out + ((size_t)(chunk0 + chn[k]) * a.pout + pp[k]) * a.out_row + a.out_coff + 16 * w + 4 * q;
-                *reinterpret_cast<f32x4 *>(dst) = y;
-            }
-        }
-    }
+    int tile = 0;
+    for (; tile + 4 <= ntiles; tile += 4) mfma_group<KW, 4>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
+    const int left = ntiles - tile;
+    if (left == 3) mfma_group<KW, 3>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
+    else if (left == 2) mfma_group<KW, 2>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
+    else if (left == 1) mfma_group<KW, 1>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -254,6 +233,20 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
     const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    // the mapping / sequence row and the length of the wave's first chunk of an iteration travel one element per lane
+    // (rows of up to 64 elements) and are requested an iteration ahead
+    const bool pre_ok = a.map_w <= 64 && a.seq_w <= 64;
+    int16_t pre_map = 0;
+    int8_t pre_seq = 0;
+    int pre_len = 0;
+    auto prefetch = [&](int64_t it) {
+        const int64_t chunk = it * a.cb + w;
+        if (!pre_ok || it >= n_iters || chunk >= a.n) return;
+        if (lane < a.map_w) pre_map = a.maps[(size_t)chunk * a.map_w + lane];
+        if (lane < a.seq_w) pre_seq = a.seqs[(size_t)chunk * a.seq_w + lane];
+        pre_len = a.lens[chunk];
+    };
+    prefetch(blockIdx.x);
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
@@ -266,12 +259,19 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
             unsigned long long *s_code = reinterpret_cast<unsigned long long *>(cbase + a.o_code);
             int16_t *s_pidx = reinterpret_cast<int16_t *>(cbase + a.o_pidx);
             float *s_u = cbase + a.o_u;  // [(maxlen+1)][KW1][16], row `maxlen` = zeros
-            int len = a.lens[chunk];
+            int len;
+            if (c == w && pre_ok) {  // the wave's first chunk: its rows left HBM during the previous matrix phase
+                len = pre_len;
+                if (lane < a.map_w) s_map[lane] = pre_map;
+                if (lane < a.seq_w) s_seq[lane] = pre_seq;
+            } else {
+                len = a.lens[chunk];
+                const int16_t *mp = a.maps + (size_t)chunk * a.map_w;
+                for (int j = lane; j < a.map_w; j += 64) s_map[j] = mp[j];
+                const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
+                for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = sq[j];
+            }
             len = len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len);
-            const int16_t *mp = a.maps + (size_t)chunk * a.map_w;
-            for (int j = lane; j < a.map_w; j += 64) s_map[j] = mp[j];
-            const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
-            for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = sq[j];
             for (int i = lane; i < KW1 * 16; i += 64) s_u[(size_t)a.maxlen * KW1 * 16 + i] = 0.0f;
             for (int s = lane; s < a.L; s += 64) s_pidx[s] = (int16_t)a.maxlen;
             wave_sync();
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
                 *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
+        prefetch(it + gridDim.x);
         __syncthreads();
         if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
     }
