@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.replace("void rmr::", "").replace("rmr::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("void rmr::", "").replace("rmr::", "")
     return name.split("(")[0]
 
 
@@ -36,7 +36,8 @@ BENCH_NAME = [("conv_mfma_kernel<128, 5, 1>", "conv_merge1"), ("conv_mfma_kernel
               ("conv_bf16s_kernel<128, 5, 1", "conv_merge1"), ("conv_bf16s_kernel<16, 13, 3", "conv_seq2"),
               ("conv_bf16s_kernel<16, 9, 3", "conv_sig3"), ("lstm_bf16s_kernel", "lstm_head"),
               ("front_sig_kernel", "front_sig"), ("front_seq_kernel", "front_seq"), ("fused_front_kernel", "fused_front"),
-              ("lstm_x16_kernel", "lstm_head"), ("encode_kernel", "encode_kmers")]
+              ("lstm_x16_kernel", "lstm_head"), ("encode_kernel", "encode_kmers"),
+              ("sig3_front_kernel", "sig3_front"), ("seq2_front_kernel", "seq2_front")]
 
 
 def write_traffic(d, dtype, chunks_per_launch, path, commit=None, per_kernel_chunks=None):
