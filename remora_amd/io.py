@@ -1148,9 +1148,12 @@ def record_with_mod_tags(rec, mm_tag, ml_tag, ref_anchored_seq=None):
     return struct.pack("<i", len(body)) + body
 
 
+_BGZF_LEVEL = int(os.environ.get("RMR_BAM_LEVEL", "6"))  # htslib's default level
+
+
 def _bgzf_block(chunk):
     """One BGZF member (gzip with the BC extra field) for up to 64 KiB of payload."""
-    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = zlib.compressobj(_BGZF_LEVEL, zlib.DEFLATED, -15)
     cdata = comp.compress(chunk) + comp.flush()
     return b"".join((b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00", struct.pack("<H", len(cdata) + 25),
                      cdata, struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))))
@@ -1161,9 +1164,16 @@ class BamWriter:
     by a small thread pool (zlib releases the GIL) and written in order, so compression - ~1 ms per 5 kb read with
     its move table - runs beside the caller instead of in it; the file is the same as with inline compression."""
 
-    def __init__(self, path, header_bytes, threads=4, max_pending=32):
+    def __init__(self, path, header_bytes, threads=None, max_pending=None):
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+
+        # deflate at level 6 runs at ~35 MB/s per thread and a 5 kb read with its move table is ~25 KB of BAM: four
+        # threads cap the writer at ~5 k reads/s, which the batched GPU path exceeds tenfold
+        if threads is None:
+            threads = int(os.environ.get("RMR_BAM_THREADS", "0")) or min(16, max(4, (os.cpu_count() or 8) // 4))
+        if max_pending is None:
+            max_pending = 8 * int(threads)
 
         self._fh = open(path, "wb")
         self._buf = bytearray(header_bytes)
