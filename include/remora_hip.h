@@ -58,7 +58,7 @@ enum rmr_arch {
 };
 
 const char *rmr_last_error(void);
-const char *rmr_version(void);
+const char *rmr_version(void); /* "remora_hip <major>.<minor> (gfx950)"; the minor number changes with every struct or entry-point change */
 
 /* ---- engine ------------------------------------------------------------------------ */
 

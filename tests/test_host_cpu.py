@@ -1520,3 +1520,66 @@ def test_pack_reads_native_gather_equals_numpy():
     bad[3] = 3
     assert lib.rmr_pack_reads(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, bad.ctypes.data, dacs.ctypes.data,
                               maps.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, 2) != 0
+
+
+def test_format_mm_ml_tags_equals_oracle_on_random_reads(O):
+    """The MM gap computation (search in the canonical-base positions) against the oracle's running-count formulation
+    (src/remora/util.py:485-537) on random sequences: unsorted positions, first / last base called, several mods."""
+    from remora_amd import util
+
+    rng = np.random.default_rng(42)
+    for trial in range(40):
+        n = int(rng.integers(1, 400))
+        seq = "".join(rng.choice(list("ACGTN"), n))
+        can = "ACGT"[trial % 4]
+        sites = np.flatnonzero(np.frombuffer(seq.encode(), np.uint8) == ord(can))
+        if sites.size == 0:
+            continue
+        poss = rng.permutation(sites[rng.random(sites.size) < 0.6]) if trial % 3 else sites.copy()
+        nm = 1 + trial % 2
+        probs = rng.random((poss.size, nm)) / nm
+        if poss.size:
+            probs[0, 0] = 1.0  # floor(p * 256) == 256 is clipped to 255
+        mods = ["m", "h"][:nm]
+        want = O.format_mm_ml_tags(seq, poss, probs, mods, can)
+        got = util.format_mm_ml_tags(seq, poss, probs, mods, can)
+        assert got[0] == want[0], (trial, seq, poss)
+        assert list(got[1]) == list(want[1])
+
+
+def test_batched_line_fits_equal_per_read_lstsq():
+    """refine_signal_map._fit_lines (numpy's LAPACK gufunc on the stacked systems) must return, bit for bit, what
+    np.linalg.lstsq returns row by row - including rank-deficient rows (all x equal)."""
+    from remora_amd import refine_signal_map as R
+
+    rng = np.random.default_rng(7)
+    X = np.sort(rng.normal(0, 1, (50, 19)), axis=1)
+    Y = 0.8 * X + 0.1 + 0.05 * rng.normal(0, 1, X.shape)
+    X[3] = 0.25  # degenerate: lstsq's minimum-norm solution
+    Y[4] = 0.0
+    got = R._fit_lines(X, Y)
+    want = np.asarray([R._fit_line(X[i], Y[i]) for i in range(X.shape[0])])
+    assert got.shape == (50, 2)
+    np.testing.assert_array_equal(got, want)
+    assert R._fit_lines(np.zeros((0, 19)), np.zeros((0, 19))).shape == (0, 2)
+
+
+def test_bam_writer_thread_count_and_level_do_not_change_the_payload(tmp_path):
+    """More deflate threads (the default is now up to 16) or another level change the compressed bytes at most, never
+    the records: every variant inflates to the same stream."""
+    import gzip
+
+    from remora_amd import io as rio
+
+    rng = np.random.default_rng(0)
+    header = b"BAM\x01" + (0).to_bytes(4, "little") + (0).to_bytes(4, "little")
+    recs = [bytes(rng.integers(0, 256, int(rng.integers(100, 40000)), dtype=np.uint8)) for _ in range(60)]
+    payloads = []
+    for threads in (1, 3, 16):
+        p = tmp_path / f"t{threads}.bam"
+        with rio.BamWriter(str(p), header, threads=threads) as w:
+            for r in recs:
+                w.write(len(r).to_bytes(4, "little") + r)
+        payloads.append(gzip.open(str(p)).read())
+    assert payloads[0] == payloads[1] == payloads[2]
+    assert payloads[0] == header + b"".join(len(r).to_bytes(4, "little") + r for r in recs)
