@@ -128,16 +128,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
             if (v0) {
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = swish_f(acc0[r]);
+                f32x2 lo = f32x2{acc0[0], acc0[1]}, hi = f32x2{acc0[2], acc0[3]};
+                swish_pk(lo, hi);  // same operations as swish_f, the plain ones two values per instruction
+                const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
                 float *dst = a.out + ((size_t)(chunk0 + ch0) * a.pout + p0) * a.out_row + a.out_coff + 16 * w + 4 * q;
                 *reinterpret_cast<f32x4 *>(dst) = y;
             }
             if (v1) {
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = swish_f(acc1[r]);
+                f32x2 lo = f32x2{acc1[0], acc1[1]}, hi = f32x2{acc1[2], acc1[3]};
+                swish_pk(lo, hi);
+                const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
                 float *dst = a.out + ((size_t)(chunk0 + ch1) * a.pout + p1) * a.out_row + a.out_coff + 16 * w + 4 * q;
                 *reinterpret_cast<f32x4 *>(dst) = y;
             }

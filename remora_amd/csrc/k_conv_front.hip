@@ -107,9 +107,9 @@ __device__ __forceinline__ void mfma_group(const ConvFrontArgs &a, const float *
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
         if (valid[k]) {
-            f32x4 y;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) y[rr] = swish_f(acc[k][rr]);
+            f32x2 lo = f32x2{acc[k][0], acc[k][1]}, hi = f32x2{acc[k][2], acc[k][3]};
+            swish_pk(lo, hi);  // same operations as swish_f, the plain ones two values per instruction
+            const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
             float *dst = a.out + ((size_t)(chunk0 + chn[k]) * a.pout + pp[k]) * a.out_row + a.out_coff + 16 * w + 4 * q;
             *reinterpret_cast<f32x4 *>(dst) = y;
         }
