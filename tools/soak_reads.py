@@ -22,4 +22,15 @@ for it in range(40):
     frees.append(torch.cuda.mem_get_info()[0] / 2**20)
 print("free MiB after iterations 1,5,10,20,40:", [round(frees[i]) for i in (0, 4, 9, 19, 39)])
 assert frees[39] >= frees[9] - 64, "device memory keeps shrinking"
-print("no leak")
+print("no leak (single-batch path with a refiner)")
+# the three-thread pipeline (batches of >= 1024 reads, no refiner): persistent streams, pinned double buffers, a second engine
+md2 = dict(md, sig_map_refiner=None)
+frees = []
+for it in range(24):
+    call_reads_mods(fresh(1024 + (it % 4) * 256), model, md2)
+    torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()
+    frees.append(torch.cuda.mem_get_info()[0] / 2**20)
+print("pipelined: free MiB after iterations 1,4,8,16,24:", [round(frees[i]) for i in (0, 3, 7, 15, 23)])
+assert frees[23] >= frees[7] - 64, "device memory keeps shrinking (pipelined path)"
+import resource
+print("no leak; max RSS MiB", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024)
