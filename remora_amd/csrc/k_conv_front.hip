@@ -164,6 +164,23 @@ __global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
     const f32x2 b2lo = f32x2{a.b_sig2[4 * quad], a.b_sig2[4 * quad + 1]}, b2hi = f32x2{a.b_sig2[4 * quad + 2], a.b_sig2[4 * quad + 3]};
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    // the signal rows of the wave's (up to two) chunks of an iteration are requested an iteration ahead, up to four
+    // samples per lane and chunk, and wait in registers under the matrix phase
+    const bool pre_ok = a.L <= 256 && a.cb <= 8;
+    float pre[2][4];
+    auto prefetch = [&](int64_t it) {
+        if (!pre_ok || it >= n_iters) return;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t chunk = it * a.cb + w + 4 * k;
+            if (w + 4 * k >= a.cb || chunk >= a.n) continue;
+            const float *src = a.signal + (size_t)chunk * a.L;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane + 64 * j < a.L) pre[k][j] = src[lane + 64 * j];
+        }
+    };
+    prefetch(blockIdx.x);
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
@@ -171,8 +188,15 @@ __global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
         for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
             float *s_sig = smem + a.o_front + (size_t)c * a.per_chunk;
             float *s_sig1 = s_sig + ((a.L + 3) & ~3);
-            const float *src = a.signal + (size_t)(chunk0 + c) * a.L;
-            for (int s = lane; s < a.L; s += 64) s_sig[s] = src[s];
+            if (pre_ok) {
+                const int k = c >> 2;  // c = w + 4 k
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (lane + 64 * j < a.L) s_sig[lane + 64 * j] = k == 0 ? pre[0][j] : pre[1][j];
+            } else {
+                const float *src = a.signal + (size_t)(chunk0 + c) * a.L;
+                for (int s = lane; s < a.L; s += 64) s_sig[s] = src[s];
+            }
             wave_sync();
             for (int pos = lane; pos < a.P1; pos += 64) {
                 f32x2 lo = b1lo, hi = b1hi;
@@ -187,24 +211,34 @@ __global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
             }
             wave_sync();
             float *row0 = smem + (size_t)quad * a.plane + (size_t)c * a.pin * 4;  // plane of this lane's channel quad
-            for (int i = lane; i < a.pin * 4; i += 64) {  // i & 3 == quad
-                const int pos = i >> 2;
-                f32x2 lo = b2lo, hi = b2hi;
+            // two positions per pass (i and i + 64, same channel quad): two independent multiply-add chains per lane, so
+            // that a wave alone covers the latency of its own LDS reads and dependent FMAs
+            const int n_items = a.pin * 4;
+            for (int i = lane; i < n_items; i += 128) {  // i & 3 == quad
+                const bool two = i + 64 < n_items;
+                const int pos0 = i >> 2, pos1 = two ? (i + 64) >> 2 : pos0;
+                f32x2 lo0 = b2lo, hi0 = b2hi, lo1 = b2lo, hi1 = b2hi;
 #pragma unroll
                 for (int t = 0; t < KW1; ++t) {
-                    const float4 xv = *reinterpret_cast<const float4 *>(s_sig1 + (pos + t) * 4);
-                    const float x4[4] = {xv.x, xv.y, xv.z, xv.w};
+                    const float4 xa = *reinterpret_cast<const float4 *>(s_sig1 + (pos0 + t) * 4);
+                    const float4 xb = *reinterpret_cast<const float4 *>(s_sig1 + (pos1 + t) * 4);
+                    const float a4[4] = {xa.x, xa.y, xa.z, xa.w}, b4v[4] = {xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
                     for (int ic = 0; ic < 4; ++ic) {
-                        const f32x2 xs = pk_splat(x4[ic]);
-                        lo = pk_fma(w2[t][ic][0], xs, lo);
-                        hi = pk_fma(w2[t][ic][1], xs, hi);
+                        const f32x2 sa = pk_splat(a4[ic]), sb = pk_splat(b4v[ic]);
+                        lo0 = pk_fma(w2[t][ic][0], sa, lo0);
+                        hi0 = pk_fma(w2[t][ic][1], sa, hi0);
+                        lo1 = pk_fma(w2[t][ic][0], sb, lo1);
+                        hi1 = pk_fma(w2[t][ic][1], sb, hi1);
                     }
                 }
-                swish_pk(lo, hi);
-                *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                swish_pk(lo0, hi0);
+                swish_pk(lo1, hi1);
+                *reinterpret_cast<float4 *>(row0 + pos0 * 4) = make_float4(lo0.x, lo0.y, hi0.x, hi0.y);
+                if (two) *reinterpret_cast<float4 *>(row0 + pos1 * 4) = make_float4(lo1.x, lo1.y, hi1.x, hi1.y);
             }
         }
+        prefetch(it + gridDim.x);
         __syncthreads();
         if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
     }
@@ -291,45 +325,61 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
             wave_sync();
             // U[p][tap][oc] = sum over the K k-mer slots of the table rows of base p's k-mer
             const int items = len * KW1 * 4;
-            for (int i = lane; i < items; i += 64) {  // i & 3 == quad
-                const int pt = i >> 2;
-                const int p = pt / KW1, t = pt - p * KW1;
-                unsigned long long wv = s_code[p];
-                const float *wt = s_wt + (size_t)t * K * 80 + 4 * quad;
-                // K known at compile time: the K gathers of an item are all in flight before the first add (two or three
+            for (int i = lane; i < items; i += 128) {  // i & 3 == quad; two (base, tap) items per pass
+                const bool two = i + 64 < items;
+                const int pt0 = i >> 2, pt1 = two ? (i + 64) >> 2 : pt0;
+                const int p0 = pt0 / KW1, t0 = pt0 - p0 * KW1, p1 = pt1 / KW1, t1 = pt1 - p1 * KW1;
+                const unsigned long long wv0 = s_code[p0], wv1 = s_code[p1];
+                const float *wt0 = s_wt + (size_t)t0 * K * 80 + 4 * quad, *wt1 = s_wt + (size_t)t1 * K * 80 + 4 * quad;
+                // K known at compile time: the 2 K gathers of a pass are all in flight before the first add (two or three
                 // waves per SIMD here, not the eight of the standalone front kernel, so the loop must not serialise them)
-                float4 v[K];
+                float4 va[K], vb[K];
 #pragma unroll
                 for (int kp = 0; kp < K; ++kp) {
-                    const int b = (int)((wv >> (3 * kp)) & 7ull);
-                    v[kp] = *reinterpret_cast<const float4 *>(wt + (kp * 5 + b) * 16);
+                    va[kp] = *reinterpret_cast<const float4 *>(wt0 + (kp * 5 + (int)((wv0 >> (3 * kp)) & 7ull)) * 16);
+                    vb[kp] = *reinterpret_cast<const float4 *>(wt1 + (kp * 5 + (int)((wv1 >> (3 * kp)) & 7ull)) * 16);
                 }
-                f32x2 lo = pk_splat(0.f), hi = pk_splat(0.f);
+                f32x2 lo0 = pk_splat(0.f), hi0 = pk_splat(0.f), lo1 = pk_splat(0.f), hi1 = pk_splat(0.f);
 #pragma unroll
                 for (int kp = 0; kp < K; ++kp) {
-                    lo += f32x2{v[kp].x, v[kp].y};
-                    hi += f32x2{v[kp].z, v[kp].w};
+                    lo0 += f32x2{va[kp].x, va[kp].y};
+                    hi0 += f32x2{va[kp].z, va[kp].w};
+                    lo1 += f32x2{vb[kp].x, vb[kp].y};
+                    hi1 += f32x2{vb[kp].z, vb[kp].w};
                 }
-                *reinterpret_cast<float4 *>(s_u + (size_t)pt * 16 + 4 * quad) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                *reinterpret_cast<float4 *>(s_u + (size_t)pt0 * 16 + 4 * quad) = make_float4(lo0.x, lo0.y, hi0.x, hi0.y);
+                if (two) *reinterpret_cast<float4 *>(s_u + (size_t)pt1 * 16 + 4 * quad) = make_float4(lo1.x, lo1.y, hi1.x, hi1.y);
             }
             wave_sync();
             float *row0 = smem + (size_t)quad * a.plane + (size_t)c * a.pin * 4;
-            for (int i = lane; i < a.pin * 4; i += 64) {
-                const int pos = i >> 2;
-                f32x2 lo = bq_lo, hi = bq_hi;
-                int pb[KW1];
-#pragma unroll
-                for (int t = 0; t < KW1; ++t) pb[t] = s_pidx[pos + t];
-                float4 v[KW1];
-#pragma unroll
-                for (int t = 0; t < KW1; ++t) v[t] = *reinterpret_cast<const float4 *>(s_u + ((size_t)pb[t] * KW1 + t) * 16 + 4 * quad);
+            const int n_pos_items = a.pin * 4;
+            for (int i = lane; i < n_pos_items; i += 128) {  // two positions per pass (same channel quad): see sig3_front_kernel
+                const bool two = i + 64 < n_pos_items;
+                const int pos0 = i >> 2, pos1 = two ? (i + 64) >> 2 : pos0;
+                f32x2 lo0 = bq_lo, hi0 = bq_hi, lo1 = bq_lo, hi1 = bq_hi;
+                int pa[KW1], pb[KW1];
 #pragma unroll
                 for (int t = 0; t < KW1; ++t) {
-                    lo += f32x2{v[t].x, v[t].y};
-                    hi += f32x2{v[t].z, v[t].w};
+                    pa[t] = s_pidx[pos0 + t];
+                    pb[t] = s_pidx[pos1 + t];
                 }
-                swish_pk(lo, hi);
-                *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                float4 va[KW1], vb[KW1];
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    va[t] = *reinterpret_cast<const float4 *>(s_u + ((size_t)pa[t] * KW1 + t) * 16 + 4 * quad);
+                    vb[t] = *reinterpret_cast<const float4 *>(s_u + ((size_t)pb[t] * KW1 + t) * 16 + 4 * quad);
+                }
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    lo0 += f32x2{va[t].x, va[t].y};
+                    hi0 += f32x2{va[t].z, va[t].w};
+                    lo1 += f32x2{vb[t].x, vb[t].y};
+                    hi1 += f32x2{vb[t].z, vb[t].w};
+                }
+                swish_pk(lo0, hi0);
+                swish_pk(lo1, hi1);
+                *reinterpret_cast<float4 *>(row0 + pos0 * 4) = make_float4(lo0.x, lo0.y, hi0.x, hi0.y);
+                if (two) *reinterpret_cast<float4 *>(row0 + pos1 * 4) = make_float4(lo1.x, lo1.y, hi1.x, hi1.y);
             }
         }
         prefetch(it + gridDim.x);
