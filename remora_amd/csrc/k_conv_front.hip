@@ -16,11 +16,13 @@
 // barrier the matrix phase is conv_mfma_kernel's: wave w owns output channels 16w..16w+15 with its weight slice in
 // registers.  The arithmetic is that of the separate kernels, operation for operation (same results bit for bit).
 //
-// Measured (1 M chunks, MI355X): sig 0.20 + 0.60 -> 0.72 ms, seq 0.365 + 0.776 -> 1.12 ms per 131 k chunks; headline
-// 22.5 -> 23.2 M chunks/s.  Timing ablations (make abl, RMR_CONV_FRONT_ABLATE): producer phase alone 0.20 / 0.34 ms,
-// matrix phase alone 0.53 / 0.82 ms - the two add up; starting every second block of a CU half an iteration late
-// (per-CU arrival counters) changed nothing, nor did four accumulator chains per wave: a producer phase running under
-// the other block's matrix phase is slowed by exactly what it saves (shared fp32 datapath).
+// Measured (1 M chunks, MI355X; ms per 131 k chunks): sig 0.20 + 0.60 -> 0.68, seq 0.365 + 0.776 -> 1.00; headline
+// 22.5 -> 24.1 M chunks/s together with the larger sub-batch.  Timing ablations (make abl, RMR_CONV_FRONT_ABLATE):
+// producer phase alone 0.18 / 0.31, matrix phase alone 0.53 / 0.75 - the two add up.  Starting every second block of a
+// CU half an iteration late (per-CU arrival counters) changed nothing, nor did four accumulator chains per wave: a
+// producer phase running under the other block's matrix phase is slowed by what it saves (shared fp32 datapath).
+// What did pay inside the producers: the K gathers of an item batched before the first add (1.22 -> 1.12), exact tile
+// groups + the next iteration's rows requested under the matrix phase (-> 1.00; sig -3 %).
 #include "rmr_internal.h"
 #include "rmr_math.h"
 
