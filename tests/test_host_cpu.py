@@ -1583,3 +1583,27 @@ def test_bam_writer_thread_count_and_level_do_not_change_the_payload(tmp_path):
         payloads.append(gzip.open(str(p)).read())
     assert payloads[0] == payloads[1] == payloads[2]
     assert payloads[0] == header + b"".join(len(r).to_bytes(4, "little") + r for r in recs)
+
+
+def test_c_abi_is_plain_c99_and_fails_cleanly_without_a_gpu(tmp_path):
+    """include/remora_hip.h compiles as pedantic C99, libremora_hip.so links from C, and a C caller gets an error code
+    plus a message (never an abort) when there is no GPU - or a working engine when there is one (tests/c/abi_from_c.c)."""
+    import shutil
+    import subprocess
+
+    from remora_amd import _lib
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = tmp_path / "abi_from_c"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cc = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "tests", "c", "abi_from_c.c"), "-o", str(exe), "-L", libdir, "-lremora_hip",
+                         f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.stdout, run.stderr)
+    out = run.stdout
+    assert "version=remora_hip" in out and "gfx950" in out
+    assert "weights=" in out and int(out.split("weights=")[1].split()[0]) > 100000
+    assert "engine ok rc=0" in out or ("engine_create rc=-" in out and "error=" in out and len(out.split("error=")[1].strip()) > 5)
