@@ -220,6 +220,9 @@ def find_focus_bases_in_int_sequence(int_seq, motifs):
     return np.fromiter(hits, int, len(hits))
 
 
+_SMALL_INT_STR = [str(i) for i in range(1024)]  # MM gaps are small: a table lookup instead of str() per gap
+
+
 def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
     """MM / ML SAM tags from per-site probabilities (src/remora/util.py:485-537)."""
     order = np.argsort(np.asarray(poss), kind="stable")
@@ -232,7 +235,8 @@ def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
     can_at = np.flatnonzero(np.frombuffer(seq.encode(), np.uint8) == ord(can_base))
     can_idx = np.searchsorted(can_at, sorted_pos, side="right") - 1
     gaps = np.diff(np.concatenate([[-1], can_idx])) - 1
-    gap_str = ",".join(map(str, gaps.tolist()))
+    gl = gaps.tolist()
+    gap_str = ",".join(map(_SMALL_INT_STR.__getitem__, gl)) if 0 <= min(gl) and max(gl) < len(_SMALL_INT_STR) else ",".join(map(str, gl))
     valid = [p is not None for p in probs] if isinstance(probs, list) else None
     if valid is not None and not all(valid):
         raise RemoraError("per-site None probabilities are not supported")
@@ -241,7 +245,7 @@ def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
         mm_tag += f"{can_base}{strand}{mod_base}?,{gap_str};"
         scaled = np.floor(probs[:, mi] * 256)
         scaled[scaled == 256] = 255
-        ml_tag.extend(scaled.astype(np.uint8))
+        ml_tag.frombytes(scaled.astype(np.uint8).tobytes())  # (extend() walks the numpy array element by element: 40 us)
     return mm_tag, ml_tag
 
 
