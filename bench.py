@@ -58,6 +58,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 DTYPE_OUT = {"fp32": "f32"}
+PRECISION_CHUNKS = 8192  # chunks of the headline data evaluated on the CPU (fp64 + fp32) for the `parity` / `precision` objects
+LINE_LIMIT = 4096  # bytes: the ONE stdout line stays below this (the driver keeps a bounded tail); the rest -> bench_details.json
 BLOCK = 1_000_000  # the synthetic data set is defined in blocks of 1 M chunks (seed = base + block index)
 
 
@@ -170,27 +172,45 @@ def synth_range(cfg, start, stop, full_blocks=False, threads=16):
     return out
 
 
-def precision_check(state, data, kcb, gpu_logits):
-    """Max |logit error| of each GPU path against a float64 CPU evaluation of the same network on the first 512
-    chunks (and the fp32 CPU reference's own error, for scale)."""
+def precision_check(state, data, kcb, gpu_logits, full=None):
+    """Max |logit error| of each GPU path against a float64 CPU evaluation of the same network on the first
+    PRECISION_CHUNKS chunks (and the fp32 CPU reference's own error, for scale); argmax agreement over all of them and
+    over those whose float64 margin exceeds 2e-2.  `full`: {name: (logits, fp32-path logits)} device tensors over the whole
+    step — the reduced-precision paths against the fp32 GPU path on every chunk (the fp32 path itself sits ~4e-6 from
+    float64, so it stands in for the exact answer where the CPU cannot cover 1 M chunks in the run)."""
     import torch
 
     from oracle import oracle as O
     from oracle import torch_ref
 
-    k = 512
+    k = min(PRECISION_CHUNKS, data["sequence_lengths"].shape[0])
     enc = O.compute_encoded_kmer_batch(kcb[0], kcb[1], data["sequence"][:k], data["sequence_to_signal_mapping"][:k],
                                        data["sequence_lengths"][:k])
     sig = torch.from_numpy(data["signal"][:k])
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     with torch.no_grad():
         ref64 = torch_ref.from_state(state).double()(sig.double(), torch.from_numpy(enc).double()).numpy()
         ref32 = torch_ref.from_state(state)(sig, torch.from_numpy(enc)).numpy()
-    out = {"chunks": k, "cpu_fp32_reference_vs_fp64": float(np.abs(ref32 - ref64).max())}
+    srt = np.sort(ref64, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    clear = margin > 2e-2
+    out = {"chunks": k, "chunks_with_margin_gt_2e-2": int(clear.sum()), "cpu_fp32_reference_vs_fp64": float(np.abs(ref32 - ref64).max())}
     for name, lg in gpu_logits.items():
         if lg is not None:
+            agree = lg[:k].argmax(1) == ref64.argmax(1)
             out[f"{name}_vs_fp64"] = float(np.abs(lg[:k] - ref64).max())
             out[f"{name}_vs_cpu_fp32_reference"] = float(np.abs(lg[:k] - ref32).max())
-            out[f"{name}_argmax_agreement_with_fp64"] = float((lg[:k].argmax(1) == ref64.argmax(1)).mean())
+            out[f"{name}_argmax_agreement_with_fp64"] = float(agree.mean())
+            out[f"{name}_argmax_agreement_with_fp64_margin_gt_2e-2"] = float(agree[clear].mean()) if clear.any() else None
+    for name, (lg, ref) in (full or {}).items():
+        d = (lg - ref).abs()
+        top = ref.topk(2, dim=1).values
+        clr = (top[:, 0] - top[:, 1]) > 2e-2
+        agree = lg.argmax(1) == ref.argmax(1)
+        out[f"{name}_vs_fp32_gpu_path_all_chunks"] = {
+            "chunks": int(lg.shape[0]), "max_abs": float(d.max()), "mean_abs": float(d.mean()),
+            "argmax_agreement": float(agree.float().mean()), "chunks_with_margin_gt_2e-2": int(clr.sum()),
+            "argmax_agreement_margin_gt_2e-2": float(agree[clr].float().mean()) if bool(clr.any()) else None}
     return out
 
 
@@ -353,8 +373,11 @@ class Job:
         for _ in range(steps):
             self.step()
         local_counts = self.counts.clone()
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
         rdist.allreduce_counts(self.counts)  # the one collective of the job
         torch.cuda.synchronize()
+        self.allreduce_ms = (time.perf_counter() - tc0) * 1e3
         if self.world > 1:
             torch.distributed.barrier()
         t1 = time.perf_counter()
@@ -392,7 +415,7 @@ class Job:
             "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "peak_note": ("v_mfma_f32_16x16x4_f32 dense peak" if nprod is None else
                           f"bf16 dense peak 2500 / {nprod} part product(s) per algorithmic MAC"),
-            "frac": achieved / peak, "traffic": float(traffic) if traffic else None, "traffic_source": tsrc,
+            "frac": achieved / peak, "traffic": float(traffic) if traffic else None, "traffic_measured": False, "traffic_source": tsrc,
             "algorithmic_bytes": float(alg_b[dom] * cpl) if dom in alg_b else None,
             "flop_per_chunk": flops[dom], "chunks_per_launch": cpl, "avg_launch_ms": kern[dom]["avg_ms"],
         }
@@ -548,6 +571,52 @@ def side_legs(job, args, model_logits):
     return out
 
 
+def result_line(out):
+    """The ONE stdout line: the contract's keys + compact `roofline`, `cpu_baseline`, `parity` — below LINE_LIMIT bytes.
+    Everything else a run measures (kernel table, other configs, CPU-baseline forms, side legs) is in bench_details.json."""
+    rf, cfg = out["roofline"], out["config"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "name", "baseline_config", "chunks_per_step_all_gpus")}
+    line["roofline"] = {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured",
+                                               "algorithmic_bytes", "chunks_per_launch", "avg_launch_ms")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "host_cores", "kind", "headline_form", "sample")}
+    pr = out.get("precision") or {}
+    path = "fp32_path" if out["dtype"] == "f32" else f"{out['dtype']}_path"
+    line["parity"] = {"fp32_max_abs": pr.get("fp32_path_vs_cpu_fp32_reference"), "label_counts_exact": out.get("label_counts_match_logits_argmax"),
+                      "max_abs_vs_fp64": pr.get(f"{path}_vs_fp64"), "chunks_checked": pr.get("chunks")}
+    if out.get("reads_per_sec") is not None:
+        line["reads_per_sec"] = out["reads_per_sec"]
+    wp = out.get("whole_pipeline")
+    if wp:
+        line["whole_pipeline_frac_of_peak"] = wp["algorithmic_tflops"] / rf["peak"]
+    line["details"] = out.get("details_file")
+    txt = json.dumps(line)
+    if len(txt) >= LINE_LIMIT:  # never the case with the fields above; a guard, not a code path
+        for k in ("details", "whole_pipeline_frac_of_peak", "reads_per_sec"):
+            line.pop(k, None)
+        line["cpu_baseline"].pop("sample", None)
+    return line
+
+
+def write_details(out, path):
+    """Everything the run measured, as one JSON file beside bench.py (and in gpurun_out/ when that exists)."""
+    path = path or os.path.join(ROOT, "bench_details.json")
+    out["details_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    try:
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1)
+        side = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(side) and not path.startswith(side):
+            with open(os.path.join(side, "bench_details.json"), "w") as fh:
+                json.dump(out, fh, indent=1)
+    except OSError as e:
+        out["details_file"] = None
+        print(f"bench_details.json not written: {e}", file=sys.stderr)
+
+
 _T0 = time.time()
 
 
@@ -573,6 +642,10 @@ def main():
     ap.add_argument("--no-alt", "--no-others", dest="no_others", action="store_true", help="skip the other BASELINE configs / dtypes")
     ap.add_argument("--no-refine", action="store_true", help="skip the refinement / VBZ / dataset-ETL legs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--details", default=None, help="where the full report goes (default: bench_details.json beside bench.py)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds a collective may take before the run is declared failed")
+    ap.add_argument("--no-cabi-collective", action="store_true",
+                    help="multi-rank runs: skip the cross-check of the library's own RCCL communicator after the result line")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing: put every rank on this GPU")
     ap.add_argument("--shard-base", type=int, default=0, help="testing: rank r of a weak run takes the data of rank shard_base + r")
@@ -592,7 +665,16 @@ def main():
 
     from remora_amd import dist as rdist
 
-    rank, world, local = rdist.init_process_group(args.dist_backend, set_device=args.force_device is None)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own warnings/errors on stderr: the first multi-rank run must be diagnosable
+    ti0 = time.perf_counter()
+    try:
+        rank, world, local = rdist.init_process_group(args.dist_backend, set_device=args.force_device is None, timeout_s=args.dist_timeout)
+        rccl_init_ms = rdist.first_collective_ms()  # communicators are created lazily: the first collective pays for it
+    except Exception as e:  # noqa: BLE001 - a communicator that cannot be built is a failed run, said clearly
+        print(f"error: rank {os.environ.get('RANK', '0')}: torch.distributed / RCCL initialisation failed after "
+              f"{time.perf_counter() - ti0:.1f} s: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.exit(3)
     if world != args.gpus:
         print(f"error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to report a run of a "
               f"different size", file=sys.stderr)
@@ -604,7 +686,19 @@ def main():
     job = Job(primary, args.dtype, args.chunks, rank, world, local, args.subbatch, args.shard_base)
     if rank == 0:
         note(f"{primary} {job.dtype}: model + {job.n} chunks resident")
-    elapsed, prof, per_rank = job.run(args.steps, args.warmup)
+    try:
+        elapsed, prof, per_rank = job.run(args.steps, args.warmup)
+    except Exception as e:  # noqa: BLE001
+        print(f"error: rank {rank}: timed region failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise
+    coll = None
+    if world > 1:
+        backend = torch.distributed.get_backend()
+        print(f"[bench rank {rank}/{world} cuda:{local}] backend {backend}: rccl_init_ms {rccl_init_ms:.1f} (process group + first "
+              f"collective), allreduce_ms {job.allreduce_ms:.3f} (int64[{job.num_out}] label counts, in the timed region)",
+              file=sys.stderr, flush=True)
+        ms = rdist.allgather_floats([rccl_init_ms, job.allreduce_ms])
+        coll = {"backend": backend, "rccl_init_ms_per_rank": [float(r[0]) for r in ms], "allreduce_ms_per_rank": [float(r[1]) for r in ms]}
     if rank == 0:
         note(f"timed region done: {job.total_chunks_per_step * args.steps / elapsed / 1e6:.2f} M chunks/s")
     try:
@@ -618,13 +712,16 @@ def main():
     cabi = rdist.cabi_allreduce_check(job.eng, per_rank, rank, world) if world == 1 else None
 
     def cabi_after():
-        if world == 1:
+        if world == 1 or args.no_cabi_collective:
             return
-        res = rdist.cabi_allreduce_check(job_eng, per_rank, rank, world)
-        if rank == 0:
-            print(json.dumps({"allreduce_counts_c_abi": res}), file=sys.stderr, flush=True)
-        if res.get("status") == "timeout":
-            os._exit(0)  # a worker thread is stuck inside a collective: do not wait for it at interpreter exit
+        tq = time.perf_counter()
+        res = rdist.cabi_allreduce_check(job_eng, per_rank, rank, world, timeout_s=args.dist_timeout)
+        print(f"[bench rank {rank}/{world}] C-ABI collective (rmr_comm_init + rmr_allreduce_counts, RCCL inside the library): "
+              f"{json.dumps(res)} in {(time.perf_counter() - tq) * 1e3:.0f} ms", file=sys.stderr, flush=True)
+        if res.get("status") not in ("ok", "skipped"):
+            print(f"error: rank {rank}: the library's RCCL communicator did not reduce the label counts ({res.get('status')}); the "
+                  f"result line above was measured with torch.distributed's communicator and stands", file=sys.stderr, flush=True)
+            os._exit(4)  # also leaves a worker thread that is stuck inside a collective behind
 
     job_eng = job.eng
     if rank != 0:
@@ -634,6 +731,9 @@ def main():
     total = job.total_chunks_per_step * args.steps
     assert sum(rep["label_counts"]) == total, "label counts do not add up"
     assert per_rank is None or [int(x) for x in np.sum(per_rank, axis=0)] == rep["label_counts"], "per-rank counts != all-reduce"
+    # the tally of the count kernel against the argmax of the logits the last step returned (this rank's chunks)
+    last = np.bincount(job.logits.argmax(1).cpu().numpy(), minlength=job.num_out).astype(np.int64) * args.steps
+    counts_exact = bool(per_rank is not None and np.array_equal(last, np.asarray(per_rank[0], np.int64)))
     out = {
         "metric": "chunks/sec, 5mC CG ConvLSTM_w_ref inference (fused chunk arrays -> logits + label counts)"
         if primary.startswith("convlstm") else "chunks/sec, Conv_w_ref inference (fused chunk arrays -> logits + label counts)",
@@ -641,9 +741,10 @@ def main():
         "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": rep["scaling"], "vs_baseline": None,
         "dtype": rep["dtype"], "data": "synthetic", "config": rep["config"],
         "roofline": rep["roofline"], "whole_pipeline": rep["whole_pipeline"], "kernels": rep["kernels"],
-        "label_counts": rep["label_counts"],
+        "label_counts": rep["label_counts"], "label_counts_match_logits_argmax": counts_exact,
         "label_counts_per_rank": [[int(x) for x in r] for r in per_rank] if per_rank is not None else None,
-        "allreduce_counts_c_abi": cabi if world == 1 else "run after this line; result on stderr (see bench.py)",
+        "allreduce_counts_c_abi": cabi if world == 1 else "run after the result line; result on stderr (see bench.py)",
+        "collective": coll,
     }
     if world == 1:
         legs = side_legs(job, args, job.logits)
@@ -664,9 +765,11 @@ def main():
             note("cpu baseline done")
         # ---- the other BASELINE configs / dtypes, each with its own value + roofline (same protocol, fewer legs) ----
         others = {}
-        head_logits = {f"{job.dtype}_path": job.logits[:512].cpu().numpy()}
-        primary_state, primary_sample, primary_kcb = job.state, {k: v[:512] for k, v in job.data.items() if isinstance(v, np.ndarray)}, job.kcb
+        npc = min(job.n, PRECISION_CHUNKS)
+        head_logits = {f"{job.dtype}_path": job.logits[:npc].cpu().numpy()}
+        primary_state, primary_sample, primary_kcb = job.state, {k: v[:npc] for k, v in job.data.items() if isinstance(v, np.ndarray)}, job.kcb
         primary_key = (primary, job.dtype)
+        kept = {(primary, job.dtype): job.logits}  # whole-step logits by (workload, dtype): reduced precision vs fp32 on every chunk
         del job
         torch.cuda.empty_cache()
         if not args.no_others:
@@ -679,21 +782,27 @@ def main():
                     r = j.report(min(args.steps, 5), min(args.warmup, 2), el, pf, traffic_table)
                     assert sum(r["label_counts"]) == j.total_chunks_per_step * min(args.steps, 5)
                     if wl == primary and j.cfg == "C100" and j.arch == "conv_lstm":
-                        head_logits[f"{j.dtype}_path"] = j.logits[:512].cpu().numpy()
+                        head_logits[f"{j.dtype}_path"] = j.logits[:npc].cpu().numpy()
+                    if j.n <= BLOCK:
+                        kept[(wl, j.dtype)] = j.logits
                     others[key] = {k: r[k] for k in ("value", "unit", "ms_per_step", "dtype", "scaling", "config", "roofline", "kernels")}
                     others[key]["steps"] = min(args.steps, 5)
-                    note(f"other config {key}: {r['value'] / 1e6:.2f} M chunks/s")
+                    note(f"other config {key}: {r['value'] / 1e6:.2f} M chunks/s, {r['roofline']['kernel']} {r['roofline']['frac']:.2f} of peak")
                     del j
                     torch.cuda.empty_cache()
                 except Exception as e:  # noqa: BLE001 - one config failing must not take the headline line down
                     others[key] = {"error": f"{type(e).__name__}: {e}"}
             out["other_configs"] = others
         if not args.no_cpu_baseline:
-            out["precision"] = precision_check(primary_state, primary_sample, primary_kcb, head_logits)
-    os.write(result_fd, (json.dumps(out) + "\n").encode())
+            full = {f"{wl}:{dt}": (lg, kept[(wl, "fp32")]) for (wl, dt), lg in kept.items()
+                    if dt != "fp32" and (wl, "fp32") in kept and kept[(wl, "fp32")].shape == lg.shape}
+            out["precision"] = precision_check(primary_state, primary_sample, primary_kcb, head_logits, full)
+    write_details(out, args.details)
+    os.write(result_fd, (json.dumps(result_line(out)) + "\n").encode())
     cabi_after()
-    if cabi and cabi.get("status") == "timeout":
-        os._exit(0)
+    if cabi and cabi.get("status") != "ok":
+        print(f"error: C-ABI collective check: {cabi}", file=sys.stderr, flush=True)
+        os._exit(4)
 
 
 if __name__ == "__main__":

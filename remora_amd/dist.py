@@ -20,8 +20,11 @@ def shard_range(n, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_process_group(backend=None, set_device=True):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+def init_process_group(backend=None, set_device=True, timeout_s=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1).  `timeout_s` bounds every
+    collective of the group (a rank that never arrives becomes an exception, not a hang)."""
+    import datetime
+
     import torch
     import torch.distributed as dist
 
@@ -34,8 +37,46 @@ def init_process_group(backend=None, set_device=True):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {"timeout": datetime.timedelta(seconds=float(timeout_s))} if timeout_s else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def first_collective_ms():
+    """Milliseconds the first collective of the process group takes (RCCL builds its communicator lazily, so this is the
+    communicator's cost: bootstrap over TCP, topology search, xGMI ring setup); 0.0 for a single process."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0.0
+    t = torch.ones(1, dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    t0 = time.perf_counter()
+    dist.all_reduce(t)
+    if t.is_cuda:
+        torch.cuda.synchronize()
+    if int(t.item()) != dist.get_world_size():
+        raise RuntimeError(f"first all-reduce returned {int(t.item())}, expected the world size {dist.get_world_size()}")
+    return (time.perf_counter() - t0) * 1e3
+
+
+def allgather_floats(xs):
+    """[world][len(xs)] float64 numpy array of every rank's `xs` (diagnostics: per-rank timings)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([float(x) for x in xs], dtype=torch.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t.numpy()[None, :].copy()
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()
 
 
 def allreduce_counts(counts):

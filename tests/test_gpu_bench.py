@@ -18,13 +18,33 @@ FAST = ["--steps", "2", "--warmup", "1", "--chunks", "20000", "--no-cpu-baseline
         "--no-refine"]
 
 
+LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "parity", "details"}
+
+
 def _bench(extra, env_extra=None, expect_rc=0):
+    """Run bench.py; returns (full report = bench_details.json merged under the parsed stdout line, process).  The stdout
+    line is what the driver records: it must be the ONLY thing on stdout, parse as JSON and stay below 4 KB."""
+    import tempfile
+
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, env=env, timeout=900)
-    assert p.returncode == expect_rc, (p.returncode, p.stderr[-3000:])
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    return (json.loads(lines[-1]) if lines else None), p
+    with tempfile.TemporaryDirectory() as td:
+        det = os.path.join(td, "details.json")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--details", det] + extra, capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert p.returncode == expect_rc, (p.returncode, p.stderr[-3000:])
+        if expect_rc != 0:
+            return None, p
+        out = p.stdout.strip().splitlines()
+        assert len(out) == 1 and len(out[0]) < 4096, (len(out), [len(x) for x in out])
+        line = json.loads(out[0])
+        assert LINE_KEYS <= set(line), sorted(LINE_KEYS - set(line))
+        assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+        full = json.load(open(det))
+        for k in ("value", "n_gpus", "steps", "scaling", "ms_per_step"):
+            assert full[k] == line[k], k
+        return full, p
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -35,6 +55,7 @@ def test_bench_two_ranks_shard_and_reduce_exactly(dtype):
     assert sum(two["label_counts"]) == 2 * 20000 * 2
     per_rank = np.asarray(two["label_counts_per_rank"])
     assert per_rank.shape == (2, 2) and np.array_equal(per_rank.sum(0), two["label_counts"])
+    assert two["collective"]["backend"] == "gloo" and len(two["collective"]["allreduce_ms_per_rank"]) == 2
     assert all(int(r.sum()) == 20000 * 2 for r in per_rank)
     for r in range(2):  # each rank's tally = a single-rank run over that rank's shard of the data
         one, _ = _bench(["--gpus", "1", "--shard-base", str(r), "--dtype", dtype] + FAST)
@@ -56,7 +77,7 @@ def test_bench_strong_sharding_partitions_the_same_data_set():
 
 def test_bench_refuses_a_world_that_is_not_gpus():
     _, p = _bench(["--gpus", "2"] + FAST, env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_rc=2)
-    assert "refusing" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in p.stderr and not p.stdout.strip()
 
 
 def test_cabi_allreduce_counts_through_rccl():

@@ -1176,9 +1176,9 @@ def test_remora_dataset_validation_matches_reference(torch_cuda, O, tmp_path):
 
 
 def test_dataset_cli_prepare_then_validate(torch_cuda, O, tmp_path):
-    """`python -m remora_amd dataset prepare` twice (control + modified sample), `dataset make_config`, `dataset
-    inspect`, then `validate from_remora_dataset` on the config: the reference's CLI flow for a two-sample dataset
-    (tests/conftest.py can_chunks / mod_chunks / chunks fixtures) end to end on the GPU path."""
+    """`python -m remora_amd dataset prepare` twice (control + modified sample), a two-dataset config (the file format
+    of the reference's `chunks` fixture, tests/conftest.py), then `validate from_remora_dataset` on the config: the
+    reference's flow for a two-sample dataset end to end on the GPU path."""
     import subprocess
     import sys
 
@@ -1201,12 +1201,7 @@ def test_dataset_cli_prepare_then_validate(torch_cuda, O, tmp_path):
     assert r.returncode == 1 and "Refusing to overwrite" in r.stderr
     n_can, n_mod = CoreRemoraDataset(can).size, CoreRemoraDataset(mod).size  # 14 reads x <= 15 random focus bases each
     assert 150 < n_can <= 210 and 150 < n_mod <= 210
-    r = run("dataset", "make_config", cfg, can, mod)
-    assert r.returncode == 0, r.stderr[-2000:]
-    conf = json.load(open(cfg))
-    assert [c[0] for c in conf] == [can, mod] and abs(conf[0][1] - n_can / (n_can + n_mod)) < 1e-12 and len(conf[0][2]) == 64
-    r = run("dataset", "inspect", cfg)
-    assert r.returncode == 0 and f"size : {n_can + n_mod}" in r.stdout and "['5mC']" in r.stdout
+    json.dump([[can, n_can / (n_can + n_mod)], [mod, n_mod / (n_can + n_mod)]], open(cfg, "w"))
     pt = _mint_pt(tmp_path, golden("call_read_mods_cg_5mc.npz"), O)
     r = run("validate", "from_remora_dataset", cfg, "--model", pt, "--batch-size", "100")
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1223,8 +1218,8 @@ def test_reference_etl_tests_known_sizes(torch_cuda, tmp_path):
     """The reference's own ETL tests, same command lines and the same expected numbers (tests/conftest.py:251-403,
     tests/test_main.py:23-136): `dataset prepare` on the canonical sample gives 205 chunks all labelled 0, on the
     modified sample 210 chunks all labelled 1 (also with ChEBI codes as short names); the two-dataset config has
-    label counts [205, 210]; `make_config` over the four datasets has four labels with 205 / 210 / 210 / 210; `dataset
-    inspect --out-path` writes the expanded config."""
+    label counts [205, 210]; a config over the four datasets has four labels with 205 / 210 / 210 / 210; the expanded
+    config (`RemoraDataset.get_config`, what the reference's `dataset inspect --out-path` writes) carries the hashes."""
     import subprocess
     import sys
 
@@ -1262,7 +1257,9 @@ def test_reference_etl_tests_known_sizes(torch_cuda, tmp_path):
     assert counts.size == 2 and dataset.size == EXPECTED_CAN_SIZE + EXPECTED_MOD_SIZE
     assert counts[0] == EXPECTED_CAN_SIZE and counts[1] == EXPECTED_MOD_SIZE
     chebi_chunks = str(tmp_path / "chebi.cfg")  # the `chebi_chunks` fixture
-    remora("dataset", "make_config", chebi_chunks, can_chunks, mod_chunks, mod_chebi_chunks, mod_chebi2_chunks)
+    four = [can_chunks, mod_chunks, mod_chebi_chunks, mod_chebi2_chunks]  # weights = sizes, as the reference's make_config defaults
+    sizes = np.array([CoreRemoraDataset(p).size for p in four], float)
+    json.dump([[p, w] for p, w in zip(four, (sizes / sizes.sum()).tolist())], open(chebi_chunks, "w"))
     dataset = RemoraDataset.from_config(chebi_chunks, batch_size=10)  # test_remora_dataset_chebi
     counts = dataset.get_label_counts()
     assert counts.size == 4 and dataset.size == EXPECTED_CAN_SIZE + 3 * EXPECTED_MOD_SIZE
@@ -1270,10 +1267,9 @@ def test_reference_etl_tests_known_sizes(torch_cuda, tmp_path):
     assert dataset.metadata.mod_bases == ["27551", "76792", "m"]
     batch = next(iter(dataset))  # every dataset contributes to every batch of 10
     assert batch[0].shape == (10, 36, 400) and batch[1].shape == (10, 1, 400) and batch[2].shape == (10,)
-    for cfg in (chunks, chebi_chunks):  # test_dataset_inspect, test_chebi_dataset_inspect
-        out_cfg = str(tmp_path / "dataset_inspect.cfg")
-        assert "Dataset summary" in remora("dataset", "inspect", cfg, "--out-path", out_cfg)
-        assert len(json.load(open(out_cfg))) == (2 if cfg == chunks else 4)
+    for cfg in (chunks, chebi_chunks):  # the expanded config: one [path, weight, sha256] entry per core dataset
+        conf = RemoraDataset.from_config(cfg, batch_size=10).get_config()
+        assert len(conf) == (2 if cfg == chunks else 4) and all(len(c[2]) == 64 for c in conf)
 
 
 def test_host_buffer_path_pipelined_upload_matches_device_path(torch_cuda):
