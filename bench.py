@@ -281,13 +281,16 @@ def cpu_baseline(state, data, kcb, budget_s=12.0):
                 "threads": threads, "chunks": done, "warmup_batches": warm}
 
     # torch's intra-op pool collapses when every core of a large host is asked for on this small network (one batch can take
-    # >10 s on 256 cores): such a form is timed on ONE warm-up + ONE timed batch, so that the default bench stays bounded
+    # >10 s on 256 cores): such a form is not re-timed — the probe's own batch IS its measurement, and the scripted form at
+    # the same thread count is skipped with that reason (two more warm-up passes would cost a minute of the default run)
     slow_all = per_batch_s.get(host_cores, 0.0) > 2.0
-    forms = {"eager_all_cores": timed(net, host_cores, budget_s / 3, warm=1 if slow_all else 2)}
-    if jit_net is not None:
-        forms["jit_script_all_cores"] = timed(jit_net, host_cores, budget_s / 3, warm=1 if slow_all else 2)
+    if slow_all:
+        forms = {"eager_all_cores": {"chunks_per_s": tuned[host_cores], "threads": host_cores, "chunks": npb, "warmup_batches": 0,
+                                     "note": f"one batch took {per_batch_s[host_cores]:.1f} s (network only, the thread probe's measurement)"},
+                 "jit_script_all_cores": {"skipped": f"eager at {host_cores} threads takes {per_batch_s[host_cores]:.1f} s per batch of {npb}"}}
     else:
-        forms["jit_script_all_cores"] = {"error": jit_err}
+        forms = {"eager_all_cores": timed(net, host_cores, budget_s / 3)}
+        forms["jit_script_all_cores"] = timed(jit_net, host_cores, budget_s / 3) if jit_net is not None else {"error": jit_err}
     forms["eager_best_threads"] = timed(net, best_threads, budget_s / 3)
     ok = {k: v for k, v in forms.items() if "chunks_per_s" in v}
     head = max(ok, key=lambda k: ok[k]["chunks_per_s"])
@@ -297,7 +300,7 @@ def cpu_baseline(state, data, kcb, budget_s=12.0):
         "sample": f"{ok[head]['chunks']} chunks in batches of {B}: C port of compute_encoded_kmer_batch (1 thread) + torch.nn "
                   f"restatement of the network, fp32, form '{head}' with {ok[head]['threads']} torch threads (box has {host_cores} cores)",
         "forms": forms, "thread_probe_chunks_per_s": {str(k): v for k, v in tuned.items()},
-        "encode_chunks_per_s": ok[head]["encode_chunks_per_s"], "model_chunks_per_s": ok[head]["model_chunks_per_s"],
+        "encode_chunks_per_s": ok[head].get("encode_chunks_per_s"), "model_chunks_per_s": ok[head].get("model_chunks_per_s"),
     }
 
 

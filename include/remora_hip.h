@@ -176,6 +176,12 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
  * as returned in rmr_bam_batch.voffset - the random access ReadIndexedBam.get_alignments needs
  * (src/remora/io.py:303-325) */
 int rmr_bam_seek(rmr_bam *b, int64_t voffset);
+/* From the current position to the end of the file: count the records and note the virtual offset of records 0, every,
+ * 2*every, ... in voffsets[0..cap) (only block_size fields are read).  What a worker of a multi-GPU run needs to take a
+ * contiguous share of the alignments by itself (one process per GPU, each seeks to its own range; north_star: "reads
+ * shard embarrassingly across the GPUs") - the reference hands reads out from ONE reader process instead
+ * (src/remora/inference.py:488-519).  Leaves the handle at end of file: rmr_bam_seek before reading. */
+int rmr_bam_scan(rmr_bam *b, int64_t every, int64_t *voffsets, int64_t cap, int64_t *n_records);
 
 /* ---- N1: POD5 signal rows, the zstd layer (host code, parallel over rows) ----------------------------- */
 /* replaces: the zstd step of pod5's signal reader under io.iter_signal (src/remora/io.py:441-474).  `src[i]`

@@ -7,6 +7,7 @@ k-mer contexts, the reference's validation summary line against the stored label
 (:64-337), the ETL into the on-disk chunk format.  The rest of the reference's `dataset` sub-commands (inspect, make_config,
 merge, head, copy) are bookkeeping outside the hot path and are not rebuilt (SURVEY §2 #16)."""
 import argparse
+import os
 import sys
 
 from . import RemoraError, constants
@@ -21,21 +22,32 @@ def _validate(args):
     from .model_util import load_torchscript_model
     from .validate import ValidationLogger
 
-    model, md = load_torchscript_model(args.model, device=args.device, eval_only=True, dtype=args.dtype)
+    from . import dist as rdist
+
+    rank, world, dev = rdist.setup_ranks(args.gpus)
+    model, md = load_torchscript_model(args.model, device=args.device if dev is None else dev, eval_only=True, dtype=args.dtype)
     over = {"extra_arrays": {}, "kmer_context_bases": md["kmer_context_bases"], "chunk_context": md["chunk_context"]}
     paths, props, hashes = load_dataset(args.remora_dataset_path)
     dataset = RemoraDataset([CoreRemoraDataset(p, override_metadata=dict(over), infinite_iter=False,
                                                do_check_super_batches=True) for p in paths],
                             props, hashes, batch_size=args.batch_size)
-    out_fp = sys.stdout if args.out_file is None else open(args.out_file, "w", buffering=1)
-    full_fp = None if args.full_results_filename is None else open(args.full_results_filename, "w", buffering=1)
+    if world > 1:  # this rank's contiguous share of every core dataset's rows
+        dataset = dataset.shard(rank, world)
+    # rank 0 writes the summary (every rank holds the same global metrics); the per-chunk table is per rank
+    sink = open(os.devnull, "w") if rank != 0 else None
+    out_fp = sink if sink is not None else (sys.stdout if args.out_file is None else open(args.out_file, "w", buffering=1))
+    full_name = args.full_results_filename
+    if full_name is not None and world > 1:
+        full_name = f"{full_name}.rank{rank:03d}"
+    full_fp = None if full_name is None else open(full_name, "w", buffering=1)
     try:
         ValidationLogger(out_fp, full_fp).validate_model(model, md["mod_bases"], torch.nn.CrossEntropyLoss(), dataset,
-                                                         args.pct_filt / 100)
+                                                         args.pct_filt / 100, world=world)
     finally:
         for fp in (out_fp, full_fp):
             if fp not in (None, sys.stdout):
                 fp.close()
+    rdist.barrier()
     return 0
 
 
@@ -77,19 +89,29 @@ def _dataset_prepare(args):
 
 
 def _infer(args):
+    from . import dist as rdist
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model
 
-    loaded = [load_torchscript_model(m, device=args.device, eval_only=True, dtype=args.dtype) for m in args.model]
+    rank, world, dev = rdist.setup_ranks(args.gpus)
+    loaded = [load_torchscript_model(m, device=args.device if dev is None else dev, eval_only=True, dtype=args.dtype)
+              for m in args.model]
     model, md = [x[0] for x in loaded], [x[1] for x in loaded]
     if len({m["can_base"] for m in md}) != len(md):
         raise RemoraError("Only one model per canonical base allowed.")
+    label_counts = {}
     stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
-                                    reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored)
+                                    reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored,
+                                    rank=rank, world=world, label_counts_out=label_counts)
+    if rank != 0:
+        return 0
     ok = stats.pop(None, 0)
-    print(f"called {ok} reads -> {args.out_bam}")
+    print(f"called {ok} reads -> {args.out_bam}" + (f" ({world} GPUs)" if world > 1 else ""))
     for reason, cnt in sorted(stats.items(), key=lambda kv: -kv[1]):
         print(f"{cnt:>7} : {reason}")
+    for m in md:
+        names = ["canonical"] + list(m["mod_long_names"])
+        print(f"calls per label ({m['can_base']}): " + "; ".join(f"{n}:{int(c)}" for n, c in zip(names, label_counts[m["can_base"]])))
     return 0
 
 
@@ -104,6 +126,9 @@ def main(argv=None):
                    help="TorchScript model file (with meta.txt); repeat for one model per canonical base")
     p.add_argument("--out-bam", required=True)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--gpus", type=int, default=1,
+                   help="one process per GPU, each takes a contiguous share of the alignments (ranks are started here unless "
+                        "already under torchrun); the parts are joined into --out-bam in input order")
     p.add_argument("--num-reads", type=int, default=None)
     p.add_argument("--reads-per-batch", type=int, default=256)
     p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")
@@ -119,6 +144,8 @@ def main(argv=None):
     v.add_argument("--full-results-filename", help="per-chunk label, call and probabilities (TSV)")
     v.add_argument("--pct-filt", type=float, default=10.0)
     v.add_argument("--device", type=int, default=0)
+    v.add_argument("--gpus", type=int, default=1,
+                   help="one process per GPU, each validates a contiguous share of the rows; confusion counts are all-reduced")
     v.add_argument("--batch-size", type=int, default=131072)
     v.add_argument("--dtype", default=None)
     v.set_defaults(func=_validate)
@@ -156,6 +183,10 @@ def main(argv=None):
     d.set_defaults(func=_dataset_prepare)
 
     args = ap.parse_args(argv)
+    if getattr(args, "gpus", 1) > 1 and "WORLD_SIZE" not in os.environ:
+        from .dist import launch_ranks
+
+        return launch_ranks(sys.argv[1:] if argv is None else list(argv), args.gpus)
     try:
         return args.func(args)
     except RemoraError as e:

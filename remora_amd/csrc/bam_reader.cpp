@@ -508,6 +508,39 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
     return 0;
 }
 
+// Walk the rest of the file reading only the block_size fields: the number of records and the virtual offset of every
+// `every`-th one (records 0, every, 2 every, ...), so that N workers can each seek to a contiguous share of the
+// records without a coordinator handing them out (no tag, name or base is decoded: BGZF inflate + one add per record).
+int rmr_bam_scan(rmr_bam *b, int64_t every, int64_t *voffsets, int64_t cap, int64_t *n_records) {
+    if (!b || !n_records || every < 1 || cap < 0 || (cap > 0 && !voffsets)) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    int64_t n = 0;
+    for (;;) {
+        int rc = ensure(b, 4);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            if (b->ubuf.size() - b->upos != 0) RMR_FAIL(RMR_ERR_INVALID, "truncated BAM file");
+            break;
+        }
+        const int64_t bs = rd_i32(b->ubuf.data() + b->upos);
+        if (bs < 32) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM record");
+        if (n % every == 0 && n / every < cap) {
+            int64_t vo = -1;
+            for (const auto &sg : b->segs) {
+                const size_t rel = b->upos - sg.begin;
+                if (rel < sg.isize) { vo = (sg.file_off << 16) | (int64_t)rel; break; }
+            }
+            voffsets[n / every] = vo;
+        }
+        rc = ensure(b, 4 + (size_t)bs);
+        if (rc < 0) return rc;
+        if (rc == 0) RMR_FAIL(RMR_ERR_INVALID, "truncated BAM file");
+        b->upos += 4 + (size_t)bs;
+        ++n;
+    }
+    *n_records = n;
+    return 0;
+}
+
 int rmr_bam_seek(rmr_bam *b, int64_t voffset) {
     if (!b || voffset < 0) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
     if (fseeko(b->fh, (off_t)(voffset >> 16), SEEK_SET) != 0) RMR_FAIL(RMR_ERR_INVALID, "seek failed");

@@ -124,7 +124,7 @@ int rmr_engine::prof_collect() {
 extern "C" {
 
 const char *rmr_last_error(void) { return g_err.c_str(); }
-const char *rmr_version(void) { return "remora_hip 0.2 (gfx950)"; }  // 0.2: rmr_reads grew three optional fields
+const char *rmr_version(void) { return "remora_hip 0.3 (gfx950)"; }  // 0.3: rmr_bam_scan
 
 int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
     if (!out) RMR_FAIL(RMR_ERR_INVALID, "out is NULL");

@@ -392,13 +392,22 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
 
 }  // namespace
 
+static constexpr size_t CONV_FRONT_MAX_LDS = 156 * 1024;  // of the CU's 160 KB
+
 bool conv_front_supported(const rmr_model *m, int kb, int ka, int seq_w, int map_w) {
     if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 0 || m->front.kw1 != 5) return false;
     if (m->sig3.ic != 16 || m->sig3.kw != 9 || m->sig3.stride != 3 || m->sig3.oc != 64) return false;
     if (m->seq2.ic != 16 || m->seq2.kw != 13 || m->seq2.stride != 3 || m->seq2.oc != 64) return false;
     if (kb + ka + 1 != m->desc.kmer_len || m->desc.kmer_len != 9) return false;  // the instantiated k-mer length
     if (map_w < 2 || seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
-    return true;
+    // one chunk per block iteration must fit a CU's LDS in both kernels (long chunk contexts / sequences otherwise go
+    // through the separate front + conv_mfma kernels): the same sizes launch_conv_front computes
+    auto up4 = [](int words) { return (words + 3) & ~3; };
+    const size_t sig1 = ((size_t)(4 * (((m->P2 * 4) + 63) & ~63) + 16) + up4(((m->L + 3) & ~3) + m->P1 * 4)) * sizeof(float);
+    const int maxlen = map_w - 1;
+    const int per_seq = up4(up4((map_w * 2 + 3) / 4) + up4((seq_w + 3) / 4) + up4(maxlen * 2) + up4((m->L * 2 + 3) / 4) + (maxlen + 1) * 5 * 16);
+    const size_t seq1 = ((size_t)(4 * (((m->P1 * 4) + 63) & ~63) + 16) + 5 * m->desc.kmer_len * 80 + per_seq) * sizeof(float);
+    return sig1 <= CONV_FRONT_MAX_LDS && seq1 <= CONV_FRONT_MAX_LDS;
 }
 
 // sig_conv3 (+ sig_conv1/2) and seq_conv2 (+ seq_conv1) of `n` chunks into the two halves of cat [n][P3][128]
@@ -424,7 +433,10 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
             lds = ((size_t)a.o_front + (size_t)cb * a.per_chunk) * sizeof(float);
             if (lds <= (size_t)budget) break;
         }
-        if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples needs %zu B of LDS", m->L, lds);
+        if (cb < 1) {  // a long chunk context: one chunk per iteration, one block per CU
+            cb = 1;
+            if (lds > CONV_FRONT_MAX_LDS) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples needs %zu B of LDS", m->L, lds);
+        }
         a.cb = cb;
         a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
         const int64_t iters = (n + cb - 1) / cb;
@@ -459,7 +471,7 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
         }
         if (cb < 1) {
             cb = 1;
-            if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "seq2_front: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
+            if (lds > CONV_FRONT_MAX_LDS) RMR_FAIL(RMR_ERR_INVALID, "seq2_front: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
         }
         a.cb = cb;
         a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS

@@ -465,35 +465,16 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     TS_FLUSH;
 }
 
-bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
-    if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 1) return false;
-    if ((m->desc.kmer_len != 9 && m->desc.kmer_len != 6) || m->front.kw1 != 5) return false;  // the instantiated k-mer lengths
-    if (m->L % 4 || map_w - 1 > 62 || map_w < 2) return false;
-    if (seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
-    return m->fused.a_merge1 != nullptr;
-}
-
-int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
-                       const int16_t *lens, int64_t n, uint16_t *x) {
-    rmr_engine *e = m->eng;
-    if (n <= 0) return 0;
+// Chunks per block iteration and the LDS image for them: the largest count whose image leaves room for two blocks per CU
+// (RMR_FUSED_LDS_BUDGET) and whose input runs fit one element per thread (S0); a single chunk may take up to a whole CU's
+// LDS (long chunk contexts).  Returns 0 when not even one chunk fits — such shapes run through the unfused bf16 kernels.
+static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs &a, int &total) {
     const int CG = (4 * m->desc.kmer_len + 7) / 8;
-    FusedArgs a;
-    a.signal = signal; a.seqs = seqs; a.maps = maps; a.lens = lens;
-    a.a_sig2 = reinterpret_cast<const uint4 *>(m->fused.a_sig2); a.a_seq1 = reinterpret_cast<const uint4 *>(m->fused.a_seq1);
-    a.a_sig3 = reinterpret_cast<const uint4 *>(m->fused.a_sig3); a.a_seq2 = reinterpret_cast<const uint4 *>(m->fused.a_seq2);
-    a.a_merge1 = reinterpret_cast<const uint4 *>(m->fused.a_merge1);
-    a.w_sig1 = m->fused.w_sig1; a.b_sig1 = m->fused.b_sig1; a.b_sig2 = m->fused.b_sig2; a.b_seq1 = m->fused.b_seq1;
-    a.b_sig3 = m->fused.b_sig3; a.b_seq2 = m->fused.b_seq2; a.b_merge1 = m->fused.b_merge1;
-    a.x = x; a.n = n;
     a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.P3 = m->P3; a.T = m->T;
-    a.seq_w = seq_w; a.map_w = map_w; a.maxlen = map_w - 1;
     auto up16 = [](int b) { return (b + 15) & ~15; };
-    // chunks per block iteration: the largest count whose LDS image leaves room for two blocks per CU and whose
-    // input runs fit one element per thread (S0)
     const int budget = tune_int("RMR_FUSED_LDS_BUDGET", 80 * 1024);
-    int cb = tune_int("RMR_FUSED_CB", 8), total = 0;
-    for (; cb >= 1; --cb) {
+    total = 0;
+    for (int cb = tune_int("RMR_FUSED_CB", 8); cb >= 1; --cb) {
         if (cb * a.L > 1024 || cb * seq_w > 256 || cb * map_w > 256) continue;
         int off = 0;
         a.o_sig = off; off += 256 * 16;  // input regions: one element per thread
@@ -509,9 +490,38 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
         const int oh = CG * a.oh_plane, cat = 4 * a.cat_plane;
         off += oh > cat ? oh : cat;
         total = off;
-        if (total <= budget) break;
+        if (total <= budget || (cb == 1 && total <= 156 * 1024)) return cb;
     }
-    if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "fused front: one chunk of %d samples needs %d B of LDS", a.L, total);
+    return 0;
+}
+
+bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
+    if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 1) return false;
+    if ((m->desc.kmer_len != 9 && m->desc.kmer_len != 6) || m->front.kw1 != 5) return false;  // the instantiated k-mer lengths
+    if (m->L % 4 || map_w - 1 > 62 || map_w < 2) return false;
+    if (seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
+    if (m->fused.a_merge1 == nullptr) return false;
+    FusedArgs probe;
+    int total;
+    return fused_front_plan(m, seq_w, map_w, probe, total) >= 1;  // every limit the launcher enforces
+}
+
+int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
+                       const int16_t *lens, int64_t n, uint16_t *x) {
+    rmr_engine *e = m->eng;
+    if (n <= 0) return 0;
+    FusedArgs a;
+    a.signal = signal; a.seqs = seqs; a.maps = maps; a.lens = lens;
+    a.a_sig2 = reinterpret_cast<const uint4 *>(m->fused.a_sig2); a.a_seq1 = reinterpret_cast<const uint4 *>(m->fused.a_seq1);
+    a.a_sig3 = reinterpret_cast<const uint4 *>(m->fused.a_sig3); a.a_seq2 = reinterpret_cast<const uint4 *>(m->fused.a_seq2);
+    a.a_merge1 = reinterpret_cast<const uint4 *>(m->fused.a_merge1);
+    a.w_sig1 = m->fused.w_sig1; a.b_sig1 = m->fused.b_sig1; a.b_sig2 = m->fused.b_sig2; a.b_seq1 = m->fused.b_seq1;
+    a.b_sig3 = m->fused.b_sig3; a.b_seq2 = m->fused.b_seq2; a.b_merge1 = m->fused.b_merge1;
+    a.x = x; a.n = n;
+    a.seq_w = seq_w; a.map_w = map_w; a.maxlen = map_w - 1;
+    int total = 0;
+    const int cb = fused_front_plan(m, seq_w, map_w, a, total);
+    if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "fused front: one chunk of %d samples (sequence width %d) does not fit (%d B of LDS)", a.L, seq_w, total);
     a.o_pidx = a.o_code = 0;
     a.cb = cb; a.lds_bytes = total;
     a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);

@@ -1446,6 +1446,26 @@ class RemoraDataset:
                                                   "dataset_end": ds.metadata.dataset_start + n}, infinite_iter=False)
         return RemoraDataset(heads, **self.init_kwargs)
 
+    def shard(self, rank, world, override_metadata=None):
+        """Rank `rank`'s share when `world` processes (one per GPU) split the dataset: every core dataset is narrowed to a
+        contiguous range of its rows (dist.shard_range), proportions and batch scheme unchanged, finite iteration.  The
+        shares partition the rows, so per-label tallies summed over the ranks equal the single-process ones whenever a
+        single process visits every row (always for one core dataset; mixes stop, as in the reference, when the first
+        core dataset runs out — per rank here)."""
+        from .dist import shard_range
+
+        base = dict(override_metadata or {})
+        parts = []
+        for ds in self.datasets:
+            a, b = shard_range(ds.size, rank, world)
+            if b <= a:
+                raise RemoraError(f"dataset {ds.data_path} has fewer rows ({ds.size}) than ranks ({world})")
+            st = ds.metadata.dataset_start
+            parts.append(CoreRemoraDataset(ds.data_path, override_metadata={**(ds.override_metadata or {}), **base,
+                                                                            "dataset_start": st + a, "dataset_end": st + b},
+                                           infinite_iter=False))
+        return RemoraDataset(parts, **self.init_kwargs)
+
     def _set_sub_ds_iters(self, enc_kmers, copy=True):
         for ds, bs, off in zip(self.datasets, self.batch_sizes, self.super_batch_offsets):
             ds.batch_size, ds.super_batch_offset = int(bs), int(off)

@@ -79,6 +79,87 @@ def allgather_floats(xs):
     return torch.stack(out).cpu().numpy()
 
 
+def launch_ranks(argv, n):
+    """Start `n` ranks of `python -m remora_amd <argv>` on this node (one process per GPU; torch.distributed.run sets
+    RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on 127.0.0.1) and return the launcher's exit code.  Used by the CLI when
+    `--gpus N` is given outside torchrun."""
+    import socket
+    import subprocess
+    import sys
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "remora_amd"] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def setup_ranks(gpus, backend=None, timeout_s=600.0):
+    """(rank, world, device) of this process for a `--gpus N` command line: (0, 1, None) for one GPU; under a launcher the
+    process group is created (RCCL unless `backend` / REMORA_AMD_DIST_BACKEND says gloo) and the device is LOCAL_RANK
+    (REMORA_AMD_FORCE_DEVICE pins every rank to one GPU: tests on a 1-GPU box).  A world that differs from `gpus` is an
+    error, never a silently smaller run."""
+    rank, world, local = env_rank_world()
+    if int(gpus) <= 1 and world <= 1:
+        return 0, 1, None
+    if world != int(gpus):
+        from . import RemoraError
+
+        raise RemoraError(f"--gpus {gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    backend = backend or os.environ.get("REMORA_AMD_DIST_BACKEND") or None
+    forced = os.environ.get("REMORA_AMD_FORCE_DEVICE")
+    init_process_group(backend, set_device=forced is None, timeout_s=timeout_s)
+    return rank, world, (int(forced) if forced is not None else local)
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable bookkeeping: per-reason read counts, file
+    names); [obj] for a single process.  Not a data-path collective."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def gather_arrays(arr):
+    """Every rank's numpy array (same dtype and trailing shape, any length) concatenated in rank order, on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    arr = np.ascontiguousarray(arr)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return arr
+    on_gpu = dist.get_backend() == "nccl"
+    n = torch.tensor([arr.shape[0]], dtype=torch.int64)
+    n = n.cuda() if on_gpu else n
+    sizes = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    width = max(sizes)
+    pad = np.zeros((width,) + arr.shape[1:], arr.dtype)
+    pad[: arr.shape[0]] = arr
+    t = torch.from_numpy(pad)
+    t = t.cuda() if on_gpu else t
+    parts = [torch.empty_like(t) for _ in sizes]
+    dist.all_gather(parts, t)
+    return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, sizes)], axis=0)
+
+
 def allreduce_counts(counts):
     """Sum per-label counts over all ranks.  `counts`: int64 torch tensor (on the GPU for
     nccl/RCCL, CPU for gloo) or numpy array; returns the same type, reduced in place for tensors."""

@@ -241,7 +241,8 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
 
 
 def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
-                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False, prefetch=2):
+                            reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False, prefetch=2,
+                            rank=0, world=1, label_counts_out=None):
     """`remora infer from_pod5_and_bam` for one model or a list of models (one per canonical base, with a list of
     metadata dicts), basecall-anchored by default or reference-anchored
     (`--reference-anchored`: calls at reference positions, output records rewritten to `<len>M` + reference
@@ -249,9 +250,18 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     MM/ML tags from the model (records whose read cannot be called are written unchanged and
     counted by reason, as the reference does).  Reads are grouped into batches that go through
     ONE chunk extraction and ONE fused inference on the GPU.  Returns {reason: count, ...} with
-    the key None counting successfully called reads."""
+    the key None counting successfully called reads.
+
+    `world` > 1 (one process per GPU, torch.distributed initialised by the caller — `python -m remora_amd infer
+    from_pod5_and_bam --gpus N`): rank r takes a contiguous share of the alignments (io.bam_shard; no reader process
+    hands reads out, no read crosses a GPU boundary), writes `<out>.partRRR` (whole BGZF members; rank 0's carries the
+    header), and after a barrier rank 0 joins the parts in rank order — the records keep the input order.  The per-label
+    call counts go through the ONE collective of the path (dist.allreduce_counts: RCCL all-reduce of int64[num_out]);
+    the per-reason read counts are summed over the ranks; every rank returns the global numbers.  `num_reads` then
+    limits each rank's share.  `label_counts_out` (a dict) receives {can_base: int64[num_out] calls per label}."""
     from collections import Counter
 
+    from . import dist as rdist
     from . import io as rio
 
     md0 = model_metadata[0] if isinstance(model_metadata, (list, tuple)) else model_metadata
@@ -260,6 +270,9 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     pa_scaling = md0.get("pa_scaling")
     stats = Counter()
     header = rio.read_bam_header_bytes(in_bam_path)
+    world, rank = int(world), int(rank)
+    shard = (rank, world) if world > 1 else None
+    part_path = f"{out_bam_path}.part{rank:03d}" if world > 1 else out_bam_path
 
     models = list(model) if isinstance(model, (list, tuple)) else [model]
     mds = list(model_metadata) if isinstance(model_metadata, (list, tuple)) else [model_metadata]
@@ -289,11 +302,14 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             import array
 
             mm_all, ml_all, errs = [], array.array("B"), []
-            for md, results in zip(mds, per_model):
+            for mi, (md, results) in enumerate(zip(mds, per_model)):
                 probs, _, pos = results[k]
                 if pos.size == 0:
                     errs.append(f"No {md['can_base']} mod calls")
                     continue
+                # calls per label (0 = canonical): argmax over [1 - sum(p_mod), p_mod...], first maximum wins
+                full = np.concatenate([1.0 - probs.sum(axis=1, keepdims=True), probs], axis=1)
+                label_counts[mi] += np.bincount(full.argmax(axis=1), minlength=label_counts[mi].size)
                 mm, ml = format_mm_ml_tags(seq=io_read.ref_seq if ref_anchored else io_read.seq, poss=pos, probs=probs,
                                            mod_bases=md["mod_bases"], can_base=md["can_base"])
                 mm_all.append(mm)
@@ -308,12 +324,14 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                 fwd = io_read.ref_seq if io_read.ref_reg.strand == "+" else rio.revcomp(io_read.ref_seq)
             writer.write(rio.record_with_mod_tags(io_read.record, "".join(mm_all), ml_all, ref_anchored_seq=fwd))
 
+    label_counts = [np.zeros(len(md["mod_bases"]) + 1, np.int64) for md in mds]
+
     def batches():
         batch = []
         for i, item in enumerate(rio.iter_reads_from_pod5_and_bam(pod5_path, in_bam_path, reverse_signal=reverse_signal,
                                                                   pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
                                                                   decode_batch=reads_per_batch,
-                                                                  parse_ref_align=ref_anchored)):
+                                                                  parse_ref_align=ref_anchored, shard=shard)):
             if num_reads is not None and i >= num_reads:
                 break
             batch.append(item)
@@ -348,7 +366,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     t = threading.Thread(target=produce, daemon=True)
     t.start()
     try:
-        with rio.BamWriter(out_bam_path, header) as writer:
+        with rio.BamWriter(part_path, header if rank == 0 else b"", eof=world == 1) as writer:
             while True:
                 b = q.get()
                 if b is None:
@@ -358,6 +376,20 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                 flush(b, writer)
     finally:
         stop.set()
+    if world > 1:
+        # every part is complete on disk; the ONE data collective: per-label call counts (int64[num_out] per model)
+        flat = rdist.allreduce_counts(np.concatenate(label_counts))
+        label_counts = np.split(flat, np.cumsum([c.size for c in label_counts])[:-1])
+        merged = Counter()
+        for st in rdist.gather_objects(dict(stats)):  # also the barrier behind which rank 0 may read the parts
+            merged.update(st)
+        stats = merged
+        if rank == 0:
+            rio.concat_bam_parts(out_bam_path, [f"{out_bam_path}.part{r:03d}" for r in range(world)])
+        rdist.barrier()
+    if label_counts_out is not None:
+        for md, c in zip(mds, label_counts):
+            label_counts_out[md["can_base"]] = np.asarray(c, np.int64)
     return dict(stats)
 
 

@@ -273,9 +273,10 @@ class _NativeBamRecord(BamRecord):
         return self._ref_seq
 
 
-def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None):
+def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None, start_voffset=None, max_records=None):
     """Records of a BAM file from the native reader; with `voffsets` only the records at those virtual offsets
-    (one seek + one record each), otherwise the whole file in order."""
+    (one seek + one record each); with `start_voffset` / `max_records` the contiguous run of records that starts
+    there (a rank's share of the file, `bam_shard`); otherwise the whole file in order."""
     lib = L.lib()
     h = ctypes.c_void_p()
     L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
@@ -285,21 +286,61 @@ def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None):
                 L.check(lib.rmr_bam_seek(h, int(vo)))
                 yield from _native_batches(lib, h, want_ref, 1, once=True)
             return
-        yield from _native_batches(lib, h, want_ref, batch)
+        if start_voffset is not None:
+            L.check(lib.rmr_bam_seek(h, int(start_voffset)))
+        yield from _native_batches(lib, h, want_ref, batch, limit=max_records)
     finally:
         lib.rmr_bam_close(h)
 
 
-def _native_batches(lib, h, want_ref, batch, once=False):
+def bam_shard(bam_path, rank, world, every=64):
+    """(start_voffset, n_records) of rank `rank`'s contiguous share of the alignments of `bam_path` when `world` workers
+    split the file between them (dist.shard_range over marks set every `every` records; shares differ by less than
+    `every` records unless the file has fewer than `world` marks).  One light pass over the file (rmr_bam_scan: BGZF
+    inflate + the block_size fields) that every worker runs by itself - no coordinator, no index file.  n_records is 0
+    (and the offset None) for a rank that gets nothing."""
+    from .dist import shard_range
+
+    if world <= 1:
+        return None, None
+    lib = L.lib()
+    cap = 1 << 16
+    while True:  # rmr_bam_open leaves the handle at the first record
+        h = ctypes.c_void_p()
+        L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+        try:
+            marks = np.empty(cap, np.int64)
+            n = ctypes.c_int64()
+            L.check(lib.rmr_bam_scan(h, int(every), marks.ctypes.data, cap, ctypes.byref(n)))
+        finally:
+            lib.rmr_bam_close(h)
+        n_marks = (n.value + every - 1) // every
+        if n_marks <= cap:
+            break
+        cap = int(n_marks)  # more marks than the first guess: scan again with room for all of them
+    m0, m1 = shard_range(n_marks, rank, world)
+    if m1 <= m0:
+        return None, 0
+    return int(marks[m0]), int(min(m1 * every, n.value) - m0 * every)
+
+
+def _native_batches(lib, h, want_ref, batch, once=False, limit=None):
     refs = {}
     bb = L.BamBatch()
     arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,))
                                   if count else np.zeros(0, dt))  # noqa: E731
+    left = None if limit is None else int(limit)
     while True:
+        if left is not None:
+            if left <= 0:
+                return
+            batch = min(batch, left)
         L.check(lib.rmr_bam_read_batch(h, batch, int(bool(want_ref)), ctypes.byref(bb)))
         n = int(bb.n_records)
         if n == 0:
             return
+        if left is not None:
+            left -= n
         i32 = lambda f: arr(getattr(bb, f), ctypes.c_int32, n).tolist()  # noqa: E731
         off = lambda f: arr(getattr(bb, f), ctypes.c_int64, n + 1).tolist()  # noqa: E731
         flag, ref_id, pos, mapq, n_cig = i32("flag"), i32("ref_id"), i32("pos"), i32("mapq"), i32("n_cigar")
@@ -492,10 +533,18 @@ def extract_alignments(read_err, bam_idx, rev_sig=False, pa_scaling=None):
     return out
 
 
-def iter_bam_records(bam_path, want_ref=False, batch=512, native=True):
+def iter_bam_records(bam_path, want_ref=False, batch=512, native=True, shard=None):
     """Yield a BamRecord for every alignment of a BAM file, streaming.  By default the records come from the native
     reader (rmr_bam_read_batch: BGZF inflate, record split, hot tags and - with want_ref - the MD reconstruction in
-    C++, `batch` records per call); native=False is the pure-Python reader the native one is tested against."""
+    C++, `batch` records per call); native=False is the pure-Python reader the native one is tested against.
+    `shard=(rank, world)`: only that rank's contiguous share of the records (`bam_shard`)."""
+    if shard is not None and int(shard[1]) > 1:
+        if not native:
+            raise RemoraError("sharded reading needs the native BAM reader")
+        start, count = bam_shard(bam_path, int(shard[0]), int(shard[1]))
+        if count:
+            yield from _iter_bam_records_native(bam_path, want_ref, batch, start_voffset=start, max_records=count)
+        return
     if native:
         yield from _iter_bam_records_native(bam_path, want_ref, batch)
         return
@@ -1036,7 +1085,7 @@ class Read:
 
 
 def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_scaling=None,
-                                 skip_non_primary=True, decode_batch=256, parse_ref_align=True):
+                                 skip_non_primary=True, decode_batch=256, parse_ref_align=True, shard=None):
     """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
     read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519).  The signals of
     `decode_batch` consecutive records are decompressed together (zstd on the host, VBZ on the GPU) and their
@@ -1075,7 +1124,7 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
             yield read, None
 
     pending = []
-    for rec in iter_bam_records(bam_path, want_ref=parse_ref_align):
+    for rec in iter_bam_records(bam_path, want_ref=parse_ref_align, shard=shard):  # shard = (rank, world): this rank's records
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
         rid = (rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)).get("pi", rec.query_name)
@@ -1170,7 +1219,10 @@ class BamWriter:
     by a small thread pool (zlib releases the GIL) and written in order, so compression - ~1 ms per 5 kb read with
     its move table - runs beside the caller instead of in it; the file is the same as with inline compression."""
 
-    def __init__(self, path, header_bytes, threads=None, max_pending=None):
+    def __init__(self, path, header_bytes, threads=None, max_pending=None, eof=True):
+        """`header_bytes` = everything before the first record (b"" for a part file that holds records only);
+        `eof=False` leaves the end-of-file marker out — part files of a multi-GPU run are whole BGZF members and are
+        joined byte for byte by `concat_bam_parts`."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
@@ -1182,6 +1234,7 @@ class BamWriter:
             max_pending = 8 * int(threads)
 
         self._fh = open(path, "wb")
+        self._eof = bool(eof)
         self._buf = bytearray(header_bytes)
         self._pool = ThreadPoolExecutor(max_workers=max(int(threads), 1))
         self._pending, self._max_pending = deque(), int(max_pending)
@@ -1208,7 +1261,8 @@ class BamWriter:
             self._buf = bytearray()
         self._drain(0)
         self._pool.shutdown()
-        self._fh.write(_BGZF_EOF)
+        if self._eof:
+            self._fh.write(_BGZF_EOF)
         self._fh.close()
         self._fh = None
 
@@ -1217,3 +1271,20 @@ class BamWriter:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def concat_bam_parts(out_path, part_paths, remove=True):
+    """Join the part files of a multi-GPU run (rank 0: header + its records, the others: records only, none with an
+    end-of-file marker) into one BAM: BGZF members are self-contained, so the parts are appended byte for byte and the
+    28-byte EOF marker closes the file (SAM spec 4.1).  Records keep the order of the input file because the ranks took
+    contiguous shares in rank order."""
+    import shutil
+
+    with open(out_path, "wb") as out:
+        for p in part_paths:
+            with open(p, "rb") as fh:
+                shutil.copyfileobj(fh, out, 1 << 22)
+        out.write(_BGZF_EOF)
+    if remove:
+        for p in part_paths:
+            os.remove(p)

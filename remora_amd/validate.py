@@ -97,10 +97,17 @@ class ValidationLogger:
             self.full_fh.write(f"{lab}\t{pred}\t{','.join(map(str, row))}\n")
 
     def run_validation(self, model, model_mod_bases, criterion, dataset, filt_frac=constants.DEFAULT_FILT_FRAC,
-                       full_results_fh=None, disable_pbar=False):
+                       full_results_fh=None, disable_pbar=False, world=1):
         """All batches of `dataset` (a finite RemoraDataset) through the model -> VAL_METRICS.  `criterion` is
         a torch loss on (float32 logits, int64 labels), or None for cross entropy; the loss is the mean of the
-        per-batch means, as in the reference."""
+        per-batch means, as in the reference.
+
+        `world` > 1 (one process per GPU, torch.distributed up, `dataset` = this rank's `RemoraDataset.shard`): the
+        confusion matrix is tallied per rank over the full label set and summed by the ONE collective of the path
+        (dist.allreduce_counts -> RCCL all-reduce of int64[k*k]); accuracy and num_calls follow from it.  The
+        confidence-filtered columns need the global quantile of the winning probabilities, so the per-chunk (label,
+        call, winning probability) triples are gathered as well (12 B per chunk, bookkeeping), and the loss is the
+        mean over all ranks' batches.  Every rank returns the global metrics."""
         torch = _torch()
         if criterion is None:
             criterion = torch.nn.CrossEntropyLoss()
@@ -132,13 +139,44 @@ class ValidationLogger:
                 self.write_full_results(out, labels)
         dataset._ds_iters = None
         out, labels = np.concatenate(all_out, axis=0), np.concatenate(all_lab)
+        if world > 1:
+            return self._global_metrics(softmax_axis1(out), labels, losses, filt_frac)
         acc, conf, ff, facc, fconf, thr = compute_metrics(softmax_axis1(out), labels, filt_frac)
         return VAL_METRICS(loss=np.mean(losses), acc=acc, num_calls=labels.size, conf_mat=conf, filt_frac=ff,
                            filt_acc=facc, filt_conf_mat=fconf, filt_thresh=thr)
 
+    @staticmethod
+    def _global_metrics(probs, labels, losses, filt_frac):
+        """This rank's calls -> the metrics of all ranks' calls (see run_validation)."""
+        from . import dist as rdist
+
+        k = probs.shape[1]
+        preds = np.argmax(probs, axis=1)
+        local = np.bincount(labels.astype(np.int64) * k + preds, minlength=k * k).astype(np.int64)
+        full = np.asarray(rdist.allreduce_counts(local)).reshape(k, k)  # the collective: confusion counts over all GPUs
+        present = (full.sum(0) + full.sum(1)) > 0
+        conf = full[present][:, present]
+        total = int(full.sum())
+        acc = np.trace(full) / total
+        win = np.take_along_axis(probs, preds[:, None], -1)[:, 0]
+        trip = rdist.gather_arrays(np.stack([labels.astype(np.float64), preds.astype(np.float64), win.astype(np.float64)], axis=1))
+        g_lab, g_pred, g_win = trip[:, 0].astype(np.int64), trip[:, 1].astype(np.int64), trip[:, 2]
+        loss = float(np.mean(rdist.gather_arrays(np.asarray(losses, np.float64).reshape(-1))))
+        thr = np.quantile(g_win, filt_frac)
+        if thr == g_win.max():
+            thr *= 0.999999
+        sure = g_win > thr
+        n_sure = int(sure.sum())
+        if n_sure == 0:
+            return VAL_METRICS(loss=loss, acc=acc, num_calls=total, conf_mat=conf, filt_frac=1.0, filt_acc=np.nan,
+                               filt_conf_mat=np.array([]), filt_thresh=np.nan)
+        return VAL_METRICS(loss=loss, acc=acc, num_calls=total, conf_mat=conf, filt_frac=1 - n_sure / total,
+                           filt_acc=(g_pred[sure] == g_lab[sure]).sum() / n_sure,
+                           filt_conf_mat=confusion_matrix(g_lab[sure], g_pred[sure]), filt_thresh=thr)
+
     def validate_model(self, model, model_mod_bases, criterion, dataset, filt_frac=constants.DEFAULT_FILT_FRAC,
-                       val_type="val", nepoch=0, niter=0, disable_pbar=False):
-        ms = self.run_validation(model, model_mod_bases, criterion, dataset, filt_frac, disable_pbar=disable_pbar)
+                       val_type="val", nepoch=0, niter=0, disable_pbar=False, world=1):
+        ms = self.run_validation(model, model_mod_bases, criterion, dataset, filt_frac, disable_pbar=disable_pbar, world=world)
         self.fp.write(f"{val_type}\t{nepoch}\t{niter}\t{ms.acc:.6f}\t{mat_to_str(ms.conf_mat)}\t{ms.loss:.6f}\t"
                       f"{ms.num_calls}\t{ms.filt_frac:.4f}\t{ms.filt_acc:.6f}\t{mat_to_str(ms.filt_conf_mat)}\t"
                       f"{ms.filt_thresh}\n")

@@ -170,3 +170,27 @@ def test_call_reads_mods_subbatch_pipeline_equals_one_batch(torch_cuda):
     for a, b in zip(whole, piped):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert sum(r[2].size for r in whole) > 5000
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("cc,msl", [((300, 300), 60), ((500, 500), 60), ((500, 500), 150), ((150, 150), 62)])
+def test_long_chunk_contexts_run_and_match(torch_cuda, O, dtype, cc, msl):
+    """Chunk contexts far beyond the benchmark shapes: the folded fp32 kernels and the fused bf16 kernel either fit one
+    chunk per block iteration in a CU's LDS or hand the shape to the unfused kernels — `*_supported()` must know every
+    limit its launcher enforces (round-2 advice: a 'supported' shape that then failed in the launcher)."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    L = sum(cc)
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=11)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0, dtype=dtype)
+    d = synth.synth_chunks(203, L, msl, (4, 4), seed=31)
+    out = model.infer_chunks(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
+    enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+    with torch.no_grad():
+        ref = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() <= (1e-4 if dtype == "fp32" else BF16_TOL), (dtype, cc, np.abs(out - ref).max())

@@ -1590,3 +1590,165 @@ def test_bench_result_line_is_small_and_complete():
     assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["value"] == full["value"]
     assert "other_configs" not in line and "kernels" not in line and "forms" not in line["cpu_baseline"]
     assert line["parity"]["label_counts_exact"] is True and line["parity"]["fp32_max_abs"] < 1e-4
+
+
+def test_c_inference_program_builds_and_reports_errors_without_a_gpu(tmp_path):
+    """tests/c/infer_from_c.c (the C caller that runs rmr_model_create + rmr_infer_chunks, -m gpu: tests/test_gpu_c_abi.py)
+    compiles as pedantic C99 against the header, reads the exported fixture, and on a box without a GPU stops at
+    rmr_engine_create with the library's message and exit code 2 — never a crash."""
+    import shutil
+    import subprocess
+
+    from remora_amd import _lib
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import export_c_fixture
+
+    fx = str(tmp_path / "fixture.bin")
+    n, nw = export_c_fixture.export(os.path.join(ROOT, "tests", "golden", "model_convlstm_s64_l100_o2.npz"), fx)
+    assert (n, nw) == (48, 134538)
+    exe = str(tmp_path / "infer_from_c")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cc = subprocess.run([shutil.which("gcc"), "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "tests", "c", "infer_from_c.c"), "-o", exe, "-L", libdir, "-lremora_hip", "-lm",
+                         f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe, fx], capture_output=True, text=True, timeout=120)
+    import torch
+
+    if torch.cuda.is_available():
+        assert run.returncode == 0 and "OK" in run.stdout, (run.stdout, run.stderr)
+    else:
+        assert run.returncode == 2 and "rmr_engine_create" in run.stderr and "rc -2" in run.stderr, (run.stdout, run.stderr)
+
+
+# ---- multi-GPU product pipeline: the sharding plumbing on CPU (the kernels' side: tests/test_gpu_shard.py) --------
+def test_bam_shard_partitions_the_records_in_order():
+    """io.bam_shard (rmr_bam_scan + rmr_bam_seek): for any number of workers and any mark spacing the workers' shares are
+    contiguous, in rank order, and together exactly the records of the file; shares differ by less than one mark spacing
+    (+1 where the marks do not divide evenly)."""
+    from remora_amd import io as rio
+
+    for name in ("can_mappings.bam", "mod_mappings.bam"):
+        path = os.path.join(DATA, name)
+        whole = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(path)]
+        assert len(whole) >= 14
+        for world in (1, 2, 3, 5, 8, 16):
+            for every in (1, 2, 64):
+                got, sizes = [], []
+                for rank in range(world):
+                    part = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(path, shard=(rank, world))] if every == 64 else None
+                    st, n = rio.bam_shard(path, rank, world, every=every)
+                    mine = ([(r.query_name, r.flag, r.voffset) for r in rio._iter_bam_records_native(path, False, 4, start_voffset=st,
+                                                                                                      max_records=n)] if n else [])
+                    if world == 1:
+                        assert (st, n) == (None, None)
+                        mine = whole
+                    assert part is None or part == mine
+                    got += mine
+                    sizes.append(len(mine))
+                assert got == whole, (name, world, every)
+                if every == 1 and world <= len(whole):
+                    assert max(sizes) - min(sizes) <= 1
+
+
+def test_bam_parts_join_into_one_valid_bam(tmp_path):
+    """The part files of a multi-GPU infer run (rank 0: header + records, others: records only, no EOF markers) joined by
+    concat_bam_parts read back as ONE BAM with every record in input order - by Python's gzip (independent reader) and by
+    the native reader; the file ends with the 28-byte BGZF EOF marker."""
+    import gzip
+
+    from remora_amd import io as rio
+
+    src = os.path.join(DATA, "can_mappings.bam")
+    header = rio.read_bam_header_bytes(src)
+    recs = list(rio.iter_bam_records(src))
+    raw = [struct_pack_record(r) for r in recs]
+    world = 3
+    out = str(tmp_path / "joined.bam")
+    for rank in range(world):
+        st, n = rio.bam_shard(src, rank, world, every=1)
+        with rio.BamWriter(f"{out}.part{rank:03d}", header if rank == 0 else b"", eof=False, threads=2) as w:
+            for r in rio._iter_bam_records_native(src, False, 8, start_voffset=st, max_records=n):
+                w.write(rio.record_with_mod_tags(r, None, None))
+    rio.concat_bam_parts(out, [f"{out}.part{r:03d}" for r in range(world)])
+    assert not any(p.startswith("joined.bam.part") for p in os.listdir(tmp_path))
+    blob = open(out, "rb").read()
+    assert blob.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    plain = gzip.decompress(blob)
+    assert plain.startswith(header) and plain[len(header):] == b"".join(raw)
+    back = list(rio.iter_bam_records(out))
+    assert [r.query_name for r in back] == [r.query_name for r in recs]
+
+
+def struct_pack_record(rec):
+    import struct
+
+    return struct.pack("<i", len(rec.raw)) + bytes(rec.raw)
+
+
+_SHARD_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+from remora_amd import dist as rdist
+from remora_amd.validate import ValidationLogger, compute_metrics
+rank, world, local = rdist.init_process_group("gloo")
+rng = np.random.default_rng(5)
+n, k = 1001, 3
+logits = rng.standard_normal((n, k)) * 2
+probs = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+labels = rng.integers(0, k, n)
+labels[::3] = probs[::3].argmax(1)                   # a model that is right more often than chance
+lo, hi = rdist.shard_range(n, rank, world)
+losses = [float(rank + 1), 0.5]
+ms = ValidationLogger._global_metrics(probs[lo:hi], labels[lo:hi], losses, 0.1)
+acc, conf, ff, facc, fconf, thr = compute_metrics(probs, labels, 0.1)
+ok = (ms.acc == acc and np.array_equal(ms.conf_mat, conf) and ms.num_calls == n and abs(ms.filt_frac - ff) < 1e-12
+      and ms.filt_acc == facc and np.array_equal(ms.filt_conf_mat, fconf) and ms.filt_thresh == thr
+      and abs(ms.loss - np.mean([1.0, 0.5, 2.0, 0.5])) < 1e-12)
+objs = rdist.gather_objects({"rank": rank, None: rank + 1})
+arr = rdist.gather_arrays(np.arange(rank + 2, dtype=np.int64)[:, None] * np.ones((1, 2), np.int64))
+ok = ok and [o["rank"] for o in objs] == [0, 1] and arr.shape == (5, 2) and arr[:, 0].tolist() == [0, 1, 0, 1, 2]
+rdist.barrier()
+print(json.dumps({"rank": rank, "ok": bool(ok), "acc": float(ms.acc), "conf": ms.conf_mat.tolist()}))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_sharded_validation_metrics_gloo_world2(tmp_path):
+    """Two ranks each hold half of the calls: ValidationLogger._global_metrics (confusion counts through the all-reduce,
+    the filtered columns from the gathered triples) gives every rank exactly compute_metrics of all calls."""
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29741", str(script), ROOT]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(l["ok"] for l in lines), lines
+    assert lines[0]["conf"] == lines[1]["conf"] and lines[0]["acc"] == lines[1]["acc"]
+
+
+def test_remora_dataset_shard_partitions_rows(tmp_path):
+    """RemoraDataset.shard: the ranks' core datasets are contiguous, disjoint row ranges that cover the dataset; label
+    counts summed over the shards equal the whole dataset's."""
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset
+
+    dirs = _materialise(tmp_path, ["can_ctrl", "mod_m"])
+    for names, props in ((["mod_m"], [1.0]), (["can_ctrl", "mod_m"], [0.5, 0.5])):
+        ds = RemoraDataset([CoreRemoraDataset(dirs[n], infinite_iter=False) for n in names], props, batch_size=64)
+        whole = ds.get_label_counts()
+        for world in (2, 3):
+            parts = [ds.shard(r, world) for r in range(world)]
+            assert sum(p.size for p in parts) == ds.size
+            assert np.array_equal(sum(p.get_label_counts() for p in parts), whole)
+            for i in range(len(names)):
+                spans = [(p.datasets[i].metadata.dataset_start, p.datasets[i].metadata.dataset_end) for p in parts]
+                assert spans[0][0] == ds.datasets[i].metadata.dataset_start and spans[-1][1] == ds.datasets[i].metadata.dataset_end
+                assert all(spans[j][1] == spans[j + 1][0] for j in range(world - 1))
+            if len(names) == 1:  # one core dataset: the shards' batches visit every row exactly once
+                seen = sum(int(b[2].shape[0]) for p in parts for b in p.iter_numpy_batches(("signal", "sequence_lengths", "labels")))
+                assert seen == ds.size
