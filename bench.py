@@ -50,6 +50,8 @@ OTHER_CONFIGS = [
     ("convlstm_c100_bf16_10m", "convlstm_c100_bf16_10m", None, None),
     ("convlstm_c200_bf16", "convlstm_c200_bf16", None, None),
     ("convlstm_c200_fp32", "convlstm_c200_bf16", "fp32", None),
+    ("convlstm_c100_f16", "convlstm_c100", "f16", None),
+    ("convlstm_c200_f16", "convlstm_c200_bf16", "f16", None),
     ("convlstm_c100_bf16x6", "convlstm_c100", "bf16x6", None),
     ("convlstm_c100_bf16x3", "convlstm_c100", "bf16x3", None),
 ]
@@ -112,7 +114,7 @@ def kernel_alg_bytes_per_chunk(arch, L, dtype, size=64, num_out=2, seq_w=28, map
     b = {"conv_sig3": P2 * 16 * 4 + P3 * size * 4, "conv_merge1": P3 * 2 * size * 4 + T * size * 4}
     if arch == "conv_lstm":
         b["conv_seq2"] = P1 * 16 * 4 + P3 * size * 4
-        b["lstm_head"] = T * size * (2 if dtype == "bf16" else 4) + 4 * num_out
+        b["lstm_head"] = T * size * (2 if dtype in ("bf16", "f16") else 4) + 4 * num_out
         b["fused_front"] = L * 4 + seq_w + 2 * map_w + 2 + T * size * 2
         b["sig3_front"] = L * 4 + P3 * size * 4
         b["seq2_front"] = seq_w + 2 * map_w + 2 + P3 * size * 4
@@ -404,7 +406,7 @@ class Job:
         achieved = flops[dom] * cpl / (kern[dom]["avg_ms"] * 1e-3) / 1e12
         # fp32 MFMA: 157.3 TF.  bf16 MFMA with split operands executes NPROD bf16 products per algorithmic MAC, so the
         # matrix-pipe ceiling for algorithmic flops is 2.5 PF / NPROD
-        nprod = {"fp32": None, "bf16": 1, "bf16x3": 3, "bf16x6": 6}[self.dtype]
+        nprod = {"fp32": None, "bf16": 1, "f16": 1, "bf16x3": 3, "bf16x6": 6}[self.dtype]
         peak = PEAK_FP32_MFMA_TFLOPS if nprod is None else PEAK_BF16_MFMA_TFLOPS / nprod
         traffic, tsrc = None, None
         ent = ((traffic_table or {}).get(f"{self.workload}:{self.dtype}") or (traffic_table or {}).get(self.dtype) or {}).get(dom)
@@ -417,7 +419,7 @@ class Job:
         roofline = {
             "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "peak_note": ("v_mfma_f32_16x16x4_f32 dense peak" if nprod is None else
-                          f"bf16 dense peak 2500 / {nprod} part product(s) per algorithmic MAC"),
+                          f"16-bit dense peak 2500 / {nprod} part product(s) per algorithmic MAC"),
             "frac": achieved / peak, "traffic": float(traffic) if traffic else None, "traffic_measured": False, "traffic_source": tsrc,
             "algorithmic_bytes": float(alg_b[dom] * cpl) if dom in alg_b else None,
             "flop_per_chunk": flops[dom], "chunks_per_launch": cpl, "avg_launch_ms": kern[dom]["avg_ms"],
@@ -637,7 +639,7 @@ def main():
                     help="'all' = the default headline plus every other BASELINE config (what a plain 1-GPU run does anyway)")
     ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU per step (weak) / in total (strong); 0 = the workload's")
     ap.add_argument("--subbatch", type=int, default=0)
-    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16x6", "bf16x3", "bf16", "f16"],
                     help="GEMM arithmetic (default: the workload's): fp32 MFMA or bf16 MFMA with 1 / 2 / 3-part operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")

@@ -84,7 +84,9 @@ typedef struct {
     int32_t num_out;    /* len(mod_bases) + 1, <= 16 */
     int32_t chunk_len;  /* sum(chunk_context) */
     int32_t dtype;      /* 0 = fp32 MFMA (exact fp32); bf16 MFMA with fp32 accumulate and split operands:
-                           1 = bf16, 2 = bf16x3 (2-part split, ~2^-16), 3 = bf16x6 (3-part split, fp32 class) */
+                           1 = bf16, 2 = bf16x3 (2-part split, ~2^-16), 3 = bf16x6 (3-part split, fp32 class);
+                           4 = f16: IEEE-half operands, fp32 accumulate, on the fused kernels (conv_lstm, size 64,
+                           k-mer length 9 or 6; rmr_infer_chunks only) - the 16-bit pipeline with 10 mantissa bits */
 } rmr_model_desc;
 
 /* `weights`: host fp32 blob, the torch state_dict tensors flattened in forward order —

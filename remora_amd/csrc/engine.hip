@@ -250,6 +250,19 @@ std::vector<ConvSpec> conv_specs(const rmr_model_desc &d) {
 static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 static inline uint32_t rne_bf16(uint32_t b) { return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u; }
+// one fp32 value as the 16-bit operand of the fused kernels, in the HIGH half of the returned word (as rne_bf16 returns
+// it): bf16, or IEEE half (round to nearest even; the compiler's conversion)
+static inline uint32_t to_op16(float v, bool f16) {
+    if (!f16) {
+        uint32_t b;
+        memcpy(&b, &v, 4);
+        return rne_bf16(b);
+    }
+    const _Float16 h = (_Float16)v;
+    uint16_t hb;
+    memcpy(&hb, &h, 2);
+    return (uint32_t)hb << 16;
+}
 static void split_parts_host(float x, int np, uint32_t *p) {
     if (np == 1) { p[0] = rne_bf16(f2u(x)); return; }
     float r = x;
@@ -288,7 +301,8 @@ bool desc_ok(const rmr_model_desc &d) {
     if (d.size != 16 && d.size != 32 && d.size != 64) return false;
     if (d.kmer_len < 1 || d.kmer_len > 64) return false;
     if (d.num_out < 1 || d.num_out > 16) return false;
-    if (d.dtype < 0 || d.dtype > 3) return false;
+    if (d.dtype < 0 || d.dtype > 4) return false;
+    if (d.dtype == 4 && (d.size != 64 || (d.kmer_len != 9 && d.kmer_len != 6))) return false;  // half: the fused kernels only
     if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || d.size % 32)) return false;
     return true;
 }
@@ -388,7 +402,7 @@ int pack_conv_split(rmr_model *m, const Folded &f, int np, ConvLayer *out) {
 // conv weights -> bf16 A fragments of the fused front kernel: [oc/16][ksteps][64 lanes][4 dwords]; lane (q, m) of
 // k-step s holds k = 32 s + 8 q + j, k = tap * C + channel (C = row width of the operand in LDS, k_fused.hip);
 // taps >= kw and channels >= ic are zero
-int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, double scale, float **dev) {
+int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, double scale, float **dev, bool f16 = false) {
     const ConvSpec &s = f.s;
     const int W = s.oc / 16;
     std::vector<uint32_t> o((size_t)W * ksteps * 64 * 4);
@@ -400,7 +414,7 @@ int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, double scale, 
                 for (int j = 0; j < 8; ++j) {
                     const int k = 32 * st + 8 * q + j, tap = k / C, ch = k % C;
                     const float v = (tap < s.kw && ch < s.ic) ? (float)(scale * (double)f.w[((size_t)oc * s.ic + ch) * s.kw + tap]) : 0.0f;
-                    b[j] = rne_bf16(f2u(v));
+                    b[j] = to_op16(v, f16);
                 }
                 for (int i = 0; i < 4; ++i) o[(((size_t)w * ksteps + st) * 64 + lane) * 4 + i] = (b[2 * i] >> 16) | b[2 * i + 1];
             }
@@ -412,7 +426,7 @@ int pack_flat_a(rmr_model *m, const Folded &f, int C, int ksteps, double scale, 
 // LSTM weights for k_lstm_x16.hip (H = 64): 16-row MFMA tiles with UNIT-MAJOR rows — row r of tile (wave wv, t) is
 // (unit 8 wv + 2 (r >> 2) + t, gate r & 3) — as bf16 A fragments [8][2][2 k-steps][64 lanes][4 dwords]; gate rows
 // pre-scaled (lstm1_gate_scale); `skip_f` zeroes the f rows (lstm2: c0 = 0)
-std::vector<float> pack_lstm_x16(const float *w, bool skip_f) {
+std::vector<float> pack_lstm_x16(const float *w, bool skip_f, bool f16 = false) {
     const int H = 64;
     std::vector<uint32_t> o((size_t)8 * 2 * 2 * 64 * 4);
     for (int wv = 0; wv < 8; ++wv)
@@ -424,7 +438,7 @@ std::vector<float> pack_lstm_x16(const float *w, bool skip_f) {
                     for (int j = 0; j < 8; ++j) {
                         const int k = 32 * ks + 8 * ql + j;
                         const double v = (skip_f && gate == 1) ? 0.0 : (double)w[(size_t)(gate * H + unit) * H + k] * lstm1_gate_scale(gate);
-                        b[j] = rne_bf16(f2u((float)v));
+                        b[j] = to_op16((float)v, f16);
                     }
                     for (int i = 0; i < 4; ++i)
                         o[((((size_t)wv * 2 + t) * 2 + ks) * 64 + lane) * 4 + i] = (b[2 * i] >> 16) | b[2 * i + 1];
@@ -509,7 +523,8 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
     std::unique_ptr<rmr_model, void (*)(rmr_model *)> m(new rmr_model(), rmr_model_destroy);
     m->eng = e;
     m->desc = *desc;
-    m->nparts = desc->dtype;  // 0 fp32 MFMA; 1 bf16; 2 bf16x3 (2-part split); 3 bf16x6 (3-part split)
+    m->nparts = desc->dtype == 4 ? 1 : desc->dtype;  // 0 fp32 MFMA; 1 bf16; 2 bf16x3 (2-part split); 3 bf16x6 (3-part split)
+    m->f16 = desc->dtype == 4;                       // 4: one-part operands as IEEE half (fused kernels)
     const int sz = desc->size, K = desc->kmer_len, L = desc->chunk_len;
 
     const float *p = weights;
@@ -578,11 +593,11 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
         if (m->nparts == 1 && sz == 64 && (K == 9 || K == 6) && kw1 == 5) {  // operands of the fused front kernel
             const int cg = (4 * K + 7) / 8;
             const double log2e = 1.4426950408889634;
-            RMR_TRY(pack_flat_a(m.get(), convs[1], 4, 1, 1.0, &m->fused.a_sig2));
-            RMR_TRY(pack_flat_a(m.get(), convs[3], 8 * cg, (5 * cg * 8 + 31) / 32, log2e, &m->fused.a_seq1));
-            RMR_TRY(pack_flat_a(m.get(), convs[2], 16, 5, 1.0, &m->fused.a_sig3));
-            RMR_TRY(pack_flat_a(m.get(), convs[4], 16, 7, 1.0, &m->fused.a_seq2));
-            RMR_TRY(pack_flat_a(m.get(), convs[5], 2 * sz, 20, 1.0, &m->fused.a_merge1));
+            RMR_TRY(pack_flat_a(m.get(), convs[1], 4, 1, 1.0, &m->fused.a_sig2, m->f16));
+            RMR_TRY(pack_flat_a(m.get(), convs[3], 8 * cg, (5 * cg * 8 + 31) / 32, log2e, &m->fused.a_seq1, m->f16));
+            RMR_TRY(pack_flat_a(m.get(), convs[2], 16, 5, 1.0, &m->fused.a_sig3, m->f16));
+            RMR_TRY(pack_flat_a(m.get(), convs[4], 16, 7, 1.0, &m->fused.a_seq2, m->f16));
+            RMR_TRY(pack_flat_a(m.get(), convs[5], 2 * sz, 20, 1.0, &m->fused.a_merge1, m->f16));
             auto scaled = [&](const std::vector<float> &v) {
                 std::vector<float> o(v.size());
                 for (size_t i = 0; i < v.size(); ++i) o[i] = (float)((double)v[i] * log2e);
@@ -626,9 +641,9 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
             RMR_TRY(upload(m.get(), pack_split_a(sh, H, H / 16, rb, 4, m->nparts), &m->lstm.s_hh1));
         }
         if (m->nparts == 1 && H == 64) {
-            RMR_TRY(upload(m.get(), pack_lstm_x16(wih1, false), &m->lstm.x_ih));
-            RMR_TRY(upload(m.get(), pack_lstm_x16(whh1, false), &m->lstm.x_hh));
-            RMR_TRY(upload(m.get(), pack_lstm_x16(wih2, true), &m->lstm.x_ih2));
+            RMR_TRY(upload(m.get(), pack_lstm_x16(wih1, false, m->f16), &m->lstm.x_ih));
+            RMR_TRY(upload(m.get(), pack_lstm_x16(whh1, false, m->f16), &m->lstm.x_hh));
+            RMR_TRY(upload(m.get(), pack_lstm_x16(wih2, true, m->f16), &m->lstm.x_ih2));
             RMR_TRY(upload(m.get(), pack_bias_x16(bih1, bhh1, false), &m->lstm.x_b1));
             RMR_TRY(upload(m.get(), pack_bias_x16(bih2, bhh2, true), &m->lstm.x_b2));
         }
@@ -681,7 +696,10 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                  float *logits) {
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
-    if (!enc && fused_front_supported(m, seq_w, map_w) && tune_int("RMR_FUSED", 1)) {
+    if (m->f16 && (enc || !fused_front_supported(m, seq_w, map_w)))
+        RMR_FAIL(RMR_ERR_INVALID, "dtype f16 runs on the fused kernels only: chunk arrays (not a dense one-hot tensor), sequence rows of at "
+                                  "most 62 bases, chunk length a multiple of 4 that fits a CU's LDS");
+    if (!enc && fused_front_supported(m, seq_w, map_w) && (m->f16 || tune_int("RMR_FUSED", 1))) {
         // plain-bf16 ConvLSTM: two launches per sub-batch, x (bf16, 3 KB/chunk @C100) is the only intermediate in
         // HBM; sub-batches are sized so that x stays in the 256 MiB Infinity Cache between producer and consumer
         int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_FUSED_SUBBATCH", 65536);

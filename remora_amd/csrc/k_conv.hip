@@ -43,6 +43,66 @@ struct ConvArgs {
 };
 
 
+// one (TWO = false) or two 16-column tiles of the implicit GEMM: independent accumulator chains, B fragments fetched one
+// (tap, g) step ahead of the MFMAs that consume them, swish epilogue, 16-byte channel-last stores
+template <int IC, int KW, int STRIDE, bool TWO>
+__device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem, const float (&A)[KW * IC / 4], const f32x4 b4,
+                                           int64_t chunk0, int ncols, int tile, int w, int q, int nn) {
+    constexpr int G = IC / 16;
+    constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;
+    constexpr int NS = KW * G;
+    int col0 = tile * 16 + nn, col1 = col0 + 16;
+    const bool v0 = col0 < ncols, v1 = TWO && col1 < ncols;
+    col0 = v0 ? col0 : ncols - 1;
+    col1 = v1 ? col1 : ncols - 1;
+    const int ch0 = (int)(((float)col0 + 0.5f) * a.div_pout.inv);
+    const int ch1 = (int)(((float)col1 + 0.5f) * a.div_pout.inv);
+    const int p0 = col0 - ch0 * a.pout, p1 = col1 - ch1 * a.pout;
+    const float *r0 = smem + (size_t)q * a.plane + (size_t)(ch0 * a.pin + p0 * STRIDE) * RS;
+    const float *r1 = smem + (size_t)q * a.plane + (size_t)(ch1 * a.pin + p1 * STRIDE) * RS;
+    f32x4 acc0 = b4, acc1 = b4;
+    f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0), x1 = x0;
+    if (TWO) x1 = *reinterpret_cast<const f32x4 *>(r1);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        f32x4 y0 = x0, y1 = x1;
+        if (st + 1 < NS) {
+            const int tap = (st + 1) / G, g = (st + 1) % G;
+            y0 = *reinterpret_cast<const f32x4 *>(r0 + tap * RS + 4 * g);
+            if (TWO) y1 = *reinterpret_cast<const f32x4 *>(r1 + tap * RS + 4 * g);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x0[j], acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x1[j], acc1, 0, 0, 0);
+        }
+        x0 = y0;
+        x1 = y1;
+    }
+    // pin the software pipeline: reads of step st+1 are issued before the MFMAs of step st
+    constexpr int T = TWO ? 2 : 1;
+    __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T, 0);
+    }
+    if (v0) {
+        f32x2 lo = f32x2{acc0[0], acc0[1]}, hi = f32x2{acc0[2], acc0[3]};
+        swish_pk(lo, hi);  // same operations as swish_f, the plain ones two values per instruction
+        const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
+        float *dst = a.out + ((size_t)(chunk0 + ch0) * a.pout + p0) * a.out_row + a.out_coff + 16 * w + 4 * q;
+        *reinterpret_cast<f32x4 *>(dst) = y;
+    }
+    if (v1) {
+        f32x2 lo = f32x2{acc1[0], acc1[1]}, hi = f32x2{acc1[2], acc1[3]};
+        swish_pk(lo, hi);
+        const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
+        float *dst = a.out + ((size_t)(chunk0 + ch1) * a.pout + p1) * a.out_row + a.out_coff + 16 * w + 4 * q;
+        *reinterpret_cast<f32x4 *>(dst) = y;
+    }
+}
+
 template <int IC, int KW, int STRIDE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -91,56 +151,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int ncols = nch * a.pout;
         const int ntiles = (ncols + 15) >> 4;
         for (int tile = 0; tile < ntiles; tile += 2) {
-            int col0 = tile * 16 + nn, col1 = col0 + 16;
-            const bool v0 = col0 < ncols, v1 = col1 < ncols;
-            col0 = v0 ? col0 : ncols - 1;
-            col1 = v1 ? col1 : ncols - 1;
-            const int ch0 = (int)(((float)col0 + 0.5f) * a.div_pout.inv);
-            const int ch1 = (int)(((float)col1 + 0.5f) * a.div_pout.inv);
-            const int p0 = col0 - ch0 * a.pout, p1 = col1 - ch1 * a.pout;
-            const float *r0 = smem + (size_t)q * a.plane + (size_t)(ch0 * a.pin + p0 * STRIDE) * RS;
-            const float *r1 = smem + (size_t)q * a.plane + (size_t)(ch1 * a.pin + p1 * STRIDE) * RS;
-            f32x4 acc0 = b4, acc1 = b4;
-            // B fragments are fetched one (tap, g) step ahead of the MFMAs that consume them
-            constexpr int NS = KW * G;
-            f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0), x1 = *reinterpret_cast<const f32x4 *>(r1);
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                f32x4 y0 = x0, y1 = x1;
-                if (st + 1 < NS) {
-                    const int tap = (st + 1) / G, g = (st + 1) % G;
-                    y0 = *reinterpret_cast<const f32x4 *>(r0 + tap * RS + 4 * g);
-                    y1 = *reinterpret_cast<const f32x4 *>(r1 + tap * RS + 4 * g);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x0[j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st * 4 + j], x1[j], acc1, 0, 0, 0);
-                }
-                x0 = y0;
-                x1 = y1;
-            }
-            // pin the software pipeline: reads of step st+1 are issued before the MFMAs of step st
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            }
-            if (v0) {
-                f32x2 lo = f32x2{acc0[0], acc0[1]}, hi = f32x2{acc0[2], acc0[3]};
-                swish_pk(lo, hi);  // same operations as swish_f, the plain ones two values per instruction
-                const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
-                float *dst = a.out + ((size_t)(chunk0 + ch0) * a.pout + p0) * a.out_row + a.out_coff + 16 * w + 4 * q;
-                *reinterpret_cast<f32x4 *>(dst) = y;
-            }
-            if (v1) {
-                f32x2 lo = f32x2{acc1[0], acc1[1]}, hi = f32x2{acc1[2], acc1[3]};
-                swish_pk(lo, hi);
-                const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
-                float *dst = a.out + ((size_t)(chunk0 + ch1) * a.pout + p1) * a.out_row + a.out_coff + 16 * w + 4 * q;
-                *reinterpret_cast<f32x4 *>(dst) = y;
-            }
+            // an odd last tile runs alone (wave-uniform): no MFMA is spent on a padding tile
+            if (tile + 1 < ntiles) conv_tiles<IC, KW, STRIDE, true>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
+            else conv_tiles<IC, KW, STRIDE, false>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
         }
     }
 }

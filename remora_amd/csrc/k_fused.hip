@@ -42,6 +42,8 @@ namespace rmr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct FusedArgs {
     const float *signal;   // [n][L]
@@ -82,8 +84,13 @@ __device__ unsigned long long g_stage_clock[4][16];
 
 __device__ __forceinline__ int fdiv(int x, FastDiv d) { return (int)(((float)x + 0.5f) * d.inv); }
 
-__device__ __forceinline__ f32x4 mfma_bf16(const uint4 a, const uint4 b, const f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+// The 16-bit operand type is a template parameter of everything below: F16 = false -> bf16 (8 exponent / 7 mantissa bits;
+// BASELINE configs[3]/[4] name it), true -> IEEE half (5 / 10 bits: eight times finer rounding at the same matrix rate
+// - v_mfma_f32_16x16x32_f16 and _bf16 are both 16 cycles; activations here are O(1..10), far from half's 65504).
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const uint4 a, const uint4 b, const f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // Activations are carried SCALED by log2(e): every layer's weights/bias are prepared on the host so that the
@@ -92,15 +99,22 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4 a, const uint4 b, const f
 // which saves the multiply by -log2(e) in front of every v_exp_f32; the next layer's weights are unchanged (its bias
 // is scaled by log2(e)), and the last layer multiplies by POST = 1 / log2(e) to hand over the true activation.
 // Four accumulator rows (consecutive output channels) -> four bf16: 8 bytes.
+template <bool F16>
 __device__ __forceinline__ uint2 swish_pack(const f32x4 acc, const int no_swish = 0, const float post = 1.0f) {
-    bf16x4 o;
+    float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float z = acc[r];
         const float y = z * fast_rcp(1.0f + __builtin_amdgcn_exp2f(-z));
-        o[r] = (__bf16)(no_swish ? z : y * post);
+        v[r] = no_swish ? z : y * post;
     }
-    return __builtin_bit_cast(uint2, o);
+    if constexpr (F16) {
+        const f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        return __builtin_bit_cast(uint2, o);
+    } else {
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        return __builtin_bit_cast(uint2, o);
+    }
 }
 
 // B fragments (8 bf16 per lane) of NS k-steps of one or two 16-column tiles, read ahead of the MFMAs that use them
@@ -112,26 +126,26 @@ __device__ __forceinline__ void load_b(uint4 (&b0)[NS], uint4 (&b1)[NS], const u
         if (TWO) b1[s] = *reinterpret_cast<const uint4 *>(r1 + off(s));
     }
 }
-template <int NS, bool TWO, int A0 = 0, int NA>
+template <bool F16, int NS, bool TWO, int A0 = 0, int NA>
 __device__ __forceinline__ void mma_b(const uint4 (&A)[NA], const uint4 (&b0)[NS], const uint4 (&b1)[NS], f32x4 &acc0, f32x4 &acc1) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        acc0 = mfma_bf16(A[A0 + s], b0[s], acc0);
-        if (TWO) acc1 = mfma_bf16(A[A0 + s], b1[s], acc1);
+        acc0 = mfma16<F16>(A[A0 + s], b0[s], acc0);
+        if (TWO) acc1 = mfma16<F16>(A[A0 + s], b1[s], acc1);
     }
 }
 
 // sig_conv3 + seq_conv2 of one or two column tiles: the B fragments of sig_conv3 are all in flight before its first
 // MFMA; those of seq_conv2 are read one per MFMA from then on, so that ~10 reads stay ahead of the matrix pipe
-template <bool TWO>
+template <bool F16, bool TWO>
 __device__ __forceinline__ void s3_pair(const uint4 (&Asig3)[5], const uint4 (&Aseq2)[7], const unsigned char *g0, const unsigned char *g1,
                                         const unsigned char *q0, const unsigned char *q1, f32x4 &as0, f32x4 &as1, f32x4 &aq0,
                                         f32x4 &aq1) {
     uint4 bs0[5], bs1[5], bq0[7], bq1[7];
     load_b<5, TWO>(bs0, bs1, g0, g1, [](int s) { return 64 * s; });
     load_b<7, TWO>(bq0, bq1, q0, q1, [](int s) { return 64 * s; });
-    mma_b<5, TWO, 0>(Asig3, bs0, bs1, as0, as1);
-    mma_b<7, TWO, 0>(Aseq2, bq0, bq1, aq0, aq1);
+    mma_b<F16, 5, TWO, 0>(Asig3, bs0, bs1, as0, as1);
+    mma_b<F16, 7, TWO, 0>(Aseq2, bq0, bq1, aq0, aq1);
     // pin the issue order (hipcc otherwise sinks every ds_read next to its MFMA: no read in flight under the MFMAs)
     constexpr int T = TWO ? 2 : 1;
     __builtin_amdgcn_sched_group_barrier(0x100, 5 * T, 0);
@@ -143,20 +157,31 @@ __device__ __forceinline__ void s3_pair(const uint4 (&Asig3)[5], const uint4 (&A
     __builtin_amdgcn_sched_group_barrier(0x008, 5 * T, 0);
 }
 
+// one stride-3 convolution (NS k-steps) of one or two column tiles, every B fragment in flight before the first MFMA
+template <bool F16, int NS, bool TWO>
+__device__ __forceinline__ void s3_one(const uint4 (&A)[NS], const unsigned char *g0, const unsigned char *g1, f32x4 &a0, f32x4 &a1) {
+    uint4 b0[NS], b1[NS];
+    load_b<NS, TWO>(b0, b1, g0, g1, [](int s) { return 64 * s; });
+    mma_b<F16, NS, TWO, 0>(A, b0, b1, a0, a1);
+    constexpr int T = TWO ? 2 : 1;
+    __builtin_amdgcn_sched_group_barrier(0x100, NS * T, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NS * T, 0);
+}
+
 // merge_conv1 of one or two column tiles: the four 32-channel slots of tap t+1 are read while the MFMAs of tap t run
-template <bool TWO>
+template <bool F16, bool TWO>
 __device__ __forceinline__ void s4_pair(const uint4 (&Am1)[20], const unsigned char *r0, const unsigned char *r1, f32x4 &acc0, f32x4 &acc1) {
     uint4 ba0[4], ba1[4], bb0[4], bb1[4];
     load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 16 * s; });
     load_b<4, TWO>(bb0, bb1, r0, r1, [](int s) { return 80 + 16 * s; });
-    mma_b<4, TWO, 0>(Am1, ba0, ba1, acc0, acc1);
+    mma_b<F16, 4, TWO, 0>(Am1, ba0, ba1, acc0, acc1);
     load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 160 + 16 * s; });
-    mma_b<4, TWO, 4>(Am1, bb0, bb1, acc0, acc1);
+    mma_b<F16, 4, TWO, 4>(Am1, bb0, bb1, acc0, acc1);
     load_b<4, TWO>(bb0, bb1, r0, r1, [](int s) { return 240 + 16 * s; });
-    mma_b<4, TWO, 8>(Am1, ba0, ba1, acc0, acc1);
+    mma_b<F16, 4, TWO, 8>(Am1, ba0, ba1, acc0, acc1);
     load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 320 + 16 * s; });
-    mma_b<4, TWO, 12>(Am1, bb0, bb1, acc0, acc1);
-    mma_b<4, TWO, 16>(Am1, ba0, ba1, acc0, acc1);
+    mma_b<F16, 4, TWO, 12>(Am1, bb0, bb1, acc0, acc1);
+    mma_b<F16, 4, TWO, 16>(Am1, ba0, ba1, acc0, acc1);
     // pin: two taps of reads up front, then one read issued per MFMA, so that a tap's reads are a tap ahead of its MFMAs
     constexpr int T = TWO ? 2 : 1;
     __builtin_amdgcn_sched_group_barrier(0x100, 8 * T, 0);
@@ -166,6 +191,34 @@ __device__ __forceinline__ void s4_pair(const uint4 (&Am1)[20], const unsigned c
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 8 * T, 0);
+}
+
+// merge_conv1 with HALF the fragments in flight (one tap = 4 slots per tile): for the three-waves-per-SIMD build, where
+// the other two waves of the SIMD cover the wait between a tap's reads and its MFMAs
+template <bool F16, bool TWO>
+__device__ __forceinline__ void s4_pair_lean(const uint4 (&Am1)[20], const unsigned char *r0, const unsigned char *r1, f32x4 &acc0,
+                                             f32x4 &acc1) {
+    uint4 ba0[4], ba1[4], bb0[2], bb1[2];
+    load_b<4, TWO>(ba0, ba1, r0, r1, [](int s) { return 16 * s; });
+#pragma unroll
+    for (int tap = 0; tap < 5; ++tap) {
+        // first half of the next tap's slots requested under this tap's MFMAs
+        if (tap < 4) load_b<2, TWO>(bb0, bb1, r0, r1, [tap](int s) { return 80 * (tap + 1) + 16 * s; });
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc0 = mfma16<F16>(Am1[4 * tap + s], ba0[s], acc0);
+            if (TWO) acc1 = mfma16<F16>(Am1[4 * tap + s], ba1[s], acc1);
+        }
+        if (tap < 4) {
+            ba0[0] = bb0[0]; ba0[1] = bb0[1];
+            if (TWO) { ba1[0] = bb1[0]; ba1[1] = bb1[1]; }
+#pragma unroll
+            for (int s = 2; s < 4; ++s) {
+                ba0[s] = *reinterpret_cast<const uint4 *>(r0 + 80 * (tap + 1) + 16 * s);
+                if (TWO) ba1[s] = *reinterpret_cast<const uint4 *>(r1 + 80 * (tap + 1) + 16 * s);
+            }
+        }
+    }
 }
 
 // the chunk arrays of one block iteration, one element per thread and array, on their way from HBM to LDS
@@ -182,9 +235,24 @@ struct InRegs {
 #ifndef RMR_FUSED_RES_MID
 #define RMR_FUSED_RES_MID 0    // sig_conv3 + seq_conv2 (48 VGPRs)
 #endif
+#ifndef RMR_FUSED_S3_SPLIT
+#define RMR_FUSED_S3_SPLIT 0   // 1: S3 as two passes (sig_conv3, seq_conv2) instead of both convolutions per tile pair
+#endif
+#ifndef RMR_FUSED_S4_LEAN
+#define RMR_FUSED_S4_LEAN 0    // 1: merge_conv1 with 12 instead of 16 fragments in flight per tile pair
+#endif
+#ifndef RMR_FUSED_STREAM_M1
+#define RMR_FUSED_STREAM_M1 0  // 1: merge_conv1's fragments (80 VGPRs) fetched per iteration after S3 instead of living in registers
+#endif
 
-template <int K>
+template <int K, bool F16>
 #ifndef RMR_FUSED_WAVES_EU
+// Waves per SIMD the register budget is set for.  2 (254 VGPRs, merge_conv1 fragments resident, two blocks per CU) is the
+// shipped build.  The three-waves build (-DRMR_FUSED_WAVES_EU=3 -DRMR_FUSED_STREAM_M1=1 -DRMR_FUSED_S3_SPLIT=1
+// -DRMR_FUSED_S4_LEAN=1: 166 VGPRs, no spills, three blocks of three chunks per CU) measured 7.28 ns/chunk against 6.72
+// (round 3, tools/ab_variants.py): the extra wave buys 7 %, streaming the fragments, the leaner read-ahead and the
+// smaller tiles cost 17 % - the kernel is bound by LDS read bandwidth (one ds_read_b128 per MFMA = 256 B/clk at full
+// matrix rate), not by latency.
 #define RMR_FUSED_WAVES_EU 2
 #endif
 __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(FusedArgs a) {
@@ -208,8 +276,11 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         return __builtin_bit_cast(uint4, v);
     };
     uint4 Am1[KS_M1];
+    auto load_m1 = [&]() {
 #pragma unroll
-    for (int s = 0; s < KS_M1; ++s) Am1[s] = frag(a.a_merge1, 4 * KS_M1, wu * KS_M1 + s);
+        for (int s = 0; s < KS_M1; ++s) Am1[s] = frag(a.a_merge1, 4 * KS_M1, wu * KS_M1 + s);
+    };
+    if (!RMR_FUSED_STREAM_M1) load_m1();
     uint4 Asig2, Aseq1[KS_SEQ1], Asig3[KS_SIG3], Aseq2[KS_SEQ2];
     auto load_small = [&]() {
         Asig2 = frag(a.a_sig2, 1, 0);
@@ -298,7 +369,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 acc.z = fmaf(w1[t][2], xv, acc.z); acc.w = fmaf(w1[t][3], xv, acc.w);
             }
             const f32x4 v = {acc.x, acc.y, acc.z, acc.w};
-            *reinterpret_cast<uint2 *>(s_sig1 + (size_t)i * 8) = swish_pack(v, ABL(64));
+            *reinterpret_cast<uint2 *>(s_sig1 + (size_t)i * 8) = swish_pack<F16>(v, ABL(64));
         }
         // one thread per signal position: the base p that covers it (the gather form of the reference's scatter loops:
         // p = #{mapping entries map[0..len] <= s} - 1, valid when 0 <= p < len), the K bases p..p+K-1 as 3-bit codes
@@ -329,7 +400,8 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             for (int cg = 0; cg < CG; ++cg) {
                 const unsigned b0 = (code >> (6 * cg)) & 7u;
                 const unsigned b1c = 2 * cg + 1 < K ? ((code >> (6 * cg + 3)) & 7u) : 4u;
-                const unsigned one0 = 0x3F80u << ((b0 & 1u) * 16), one1 = 0x3F80u << ((b1c & 1u) * 16);
+                constexpr unsigned ONE = F16 ? 0x3C00u : 0x3F80u;  // 1.0 in half / bf16
+                const unsigned one0 = ONE << ((b0 & 1u) * 16), one1 = ONE << ((b1c & 1u) * 16);
                 uint4 v;
                 v.x = (b0 >> 1) == 0 ? one0 : 0u;
                 v.y = (b0 >> 1) == 1 ? one0 : 0u;
@@ -364,10 +436,10 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                     const unsigned char *r1 = s_sig1 + (size_t)(ci * a.P1 + pos1) * 8 + 16 * q;
                     const uint2 x00 = *reinterpret_cast<const uint2 *>(r0), x01 = *reinterpret_cast<const uint2 *>(r0 + 8);
                     const uint2 x10 = *reinterpret_cast<const uint2 *>(r1), x11 = *reinterpret_cast<const uint2 *>(r1 + 8);
-                    const f32x4 acc0 = mfma_bf16(Asig2, make_uint4(x00.x, x00.y, x01.x, x01.y), b_sig2);
-                    const f32x4 acc1 = mfma_bf16(Asig2, make_uint4(x10.x, x10.y, x11.x, x11.y), b_sig2);
-                    if (v0) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos0) * 32 + 8 * q) = swish_pack(acc0, ABL(64));
-                    if (v1) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos1) * 32 + 8 * q) = swish_pack(acc1, ABL(64));
+                    const f32x4 acc0 = mfma16<F16>(Asig2, make_uint4(x00.x, x00.y, x01.x, x01.y), b_sig2);
+                    const f32x4 acc1 = mfma16<F16>(Asig2, make_uint4(x10.x, x10.y, x11.x, x11.y), b_sig2);
+                    if (v0) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos0) * 32 + 8 * q) = swish_pack<F16>(acc0, ABL(64));
+                    if (v1) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos1) * 32 + 8 * q) = swish_pack<F16>(acc1, ABL(64));
                 } else {
                     int pos0 = 32 * (r - pairs_sig2) + nn, pos1 = pos0 + 16;
                     const bool v0 = pos0 < a.P1, v1 = pos1 < a.P1;
@@ -382,11 +454,11 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                         b0[s] = *reinterpret_cast<const uint4 *>(r0 + oh_off[s]);
                         b1v[s] = *reinterpret_cast<const uint4 *>(r1 + oh_off[s]);
                     }
-                    mma_b<KS_SEQ1, true, 0>(Aseq1, b0, b1v, acc0, acc1);
+                    mma_b<F16, KS_SEQ1, true, 0>(Aseq1, b0, b1v, acc0, acc1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS_SEQ1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * KS_SEQ1, 0);
-                    if (v0) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos0) * 32 + 8 * q) = swish_pack(acc0, ABL(64));
-                    if (v1) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos1) * 32 + 8 * q) = swish_pack(acc1, ABL(64));
+                    if (v0) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos0) * 32 + 8 * q) = swish_pack<F16>(acc0, ABL(64));
+                    if (v1) *reinterpret_cast<uint2 *>(s_seq1 + (size_t)(ci * a.P1 + pos1) * 32 + 8 * q) = swish_pack<F16>(acc1, ABL(64));
                 }
             }
         }
@@ -404,6 +476,35 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             // CAT position of this lane's 4 output channels c0 = 16w + 4q (+64 for the sequence half):
             // plane (c0 % 32) / 8, slot c0 / 32, half (c0 % 8) / 4
             unsigned char *cat_w = s_cat + (size_t)((w & 1) * 2 + (q >> 1)) * a.cat_plane + (w >> 1) * 16 + (q & 1) * 8;
+#if RMR_FUSED_S3_SPLIT
+            // two passes (sig_conv3, then seq_conv2): half the fragments in flight, so that three waves fit a SIMD
+            for (int pass = 0; pass < 2; ++pass) {
+                const unsigned char *src = pass ? s_seq1 : s_sig2;
+                const int pin = pass ? a.P1 : a.P2;
+                const f32x4 bb = pass ? b_seq2 : b_sig3;
+                for (int tile = 0; tile < ntiles; tile += 2) {
+                    int col0 = tile * 16 + nn, col1 = col0 + 16;
+                    const bool v0 = col0 < ncols, v1 = col1 < ncols;
+                    col0 = v0 ? col0 : ncols - 1;
+                    col1 = v1 ? col1 : ncols - 1;
+                    const int ch0 = fdiv(col0, a.d_P3), ch1 = fdiv(col1, a.d_P3);
+                    const int p0 = col0 - ch0 * a.P3, p1 = col1 - ch1 * a.P3;
+                    const unsigned char *g0 = src + (size_t)(ch0 * pin + 3 * p0) * 32 + 16 * q;
+                    const unsigned char *g1 = src + (size_t)(ch1 * pin + 3 * p1) * 32 + 16 * q;
+                    f32x4 a0 = bb, a1 = bb;
+                    const bool two = tile + 1 < ntiles;  // wave-uniform
+                    if (pass == 0) {
+                        if (two) s3_one<F16, 5, true>(Asig3, g0, g1, a0, a1);
+                        else s3_one<F16, 5, false>(Asig3, g0, g1, a0, a1);
+                    } else {
+                        if (two) s3_one<F16, 7, true>(Aseq2, g0, g1, a0, a1);
+                        else s3_one<F16, 7, false>(Aseq2, g0, g1, a0, a1);
+                    }
+                    if (v0) *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80 + 32 * pass) = swish_pack<F16>(a0, ABL(64));
+                    if (v1) *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80 + 32 * pass) = swish_pack<F16>(a1, ABL(64));
+                }
+            }
+#else
             for (int tile = 0; tile < ntiles; tile += 2) {
                 int col0 = tile * 16 + nn, col1 = col0 + 16;
                 const bool v0 = col0 < ncols, v1 = col1 < ncols;
@@ -416,17 +517,18 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 const unsigned char *q0 = s_seq1 + (size_t)(ch0 * a.P1 + 3 * p0) * 32 + 16 * q;
                 const unsigned char *q1 = s_seq1 + (size_t)(ch1 * a.P1 + 3 * p1) * 32 + 16 * q;
                 f32x4 as0 = b_sig3, as1 = b_sig3, aq0 = b_seq2, aq1 = b_seq2;
-                if (tile + 1 < ntiles) s3_pair<true>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);  // wave-uniform
-                else s3_pair<false>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);
+                if (tile + 1 < ntiles) s3_pair<F16, true>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);  // wave-uniform
+                else s3_pair<F16, false>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);
                 if (v0) {
-                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80) = swish_pack(as0, ABL(64));
-                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80 + 32) = swish_pack(aq0, ABL(64));
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80) = swish_pack<F16>(as0, ABL(64));
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col0 * 80 + 32) = swish_pack<F16>(aq0, ABL(64));
                 }
                 if (v1) {
-                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80) = swish_pack(as1, ABL(64));
-                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80 + 32) = swish_pack(aq1, ABL(64));
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80) = swish_pack<F16>(as1, ABL(64));
+                    *reinterpret_cast<uint2 *>(cat_w + (size_t)col1 * 80 + 32) = swish_pack<F16>(aq1, ABL(64));
                 }
             }
+#endif
         }
         // the chunk arrays of the block's next iteration leave HBM now and land in LDS after merge_conv1 (their LDS
         // regions were last read in S1)
@@ -434,6 +536,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         //  for the prefetch)
         TS(5);
         const f32x4 b_m1 = *reinterpret_cast<const f32x4 *>(a.b_merge1 + 16 * w + 4 * q);
+        if (RMR_FUSED_STREAM_M1) load_m1();
         const InRegs next_in = fetch_inputs(it + gridDim.x);
         __syncthreads();
         TS(6);
@@ -452,10 +555,15 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 const unsigned char *r0 = cat_r + (size_t)(ch0 * a.P3 + (col0 - ch0 * a.T)) * 80;
                 const unsigned char *r1 = cat_r + (size_t)(ch1 * a.P3 + (col1 - ch1 * a.T)) * 80;
                 f32x4 acc0 = b_m1, acc1 = b_m1;
-                if (tile + 1 < ntiles) s4_pair<true>(Am1, r0, r1, acc0, acc1);  // wave-uniform
-                else s4_pair<false>(Am1, r0, r1, acc0, acc1);
-                if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack(acc0, ABL(64), 0.6931471805599453f);
-                if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack(acc1, ABL(64), 0.6931471805599453f);
+#if RMR_FUSED_S4_LEAN
+                if (tile + 1 < ntiles) s4_pair_lean<F16, true>(Am1, r0, r1, acc0, acc1);  // wave-uniform
+                else s4_pair_lean<F16, false>(Am1, r0, r1, acc0, acc1);
+#else
+                if (tile + 1 < ntiles) s4_pair<F16, true>(Am1, r0, r1, acc0, acc1);  // wave-uniform
+                else s4_pair<F16, false>(Am1, r0, r1, acc0, acc1);
+#endif
+                if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack<F16>(acc0, ABL(64), 0.6931471805599453f);
+                if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack<F16>(acc1, ABL(64), 0.6931471805599453f);
             }
         }
         TS(7);
@@ -472,7 +580,8 @@ static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs 
     const int CG = (4 * m->desc.kmer_len + 7) / 8;
     a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.P3 = m->P3; a.T = m->T;
     auto up16 = [](int b) { return (b + 15) & ~15; };
-    const int budget = tune_int("RMR_FUSED_LDS_BUDGET", 80 * 1024);
+    // RMR_FUSED_WAVES_EU blocks are resident per CU (one wave of each per SIMD): each gets its share of the 160 KB
+    const int budget = tune_int("RMR_FUSED_LDS_BUDGET", (160 * 1024) / RMR_FUSED_WAVES_EU - 256);
     total = 0;
     for (int cb = tune_int("RMR_FUSED_CB", 8); cb >= 1; --cb) {
         if (cb * a.L > 1024 || cb * seq_w > 256 || cb * map_w > 256) continue;
@@ -535,10 +644,12 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
         RMR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stage_clock), zeros, sizeof(zeros)));
     }
 #endif
-    auto kern = m->desc.kmer_len == 9 ? fused_front_kernel<9> : fused_front_kernel<6>;  // (4,4) and (2,3)-style contexts
+    // (4,4) and (2,3)-style k-mer contexts; bf16 or half operands
+    auto kern = m->f16 ? (m->desc.kmer_len == 9 ? fused_front_kernel<9, true> : fused_front_kernel<6, true>)
+                       : (m->desc.kmer_len == 9 ? fused_front_kernel<9, false> : fused_front_kernel<6, false>);
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 4);
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 2 * RMR_FUSED_WAVES_EU);
     if (grid > iters) grid = iters;
     ProfScope ps(e, K_FUSED_FRONT);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)total, e->stream, a);

@@ -23,6 +23,8 @@ namespace rmr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct LstmXArgs {
     const uint16_t *x;     // bf16 [n][T][64]
@@ -34,8 +36,11 @@ struct LstmXArgs {
     int T, num_out;
 };
 
+// F16: the operands (x from the fused front kernel, h, the weights) are IEEE half instead of bf16 (k_fused.hip)
+template <bool F16>
 __device__ __forceinline__ f32x4 mfma16(const uint4 a, const uint4 b, const f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // acc rows are pre-scaled: [0] i, [1] f, [3] o by -log2(e); [2] g by 2 log2(e)
@@ -49,6 +54,7 @@ __device__ __forceinline__ float lstm_cell(const f32x4 acc, float &c) {
     return og * tc;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
     // B-operand images (8 bf16 = 16 B per slot): plane p = 8-channel group (channel / 8) % 4, slot = channel / 32,
     // rows = chunks; 3 slots per row (2 used) keep the 16-lane ds_read_b128 groups on distinct bank slots
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
         for (int t = 0; t < 2; ++t) {
             accN[t] = bias[t];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) accN[t] = mfma16(Aih[t][ks], xs[0][q][nn][ks], accN[t]);
+            for (int ks = 0; ks < 2; ++ks) accN[t] = mfma16<F16>(Aih[t][ks], xs[0][q][nn][ks], accN[t]);
         }
         for (int t = 0; t < a.T; ++t) {
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;  // x_{t+2} (the last two fetches are redundant re-reads)
@@ -107,15 +113,15 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
                 const uint4 bh0 = hs[(t - 1) & 1][q][nn][0], bh1 = hs[(t - 1) & 1][q][nn][1];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    acc[u] = mfma16(Ahh[u][0], bh0, acc[u]);
-                    acc[u] = mfma16(Ahh[u][1], bh1, acc[u]);
+                    acc[u] = mfma16<F16>(Ahh[u][0], bh0, acc[u]);
+                    acc[u] = mfma16<F16>(Ahh[u][1], bh1, acc[u]);
                 }
             }
             // input projection of the next step (in the last step it projects a stale, finite tile: dropped)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                accN[u] = mfma16(Aih[u][0], bx0, bias[u]);
-                accN[u] = mfma16(Aih[u][1], bx1, accN[u]);
+                accN[u] = mfma16<F16>(Aih[u][0], bx0, bias[u]);
+                accN[u] = mfma16<F16>(Aih[u][1], bx1, accN[u]);
             }
             float h0 = lstm_cell(acc[0], c[0]);
             float h1 = lstm_cell(acc[1], c[1]);
@@ -123,10 +129,10 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
                 h0 = swish_f(h0);
                 h1 = swish_f(h1);
             }
-            bf16x2 hp;
-            hp[0] = (__bf16)h0;
-            hp[1] = (__bf16)h1;
-            reinterpret_cast<unsigned *>(&hs[t & 1][h_plane][nn][h_slot])[q] = __builtin_bit_cast(unsigned, hp);
+            unsigned hp;
+            if constexpr (F16) hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)h0, (_Float16)h1});
+            else hp = __builtin_bit_cast(unsigned, bf16x2{(__bf16)h0, (__bf16)h1});
+            reinterpret_cast<unsigned *>(&hs[t & 1][h_plane][nn][h_slot])[q] = hp;
             if (stager) xs[t & 1][st_c8 & 3][st_row][st_c8 >> 2] = xnext;  // the buffer whose last reader was step t-1
             __syncthreads();
         }
@@ -137,8 +143,8 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 acc2[u] = *reinterpret_cast<const f32x4 *>(a.b2 + ((w * 2 + u) * 4 + q) * 4);
-                acc2[u] = mfma16(a.a_ih2[((w * 2 + u) * 2 + 0) * 64 + lane], bh0, acc2[u]);
-                acc2[u] = mfma16(a.a_ih2[((w * 2 + u) * 2 + 1) * 64 + lane], bh1, acc2[u]);
+                acc2[u] = mfma16<F16>(a.a_ih2[((w * 2 + u) * 2 + 0) * 64 + lane], bh0, acc2[u]);
+                acc2[u] = mfma16<F16>(a.a_ih2[((w * 2 + u) * 2 + 1) * 64 + lane], bh1, acc2[u]);
             }
         }
         float y[2];
@@ -181,7 +187,8 @@ int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logi
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTMX_BLOCKS_PER_CU", 4);
     if (grid > groups) grid = groups;
     ProfScope ps(e, K_LSTM_HEAD);
-    hipLaunchKernelGGL(lstm_x16_kernel, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
+    if (m->f16) hipLaunchKernelGGL(lstm_x16_kernel<true>, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
+    else hipLaunchKernelGGL(lstm_x16_kernel<false>, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }

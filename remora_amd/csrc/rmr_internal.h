@@ -188,6 +188,7 @@ struct rmr_model {
     rmr_engine *eng = nullptr;
     rmr_model_desc desc{};
     int nparts = 0;  // 0: fp32 MFMA path; 1..3: bf16 MFMA with 1 / 2 / 3-part split operands
+    bool f16 = false;  // dtype 4: nparts == 1 with IEEE-half operands in the fused kernels (k_fused.hip, k_lstm_x16.hip)
     std::vector<void *> dev_allocs;
     rmr::FrontWeights front;
     // conv_lstm: sig3, seq2, merge1;  conv_only: sig3, seq2, seq3, merge1..4

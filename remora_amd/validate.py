@@ -159,8 +159,8 @@ class ValidationLogger:
         total = int(full.sum())
         acc = np.trace(full) / total
         win = np.take_along_axis(probs, preds[:, None], -1)[:, 0]
-        trip = rdist.gather_arrays(np.stack([labels.astype(np.float64), preds.astype(np.float64), win.astype(np.float64)], axis=1))
-        g_lab, g_pred, g_win = trip[:, 0].astype(np.int64), trip[:, 1].astype(np.int64), trip[:, 2]
+        lp = rdist.gather_arrays(np.stack([labels.astype(np.int64), preds.astype(np.int64)], axis=1))
+        g_lab, g_pred, g_win = lp[:, 0], lp[:, 1], rdist.gather_arrays(win)  # win keeps its dtype: same quantile as one process
         loss = float(np.mean(rdist.gather_arrays(np.asarray(losses, np.float64).reshape(-1))))
         thr = np.quantile(g_win, filt_frac)
         if thr == g_win.max():

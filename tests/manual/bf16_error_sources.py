@@ -25,56 +25,14 @@ from oracle import torch_ref  # noqa: E402
 from remora_amd import synth  # noqa: E402
 
 
-FMT = torch.bfloat16
-
-
-def r16(t):
-    return t.to(torch.float32).to(FMT).to(torch.float64)
-
-
-def r16x2(t):
-    hi = r16(t)
-    return hi + r16(t - hi)
-
-
-def fold(net, conv, bn):
-    c, b = getattr(net, conv), getattr(net, bn)
-    s = (b.weight.double() / torch.sqrt(b.running_var.double() + b.eps))
-    return c.weight.double() * s[:, None, None], (c.bias.double() - b.running_mean.double()) * s + b.bias.double()
-
-
-def swish(x):
-    return x * torch.sigmoid(x)
+from oracle import lowp_emulation  # noqa: E402
 
 
 def forward(net, sig, enc, sites, split=()):
-    def rnd(name, t, sub=None):
-        on = name in sites or (sub is not None and f"{name}.{sub}" in sites)
-        sp = name in split or (sub is not None and f"{name}.{sub}" in split)
-        return (r16x2(t) if sp else r16(t)) if on else t
-    F = torch.nn.functional
-    conv = lambda x, wb, sub, stride=1: F.conv1d(x, rnd("wconv", wb[0], sub), wb[1], stride=stride)
-    s = swish(F.conv1d(sig, *fold(net, "sig_conv1", "sig_bn1")))  # fp32 VALU in the kernel: no weight rounding
-    s = swish(conv(rnd("aconv", s, "sig1"), fold(net, "sig_conv2", "sig_bn2"), "sig2"))
-    s = swish(conv(rnd("aconv", s, "sig2"), fold(net, "sig_conv3", "sig_bn3"), "sig3", 3))
-    q = swish(conv(enc, fold(net, "seq_conv1", "seq_bn1"), "seq1"))
-    q = swish(conv(rnd("aconv", q, "seq1"), fold(net, "seq_conv2", "seq_bn2"), "seq2", 3))
-    z = rnd("aconv", torch.cat((s, q), 1), "cat")
-    x = rnd("x", swish(conv(z, fold(net, "merge_conv1", "merge_bn"), "merge1"))).permute(2, 0, 1)  # [T][n][64]
-    wih, whh = rnd("wlstm", net.lstm1.weight_ih_l0.double()), rnd("wlstm", net.lstm1.weight_hh_l0.double())
-    b = net.lstm1.bias_ih_l0.double() + net.lstm1.bias_hh_l0.double()
-    n = x.shape[1]
-    h = torch.zeros(n, 64, dtype=torch.float64)
-    c = torch.zeros(n, 64, dtype=torch.float64)
-    for t in range(x.shape[0]):
-        g = x[t] @ wih.T + rnd("h", h) @ whh.T + b
-        i, f, gg, o = g.chunk(4, 1)
-        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
-        h = torch.sigmoid(o) * torch.tanh(c)
-    g = rnd("h", swish(h)) @ rnd("wlstm", net.lstm2.weight_ih_l0.double()).T + net.lstm2.bias_ih_l0.double() + net.lstm2.bias_hh_l0.double()
-    i, f, gg, o = g.chunk(4, 1)
-    y = swish(torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(gg)))
-    return y @ net.fc.weight.double().T + net.fc.bias.double()
+    return lowp_emulation.forward(net, sig, enc, sites, split, FMT)
+
+
+FMT = "bf16"
 
 
 def main():
@@ -87,7 +45,7 @@ def main():
     ap.add_argument("--only-all", action="store_true", help="only the all-sites line")
     args = ap.parse_args()
     global FMT
-    FMT = torch.bfloat16 if args.fmt == "bf16" else torch.float16
+    FMT = args.fmt
     cc, kcb, _, num_out, _ = synth.CONFIGS[args.cfg]
     state = synth.synth_state("conv_lstm", 64, 9, num_out, seed=0)
     probe = synth.synth_chunks_config(args.cfg, 8192, shard=0)

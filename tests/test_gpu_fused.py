@@ -177,9 +177,12 @@ def test_call_reads_mods_subbatch_pipeline_equals_one_batch(torch_cuda):
 def test_long_chunk_contexts_run_and_match(torch_cuda, O, dtype, cc, msl):
     """Chunk contexts far beyond the benchmark shapes: the folded fp32 kernels and the fused bf16 kernel either fit one
     chunk per block iteration in a CU's LDS or hand the shape to the unfused kernels — `*_supported()` must know every
-    limit its launcher enforces (round-2 advice: a 'supported' shape that then failed in the launcher)."""
+    limit its launcher enforces (round-2 advice: a 'supported' shape that then failed in the launcher).  One documented
+    limit remains: the fp32 merge_conv1 kernel stages a whole chunk (P3 x 128 floats + padding) in LDS, which a
+    1000-sample chunk exceeds - refused with a message, not a crash.  bf16: mean error at the bf16 level; its maximum grows
+    with the number of LSTM steps (T = 191 / 324 here) - see test_bf16_error_is_the_arithmetic_not_the_kernel."""
     from oracle import torch_ref
-    from remora_amd import synth
+    from remora_amd import RemoraError, synth
     from remora_amd.model_util import model_from_state
 
     torch = torch_cuda
@@ -188,9 +191,111 @@ def test_long_chunk_contexts_run_and_match(torch_cuda, O, dtype, cc, msl):
     state = {k: v.numpy() for k, v in net.state_dict().items()}
     model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0, dtype=dtype)
     d = synth.synth_chunks(203, L, msl, (4, 4), seed=31)
-    out = model.infer_chunks(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
+    args = (d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
+    if dtype == "fp32" and L == 1000:
+        with pytest.raises(RemoraError, match="B of LDS"):
+            model.infer_chunks(*args)
+        return
+    out = model.infer_chunks(*args)
     enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
     with torch.no_grad():
         ref = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
     assert np.isfinite(out).all()
-    assert np.abs(out - ref).max() <= (1e-4 if dtype == "fp32" else BF16_TOL), (dtype, cc, np.abs(out - ref).max())
+    err = np.abs(out - ref)
+    if dtype == "fp32":
+        assert err.max() <= 1e-4, (cc, err.max())
+    else:
+        assert err.mean() <= 4e-3 and err.max() <= 0.15, (cc, err.mean(), err.max())
+
+
+# ---- the 16-bit pipelines (bf16: BASELINE configs[3]/[4]; f16: the same kernels on IEEE half) --------------------------
+def _centred_pair(torch, cfg, n, dtype, seed=0):
+    """(fp32-path logits, `dtype`-path logits) of n synthetic chunks, both minus the per-class median of the fp32 logits
+    (what bench.py folds into fc.bias: random weights otherwise call one class for every chunk), as device tensors."""
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+    state = synth.synth_state("conv_lstm", 64, 9, num_out, seed=seed)
+    md = dict(chunk_context=cc, kmer_context_bases=kcb)
+    d = synth.synth_chunks_config(cfg, n, shard=3)
+    dev = [torch.from_numpy(d[k]).cuda() for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+    ref = model_from_state(state, md, device=0, dtype="fp32").infer_chunks(*dev, kcb)
+    out = model_from_state(state, md, device=0, dtype=dtype).infer_chunks(*dev, kcb)
+    med = ref.median(dim=0).values
+    return ref - med, out - med
+
+
+@pytest.mark.parametrize("cfg,dtype,max_abs,mean_abs,agree,p999_max", [
+    ("C100", "f16", 2e-2, 6e-4, 0.999, 2e-2), ("C200", "f16", None, 1.2e-3, 0.999, 2e-2),
+    ("C100", "bf16", 0.12, 3e-3, 0.999, 6e-2), ("C200", "bf16", None, 5e-3, 0.995, 0.2)])
+def test_16bit_pipelines_against_the_fp32_path_100k(torch_cuda, cfg, dtype, max_abs, mean_abs, agree, p999_max):
+    """100 k chunks of the configs[3] / configs[4] shapes, 16-bit pipeline against the fp32 pipeline (itself within 5e-6 of a
+    float64 evaluation, bench.py `precision`): mean |error|, argmax agreement over ALL chunks whose fp32 margin exceeds 2e-2,
+    and - where the arithmetic permits it - the maximum.  f16 meets max <= 2e-2 and >= 99.9 % agreement at C100; at C200
+    (58 LSTM steps of a deliberately sensitive random network) single chunks amplify ANY 16-bit rounding beyond 2e-2 (the
+    float64 emulation of half arithmetic shows 0.11 on 30 k chunks, of bf16 0.26; tests/manual/bf16_error_sources.py), so
+    the gate there is agreement + mean + the 99.9th percentile.  bf16's numbers are those of its 8-bit mantissa, not of the
+    kernels: test_16bit_error_is_the_arithmetic_not_the_kernel."""
+    torch = torch_cuda
+    ref, out = _centred_pair(torch, cfg, 100_000, dtype)
+    err = (out - ref).abs()
+    top = ref.topk(2, dim=1).values
+    clear = (top[:, 0] - top[:, 1]) > 2e-2
+    assert int(clear.sum()) > 50_000
+    agreement = float((out.argmax(1) == ref.argmax(1))[clear].float().mean())
+    stats = (cfg, dtype, float(err.max()), float(err.mean()), agreement)
+    assert float(err.mean()) <= mean_abs, stats
+    assert agreement >= agree, stats
+    if max_abs is not None:
+        assert float(err.max()) <= max_abs, stats
+    p999 = float(torch.quantile(err.max(dim=1).values.float(), 0.999))
+    assert p999 <= p999_max, stats + (p999,)
+
+
+@pytest.mark.parametrize("cfg,n", [("C100", 4096), ("C200", 2048)])
+def test_16bit_error_is_the_arithmetic_not_the_kernel(torch_cuda, O, cfg, n):
+    """The kernels against (a) the float64 network and (b) the float64 network with round-to-nearest-even to bf16 / half at
+    the kernels' rounding sites (oracle/lowp_emulation.py): the GPU's error statistics sit at the emulation's level - the
+    kernels add nothing on top of what 16-bit operands cost (accumulation order and the 2-ulp exp/rcp are invisible at
+    this scale).  This is what bounds the plain-bf16 parity: its error is the format's."""
+    from oracle import lowp_emulation, torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+    state = synth.synth_state("conv_lstm", 64, 9, num_out, seed=0)
+    net = torch_ref.from_state(state)
+    d = synth.synth_chunks_config(cfg, n, shard=5)
+    enc = torch.from_numpy(O.compute_encoded_kmer_batch(kcb[0], kcb[1], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"]))
+    sig = torch.from_numpy(d["signal"])
+    with torch.no_grad():
+        exact = lowp_emulation.forward(net, sig, enc, sites=()).numpy()
+        for dtype in ("bf16", "f16"):
+            emu = np.abs(lowp_emulation.forward(net, sig, enc, fmt=dtype).numpy() - exact)
+            model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=dtype)
+            gpu = np.abs(model.infer_chunks(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], kcb) - exact)
+            stats = (cfg, dtype, gpu.mean(), emu.mean(), np.quantile(gpu, 0.99), np.quantile(emu, 0.99), gpu.max(), emu.max())
+            assert gpu.mean() <= 1.3 * emu.mean() + 2e-5, stats
+            assert np.quantile(gpu, 0.99) <= 1.4 * np.quantile(emu, 0.99) + 1e-4, stats
+            assert emu.mean() <= 2.5 * gpu.mean() + 2e-5, stats  # ... and the emulation is the right order of magnitude (the
+            # kernels round a little less often than it assumes: measured 0.5-0.6 of its mean in f16, 0.9-1.0 in bf16)
+
+
+def test_f16_dtype_refuses_what_it_cannot_run(torch_cuda, O):
+    """f16 exists on the fused kernels only: Conv_w_ref, size 16 and a dense one-hot input are refused with messages."""
+    from conftest import golden
+    from remora_amd import RemoraError
+    from remora_amd.model_util import model_from_state
+
+    with pytest.raises(RemoraError):
+        model_from_state(O.state_from_npz(golden("model_conv_s64_l100_o2.npz")), dict(chunk_context=(50, 50)), device=0, dtype="f16")
+    with pytest.raises(RemoraError):
+        model_from_state(O.state_from_npz(golden("model_convlstm_s16_l100_o2.npz")), dict(chunk_context=(50, 50)), device=0, dtype="f16")
+    g = golden("model_convlstm_s64_l100_o2.npz")
+    model = model_from_state(O.state_from_npz(g), dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0, dtype="f16")
+    out = model.infer_chunks(g["sigs"], g["seqs"], g["maps"], g["lens"], (4, 4))
+    assert np.abs(out - g["logits"]).max() <= 4e-3
+    with pytest.raises(RemoraError, match="fused kernels only"):
+        model(torch_cuda.from_numpy(g["sigs"][:8]).cuda(), torch_cuda.from_numpy(g["dense_seqs"]).cuda())

@@ -469,16 +469,19 @@ def test_errors_surface_as_remora_error(torch_cuda):
 
 
 # ---- bf16-MFMA modes (split operands): own tolerances ---------------------------------------------
-# bf16x6 is fp32-class (as close to a float64 evaluation as the fp32-MFMA path, tests/manual/precision_vs_float64.py);
-# bf16x3 and bf16 are reduced-precision modes with their own tolerances
-SPLIT_TOL = {"bf16x6": 1e-4, "bf16x3": 5e-4, "bf16": 3e-2}
+# bf16x6 is fp32-class (as close to a float64 evaluation as the fp32-MFMA path, tests/manual/precision_vs_float64.py) and
+# holds the fp32 gate of 1e-4; bf16x3 (two-part operands, ~2^-16 relative) is a 5e-4 mode: 1.4e-4 measured on 8192
+# synthetic chunks, 1.8e-4 over 1 M - it does NOT meet 1e-4 and does not claim to; plain bf16 and f16 are the 16-bit
+# pipelines, gated in tests/test_gpu_fused.py against the float64 network and the emulated 16-bit arithmetic
+SPLIT_TOL = {"bf16x6": 1e-4, "bf16x3": 5e-4, "bf16": 3e-2, "f16": 4e-3}
 
 
-@pytest.mark.parametrize("dtype", ["bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["bf16x6", "bf16x3", "bf16", "f16"])
 @pytest.mark.parametrize("name", ["convlstm_s64_l100_o2", "convlstm_s64_l200_o3", "convlstm_s64_l100_k23"])
 def test_split_bf16_logits_golden(torch_cuda, O, name, dtype):
-    """bf16x6 / bf16x3 must still meet the fp32 gate (<= 1e-4); plain bf16 has its own tolerance
-    plus an argmax-agreement requirement on clearly separated chunks."""
+    """The reference-generated logits under every reduced-precision mode: bf16x6 within the fp32 gate (1e-4), bf16x3
+    within 5e-4, plain bf16 within 3e-2 and f16 within 4e-3 on these 24-48 chunks, each with argmax agreement on the chunks
+    whose margin exceeds four tolerances."""
     from remora_amd.model_util import model_from_state
 
     g = golden(f"model_{name}.npz")

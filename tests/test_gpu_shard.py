@@ -45,8 +45,7 @@ def _mint(tmp_path, g):
 def test_infer_cli_two_ranks_equal_one_rank(tmp_path, prefix, anchored):
     from remora_amd import io as rio
 
-    g = dict(golden("real_reads_can.npz"))
-    pt = _mint(tmp_path, g)
+    pt = _mint(tmp_path, golden("real_reads_can.npz"))  # the CG 5mC model that calls both halves of configs[0]
     args = ["infer", "from_pod5_and_bam", os.path.join(DATA, f"{prefix}_reads.pod5"), os.path.join(DATA, f"{prefix}_mappings.bam"),
             "--model", pt, "--reads-per-batch", "3"] + (["--reference-anchored"] if anchored else [])
     one, two = str(tmp_path / "one.bam"), str(tmp_path / "two.bam")
