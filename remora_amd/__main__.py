@@ -24,7 +24,7 @@ def _validate(args):
 
     from . import dist as rdist
 
-    rank, world, dev = rdist.setup_ranks(args.gpus)
+    rank, world, dev = rdist.setup_ranks(args.gpus, args.procs_per_gpu)
     model, md = load_torchscript_model(args.model, device=args.device if dev is None else dev, eval_only=True, dtype=args.dtype)
     over = {"extra_arrays": {}, "kmer_context_bases": md["kmer_context_bases"], "chunk_context": md["chunk_context"]}
     paths, props, hashes = load_dataset(args.remora_dataset_path)
@@ -93,20 +93,28 @@ def _infer(args):
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model
 
-    rank, world, dev = rdist.setup_ranks(args.gpus)
+    rank, world, dev = rdist.setup_ranks(args.gpus, args.procs_per_gpu)
     loaded = [load_torchscript_model(m, device=args.device if dev is None else dev, eval_only=True, dtype=args.dtype)
               for m in args.model]
     model, md = [x[0] for x in loaded], [x[1] for x in loaded]
     if len({m["can_base"] for m in md}) != len(md):
         raise RemoraError("Only one model per canonical base allowed.")
+    import time
+
     label_counts = {}
+    rdist.barrier()  # every rank has its model: the clock below covers the file-to-file work, not interpreter start-up
+    t0 = time.perf_counter()
     stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
                                     reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored,
                                     rank=rank, world=world, label_counts_out=label_counts)
+    dt = time.perf_counter() - t0
     if rank != 0:
         return 0
     ok = stats.pop(None, 0)
-    print(f"called {ok} reads -> {args.out_bam}" + (f" ({world} GPUs)" if world > 1 else ""))
+    nrec = ok + sum(stats.values())
+    print(f"{nrec} records in {dt:.2f} s = {nrec / max(dt, 1e-9):.0f} reads/s (models loaded; parts joined)", file=sys.stderr)
+    print(f"called {ok} reads -> {args.out_bam}" + (f" ({args.gpus} GPUs" + (f" x {args.procs_per_gpu} processes" if args.procs_per_gpu > 1 else "") + ")"
+                                                  if world > 1 else ""))
     for reason, cnt in sorted(stats.items(), key=lambda kv: -kv[1]):
         print(f"{cnt:>7} : {reason}")
     for m in md:
@@ -129,6 +137,9 @@ def main(argv=None):
     p.add_argument("--gpus", type=int, default=1,
                    help="one process per GPU, each takes a contiguous share of the alignments (ranks are started here unless "
                         "already under torchrun); the parts are joined into --out-bam in input order")
+    p.add_argument("--procs-per-gpu", type=int, default=1,
+                   help="processes per GPU: the host side (BAM / POD5 parsing, per-read arithmetic, MM/ML formatting, BGZF) is "
+                        "Python and scales with processes; each takes its own contiguous share of the alignments")
     p.add_argument("--num-reads", type=int, default=None)
     p.add_argument("--reads-per-batch", type=int, default=256)
     p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")
@@ -146,6 +157,7 @@ def main(argv=None):
     v.add_argument("--device", type=int, default=0)
     v.add_argument("--gpus", type=int, default=1,
                    help="one process per GPU, each validates a contiguous share of the rows; confusion counts are all-reduced")
+    v.add_argument("--procs-per-gpu", type=int, default=1)
     v.add_argument("--batch-size", type=int, default=131072)
     v.add_argument("--dtype", default=None)
     v.set_defaults(func=_validate)
@@ -183,10 +195,11 @@ def main(argv=None):
     d.set_defaults(func=_dataset_prepare)
 
     args = ap.parse_args(argv)
-    if getattr(args, "gpus", 1) > 1 and "WORLD_SIZE" not in os.environ:
+    nranks = getattr(args, "gpus", 1) * max(getattr(args, "procs_per_gpu", 1), 1)
+    if nranks > 1 and "WORLD_SIZE" not in os.environ:
         from .dist import launch_ranks
 
-        return launch_ranks(sys.argv[1:] if argv is None else list(argv), args.gpus)
+        return launch_ranks(sys.argv[1:] if argv is None else list(argv), nranks)
     try:
         return args.func(args)
     except RemoraError as e:

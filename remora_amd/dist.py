@@ -99,22 +99,32 @@ def launch_ranks(argv, n):
     return subprocess.call(cmd, env=env)
 
 
-def setup_ranks(gpus, backend=None, timeout_s=600.0):
-    """(rank, world, device) of this process for a `--gpus N` command line: (0, 1, None) for one GPU; under a launcher the
-    process group is created (RCCL unless `backend` / REMORA_AMD_DIST_BACKEND says gloo) and the device is LOCAL_RANK
-    (REMORA_AMD_FORCE_DEVICE pins every rank to one GPU: tests on a 1-GPU box).  A world that differs from `gpus` is an
-    error, never a silently smaller run."""
+def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):
+    """(rank, world, device) of this process for a `--gpus N [--procs-per-gpu P]` command line: (0, 1, None) for a single
+    process; under a launcher the process group is created and the device is LOCAL_RANK // P.  P > 1 puts several
+    processes on each GPU - the host side of a file-to-file run (record parsing, per-read arithmetic, tag formatting,
+    BGZF) is Python and scales with processes, as the reference's reader / prepare workers do
+    (src/remora/inference.py:488-572); their kernels share the GPU.  Transport of the one small collective: RCCL when
+    every rank owns a GPU, gloo when GPUs are shared (RCCL refuses two ranks on one device) or when
+    REMORA_AMD_DIST_BACKEND / `backend` says so.  REMORA_AMD_FORCE_DEVICE pins every rank to one GPU (tests).  A world
+    that differs from gpus x P is an error, never a silently smaller run."""
     rank, world, local = env_rank_world()
-    if int(gpus) <= 1 and world <= 1:
+    gpus, procs_per_gpu = int(gpus), max(int(procs_per_gpu), 1)
+    if gpus * procs_per_gpu <= 1 and world <= 1:
         return 0, 1, None
-    if world != int(gpus):
+    if world != gpus * procs_per_gpu:
         from . import RemoraError
 
-        raise RemoraError(f"--gpus {gpus} but the launcher started WORLD_SIZE={world} rank(s)")
-    backend = backend or os.environ.get("REMORA_AMD_DIST_BACKEND") or None
+        raise RemoraError(f"--gpus {gpus} x --procs-per-gpu {procs_per_gpu} but the launcher started WORLD_SIZE={world} rank(s)")
     forced = os.environ.get("REMORA_AMD_FORCE_DEVICE")
-    init_process_group(backend, set_device=forced is None, timeout_s=timeout_s)
-    return rank, world, (int(forced) if forced is not None else local)
+    backend = backend or os.environ.get("REMORA_AMD_DIST_BACKEND") or ("gloo" if procs_per_gpu > 1 or forced is not None else None)
+    device = int(forced) if forced is not None else local // procs_per_gpu
+    if backend != "gloo":
+        import torch
+
+        torch.cuda.set_device(device)
+    init_process_group(backend, set_device=False, timeout_s=timeout_s)
+    return rank, world, device
 
 
 def barrier():

@@ -249,12 +249,22 @@ torch.distributed.destroy_process_group()
 '''
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def test_count_allreduce_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29731", str(script), ROOT]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script), ROOT]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -1712,7 +1722,7 @@ objs = rdist.gather_objects({"rank": rank, None: rank + 1})
 arr = rdist.gather_arrays(np.arange(rank + 2, dtype=np.int64)[:, None] * np.ones((1, 2), np.int64))
 ok = ok and [o["rank"] for o in objs] == [0, 1] and arr.shape == (5, 2) and arr[:, 0].tolist() == [0, 1, 0, 1, 2]
 rdist.barrier()
-print(json.dumps({"rank": rank, "ok": bool(ok), "acc": float(ms.acc), "conf": ms.conf_mat.tolist()}))
+os.write(1, (json.dumps({"rank": rank, "ok": bool(ok), "acc": float(ms.acc), "conf": ms.conf_mat.tolist()}) + "\n").encode())  # one atomic write per rank
 torch.distributed.destroy_process_group()
 '''
 
@@ -1724,10 +1734,10 @@ def test_sharded_validation_metrics_gloo_world2(tmp_path):
     script.write_text(_SHARD_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29741", str(script), ROOT]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script), ROOT]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = [json.loads(l) for l in out.stdout.replace("}{", "}\n{").splitlines() if l.startswith("{")]
     assert len(lines) == 2 and all(l["ok"] for l in lines), lines
     assert lines[0]["conf"] == lines[1]["conf"] and lines[0]["acc"] == lines[1]["acc"]
 
