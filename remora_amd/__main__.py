@@ -106,7 +106,7 @@ def _infer(args):
     t0 = time.perf_counter()
     stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
                                     reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored,
-                                    rank=rank, world=world, label_counts_out=label_counts)
+                                    rank=rank, world=world, label_counts_out=label_counts, bam_level=args.bam_level)
     dt = time.perf_counter() - t0
     if rank != 0:
         return 0
@@ -140,6 +140,7 @@ def main(argv=None):
     p.add_argument("--procs-per-gpu", type=int, default=1,
                    help="processes per GPU: the host side (BAM / POD5 parsing, per-read arithmetic, MM/ML formatting, BGZF) is "
                         "Python and scales with processes; each takes its own contiguous share of the alignments")
+    p.add_argument("--bam-level", type=int, default=None, help="zlib level of the output BAM (default 6, as htslib; 1 = fast)")
     p.add_argument("--num-reads", type=int, default=None)
     p.add_argument("--reads-per-batch", type=int, default=256)
     p.add_argument("--dtype", default=None, help="fp32 (default) | bf16x6 | bf16x3 | bf16")

@@ -470,8 +470,9 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         if (p != end) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM tag region");
         // SAM spec 4.2.2: a CIGAR that does not fit the 16-bit count is stored in CG and the record carries the
         // placeholder <l_seq>S<ref_len>N (htslib / pysam resolve this transparently)
-        if (cg && cg_n > 0 && n_cig == 2 && (b->cigar[cig0] & 0xF) == 4 && (int64_t)(b->cigar[cig0] >> 4) == l_seq &&
-            (b->cigar[cig0 + 1] & 0xF) == 3) {
+        // (htslib's bam_tag2cigar looks at the first operation only, on mapped records)
+        if (cg && cg_n > 0 && n_cig >= 1 && ref_id >= 0 && pos >= 0 && (b->cigar[cig0] & 0xF) == 4 &&
+            (int64_t)(b->cigar[cig0] >> 4) == l_seq) {
             b->cigar.resize(cig0);
             for (int64_t k = 0; k < cg_n; ++k) b->cigar.push_back(rd_u32(cg + 4 * k));  // n_cigar keeps the record's own count (byte offsets)
         }

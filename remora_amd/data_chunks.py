@@ -149,16 +149,19 @@ def _pinned_bytes(count, slot=0):
 
 
 def device_to_numpy(t):
-    """`t.cpu().numpy()` through a pinned host tensor (torch caches pinned blocks): a pageable destination makes the
-    runtime bounce a large copy through its own small staging buffers (about 3 GB/s; pinned: PCIe rate).  The array
-    owns its pinned block until it is dropped."""
+    """`t.cpu().numpy()` through this thread's pinned staging buffer: a pageable destination makes the runtime bounce a
+    large copy through its own small staging buffers (about 3 GB/s; pinned: PCIe rate).  The result is an ordinary
+    pageable array (one host memcpy out of the staging buffer): callers keep per-read slices of it for as long as they
+    like without holding page-locked memory, which is neither swappable nor ever trimmed by torch's host allocator."""
     torch = _torch()
-    if not t.is_cuda or t.numel() * t.element_size() < (1 << 20):
+    nbytes = t.numel() * t.element_size()
+    if not t.is_cuda or nbytes < (1 << 20):
         return t.cpu().numpy()
-    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    t = t.contiguous()
+    host = _pinned_bytes(nbytes, slot=3)[:nbytes].view(t.dtype).view(t.shape)
     host.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
-    return host.numpy()
+    return host.numpy().copy()
 
 
 def _pinned_slot_async():

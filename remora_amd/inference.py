@@ -123,14 +123,22 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
     key = prep.device
     with _PIPE_LOCK:
         if key not in _PIPE:
-            _PIPE[key] = dict(streams=[torch.cuda.Stream(device=tdev) for _ in range(3)],
+            streams = [torch.cuda.Stream(device=tdev) for _ in range(3)]
+            # the worker streams are handed out through ONE queue per GPU: two generators alive at once (two threads in
+            # call_reads_mods, interleaved iter_call_reads_mods iterators) share the two worker threads, and whichever
+            # worker runs takes a stream nobody else holds; the single stager thread serialises their uploads
+            fs = queue.SimpleQueue()
+            for st in streams[1:]:
+                fs.put(st)
+            _PIPE[key] = dict(streams=streams, free_streams=fs,
                               stager=ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmr-stage"),
                               workers=ThreadPoolExecutor(max_workers=2, thread_name_prefix="rmr-work"))
+            import atexit
+
+            atexit.register(lambda p=_PIPE[key]: (p["stager"].shutdown(wait=False), p["workers"].shutdown(wait=False)))
         pipe = _PIPE[key]
     upload = pipe["streams"][0]
-    free_streams = queue.SimpleQueue()
-    for st in pipe["streams"][1:]:
-        free_streams.put(st)
+    free_streams = pipe["free_streams"]
 
     def stage(part):
         slots.acquire()
@@ -242,7 +250,7 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
 
 def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
                             reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False, prefetch=2,
-                            rank=0, world=1, label_counts_out=None):
+                            rank=0, world=1, label_counts_out=None, bam_level=None):
     """`remora infer from_pod5_and_bam` for one model or a list of models (one per canonical base, with a list of
     metadata dicts), basecall-anchored by default or reference-anchored
     (`--reference-anchored`: calls at reference positions, output records rewritten to `<len>M` + reference
@@ -258,7 +266,9 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     header), and after a barrier rank 0 joins the parts in rank order — the records keep the input order.  The per-label
     call counts go through the ONE collective of the path (dist.allreduce_counts: RCCL all-reduce of int64[num_out]);
     the per-reason read counts are summed over the ranks; every rank returns the global numbers.  `num_reads` then
-    limits each rank's share.  `label_counts_out` (a dict) receives {can_base: int64[num_out] calls per label}."""
+    limits each rank's share.  `label_counts_out` (a dict) receives {can_base: int64[num_out] calls per label}.
+    `bam_level`: zlib level of the output's BGZF members (None = 6, htslib's default; 1 costs a third of the CPU time for
+    ~10 % larger files - deflate is the largest single host cost of a file-to-file run)."""
     from collections import Counter
 
     from . import dist as rdist
@@ -279,7 +289,12 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     if len(models) != len(mds):
         raise RemoraError("one metadata dict per model is required")
 
+    import time as _time
+
+    clock = {"prep": 0.0, "gpu": 0.0, "tags_write": 0.0, "wait_ingest": 0.0, "ingest": 0.0, "close": 0.0}  # RMR_INFER_TIMING=1 prints it
+
     def flush(batch, writer):
+        tq = _time.perf_counter()
         good = []
         for io_read, err in batch:
             if err is None:
@@ -295,9 +310,14 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         # one pass per model (the reference runs one model per canonical base, src/remora/inference.py:277-316);
         # every model works on its own copy of the reads because refinement rewrites their mappings
         per_model = []
+        tg = _time.perf_counter()
+        clock["prep"] += tg - tq
         for mdl, md in zip(models, mds):
             reads = [rr.copy() for _, rr in good] if len(models) > 1 else [rr for _, rr in good]
             per_model.append(call_reads_mods(reads, mdl, md, return_mod_probs=True))
+        tw = _time.perf_counter()
+        clock["gpu"] += tw - tg
+        clock["tags_write"] -= tw
         for k, (io_read, rr) in enumerate(good):
             import array
 
@@ -323,6 +343,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             if ref_anchored:
                 fwd = io_read.ref_seq if io_read.ref_reg.strand == "+" else rio.revcomp(io_read.ref_seq)
             writer.write(rio.record_with_mod_tags(io_read.record, "".join(mm_all), ml_all, ref_anchored_seq=fwd))
+        clock["tags_write"] += _time.perf_counter()
 
     label_counts = [np.zeros(len(md["mod_bases"]) + 1, np.int64) for md in mds]
 
@@ -350,7 +371,9 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     def produce():
         try:
+            ti = _time.perf_counter()
             for b in batches():
+                clock["ingest"] += _time.perf_counter() - ti
                 while not stop.is_set():
                     try:
                         q.put(b, timeout=0.1)
@@ -359,6 +382,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                         continue
                 if stop.is_set():
                     return
+                ti = _time.perf_counter()
             q.put(None)
         except BaseException as e:  # noqa: BLE001 - handed to the consumer
             q.put(e)
@@ -366,16 +390,24 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     t = threading.Thread(target=produce, daemon=True)
     t.start()
     try:
-        with rio.BamWriter(part_path, header if rank == 0 else b"", eof=world == 1) as writer:
+        with rio.BamWriter(part_path, header if rank == 0 else b"", eof=world == 1, level=bam_level) as writer:
             while True:
+                tq0 = _time.perf_counter()
                 b = q.get()
+                clock["wait_ingest"] += _time.perf_counter() - tq0
                 if b is None:
                     break
                 if isinstance(b, BaseException):
                     raise b
                 flush(b, writer)
+            tc = _time.perf_counter()
+        clock["close"] = _time.perf_counter() - tc
     finally:
         stop.set()
+    if os.environ.get("RMR_INFER_TIMING"):
+        import sys as _sys
+
+        print(f"[infer rank {rank}/{world}] " + " ".join(f"{k} {v:.2f}s" for k, v in clock.items()), file=_sys.stderr, flush=True)
     if world > 1:
         # every part is complete on disk; the ONE data collective: per-label call counts (int64[num_out] per model)
         flat = rdist.allreduce_counts(np.concatenate(label_counts))

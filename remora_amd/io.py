@@ -203,7 +203,9 @@ def _resolve_long_cigar(cig, l_seq, get_tags):
     """SAM spec 4.2.2: a CIGAR with more than 65535 operations lives in the CG:B,I tag and the record itself holds
     the placeholder <l_seq>S<ref_len>N; htslib (hence pysam, which the reference reads alignments with) resolves it
     when the record is read.  `cig`: uint32 operations as stored; returns the operations to use."""
-    if cig.size == 2 and (int(cig[0]) & 0xF) == 4 and (int(cig[0]) >> 4) == l_seq and (int(cig[1]) & 0xF) == 3:
+    # htslib's bam_tag2cigar: a mapped record whose FIRST operation is <l_seq>S carries the real CIGAR in CG (it does not
+    # look at the second operation)
+    if cig.size >= 1 and (int(cig[0]) & 0xF) == 4 and (int(cig[0]) >> 4) == l_seq:
         for k, v in get_tags():
             if k == "CG" and isinstance(v, array.array) and v.typecode == "I" and len(v):
                 return np.frombuffer(v.tobytes(), dtype="<u4")
@@ -232,7 +234,10 @@ class _NativeBamRecord(BamRecord):
     def _parse_all_tags(self):
         spans = []
         self._tags = _parse_tags(self.raw[self.tags_offset :], spans)
-        self._tag_spans = spans
+        self._tag_spans = spans  # byte spans of ALL stored tags (records are re-emitted as stored)
+        if self._cigar is not None and len(self._cigar) != self._n_cigar:
+            # the long CIGAR was taken from CG: htslib removes the tag when it does that, so pysam callers never see it
+            self._tags = [(k, v) for k, v in self._tags if k != "CG"]
 
     @property
     def tags(self):
@@ -303,6 +308,9 @@ def bam_shard(bam_path, rank, world, every=64):
 
     if world <= 1:
         return None, None
+    import time
+
+    t_scan = time.perf_counter()
     lib = L.lib()
     cap = 1 << 16
     while True:  # rmr_bam_open leaves the handle at the first record
@@ -318,6 +326,10 @@ def bam_shard(bam_path, rank, world, every=64):
         if n_marks <= cap:
             break
         cap = int(n_marks)  # more marks than the first guess: scan again with room for all of them
+    if os.environ.get("RMR_INFER_TIMING"):
+        import sys
+
+        print(f"[bam_shard rank {rank}/{world}] scan of {n.value} records: {time.perf_counter() - t_scan:.2f}s", file=sys.stderr, flush=True)
     m0, m1 = shard_range(n_marks, rank, world)
     if m1 <= m0:
         return None, 0
@@ -413,6 +425,7 @@ class ReadIndexedBam:
         self.num_reads = self.num_records = None
         self._bam_idx = None
         self._handle = None
+        self._handle_pid = None
         self._lock = threading.Lock()
         self.compute_read_index()
 
@@ -447,25 +460,27 @@ class ReadIndexedBam:
         self.num_reads = len(self._bam_idx)
 
     def get_alignments(self, read_id, want_ref=True):
+        """Generator over the alignments of `read_id` (src/remora/io.py:303-325): errors surface on the first `next`,
+        as with the reference's generator."""
         if self._bam_idx is None:
             raise RemoraError("Bam index not yet computed")
         try:
             offsets = self._bam_idx[read_id]
         except KeyError:
             raise RemoraError(f"Could not find {read_id} in {self.bam_path}")
-        # one native handle for the lifetime of the index (the reference keeps its pysam handle open the same way):
-        # a seek + one record per offset instead of a header parse and an inflate pool per look-up
+        # one native handle per process for the lifetime of the index (the reference keeps its pysam handle open the
+        # same way): a seek + one record per offset instead of a header parse and an inflate pool per look-up.  A
+        # handle inherited through fork() shares its file offset with the parent: a child re-opens on first use.
         lib = L.lib()
-        with self._lock:
-            if self._handle is None:
-                h = ctypes.c_void_p()
-                L.check(lib.rmr_bam_open(str(self.bam_path).encode(), ctypes.byref(h)))
-                self._handle = h
-            recs = []
-            for vo in offsets:
+        for vo in offsets:
+            with self._lock:  # one record per lock hold: other threads' look-ups interleave between the records
+                if self._handle is None or self._handle_pid != os.getpid():
+                    h = ctypes.c_void_p()
+                    L.check(lib.rmr_bam_open(str(self.bam_path).encode(), ctypes.byref(h)))
+                    self._handle, self._handle_pid = h, os.getpid()
                 L.check(lib.rmr_bam_seek(self._handle, int(vo)))
-                recs.extend(_native_batches(lib, self._handle, want_ref, 1, once=True))
-        return iter(recs)
+                recs = list(_native_batches(lib, self._handle, want_ref, 1, once=True))
+            yield from recs
 
     def get_first_alignment(self, read_id):
         return next(self.get_alignments(read_id))
@@ -473,7 +488,8 @@ class ReadIndexedBam:
     def close(self):
         with self._lock:
             if self._handle is not None:
-                L.lib().rmr_bam_close(self._handle)
+                if self._handle_pid == os.getpid():  # a forked child does not close (or free) the parent's handle
+                    L.lib().rmr_bam_close(self._handle)
                 self._handle = None
 
     def __del__(self):
@@ -583,7 +599,10 @@ def _iter_bam_records_py(bam_path):
             qual = bytes(rec[q : q + l_seq]); q += l_seq
             spans = []
             tags = _parse_tags(rec[q:], spans)
-            cig = _resolve_long_cigar(cig, l_seq, lambda: tags)
+            stored = cig
+            cig = _resolve_long_cigar(cig, l_seq, lambda: tags) if ref_id >= 0 and pos >= 0 else cig
+            if cig is not stored:  # resolved from CG: the tag disappears from the exposed list (htslib deletes it)
+                tags = [(k, v) for k, v in tags if k != "CG"]
             cigartuples = list(zip((cig & 0xF).tolist(), (cig >> 4).tolist()))
             yield BamRecord(name, flag, ref_id, refs[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq,
                             qual, tags, bytes(rec), q, spans)
@@ -656,7 +675,7 @@ def vbz_decode_batch(blobs, n_samples, engine=None, to_host=True):
     out_off = np.zeros(n + 1, np.int64)
     np.cumsum(np.asarray(n_samples, np.int64), out=out_off[1:])
     buf = np.zeros(int(row_off[-1]) + 16, np.uint8)  # the kernel reads whole dwords: a little slack at the end
-    L.check(L.lib().rmr_zstd_rows(src, p(src_len), n, p(buf), p(row_off), min(8, os.cpu_count() or 1)))
+    L.check(L.lib().rmr_zstd_rows(src, p(src_len), n, p(buf), p(row_off), min(8, _eff_cpus())))
     rn = np.ascontiguousarray(n_samples, np.int32)
     if to_host:
         out = np.empty(int(out_off[-1]), np.int16)
@@ -1206,9 +1225,15 @@ def record_with_mod_tags(rec, mm_tag, ml_tag, ref_anchored_seq=None):
 _BGZF_LEVEL = int(os.environ.get("RMR_BAM_LEVEL", "6"))  # htslib's default level
 
 
-def _bgzf_block(chunk):
+def _eff_cpus():
+    from .util import effective_cpu_count
+
+    return effective_cpu_count()
+
+
+def _bgzf_block(chunk, level=None):
     """One BGZF member (gzip with the BC extra field) for up to 64 KiB of payload."""
-    comp = zlib.compressobj(_BGZF_LEVEL, zlib.DEFLATED, -15)
+    comp = zlib.compressobj(_BGZF_LEVEL if level is None else int(level), zlib.DEFLATED, -15)
     cdata = comp.compress(chunk) + comp.flush()
     return b"".join((b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00", struct.pack("<H", len(cdata) + 25),
                      cdata, struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))))
@@ -1219,7 +1244,7 @@ class BamWriter:
     by a small thread pool (zlib releases the GIL) and written in order, so compression - ~1 ms per 5 kb read with
     its move table - runs beside the caller instead of in it; the file is the same as with inline compression."""
 
-    def __init__(self, path, header_bytes, threads=None, max_pending=None, eof=True):
+    def __init__(self, path, header_bytes, threads=None, max_pending=None, eof=True, level=None):
         """`header_bytes` = everything before the first record (b"" for a part file that holds records only);
         `eof=False` leaves the end-of-file marker out — part files of a multi-GPU run are whole BGZF members and are
         joined byte for byte by `concat_bam_parts`."""
@@ -1229,12 +1254,18 @@ class BamWriter:
         # deflate at level 6 runs at ~35 MB/s per thread and a 5 kb read with its move table is ~25 KB of BAM: four
         # threads cap the writer at ~5 k reads/s, which the batched GPU path exceeds tenfold
         if threads is None:
-            threads = int(os.environ.get("RMR_BAM_THREADS", "0")) or min(16, max(4, (os.cpu_count() or 8) // 4))
+            from .util import effective_cpu_count
+
+            # the cores this process may really use (cgroup quota, not os.cpu_count()), shared with the other ranks of
+            # the node when several processes run side by side
+            local_ranks = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1), 1)
+            threads = int(os.environ.get("RMR_BAM_THREADS", "0")) or min(16, max(2, effective_cpu_count() // (2 * local_ranks)))
         if max_pending is None:
             max_pending = 8 * int(threads)
 
         self._fh = open(path, "wb")
         self._eof = bool(eof)
+        self._level = level  # zlib level of the BGZF members (None = RMR_BAM_LEVEL, default 6 = htslib's)
         self._buf = bytearray(header_bytes)
         self._pool = ThreadPoolExecutor(max_workers=max(int(threads), 1))
         self._pending, self._max_pending = deque(), int(max_pending)
@@ -1244,7 +1275,7 @@ class BamWriter:
             self._fh.write(self._pending.popleft().result())
 
     def _flush_block(self, chunk):
-        self._pending.append(self._pool.submit(_bgzf_block, bytes(chunk)))
+        self._pending.append(self._pool.submit(_bgzf_block, bytes(chunk), self._level))
         self._drain(self._max_pending)
 
     def write(self, record_bytes):

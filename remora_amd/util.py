@@ -262,3 +262,30 @@ def prepare_out_dir(out_dir, overwrite):
             raise RemoraError("Refusing to overwrite existing directory.")
         shutil.rmtree(out_dir) if os.path.isdir(out_dir) else os.remove(out_dir)
     os.makedirs(out_dir, exist_ok=True)
+
+
+def effective_cpu_count():
+    """Cores this process may actually use: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU
+    quota (containers commonly show every host core in os.cpu_count() while cpu.max grants a fraction: thread pools sized
+    by the former thrash).  At least 1."""
+    import math
+    import os
+
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(int(n), 1)

@@ -28,6 +28,7 @@ from remora_amd import io as rio  # noqa: E402
 REP = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 PROCS = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8,16").split(",")]
 DT = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+LEVEL = sys.argv[4] if len(sys.argv) > 4 else "6"
 data = os.path.join(ROOT, "tests", "golden", "data")
 pod5, bam = os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam")
 tmp = tempfile.mkdtemp()
@@ -48,8 +49,10 @@ for p in PROCS:
     out = os.path.join(tmp, f"out{p}.bam")
     t = time.perf_counter()
     r = subprocess.run([sys.executable, "-m", "remora_amd", "infer", "from_pod5_and_bam", pod5, big, "--model", pt, "--out-bam", out,
-                        "--dtype", DT, "--procs-per-gpu", str(p), "--reads-per-batch", "512"], cwd=ROOT, capture_output=True, text=True)
+                        "--dtype", DT, "--procs-per-gpu", str(p), "--reads-per-batch", "512", "--bam-level", LEVEL], cwd=ROOT, capture_output=True, text=True)
     wall = time.perf_counter() - t
+    if os.environ.get("RMR_INFER_TIMING"):
+        print("\n".join(ln for ln in r.stderr.splitlines() if ln.startswith("[")), flush=True)
     m = re.search(r"= (\d+) reads/s", r.stderr)
     res[p] = {"reads_per_s_excl_startup": int(m.group(1)) if m else None, "wall_s": wall, "rc": r.returncode}
     print(f"procs/gpu {p:3d}: {res[p]['reads_per_s_excl_startup']} reads/s (work only), {n / wall:.0f} reads/s incl. start-up ({wall:.1f} s)"
@@ -61,4 +64,4 @@ for p in PROCS:
         import gzip
         same = gzip.decompress(a) == gzip.decompress(b)
         print(f"              output identical to procs/gpu {PROCS[0]}: {same}", flush=True)
-print("RESULT " + json.dumps({"records": n, "dtype": DT, "by_procs": res}))
+print("RESULT " + json.dumps({"records": n, "dtype": DT, "bam_level": LEVEL, "by_procs": res}))

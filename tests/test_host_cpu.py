@@ -1352,13 +1352,19 @@ def test_bam_long_cigar_in_cg_tag(tmp_path):
     cg = b"CGBI" + struct.pack("<i", len(real)) + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in real)
     md = b"MDZ3^G4\x00"
     _tiny_bam(tmp_path / "cg.bam", [("ultra", 0, "ACGTTACA", [(4, 8), (3, 8)], [md, cg]),
-                                    ("plain", 0, "ACGT", [(4, 4), (3, 9)], [])])
+                                    ("plain", 0, "ACGT", [(4, 4), (3, 9)], []),
+                                    ("odd", 0, "ACGTTACA", [(4, 8), (0, 1), (3, 7)], [md, cg])])
     for native in (True, False):
-        a, b = list(rio.iter_bam_records(str(tmp_path / "cg.bam"), want_ref=True, native=native))
+        a, b, c = list(rio.iter_bam_records(str(tmp_path / "cg.bam"), want_ref=True, native=native))
         assert a.cigartuples == real, native
         assert a.get_reference_sequence() == "ACGGTTCA", native  # I base (index 5, 'A') dropped, deleted G inserted
         assert b.cigartuples == [(4, 4), (3, 9)]  # no CG tag: the record's own CIGAR stands
         assert len(a.query_qualities) == 8
+        # htslib (bam_tag2cigar) only asks for a first operation of <l_seq>S on a mapped record, whatever follows
+        assert c.cigartuples == real, native
+        # ... and deletes CG once it has used it: pysam callers never see the tag; the stored bytes still hold it
+        assert "CG" not in dict(a.tags) and "CG" not in dict(c.tags) and "MD" in dict(a.tags), native
+        assert b"CGBI" in bytes(a.raw)
 
 
 def test_device_reads_refuse_dacs_that_int16_cannot_hold():
