@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     const int tiles_sig2 = (a.P2 + 15) >> 4, tiles_seq1 = (a.P1 + 15) >> 4;
     const int pairs_sig2 = (tiles_sig2 + 1) >> 1, pairs_seq1 = (tiles_seq1 + 1) >> 1;
     const int pairs_chunk = pairs_sig2 + pairs_seq1;
-    const FastDiv d_pc = FastDiv{pairs_chunk, 1.0f / (float)pairs_chunk};
+    const FastDiv d_ps2 = FastDiv{pairs_sig2, 1.0f / (float)pairs_sig2}, d_pq1 = FastDiv{pairs_seq1, 1.0f / (float)pairs_seq1};
     int nsearch = 1;  // bisection steps that cover maxlen + 1 mapping entries
     while ((1 << nsearch) < a.maxlen + 2) ++nsearch;
 
@@ -425,9 +425,15 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 const int k8 = 4 * s + q, tap = k8 / CG, cg = k8 - tap * CG;
                 oh_off[s] = cg * a.oh_plane + tap * 16;
             }
-            for (int item = w; item < (ABL(8) ? 0 : nch) * pairs_chunk; item += 4) {
-                const int ci = fdiv(item, d_pc), r = item - ci * pairs_chunk;
-                if (r < pairs_sig2) {
+            // the expensive items (seq_conv1 pairs: 14 MFMAs) first, striped over the waves, then the cheap ones (sig_conv2
+            // pairs: 2 MFMAs): every wave gets the same number of each (+-1).  Striping the chunk-major list instead gave
+            // waves 1 and 3 twice the seq_conv1 pairs of waves 0 and 2 (6 items per chunk against a stride of 4).
+            const int n_seq_items = (ABL(8) ? 0 : nch) * pairs_seq1, n_items = (ABL(8) ? 0 : nch) * pairs_chunk;
+            for (int item = w; item < n_items; item += 4) {
+                const bool is_sig = item >= n_seq_items;
+                const int j = is_sig ? item - n_seq_items : item;
+                const int ci = fdiv(j, is_sig ? d_ps2 : d_pq1), r = j - ci * (is_sig ? pairs_sig2 : pairs_seq1);
+                if (is_sig) {
                     int pos0 = 32 * r + nn, pos1 = pos0 + 16;
                     const bool v0 = pos0 < a.P2, v1 = pos1 < a.P2;
                     pos0 = v0 ? pos0 : a.P2 - 1;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                     if (v0) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos0) * 32 + 8 * q) = swish_pack<F16>(acc0, ABL(64));
                     if (v1) *reinterpret_cast<uint2 *>(s_sig2 + (size_t)(ci * a.P2 + pos1) * 32 + 8 * q) = swish_pack<F16>(acc1, ABL(64));
                 } else {
-                    int pos0 = 32 * (r - pairs_sig2) + nn, pos1 = pos0 + 16;
+                    int pos0 = 32 * r + nn, pos1 = pos0 + 16;
                     const bool v0 = pos0 < a.P1, v1 = pos1 < a.P1;
                     pos0 = v0 ? pos0 : a.P1 - 1;
                     pos1 = v1 ? pos1 : a.P1 - 1;
