@@ -45,9 +45,10 @@ struct ConvArgs {
 
 // one (TWO = false) or two 16-column tiles of the implicit GEMM: independent accumulator chains, B fragments fetched one
 // (tap, g) step ahead of the MFMAs that consume them, swish epilogue, 16-byte channel-last stores
-template <int IC, int KW, int STRIDE, bool TWO>
-__device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem, const float (&A)[KW * IC / 4], const f32x4 b4,
-                                           int64_t chunk0, int ncols, int tile, int w, int q, int nn) {
+// `store(chunk in the iteration, output position, swish(acc) as four consecutive output channels)` receives every valid column
+template <int IC, int KW, int STRIDE, bool TWO, typename Store>
+__device__ __forceinline__ void conv_tiles_to(const float *smem, int plane, int pin, int pout, FastDiv div_pout, const float (&A)[KW * IC / 4],
+                                              const f32x4 b4, int ncols, int tile, int q, int nn, Store store) {
     constexpr int G = IC / 16;
     constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;
     constexpr int NS = KW * G;
@@ -55,11 +56,11 @@ __device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem,
     const bool v0 = col0 < ncols, v1 = TWO && col1 < ncols;
     col0 = v0 ? col0 : ncols - 1;
     col1 = v1 ? col1 : ncols - 1;
-    const int ch0 = (int)(((float)col0 + 0.5f) * a.div_pout.inv);
-    const int ch1 = (int)(((float)col1 + 0.5f) * a.div_pout.inv);
-    const int p0 = col0 - ch0 * a.pout, p1 = col1 - ch1 * a.pout;
-    const float *r0 = smem + (size_t)q * a.plane + (size_t)(ch0 * a.pin + p0 * STRIDE) * RS;
-    const float *r1 = smem + (size_t)q * a.plane + (size_t)(ch1 * a.pin + p1 * STRIDE) * RS;
+    const int ch0 = (int)(((float)col0 + 0.5f) * div_pout.inv);
+    const int ch1 = (int)(((float)col1 + 0.5f) * div_pout.inv);
+    const int p0 = col0 - ch0 * pout, p1 = col1 - ch1 * pout;
+    const float *r0 = smem + (size_t)q * plane + (size_t)(ch0 * pin + p0 * STRIDE) * RS;
+    const float *r1 = smem + (size_t)q * plane + (size_t)(ch1 * pin + p1 * STRIDE) * RS;
     f32x4 acc0 = b4, acc1 = b4;
     f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0), x1 = x0;
     if (TWO) x1 = *reinterpret_cast<const f32x4 *>(r1);
@@ -90,17 +91,24 @@ __device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem,
     if (v0) {
         f32x2 lo = f32x2{acc0[0], acc0[1]}, hi = f32x2{acc0[2], acc0[3]};
         swish_pk(lo, hi);  // same operations as swish_f, the plain ones two values per instruction
-        const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
-        float *dst = a.out + ((size_t)(chunk0 + ch0) * a.pout + p0) * a.out_row + a.out_coff + 16 * w + 4 * q;
-        *reinterpret_cast<f32x4 *>(dst) = y;
+        store(ch0, p0, f32x4{lo.x, lo.y, hi.x, hi.y});
     }
     if (v1) {
         f32x2 lo = f32x2{acc1[0], acc1[1]}, hi = f32x2{acc1[2], acc1[3]};
         swish_pk(lo, hi);
-        const f32x4 y = {lo.x, lo.y, hi.x, hi.y};
-        float *dst = a.out + ((size_t)(chunk0 + ch1) * a.pout + p1) * a.out_row + a.out_coff + 16 * w + 4 * q;
-        *reinterpret_cast<f32x4 *>(dst) = y;
+        store(ch1, p1, f32x4{lo.x, lo.y, hi.x, hi.y});
     }
+}
+
+// the kernel below: columns leave as 16-byte channel-last stores to HBM
+template <int IC, int KW, int STRIDE, bool TWO>
+__device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem, const float (&A)[KW * IC / 4], const f32x4 b4,
+                                           int64_t chunk0, int ncols, int tile, int w, int q, int nn) {
+    conv_tiles_to<IC, KW, STRIDE, TWO>(smem, a.plane, a.pin, a.pout, a.div_pout, A, b4, ncols, tile, q, nn,
+                                       [&](int ch, int p, const f32x4 y) {
+                                           float *dst = a.out + ((size_t)(chunk0 + ch) * a.pout + p) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                                           *reinterpret_cast<f32x4 *>(dst) = y;
+                                       });
 }
 
 template <int IC, int KW, int STRIDE>
@@ -163,13 +171,40 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
                          float *out, int out_row, int out_coff, int pout, int64_t n) {
     constexpr int G = IC / 16;
     constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;
-    // chunks per iteration: fill <= 72 KB of LDS (2 blocks per CU) and give an even
-    // number of 16-column tiles where possible
+    // chunks per iteration.  How many blocks a CU holds is set by the instantiation's registers (512 per SIMD lane, granule
+    // 8: the 16-channel layers reach 3-4 waves per SIMD, merge_conv1's 160-register weight slice 2), so the LDS budget of a
+    // block is its share of the 160 KB at that occupancy, capped by RMR_CONV_LDS_BUDGET (72 KB: two blocks per CU).  Among the
+    // chunk counts that fit, the one whose columns fill their 16-column tiles best wins (Conv_w_ref's merge_conv1: 4 x 20
+    // columns = 5 tiles exactly, where 5 chunks would pad the 7th tile to 25 %); ties go to the larger count.
+    const int threads_pb = 64 * (c.oc / 16);
+    static int regs = 0;  // per instantiation; the same binary on every device
+    if (regs == 0) {
+        hipFuncAttributes attr;
+        regs = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(conv_mfma_kernel<IC, KW, STRIDE>)) == hipSuccess ? attr.numRegs : 256;
+        if (regs < 1) regs = 256;
+    }
+    int wps = 512 / ((regs + 7) & ~7);
+    wps = wps < 1 ? 1 : (wps > 8 ? 8 : wps);
+    int resident = wps * 4 / (threads_pb / 64);
+    resident = resident < 1 ? 1 : (resident > 8 ? 8 : resident);
     const size_t row_bytes = (size_t)pin * RS * 4 * sizeof(float);  // all four planes
-    int cb = (int)((size_t)tune_int("RMR_CONV_LDS_BUDGET", 73728) / (c.oc >= 64 ? 1 : 64 / c.oc) / row_bytes);
-    if (cb < 1) cb = 1;
-    if (cb > 8) cb = 8;
-    if (cb >= 4) cb &= ~3;  // multiples of 4 chunks -> cb*pout divisible by 4
+    size_t budget = (size_t)tune_int("RMR_CONV_LDS_BUDGET", 73728);
+    if (tune_int("RMR_CONV_OCCUPANCY_CB", 1)) {
+        const size_t share = (size_t)160 * 1024 / resident - 512;
+        if (share < budget) budget = share;
+    } else {
+        budget /= (c.oc >= 64 ? 1 : 64 / c.oc);
+    }
+    int cb_max = (int)(budget / row_bytes);
+    if (cb_max < 1) cb_max = 1;
+    if (cb_max > 8) cb_max = 8;
+    int cb = cb_max;
+    double best = -1.0;
+    for (int k = cb_max; k >= (cb_max + 1) / 2; --k) {
+        const int cols = k * pout;
+        const double eff = (double)cols / (16.0 * ((cols + 15) / 16));
+        if (eff > best + 1e-9) { best = eff; cb = k; }
+    }
     const int plane = ((cb * pin * RS) + 63) & ~63;
     const size_t lds = (size_t)plane * 4 * sizeof(float) + 64;  // + trash slot for masked staging writes
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "conv layer needs %zu B of LDS", lds);
@@ -178,8 +213,8 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     a.in_row = in_row; a.pin = pin; a.pout = pout; a.out_row = out_row; a.out_coff = out_coff;
     a.cb = cb; a.plane = plane; a.div_pout = make_fastdiv(pout);
     const int64_t iters = (n + cb - 1) / cb;
-    const int threads = 64 * (c.oc / 16);
-    // two 256-thread blocks per CU (or four 128-thread blocks for the 32-channel layer)
+    const int threads = threads_pb;
+    // persistent blocks: a grid of several times the resident count evens out the tail
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8) * (c.oc >= 64 ? 1 : 64 / c.oc);
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
@@ -190,6 +225,11 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     RMR_HIP(hipGetLastError());
     return 0;
 }
+
+// (A one-launch tail for Conv_w_ref - merge_conv3 -> merge_conv4 -> flatten + fc with both intermediates in LDS - was built
+//  on conv_tiles_to in round 3 and measured: bit-identical, 4.38 ns per chunk against 1.92 + 1.00 + 0.56 = 3.48 for the three
+//  launches.  Two weight slices cost 160 VGPRs (three waves per SIMD instead of four) and an iteration of 6-8 chunks has
+//  only 5 column tiles of work between its four barriers; removed.)
 
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                 float *out, int out_row, int out_coff, int pout, int64_t n) {

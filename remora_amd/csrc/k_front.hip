@@ -250,6 +250,111 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// sequence branch, two-level gather walked TAP BY TAP (Conv_w_ref's 11-tap seq_conv1).  The per-base table
+// U[p][tap][oc] of the two-level form costs (max_seq_len + 1) x KW x 64 B of LDS per chunk - 14.8 KB at KW = 11, which left
+// four waves per CU and made the kernel latency-bound, so round 1 shipped the DIRECT form for this shape: KW x K = 99
+// table gathers per output position, 35.6 k float4 gathers per chunk, LDS-bound at 9.5 ns per chunk (17 % of the
+// Conv_w_ref step).  Here the taps are the OUTER loop: for tap t a wave builds only U_t[p][oc] (max_seq_len x 64 B = 1.3 KB),
+// every lane adds U_t[p(pos + t)] to the accumulators of its output positions, and the buffer is reused for tap t + 1.
+// Same 12 k gathers per chunk as the two-level form, 3.4 KB of private LDS per wave, one wave per chunk, 16 waves per CU.
+// Sum order: over the K slots inside a (base, tap), then over the taps in ascending order - the order of
+// front_seq_kernel<KW, false>.
+// ---------------------------------------------------------------------------------------
+template <int KW, int K>
+__global__ __launch_bounds__(512, 4) void front_seq_tap_kernel(FrontSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MAXJ = 6;  // output items (position, channel quad) per lane: P1 * 4 <= 64 * MAXJ (Conv_w_ref: L = 100, P1 = 90)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6, quad = lane & 3;
+    float *s_wt = smem;  // [KW][K][5][16]
+    constexpr int wt_words = KW * K * 80;
+    float *cbase = smem + wt_words + (size_t)w * a.per_chunk;
+    int16_t *s_map = reinterpret_cast<int16_t *>(cbase + a.o_map);
+    int8_t *s_seq = reinterpret_cast<int8_t *>(cbase + a.o_seq);
+    unsigned *s_code = reinterpret_cast<unsigned *>(cbase + a.o_code);
+    int16_t *s_pidx = reinterpret_cast<int16_t *>(cbase + a.o_pidx);
+    float *s_ut = cbase + a.o_u;  // [(maxlen + 1)][16], row `maxlen` = zeros (positions no base owns)
+    static_assert(K <= 10, "base codes of a k-mer are packed 3 bits each into 32 bits");
+
+    for (int i = tid; i < wt_words; i += blockDim.x) s_wt[i] = a.wt5[i];
+    if (lane < 16) s_ut[(size_t)a.maxlen * 16 + lane] = 0.0f;
+    const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
+    __syncthreads();  // gather table visible to every wave
+
+    const int n_items = a.P1 * 4;  // (position, quad) pairs of a chunk; item i = lane + 64 j has quad = lane & 3
+    for (int64_t chunk = (int64_t)blockIdx.x * nw + w; chunk < a.n; chunk += (int64_t)gridDim.x * nw) {
+        int len = a.lens[chunk];
+        len = len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len);
+        wave_sync();  // the previous chunk's reads of the row buffers are done
+        {
+            const int16_t *mp = a.maps + (size_t)chunk * a.map_w;
+            for (int j = lane; j < a.map_w; j += 64) s_map[j] = mp[j];
+            const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
+            for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = sq[j];
+            for (int s = lane; s < a.L; s += 64) s_pidx[s] = (int16_t)a.maxlen;
+        }
+        wave_sync();
+        // base covering every signal position, written as runs (base p owns [map[p], map[p+1])): the gather form of the
+        // reference's scatter loops (src/remora/encoded_kmers.pyx:33-44); the K bases of a window as 3-bit codes, 4 = missing
+        for (int p = lane; p < len; p += 64) {
+            const int s0 = max((int)s_map[p], 0), s1 = min((int)s_map[p + 1], a.L);
+            for (int s = s0; s < s1; ++s) s_pidx[s] = (int16_t)p;
+            unsigned code = 0;
+#pragma unroll
+            for (int kp = 0; kp < K; ++kp) {
+                const int b = s_seq[p + kp];
+                code |= (unsigned)((b >= 0 && b < 4) ? b : 4) << (3 * kp);
+            }
+            s_code[p] = code;
+        }
+        wave_sync();
+        f32x2 lo[MAXJ], hi[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) { lo[j] = bq_lo; hi[j] = bq_hi; }
+        const int u_items = len * 4;  // (base, quad) pairs
+#pragma unroll 1
+        for (int t = 0; t < KW; ++t) {
+            const float *wt = s_wt + (size_t)t * K * 80 + 4 * quad;
+            for (int i = lane; i < u_items; i += 64) {  // i & 3 == quad
+                const int p = i >> 2;
+                const unsigned code = s_code[p];
+                float4 v[K];  // the K gathers of an item are all in flight before the first add
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) v[kp] = *reinterpret_cast<const float4 *>(wt + (kp * 5 + (int)((code >> (3 * kp)) & 7u)) * 16);
+                f32x2 ul = pk_splat(0.f), uh = pk_splat(0.f);
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    ul += f32x2{v[kp].x, v[kp].y};
+                    uh += f32x2{v[kp].z, v[kp].w};
+                }
+                *reinterpret_cast<float4 *>(s_ut + (size_t)p * 16 + 4 * quad) = make_float4(ul.x, ul.y, uh.x, uh.y);
+            }
+            wave_sync();  // U_t complete
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int i = lane + 64 * j;
+                if (i < n_items) {
+                    const int p = s_pidx[(i >> 2) + t];
+                    const float4 v = *reinterpret_cast<const float4 *>(s_ut + (size_t)p * 16 + 4 * quad);
+                    lo[j] += f32x2{v.x, v.y};
+                    hi[j] += f32x2{v.z, v.w};
+                }
+            }
+            wave_sync();  // U_t consumed: the buffer takes tap t + 1
+        }
+        float *dst = a.seq1 + (size_t)chunk * a.P1 * 16;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int i = lane + 64 * j;
+            if (i < n_items) {
+                swish_pk(lo[j], hi[j]);
+                *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = make_float4(lo[j].x, lo[j].y, hi[j].x, hi[j].y);
+            }
+        }
+    }
+}
+
 int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t *seqs, int seq_w,
                  const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka, int64_t n,
                  float *sig2, float *seq1) {
@@ -288,6 +393,30 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     a.o_seq = off; off += up4((seq_w + 3) / 4);
     a.o_code = off; off += up4(a.maxlen * 2);
     a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
+    // Conv_w_ref's released shape (11 taps, k-mer length 9): the tap-by-tap two-level kernel, one wave per chunk
+    if (kw == 11 && K == 9 && m->P1 * 4 <= 64 * 6 && a.maxlen <= 1024 && tune_int("RMR_FRONT_SEQ_TAP", 1) != 0) {
+        int off = 0;
+        a.o_map = off; off += up4((map_w * 2 + 3) / 4);
+        a.o_seq = off; off += up4((seq_w + 3) / 4);
+        a.o_code = off; off += up4(a.maxlen);
+        a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
+        a.o_u = off; off += (a.maxlen + 1) * 16;
+        a.per_chunk = up4(off);
+        a.cb = 1;
+        const int waves = 8;
+        const size_t lds = ((size_t)kw * K * 80 + (size_t)waves * a.per_chunk) * 4;
+        if (lds <= 80 * 1024) {  // two blocks (16 waves) per CU; longer rows fall through to the forms below
+            auto kern = front_seq_tap_kernel<11, 9>;
+            RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
+            int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SEQ_BLOCKS_PER_CU", 4);
+            const int64_t need = (n + waves - 1) / waves;
+            if (grid > need) grid = need;
+            ProfScope ps(e, K_FRONT_SEQ, st, true);
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
+            RMR_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     const bool direct = (kw == 11) && tune_int("RMR_FRONT_SEQ_DIRECT", 1) != 0;
     a.o_u = off; if (!direct) off += (a.maxlen + 1) * kw * 16;
     a.per_chunk = up4(off);
