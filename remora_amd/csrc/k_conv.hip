@@ -43,6 +43,11 @@ struct ConvArgs {
 };
 
 
+// Waves per SIMD the register allocator is held to.  Left alone it takes 136-152 registers for layers that fit 128 without a
+// spill (3 waves per SIMD instead of 4: merge_conv2 140, the 16-channel stride-3 layers 120-136); merge_conv1's 160-register
+// weight slice needs two-wave occupancy, Conv_w_ref's seq_conv3 (72-register slice + 8 x 16-byte staging loads) three.
+constexpr int conv_min_waves(int ic, int kw) { return kw * ic / 4 >= 160 ? 2 : (kw * ic / 4 >= 72 ? 3 : 4); }
+
 // one (TWO = false) or two 16-column tiles of the implicit GEMM: independent accumulator chains, B fragments fetched one
 // (tap, g) step ahead of the MFMAs that consume them, swish epilogue, 16-byte channel-last stores
 // `store(chunk in the iteration, output position, swish(acc) as four consecutive output channels)` receives every valid column
@@ -112,7 +117,7 @@ __device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem,
 }
 
 template <int IC, int KW, int STRIDE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, conv_min_waves(IC, KW)) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int G = IC / 16;        // 16-channel groups
     constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;  // floats per row per plane, RS/4 odd
