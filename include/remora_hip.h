@@ -185,6 +185,25 @@ int rmr_bam_seek(rmr_bam *b, int64_t voffset);
  * (src/remora/inference.py:488-519).  Leaves the handle at end of file: rmr_bam_seek before reading. */
 int rmr_bam_scan(rmr_bam *b, int64_t every, int64_t *voffsets, int64_t cap, int64_t *n_records);
 
+/* ---- N3: the output side of `remora infer` for a batch of reads (host code) ----------------------------- */
+/* replaces: util.format_mm_ml_tags (src/remora/util.py:485-537) as inference.post_process_reads calls it per read
+ * (src/remora/inference.py:429-459; flagged slow in the source, :55).  Read r has calls call_off[r] .. call_off[r+1]:
+ * pos[] = positions in its sequence seq[seq_off[r] .. seq_off[r+1]) (any order: sorted stably here), probs[call][n_mods]
+ * = probabilities of the modified bases.  mod_codes = n_mods NUL-terminated short names one after the other ("m\0h\0",
+ * ChEBI codes allowed).  Per read and modified base: "<can_base><strand><code>?,<gaps>;" appended to mm (gaps = canonical
+ * bases skipped between consecutive calls) and floor(p * 256) clipped to 255 appended to ml (all calls of base 0, then of
+ * base 1, ...); mm_off / ml_off [n_reads + 1] delimit the reads' slices; a read without calls gets empty slices. */
+int rmr_format_mm_ml(int64_t n_reads, const char *seq, const int64_t *seq_off, const int64_t *pos, const double *probs,
+                     const int64_t *call_off, int n_mods, const char *mod_codes, char can_base, char strand, char *mm,
+                     int64_t mm_cap, int64_t *mm_off, uint8_t *ml, int64_t ml_cap, int64_t *ml_off);
+/* replaces: pysam.AlignedSegment.from_dict(io_read.full_align) + the MM/ML tags, src/remora/inference.py:450, :619-623.
+ * raw[r] = record r as stored (without block_size, raw_len[r] bytes), tags_off[r] = offset of its tag region.  Written to
+ * `out`, one after the other: int32 block_size + the record with any MM/ML/Mm/Ml tag removed and, when has_tags[r],
+ * MM:Z:<mm slice> and ML:B:C<ml slice> appended (has_tags[r] = 0: the record leaves without modified-base tags). */
+int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off,
+                              const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
+                              const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len);
+
 /* ---- N1: POD5 signal rows, the zstd layer (host code, parallel over rows) ----------------------------- */
 /* replaces: the zstd step of pod5's signal reader under io.iter_signal (src/remora/io.py:441-474).  `src[i]`
  * points at row i's compressed bytes (one zstd frame, src_len[i] bytes).  rmr_zstd_frame_sizes reads the

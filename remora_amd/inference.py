@@ -318,6 +318,34 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         tw = _time.perf_counter()
         clock["gpu"] += tw - tg
         clock["tags_write"] -= tw
+        if len(mds) == 1 and not ref_anchored and os.environ.get("RMR_NATIVE_TAGS", "1") != "0":
+            # one model, basecall-anchored (the common case): MM/ML strings and the rewritten records of the whole batch in
+            # two native calls (rmr_format_mm_ml, rmr_records_with_mod_tags) - byte for byte the per-read Python path below
+            from .util import format_mm_ml_tags_batch
+
+            md, results = mds[0], per_model[0]
+            sizes = np.fromiter((r[2].size for r in results), np.int64, len(results))
+            live = [r for r in results if r[2].size]
+            pos = np.concatenate([r[2] for r in live]) if live else np.zeros(0, np.int64)
+            probs = np.concatenate([r[0] for r in live]) if live else np.zeros((0, len(md["mod_bases"])))
+            if pos.size:  # calls per label (0 = canonical): argmax over [1 - sum(p_mod), p_mod...], first maximum wins
+                full = np.concatenate([1.0 - probs.sum(axis=1, keepdims=True), probs], axis=1)
+                label_counts[0] += np.bincount(full.argmax(axis=1), minlength=label_counts[0].size)
+            seqs = [io_read.seq for io_read, _ in good]
+            seq_off = np.zeros(len(seqs) + 1, np.int64)
+            np.cumsum([len(x) for x in seqs], out=seq_off[1:])
+            call_off = np.zeros(len(seqs) + 1, np.int64)
+            np.cumsum(sizes, out=call_off[1:])
+            mm, mm_off, ml, ml_off = format_mm_ml_tags_batch("".join(seqs).encode("latin-1"), seq_off, pos, probs, call_off,
+                                                             md["mod_bases"], md["can_base"])
+            has = sizes > 0
+            writer.write(rio.records_with_mod_tags_batch([io_read.record for io_read, _ in good], mm, mm_off, ml, ml_off, has))
+            n_ok = int(has.sum())
+            stats[None] += n_ok
+            if n_ok < len(good):
+                stats[f"No {md['can_base']} mod calls"] += len(good) - n_ok
+            clock["tags_write"] += _time.perf_counter()
+            return
         for k, (io_read, rr) in enumerate(good):
             import array
 

@@ -1222,6 +1222,25 @@ def record_with_mod_tags(rec, mm_tag, ml_tag, ref_anchored_seq=None):
     return struct.pack("<i", len(body)) + body
 
 
+def records_with_mod_tags_batch(records, mm, mm_off, ml, ml_off, has_tags):
+    """record_with_mod_tags for a batch in one native call (rmr_records_with_mod_tags): the records' bytes (block_size
+    included) one after the other, old MM/ML/Mm/Ml tags removed, read r's MM / ML slices appended where has_tags[r].
+    `records`: objects with `.raw` (bytes) and `.tags_offset`; the tag arrays as format_mm_ml_tags_batch returns them."""
+    n = len(records)
+    raws = [bytes(r.raw) if not isinstance(r.raw, bytes) else r.raw for r in records]
+    ptrs = (ctypes.c_char_p * n)(*raws)
+    raw_len = np.fromiter((len(b) for b in raws), np.int64, n)
+    tags_off = np.fromiter((r.tags_offset for r in records), np.int64, n)
+    has = np.ascontiguousarray(has_tags, np.uint8)
+    mm_off, ml_off = np.ascontiguousarray(mm_off, np.int64), np.ascontiguousarray(ml_off, np.int64)
+    out = np.empty(int(raw_len.sum()) + 16 * n + int(mm_off[-1]) + int(ml_off[-1]) + 16, np.uint8)
+    out_len = ctypes.c_int64()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.check(L.lib().rmr_records_with_mod_tags(n, ctypes.cast(ptrs, ctypes.c_void_p), p(raw_len), p(tags_off), p(mm), p(mm_off), p(ml),
+                                              p(ml_off), p(has), p(out), out.size, ctypes.byref(out_len)))
+    return out[: out_len.value].tobytes()
+
+
 _BGZF_LEVEL = int(os.environ.get("RMR_BAM_LEVEL", "6"))  # htslib's default level
 
 
@@ -1259,7 +1278,7 @@ class BamWriter:
             # the cores this process may really use (cgroup quota, not os.cpu_count()), shared with the other ranks of
             # the node when several processes run side by side
             local_ranks = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1), 1)
-            threads = int(os.environ.get("RMR_BAM_THREADS", "0")) or min(16, max(2, effective_cpu_count() // (2 * local_ranks)))
+            threads = int(os.environ.get("RMR_BAM_THREADS", "0")) or min(16, max(4, effective_cpu_count() // local_ranks))
         if max_pending is None:
             max_pending = 8 * int(threads)
 
@@ -1279,10 +1298,23 @@ class BamWriter:
         self._drain(self._max_pending)
 
     def write(self, record_bytes):
-        self._buf += record_bytes
-        while len(self._buf) >= 0xFF00:
-            self._flush_block(self._buf[:0xFF00])
-            del self._buf[:0xFF00]
+        """Append record bytes (one record or a whole batch of them); full 0xFF00-byte blocks go to the deflate pool."""
+        buf = self._buf
+        if len(buf) + len(record_bytes) < 0xFF00:
+            buf += record_bytes
+            return
+        view = memoryview(record_bytes)
+        start = 0
+        if buf:  # top the pending partial block up first
+            start = 0xFF00 - len(buf)
+            buf += view[:start]
+            self._flush_block(buf)
+            self._buf = buf = bytearray()
+        end = len(view)
+        while end - start >= 0xFF00:  # whole blocks straight from the caller's buffer (no front deletions of a large bytearray)
+            self._flush_block(view[start : start + 0xFF00])
+            start += 0xFF00
+        buf += view[start:]
 
     def close(self):
         if self._fh is None:

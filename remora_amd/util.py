@@ -249,6 +249,37 @@ def format_mm_ml_tags(seq, poss, probs, mod_bases, can_base, strand="+"):
     return mm_tag, ml_tag
 
 
+def format_mm_ml_tags_batch(seq_bytes, seq_off, pos, probs, call_off, mod_bases, can_base, strand="+"):
+    """format_mm_ml_tags for a batch of reads in one native call (rmr_format_mm_ml, host code): `seq_bytes` = the reads'
+    sequences one after the other (bytes, read r at seq_off[r] .. seq_off[r+1]), `pos` int64[N] / `probs` float64[N, n_mods]
+    = all calls, read r's at call_off[r] .. call_off[r+1] (any order inside a read).  Returns (mm uint8[...], mm_off, ml
+    uint8[...], ml_off): read r's MM string is mm[mm_off[r]:mm_off[r+1]].tobytes().decode(), its ML values
+    ml[ml_off[r]:ml_off[r+1]] - byte for byte what format_mm_ml_tags returns per read (empty for a read without calls)."""
+    import ctypes
+
+    from . import _lib as L
+
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    call_off = np.ascontiguousarray(call_off, np.int64)
+    n = seq_off.size - 1
+    pos = np.ascontiguousarray(pos, np.int64)
+    probs = np.ascontiguousarray(probs, np.float64).reshape(pos.size, -1) if pos.size else np.zeros((0, len(mod_bases)), np.float64)
+    n_mods = len(mod_bases)
+    if probs.shape[1] != n_mods or call_off.size != n + 1:
+        raise RemoraError("format_mm_ml_tags_batch: inconsistent array shapes")
+    codes = b"".join(str(mb).encode() + b"\x00" for mb in mod_bases)
+    head = sum(len(str(mb)) for mb in mod_bases) + 5 * n_mods
+    mm = np.empty(int(pos.size) * n_mods * 21 + n * head + 16, np.uint8)  # a gap prints in <= 20 characters + its comma
+    ml = np.empty(int(pos.size) * n_mods + 16, np.uint8)
+    mm_off, ml_off = np.empty(n + 1, np.int64), np.empty(n + 1, np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    buf = seq_bytes if isinstance(seq_bytes, (bytes, bytearray)) else bytes(seq_bytes)
+    L.check(L.lib().rmr_format_mm_ml(n, ctypes.cast(ctypes.c_char_p(bytes(buf)), ctypes.c_void_p), p(seq_off), p(pos), p(probs), p(call_off),
+                                     n_mods, codes, can_base.encode(), strand.encode(), p(mm), mm.size, p(mm_off), p(ml), ml.size,
+                                     p(ml_off)))
+    return mm, mm_off, ml, ml_off
+
+
 def resolve_path(fn_path):
     """Absolute, user-expanded, symlink-free path; None stays None (src/remora/util.py:161-167)."""
     return None if fn_path is None else os.path.realpath(os.path.expanduser(str(fn_path)))

@@ -1768,3 +1768,64 @@ def test_remora_dataset_shard_partitions_rows(tmp_path):
             if len(names) == 1:  # one core dataset: the shards' batches visit every row exactly once
                 seen = sum(int(b[2].shape[0]) for p in parts for b in p.iter_numpy_batches(("signal", "sequence_lengths", "labels")))
                 assert seen == ds.size
+
+
+def test_native_mm_ml_and_record_rewrite_match_the_python_forms(tmp_path):
+    """rmr_format_mm_ml / rmr_records_with_mod_tags (host C++, one call per batch) against util.format_mm_ml_tags and
+    io.record_with_mod_tags per read: byte-identical MM strings, ML arrays and output records for random reads - one
+    and two modified bases (also a ChEBI code), unsorted and repeated positions, reads without calls, positions on
+    non-canonical bases, probabilities of exactly 0 and 1, input records that already carry MM/ML/Mm/Ml tags, records with
+    a 'MMZ' byte pattern inside another tag's data."""
+    import struct
+
+    from remora_amd import io as rio
+    from remora_amd import util
+
+    rng = np.random.default_rng(11)
+    md = lambda s: b"MDZ" + s.encode() + b"\x00"  # noqa: E731
+    old_mm = b"MMZC+m?,1,2;\x00" + b"MLBC" + struct.pack("<i", 2) + bytes([9, 200])
+    old_lower = b"MmZC+h?,0;\x00" + b"MlBC" + struct.pack("<i", 1) + bytes([7])
+    trap = b"XXZabMMZcd\x00"  # the header pattern inside another tag's value: the record is walked, nothing is dropped
+    recs_spec = []
+    seqs = []
+    for i in range(40):
+        n = int(rng.integers(30, 400))
+        seq = "".join(rng.choice(list("ACGT"), n))
+        tags = [md(str(n))]
+        if i % 4 == 1:
+            tags.append(old_mm)
+        if i % 4 == 2:
+            tags = [old_lower] + tags + [trap]
+        if i % 7 == 3:
+            tags.append(b"ntC" + bytes([5]))
+        recs_spec.append((f"r{i}", 0, seq, [(0, n)], tags))
+        seqs.append(seq)
+    _tiny_bam(tmp_path / "t.bam", recs_spec)
+    recs = list(rio.iter_bam_records(str(tmp_path / "t.bam")))
+    assert len(recs) == 40
+    for mod_bases, can in ((["m"], "C"), (["h", "m"], "C"), (["27551"], "A")):
+        poss, probs, sizes = [], [], []
+        for i, seq in enumerate(seqs):
+            cand = np.flatnonzero(np.frombuffer(seq.encode(), np.uint8) == ord(can))
+            k = 0 if i % 9 == 0 else int(rng.integers(1, max(2, cand.size)))
+            p = rng.choice(cand, min(k, cand.size), replace=False) if cand.size and k else np.zeros(0, np.int64)
+            if i % 5 == 1 and p.size > 2:
+                p[0] = (p[0] + 1) % len(seq)       # a position that is not on a canonical base
+                p[1] = p[2]                        # a repeated position
+            pr = rng.random((p.size, len(mod_bases))) / len(mod_bases)
+            if p.size:
+                pr[0, 0] = 0.0
+                pr[-1, 0] = 1.0 if len(mod_bases) == 1 else pr[-1, 0]
+            poss.append(p.astype(np.int64)); probs.append(pr); sizes.append(p.size)
+        seq_off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+        call_off = np.concatenate([[0], np.cumsum(sizes)])
+        mm, mm_off, ml, ml_off = util.format_mm_ml_tags_batch("".join(seqs).encode(), seq_off, np.concatenate(poss),
+                                                              np.concatenate(probs), call_off, mod_bases, can)
+        want_recs = []
+        for i, seq in enumerate(seqs):
+            w_mm, w_ml = util.format_mm_ml_tags(seq, poss[i], probs[i], mod_bases, can)
+            assert mm[mm_off[i] : mm_off[i + 1]].tobytes().decode() == w_mm, (mod_bases, i)
+            assert ml[ml_off[i] : ml_off[i + 1]].tobytes() == bytes(w_ml), (mod_bases, i)
+            want_recs.append(rio.record_with_mod_tags(recs[i], w_mm, w_ml) if sizes[i] else rio.record_with_mod_tags(recs[i], None, None))
+        got = rio.records_with_mod_tags_batch(recs, mm, mm_off, ml, ml_off, np.asarray(sizes) > 0)
+        assert got == b"".join(want_recs), mod_bases
