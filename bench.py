@@ -103,6 +103,7 @@ def kernel_flops_per_chunk(arch, L, size=64, K=9, num_out=2):
         f["conv_merge3"] = 2 * size * size * 3 * T3
         f["conv_merge4"] = 2 * size * size * 3 * T4
         f["fc_head"] = 2 * num_out * size * T4
+        f["sig3_front"] = f["front_sig"] + f["conv_sig3"]  # the signal branch folded (k_conv_front.hip, matrix-core producer)
     return f
 
 

@@ -727,6 +727,9 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     // sig_conv3 / seq_conv2 (k_conv_front.hip); sig2 / seq1 never exist in HBM
     const bool fold = !enc && tune_int("RMR_TWO_STREAM", 0) == 0 && tune_int("RMR_CONV_FRONT", 1) &&
                       conv_front_supported(m, kb, ka, seq_w, map_w);
+    // every other fp32 path (Conv_w_ref; ConvLSTM shapes the two-branch fold does not cover): the signal branch alone is
+    // folded - sig_conv1 / sig_conv2 (matrix cores) produced inside the staging of sig_conv3, sig2 never in HBM
+    const bool sigfold = !fold && m->nparts == 0 && tune_int("RMR_TWO_STREAM", 0) == 0 && sig3_front_mfma_supported(m);
     const size_t front_fl = fold ? 0 : (size_t)(m->P1 + m->P2) * 16;
     RMR_TRY(e->ensure(e->act, (per + front_fl) * sb * sizeof(float)));
     // RMR_TWO_STREAM: 1 = front kernels of sub-batch i+1 on the aux stream from the start of sub-batch i (they then share
@@ -746,7 +749,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         float *seq1 = front_buf[slot], *sig2 = seq1 + (size_t)nb * m->P1 * 16;
         const float *sig_b = signal + (size_t)c0 * L;
         if (enc) {
-            RMR_TRY(launch_front(m, fs, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
+            if (!sigfold) RMR_TRY(launch_front(m, fs, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
             if (two_stream) {  // the dense seq_conv1 kernel runs on the main stream
                 RMR_HIP(hipEventRecord(e->ev_front[slot], fs));
                 RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_front[slot], 0));
@@ -754,7 +757,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             RMR_TRY(launch_seq1_dense(m, enc + (size_t)c0 * EC * L, nb, seq1));
         } else {
             RMR_TRY(launch_front(m, fs, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
-                                 map_w, lens + c0, kb, ka, nb, sig2, seq1));
+                                 map_w, lens + c0, kb, ka, nb, sigfold ? nullptr : sig2, seq1));
             if (two_stream) RMR_HIP(hipEventRecord(e->ev_front[slot], fs));
         }
         return 0;
@@ -778,6 +781,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         if (fold) RMR_TRY(launch_conv_front(m, signal + (size_t)c0 * L, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
                                             map_w, lens + c0, nb, cat));
         else if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
+        else if (sigfold) RMR_TRY(launch_sig3_front_mfma(m, signal + (size_t)c0 * L, nb, cat));
         else RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
         if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
             float *x = base; base += (size_t)nb * m->T * sz;

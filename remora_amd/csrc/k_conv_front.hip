@@ -247,6 +247,99 @@ __global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// signal branch with the producer's sig_conv2 on the matrix cores (round 3): sig_conv1 -> sig_conv2 -> LDS planes -> sig_conv3.
+// The VALU producer above keeps a lane's 4-channel slice of the sig_conv2 weights in registers (KW1 x 4 x 4 floats: 80 at
+// 5 taps - 248 VGPRs for the kernel, two waves per SIMD -, 176 at Conv_w_ref's 11 taps: does not fit next to sig_conv3's
+// slice at all).  As an implicit GEMM (M = 16 channels, N = positions, K = (tap, input channel)) one tap is ONE
+// v_mfma_f32_16x16x4_f32: A of lane (q, m) = w_sig2[tap][ic = q][oc = m] (KW1 VGPRs, read from the VALU kernel's table), B of
+// lane (q, n) = sig1[ic = q][pos + tap] from a channel-planar row in the wave's scratch.  The D fragment - four consecutive
+// output channels of one position - is one float4 store into plane q of the image sig_conv3 reads.  An fp32 MFMA is a
+// k-ordered fmaf chain (bit-for-bit the VALU loop: same order tap-major, input channel minor), so the activations equal the
+// VALU producer's bit for bit.  One wave produces a chunk at a time, all its column tiles advancing together.
+// ---------------------------------------------------------------------------------------
+template <int KW1, int MAXT>
+__global__ __launch_bounds__(256, (KW1 <= 5 ? 3 : 2)) void sig3_front_mfma_kernel(ConvFrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KW = 9, S = KW * 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+
+    float A[S];
+    {
+        const float *ap = a.apack + (size_t)w * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) A[s] = ap[(size_t)s * 64];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
+    float A2[KW1];
+#pragma unroll
+    for (int t = 0; t < KW1; ++t) A2[t] = a.w_sig2[(t * 4 + q) * 16 + nn];
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b_sig2 + 4 * q);
+    float w1[KW1][4];
+#pragma unroll
+    for (int t = 0; t < KW1; ++t)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w1[t][o] = a.w_sig1[t * 4 + o];
+    const float b1[4] = {a.b_sig1[0], a.b_sig1[1], a.b_sig1[2], a.b_sig1[3]};
+
+    const int Lp = (a.L + 3) & ~3, Pst = (a.P1 + 16 + 3) & ~3;  // planar row stride: a padded last tile reads inside the wave's scratch
+    float *s_sig = smem + a.o_front + (size_t)w * a.per_chunk;   // per WAVE here: [Lp] signal, [4][Pst] sig1
+    float *s_sig1 = s_sig + Lp;
+    for (int i = lane; i < 4 * Pst; i += 64) s_sig1[i] = 0.0f;   // padding positions stay finite
+    const int ntiles = (a.pin + 15) >> 4;                        // pin = P2 = positions of sig_conv2's output
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        __syncthreads();  // the matrix phase of the previous iteration has read the planes
+        for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
+            wave_sync();
+            const float *src = a.signal + (size_t)(chunk0 + c) * a.L;
+            for (int s = lane; s < a.L; s += 64) s_sig[s] = src[s];
+            wave_sync();
+            for (int pos = lane; pos < a.P1; pos += 64) {
+                float acc[4] = {b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    const float xv = s_sig[pos + t];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[o] = fmaf(w1[t][o], xv, acc[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) s_sig1[o * Pst + pos] = swish_f(acc[o]);
+            }
+            wave_sync();
+            float *row0 = smem + (size_t)q * a.plane + (size_t)c * a.pin * 4;  // plane q = channels 4q..4q+3 of every row
+            for (int t0 = 0; t0 < ntiles; t0 += MAXT) {
+                f32x4 acc[MAXT];
+#pragma unroll
+                for (int k = 0; k < MAXT; ++k) acc[k] = b2;
+                const float *row = s_sig1 + q * Pst + 16 * t0 + nn;
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+#pragma unroll
+                    for (int k = 0; k < MAXT; ++k)
+                        if (t0 + k < ntiles)  // wave-uniform
+                            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[t], row[16 * k + t], acc[k], 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < MAXT; ++k) {
+                    const int pos = 16 * (t0 + k) + nn;
+                    if (t0 + k < ntiles && pos < a.pin) {
+                        f32x2 lo = f32x2{acc[k][0], acc[k][1]}, hi = f32x2{acc[k][2], acc[k][3]};
+                        swish_pk(lo, hi);
+                        *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // sequence branch (two-level gather of k_front.hip's front_seq_kernel<5, false>, 64 lanes per chunk)
 // ---------------------------------------------------------------------------------------
 template <int K>
@@ -410,6 +503,65 @@ bool conv_front_supported(const rmr_model *m, int kb, int ka, int seq_w, int map
     return sig1 <= CONV_FRONT_MAX_LDS && seq1 <= CONV_FRONT_MAX_LDS;
 }
 
+bool sig3_front_mfma_supported(const rmr_model *m) {
+    if (m->desc.size != 64 || m->nparts != 0 || (m->front.kw1 != 5 && m->front.kw1 != 11)) return false;
+    if (m->sig3.ic != 16 || m->sig3.kw != 9 || m->sig3.stride != 3 || m->sig3.oc != 64) return false;
+    const int Lp = (m->L + 3) & ~3, Pst = (m->P1 + 16 + 3) & ~3;
+    const size_t one = ((size_t)(4 * (((m->P2 * 4) + 63) & ~63) + 16) + 4 * (size_t)(Lp + 4 * Pst)) * sizeof(float);
+    return one <= CONV_FRONT_MAX_LDS && tune_int("RMR_SIG3_MFMA", 1) != 0;
+}
+
+// sig_conv1 -> sig_conv2 (matrix cores) -> sig_conv3 of `n` chunks into channels [0, 64) of cat [n][P3][out_row]
+int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *cat) {
+    rmr_engine *e = m->eng;
+    if (n <= 0) return 0;
+    const int sz = m->desc.size, kw1 = m->front.kw1;
+    ConvFrontArgs a{};
+    a.signal = signal; a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1; a.w_sig2 = m->front.w_sig2; a.b_sig2 = m->front.b_sig2;
+    a.L = m->L; a.P1 = m->P1;
+    a.out = cat; a.apack = m->sig3.apack; a.bias = m->sig3.bias; a.n = n;
+    a.pin = m->P2; a.pout = m->P3; a.out_row = 2 * sz; a.out_coff = 0; a.div_pout = make_fastdiv(m->P3);
+    const int Lp = (m->L + 3) & ~3, Pst = (m->P1 + 16 + 3) & ~3;
+    a.per_chunk = Lp + 4 * Pst;  // scratch per WAVE
+    auto kern = kw1 == 5 ? sig3_front_mfma_kernel<5, 6> : sig3_front_mfma_kernel<11, 5>;
+    // blocks per CU by registers, LDS share accordingly; among the chunk counts that fit, the one that fills its tiles best
+    static int regs5 = 0, regs11 = 0;
+    int &regs = kw1 == 5 ? regs5 : regs11;
+    if (regs == 0) {
+        hipFuncAttributes attr;
+        regs = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
+    }
+    int resident = 512 / ((regs + 7) & ~7);
+    resident = resident < 1 ? 1 : (resident > 4 ? 4 : resident);
+    size_t budget = (size_t)tune_int("RMR_CONV_FRONT_LDS_BUDGET", 73728);
+    const size_t share = (size_t)160 * 1024 / resident - 512;
+    if (share < budget) budget = share;
+    // score of a chunk count = tile fill of the matrix phase x balance of the producer phase (4 waves, one chunk at a time)
+    int cb = 0;
+    size_t lds = 0;
+    double best = -1.0;
+    for (int k = 8; k >= 1; --k) {
+        const int plane = ((k * a.pin * 4) + 63) & ~63;
+        const size_t need = ((size_t)4 * plane + 16 + 4 * (size_t)a.per_chunk) * sizeof(float);
+        if (need > budget && !(k == 1 && need <= CONV_FRONT_MAX_LDS)) continue;
+        if (cb == 0) cb = k;            // the largest count that fits
+        if (2 * k < cb) break;          // never below half of it
+        const int cols = k * a.pout;
+        const double score = (double)cols / (16.0 * ((cols + 15) / 16)) * (double)k / (4.0 * ((k + 3) / 4));
+        if (score > best + 1e-9) { best = score; a.cb = k; a.plane = plane; a.o_front = 4 * plane + 16; lds = need; }
+    }
+    if (cb == 0) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples does not fit the LDS", m->L);
+    a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+    const int64_t iters = (n + a.cb - 1) / a.cb;
+    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
+    if (grid > iters) grid = iters;
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
+    ProfScope ps(e, K_SIG3_FRONT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 // sig_conv3 (+ sig_conv1/2) and seq_conv2 (+ seq_conv1) of `n` chunks into the two halves of cat [n][P3][128]
 int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
                       const int16_t *lens, int64_t n, float *cat) {
@@ -418,7 +570,11 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
     const int sz = m->desc.size, K = m->desc.kmer_len;
     const int budget = tune_int("RMR_CONV_FRONT_LDS_BUDGET", 73728);
     auto up4 = [](int words) { return (words + 3) & ~3; };
-    {   // ---- signal branch ----
+    // (the matrix-core producer is bit-identical here too; measured 5.40 vs 5.47 ns per chunk at C100 but 12.58 vs 12.03 at
+    //  C200, so the two-branch fold keeps the VALU producer unless asked)
+    if (tune_int("RMR_SIG3_MFMA_LSTM", 0) != 0 && sig3_front_mfma_supported(m)) {
+        RMR_TRY(launch_sig3_front_mfma(m, signal, n, cat));
+    } else {   // ---- signal branch, VALU producer ----
         ConvFrontArgs a{};
         a.signal = signal; a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1; a.w_sig2 = m->front.w_sig2; a.b_sig2 = m->front.b_sig2;
         a.L = m->L; a.P1 = m->P1;

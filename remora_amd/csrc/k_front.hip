@@ -363,7 +363,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     const int K = m->desc.kmer_len;
     const int kw = m->front.kw1;
     if (kw != 5 && kw != 11) RMR_FAIL(RMR_ERR_INVALID, "front kernel width %d unsupported", kw);
-    {   // ---- signal branch ----
+    if (sig2) {   // ---- signal branch (skipped when the caller folds it into sig_conv3: launch_sig3_front_mfma) ----
         FrontSigArgs a;
         a.signal = signal; a.w_sig1 = m->front.w_sig1; a.b_sig1 = m->front.b_sig1;
         a.w_sig2 = m->front.w_sig2; a.b_sig2 = m->front.b_sig2; a.sig2 = sig2; a.n = n;

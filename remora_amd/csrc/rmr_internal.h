@@ -234,6 +234,9 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
 int launch_seq1_dense(rmr_model *m, const float *enc, int64_t n, float *seq1);
 // k_conv_front.hip: fp32 sig_conv3 / seq_conv2 with their producers (sig_conv1/2, seq_conv1) folded into the staging
 bool conv_front_supported(const rmr_model *m, int kb, int ka, int seq_w, int map_w);
+// the signal half alone with sig_conv2 on the matrix cores (both architectures, 5 or 11 taps): signal -> cat channels [0, 64)
+bool sig3_front_mfma_supported(const rmr_model *m);
+int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *cat);
 int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
                       const int16_t *lens, int64_t n, float *cat);
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
