@@ -435,7 +435,9 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     if os.environ.get("RMR_INFER_TIMING"):
         import sys as _sys
 
-        print(f"[infer rank {rank}/{world}] " + " ".join(f"{k} {v:.2f}s" for k, v in clock.items()), file=_sys.stderr, flush=True)
+        tm = os.times()  # CPU seconds of this process (all its threads) since start, children excluded
+        print(f"[infer rank {rank}/{world}] " + " ".join(f"{k} {v:.2f}s" for k, v in clock.items()) +
+              f" | process cpu user {tm.user:.2f}s sys {tm.system:.2f}s", file=_sys.stderr, flush=True)
     if world > 1:
         # every part is complete on disk; the ONE data collective: per-label call counts (int64[num_out] per model)
         flat = rdist.allreduce_counts(np.concatenate(label_counts))
