@@ -93,6 +93,16 @@ def _infer(args):
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model
 
+    # this rank's share of the BAM: one light pass over the whole file (rmr_bam_scan) - started now, in a thread, so that
+    # it runs under the model load instead of in front of the first batch
+    erank, eworld, _ = rdist.env_rank_world()
+    shard_future = None
+    if eworld > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        from .io import bam_shard
+
+        shard_future = ThreadPoolExecutor(max_workers=1).submit(bam_shard, args.in_bam, erank, eworld)
     rank, world, dev = rdist.setup_ranks(args.gpus, args.procs_per_gpu)
     loaded = [load_torchscript_model(m, device=args.device if dev is None else dev, eval_only=True, dtype=args.dtype)
               for m in args.model]
@@ -106,7 +116,8 @@ def _infer(args):
     t0 = time.perf_counter()
     stats = infer_from_pod5_and_bam(args.pod5, args.in_bam, model, md, args.out_bam, num_reads=args.num_reads,
                                     reads_per_batch=args.reads_per_batch, ref_anchored=args.reference_anchored,
-                                    rank=rank, world=world, label_counts_out=label_counts, bam_level=args.bam_level)
+                                    rank=rank, world=world, label_counts_out=label_counts, bam_level=args.bam_level,
+                                    shard_future=shard_future)
     dt = time.perf_counter() - t0
     if rank != 0:
         return 0

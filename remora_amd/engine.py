@@ -126,6 +126,20 @@ def get_prep_engine(device):
         return _prep_engines[idx]
 
 
+_ingest_engines = {}
+
+
+def get_ingest_engine(device=None):
+    """A third engine (own stream, own mutex) for the ingest thread of a file-to-file run: the VBZ decode and the move-table
+    expansion of the NEXT batches are small synchronous calls; on the model's engine they would wait, call by call, behind
+    the inference kernels of the current batch (one mutex and one stream per engine)."""
+    idx = get_engine(device).device
+    with _engines_lock:
+        if idx not in _ingest_engines:
+            _ingest_engines[idx] = Engine(idx, use_torch_stream=False)
+        return _ingest_engines[idx]
+
+
 def _ptr(x):
     """(address, is_device, keepalive) for a torch tensor or numpy array (must be contiguous)."""
     torch = _torch()

@@ -250,7 +250,7 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
 
 def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_bam_path, num_reads=None,
                             reads_per_batch=256, reverse_signal=None, skip_non_primary=True, ref_anchored=False, prefetch=2,
-                            rank=0, world=1, label_counts_out=None, bam_level=None):
+                            rank=0, world=1, label_counts_out=None, bam_level=None, shard_future=None):
     """`remora infer from_pod5_and_bam` for one model or a list of models (one per canonical base, with a list of
     metadata dicts), basecall-anchored by default or reference-anchored
     (`--reference-anchored`: calls at reference positions, output records rewritten to `<len>M` + reference
@@ -281,7 +281,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     stats = Counter()
     header = rio.read_bam_header_bytes(in_bam_path)
     world, rank = int(world), int(rank)
-    shard = (rank, world) if world > 1 else None
+    shard = (shard_future if shard_future is not None else (rank, world)) if world > 1 else None  # future of io.bam_shard(...)
     part_path = f"{out_bam_path}.part{rank:03d}" if world > 1 else out_bam_path
 
     models = list(model) if isinstance(model, (list, tuple)) else [model]

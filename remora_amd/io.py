@@ -554,10 +554,15 @@ def iter_bam_records(bam_path, want_ref=False, batch=512, native=True, shard=Non
     reader (rmr_bam_read_batch: BGZF inflate, record split, hot tags and - with want_ref - the MD reconstruction in
     C++, `batch` records per call); native=False is the pure-Python reader the native one is tested against.
     `shard=(rank, world)`: only that rank's contiguous share of the records (`bam_shard`)."""
-    if shard is not None and int(shard[1]) > 1:
+    if shard is not None and (hasattr(shard, "result") or int(shard[1]) > 1):
         if not native:
             raise RemoraError("sharded reading needs the native BAM reader")
-        start, count = bam_shard(bam_path, int(shard[0]), int(shard[1]))
+        # (rank, world), or a future of bam_shard's result started earlier (the scan of a large file takes seconds: a
+        # caller overlaps it with its own start-up, e.g. the model load of `infer --gpus N`)
+        start, count = shard.result() if hasattr(shard, "result") else bam_shard(bam_path, int(shard[0]), int(shard[1]))
+        if count is None:  # a single worker: the whole file
+            yield from _iter_bam_records_native(bam_path, want_ref, batch)
+            return
         if count:
             yield from _iter_bam_records_native(bam_path, want_ref, batch, start_voffset=start, max_records=count)
         return
@@ -1111,11 +1116,14 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
     move tables are expanded in one launch; decode_batch <= 1 works read by read (one launch per read).  `parse_ref_align=False` skips the
     reference side of the alignment (MD reconstruction, ref_to_signal) when only basecall-anchored reads are needed."""
     signals = Pod5File(pod5_path)
+    from .engine import get_ingest_engine
+
+    ingest_eng = get_ingest_engine() if decode_batch > 1 else None  # own stream: not behind the model's kernels
 
     def emit(recs):
         if decode_batch > 1 and recs:
             ids = list(dict.fromkeys(rid for _, rid in recs))
-            pods = dict(zip(ids, signals.get_many(ids)))
+            pods = dict(zip(ids, signals.get_many(ids, engine=ingest_eng)))
         else:
             pods = None
         reads = [Read.from_pod5(pods[rid] if pods is not None else signals.get(rid), reverse_signal=reverse_signal)
@@ -1131,7 +1139,7 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
                     mvs.append(tags["mv"])
                     qls.append(len(rec.query_sequence))
                     have.append(k)
-            for k, res in zip(have, parse_move_tags(mvs, sls, qls, reverse_signal=reverse_signal)):
+            for k, res in zip(have, parse_move_tags(mvs, sls, qls, reverse_signal=reverse_signal, engine=ingest_eng)):
                 moves[k] = res
         for (rec, rid), read, mv in zip(recs, reads, moves):
             try:
