@@ -93,8 +93,8 @@ def _infer(args):
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model
 
-    # this rank's share of the BAM: one light pass over the whole file (rmr_bam_scan) - started now, in a thread, so that
-    # it runs under the model load instead of in front of the first batch
+    # this rank's share of the BAM: the marks of the launcher's pass over the file (or this rank's own pass under a foreign
+    # launcher) - awaited in a thread, under the model load instead of in front of the first batch
     erank, eworld, _ = rdist.env_rank_world()
     shard_future = None
     if eworld > 1:
@@ -211,7 +211,8 @@ def main(argv=None):
     if nranks > 1 and "WORLD_SIZE" not in os.environ:
         from .dist import launch_ranks
 
-        return launch_ranks(sys.argv[1:] if argv is None else list(argv), nranks)
+        scan_bam = args.in_bam if args.func is _infer else None
+        return launch_ranks(sys.argv[1:] if argv is None else list(argv), nranks, scan_bam=scan_bam)
     try:
         return args.func(args)
     except RemoraError as e:

@@ -79,13 +79,16 @@ def allgather_floats(xs):
     return torch.stack(out).cpu().numpy()
 
 
-def launch_ranks(argv, n):
+def launch_ranks(argv, n, scan_bam=None):
     """Start `n` ranks of `python -m remora_amd <argv>` on this node (one process per GPU; torch.distributed.run sets
     RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on 127.0.0.1) and return the launcher's exit code.  Used by the CLI when
-    `--gpus N` is given outside torchrun."""
+    `--gpus N` is given outside torchrun.  `scan_bam`: while the ranks start (interpreter, torch, model load) this
+    process makes the one pass over that BAM which tells every rank where its share begins (io.write_bam_scan), instead
+    of each rank inflating the whole file for itself."""
     import socket
     import subprocess
     import sys
+    import tempfile
 
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
@@ -96,7 +99,25 @@ def launch_ranks(argv, n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    scan_path = None
+    if scan_bam is not None:
+        from .io import SCAN_ENV
+
+        scan_path = os.path.join(tempfile.gettempdir(), f"remora_amd_scan_{os.getpid()}_{port}.npz")
+        env[SCAN_ENV] = scan_path
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        if scan_path is not None:
+            from .io import write_bam_scan
+
+            write_bam_scan(scan_bam, scan_path)
+        return proc.wait()
+    except BaseException:
+        proc.terminate()
+        raise
+    finally:
+        if scan_path is not None and os.path.exists(scan_path):
+            os.unlink(scan_path)
 
 
 def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):

@@ -298,19 +298,9 @@ def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None, start_vof
         lib.rmr_bam_close(h)
 
 
-def bam_shard(bam_path, rank, world, every=64):
-    """(start_voffset, n_records) of rank `rank`'s contiguous share of the alignments of `bam_path` when `world` workers
-    split the file between them (dist.shard_range over marks set every `every` records; shares differ by less than
-    `every` records unless the file has fewer than `world` marks).  One light pass over the file (rmr_bam_scan: BGZF
-    inflate + the block_size fields) that every worker runs by itself - no coordinator, no index file.  n_records is 0
-    (and the offset None) for a rank that gets nothing."""
-    from .dist import shard_range
-
-    if world <= 1:
-        return None, None
-    import time
-
-    t_scan = time.perf_counter()
+def bam_scan(bam_path, every=64):
+    """(marks, n_records): the BGZF virtual offset of records 0, every, 2 every, ... of `bam_path` and the number of
+    records.  One light pass over the file (rmr_bam_scan: BGZF inflate + the block_size fields)."""
     lib = L.lib()
     cap = 1 << 16
     while True:  # rmr_bam_open leaves the handle at the first record
@@ -324,16 +314,80 @@ def bam_shard(bam_path, rank, world, every=64):
             lib.rmr_bam_close(h)
         n_marks = (n.value + every - 1) // every
         if n_marks <= cap:
-            break
+            return marks[:n_marks].copy(), int(n.value)
         cap = int(n_marks)  # more marks than the first guess: scan again with room for all of them
+
+
+SCAN_ENV = "REMORA_AMD_BAM_SCAN"  # set by dist.launch_ranks: the launcher scans the BAM once for all of its ranks
+
+
+def _scan_key(bam_path, every):
+    st = os.stat(bam_path)
+    return np.array([st.st_size, st.st_mtime_ns, int(every)], np.int64)
+
+
+def write_bam_scan(bam_path, out_path, every=64):
+    """Scan `bam_path` and leave (marks, n_records) in `out_path` for the ranks of this launch (`bam_shard` picks it up
+    through REMORA_AMD_BAM_SCAN).  The file appears atomically; a scan that fails leaves a marker instead, and the ranks
+    scan for themselves (and report the error in their own words)."""
+    tmp = f"{out_path}.tmp{os.getpid()}"
+    try:
+        marks, n = bam_scan(bam_path, every)
+        payload = dict(key=_scan_key(bam_path, every), marks=marks, n=np.int64(n))
+    except Exception:  # noqa: BLE001 - whatever it is, the ranks will meet it themselves
+        payload = dict(key=np.zeros(3, np.int64), marks=np.zeros(0, np.int64), n=np.int64(-1))
+    with open(tmp, "wb") as fh:
+        np.savez(fh, **payload)
+    os.replace(tmp, out_path)
+
+
+def _launcher_bam_scan(bam_path, every, wait_s=120.0):
+    """(marks, n_records) from the launcher's scan of this very file, or None (no launcher scan announced, it failed,
+    it is about another file, or it did not appear in `wait_s`)."""
+    import time
+
+    path = os.environ.get(SCAN_ENV)
+    if not path:
+        return None
+    deadline = time.monotonic() + wait_s
+    while not os.path.exists(path):
+        if time.monotonic() > deadline:
+            return None
+        time.sleep(0.005)
+    try:
+        with np.load(path) as z:
+            if int(z["n"]) < 0 or not np.array_equal(z["key"], _scan_key(bam_path, every)):
+                return None
+            return z["marks"].copy(), int(z["n"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def bam_shard(bam_path, rank, world, every=64):
+    """(start_voffset, n_records) of rank `rank`'s contiguous share of the alignments of `bam_path` when `world` workers
+    split the file between them (dist.shard_range over marks set every `every` records; shares differ by less than
+    `every` records unless the file has fewer than `world` marks).  The marks come from one light pass over the file
+    (`bam_scan`): the launcher of the ranks makes it once for all of them (dist.launch_ranks); under a foreign launcher
+    (torchrun) every worker makes it by itself - no coordinator, no index file.  n_records is 0 (and the offset None)
+    for a rank that gets nothing."""
+    from .dist import shard_range
+
+    if world <= 1:
+        return None, None
+    import time
+
+    t_scan = time.perf_counter()
+    got = _launcher_bam_scan(bam_path, every)
+    marks, n = got if got is not None else bam_scan(bam_path, every)
     if os.environ.get("RMR_INFER_TIMING"):
         import sys
 
-        print(f"[bam_shard rank {rank}/{world}] scan of {n.value} records: {time.perf_counter() - t_scan:.2f}s", file=sys.stderr, flush=True)
-    m0, m1 = shard_range(n_marks, rank, world)
+        print(f"[bam_shard rank {rank}/{world}] {n} records, marks from {'the launcher' if got is not None else 'its own scan'}: "
+              f"{time.perf_counter() - t_scan:.2f}s", file=sys.stderr, flush=True)
+    m0, m1 = shard_range(len(marks), rank, world)
     if m1 <= m0:
         return None, 0
-    return int(marks[m0]), int(min(m1 * every, n.value) - m0 * every)
+    return int(marks[m0]), int(min(m1 * every, n) - m0 * every)
 
 
 def _native_batches(lib, h, want_ref, batch, once=False, limit=None):

@@ -1668,6 +1668,37 @@ def test_bam_shard_partitions_the_records_in_order():
                     assert max(sizes) - min(sizes) <= 1
 
 
+def test_bam_shard_takes_the_launchers_scan(tmp_path, monkeypatch):
+    """dist.launch_ranks scans the BAM once while its ranks start and announces the result through REMORA_AMD_BAM_SCAN;
+    bam_shard then gives exactly the shares of a rank's own scan.  A scan of another file, a failed scan or a missing
+    file fall back to the rank's own scan, never to wrong offsets."""
+    import shutil
+
+    from remora_amd import io as rio
+
+    path = os.path.join(DATA, "can_mappings.bam")
+    own = [rio.bam_shard(path, r, 3, every=2) for r in range(3)]
+    scan = str(tmp_path / "scan.npz")
+    rio.write_bam_scan(path, scan, every=2)
+    monkeypatch.setenv(rio.SCAN_ENV, scan)
+    marks, n = rio._launcher_bam_scan(path, 2)
+    assert (marks.tolist(), n) == (rio.bam_scan(path, 2)[0].tolist(), rio.bam_scan(path, 2)[1])
+    calls = []
+    real = rio.bam_scan
+    monkeypatch.setattr(rio, "bam_scan", lambda *a, **k: (calls.append(a), real(*a, **k))[1])
+    assert [rio.bam_shard(path, r, 3, every=2) for r in range(3)] == own and not calls
+    # the announced scan is about another file (or another mark spacing): not used
+    other = str(tmp_path / "other.bam")
+    shutil.copy(os.path.join(DATA, "mod_mappings.bam"), other)
+    assert rio._launcher_bam_scan(other, 2) is None and rio._launcher_bam_scan(path, 3) is None
+    assert rio.bam_shard(other, 1, 2, every=2) == rio.bam_shard(other, 1, 2, every=2) and len(calls) == 2
+    # a failed launcher scan leaves a marker; a scan that never appears times out
+    rio.write_bam_scan(str(tmp_path / "missing.bam"), scan, every=2)
+    assert rio._launcher_bam_scan(path, 2) is None
+    monkeypatch.setenv(rio.SCAN_ENV, str(tmp_path / "never.npz"))
+    assert rio._launcher_bam_scan(path, 2, wait_s=0.05) is None
+
+
 def test_bam_parts_join_into_one_valid_bam(tmp_path):
     """The part files of a multi-GPU infer run (rank 0: header + records, others: records only, no EOF markers) joined by
     concat_bam_parts read back as ONE BAM with every record in input order - by Python's gzip (independent reader) and by
