@@ -57,10 +57,11 @@ struct FusedArgs {
     int64_t n;
     int L, P1, P2, P3, T, seq_w, map_w, maxlen, cb;
     // LDS carve, byte offsets (all multiples of 16)
-    int o_sig, o_seq, o_map, o_len, o_pidx, o_code, o_sig1, o_sig2, o_seq1, o_oh;
+    int o_sig, o_seq, o_map, o_len, o_tab, o_col3, o_col4, o_sig1, o_sig2, o_seq1, o_oh;
     int oh_plane, cat_plane;  // bytes
     int lds_bytes;
     FastDiv d_L, d_P1, d_P3, d_T, d_maxlen;
+    unsigned mg_ps2, mg_pq1;  // ceil(2^32 / tile pairs per chunk) of sig_conv2 / seq_conv1: S2's item -> (chunk, pair) on the SALU
     int abl;  // experiment builds only (-DRMR_TIMING_ABLATIONS): bit mask of stages to skip, see ABL() below
 };
 
@@ -99,20 +100,38 @@ __device__ __forceinline__ f32x4 mfma16(const uint4 a, const uint4 b, const f32x
 // which saves the multiply by -log2(e) in front of every v_exp_f32; the next layer's weights are unchanged (its bias
 // is scaled by log2(e)), and the last layer multiplies by POST = 1 / log2(e) to hand over the true activation.
 // Four accumulator rows (consecutive output channels) -> four bf16: 8 bytes.
+// The VALU is what this kernel is short of, so the four activations of an accumulator are worked as two
+// register pairs: 4 v_exp + 2 v_pk_add_f32 + 4 v_rcp + 2 v_pk_mul_f32 + 2 packs = 14 instructions; left to itself hipcc
+// paired elements (1, 2), moved them into an aligned register pair and re-assembled the result with v_perm / v_alignbit
+// (22).  Packed and scalar fp32 add / mul round alike: same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RMR_SWISH_PAIRS
+#define RMR_SWISH_PAIRS 1
+#endif
 template <bool F16>
 __device__ __forceinline__ uint2 swish_pack(const f32x4 acc, const int no_swish = 0, const float post = 1.0f) {
-    float v[4];
+    f32x2 lo = {acc[0], acc[1]}, hi = {acc[2], acc[3]};
+    if (!RMR_SWISH_PAIRS) {  // the element-by-element form, kept for the A/B (tools/ab_variants.py)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float z = acc[r];
-        const float y = z * fast_rcp(1.0f + __builtin_amdgcn_exp2f(-z));
-        v[r] = no_swish ? z : y * post;
+        for (int r = 0; r < 4; ++r) {
+            const float z = acc[r];
+            const float y = no_swish ? z : z * fast_rcp(1.0f + __builtin_amdgcn_exp2f(-z)) * post;
+            if (r < 2) lo[r] = y;
+            else hi[r - 2] = y;
+        }
+    } else if (!no_swish) {
+        const f32x2 elo = {__builtin_amdgcn_exp2f(-lo.x), __builtin_amdgcn_exp2f(-lo.y)};
+        const f32x2 ehi = {__builtin_amdgcn_exp2f(-hi.x), __builtin_amdgcn_exp2f(-hi.y)};
+        const f32x2 dlo = elo + 1.0f, dhi = ehi + 1.0f;
+        const f32x2 rlo = {fast_rcp(dlo.x), fast_rcp(dlo.y)}, rhi = {fast_rcp(dhi.x), fast_rcp(dhi.y)};
+        lo = lo * rlo * post;
+        hi = hi * rhi * post;
     }
     if constexpr (F16) {
-        const f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        const f16x4 o = {(_Float16)lo.x, (_Float16)lo.y, (_Float16)hi.x, (_Float16)hi.y};
         return __builtin_bit_cast(uint2, o);
     } else {
-        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        const bf16x4 o = {(__bf16)lo.x, (__bf16)lo.y, (__bf16)hi.x, (__bf16)hi.y};
         return __builtin_bit_cast(uint2, o);
     }
 }
@@ -309,6 +328,9 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     unsigned char *s_sig1 = smem + a.o_sig1;  // [row][4] bf16, 8 B rows
     unsigned char *s_sig2 = smem + a.o_sig2;  // [row][16] bf16, 32 B rows
     unsigned char *s_seq1 = smem + a.o_seq1;  // [row][16] bf16
+    uint4 *s_tab = reinterpret_cast<uint4 *>(smem + a.o_tab);  // [64] one-hot pieces by base-code pair
+    int2 *s_col3 = reinterpret_cast<int2 *>(smem + a.o_col3);  // [cb * P3] byte offsets of a column's first SIG2 / SEQ1 row
+    int *s_col4 = reinterpret_cast<int *>(smem + a.o_col4);    // [cb * T]  byte offset of a column's first CAT row
     unsigned char *s_oh = smem + a.o_oh;      // CG planes x [row] x 16 B;  aliased by
     unsigned char *s_cat = smem + a.o_oh;     // 4 planes x [row][5 slots] x 16 B
 
@@ -318,7 +340,6 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     const int tiles_sig2 = (a.P2 + 15) >> 4, tiles_seq1 = (a.P1 + 15) >> 4;
     const int pairs_sig2 = (tiles_sig2 + 1) >> 1, pairs_seq1 = (tiles_seq1 + 1) >> 1;
     const int pairs_chunk = pairs_sig2 + pairs_seq1;
-    const FastDiv d_ps2 = FastDiv{pairs_sig2, 1.0f / (float)pairs_sig2}, d_pq1 = FastDiv{pairs_seq1, 1.0f / (float)pairs_seq1};
     int nsearch = 1;  // bisection steps that cover maxlen + 1 mapping entries
     while ((1 << nsearch) < a.maxlen + 2) ++nsearch;
 
@@ -339,11 +360,35 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     };
     auto store_inputs = [&](const InRegs &r) {
         reinterpret_cast<float4 *>(s_sig)[tid] = r.sig;  // the regions are 256 elements wide (launcher)
-        s_seq[tid] = r.seq;
+        s_seq[tid] = (unsigned char)r.seq < 4 ? r.seq : (int8_t)4;  // base codes 0..3, everything else (N, padding) = 4: missing
         s_map[tid] = r.map;
         if (tid < a.cb) s_len[tid] = (int16_t)(r.len < 0 ? 0 : (r.len > a.maxlen ? a.maxlen : r.len));
     };
     __syncthreads();  // the zero fill is done before the first inputs land
+    // column (chunk, position) -> operand row, once per block instead of a division and four multiply-adds per lane and
+    // tile pair: the column tiles of the M = 64 layers run across chunk boundaries
+    for (int col = tid; col < a.cb * a.P3; col += 256) {
+        const int ch = fdiv(col, a.d_P3), p3 = col - ch * a.P3;
+        s_col3[col] = make_int2((ch * a.P2 + 3 * p3) * 32, (ch * a.P1 + 3 * p3) * 32);
+    }
+    for (int col = tid; col < a.cb * a.T; col += 256) {
+        const int ch = fdiv(col, a.d_T);
+        s_col4[col] = (ch * a.P3 + (col - ch * a.T)) * 80;
+    }
+    // one-hot pieces: entry (b0 | b1 << 3) = the 8 channels of two neighbouring k-mer slots holding base codes b0, b1
+    // (0..3 = A, C, G, T -> 1.0 in that channel, 4 = missing -> zeros); 12 instructions per piece when computed in place
+    // (read from the first S1 on, behind the barrier at the top of the iteration)
+    if (tid < 64) {
+        constexpr unsigned ONE = F16 ? 0x3C00u : 0x3F80u;  // 1.0 in half / bf16
+        const unsigned b0 = tid & 7u, b1c = tid >> 3;
+        const unsigned one0 = ONE << ((b0 & 1u) * 16), one1 = ONE << ((b1c & 1u) * 16);
+        uint4 v;
+        v.x = (b0 >> 1) == 0 ? one0 : 0u;
+        v.y = (b0 >> 1) == 1 ? one0 : 0u;
+        v.z = (b1c >> 1) == 0 ? one1 : 0u;
+        v.w = (b1c >> 1) == 1 ? one1 : 0u;
+        s_tab[tid] = v;
+    }
     store_inputs(fetch_inputs(blockIdx.x));
 
     TS_DECL;
@@ -388,27 +433,33 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             }
             const int p = lo - 1;
             const bool valid = p >= 0 && p < len;
-            const int8_t *sq = s_seq + ci * a.seq_w + (valid ? p : 0);
-            unsigned code = 0;
-#pragma unroll
-            for (int kp = 0; kp < K; ++kp) {
-                const int b = sq[kp];
-                code |= (unsigned)((valid && b >= 0 && b < 4) ? b : 4) << (3 * kp);
-            }
+            // the K base codes (one byte each, 0..4) squeezed to 3 bits each: two shift-or-mask steps per four bytes
+            const unsigned char *sq = reinterpret_cast<const unsigned char *>(s_seq) + ci * a.seq_w + (valid ? p : 0);
+            unsigned w0, w1;
+            __builtin_memcpy(&w0, sq, 4);
+            __builtin_memcpy(&w1, sq + 4, 4);  // (K < 8: bytes of the following bases, masked off below)
+            auto squeeze = [](unsigned wv) {
+                const unsigned x = (wv | (wv >> 5)) & 0x003F003Fu;
+                return (x | (x >> 10)) & 0xFFFu;
+            };
+            unsigned code = squeeze(w0) | (squeeze(w1) << 12);
+            if (K > 8) code |= (unsigned)sq[8] << 24;
+            constexpr unsigned KMASK = (1u << (3 * K)) - 1u, ALL_MISSING = 0x24924924u & KMASK;  // 4 in every 3-bit slot
+            code = valid ? (code & KMASK) : ALL_MISSING;
+            if (K & 1) code |= 4u << (3 * K);  // the odd k-mer's last piece has no second base
+            // slots 2cg, 2cg+1 of the k-mer by their two codes; all pieces are read before the first is written (the
+            // compiler cannot tell that table and rows never overlap, and would wait for every read in turn)
+            static_assert(CG <= 5, "pieces p0..p4");
+            auto piece = [&](int cg) { return s_tab[(code >> (6 * cg)) & 63u]; };
+            const uint4 p0 = piece(0), p1 = piece(CG > 1 ? 1 : 0), p2 = piece(CG > 2 ? 2 : 0), p3 = piece(CG > 3 ? 3 : 0),
+                        p4 = piece(CG > 4 ? 4 : 0);
             unsigned char *dst = s_oh + (size_t)row * 16;
-#pragma unroll
-            for (int cg = 0; cg < CG; ++cg) {
-                const unsigned b0 = (code >> (6 * cg)) & 7u;
-                const unsigned b1c = 2 * cg + 1 < K ? ((code >> (6 * cg + 3)) & 7u) : 4u;
-                constexpr unsigned ONE = F16 ? 0x3C00u : 0x3F80u;  // 1.0 in half / bf16
-                const unsigned one0 = ONE << ((b0 & 1u) * 16), one1 = ONE << ((b1c & 1u) * 16);
-                uint4 v;
-                v.x = (b0 >> 1) == 0 ? one0 : 0u;
-                v.y = (b0 >> 1) == 1 ? one0 : 0u;
-                v.z = (b1c >> 1) == 0 ? one1 : 0u;
-                v.w = (b1c >> 1) == 1 ? one1 : 0u;
-                *reinterpret_cast<uint4 *>(dst + (size_t)cg * a.oh_plane) = v;
-            }
+            auto put = [&](int cg, const uint4 &v) { *reinterpret_cast<uint4 *>(dst + (size_t)cg * a.oh_plane) = v; };
+            put(0, p0);
+            if (CG > 1) put(1, p1);
+            if (CG > 2) put(2, p2);
+            if (CG > 3) put(3, p3);
+            if (CG > 4) put(4, p4);
         }
         TS(1);
         __syncthreads();
@@ -429,10 +480,11 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             // pairs: 2 MFMAs): every wave gets the same number of each (+-1).  Striping the chunk-major list instead gave
             // waves 1 and 3 twice the seq_conv1 pairs of waves 0 and 2 (6 items per chunk against a stride of 4).
             const int n_seq_items = (ABL(8) ? 0 : nch) * pairs_seq1, n_items = (ABL(8) ? 0 : nch) * pairs_chunk;
-            for (int item = w; item < n_items; item += 4) {
+            // (the item and what follows from it are wave-uniform: scalar registers, a multiply-high for the division)
+            for (int item = wu; item < n_items; item += 4) {
                 const bool is_sig = item >= n_seq_items;
                 const int j = is_sig ? item - n_seq_items : item;
-                const int ci = fdiv(j, is_sig ? d_ps2 : d_pq1), r = j - ci * (is_sig ? pairs_sig2 : pairs_seq1);
+                const int ci = (int)__umulhi((unsigned)j, is_sig ? a.mg_ps2 : a.mg_pq1), r = j - ci * (is_sig ? pairs_sig2 : pairs_seq1);
                 if (is_sig) {
                     int pos0 = 32 * r + nn, pos1 = pos0 + 16;
                     const bool v0 = pos0 < a.P2, v1 = pos1 < a.P2;
@@ -511,17 +563,16 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 }
             }
 #else
+            const unsigned char *sig2_q = s_sig2 + 16 * q, *seq1_q = s_seq1 + 16 * q;
+            auto col_of = [&](int c) { return c < ncols ? c : ncols - 1; };  // columns past the end repeat the last one
+            int2 e0 = s_col3[col_of(nn)], e1 = s_col3[col_of(nn + 16)];      // (entries of the next pair are read a pair ahead)
             for (int tile = 0; tile < ntiles; tile += 2) {
-                int col0 = tile * 16 + nn, col1 = col0 + 16;
+                const int col0 = tile * 16 + nn, col1 = col0 + 16;
                 const bool v0 = col0 < ncols, v1 = col1 < ncols;
-                col0 = v0 ? col0 : ncols - 1;
-                col1 = v1 ? col1 : ncols - 1;
-                const int ch0 = fdiv(col0, a.d_P3), ch1 = fdiv(col1, a.d_P3);
-                const int p0 = col0 - ch0 * a.P3, p1 = col1 - ch1 * a.P3;
-                const unsigned char *g0 = s_sig2 + (size_t)(ch0 * a.P2 + 3 * p0) * 32 + 16 * q;
-                const unsigned char *g1 = s_sig2 + (size_t)(ch1 * a.P2 + 3 * p1) * 32 + 16 * q;
-                const unsigned char *q0 = s_seq1 + (size_t)(ch0 * a.P1 + 3 * p0) * 32 + 16 * q;
-                const unsigned char *q1 = s_seq1 + (size_t)(ch1 * a.P1 + 3 * p1) * 32 + 16 * q;
+                const unsigned char *g0 = sig2_q + e0.x, *g1 = sig2_q + e1.x;
+                const unsigned char *q0 = seq1_q + e0.y, *q1 = seq1_q + e1.y;
+                e0 = s_col3[col_of(col0 + 32)];
+                e1 = s_col3[col_of(col1 + 32)];
                 f32x4 as0 = b_sig3, as1 = b_sig3, aq0 = b_seq2, aq1 = b_seq2;
                 if (tile + 1 < ntiles) s3_pair<F16, true>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);  // wave-uniform
                 else s3_pair<F16, false>(Asig3, Aseq2, g0, g1, q0, q1, as0, as1, aq0, aq1);
@@ -552,14 +603,14 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             const int ntiles = ABL(32) ? 0 : (ncols + 15) >> 4;
             uint16_t *xo = a.x + (size_t)chunk0 * a.T * 64 + 16 * w + 4 * q;
             const unsigned char *cat_r = s_cat + (size_t)q * a.cat_plane;
+            auto col_of = [&](int c) { return c < ncols ? c : ncols - 1; };
+            int c0 = s_col4[col_of(nn)], c1 = s_col4[col_of(nn + 16)];
             for (int tile = 0; tile < ntiles; tile += 2) {
-                int col0 = tile * 16 + nn, col1 = col0 + 16;
+                const int col0 = tile * 16 + nn, col1 = col0 + 16;
                 const bool v0 = col0 < ncols, v1 = col1 < ncols;
-                col0 = v0 ? col0 : ncols - 1;
-                col1 = v1 ? col1 : ncols - 1;
-                const int ch0 = fdiv(col0, a.d_T), ch1 = fdiv(col1, a.d_T);
-                const unsigned char *r0 = cat_r + (size_t)(ch0 * a.P3 + (col0 - ch0 * a.T)) * 80;
-                const unsigned char *r1 = cat_r + (size_t)(ch1 * a.P3 + (col1 - ch1 * a.T)) * 80;
+                const unsigned char *r0 = cat_r + c0, *r1 = cat_r + c1;
+                c0 = s_col4[col_of(col0 + 32)];
+                c1 = s_col4[col_of(col1 + 32)];
                 f32x4 acc0 = b_m1, acc1 = b_m1;
 #if RMR_FUSED_S4_LEAN
                 if (tile + 1 < ntiles) s4_pair_lean<F16, true>(Am1, r0, r1, acc0, acc1);  // wave-uniform
@@ -596,6 +647,9 @@ static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs 
         a.o_seq = off; off += 256;
         a.o_map = off; off += 512;
         a.o_len = off; off += 16;
+        a.o_tab = off; off += 64 * 16;  // the 16-byte one-hot piece of every pair of base codes
+        a.o_col3 = off; off += up16(cb * a.P3 * 8);  // per output column of S3 / S4: where its operand rows begin
+        a.o_col4 = off; off += up16(cb * a.T * 4);
         a.o_sig1 = off; off += up16((cb * a.P1 + 8) * 8);
         a.o_sig2 = off; off += (cb * a.P2 + 4) * 32;
         a.o_seq1 = off; off += (cb * a.P1 + 4) * 32;
@@ -637,10 +691,12 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     int total = 0;
     const int cb = fused_front_plan(m, seq_w, map_w, a, total);
     if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "fused front: one chunk of %d samples (sequence width %d) does not fit (%d B of LDS)", a.L, seq_w, total);
-    a.o_pidx = a.o_code = 0;
     a.cb = cb; a.lds_bytes = total;
     a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);
     a.d_maxlen = make_fastdiv(a.maxlen);
+    auto magic = [](int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };  // exact for x * d < 2^32
+    a.mg_ps2 = magic((((a.P2 + 15) >> 4) + 1) >> 1);
+    a.mg_pq1 = magic((((a.P1 + 15) >> 4) + 1) >> 1);
     a.abl = tune_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
 #ifdef RMR_TIMING_ABLATIONS
     const bool stage_clock = tune_int("RMR_FUSED_STAGE_CLOCK", 0) != 0;

@@ -54,6 +54,30 @@ __device__ __forceinline__ float lstm_cell(const f32x4 acc, float &c) {
     return og * tc;
 }
 
+// The lane's TWO units at once: everything that is not an exp or a rcp works on register pairs (v_pk_add_f32,
+// v_pk_fma_f32, v_pk_mul_f32: 11 packed + 20 transcendental instructions instead of 22 + 20; the VALU is this kernel's
+// bound).  Packed and scalar fp32 operations round alike: same bits as two lstm_cell calls.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RMR_LSTM_PAIRS
+#define RMR_LSTM_PAIRS 1
+#endif
+__device__ __forceinline__ f32x2 exp2_2(const f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+__device__ __forceinline__ f32x2 rcp_2(const f32x2 v) { return f32x2{fast_rcp(v.x), fast_rcp(v.y)}; }
+__device__ __forceinline__ f32x2 lstm_cell2(const f32x4 acc0, const f32x4 acc1, float &c0, float &c1) {
+    if (!RMR_LSTM_PAIRS) return f32x2{lstm_cell(acc0, c0), lstm_cell(acc1, c1)};
+    const f32x2 ig = rcp_2(exp2_2(f32x2{acc0[0], acc1[0]}) + 1.0f);
+    const f32x2 fg = rcp_2(exp2_2(f32x2{acc0[1], acc1[1]}) + 1.0f);
+    const f32x2 gr = rcp_2(exp2_2(f32x2{acc0[2], acc1[2]}) + 1.0f);
+    const f32x2 og = rcp_2(exp2_2(f32x2{acc0[3], acc1[3]}) + 1.0f);
+    const f32x2 gg = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, gr, f32x2{1.0f, 1.0f});
+    const f32x2 c = __builtin_elementwise_fma(fg, f32x2{c0, c1}, ig * gg);
+    c0 = c.x;
+    c1 = c.y;
+    const f32x2 tr = rcp_2(exp2_2(c * 2.8853900817779268f) + 1.0f);
+    const f32x2 tc = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, tr, f32x2{1.0f, 1.0f});
+    return og * tc;
+}
+
 template <bool F16>
 __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
     // B-operand images (8 bf16 = 16 B per slot): plane p = 8-channel group (channel / 8) % 4, slot = channel / 32,
@@ -123,8 +147,8 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
                 accN[u] = mfma16<F16>(Aih[u][0], bx0, bias[u]);
                 accN[u] = mfma16<F16>(Aih[u][1], bx1, accN[u]);
             }
-            float h0 = lstm_cell(acc[0], c[0]);
-            float h1 = lstm_cell(acc[1], c[1]);
+            const f32x2 hh = lstm_cell2(acc[0], acc[1], c[0], c[1]);
+            float h0 = hh.x, h1 = hh.y;
             if (t + 1 == a.T) {  // lstm2 consumes swish(h1[T-1]) (models/ConvLSTM_w_ref.py:52)
                 h0 = swish_f(h0);
                 h1 = swish_f(h1);
