@@ -538,17 +538,13 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             // two passes (sig_conv3, then seq_conv2): half the fragments in flight, so that three waves fit a SIMD
             for (int pass = 0; pass < 2; ++pass) {
                 const unsigned char *src = pass ? s_seq1 : s_sig2;
-                const int pin = pass ? a.P1 : a.P2;
                 const f32x4 bb = pass ? b_seq2 : b_sig3;
+                const unsigned char *src_q = src + 16 * q;
                 for (int tile = 0; tile < ntiles; tile += 2) {
-                    int col0 = tile * 16 + nn, col1 = col0 + 16;
+                    const int col0 = tile * 16 + nn, col1 = col0 + 16;
                     const bool v0 = col0 < ncols, v1 = col1 < ncols;
-                    col0 = v0 ? col0 : ncols - 1;
-                    col1 = v1 ? col1 : ncols - 1;
-                    const int ch0 = fdiv(col0, a.d_P3), ch1 = fdiv(col1, a.d_P3);
-                    const int p0 = col0 - ch0 * a.P3, p1 = col1 - ch1 * a.P3;
-                    const unsigned char *g0 = src + (size_t)(ch0 * pin + 3 * p0) * 32 + 16 * q;
-                    const unsigned char *g1 = src + (size_t)(ch1 * pin + 3 * p1) * 32 + 16 * q;
+                    const int2 e0 = s_col3[v0 ? col0 : ncols - 1], e1 = s_col3[v1 ? col1 : ncols - 1];
+                    const unsigned char *g0 = src_q + (pass ? e0.y : e0.x), *g1 = src_q + (pass ? e1.y : e1.x);
                     f32x4 a0 = bb, a1 = bb;
                     const bool two = tile + 1 < ntiles;  // wave-uniform
                     if (pass == 0) {

@@ -63,6 +63,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 __device__ __forceinline__ f32x2 exp2_2(const f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
 __device__ __forceinline__ f32x2 rcp_2(const f32x2 v) { return f32x2{fast_rcp(v.x), fast_rcp(v.y)}; }
+// Tried and dropped (profiles/r03_lstm_shared_rcp_ab.log): sharing reciprocals - sig(i) tanh(g) = (G - 1) / ((1 + A)(1 + G)),
+// sig(o) tanh(c) = (C - 1) / ((1 + O)(1 + C)), 5 exp + 3 rcp per unit instead of 5 + 5 - ran 2.42 against 2.37 ns/chunk: the
+// step is bound by the recurrent chain (h -> MFMA -> gates -> h), which the extra multiply in front of each rcp lengthens.
 __device__ __forceinline__ f32x2 lstm_cell2(const f32x4 acc0, const f32x4 acc1, float &c0, float &c1) {
     if (!RMR_LSTM_PAIRS) return f32x2{lstm_cell(acc0, c0), lstm_cell(acc1, c1)};
     const f32x2 ig = rcp_2(exp2_2(f32x2{acc0[0], acc1[0]}) + 1.0f);
