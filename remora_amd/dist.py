@@ -13,6 +13,19 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _single_forced():
+    """REMORA_AMD_DIST_SINGLE=1: a world of ONE rank still builds its process group and sends every helper below through
+    the backend's collectives (tests: the RCCL paths - device tensors, dtypes, object gathers - run on a 1-GPU box)."""
+    return os.environ.get("REMORA_AMD_DIST_SINGLE") == "1"
+
+
+def _collective():
+    """True when the helpers below have a process group to talk to (more than one rank, or the forced single rank)."""
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_forced())
+
+
 def shard_range(n, rank, world):
     """Contiguous [start, stop) of `n` units for `rank`; sizes differ by at most one."""
     base, rem = divmod(int(n), int(world))
@@ -29,12 +42,18 @@ def init_process_group(backend=None, set_device=True, timeout_s=None):
     import torch.distributed as dist
 
     rank, world, local = env_rank_world()
-    if world <= 1:
+    if world <= 1 and not _single_forced():
         return rank, world, local
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world <= 1 and "MASTER_PORT" not in os.environ:  # the forced single rank outside a launcher
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
         kw = {"timeout": datetime.timedelta(seconds=float(timeout_s))} if timeout_s else {}
@@ -50,7 +69,7 @@ def first_collective_ms():
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return 0.0
     t = torch.ones(1, dtype=torch.int64)
     if dist.get_backend() == "nccl":
@@ -70,7 +89,7 @@ def allgather_floats(xs):
     import torch.distributed as dist
 
     t = torch.tensor([float(x) for x in xs], dtype=torch.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return t.numpy()[None, :].copy()
     if dist.get_backend() == "nccl":
         t = t.cuda()
@@ -151,7 +170,7 @@ def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):
 def barrier():
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         dist.barrier()
 
 
@@ -160,7 +179,7 @@ def gather_objects(obj):
     names); [obj] for a single process.  Not a data-path collective."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return [obj]
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
@@ -173,7 +192,7 @@ def gather_arrays(arr):
     import torch.distributed as dist
 
     arr = np.ascontiguousarray(arr)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return arr
     on_gpu = dist.get_backend() == "nccl"
     n = torch.tensor([arr.shape[0]], dtype=torch.int64)
@@ -197,7 +216,7 @@ def allreduce_counts(counts):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return counts
     if isinstance(counts, np.ndarray):
         t = torch.from_numpy(np.ascontiguousarray(counts, np.int64))
@@ -219,7 +238,7 @@ def allreduce_max_float(x):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return float(x)
     t = torch.tensor([float(x)], dtype=torch.float64)
     if dist.get_backend() == "nccl":
@@ -235,7 +254,7 @@ def allgather_counts(counts):
     import torch.distributed as dist
 
     t = counts if hasattr(counts, "is_cuda") else torch.from_numpy(np.ascontiguousarray(counts, np.int64))
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return t.detach().cpu().numpy()[None, :].copy()
     if dist.get_backend() == "nccl":
         t = t.cuda() if not t.is_cuda else t

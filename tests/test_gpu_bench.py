@@ -107,3 +107,52 @@ def test_cabi_allreduce_counts_through_rccl():
         L.check(L.lib().rmr_comm_destroy(eng.handle))
     chk = rdist.cabi_allreduce_check(eng, np.array([[3, 4]], np.int64), 0, 1)
     assert chk["status"] == "ok" and chk["got"] == [3, 4], chk
+
+
+_ONE_RANK_RCCL = r'''
+import json, os, sys
+import numpy as np
+import torch
+from remora_amd import dist as rdist
+
+rank, world, local = rdist.init_process_group("nccl", timeout_s=120)
+import torch.distributed as dist
+out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "first_ms": rdist.first_collective_ms()}
+out["floats"] = rdist.allgather_floats([1.5, 2.5]).tolist()
+out["np_counts"] = rdist.allreduce_counts(np.array([3, 4, 5], np.int64)).tolist()
+c = torch.tensor([7, 8], dtype=torch.int64, device="cuda:0")
+out["cuda_counts"] = rdist.allreduce_counts(c).tolist()
+out["max"] = rdist.allreduce_max_float(2.25)
+out["rows"] = rdist.allgather_counts(c).tolist()
+out["objects"] = rdist.gather_objects({"ok": 3, None: 1})[0][None]
+out["arrays"] = rdist.gather_arrays(np.arange(6, dtype=np.float32).reshape(3, 2)).tolist()
+out["ints"] = rdist.gather_arrays(np.arange(4, dtype=np.int64)).tolist()
+rdist.barrier()
+# the sharded validation's global metrics use the same helpers
+from remora_amd.validate import ValidationLogger
+probs = np.array([[0.9, 0.1], [0.2, 0.8], [0.6, 0.4]], np.float32)
+m = ValidationLogger._global_metrics(probs, np.array([0, 1, 1]), np.array([0.1, 0.2, 0.9]), 0.1)
+out["acc"], out["calls"] = float(m.acc), int(m.num_calls)
+dist.destroy_process_group()
+print("\nRESULT " + json.dumps(out), flush=True)
+'''
+
+
+def test_torch_distributed_helpers_through_one_rank_rccl():
+    """Every dist.py helper the bench and the sharded product pipeline call, through torch.distributed's nccl (= RCCL)
+    backend with a process group of ONE rank (REMORA_AMD_DIST_SINGLE=1 lifts the single-process short cuts): device
+    placement of the tensors, the dtypes RCCL is asked to move (int64, float64, float32), all_gather_object and barrier on
+    the GPU backend.  What only more ranks can show - the ring over xGMI - stays the driver's 8-GPU run."""
+    env = dict(os.environ, REMORA_AMD_DIST_SINGLE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run([sys.executable, "-c", _ONE_RANK_RCCL], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    at = p.stdout.rfind("RESULT {")  # (RCCL's version banner shares stdout and does not always end its last line)
+    assert at >= 0, (p.stdout[-2000:], p.stderr[-2000:])
+    out = json.loads(p.stdout[at + 7:].splitlines()[0])
+    assert out["backend"] == "nccl" and out["world"] == 1 and out["first_ms"] > 0
+    assert out["floats"] == [[1.5, 2.5]] and out["np_counts"] == [3, 4, 5] and out["cuda_counts"] == [7, 8]
+    assert out["max"] == 2.25 and out["rows"] == [[7, 8]] and out["objects"] == 1
+    assert out["arrays"] == [[0.0, 1.0], [2.0, 3.0], [4.0, 5.0]] and out["ints"] == [0, 1, 2, 3]
+    assert abs(out["acc"] - 2 / 3) < 1e-12 and out["calls"] == 3

@@ -1860,3 +1860,24 @@ def test_native_mm_ml_and_record_rewrite_match_the_python_forms(tmp_path):
             want_recs.append(rio.record_with_mod_tags(recs[i], w_mm, w_ml) if sizes[i] else rio.record_with_mod_tags(recs[i], None, None))
         got = rio.records_with_mod_tags_batch(recs, mm, mm_off, ml, ml_off, np.asarray(sizes) > 0)
         assert got == b"".join(want_recs), mod_bases
+
+
+def test_forced_single_rank_process_group_gloo():
+    """REMORA_AMD_DIST_SINGLE=1 (what tests/test_gpu_bench.py uses to send every dist.py helper through RCCL on a 1-GPU
+    box): a world of one rank builds its process group and the helpers go through the backend instead of short-cutting."""
+    code = ("import numpy as np\nfrom remora_amd import dist as rdist\nimport torch.distributed as dist\n"
+            "rdist.init_process_group('gloo', timeout_s=60)\n"
+            "assert dist.is_initialized() and dist.get_world_size() == 1 and rdist._collective()\n"
+            "assert rdist.first_collective_ms() > 0\n"
+            "assert rdist.allreduce_counts(np.array([3, 4], np.int64)).tolist() == [3, 4]\n"
+            "assert rdist.gather_objects('x') == ['x'] and rdist.allgather_floats([1.0]).tolist() == [[1.0]]\n"
+            "assert rdist.gather_arrays(np.arange(3)).tolist() == [0, 1, 2]\n"
+            "rdist.barrier()\ndist.destroy_process_group()\nprint('OK')\n")
+    env = dict(os.environ, REMORA_AMD_DIST_SINGLE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
+    # without the switch a single process never touches torch.distributed
+    from remora_amd import dist as rdist
+
+    assert not rdist._single_forced() and not rdist._collective() and rdist.first_collective_ms() == 0.0
