@@ -26,23 +26,70 @@ struct EncodeArgs {
     float inv_L;
 };
 
+// PF = the wave carries the mapping and sequence rows of its NEXT chunk from HBM in registers (map_w, seq_w <= 64 * PF
+// elements): the loads leave before the current chunk's stores, so the `s_waitcnt vmcnt` in front of their use counts
+// past the 4K*L/256 stores issued after them - the loop never waits for a store to land.  (The first version bisected
+// the mapping row in HBM: every step a dependent global load whose vmcnt(0) also drained the previous chunk's stores.)
+// PF = 0: rows of any width, read where they are needed.
+// NST = the 16-byte stores a lane issues per chunk, ceil(K L / 64), as a compile-time count: gfx950 has ONE counter for
+// loads and stores, retired in order, and only with the store loop unrolled can the compiler wait for "all but the NST
+// newest" instead of "all" (NST = 0: any shape, a plain loop, and with PF the conservative wait).
+template <int PF, int NST>
 __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
     // one WAVE per chunk: the wave's LDS slice is private, so only wave-level ordering is needed
     // and the four waves of a block stream their 14 KB of stores independently
     const int Lp = (a.L + 7) & ~7;
-    const int per_wave = (Lp * 2 + ((a.seq_w + 15) & ~15) + 15) & ~15;  // bytes
+    const int mapb = PF ? ((a.map_w * 2 + 15) & ~15) : 0;
+    const int per_wave = (Lp * 2 + ((a.seq_w + 15) & ~15) + mapb + 15) & ~15;  // bytes
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     char *base = reinterpret_cast<char *>(smem_i) + (size_t)wv * per_wave;
     int16_t *s_pidx = reinterpret_cast<int16_t *>(base);   // [Lp]
     int8_t *s_seq = reinterpret_cast<int8_t *>(base + Lp * 2);  // [seq_w]
+    int16_t *s_map = reinterpret_cast<int16_t *>(base + Lp * 2 + ((a.seq_w + 15) & ~15));  // [map_w] (PF only)
     const int total = 4 * a.K * a.L;       // floats per chunk (multiple of 4)
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+    constexpr int NP = PF ? PF : 1;
+    int16_t r_map[NP];
+    int8_t r_seq[NP];
+    int r_len = 0;
+    auto prefetch = [&](int64_t c) {  // (clamped indices instead of predicates: no branch between the loads)
+        if (!PF || c >= a.n) return;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int j = lane + 64 * k;
+            r_map[k] = a.maps[(size_t)c * a.map_w + (j < a.map_w ? j : a.map_w - 1)];
+            r_seq[k] = a.seqs[(size_t)c * a.seq_w + (j < a.seq_w ? j : a.seq_w - 1)];
+        }
+        r_len = a.lens[c];
+    };
+    auto to_lds = [&]() {  // the prefetched rows -> this wave's LDS slice
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int j = lane + 64 * k;
+            if (j < a.map_w) s_map[j] = r_map[k];
+            if (j < a.seq_w) s_seq[j] = r_seq[k];
+        }
+    };
+    int len = 0;
+    if (PF) {
+        prefetch(wave_id);
+        to_lds();
+        len = r_len;
+    }
     for (int64_t c = wave_id; c < a.n; c += n_waves) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int len = a.lens[c];
-        const int16_t *mp = a.maps + (size_t)c * a.map_w;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int16_t *mp;
+        if (PF) {
+            mp = s_map;
+            prefetch(c + n_waves);  // consumed at the END of this iteration, behind exactly NST stores
+        } else {
+            len = a.lens[c];
+            mp = a.maps + (size_t)c * a.map_w;
+            for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = a.seqs[(size_t)c * a.seq_w + j];
+        }
         for (int s = lane; s < a.L; s += 64) {
             int lo = 0, hi = len + 1;
             while (lo < hi) {
@@ -52,12 +99,11 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
             const int p = lo - 1;
             s_pidx[s] = (int16_t)((p >= 0 && p < len) ? p : -1);
         }
-        for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = a.seqs[(size_t)c * a.seq_w + j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float4 *dst = reinterpret_cast<float4 *>(a.out + (size_t)c * total);
-        for (int f = lane; f < total / 4; f += 64) {
+        auto put = [&](int f) {
             float v[4];
             const int e0 = 4 * f;
             int row = (int)(((float)e0 + 0.5f) * a.inv_L);
@@ -72,6 +118,21 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
             typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
             const nt_f32x4 ov = {v[0], v[1], v[2], v[3]};
             __builtin_nontemporal_store(ov, reinterpret_cast<nt_f32x4 *>(dst) + f);
+        };
+        if (NST) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int f = lane + 64 * i;
+                if (i + 1 < NST || f < total / 4) put(f);  // only the last round is partial
+            }
+        } else {
+            for (int f = lane; f < total / 4; f += 64) put(f);
+        }
+        if (PF) {  // the stores above read LDS when they were built: the slice can take the next chunk's rows
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            to_lds();
+            len = r_len;
         }
     }
 }
@@ -86,12 +147,24 @@ int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
     a.inv_L = 1.0f / (float)sig_len;
     if ((size_t)4 * a.K * sig_len >= (1u << 21)) RMR_FAIL(RMR_ERR_INVALID, "encode: chunk too large");
     const int Lp = (sig_len + 7) & ~7;
-    const size_t per_wave = ((size_t)Lp * 2 + ((seq_w + 15) & ~15) + 15) & ~(size_t)15;
+    const int wide = seq_w > map_w ? seq_w : map_w;
+    const int pf = tune_int("RMR_ENCODE_PREFETCH", 1) ? (wide <= 64 ? 1 : wide <= 128 ? 2 : wide <= 256 ? 4 : 0) : 0;
+    const size_t mapb = pf ? (((size_t)map_w * 2 + 15) & ~(size_t)15) : 0;
+    const size_t per_wave = ((size_t)Lp * 2 + ((seq_w + 15) & ~15) + mapb + 15) & ~(size_t)15;
     const size_t lds = per_wave * 4;
     int64_t grid = (int64_t)e->num_cus * 8;
     if (grid > (n + 3) / 4) grid = (n + 3) / 4;
     ProfScope ps(e, K_ENCODE);
-    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+    // the shapes of the shipped models' chunk contexts get an unrolled store loop; anything else the plain one
+    const int nst = (a.K * sig_len + 63) / 64;
+    void (*kern)(EncodeArgs) = pf == 1 ? encode_kernel<1, 0> : pf == 2 ? encode_kernel<2, 0> : pf == 4 ? encode_kernel<4, 0> : encode_kernel<0, 0>;
+    if (pf == 1 && tune_int("RMR_ENCODE_UNROLL", 1)) {
+        if (nst == 15) kern = encode_kernel<1, 15>;       // 9-mer, 100 samples
+        else if (nst == 29) kern = encode_kernel<1, 29>;  // 9-mer, 200 samples
+        else if (nst == 10) kern = encode_kernel<1, 10>;  // 6-mer, 100 samples
+        else if (nst == 19) kern = encode_kernel<1, 19>;  // 6-mer, 200 samples
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }

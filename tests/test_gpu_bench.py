@@ -156,3 +156,14 @@ def test_torch_distributed_helpers_through_one_rank_rccl():
     assert out["max"] == 2.25 and out["rows"] == [[7, 8]] and out["objects"] == 1
     assert out["arrays"] == [[0.0, 1.0], [2.0, 3.0], [4.0, 5.0]] and out["ints"] == [0, 1, 2, 3]
     assert abs(out["acc"] - 2 / 3) < 1e-12 and out["calls"] == 3
+
+
+def test_bench_one_rank_through_rccl_reproduces_the_plain_run():
+    """bench.py itself with its process group built over nccl for ONE rank (REMORA_AMD_DIST_SINGLE=1): the timed region's
+    all-reduce of the device-resident label counts, the max-over-ranks clock and the per-rank gather run through RCCL and
+    leave the numbers of the plain single-process run."""
+    plain, _ = _bench(["--gpus", "1"] + FAST)
+    forced, p = _bench(["--gpus", "1"] + FAST, env_extra={"REMORA_AMD_DIST_SINGLE": "1", "RANK": "0", "WORLD_SIZE": "1",
+                                                         "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1"})
+    assert forced["label_counts"] == plain["label_counts"] and forced["label_counts_per_rank"] == plain["label_counts_per_rank"]
+    assert forced["n_gpus"] == 1 and forced["value"] > 0
