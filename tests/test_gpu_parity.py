@@ -67,6 +67,29 @@ def test_encode_kmers_oracle_synth(torch_cuda, O, cfg):
     assert np.all(enc.sum(axis=(1, 2)) == (kb + ka + 1) * d["chunk_len"])
 
 
+@pytest.mark.parametrize("L,max_seq,kcb", [(100, 20, (4, 4)), (200, 40, (4, 4)), (100, 20, (2, 3)), (200, 40, (2, 3)),  # unrolled stores
+                                           (60, 12, (4, 4)), (300, 100, (4, 4)), (400, 200, (1, 1)), (640, 300, (4, 4))])
+def test_encode_kmers_every_kernel_form(torch_cuda, O, L, max_seq, kcb, monkeypatch):
+    """Every instantiation of the encode kernel against the oracle, bit for bit: rows prefetched in registers one, two
+    and four elements per lane (widths up to 64 / 128 / 256), rows read where needed (wider), the store loop unrolled
+    for the shipped shapes and plain for the others - and the round-2 form (RMR_ENCODE_PREFETCH=0) on the same inputs."""
+    from remora_amd import synth
+    from remora_amd.encoded_kmers import compute_encoded_kmer_batch
+
+    torch = torch_cuda
+    d = synth.synth_chunks(777, chunk_len=L, max_seq_len=max_seq, kmer_context_bases=kcb, cg_context=False, shard=11)
+    kb, ka = kcb
+    args = (d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+    ref = O.compute_encoded_kmer_batch(kb, ka, *args)
+    dev = [torch.from_numpy(a).cuda() for a in args]
+    got = compute_encoded_kmer_batch(kb, ka, *dev).cpu().numpy()
+    assert got.shape == ref.shape == (777, 4 * (kb + ka + 1), L) and np.array_equal(got, ref)
+    monkeypatch.setenv("RMR_ENCODE_UNROLL", "0")
+    assert np.array_equal(compute_encoded_kmer_batch(kb, ka, *dev).cpu().numpy(), ref)
+    monkeypatch.setenv("RMR_ENCODE_PREFETCH", "0")
+    assert np.array_equal(compute_encoded_kmer_batch(kb, ka, *dev).cpu().numpy(), ref)
+
+
 def test_encode_kmers_full_size_checksum(torch_cuda):
     """1M C100 chunks (BASELINE config size): per-chunk sum == kmer_len * L, every value in {0,1}."""
     from remora_amd import synth
