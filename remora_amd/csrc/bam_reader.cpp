@@ -11,6 +11,7 @@
 #include <zlib.h>
 
 #include <cctype>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -36,7 +37,8 @@ struct rmr_bam {
     std::vector<int64_t> voff;    // per record of the batch: BGZF virtual offset (file_off << 16 | offset in block)
     bool eof = false;
     // BGZF members are independent deflate streams: kSlots of them are read ahead and inflated by as many threads
-    static constexpr int kSlots = 8;
+    static constexpr int kSlots = 32;  // upper bound; `nslots` of them are in use
+    int nslots = 8;                    // RMR_BAM_INFLATE_THREADS at open (a launcher that scans for all of its ranks asks for more)
     struct Slot {
         std::vector<uint8_t> cbuf, out;
         uint32_t crc = 0, isize = 0;
@@ -156,7 +158,7 @@ void worker_loop(rmr_bam *b, int w) {
 // returns the number of members read (0 = clean EOF) or a negative error
 int next_blocks(rmr_bam *b) {
     int n = 0, rc = 1;
-    while (n < rmr_bam::kSlots) {
+    while (n < b->nslots) {
         rc = read_member(b, b->slot[n]);
         if (rc <= 0) break;
         ++n;
@@ -165,7 +167,7 @@ int next_blocks(rmr_bam *b) {
     if (n == 0) return 0;
     if (n > 1) {
         if (b->workers.empty()) {
-            for (int w = 1; w < rmr_bam::kSlots; ++w) b->workers.emplace_back(worker_loop, b, w);
+            for (int w = 1; w < b->nslots; ++w) b->workers.emplace_back(worker_loop, b, w);
         }
         {
             std::lock_guard<std::mutex> lk(b->mu);
@@ -323,6 +325,10 @@ int rmr_bam_open(const char *path, rmr_bam **out) {
     std::unique_ptr<rmr_bam> b(new rmr_bam());
     b->fh = fopen(path, "rb");
     if (!b->fh) RMR_FAIL(RMR_ERR_INVALID, "cannot open %s", path);
+    if (const char *ev = getenv("RMR_BAM_INFLATE_THREADS")) {
+        const int v = atoi(ev);
+        if (v >= 1) b->nslots = v > rmr_bam::kSlots ? rmr_bam::kSlots : v;
+    }
     auto fail = [&](int rc) {
         stop_workers(b.get());
         fclose(b->fh);

@@ -331,11 +331,17 @@ def write_bam_scan(bam_path, out_path, every=64):
     through REMORA_AMD_BAM_SCAN).  The file appears atomically; a scan that fails leaves a marker instead, and the ranks
     scan for themselves (and report the error in their own words)."""
     tmp = f"{out_path}.tmp{os.getpid()}"
+    prev = os.environ.get("RMR_BAM_INFLATE_THREADS")
     try:
+        if prev is None:  # this process has nothing else to do while its ranks start: every core it may use inflates
+            os.environ["RMR_BAM_INFLATE_THREADS"] = str(max(8, min(32, _eff_cpus())))
         marks, n = bam_scan(bam_path, every)
         payload = dict(key=_scan_key(bam_path, every), marks=marks, n=np.int64(n))
     except Exception:  # noqa: BLE001 - whatever it is, the ranks will meet it themselves
         payload = dict(key=np.zeros(3, np.int64), marks=np.zeros(0, np.int64), n=np.int64(-1))
+    finally:
+        if prev is None:
+            os.environ.pop("RMR_BAM_INFLATE_THREADS", None)
     with open(tmp, "wb") as fh:
         np.savez(fh, **payload)
     os.replace(tmp, out_path)
