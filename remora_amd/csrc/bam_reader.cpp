@@ -38,6 +38,7 @@ struct rmr_bam {
     bool eof = false;
     // BGZF members are independent deflate streams: kSlots of them are read ahead and inflated by as many threads
     static constexpr int kSlots = 32;  // upper bound; `nslots` of them are in use
+    bool check_crc = true;
     int nslots = 8;                    // RMR_BAM_INFLATE_THREADS at open (a launcher that scans for all of its ranks asks for more)
     struct Slot {
         std::vector<uint8_t> cbuf, out;
@@ -46,6 +47,7 @@ struct rmr_bam {
         int64_t file_off = 0;
         z_stream zs{};
         bool zs_init = false;
+        bool check = true;  // verify the member's CRC32 (off during rmr_bam_scan: whoever reads the records verifies them)
         int rc = 0;
     } slot[kSlots];
     // persistent inflate workers (creating threads per batch of members costs more than the inflate itself in a
@@ -131,7 +133,7 @@ void inflate_member(rmr_bam::Slot &sl) {
     sl.zs.next_out = sl.out.data();
     sl.zs.avail_out = sl.isize;
     if (inflate(&sl.zs, Z_FINISH) != Z_STREAM_END || sl.zs.avail_out != 0) { sl.rc = 1; return; }
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), sl.out.data(), sl.isize) != sl.crc) sl.rc = 2;
+    if (sl.check && (uint32_t)crc32(crc32(0L, Z_NULL, 0), sl.out.data(), sl.isize) != sl.crc) sl.rc = 2;
 }
 
 // worker w inflates slot w of every generation that has that many members
@@ -161,6 +163,7 @@ int next_blocks(rmr_bam *b) {
     while (n < b->nslots) {
         rc = read_member(b, b->slot[n]);
         if (rc <= 0) break;
+        b->slot[n].check = b->check_crc;
         ++n;
     }
     if (rc < 0) return rc;
@@ -521,6 +524,8 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
 int rmr_bam_scan(rmr_bam *b, int64_t every, int64_t *voffsets, int64_t cap, int64_t *n_records) {
     if (!b || !n_records || every < 1 || cap < 0 || (cap > 0 && !voffsets)) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
     int64_t n = 0;
+    // boundaries only: the record bytes are verified by whoever seeks here and reads them (this handle included, later)
+    struct NoCrc { rmr_bam *b; explicit NoCrc(rmr_bam *x) : b(x) { b->check_crc = false; } ~NoCrc() { b->check_crc = true; } } no_crc(b);
     for (;;) {
         int rc = ensure(b, 4);
         if (rc < 0) return rc;

@@ -98,41 +98,66 @@ def allgather_floats(xs):
     return torch.stack(out).cpu().numpy()
 
 
-def launch_ranks(argv, n, scan_bam=None):
-    """Start `n` ranks of `python -m remora_amd <argv>` on this node (one process per GPU; torch.distributed.run sets
-    RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on 127.0.0.1) and return the launcher's exit code.  Used by the CLI when
-    `--gpus N` is given outside torchrun.  `scan_bam`: while the ranks start (interpreter, torch, model load) this
-    process makes the one pass over that BAM which tells every rank where its share begins (io.write_bam_scan), instead
-    of each rank inflating the whole file for itself."""
+def launch_ranks(argv, n, scan_bam=None, command=None):
+    """Start `n` ranks of `python -m remora_amd <argv>` on this node (one process per GPU or several, rendezvous on
+    127.0.0.1) and return 0 when all of them did, else the first non-zero exit code (the other ranks are stopped).  Used by
+    the CLI when `--gpus N` is given outside a launcher.  The ranks are started directly with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment - what torch.distributed.run would set, without the two
+    seconds that launcher needs to import torch before it starts anything.  `scan_bam`: while the ranks start
+    (interpreter, torch, model load) this process makes the one pass over that BAM which tells every rank where its
+    share begins (io.write_bam_scan), instead of each rank inflating the whole file for itself.  `command` replaces
+    `python -m remora_amd` (tests)."""
     import socket
     import subprocess
     import sys
     import tempfile
+    import time
 
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "remora_amd"] + list(argv)
+    n = int(n)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     scan_path = None
     if scan_bam is not None:
         from .io import SCAN_ENV
 
         scan_path = os.path.join(tempfile.gettempdir(), f"remora_amd_scan_{os.getpid()}_{port}.npz")
         env[SCAN_ENV] = scan_path
-    proc = subprocess.Popen(cmd, env=env)
+    cmd = list(command or [sys.executable, "-m", "remora_amd"]) + list(argv)
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
     try:
         if scan_path is not None:
             from .io import write_bam_scan
 
             write_bam_scan(scan_bam, scan_path)
-        return proc.wait()
+        while True:  # a rank that fails takes the others with it (they would wait for it in the next collective)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                stop_all()
+                return bad[0]
+            if all(c == 0 for c in codes):
+                return 0
+            time.sleep(0.02)
     except BaseException:
-        proc.terminate()
+        stop_all()
         raise
     finally:
         if scan_path is not None and os.path.exists(scan_path):

@@ -1881,3 +1881,23 @@ def test_forced_single_rank_process_group_gloo():
     from remora_amd import dist as rdist
 
     assert not rdist._single_forced() and not rdist._collective() and rdist.first_collective_ms() == 0.0
+
+
+def test_launch_ranks_starts_the_ranks_itself_and_stops_them_together():
+    """dist.launch_ranks: N processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment (no
+    torch.distributed.run in between) that can build a process group and reduce; a rank that fails ends the launch with its
+    exit code and takes the waiting ranks with it."""
+    import time
+
+    from remora_amd import dist as rdist
+
+    ok = ("import os, sys\nimport numpy as np\nfrom remora_amd import dist as rdist\n"
+          "rank, world, local = rdist.init_process_group('gloo', timeout_s=60)\n"
+          "got = rdist.allreduce_counts(np.array([rank + 1, 10], np.int64)).tolist()\n"
+          "assert world == 3 and local == rank and got == [6, 30], (rank, world, local, got)\n"
+          "assert os.environ['LOCAL_WORLD_SIZE'] == '3' and sys.argv[1:] == ['--flag', 'x']\n")
+    assert rdist.launch_ranks(["--flag", "x"], 3, command=[sys.executable, "-c", ok]) == 0
+    bad = "import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(120)\n"
+    t0 = time.monotonic()
+    assert rdist.launch_ranks([], 3, command=[sys.executable, "-c", bad]) == 7
+    assert time.monotonic() - t0 < 30
