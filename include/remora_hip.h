@@ -184,6 +184,13 @@ int rmr_bam_seek(rmr_bam *b, int64_t voffset);
  * shard embarrassingly across the GPUs") - the reference hands reads out from ONE reader process instead
  * (src/remora/inference.py:488-519).  Leaves the handle at end of file: rmr_bam_seek before reading. */
 int rmr_bam_scan(rmr_bam *b, int64_t every, int64_t *voffsets, int64_t cap, int64_t *n_records);
+/* The virtual offset of the first record that starts in a BGZF member at or behind byte `file_offset` of the file, found
+ * WITHOUT the records in front of it (*voffset = -1: none); the handle is left there.  A position counts as a record start
+ * when the record and the records chained behind it pass every structural check of the format (field ranges against
+ * the header, printable name, CIGAR codes, a tag region that parses to block_size exactly).  With it N workers split a
+ * file by byte ranges in O(1) instead of one O(file) pass; the worker in front verifies each guess for certain (its
+ * own chain of records has to end on it).  Same reference counterpart as rmr_bam_scan. */
+int rmr_bam_guess_start(rmr_bam *b, int64_t file_offset, int64_t *voffset);
 
 /* ---- N3: the output side of `remora infer` for a batch of reads (host code) ----------------------------- */
 /* replaces: util.format_mm_ml_tags (src/remora/util.py:485-537) as inference.post_process_reads calls it per read

@@ -93,16 +93,17 @@ def _infer(args):
     from .inference import infer_from_pod5_and_bam
     from .model_util import load_torchscript_model
 
-    # this rank's share of the BAM: the marks of the launcher's pass over the file (or this rank's own pass under a foreign
-    # launcher) - awaited in a thread, under the model load instead of in front of the first batch
+    # this rank's share of the BAM, found in a thread under the model load.  By byte range (default): where the share and
+    # the next one begin is read off the bytes there (io.bam_byte_shard - no pass over the file, and the rank in front
+    # verifies the guess); REMORA_AMD_BAM_SHARD=scan: by record count from one exact pass (the launcher's, or this rank's own)
     erank, eworld, _ = rdist.env_rank_world()
     shard_future = None
     if eworld > 1:
         from concurrent.futures import ThreadPoolExecutor
 
-        from .io import bam_shard
+        from . import io as rio
 
-        shard_future = ThreadPoolExecutor(max_workers=1).submit(bam_shard, args.in_bam, erank, eworld)
+        shard_future = ThreadPoolExecutor(max_workers=1).submit(rio.shard_of, args.in_bam, erank, eworld)
     rank, world, dev = rdist.setup_ranks(args.gpus, args.procs_per_gpu)
     loaded = [load_torchscript_model(m, device=args.device if dev is None else dev, eval_only=True, dtype=args.dtype)
               for m in args.model]
@@ -211,7 +212,8 @@ def main(argv=None):
     if nranks > 1 and "WORLD_SIZE" not in os.environ:
         from .dist import launch_ranks
 
-        scan_bam = args.in_bam if args.func is _infer else None
+        by_scan = os.environ.get("REMORA_AMD_BAM_SHARD", "bytes") == "scan"
+        scan_bam = args.in_bam if args.func is _infer and by_scan else None
         return launch_ranks(sys.argv[1:] if argv is None else list(argv), nranks, scan_bam=scan_bam)
     try:
         return args.func(args)

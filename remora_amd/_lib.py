@@ -71,6 +71,7 @@ SIGNATURES = {
     "rmr_bam_read_batch": (c_int, [c_vp, c_i64, c_int, c_vp]),
     "rmr_bam_seek": (c_int, [c_vp, c_i64]),
     "rmr_bam_scan": (c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    "rmr_bam_guess_start": (c_int, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "rmr_format_mm_ml": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.c_char_p, ctypes.c_char, ctypes.c_char, c_vp, c_i64,
                                  c_vp, c_vp, c_i64, c_vp]),
     "rmr_records_with_mod_tags": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]),

@@ -10,6 +10,7 @@
 // Host code only (no device work): plain C++17 + zlib, part of libremora_hip.so.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cstdlib>
 #include <cstdio>
@@ -59,6 +60,7 @@ struct rmr_bam {
     int n_active = 0, n_pending = 0;
     bool stop = false;
     std::vector<uint8_t> header;  // everything before the first record (magic, text, references)
+    int64_t first_voffset = -1;   // of the first record (-1: the file holds none)
     std::vector<std::string> refs;
     // batch arenas (valid until the next read_batch call)
     std::vector<int32_t> flag, ref_id, pos, mapq, l_seq, n_cigar, ts, ns, sp;
@@ -223,6 +225,122 @@ int ensure(rmr_bam *b, size_t n) {
 inline int32_t rd_i32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
 inline uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
+// BGZF virtual offset (member's file offset << 16 | offset inside the inflated member) of byte `pos` of ubuf
+int64_t voffset_at(const rmr_bam *b, size_t pos) {
+    for (const auto &sg : b->segs) {
+        const size_t rel = pos - sg.begin;  // (wraps for members in front of pos: then rel >= isize)
+        if (rel < sg.isize) return (sg.file_off << 16) | (int64_t)rel;
+    }
+    return -1;
+}
+
+// ---- where does a record start?  (rmr_bam_guess_start) ---------------------------------------------------
+// A worker that begins in the middle of the file needs a record boundary without walking the block_size chain from
+// the first record.  A position is accepted when a record AND the records chained behind it (kGuessChain of them, or
+// up to the end of the file) pass every check the format allows: field ranges against the header's reference count,
+// a printable NUL-terminated name, CIGAR operation codes, and a tag region that parses tag by tag and ends exactly
+// where block_size says.  The worker in front of this one verifies the guess for certain: its own chain of records
+// must END on it (io.py: a share that runs past its end mark is an error, never a silent overlap).
+constexpr int kGuessChain = 8;
+
+// length (4 + block_size) of a valid record at ubuf[q] (upos is 0 during the search), 0 = not a record here, < 0 = I/O error
+int64_t plausible_record(rmr_bam *b, size_t q) {
+    int rc = ensure(b, q + 36);
+    if (rc < 0) return rc;
+    if (rc == 0) return 0;
+    const uint8_t *r = b->ubuf.data() + q;
+    const int64_t bs = rd_i32(r), n_ref = (int64_t)b->refs.size();
+    const int64_t ref_id = rd_i32(r + 4), pos = rd_i32(r + 8), l_name = r[12], n_cig = r[16] | (r[17] << 8), l_seq = rd_i32(r + 20);
+    const int64_t nref_id = rd_i32(r + 24), npos = rd_i32(r + 28);
+    if (bs < 32 + 1 || bs > (1 << 28) || ref_id < -1 || ref_id >= n_ref || pos < -1 || l_name < 1 || l_seq < 0) return 0;
+    if (nref_id < -1 || nref_id >= n_ref || npos < -1) return 0;
+    const int64_t fixed = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq;
+    if (fixed > bs) return 0;
+    rc = ensure(b, q + 36 + (size_t)l_name);
+    if (rc < 0) return rc;
+    if (rc == 0) return 0;
+    r = b->ubuf.data() + q;
+    if (r[36 + l_name - 1] != 0) return 0;
+    for (int64_t i = 0; i + 1 < l_name; ++i)
+        if (r[36 + i] < 33 || r[36 + i] > 126) return 0;
+    rc = ensure(b, q + 4 + (size_t)bs);  // (only a position that looks like a record so far makes the window grow)
+    if (rc < 0) return rc;
+    if (rc == 0) return 0;
+    r = b->ubuf.data() + q;
+    const uint8_t *cig = r + 36 + l_name;
+    for (int64_t i = 0; i < n_cig; ++i)
+        if ((rd_u32(cig + 4 * i) & 0xF) > 8) return 0;
+    const uint8_t *t = r + 4 + fixed, *end = r + 4 + bs;
+    while (t < end) {
+        if (end - t < 4 || !isalpha(t[0]) || !isalnum(t[1])) return 0;
+        const char ty = (char)t[2];
+        t += 3;
+        int64_t sz;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': {
+                const void *z = memchr(t, 0, (size_t)(end - t));
+                if (!z) return 0;
+                sz = (const uint8_t *)z - t + 1;
+                break;
+            }
+            case 'B': {
+                if (end - t < 5) return 0;
+                int64_t el;
+                switch ((char)t[0]) {
+                    case 'c': case 'C': el = 1; break;
+                    case 's': case 'S': el = 2; break;
+                    case 'i': case 'I': case 'f': el = 4; break;
+                    default: return 0;
+                }
+                const int64_t cnt = rd_i32(t + 1);
+                if (cnt < 0) return 0;
+                sz = 5 + el * cnt;
+                break;
+            }
+            default: return 0;
+        }
+        if (sz > end - t) return 0;
+        t += sz;
+    }
+    return 4 + bs;
+}
+
+// 1 = a chain of records starts at ubuf[p], 0 = not, < 0 = I/O error
+int record_chain_at(rmr_bam *b, size_t p) {
+    size_t q = p;
+    for (int k = 0; k < kGuessChain; ++k) {
+        const int rc = ensure(b, q + 1);
+        if (rc < 0) return rc;
+        if (rc == 0) return (k > 0 && q == b->ubuf.size()) ? 1 : 0;  // the file ends behind a record: as good as a chain
+        const int64_t len = plausible_record(b, q);
+        if (len < 0) return (int)len;
+        if (len == 0) return 0;
+        q += (size_t)len;
+    }
+    return 1;
+}
+
+// a BGZF member header at buf[i] (n bytes available): its total size, or 0
+int member_size_at(const uint8_t *buf, size_t n, size_t i) {
+    if (i + 18 > n || buf[i] != 0x1f || buf[i + 1] != 0x8b || buf[i + 2] != 8 || !(buf[i + 3] & 4)) return 0;
+    const int xlen = buf[i + 10] | (buf[i + 11] << 8);
+    if (i + 12 + (size_t)xlen > n) return 0;
+    for (int p = 0; p + 4 <= xlen;) {
+        const uint8_t *e = buf + i + 12 + p;
+        const int slen = e[2] | (e[3] << 8);
+        if (e[0] == 'B' && e[1] == 'C' && slen == 2 && p + 6 <= xlen) {
+            const int bsize = (e[4] | (e[5] << 8)) + 1;
+            return bsize >= xlen + 20 ? bsize : 0;
+        }
+        p += 4 + slen;
+    }
+    return 0;
+}
+
+
 const char NT16[] = "=ACMGRSVTWYHKDBN";
 
 // size in bytes of a tag value at p (type t); -1 on error / overrun
@@ -360,6 +478,9 @@ int rmr_bam_open(const char *path, rmr_bam **out) {
     }
     b->header.assign(b->ubuf.begin(), b->ubuf.begin() + (ptrdiff_t)p);
     b->upos = p;
+    rc = ensure(b.get(), 1);
+    if (rc < 0) return fail(rc);
+    b->first_voffset = rc == 0 ? -1 : voffset_at(b.get(), b->upos);
     *out = b.release();
     return 0;
 }
@@ -551,6 +672,55 @@ int rmr_bam_scan(rmr_bam *b, int64_t every, int64_t *voffsets, int64_t cap, int6
     }
     *n_records = n;
     return 0;
+}
+
+// The virtual offset of the first record that starts in a BGZF member at or behind byte `file_offset` of the file
+// (-1: none), found without the records in front of it: see plausible_record above.  Leaves the handle there.
+int rmr_bam_guess_start(rmr_bam *b, int64_t file_offset, int64_t *voffset) {
+    if (!b || !voffset || file_offset < 0) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    *voffset = -1;
+    if (b->first_voffset < 0) return 0;
+    if (file_offset <= (b->first_voffset >> 16)) {
+        *voffset = b->first_voffset;
+        return rmr_bam_seek(b, b->first_voffset);
+    }
+    if (fseeko(b->fh, 0, SEEK_END) != 0) RMR_FAIL(RMR_ERR_INVALID, "seek failed");
+    const int64_t fsize = (int64_t)ftello(b->fh);
+    if (file_offset >= fsize) return 0;
+    // the next member boundary: a header whose size leads to another header (or to the end of the file)
+    std::vector<uint8_t> buf((size_t)std::min<int64_t>(fsize - file_offset, 3 * 65536 + 64));
+    if (fseeko(b->fh, (off_t)file_offset, SEEK_SET) != 0 || fread(buf.data(), 1, buf.size(), b->fh) != buf.size())
+        RMR_FAIL(RMR_ERR_INVALID, "read failed");
+    int64_t member = -1;
+    for (size_t i = 0; i < buf.size() && i <= 65536; ++i) {
+        const int sz = member_size_at(buf.data(), buf.size(), i);
+        if (!sz) continue;
+        const size_t nx = i + (size_t)sz;
+        if (file_offset + (int64_t)nx == fsize || member_size_at(buf.data(), buf.size(), nx)) { member = file_offset + (int64_t)i; break; }
+    }
+    if (member < 0) {
+        if (file_offset + (int64_t)buf.size() == fsize && buf.size() <= 65536) return 0;  // inside the last member: nothing starts behind it
+        RMR_FAIL(RMR_ERR_INVALID, "no BGZF block boundary within 64 KiB of offset %lld", (long long)file_offset);
+    }
+    if (fseeko(b->fh, (off_t)member, SEEK_SET) != 0) RMR_FAIL(RMR_ERR_INVALID, "seek failed");
+    b->ubuf.clear();
+    b->segs.clear();
+    b->upos = 0;
+    b->eof = false;
+    const size_t limit = (size_t)1 << 29;  // a record and its chain within 512 MiB of inflated data, or the file is something else
+    for (size_t p = 0;; ++p) {
+        int rc = ensure(b, p + 1);
+        if (rc < 0) return rc;
+        if (rc == 0) return 0;  // nothing starts behind file_offset
+        rc = record_chain_at(b, p);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            *voffset = voffset_at(b, p);
+            b->upos = p;
+            return 0;
+        }
+        if (p > limit) RMR_FAIL(RMR_ERR_INVALID, "no alignment record found behind offset %lld", (long long)file_offset);
+    }
 }
 
 int rmr_bam_seek(rmr_bam *b, int64_t voffset) {

@@ -278,10 +278,11 @@ class _NativeBamRecord(BamRecord):
         return self._ref_seq
 
 
-def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None, start_voffset=None, max_records=None):
+def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None, start_voffset=None, max_records=None, end_voffset=None):
     """Records of a BAM file from the native reader; with `voffsets` only the records at those virtual offsets
-    (one seek + one record each); with `start_voffset` / `max_records` the contiguous run of records that starts
-    there (a rank's share of the file, `bam_shard`); otherwise the whole file in order."""
+    (one seek + one record each); with `start_voffset` and `max_records` / `end_voffset` the contiguous run of records
+    that starts there (a rank's share of the file: `bam_shard` counts records, `bam_byte_shard` names the record the
+    next share begins with - a run that passes that record without meeting it is an error); otherwise the whole file."""
     lib = L.lib()
     h = ctypes.c_void_p()
     L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
@@ -293,9 +294,61 @@ def _iter_bam_records_native(bam_path, want_ref, batch, voffsets=None, start_vof
             return
         if start_voffset is not None:
             L.check(lib.rmr_bam_seek(h, int(start_voffset)))
-        yield from _native_batches(lib, h, want_ref, batch, limit=max_records)
+        if end_voffset is None:
+            yield from _native_batches(lib, h, want_ref, batch, limit=max_records)
+            return
+        end_voffset = int(end_voffset)
+        for rec in _native_batches(lib, h, want_ref, batch):
+            if rec.voffset >= end_voffset:
+                if rec.voffset != end_voffset:
+                    raise RemoraError(f"{bam_path}: the records of this share run past virtual offset {end_voffset} without one "
+                                      f"starting there - the next share's start was guessed wrong (REMORA_AMD_BAM_SHARD=scan "
+                                      f"splits by an exact pass over the file instead)")
+                return
+            yield rec
+        raise RemoraError(f"{bam_path}: end of file before the record at virtual offset {end_voffset} where the next share begins")
     finally:
         lib.rmr_bam_close(h)
+
+
+def bam_guess_start(bam_path, file_offset):
+    """Virtual offset of the first record that starts in a BGZF member at or behind byte `file_offset` of the file, or
+    None (rmr_bam_guess_start: found from the bytes there, not from the records in front)."""
+    lib = L.lib()
+    h = ctypes.c_void_p()
+    L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+    try:
+        v = ctypes.c_int64()
+        L.check(lib.rmr_bam_guess_start(h, int(file_offset), ctypes.byref(v)))
+        return None if v.value < 0 else int(v.value)
+    finally:
+        lib.rmr_bam_close(h)
+
+
+def shard_of(bam_path, rank, world):
+    """What `iter_bam_records(shard=...)` reads for (rank, world): ("bytes", start, end) - a share by byte range
+    (`bam_byte_shard`, the default) - or, with REMORA_AMD_BAM_SHARD=scan, (start, n_records) from one exact pass over
+    the file (`bam_shard`)."""
+    if os.environ.get("REMORA_AMD_BAM_SHARD", "bytes") == "scan":
+        return bam_shard(bam_path, rank, world)
+    return ("bytes",) + bam_byte_shard(bam_path, rank, world)
+
+
+def bam_byte_shard(bam_path, rank, world):
+    """(start_voffset, end_voffset) of rank `rank`'s share when `world` workers split `bam_path` by BYTE ranges: the
+    records that start in BGZF members at or behind byte size * rank / world and in front of size * (rank + 1) / world.
+    No pass over the file and no coordinator: both ends come from `bam_guess_start`, a pure function of the file, so
+    rank r's end IS rank r + 1's start.  end None = to the end of the file; start None = nothing for this rank.  The
+    guess is verified by the worker in front: its chain of records, exact from the file's first record on, has to end
+    on it (`_iter_bam_records_native`)."""
+    if world <= 1:
+        return bam_guess_start(bam_path, 0), None
+    size = os.path.getsize(bam_path)
+    start = bam_guess_start(bam_path, size * int(rank) // int(world))
+    if start is None:
+        return None, None
+    end = None if rank == world - 1 else bam_guess_start(bam_path, size * (int(rank) + 1) // int(world))
+    return (None, None) if end is not None and end == start else (start, end)
 
 
 def bam_scan(bam_path, every=64):
@@ -613,13 +666,20 @@ def iter_bam_records(bam_path, want_ref=False, batch=512, native=True, shard=Non
     """Yield a BamRecord for every alignment of a BAM file, streaming.  By default the records come from the native
     reader (rmr_bam_read_batch: BGZF inflate, record split, hot tags and - with want_ref - the MD reconstruction in
     C++, `batch` records per call); native=False is the pure-Python reader the native one is tested against.
-    `shard=(rank, world)`: only that rank's contiguous share of the records (`bam_shard`)."""
+    `shard=(rank, world)`: only that rank's contiguous share of the records (`shard_of`: by byte range, or by record
+    count with REMORA_AMD_BAM_SHARD=scan); or a future of such a result, started earlier."""
     if shard is not None and (hasattr(shard, "result") or int(shard[1]) > 1):
         if not native:
             raise RemoraError("sharded reading needs the native BAM reader")
         # (rank, world), or a future of bam_shard's result started earlier (the scan of a large file takes seconds: a
         # caller overlaps it with its own start-up, e.g. the model load of `infer --gpus N`)
-        start, count = shard.result() if hasattr(shard, "result") else bam_shard(bam_path, int(shard[0]), int(shard[1]))
+        got = shard.result() if hasattr(shard, "result") else shard_of(bam_path, int(shard[0]), int(shard[1]))
+        if len(got) == 3:  # ("bytes", start, end): a share by byte range (bam_byte_shard)
+            _, start, end = got
+            if start is not None:
+                yield from _iter_bam_records_native(bam_path, want_ref, batch, start_voffset=start, end_voffset=end)
+            return
+        start, count = got
         if count is None:  # a single worker: the whole file
             yield from _iter_bam_records_native(bam_path, want_ref, batch)
             return

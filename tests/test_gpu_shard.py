@@ -41,8 +41,10 @@ def _mint(tmp_path, g):
     return pt
 
 
-@pytest.mark.parametrize("prefix,anchored", [("can", False), ("mod", True)])
-def test_infer_cli_two_ranks_equal_one_rank(tmp_path, prefix, anchored):
+@pytest.mark.parametrize("prefix,anchored,split", [("can", False, "bytes"), ("mod", True, "bytes"), ("can", False, "scan")])
+def test_infer_cli_two_ranks_equal_one_rank(tmp_path, prefix, anchored, split):
+    """Two ranks (shares of the BAM by byte range - the default - or by an exact scan of the launcher's) write the
+    single-process output byte for byte."""
     from remora_amd import io as rio
 
     pt = _mint(tmp_path, golden("real_reads_can.npz"))  # the CG 5mC model that calls both halves of configs[0]
@@ -50,7 +52,7 @@ def test_infer_cli_two_ranks_equal_one_rank(tmp_path, prefix, anchored):
             "--model", pt, "--reads-per-batch", "3"] + (["--reference-anchored"] if anchored else [])
     one, two = str(tmp_path / "one.bam"), str(tmp_path / "two.bam")
     o1 = _remora(*args, "--out-bam", one)
-    o2 = _remora(*args, "--out-bam", two, "--gpus", "2", env_extra=TWO)
+    o2 = _remora(*args, "--out-bam", two, "--gpus", "2", env_extra=dict(TWO, REMORA_AMD_BAM_SHARD=split))
     assert "called 14 reads" in o1 and "called 14 reads" in o2 and "(2 GPUs)" in o2
     tally = lambda o: [ln for ln in o.splitlines() if ln.startswith("calls per label")]
     assert tally(o1) == tally(o2) and len(tally(o1)) == 1

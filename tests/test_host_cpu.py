@@ -1639,12 +1639,55 @@ def test_c_inference_program_builds_and_reports_errors_without_a_gpu(tmp_path):
 
 
 # ---- multi-GPU product pipeline: the sharding plumbing on CPU (the kernels' side: tests/test_gpu_shard.py) --------
-def test_bam_shard_partitions_the_records_in_order():
+def test_bam_byte_shares_partition_the_records_and_verify_their_ends(tmp_path):
+    """io.bam_byte_shard (rmr_bam_guess_start): for any number of workers the shares by byte range are contiguous, in rank
+    order and together exactly the records of the file - found without a pass over it; rmr_bam_guess_start agrees with
+    the exact record list at every probed offset; a share whose end mark is not a record start is refused."""
+    import random
+    import struct
+
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    big = str(tmp_path / "big.bam")
+    recs = list(rio.iter_bam_records(os.path.join(DATA, "can_mappings.bam"))) + list(rio.iter_bam_records(os.path.join(DATA, "mod_mappings.bam")))
+    with rio.BamWriter(big, rio.read_bam_header_bytes(os.path.join(DATA, "can_mappings.bam")), level=1) as w:
+        for k in range(12):
+            for r in recs:
+                raw = bytes(r.raw)
+                w.write(struct.pack("<i", len(raw)) + raw)
+    for path in (big, os.path.join(DATA, "can_mappings.bam"), os.path.join(DATA, "mod_mappings.bam")):
+        whole = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(path)]
+        vos = [w[2] for w in whole]
+        size = os.path.getsize(path)
+        rng = random.Random(7)
+        for off in [0, 1, size // 3, size // 2, size - 29, size - 28, size - 1, size, size + 9] + [rng.randrange(size) for _ in range(60)]:
+            want = next((v for v in vos if (v >> 16) >= off), None) if off > (vos[0] >> 16) else vos[0]
+            assert rio.bam_guess_start(path, off) == want, (path, off)
+        for world in (1, 2, 3, 5, 8, 16, 33):
+            got = []
+            for rank in range(world):
+                part = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(path, shard=(rank, world))]
+                st, en = rio.bam_byte_shard(path, rank, world)
+                assert (part[0][2] == st if part else True) and (st is None or en is None or en > st)
+                got += part
+            assert got == whole, (path, world)
+    # an end mark that is no record start: the share in front runs past it and says so
+    whole = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(big)]
+    vos, size = [w[2] for w in whole], os.path.getsize(big)
+    with pytest.raises(RemoraError, match="guessed wrong"):
+        list(rio._iter_bam_records_native(big, False, 64, start_voffset=vos[0], end_voffset=whole[5][2] + 1))
+    with pytest.raises(RemoraError, match="end of file before"):
+        list(rio._iter_bam_records_native(big, False, 64, start_voffset=vos[0], end_voffset=(size + 5) << 16))
+
+
+def test_bam_shard_partitions_the_records_in_order(monkeypatch):
     """io.bam_shard (rmr_bam_scan + rmr_bam_seek): for any number of workers and any mark spacing the workers' shares are
     contiguous, in rank order, and together exactly the records of the file; shares differ by less than one mark spacing
     (+1 where the marks do not divide evenly)."""
     from remora_amd import io as rio
 
+    monkeypatch.setenv("REMORA_AMD_BAM_SHARD", "scan")  # (the default splits by byte range: the test above)
     for name in ("can_mappings.bam", "mod_mappings.bam"):
         path = os.path.join(DATA, name)
         whole = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(path)]
@@ -1901,3 +1944,68 @@ def test_launch_ranks_starts_the_ranks_itself_and_stops_them_together():
     t0 = time.monotonic()
     assert rdist.launch_ranks([], 3, command=[sys.executable, "-c", bad]) == 7
     assert time.monotonic() - t0 < 30
+
+
+def test_bam_guess_start_on_random_records(tmp_path):
+    """rmr_bam_guess_start against records built to confuse it: random bytes in qualities, sequences and B-array tags
+    (every byte pattern, BGZF magic and plausible block_size fields included), names of 1..254 characters, unmapped and
+    zero-length records, records of 40 B to 300 KB spanning many BGZF members, every tag type.  At every probed offset
+    the guess is the true first record start behind it, and byte-range shares partition the file for any worker count."""
+    import random
+    import struct
+
+    from remora_amd import io as rio
+
+    rng = random.Random(20260927)
+    src = os.path.join(DATA, "can_mappings.bam")
+    header = rio.read_bam_header_bytes(src)
+    n_ref = struct.unpack_from("<i", header, 8 + struct.unpack_from("<i", header, 4)[0])[0]
+    assert n_ref >= 1
+
+    def record(i):
+        name = "".join(chr(rng.randrange(33, 127)) for _ in range(rng.choice([1, 3, 36, 36, 36, 120, 253]))).encode() + b"\x00"
+        l_seq = rng.choice([0, 0, 1, 7, 300, 5000, 60000]) if i % 7 else rng.randrange(0, 150000)
+        n_cig = rng.choice([0, 1, 3, 40])
+        unmapped = rng.random() < 0.2
+        ref_id, pos = (-1, -1) if unmapped else (rng.randrange(n_ref), rng.randrange(0, 1 << 28))
+        cigar = b"".join(struct.pack("<I", (rng.randrange(1, 1 << 20) << 4) | rng.randrange(9)) for _ in range(n_cig))
+        seq, qual = rng.randbytes((l_seq + 1) // 2), rng.randbytes(l_seq)
+        tags = b""
+        for _ in range(rng.randrange(0, 7)):
+            tag = bytes([rng.choice(b"ABXYZmnpq"), rng.choice(b"ABXYZmnpq0123")])
+            ty = rng.choice("AcCsSiIfZHB")
+            if ty in "AcC":
+                tags += tag + ty.encode() + rng.randbytes(1)
+            elif ty in "sS":
+                tags += tag + ty.encode() + rng.randbytes(2)
+            elif ty in "iIf":
+                tags += tag + ty.encode() + rng.randbytes(4)
+            elif ty in "ZH":
+                tags += tag + ty.encode() + bytes(rng.randrange(1, 256) for _ in range(rng.randrange(0, 200))) + b"\x00"
+            else:
+                sub = rng.choice("cCsSiIf")
+                cnt = rng.choice([0, 1, 50, 3000, 70000])
+                tags += tag + b"B" + sub.encode() + struct.pack("<i", cnt) + rng.randbytes(cnt * {"c": 1, "C": 1, "s": 2, "S": 2}.get(sub, 4))
+        if rng.random() < 0.3:  # a decoy: what a record header looks like, inside a B array
+            decoy = struct.pack("<iiiBBHHHiiii", 60, 0, 5, 4, 0, 0, 0, 0, 10, -1, -1, 0) + b"abc\x00" + bytes(30)
+            tags += b"dcBC" + struct.pack("<i", len(decoy)) + decoy
+        body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(name), rng.randrange(256), rng.randrange(65536), n_cig, rng.randrange(4096),
+                           l_seq, -1 if unmapped else rng.randrange(-1, n_ref), rng.randrange(-1, 1 << 20), rng.randrange(-1000, 1000))
+        body += name + cigar + seq + qual + tags
+        return struct.pack("<i", len(body)) + body
+
+    path = str(tmp_path / "random.bam")
+    with rio.BamWriter(path, header, level=1) as w:
+        for i in range(700):
+            w.write(record(i))
+    whole = [(r.query_name, r.voffset) for r in rio.iter_bam_records(path)]
+    assert len(whole) == 700
+    vos, size = [v for _, v in whole], os.path.getsize(path)
+    for off in [rng.randrange(size) for _ in range(400)]:
+        want = next((v for v in vos if (v >> 16) >= off), None) if off > (vos[0] >> 16) else vos[0]
+        assert rio.bam_guess_start(path, off) == want, off
+    for world in (2, 7, 32):
+        got = []
+        for rank in range(world):
+            got += [(r.query_name, r.voffset) for r in rio.iter_bam_records(path, shard=(rank, world))]
+        assert got == whole, world
