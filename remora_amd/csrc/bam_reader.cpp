@@ -238,7 +238,7 @@ int64_t voffset_at(const rmr_bam *b, size_t pos) {
 // A worker that begins in the middle of the file needs a record boundary without walking the block_size chain from
 // the first record.  A position is accepted when a record AND the records chained behind it (kGuessChain of them, or
 // up to the end of the file) pass every check the format allows: field ranges against the header's reference count,
-// a printable NUL-terminated name, CIGAR operation codes, and a tag region that parses tag by tag and ends exactly
+// a NUL-terminated name without control characters, CIGAR operation codes, and a tag region that parses tag by tag and ends exactly
 // where block_size says.  The worker in front of this one verifies the guess for certain: its own chain of records
 // must END on it (io.py: a share that runs past its end mark is an error, never a silent overlap).
 constexpr int kGuessChain = 8;
@@ -262,7 +262,7 @@ int64_t plausible_record(rmr_bam *b, size_t q) {
     r = b->ubuf.data() + q;
     if (r[36 + l_name - 1] != 0) return 0;
     for (int64_t i = 0; i + 1 < l_name; ++i)
-        if (r[36 + i] < 33 || r[36 + i] > 126) return 0;
+        if (r[36 + i] < 33 || r[36 + i] == 127) return 0;  // (bytes >= 0x80 pass: names in UTF-8 occur in the wild)
     rc = ensure(b, q + 4 + (size_t)bs);  // (only a position that looks like a record so far makes the window grow)
     if (rc < 0) return rc;
     if (rc == 0) return 0;
