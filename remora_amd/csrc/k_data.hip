@@ -34,6 +34,13 @@ struct EncodeArgs {
 // NST = the 16-byte stores a lane issues per chunk, ceil(K L / 64), as a compile-time count: gfx950 has ONE counter for
 // loads and stores, retired in order, and only with the store loop unrolled can the compiler wait for "all but the NST
 // newest" instead of "all" (NST = 0: any shape, a plain loop, and with PF the conservative wait).
+#ifndef RMR_ENCODE_NT
+#define RMR_ENCODE_NT 1  // non-temporal stores: 5.05 against 4.97 TB/s in this kernel, although a pure store stream of the same shape
+                         // prefers plain ones (5.55 against 5.28 TB/s, tools/ubench/write_bw.hip): the kernel is within 4 % of that stream
+#endif
+#ifndef RMR_ENCODE_CODE_FORM
+#define RMR_ENCODE_CODE_FORM 1  // 0: the per-element select form everywhere (A/B builds)
+#endif
 template <int PF, int NST>
 __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
@@ -41,12 +48,18 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
     // and the four waves of a block stream their 14 KB of stores independently
     const int Lp = (a.L + 7) & ~7;
     const int mapb = PF ? ((a.map_w * 2 + 15) & ~15) : 0;
-    const int per_wave = (Lp * 2 + ((a.seq_w + 15) & ~15) + mapb + 15) & ~15;  // bytes
+    const int per_wave = (Lp * 4 + ((a.seq_w + 15) & ~15) + mapb + 15) & ~15;  // bytes
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     char *base = reinterpret_cast<char *>(smem_i) + (size_t)wv * per_wave;
-    int16_t *s_pidx = reinterpret_cast<int16_t *>(base);   // [Lp]
-    int8_t *s_seq = reinterpret_cast<int8_t *>(base + Lp * 2);  // [seq_w]
-    int16_t *s_map = reinterpret_cast<int16_t *>(base + Lp * 2 + ((a.seq_w + 15) & ~15));  // [map_w] (PF only)
+    int16_t *s_pidx = reinterpret_cast<int16_t *>(base);   // [Lp] covering base of a position (general form)
+    unsigned *s_code = reinterpret_cast<unsigned *>(base);  // [Lp] or: its k-mer as 3-bit base codes, 4 = none (code form)
+    int8_t *s_seq = reinterpret_cast<int8_t *>(base + Lp * 4);  // [seq_w]
+    int16_t *s_map = reinterpret_cast<int16_t *>(base + Lp * 4 + ((a.seq_w + 15) & ~15));  // [map_w] (PF only)
+    // code form (chunk lengths that are multiples of 4, k-mers of up to 10 bases - the unrolled shapes always): a
+    // float4 of the output is four positions of ONE row (k-mer slot kp, base b), and each element is
+    // ((code >> 3 kp) & 7) == b worked out in arithmetic - on gfx950 a v_cndmask_b32 that reads VCC costs 16-19 cycles
+    // against 4.5 for plain VALU (tools/ubench/valu_cycles.hip), and the general form below selects per element
+    const bool code_form = RMR_ENCODE_CODE_FORM && (NST > 0 || ((a.L & 3) == 0 && a.K <= 10));
     const int total = 4 * a.K * a.L;       // floats per chunk (multiple of 4)
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
     constexpr int NP = PF ? PF : 1;
@@ -97,7 +110,18 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
                 if (mp[mid] <= s) lo = mid + 1; else hi = mid;
             }
             const int p = lo - 1;
-            s_pidx[s] = (int16_t)((p >= 0 && p < len) ? p : -1);
+            const bool valid = p >= 0 && p < len;
+            if (code_form) {
+                const unsigned char *sq = reinterpret_cast<const unsigned char *>(s_seq) + (valid ? p : 0);
+                unsigned code = 0;
+                for (int kp = 0; kp < a.K; ++kp) {
+                    const unsigned bb = sq[kp];  // 0..3, or 0xFF (-1: beyond the sequence) and anything else -> 4
+                    code |= (bb < 4u ? bb : 4u) << (3 * kp);
+                }
+                s_code[s] = valid ? code : 0x24924924u;
+            } else {
+                s_pidx[s] = (int16_t)(valid ? p : -1);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -108,6 +132,21 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
             const int e0 = 4 * f;
             int row = (int)(((float)e0 + 0.5f) * a.inv_L);
             int s = e0 - row * a.L;
+            if (code_form) {
+                const uint4 cd = *reinterpret_cast<const uint4 *>(s_code + s);
+                const unsigned sh = 3u * (unsigned)(row >> 2), b = (unsigned)row & 3u;
+                auto one = [&](unsigned c) {  // 1.0f where the slot holds base b: (x == 0) as ((min(x, 1) - 1) & bits of 1.0f)
+                    const unsigned x = ((c >> sh) & 7u) ^ b;
+                    unsigned t;  // (in assembly: written in C++ the optimiser turns the expression back into compare + select)
+                    asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(x));
+                    return (t - 1u) & 0x3F800000u;
+                };
+                typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+                const nt_u32x4 ov = {one(cd.x), one(cd.y), one(cd.z), one(cd.w)};
+                if (RMR_ENCODE_NT) __builtin_nontemporal_store(ov, reinterpret_cast<nt_u32x4 *>(dst) + f);
+                else reinterpret_cast<nt_u32x4 *>(dst)[f] = ov;
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int p = s_pidx[s];
@@ -117,7 +156,8 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
             }
             typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
             const nt_f32x4 ov = {v[0], v[1], v[2], v[3]};
-            __builtin_nontemporal_store(ov, reinterpret_cast<nt_f32x4 *>(dst) + f);
+            if (RMR_ENCODE_NT) __builtin_nontemporal_store(ov, reinterpret_cast<nt_f32x4 *>(dst) + f);
+            else reinterpret_cast<nt_f32x4 *>(dst)[f] = ov;
         };
         if (NST) {
 #pragma unroll
@@ -150,7 +190,7 @@ int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
     const int wide = seq_w > map_w ? seq_w : map_w;
     const int pf = tune_int("RMR_ENCODE_PREFETCH", 1) ? (wide <= 64 ? 1 : wide <= 128 ? 2 : wide <= 256 ? 4 : 0) : 0;
     const size_t mapb = pf ? (((size_t)map_w * 2 + 15) & ~(size_t)15) : 0;
-    const size_t per_wave = ((size_t)Lp * 2 + ((seq_w + 15) & ~15) + mapb + 15) & ~(size_t)15;
+    const size_t per_wave = ((size_t)Lp * 4 + ((seq_w + 15) & ~15) + mapb + 15) & ~(size_t)15;
     const size_t lds = per_wave * 4;
     int64_t grid = (int64_t)e->num_cus * 8;
     if (grid > (n + 3) / 4) grid = (n + 3) / 4;

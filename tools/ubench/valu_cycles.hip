@@ -22,6 +22,11 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
 #define AND(i) asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(r[i]));
 #define SHL(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r[i]));
 #define CND(i) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(r[i]));
+#define CND64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %0, s[10:11]" : "+v"(r[i]));
+#define CNDI(i) asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(r[i]));
+#define CMP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %0" : : "v"(r[i]) : "vcc");
+#define MED3(i) asm volatile("v_med3_f32 %0, %0, %0, %0" : "+v"(r[i]));
+#define MINF(i) asm volatile("v_min_f32 %0, %0, %0" : "+v"(r[i]));
 #define EXPH(i) asm volatile("v_exp_f16 %0, %0" : "+v"(r[i]));
 #define PKF(i) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(double *)&r[(i) & 14]));
 #define SQRT(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(r[i]));
@@ -41,6 +46,11 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
         if (MODE == 11) { R16(SQRT) R16(SQRT) R16(SQRT) R16(SQRT) }
         if (MODE == 12) { R16(LOG) R16(LOG) R16(LOG) R16(LOG) }
         if (MODE == 13) { R16(FMA_EXP) R16(FMA_EXP) }  // 32 fma + 32 exp interleaved (64 instr)
+        if (MODE == 14) { R16(CND64) R16(CND64) R16(CND64) R16(CND64) }
+        if (MODE == 15) { R16(CNDI) R16(CNDI) R16(CNDI) R16(CNDI) }
+        if (MODE == 16) { R16(CMP) R16(CMP) R16(CMP) R16(CMP) }
+        if (MODE == 17) { R16(MED3) R16(MED3) R16(MED3) R16(MED3) }
+        if (MODE == 18) { R16(MINF) R16(MINF) R16(MINF) R16(MINF) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
@@ -77,6 +87,8 @@ int main() {
         run<6>("v_and_b32", d, dc, cus, wps, it); run<7>("v_lshlrev_b32", d, dc, cus, wps, it); run<8>("v_cndmask_b32", d, dc, cus, wps, it);
         run<9>("v_exp_f16", d, dc, cus, wps, it); run<10>("v_pk_fma_f32", d, dc, cus, wps, it); run<11>("v_sqrt_f32", d, dc, cus, wps, it);
         run<12>("v_log_f32", d, dc, cus, wps, it); run<13>("fma+exp interleaved", d, dc, cus, wps, it);
+        run<14>("v_cndmask_b32_e64 sgpr", d, dc, cus, wps, it); run<15>("v_cndmask_b32 0,v,vcc", d, dc, cus, wps, it); run<16>("v_cmp_lt_f32 vcc", d, dc, cus, wps, it);
+        run<17>("v_med3_f32", d, dc, cus, wps, it); run<18>("v_min_f32", d, dc, cus, wps, it);
     }
     // wall-clock cross-check of the tick unit: time the fma kernel with events
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
