@@ -423,15 +423,17 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             const int ci = fdiv(row, a.d_L), s = row - ci * a.L;
             const int16_t *mp = s_map + ci * a.map_w;
             const int len = s_len[ci];
-            int lo = 0, hi = len + 1;
-            for (int k = 0; k < nsearch; ++k) {
-                const int mid = (lo + hi) >> 1;
-                const bool go = lo < hi;
-                const bool le = go && (int)mp[go ? mid : 0] <= s;
-                lo = le ? mid + 1 : lo;
-                hi = (go && !le) ? mid : hi;
+            // the count by binary steps, in arithmetic: a v_cmp + v_cndmask pair through VCC costs 25 cycles on gfx950 against
+            // 4.5 per plain instruction (tools/ubench/valu_cycles.hip).  Entries behind map[len] read as map[len]: if that
+            // one is <= s the count may overshoot len + 1 - the position has no base either way (p >= len).
+            int cnt = 0;
+            for (int step = 1 << (nsearch - 1); step; step >>= 1) {
+                const int idx = cnt + step - 1;  // the entry that would bring the count to cnt + step
+                int d = s - (int)mp[idx < len ? idx : len], m;
+                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(d));  // 0 when the entry is <= s, else -1 (in assembly: in
+                cnt += step & ~m;                                   // C++ the optimiser makes a compare + select of it)
             }
-            const int p = lo - 1;
+            const int p = cnt - 1;
             const bool valid = p >= 0 && p < len;
             // the K base codes (one byte each, 0..4) squeezed to 3 bits each: two shift-or-mask steps per four bytes
             const unsigned char *sq = reinterpret_cast<const unsigned char *>(s_seq) + ci * a.seq_w + (valid ? p : 0);
