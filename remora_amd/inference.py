@@ -261,8 +261,8 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
     the key None counting successfully called reads.
 
     `world` > 1 (one process per GPU, torch.distributed initialised by the caller — `python -m remora_amd infer
-    from_pod5_and_bam --gpus N`): rank r takes a contiguous share of the alignments (io.bam_shard; no reader process
-    hands reads out, no read crosses a GPU boundary), writes `<out>.partRRR` (whole BGZF members; rank 0's carries the
+    from_pod5_and_bam --gpus N`): rank r takes a contiguous share of the alignments (io.shard_of: by byte range of the
+    file, nothing to coordinate; no reader process hands reads out, no read crosses a GPU boundary), writes `<out>.partRRR` (whole BGZF members; rank 0's carries the
     header), and after a barrier rank 0 joins the parts in rank order — the records keep the input order.  The per-label
     call counts go through the ONE collective of the path (dist.allreduce_counts: RCCL all-reduce of int64[num_out]);
     the per-reason read counts are summed over the ranks; every rank returns the global numbers.  `num_reads` then
