@@ -61,7 +61,12 @@ def _dataset_prepare(args):
 
     if args.mod_base is None and not args.mod_base_control:
         raise RemoraError("Must specify either --mod-base or --mod-base-control")
-    prepare_out_dir(args.output_path, args.overwrite)
+    from . import dist as rdist
+
+    rank, world, dev = rdist.setup_ranks(args.gpus, args.procs_per_gpu)
+    if rank == 0:
+        prepare_out_dir(args.output_path, args.overwrite)
+    rdist.barrier()
     refiner = SigMapRefiner(kmer_model_filename=args.refine_kmer_level_table, do_rough_rescale=args.refine_rough_rescale,
                             scale_iters=args.refine_scale_iters, algo=args.refine_algo,
                             half_bandwidth=args.refine_half_bandwidth, sd_params=args.refine_short_dwell_parameters,
@@ -77,7 +82,9 @@ def _dataset_prepare(args):
         kmer_context_bases=args.kmer_context_bases, base_start_justify=args.base_start_justify, offset=args.offset,
         num_reads=args.num_reads, basecall_anchor=args.basecall_anchor, rev_sig=args.reverse_signal,
         save_every=args.save_every, skip_shuffle=args.skip_shuffle, reads_per_batch=args.reads_per_batch,
-        engine=get_engine(args.device))
+        engine=get_engine(args.device if dev is None else dev), rank=rank, world=world)
+    if rank != 0:
+        return 0
     if dataset is None:
         print("no reads with signal and alignment")
         return 0
@@ -205,6 +212,9 @@ def main(argv=None):
     d.add_argument("--mod-base-control", action="store_true")
     d.add_argument("--reads-per-batch", type=int, default=256)
     d.add_argument("--device", type=int, default=0)
+    d.add_argument("--gpus", type=int, default=1,
+                   help="one process per GPU, each extracts the chunks of its own share of the BAM; the parts become one dataset")
+    d.add_argument("--procs-per-gpu", type=int, default=1)
     d.set_defaults(func=_dataset_prepare)
 
     args = ap.parse_args(argv)

@@ -158,12 +158,13 @@ def extract_chunks(read_errs, int_label, motifs, focus_ref_pos, sig_map_refiner,
     return out
 
 
-def count_reads(pod5_path, bam_path, skip_non_primary=True):
+def count_reads(pod5_path, bam_path, skip_non_primary=True, shard=None):
     """Number of BAM records (after the primary filter) whose parent read has signal in the POD5 file, and the
-    total record count - the quantities of get_read_ids (src/remora/io.py:362-391)."""
+    total record count - the quantities of get_read_ids (src/remora/io.py:362-391).  `shard=(rank, world)`: of that
+    rank's share of the BAM only."""
     signals = rio.Pod5File(pod5_path)
     total = both = 0
-    for rec in rio.iter_bam_records(bam_path):
+    for rec in rio.iter_bam_records(bam_path, shard=shard):
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
         total += 1
@@ -175,27 +176,52 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
                           chunk_context, min_samps_per_base, max_chunks_per_read, pa_scaling, sig_map_refiner,
                           kmer_context_bases, base_start_justify, offset, num_reads, num_extract_alignment_threads=1,
                           num_extract_chunks_threads=1, skip_non_primary=True, basecall_anchor=False, rev_sig=False,
-                          save_every=100_000, skip_shuffle=False, reads_per_batch=256, engine=None):
+                          save_every=100_000, skip_shuffle=False, reads_per_batch=256, engine=None, rank=0, world=1):
     """POD5 + BAM -> CoreRemoraDataset directory (prepare_train_data.py:124-276; the two worker-count arguments
     are accepted for signature compatibility and unused: the batch is the unit of parallelism here).  Returns
-    (dataset, {reason: count})."""
-    num_both, num_records = count_reads(pod5_path, bam_path, skip_non_primary)
+    (dataset, {reason: count}).
+
+    `world` > 1 (one process per GPU or several, torch.distributed initialised by the caller - `python -m remora_amd dataset
+    prepare --gpus N [--procs-per-gpu P]`): every rank extracts the chunks of its own share of the BAM (io.shard_of, as
+    `infer` does) into `<out_path>.partRRR`; after a barrier rank 0 appends the parts' rows in rank order to the dataset at
+    `out_path` - the rows of a single-process run, in its order - and shuffles once unless told not to.  The reference
+    spreads the same work over worker processes behind queues (prepare_train_data.py:124-276).  Rank 0 returns the
+    dataset, the others None; the reason counts are summed over the ranks."""
+    import shutil
+
+    from . import dist as rdist
+
+    world, rank = int(world), int(rank)
+    shard = (rank, world) if world > 1 else None
+    if world > 1 and num_reads is not None:
+        raise RemoraError("--num-reads names the FIRST reads of the file: not available when the file is split over ranks")
+    num_both, num_records = count_reads(pod5_path, bam_path, skip_non_primary, shard=shard)
+    if world > 1:
+        shares = rdist.gather_objects((num_both, num_records))
+        num_records, total_both = sum(x[1] for x in shares), sum(x[0] for x in shares)
+    else:
+        total_both = num_both
     if num_records == 0:
         raise RemoraError("No records found in BAM file.")
     num_reads = num_both if num_reads is None else min(int(num_reads), num_both)
-    if num_reads == 0:
+    if total_both == 0:
         return None, {}
     max_seq_len = sum(chunk_context) // min_samps_per_base
-    dataset = CoreRemoraDataset(
-        data_path=out_path, mode="w",
-        metadata=DatasetMetadata(
-            allocate_size=max_chunks_per_read * num_reads, max_seq_len=max_seq_len,
-            mod_bases=[] if mod_base_control else [mod_base[0]], mod_long_names=[] if mod_base_control else [mod_base[1]],
-            motif_sequences=[m.raw_motif for m in motifs], motif_offsets=[m.focus_pos for m in motifs],
-            extra_arrays={"read_ids": ("<U36", "Read identifier"),
-                          "read_focus_bases": ("int64", "Position within read training sequence")},
-            chunk_context=chunk_context, kmer_context_bases=kmer_context_bases, reverse_signal=rev_sig,
-            pa_scaling=pa_scaling, sig_map_refiner=sig_map_refiner, base_start_justify=base_start_justify, offset=offset))
+
+    def new_dataset(path, n_reads):
+        return CoreRemoraDataset(
+            data_path=path, mode="w",
+            metadata=DatasetMetadata(
+                allocate_size=max_chunks_per_read * n_reads, max_seq_len=max_seq_len,
+                mod_bases=[] if mod_base_control else [mod_base[0]], mod_long_names=[] if mod_base_control else [mod_base[1]],
+                motif_sequences=[m.raw_motif for m in motifs], motif_offsets=[m.focus_pos for m in motifs],
+                extra_arrays={"read_ids": ("<U36", "Read identifier"),
+                              "read_focus_bases": ("int64", "Position within read training sequence")},
+                chunk_context=chunk_context, kmer_context_bases=kmer_context_bases, reverse_signal=rev_sig,
+                pa_scaling=pa_scaling, sig_map_refiner=sig_map_refiner, base_start_justify=base_start_justify, offset=offset))
+
+    part_path = f"{str(out_path).rstrip('/')}.part{rank:03d}" if world > 1 else out_path
+    dataset = new_dataset(part_path, max(num_reads, 1))
     errs = defaultdict(int)
     int_label = 0 if mod_base_control else 1
     next_save = save_every
@@ -222,7 +248,7 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
 
     batch, seen = [], 0
     for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,
-                                                     skip_non_primary=skip_non_primary):
+                                                     skip_non_primary=skip_non_primary, shard=shard):
         if seen >= num_reads:
             break
         seen += 1
@@ -233,8 +259,35 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
     if batch:
         run(batch)
     errs = {k: v for k, v in errs.items() if v}
+    if world == 1:
+        dataset.write_metadata()
+        if not skip_shuffle:
+            dataset.shuffle()
+        dataset.flush()
+        return dataset, errs
+    # ---- several ranks: the parts become one dataset ----
     dataset.write_metadata()
-    if not skip_shuffle:
-        dataset.shuffle()
     dataset.flush()
-    return dataset, errs
+    del dataset
+    summed = defaultdict(int)
+    for part_errs in rdist.gather_objects(errs):  # (also the barrier behind which every part is on disk)
+        for k, v in part_errs.items():
+            summed[k] += v
+    rdist.barrier()
+    out = None
+    if rank == 0:
+        out = new_dataset(out_path, total_both)
+        for r in range(world):
+            path = f"{str(out_path).rstrip('/')}.part{r:03d}"
+            part = CoreRemoraDataset(data_path=path, mode="r")
+            a0, a1 = int(part.metadata.dataset_start), int(part.metadata.dataset_end)
+            for st in range(a0, a1, 100_000):
+                out.write_batch({name: np.asarray(part.arrays[name][st : min(st + 100_000, a1)]) for name in out.array_names})
+            del part
+            shutil.rmtree(path)
+        out.write_metadata()
+        if not skip_shuffle:
+            out.shuffle()
+        out.flush()
+    rdist.barrier()
+    return out, dict(summed)

@@ -81,3 +81,24 @@ def test_validate_cli_two_ranks_same_confusion_matrix(tmp_path):
     assert f1[7:10] == f2[7:10]
     assert abs(float(f1[5]) - float(f2[5])) <= 2e-3 * max(1.0, abs(float(f1[5])))
     assert abs(float(f1[10]) - float(f2[10])) <= 1e-9
+
+
+@pytest.mark.parametrize("procs", [2, 3])
+def test_dataset_prepare_cli_ranks_write_the_single_process_dataset(tmp_path, procs):
+    """`dataset prepare --gpus 1 --procs-per-gpu P` (every rank extracts its own share of the BAM, rank 0 joins the parts):
+    with the shuffle off and no per-read down-sampling (both draw from numpy's global generator, as in the reference) the
+    dataset directory holds the same files, byte for byte, as the single-process run's - arrays, metadata, row order."""
+    base = ["dataset", "prepare", os.path.join(DATA, "mod_reads.pod5"), os.path.join(DATA, "mod_mappings.bam"), "--mod-base", "m", "5mC",
+            "--motif", "CG", "0", "--chunk-context", "50", "50", "--skip-shuffle", "--max-chunks-per-read", "400"]
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    o1 = _remora(*base, "--output-path", one)
+    o2 = _remora(*base, "--output-path", many, "--procs-per-gpu", str(procs), env_extra=TWO)
+    tail = lambda o: [ln for ln in o.splitlines() if ln.startswith(("Extracted", "Label distribution"))]
+    assert [ln.replace(many, one) for ln in tail(o2)] == tail(o1) and len(tail(o1)) == 2
+    assert sorted(os.listdir(one)) == sorted(os.listdir(many))
+    for name in os.listdir(one):
+        a, b = open(os.path.join(one, name), "rb").read(), open(os.path.join(many, name), "rb").read()
+        assert a == b, name
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    with pytest.raises(AssertionError, match="not available when the file is split"):
+        _remora(*base, "--output-path", str(tmp_path / "x"), "--procs-per-gpu", "2", "--num-reads", "5", env_extra=TWO)
