@@ -168,7 +168,8 @@ def count_reads(pod5_path, bam_path, skip_non_primary=True, shard=None):
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
         total += 1
-        both += dict(rec.tags).get("pi", rec.query_name) in signals
+        tags = rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)  # (the native reader's: no Python walk over mv)
+        both += tags.get("pi", rec.query_name) in signals
     return both, total
 
 
