@@ -1672,6 +1672,18 @@ def test_bam_byte_shares_partition_the_records_and_verify_their_ends(tmp_path):
                 assert (part[0][2] == st if part else True) and (st is None or en is None or en > st)
                 got += part
             assert got == whole, (path, world)
+    # a file without records, and one with a single record: empty shares, nothing lost
+    header = rio.read_bam_header_bytes(os.path.join(DATA, "can_mappings.bam"))
+    none, single = str(tmp_path / "none.bam"), str(tmp_path / "single.bam")
+    with rio.BamWriter(none, header):
+        pass
+    with rio.BamWriter(single, header) as w:
+        raw = bytes(recs[0].raw)
+        w.write(struct.pack("<i", len(raw)) + raw)
+    for world in (1, 2, 5):
+        assert [len(list(rio.iter_bam_records(none, shard=(r, world)))) for r in range(world)] == [0] * world
+        assert sum(len(list(rio.iter_bam_records(single, shard=(r, world)))) for r in range(world)) == 1
+    assert rio.bam_guess_start(none, 0) is None and rio.bam_byte_shard(none, 0, 1) == (None, None)
     # an end mark that is no record start: the share in front runs past it and says so
     whole = [(r.query_name, r.flag, r.voffset) for r in rio.iter_bam_records(big)]
     vos, size = [w[2] for w in whole], os.path.getsize(big)
