@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Round 3: the boxes of this pool list NO agent with PC-sampling support - `rocprofv3-avail list --pc-sampling` is empty and
+# every configuration is refused - so this has produced nothing yet; tools/isa_blocks.py took its place.)
 # Run on the GPU box (via gpurun): rocprofv3 PC sampling of bench.py (no counters, no traces in the same pass), then
 # tools/pc_sample_agg.py folds the samples per instruction and stall reason.  Usage: tools/pc_sample.sh <tag> [bench args...]
 set -u
