@@ -2021,3 +2021,24 @@ def test_bam_guess_start_on_random_records(tmp_path):
         for rank in range(world):
             got += [(r.query_name, r.voffset) for r in rio.iter_bam_records(path, shard=(rank, world))]
         assert got == whole, world
+
+
+def test_launch_ranks_scans_for_its_ranks_in_scan_mode(tmp_path):
+    """The exact-pass form end to end on CPU: dist.launch_ranks(scan_bam=...) scans while its ranks start, the ranks'
+    io.bam_shard takes the marks from the announced file (not from a scan of their own) and the shares partition the
+    file; the scan file is gone afterwards."""
+    from remora_amd import dist as rdist
+    from remora_amd import io as rio
+
+    path = os.path.join(DATA, "mod_mappings.bam")
+    out = str(tmp_path / "share")
+    code = ("import os, sys, json\nfrom remora_amd import io as rio\n"
+            "calls = []\nreal = rio.bam_scan\nrio.bam_scan = lambda *a, **k: (calls.append(1), real(*a, **k))[1]\n"
+            f"rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+            f"st, n = rio.bam_shard({path!r}, rank, world)\n"
+            f"names = [r.query_name for r in rio._iter_bam_records_native({path!r}, False, 4, start_voffset=st, max_records=n)] if n else []\n"
+            f"json.dump({{'names': names, 'own_scans': len(calls), 'scan_file': os.environ.get(rio.SCAN_ENV)}}, open({out!r} + os.environ['RANK'], 'w'))\n")
+    assert rdist.launch_ranks([], 3, scan_bam=path, command=[sys.executable, "-c", code]) == 0
+    got = [json.load(open(out + str(r))) for r in range(3)]
+    assert sum((g["names"] for g in got), []) == [r.query_name for r in rio.iter_bam_records(path)]
+    assert all(g["own_scans"] == 0 and g["scan_file"] for g in got) and not os.path.exists(got[0]["scan_file"])
