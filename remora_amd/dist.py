@@ -120,7 +120,13 @@ def launch_ranks(argv, n, scan_bam=None, command=None):
     n = int(n)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # helper threads of a rank (OpenMP in torch, the batch gather): its share of the cores this process may use, between 2
+    # and 8 - six ranks with eight each on a 16-core allowance cost 2-4 % (profiles/r03_infer_cli_threads_ab.log)
+    from .util import effective_cpu_count
+
+    per_rank = str(max(2, min(8, effective_cpu_count() // max(n, 1))))
+    env.setdefault("OMP_NUM_THREADS", per_rank)
+    env.setdefault("RMR_PACK_THREADS", per_rank)
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     scan_path = None
     if scan_bam is not None:
