@@ -2042,3 +2042,35 @@ def test_launch_ranks_scans_for_its_ranks_in_scan_mode(tmp_path):
     got = [json.load(open(out + str(r))) for r in range(3)]
     assert sum((g["names"] for g in got), []) == [r.query_name for r in rio.iter_bam_records(path)]
     assert all(g["own_scans"] == 0 and g["scan_file"] for g in got) and not os.path.exists(got[0]["scan_file"])
+
+
+@pytest.mark.parametrize("workers", [1, 2, 5, 9])
+def test_bam_shares_from_a_c_program(tmp_path, workers):
+    """tests/c/bam_shares_from_c.c: the byte-range split of a BAM through the C ABI alone (rmr_bam_guess_start +
+    rmr_bam_read_batch, pedantic C99, no Python, no GPU): the workers' shares meet end to start and hold exactly the
+    file's records."""
+    import shutil
+    import struct
+    import subprocess
+
+    from remora_amd import _lib
+    from remora_amd import io as rio
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe, libdir = str(tmp_path / "bam_shares_from_c"), os.path.dirname(_lib.LIB_PATH)
+    cc = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "tests", "c", "bam_shares_from_c.c"), "-o", exe, "-L", libdir, "-lremora_hip",
+                         f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    big = str(tmp_path / "big.bam")
+    recs = list(rio.iter_bam_records(os.path.join(DATA, "can_mappings.bam")))
+    with rio.BamWriter(big, rio.read_bam_header_bytes(os.path.join(DATA, "can_mappings.bam")), level=1) as w:
+        for _ in range(20):
+            for r in recs:
+                raw = bytes(r.raw)
+                w.write(struct.pack("<i", len(raw)) + raw)
+    run = subprocess.run([exe, big, str(workers)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.stdout, run.stderr)
+    assert f"{20 * len(recs)} records in the file, {20 * len(recs)} in the shares" in run.stdout
+    assert len([ln for ln in run.stdout.splitlines() if ln.startswith("worker ")]) == workers
