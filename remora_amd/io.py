@@ -1471,14 +1471,42 @@ def concat_bam_parts(out_path, part_paths, remove=True):
     """Join the part files of a multi-GPU run (rank 0: header + its records, the others: records only, none with an
     end-of-file marker) into one BAM: BGZF members are self-contained, so the parts are appended byte for byte and the
     28-byte EOF marker closes the file (SAM spec 4.1).  Records keep the order of the input file because the ranks took
-    contiguous shares in rank order."""
+    contiguous shares in rank order.  With `remove` the first part BECOMES the output (a rename, nothing copied) and the
+    others are appended inside the kernel (os.copy_file_range / os.sendfile; a plain read-write loop where those are
+    not to be had) - the join of a run is a copy of everything the other ranks wrote, on rank 0, inside the clock."""
     import shutil
 
-    with open(out_path, "wb") as out:
-        for p in part_paths:
-            with open(p, "rb") as fh:
-                shutil.copyfileobj(fh, out, 1 << 22)
+    part_paths = list(part_paths)
+
+    def append(src_path, out):
+        with open(src_path, "rb") as fh:
+            left = os.fstat(fh.fileno()).st_size
+            out.flush()
+            for fn in (getattr(os, "copy_file_range", None), None):
+                try:
+                    while left > 0:
+                        if fn is not None:
+                            n = fn(fh.fileno(), out.fileno(), min(left, 1 << 30))
+                        else:
+                            n = os.sendfile(out.fileno(), fh.fileno(), None, min(left, 1 << 30))
+                        if n == 0:
+                            break
+                        left -= n
+                    if left == 0:
+                        return
+                except (OSError, AttributeError):
+                    pass  # not supported between these files: the next way down
+            shutil.copyfileobj(fh, out, 1 << 22)  # (fh stands where the kernel copies stopped)
+
+    rest = part_paths
+    if remove and part_paths:
+        os.replace(part_paths[0], out_path)
+        rest = part_paths[1:]
+    with open(out_path, "ab" if remove and part_paths else "wb") as out:
+        for p in rest:
+            append(p, out)
         out.write(_BGZF_EOF)
+    part_paths = rest
     if remove:
         for p in part_paths:
             os.remove(p)
