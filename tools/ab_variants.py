@@ -57,24 +57,35 @@ def main():
     ap.add_argument("--arch", default="conv_lstm")
     ap.add_argument("--n", type=int, default=524288)
     ap.add_argument("--cfgs", default="C100,C200")
+    ap.add_argument("--envs", default="", help="';'-separated env sets applied on top of each lib, each 'label:K=V,K=V' (label optional)")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
         return child(args.dtype, args.n, args.cfgs.split(","), args.arch)
+    runs = []
     for lib in args.libs.split(","):
+        for es in (args.envs.split(";") if args.envs else [""]):
+            label, _, kv = es.rpartition(":")
+            extra = dict(item.split("=", 1) for item in kv.split(",") if item)
+            runs.append((lib + ("/" + (label or kv) if es else ""), lib, extra))
+    for name, lib, extra in runs:
         env = dict(os.environ)
+        env.update(extra)
         if lib != "default":
             env["REMORA_HIP_LIB"] = os.path.join(ROOT, "remora_amd", f"libremora_hip_{lib}.so")
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--dtype", args.dtype, "--n", str(args.n), "--cfgs", args.cfgs,
-                            "--arch", args.arch], env=env, capture_output=True, text=True, timeout=900)
+                            "--arch", args.arch], env=env, capture_output=True, text=True, timeout=240)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
         if p.returncode != 0 or not line:
-            print(f"{lib}: FAILED rc={p.returncode}\n{p.stderr[-1500:]}")
+            print(f"{name}: FAILED rc={p.returncode}\n{p.stderr[-1500:]}")
             continue
         res = json.loads(line[-1][7:])
+        clk = [ln for ln in p.stderr.splitlines() if ln.startswith("[fused2 clock]") or ln.startswith("[stage clock]")]
+        for ln in clk[-8:]:  # the last launch's (C200 when both configurations run)
+            print("    " + ln)
         for cfg, r in res.items():
             ks = "  ".join(f"{k} {v:.3f}" for k, v in sorted(r["kernels_ns_per_chunk"].items(), key=lambda kv: -kv[1]))
-            print(f"{lib:10s} {cfg}: {r['M_chunks_per_s']:7.2f} M chunks/s  wall {r['wall_ns_per_chunk']:.3f} ns/chunk | {ks} | sha {r['logits_sha']}", flush=True)
+            print(f"{name:24s} {cfg}: {r['M_chunks_per_s']:7.2f} M chunks/s  wall {r['wall_ns_per_chunk']:.3f} ns/chunk | {ks} | sha {r['logits_sha']}", flush=True)
 
 
 if __name__ == "__main__":
