@@ -190,9 +190,9 @@ def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):
     forced = os.environ.get("REMORA_AMD_FORCE_DEVICE")
     backend = backend or os.environ.get("REMORA_AMD_DIST_BACKEND") or ("gloo" if procs_per_gpu > 1 or forced is not None else None)
     device = int(forced) if forced is not None else local // procs_per_gpu
-    if backend != "gloo":
-        import torch
+    import torch
 
+    if torch.cuda.is_available():  # whatever the transport: everything that resolves "the current device" must land on this rank's GPU
         torch.cuda.set_device(device)
     init_process_group(backend, set_device=False, timeout_s=timeout_s)
     return rank, world, device

@@ -380,7 +380,8 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         for i, item in enumerate(rio.iter_reads_from_pod5_and_bam(pod5_path, in_bam_path, reverse_signal=reverse_signal,
                                                                   pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
                                                                   decode_batch=reads_per_batch,
-                                                                  parse_ref_align=ref_anchored, shard=shard)):
+                                                                  parse_ref_align=ref_anchored, shard=shard,
+                                                                  device=models[0].engine.device)):
             if num_reads is not None and i >= num_reads:
                 break
             batch.append(item)
@@ -399,6 +400,9 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     def produce():
         try:
+            import torch
+
+            torch.cuda.set_device(models[0].engine.torch_device)  # a new thread starts on device 0
             ti = _time.perf_counter()
             for b in batches():
                 clock["ingest"] += _time.perf_counter() - ti
@@ -430,6 +434,12 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                 flush(b, writer)
             tc = _time.perf_counter()
         clock["close"] = _time.perf_counter() - tc
+    except BaseException:
+        # a failed rank (e.g. a byte-range share whose guessed boundary the rank in front could not confirm) leaves no
+        # `<out>.partNNN` behind; the launcher ends the other ranks, whose handlers remove theirs
+        if world > 1 and os.path.exists(part_path):
+            os.remove(part_path)
+        raise
     finally:
         stop.set()
     if os.environ.get("RMR_INFER_TIMING"):

@@ -1229,16 +1229,18 @@ class Read:
 
 
 def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_scaling=None,
-                                 skip_non_primary=True, decode_batch=256, parse_ref_align=True, shard=None):
+                                 skip_non_primary=True, decode_batch=256, parse_ref_align=True, shard=None, device=None):
     """(io.Read, error-or-None) for every BAM record whose signal is in the POD5 file — the
     read-producing front of infer_from_pod5_and_bam (src/remora/inference.py:477-519).  The signals of
     `decode_batch` consecutive records are decompressed together (zstd on the host, VBZ on the GPU) and their
     move tables are expanded in one launch; decode_batch <= 1 works read by read (one launch per read).  `parse_ref_align=False` skips the
-    reference side of the alignment (MD reconstruction, ref_to_signal) when only basecall-anchored reads are needed."""
+    reference side of the alignment (MD reconstruction, ref_to_signal) when only basecall-anchored reads are needed.
+    `device`: the GPU that decodes (the model's): the generator usually runs in a producer THREAD, and a new thread's
+    current device is 0 whatever the rank's device is - every rank of a `--gpus N` run would otherwise decode on GPU 0."""
     signals = Pod5File(pod5_path)
     from .engine import get_ingest_engine
 
-    ingest_eng = get_ingest_engine() if decode_batch > 1 else None  # own stream: not behind the model's kernels
+    ingest_eng = get_ingest_engine(device) if decode_batch > 1 else None  # own stream: not behind the model's kernels
 
     def emit(recs):
         if decode_batch > 1 and recs:
@@ -1416,9 +1418,12 @@ class BamWriter:
         self._fh = open(path, "wb")
         self._eof = bool(eof)
         self._level = level  # zlib level of the BGZF members (None = RMR_BAM_LEVEL, default 6 = htslib's)
-        self._buf = bytearray(header_bytes)
+        self._buf = bytearray()
         self._pool = ThreadPoolExecutor(max_workers=max(int(threads), 1))
         self._pending, self._max_pending = deque(), int(max_pending)
+        # the header goes through write(): one with many reference sequences (hg38 with alt / decoy contigs: > 64 KiB) is
+        # split into members of at most 0xFF00 bytes like everything else (a BGZF member holds at most 64 KiB)
+        self.write(bytes(header_bytes))
 
     def _drain(self, keep):
         while len(self._pending) > keep:
@@ -1478,31 +1483,42 @@ def concat_bam_parts(out_path, part_paths, remove=True):
 
     part_paths = list(part_paths)
 
+    how = {"copy_file_range": 0, "sendfile": 0, "read_write": 0}  # parts appended by each way (returned: tests look at it)
+
     def append(src_path, out):
         with open(src_path, "rb") as fh:
             left = os.fstat(fh.fileno()).st_size
             out.flush()
-            for fn in (getattr(os, "copy_file_range", None), None):
+            for name in ("copy_file_range", "sendfile"):
+                if not hasattr(os, name):
+                    continue
                 try:
                     while left > 0:
-                        if fn is not None:
-                            n = fn(fh.fileno(), out.fileno(), min(left, 1 << 30))
+                        if name == "copy_file_range":  # (both advance the file offsets of the descriptors they are given)
+                            n = os.copy_file_range(fh.fileno(), out.fileno(), min(left, 1 << 30))
                         else:
                             n = os.sendfile(out.fileno(), fh.fileno(), None, min(left, 1 << 30))
                         if n == 0:
                             break
                         left -= n
                     if left == 0:
+                        how[name] += 1
+                        out.seek(0, os.SEEK_END)  # the Python file object did not see the descriptor move
                         return
-                except (OSError, AttributeError):
+                except OSError:
                     pass  # not supported between these files: the next way down
+            out.seek(0, os.SEEK_END)
             shutil.copyfileobj(fh, out, 1 << 22)  # (fh stands where the kernel copies stopped)
+            how["read_write"] += 1
 
     rest = part_paths
     if remove and part_paths:
         os.replace(part_paths[0], out_path)
         rest = part_paths[1:]
-    with open(out_path, "ab" if remove and part_paths else "wb") as out:
+    # "r+b" and a seek to the end, NOT "ab": copy_file_range / sendfile refuse a descriptor opened with O_APPEND (EBADF /
+    # EINVAL), which silently sent every join down the read-write loop
+    with open(out_path, "r+b" if remove and part_paths else "wb") as out:
+        out.seek(0, os.SEEK_END)
         for p in rest:
             append(p, out)
         out.write(_BGZF_EOF)
@@ -1510,3 +1526,4 @@ def concat_bam_parts(out_path, part_paths, remove=True):
     if remove:
         for p in part_paths:
             os.remove(p)
+    return how

@@ -249,7 +249,8 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
 
     batch, seen = [], 0
     for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,
-                                                     skip_non_primary=skip_non_primary, shard=shard):
+                                                     skip_non_primary=skip_non_primary, shard=shard,
+                                                     device=engine.device if engine is not None else None):
         if seen >= num_reads:
             break
         seen += 1

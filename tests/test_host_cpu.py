@@ -1773,7 +1773,10 @@ def test_bam_parts_join_into_one_valid_bam(tmp_path):
         with rio.BamWriter(f"{out}.part{rank:03d}", header if rank == 0 else b"", eof=False, threads=2) as w:
             for r in rio._iter_bam_records_native(src, False, 8, start_voffset=st, max_records=n):
                 w.write(rio.record_with_mod_tags(r, None, None))
-    rio.concat_bam_parts(out, [f"{out}.part{r:03d}" for r in range(world)])
+    how = rio.concat_bam_parts(out, [f"{out}.part{r:03d}" for r in range(world)])
+    # the two appended parts went through the kernel (copy_file_range / sendfile), not through the read-write loop: an
+    # output opened with O_APPEND made both fail silently (round-3 advice)
+    assert how["read_write"] == 0 and how["copy_file_range"] + how["sendfile"] == world - 1, how
     assert not any(p.startswith("joined.bam.part") for p in os.listdir(tmp_path))
     blob = open(out, "rb").read()
     assert blob.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
@@ -1781,6 +1784,37 @@ def test_bam_parts_join_into_one_valid_bam(tmp_path):
     assert plain.startswith(header) and plain[len(header):] == b"".join(raw)
     back = list(rio.iter_bam_records(out))
     assert [r.query_name for r in back] == [r.query_name for r in recs]
+
+
+def test_bam_writer_splits_a_header_larger_than_one_bgzf_member(tmp_path):
+    """A header with thousands of reference sequences (hg38 with alt / decoy contigs) is larger than the 64 KiB a BGZF member
+    may hold: every member the writer emits must inflate to at most 65536 bytes (ISIZE), whatever the header's size, and the
+    stream must read back whole."""
+    import gzip
+    import struct
+
+    from remora_amd import io as rio
+
+    text = b"@HD\tVN:1.6\n" + b"".join(b"@SQ\tSN:contig_%05d_alt\tLN:%d\n" % (i, 1000 + i) for i in range(6000))
+    refs = b"".join(struct.pack("<i", 17) + b"contig_%05d_alt\0" % i + struct.pack("<i", 1000 + i) for i in range(6000))
+    header = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 6000) + refs
+    assert len(header) > 3 * 65536
+    rec = struct.pack("<iiBBHHHIiii", -1, -1, 3, 0, 4680, 0, 4, 4, -1, -1, 0) + b"r0\0" + bytes([0x12, 0x48]) + b"\xff" * 4
+    rec = struct.pack("<i", len(rec)) + rec
+    for eof in (True, False):
+        path = tmp_path / f"big_header_{eof}.bam"
+        with rio.BamWriter(str(path), header, threads=2, eof=eof) as w:
+            for _ in range(5):
+                w.write(rec)
+        blob = open(path, "rb").read()
+        off, sizes = 0, []
+        while off < len(blob):
+            assert blob[off : off + 4] == b"\x1f\x8b\x08\x04" and blob[off + 12 : off + 14] == b"BC"
+            bsize = struct.unpack_from("<H", blob, off + 16)[0] + 1
+            sizes.append(struct.unpack_from("<I", blob, off + bsize - 4)[0])
+            off += bsize
+        assert off == len(blob) and max(sizes) <= 65536, max(sizes)
+        assert gzip.decompress(blob) == header + 5 * rec
 
 
 def struct_pack_record(rec):
