@@ -82,3 +82,62 @@ def pod5_reads_cpu(pod5_path, read_ids=None):
         off, scale = f.calibration(rid)
         out.append(rio.Pod5Read(rid, np.concatenate(parts) if len(parts) > 1 else parts[0], off, scale))
     return out
+
+
+class RecordWithTags:
+    """A BAM record seen through edited tags, for the branches of Read.add_alignment (src/remora/io.py:1972-2044) that the
+    reference's test files never take: tags dropped (`sm` / `sd` -> median / MAD scaling), added or replaced (`sp`, `pi`
+    -> split reads), another query name (the child of a split read).  Everything else is the wrapped record's.  Used by
+    tools/gen_golden.py (fed to the reference's add_alignment) and by the tests (fed to remora_amd's) alike."""
+
+    _HOT = ("mv", "ts", "ns", "sp", "sm", "sd", "pi")
+
+    def __init__(self, rec, drop=(), add=None, query_name=None):
+        add = dict(add or {})
+        self._rec = rec
+        self.tags = [(k, v) for k, v in rec.tags if k not in drop and k not in add] + list(add.items())
+        self.query_name = rec.query_name if query_name is None else query_name
+
+    def hot_tags(self):
+        hot = dict(self._rec.hot_tags()) if hasattr(self._rec, "hot_tags") else dict(self._rec.tags)
+        names = {k for k, _ in self.tags}
+        hot = {k: v for k, v in hot.items() if k in names}
+        hot.update({k: v for k, v in self.tags if k in self._HOT and k not in hot})
+        for k, v in self.tags:  # replaced values win
+            if k in self._HOT and k != "mv":
+                hot[k] = v
+        return hot
+
+    def get_tag(self, name):
+        for k, v in self.tags:
+            if k == name:
+                return v
+        raise KeyError(name)
+
+    def __getattr__(self, name):  # flag, is_reverse, reference_name, query_sequence, to_dict, cigartuples, ...
+        return getattr(self._rec, name)
+
+
+REAL_READ_BRANCHES = ("rev", "nosmsd", "split", "pa")
+PA_SCALING = (87.5, 14.25)  # picoamp -> zero-centred picoamp (shift, scale) of the "pa" branch
+SPLIT_PREFIX = 137          # samples of the parent read in front of the child of the "split" branch
+
+
+def real_read_branch(variant, pod, rec, rng_seed):
+    """(read id, dacs, record, add_alignment keyword arguments, reverse_signal at read creation) of one branch case, built the
+    same way for the reference (generator) and for remora_amd (test):
+      rev     the signal is read 3'->5' (RNA): reversed when the read is made (io.py:466) and around the sp/ts/ns trims
+      nosmsd  no sm / sd tags: the pA -> norm scaling is median / MAD of the pA signal (io.py:1851-1856)
+      split   the record is the child of a longer parent read: `sp` samples are cut off the front, `pi` names the parent
+      pa      pa_scaling given: into_remora_read composes the zero-centred pA scaling instead of sm / sd (io.py:2159-2167)"""
+    if variant == "rev":
+        return pod.read_id, pod.signal[::-1], rec, dict(reverse_signal=True), True
+    if variant == "nosmsd":
+        return pod.read_id, pod.signal, RecordWithTags(rec, drop=("sm", "sd")), {}, False
+    if variant == "split":
+        front = np.random.default_rng(rng_seed).integers(300, 700, SPLIT_PREFIX).astype(pod.signal.dtype)
+        parent = "parent-of-" + pod.read_id
+        return parent, np.concatenate([front, pod.signal]), RecordWithTags(rec, add={"sp": SPLIT_PREFIX, "pi": parent}), {}, False
+    if variant == "pa":
+        return pod.read_id, pod.signal, rec, dict(pa_scaling=PA_SCALING), False
+    raise ValueError(variant)

@@ -94,7 +94,14 @@ def test_fused_front_vs_oracle_and_unfused(torch_cuda, O, cfg, num_out):
         assert np.array_equal(out.argmax(1)[clear], ref.argmax(1)[clear])
 
 
-def test_fused_front_golden_models(torch_cuda, O):
+# 16-bit error on networks with the REFERENCE's default initialisation (the golden models): measured 5.5e-4 .. 1.5e-3 in f16
+# and 5.0e-3 .. 5.3e-3 in bf16 on logits of magnitude 0.9 .. 1.6 (tools/measure_16bit_parity.py, round 4); the gates sit 25-30 %
+# above the worst model of each type.  (The synthetic networks of bench.py are deliberately 5-10x more sensitive: below.)
+GOLDEN_TOL = {"f16": 2e-3, "bf16": 6.5e-3}
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_fused_front_golden_models(torch_cuda, O, dtype):
     """The reference-generated logits (tests/golden/model_convlstm_*.npz; weights with non-trivial BatchNorm stats)."""
     from conftest import golden
     from remora_amd.engine import get_engine
@@ -105,14 +112,14 @@ def test_fused_front_golden_models(torch_cuda, O):
         state = O.state_from_npz(g)
         size, kb, ka, L, num_out = (int(x) for x in g["params"])
         model = model_from_state(state, dict(chunk_context=(L // 2, L - L // 2), kmer_context_bases=(kb, ka)), device=0,
-                                 dtype="bf16")
+                                 dtype=dtype)
         eng = get_engine(0)
         eng.profile_reset()
         eng.profile_enable(True)
         out = model.infer_chunks(g["sigs"], g["seqs"], g["maps"], g["lens"], (kb, ka))
         eng.profile_enable(False)
         assert "fused_front" in eng.profile()  # k-mer lengths 9 (4,4) and 6 (2,3) are instantiated
-        assert np.abs(out - g["logits"]).max() <= BF16_TOL, name
+        assert np.abs(out - g["logits"]).max() <= GOLDEN_TOL[dtype], (name, dtype, float(np.abs(out - g["logits"]).max()))
 
 
 def test_fused_front_full_size_properties(torch_cuda):
@@ -223,22 +230,42 @@ def _centred_pair(torch, cfg, n, dtype, seed=0):
     ref = model_from_state(state, md, device=0, dtype="fp32").infer_chunks(*dev, kcb)
     out = model_from_state(state, md, device=0, dtype=dtype).infer_chunks(*dev, kcb)
     med = ref.median(dim=0).values
-    return ref - med, out - med
+    return ref - med, out - med, med
 
 
-@pytest.mark.parametrize("cfg,dtype,max_abs,mean_abs,agree,p999_max", [
-    ("C100", "f16", 2e-2, 6e-4, 0.999, 2e-2), ("C200", "f16", None, 1.2e-3, 0.999, 2e-2),
-    ("C100", "bf16", 0.12, 3e-3, 0.999, 6e-2), ("C200", "bf16", None, 5e-3, 0.995, 0.2)])
-def test_16bit_pipelines_against_the_fp32_path_100k(torch_cuda, cfg, dtype, max_abs, mean_abs, agree, p999_max):
+# Gates of the synthetic (deliberately amplified: synth.py scales conv x2.45, LSTM x2.5, fc x12) networks = the measured level
+# x 1.25-1.3 (tools/measure_16bit_parity.py, round 4; the kernels are deterministic, the margin is for other shapes of the
+# same arithmetic only).  Measured max / mean / 99.9th percentile over 100 k chunks against the fp32 path:
+#   C100 f16 5.9e-3 / 1.4e-4 / 2.6e-3     C100 bf16 4.6e-2 / 1.3e-3 / 2.7e-2
+#   C200 f16 8.4e-2 / 2.4e-4 / 1.4e-2     C200 bf16 0.244  / 2.1e-3 / 0.131
+# and over the first 8192 chunks against the ORACLE's fp32 forward (the comparand that is not this library):
+#   C100 f16 5.9e-3, bf16 3.9e-2;  C200 f16 3.8e-2, bf16 0.231
+@pytest.mark.parametrize("cfg,dtype,max_abs,mean_abs,agree,p999_max,oracle_max", [
+    ("C100", "f16", 8e-3, 2e-4, 0.999, 3.5e-3, 8e-3), ("C200", "f16", 0.11, 3.2e-4, 0.999, 1.9e-2, 5e-2),
+    ("C100", "bf16", 6e-2, 1.75e-3, 0.999, 3.6e-2, 5.2e-2), ("C200", "bf16", 0.32, 2.8e-3, 0.995, 0.17, 0.30)])
+def test_16bit_pipelines_against_the_fp32_path_100k(torch_cuda, O, cfg, dtype, max_abs, mean_abs, agree, p999_max, oracle_max):
     """100 k chunks of the configs[3] / configs[4] shapes, 16-bit pipeline against the fp32 pipeline (itself within 5e-6 of a
-    float64 evaluation, bench.py `precision`): mean |error|, argmax agreement over ALL chunks whose fp32 margin exceeds 2e-2,
-    and - where the arithmetic permits it - the maximum.  f16 meets max <= 2e-2 and >= 99.9 % agreement at C100; at C200
-    (58 LSTM steps of a deliberately sensitive random network) single chunks amplify ANY 16-bit rounding beyond 2e-2 (the
-    float64 emulation of half arithmetic shows 0.11 on 30 k chunks, of bf16 0.26; tests/manual/bf16_error_sources.py), so
-    the gate there is agreement + mean + the 99.9th percentile.  bf16's numbers are those of its 8-bit mantissa, not of the
-    kernels: test_16bit_error_is_the_arithmetic_not_the_kernel."""
+    float64 evaluation, bench.py `precision`) AND, on the first 8192 chunks, against the oracle's fp32 forward: maximum, mean,
+    99.9th percentile of the per-chunk maximum, argmax agreement over ALL chunks whose fp32 margin exceeds 2e-2.  At C200
+    (58 LSTM steps of a deliberately sensitive random network) single chunks amplify ANY 16-bit rounding (the float64
+    emulation of half arithmetic shows 0.11 on 30 k chunks, of bf16 0.26; oracle/lowp_emulation.py); on networks with the
+    reference's initialisation the same kernels stay below 2e-3 / 6.5e-3 (test_fused_front_golden_models).  bf16's numbers
+    are those of its 8-bit mantissa, not of the kernels: test_16bit_error_is_the_arithmetic_not_the_kernel."""
+    from oracle import torch_ref
+    from remora_amd import synth
+
     torch = torch_cuda
-    ref, out = _centred_pair(torch, cfg, 100_000, dtype)
+    ref, out, med = _centred_pair(torch, cfg, 100_000, dtype)
+    # the oracle as comparand: same chunks (shard 3), same state (seed 0), first 8192
+    cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+    d = synth.synth_chunks_config(cfg, 100_000, shard=3)
+    net = torch_ref.from_state(synth.synth_state("conv_lstm", 64, 9, num_out, seed=0))
+    enc = torch.from_numpy(O.compute_encoded_kmer_batch(kcb[0], kcb[1], d["sequence"][:8192], d["sequence_to_signal_mapping"][:8192],
+                                                        d["sequence_lengths"][:8192]))
+    with torch.no_grad():
+        ref_cpu = net(torch.from_numpy(d["signal"][:8192]), enc)
+    err_oracle = float((out[:8192].cpu() - (ref_cpu - med.cpu())).abs().max())
+    assert err_oracle <= oracle_max, (cfg, dtype, err_oracle)
     err = (out - ref).abs()
     top = ref.topk(2, dim=1).values
     clear = (top[:, 0] - top[:, 1]) > 2e-2
@@ -247,8 +274,7 @@ def test_16bit_pipelines_against_the_fp32_path_100k(torch_cuda, cfg, dtype, max_
     stats = (cfg, dtype, float(err.max()), float(err.mean()), agreement)
     assert float(err.mean()) <= mean_abs, stats
     assert agreement >= agree, stats
-    if max_abs is not None:
-        assert float(err.max()) <= max_abs, stats
+    assert float(err.max()) <= max_abs, stats
     p999 = float(torch.quantile(err.max(dim=1).values.float(), 0.999))
     assert p999 <= p999_max, stats + (p999,)
 

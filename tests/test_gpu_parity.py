@@ -578,6 +578,54 @@ def test_real_reads_pod5_bam_end_to_end(torch_cuda, O, tmp_path, prefix, n_chunk
     assert i == 13 and n == n_chunks
 
 
+@pytest.mark.parametrize("prefix", ["can", "mod"])
+def test_add_alignment_branches_the_test_files_never_take(torch_cuda, O, tmp_path, prefix):
+    """Read.add_alignment / into_remora_read on the branches no record of tests/data exercises — reverse_signal (the double
+    flip around the sp / ts / ns trims and the reversed move table, src/remora/io.py:1995-2010), no sm / sd tags (median /
+    MAD scaling, :1851-1856, :2035-2040), split reads (sp + pi, the child's id, and the mismatch error, :2001-2020),
+    pa_scaling (:442-461, :2159-2167) — against the reference's own add_alignment run on the same records through the same
+    edited tags (tests/golden_util.py: real_read_branch; tools/gen_golden.py: gen_real_read_branches)."""
+    from golden_util import REAL_READ_BRANCHES, RecordWithTags, pod5_reads_cpu, real_read_branch
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+    from remora_amd.inference import call_read_mods
+    from remora_amd.model_util import load_model
+
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    g = golden("real_read_branches.npz")
+    model, md = load_model(_mint_pt(tmp_path, _real_reads_golden("can"), O), device=0)
+    pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(data, f"{prefix}_reads.pod5"))}
+    recs = list(rio.iter_bam_records(os.path.join(data, f"{prefix}_mappings.bam")))
+    assert len(recs) == 14
+    for i, rec in enumerate(recs):
+        pod = pods[rec.query_name]
+        for variant in REAL_READ_BRANCHES:
+            read_id, dacs, rec_v, kw, _ = real_read_branch(variant, pod, rec, 1000 + i)
+            read = rio.Read(read_id=read_id, dacs=dacs, shift_dacs_to_pa=pod.calibration_offset, scale_dacs_to_pa=pod.calibration_scale)
+            read.add_alignment(rec_v, parse_ref_align=False, **kw)
+            rr = read.into_remora_read(False)
+            key = f"{prefix}_r{i}_{variant}"
+            assert [rr.shift, rr.scale] == list(g[f"{key}_shift_scale"]), key
+            assert rr.dacs.size == int(g[f"{key}_ndacs"]), key
+            assert int(np.bitwise_xor.reduce(rr.dacs.astype(np.int64) * (np.arange(rr.dacs.size) % 251 + 1))) == int(g[f"{key}_dacs_crc"]), key
+            assert np.array_equal(rr.seq_to_sig_map, g[f"{key}_map"]), key
+            assert [read.read_id, read.child_read_id] == [str(x) for x in g[f"{key}_read_ids"]], key
+            nn_out, labels, pos = call_read_mods(rr, model, md)
+            assert np.array_equal(pos, g[f"{key}_pos"]), key
+            assert np.abs(nn_out - g[f"{key}_nn_out"]).max() <= 1e-4, key
+    pod, rec = pods[recs[0].query_name], recs[0]
+    read = rio.Read(read_id=pod.read_id, dacs=pod.signal, shift_dacs_to_pa=pod.calibration_offset, scale_dacs_to_pa=pod.calibration_scale)
+    with pytest.raises(RemoraError) as ei:
+        read.add_alignment(RecordWithTags(rec, add={"pi": "somebody-else"}), parse_ref_align=False)
+    assert str(ei.value) == str(g[f"{prefix}_split_mismatch_error"])
+    # the batched ingest takes the same branches (reverse_signal through the batched move-table expansion)
+    for i, (read, err) in enumerate(rio.iter_reads_from_pod5_and_bam(os.path.join(data, f"{prefix}_reads.pod5"),
+                                                                     os.path.join(data, f"{prefix}_mappings.bam"),
+                                                                     reverse_signal=True, parse_ref_align=False)):
+        assert err is None
+        assert np.array_equal(read.into_remora_read(False).seq_to_sig_map, g[f"{prefix}_r{i}_rev_map"])
+
+
 def test_batched_call_reads_mods_matches_single_read_api(torch_cuda, O):
     from oracle import torch_ref
     from remora_amd import synth

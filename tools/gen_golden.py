@@ -758,6 +758,66 @@ def _gen_real_reads_one(R, out, data, prefix, rio, pod5_reads_cpu):
           sum(int(d[f"r{i}_ra_pos"].size) for i in range(len(recs))), "reference-anchored chunks")
 
 
+def gen_real_read_branches(R, out):
+    """The branches of io.Read.add_alignment / into_remora_read that the reference's test files never take
+    (src/remora/io.py:1995-2044 reverse_signal, 1851-1856 median / MAD without sm / sd, 2001-2020 split reads with sp / pi,
+    442-461 + 2159-2167 pa_scaling), driven on the same parsed records as gen_real_reads through edited tags
+    (tests/golden_util.py: real_read_branch) -> real_read_branches.npz: per file, record and branch the composed shift /
+    scale, the trimmed signal's checksum, the query-to-signal map and the logits of the CG 5mC model of real_reads_can.npz."""
+    import tempfile
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from golden_util import REAL_READ_BRANCHES, RecordWithTags, pod5_reads_cpu, real_read_branch
+    from remora_amd import io as rio
+
+    data = os.path.join(out, "data")
+    net = make_net(R, "ConvLSTM_w_ref", 64, 9, 2, seed=300)  # the model of gen_real_reads
+    ckpt = _ckpt((4, 4), (50, 50), ["m"], ["5mC"], [("CG", 0)], 64, 9, 2)
+    with tempfile.TemporaryDirectory() as td:
+        pt = os.path.join(td, "m.pt")
+        R.model_util.export_model_torchscript(ckpt, net, pt)
+        model, md = R.model_util.load_model(pt, quiet=True, eval_only=True)
+    d, n_cases = {}, 0
+    for prefix in ("can", "mod"):
+        pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(data, f"{prefix}_reads.pod5"))}
+        recs = list(rio.iter_bam_records(os.path.join(data, f"{prefix}_mappings.bam")))
+        for i, rec in enumerate(recs):
+            pod = pods[rec.query_name]
+            for variant in REAL_READ_BRANCHES:
+                read_id, dacs, rec_v, kw, _ = real_read_branch(variant, pod, rec, 1000 + i)
+                init_kw = {}
+                if "pa_scaling" in kw:  # iter_signal hands it to the constructor as well (io.py:457-472)
+                    init_kw = dict(shift_pa_to_zc_pa=kw["pa_scaling"][0], scale_pa_to_zc_pa=kw["pa_scaling"][1])
+                read = R.io.Read(read_id=read_id, dacs=dacs, shift_dacs_to_pa=pod.calibration_offset,
+                                 scale_dacs_to_pa=pod.calibration_scale, **init_kw)
+                read.add_alignment(rec_v, parse_ref_align=False, **kw)
+                rr = read.into_remora_read(False)
+                key = f"{prefix}_r{i}_{variant}"
+                d[f"{key}_shift_scale"] = np.asarray([rr.shift, rr.scale], np.float64)
+                d[f"{key}_ndacs"] = np.asarray(rr.dacs.size)
+                d[f"{key}_dacs_crc"] = np.asarray(int(np.bitwise_xor.reduce(rr.dacs.astype(np.int64) * (np.arange(rr.dacs.size) % 251 + 1))))
+                d[f"{key}_map"] = np.asarray(rr.seq_to_sig_map, np.int64)
+                d[f"{key}_read_ids"] = np.asarray([read.read_id, read.child_read_id])
+                nn_out, labels, pos = R.inference.call_read_mods(rr, model, md)
+                d[f"{key}_nn_out"] = np.asarray(nn_out, np.float32)
+                d[f"{key}_pos"] = np.asarray(pos, np.int64)
+                n_cases += 1
+        # the error of a split read whose parent is another read (io.py:2016-2018), once per file
+        pod, rec = pods[recs[0].query_name], recs[0]
+        read = R.io.Read(read_id=pod.read_id, dacs=pod.signal, shift_dacs_to_pa=pod.calibration_offset,
+                         scale_dacs_to_pa=pod.calibration_scale)
+        try:
+            read.add_alignment(RecordWithTags(rec, add={"pi": "somebody-else"}), parse_ref_align=False)
+            raise AssertionError("expected an error")
+        except R.remora.RemoraError as e:
+            d[f"{prefix}_split_mismatch_error"] = np.asarray(str(e))
+    np.savez_compressed(os.path.join(out, "real_read_branches.npz"), **d)
+    print("real_read_branches:", n_cases, "cases")
+
+
 def gen_core_dataset(R, out):
     """On-disk CoreRemoraDataset (src/remora/data_chunks.py:926-1702) written by the reference from
     two synthetic labelled reads (chunk_context (50,50), k-mer (4,4)), then read back by the
@@ -1285,6 +1345,7 @@ def main():
         post=gen_post,
         dataset_batches=gen_dataset_batches,
         real_reads=gen_real_reads,
+        real_read_branches=gen_real_read_branches,
         core_dataset=gen_core_dataset,
         refine=gen_refine,
         batching=gen_batching,
