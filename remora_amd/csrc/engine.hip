@@ -698,7 +698,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     if (n <= 0) return 0;
     if (m->f16 && (enc || !fused_front_supported(m, seq_w, map_w)))
         RMR_FAIL(RMR_ERR_INVALID, "dtype f16 runs on the fused kernels only: chunk arrays (not a dense one-hot tensor), sequence rows of at "
-                                  "most 62 bases, chunk length a multiple of 4 that fits a CU's LDS");
+                                  "most 256 columns, a chunk length that is a multiple of 4");
     if (!enc && fused_front_supported(m, seq_w, map_w) && (m->f16 || tune_int("RMR_FUSED", 1))) {
         // plain-bf16 ConvLSTM: two launches per sub-batch, x (bf16, 3 KB/chunk @C100) is the only intermediate in
         // HBM; sub-batches are sized so that x stays in the 256 MiB Infinity Cache between producer and consumer

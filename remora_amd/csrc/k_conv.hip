@@ -40,6 +40,11 @@ struct ConvArgs {
     int cb;         // chunks per block iteration
     int plane;      // LDS plane stride in floats (multiple of 64)
     FastDiv div_pout;
+    // Position windows (long chunk contexts: one chunk's input no longer fits a block's LDS share).  nwin > 1: an iteration is
+    // ONE window of ONE chunk (cb == 1) - `pin` / `pout` above are then the rows staged / the columns computed per window, the
+    // chunk's own extents are pin_total / pout_total, and window w covers output positions [w * pout, (w + 1) * pout).  The
+    // reference's Conv1d knows no such limit (models/ConvLSTM_w_ref.py:39-58 is length-agnostic).
+    int nwin, pin_total, pout_total;
 };
 
 
@@ -108,10 +113,10 @@ __device__ __forceinline__ void conv_tiles_to(const float *smem, int plane, int 
 // the kernel below: columns leave as 16-byte channel-last stores to HBM
 template <int IC, int KW, int STRIDE, bool TWO>
 __device__ __forceinline__ void conv_tiles(const ConvArgs &a, const float *smem, const float (&A)[KW * IC / 4], const f32x4 b4,
-                                           int64_t chunk0, int ncols, int tile, int w, int q, int nn) {
+                                           int64_t chunk0, int pbase, int ncols, int tile, int w, int q, int nn) {
     conv_tiles_to<IC, KW, STRIDE, TWO>(smem, a.plane, a.pin, a.pout, a.div_pout, A, b4, ncols, tile, q, nn,
                                        [&](int ch, int p, const f32x4 y) {
-                                           float *dst = a.out + ((size_t)(chunk0 + ch) * a.pout + p) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                                           float *dst = a.out + ((size_t)(chunk0 + ch) * a.pout_total + pbase + p) * a.out_row + a.out_coff + 16 * w + 4 * q;
                                            *reinterpret_cast<f32x4 *>(dst) = y;
                                        });
 }
@@ -134,16 +139,27 @@ __global__ __launch_bounds__(256, conv_min_waves(IC, KW)) void conv_mfma_kernel(
     }
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
 
-    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    const int64_t n_iters = a.nwin > 1 ? a.n * a.nwin : (a.n + a.cb - 1) / a.cb;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
-        const int64_t chunk0 = it * a.cb;
-        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        // whole chunks (nwin == 1): cb chunks from chunk0;  windows: window `win` of chunk `chunk0`, rows clipped to the chunk
+        int64_t chunk0 = it * a.cb;
+        int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb), pbase = 0, rows = nch * a.pin, ncols = nch * a.pout;
+        size_t src_row = (size_t)chunk0 * a.pin;
+        if (a.nwin > 1) {
+            chunk0 = it / a.nwin;  // (64-bit: n * nwin may pass 2^31 only in theory, the division is per iteration anyway)
+            const int win = (int)(it - chunk0 * a.nwin);
+            pbase = win * a.pout;
+            nch = 1;
+            ncols = a.pout_total - pbase < a.pout ? a.pout_total - pbase : a.pout;
+            rows = a.pin_total - pbase * STRIDE < a.pin ? a.pin_total - pbase * STRIDE : a.pin;
+            src_row = (size_t)chunk0 * a.pin_total + (size_t)pbase * STRIDE;
+        }
         __syncthreads();  // all reads of the previous iteration are done
-        {                 // stage nch * pin rows of IC floats into the 4 planes
+        {                 // stage `rows` rows of IC floats into the 4 planes
             constexpr int R4 = IC / 4;
             constexpr int UNR = 8;  // loads in flight per thread before the first LDS write
-            const int total4 = nch * a.pin * R4;
-            const float4 *src = reinterpret_cast<const float4 *>(a.in + (size_t)chunk0 * a.pin * a.in_row);
+            const int total4 = rows * R4;
+            const float4 *src = reinterpret_cast<const float4 *>(a.in + src_row * a.in_row);
             for (int base = tid; base < total4; base += UNR * (int)blockDim.x) {
                 float4 v[UNR];
                 int dsto[UNR];
@@ -161,12 +177,11 @@ __global__ __launch_bounds__(256, conv_min_waves(IC, KW)) void conv_mfma_kernel(
             }
         }
         __syncthreads();
-        const int ncols = nch * a.pout;
         const int ntiles = (ncols + 15) >> 4;
         for (int tile = 0; tile < ntiles; tile += 2) {
             // an odd last tile runs alone (wave-uniform): no MFMA is spent on a padding tile
-            if (tile + 1 < ntiles) conv_tiles<IC, KW, STRIDE, true>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
-            else conv_tiles<IC, KW, STRIDE, false>(a, smem, A, b4, chunk0, ncols, tile, w, q, nn);
+            if (tile + 1 < ntiles) conv_tiles<IC, KW, STRIDE, true>(a, smem, A, b4, chunk0, pbase, ncols, tile, w, q, nn);
+            else conv_tiles<IC, KW, STRIDE, false>(a, smem, A, b4, chunk0, pbase, ncols, tile, w, q, nn);
         }
     }
 }
@@ -210,14 +225,27 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
         const double eff = (double)cols / (16.0 * ((cols + 15) / 16));
         if (eff > best + 1e-9) { best = eff; cb = k; }
     }
-    const int plane = ((cb * pin * RS) + 63) & ~63;
+    // a chunk whose rows do not fit a block's share goes through position windows: the most output positions whose input rows
+    // ((win - 1) * STRIDE + KW of them) fit the share, one window of one chunk per iteration
+    int nwin = 1, pin_w = pin, pout_w = pout;
+    if (row_bytes > budget) {
+        const int rows_fit = (int)(budget / ((size_t)RS * 4 * sizeof(float)));
+        pout_w = (rows_fit - KW) / STRIDE + 1;
+        if (pout_w < 16) RMR_FAIL(RMR_ERR_INVALID, "conv layer: not even a 16-column window fits %zu B of LDS", budget);
+        pout_w &= ~15;  // whole column tiles
+        nwin = (pout + pout_w - 1) / pout_w;
+        pin_w = (pout_w - 1) * STRIDE + KW;
+        cb = 1;
+    }
+    const int plane = ((cb * pin_w * RS) + 63) & ~63;
     const size_t lds = (size_t)plane * 4 * sizeof(float) + 64;  // + trash slot for masked staging writes
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "conv layer needs %zu B of LDS", lds);
     ConvArgs a;
     a.in = in; a.out = out; a.apack = c.apack; a.bias = c.bias; a.n = n;
-    a.in_row = in_row; a.pin = pin; a.pout = pout; a.out_row = out_row; a.out_coff = out_coff;
-    a.cb = cb; a.plane = plane; a.div_pout = make_fastdiv(pout);
-    const int64_t iters = (n + cb - 1) / cb;
+    a.in_row = in_row; a.pin = pin_w; a.pout = pout_w; a.out_row = out_row; a.out_coff = out_coff;
+    a.cb = cb; a.plane = plane; a.div_pout = make_fastdiv(pout_w);
+    a.nwin = nwin; a.pin_total = pin; a.pout_total = pout;
+    const int64_t iters = nwin > 1 ? n * nwin : (n + cb - 1) / cb;
     const int threads = threads_pb;
     // persistent blocks: a grid of several times the resident count evens out the tail
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8) * (c.oc >= 64 ? 1 : 64 / c.oc);

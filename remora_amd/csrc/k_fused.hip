@@ -37,6 +37,8 @@
 #include "rmr_internal.h"
 #include "rmr_math.h"
 
+#include <type_traits>
+
 namespace rmr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -63,6 +65,13 @@ struct FusedArgs {
     FastDiv d_L, d_P1, d_P3, d_T, d_maxlen;
     unsigned mg_ps2, mg_pq1;  // ceil(2^32 / tile pairs per chunk) of sig_conv2 / seq_conv1: S2's item -> (chunk, pair) on the SALU
     int abl;  // experiment builds only (-DRMR_TIMING_ABLATIONS): bit mask of stages to skip, see ABL() below
+    // Position windows (WIN kernels: chunks too long for a CU's LDS, e.g. chunk_context (500, 500)).  The kernel then works on
+    // VIRTUAL chunks: window `win` of chunk `c` covers output positions [win * Tw, (win + 1) * Tw) of the chunk's T_total and
+    // reads L samples from sample 3 * Tw * win on (L, P1 .. T above are the WINDOW's geometry, T >= Tw); the k-mer one-hot looks
+    // positions up in the whole chunk's mapping row.  Per virtual chunk of an iteration, LDS at o_win: {first sample, valid
+    // outputs, x row of its first output (two words)}.
+    int nwin, Tw, L_total, T_total, o_win;
+    FastDiv d_nwin, d_L4, d_seqw, d_mapw;
 };
 
 // Timing ablations (which stage costs what): compiled in only with -DRMR_TIMING_ABLATIONS (make abl ->
@@ -264,7 +273,7 @@ struct InRegs {
 #define RMR_FUSED_STREAM_M1 0  // 1: merge_conv1's fragments (80 VGPRs) fetched per iteration after S3 instead of living in registers
 #endif
 
-template <int K, bool F16>
+template <int K, bool F16, bool WIN>
 #ifndef RMR_FUSED_WAVES_EU
 // Waves per SIMD the register budget is set for.  2 (254 VGPRs, merge_conv1 fragments resident, two blocks per CU) is the
 // shipped build.  The three-waves build (-DRMR_FUSED_WAVES_EU=3 -DRMR_FUSED_STREAM_M1=1 -DRMR_FUSED_S3_SPLIT=1
@@ -343,26 +352,64 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
     int nsearch = 1;  // bisection steps that cover maxlen + 1 mapping entries
     while ((1 << nsearch) < a.maxlen + 2) ++nsearch;
 
-    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    const int64_t n_items = WIN ? a.n * a.nwin : a.n;  // (virtual) chunks
+    const int64_t n_iters = (n_items + a.cb - 1) / a.cb;
+    int *s_win = reinterpret_cast<int *>(smem + a.o_win);  // WIN: [cb][4]
     // S0: each array of the chunks of an iteration is ONE contiguous run in HBM; the launcher keeps every run within
-    // 256 elements (float4 / byte / int16), so a thread carries one element of each from HBM to LDS
+    // 256 elements (float4 / byte / int16), so a thread carries one element of each from HBM to LDS.  (WIN: the virtual chunks
+    // of an iteration are windows of possibly different chunks - every thread finds its own chunk and window)
     auto fetch_inputs = [&](int64_t it) -> InRegs {
         InRegs r;
         r.sig = make_float4(0.f, 0.f, 0.f, 0.f); r.seq = 0; r.map = 0; r.len = 0;
         if (it >= n_iters || ABL(1)) return r;
         const int64_t chunk0 = it * a.cb;
-        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
-        if (tid < ((nch * a.L) >> 2)) r.sig = reinterpret_cast<const float4 *>(a.signal + (size_t)chunk0 * a.L)[tid];
-        if (tid < nch * a.seq_w) r.seq = a.seqs[(size_t)chunk0 * a.seq_w + tid];
-        if (tid < nch * a.map_w) r.map = a.maps[(size_t)chunk0 * a.map_w + tid];
-        if (tid < nch) r.len = a.lens[chunk0 + tid];
+        const int nch = (int)((n_items - chunk0) < a.cb ? (n_items - chunk0) : a.cb);
+        if constexpr (WIN) {
+            auto chunk_win = [&](int ci, int &win) {  // virtual chunk chunk0 + ci -> (chunk, window); exact for n * nwin < 2^24
+                const int v = (int)chunk0 + ci, c = fdiv(v, a.d_nwin);
+                win = v - c * a.nwin;
+                return c;
+            };
+            int win;
+            if (tid < ((nch * a.L) >> 2)) {
+                const int ci = fdiv(tid, a.d_L4), j = tid - ci * (a.L >> 2), c = chunk_win(ci, win);
+                const int smp = 3 * a.Tw * win + 4 * j;  // (a multiple of 4: Tw is)
+                if (smp < a.L_total) r.sig = *reinterpret_cast<const float4 *>(a.signal + (size_t)c * a.L_total + smp);
+            }
+            if (tid < nch * a.seq_w) {
+                const int ci = fdiv(tid, a.d_seqw), c = chunk_win(ci, win);
+                r.seq = a.seqs[(size_t)c * a.seq_w + (tid - ci * a.seq_w)];
+            }
+            if (tid < nch * a.map_w) {
+                const int ci = fdiv(tid, a.d_mapw), c = chunk_win(ci, win);
+                r.map = a.maps[(size_t)c * a.map_w + (tid - ci * a.map_w)];
+            }
+            if (tid < nch) r.len = a.lens[chunk_win(tid, win)];
+        } else {
+            if (tid < ((nch * a.L) >> 2)) r.sig = reinterpret_cast<const float4 *>(a.signal + (size_t)chunk0 * a.L)[tid];
+            if (tid < nch * a.seq_w) r.seq = a.seqs[(size_t)chunk0 * a.seq_w + tid];
+            if (tid < nch * a.map_w) r.map = a.maps[(size_t)chunk0 * a.map_w + tid];
+            if (tid < nch) r.len = a.lens[chunk0 + tid];
+        }
         return r;
     };
-    auto store_inputs = [&](const InRegs &r) {
+    auto store_inputs = [&](const InRegs &r, int64_t it) {
         reinterpret_cast<float4 *>(s_sig)[tid] = r.sig;  // the regions are 256 elements wide (launcher)
         s_seq[tid] = (unsigned char)r.seq < 4 ? r.seq : (int8_t)4;  // base codes 0..3, everything else (N, padding) = 4: missing
         s_map[tid] = r.map;
         if (tid < a.cb) s_len[tid] = (int16_t)(r.len < 0 ? 0 : (r.len > a.maxlen ? a.maxlen : r.len));
+        if constexpr (WIN) {
+            if (tid < a.cb) {
+                const int64_t v = it * a.cb + tid;
+                const int c = fdiv((int)(v < n_items ? v : 0), a.d_nwin), win = (int)(v < n_items ? v : 0) - c * a.nwin;
+                const int left = a.T_total - win * a.Tw;
+                const long long row = (long long)c * a.T_total + (long long)win * a.Tw;
+                s_win[4 * tid + 0] = 3 * a.Tw * win;
+                s_win[4 * tid + 1] = v < n_items ? (left < a.Tw ? left : a.Tw) : 0;
+                s_win[4 * tid + 2] = (int)(row & 0xFFFFFFFFll);
+                s_win[4 * tid + 3] = (int)(row >> 32);
+            }
+        }
     };
     __syncthreads();  // the zero fill is done before the first inputs land
     // column (chunk, position) -> operand row, once per block instead of a division and four multiply-adds per lane and
@@ -389,12 +436,12 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         v.w = (b1c >> 1) == 1 ? one1 : 0u;
         s_tab[tid] = v;
     }
-    store_inputs(fetch_inputs(blockIdx.x));
+    store_inputs(fetch_inputs(blockIdx.x), blockIdx.x);
 
     TS_DECL;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
-        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        const int nch = (int)((n_items - chunk0) < a.cb ? (n_items - chunk0) : a.cb);
         TS(9);
         __syncthreads();  // inputs of this iteration are in LDS; merge_conv1 of the previous one has read CAT (OH aliases it)
         // A fragments of the two M = 16 layers: fetched (L2-resident, 8 KB) at the top of every iteration and dead
@@ -420,7 +467,9 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         // p = #{mapping entries map[0..len] <= s} - 1, valid when 0 <= p < len), the K bases p..p+K-1 as 3-bit codes
         // (4 = missing), and the row of CG 16-byte pieces (bf16 1.0 = 0x3F80; piece cg = k-mer slots 2cg, 2cg+1)
         for (int row = tid; row < (ABL(4) ? 0 : nch) * a.L; row += 256) {
-            const int ci = fdiv(row, a.d_L), s = row - ci * a.L;
+            const int ci = fdiv(row, a.d_L);
+            int s = row - ci * a.L;
+            if constexpr (WIN) s += s_win[4 * ci];  // the position within the whole chunk
             const int16_t *mp = s_map + ci * a.map_w;
             const int len = s_len[ci];
             // the count by binary steps, in arithmetic: a v_cmp + v_cndmask pair through VCC costs 25 cycles on gfx950 against
@@ -617,12 +666,25 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
                 if (tile + 1 < ntiles) s4_pair<F16, true>(Am1, r0, r1, acc0, acc1);  // wave-uniform
                 else s4_pair<F16, false>(Am1, r0, r1, acc0, acc1);
 #endif
-                if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack<F16>(acc0, ABL(64), 0.6931471805599453f);
-                if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack<F16>(acc1, ABL(64), 0.6931471805599453f);
+                if constexpr (WIN) {  // a column's row of x: its window's first row + its position, if the window has that output
+                    auto put = [&](int col, const f32x4 &acc) {
+                        const int ci = fdiv(col, a.d_T), t = col - ci * a.T;
+                        if (t < s_win[4 * ci + 1]) {
+                            const long long row = (((long long)s_win[4 * ci + 3] << 32) | (unsigned)s_win[4 * ci + 2]) + t;
+                            *reinterpret_cast<uint2 *>(a.x + (size_t)row * 64 + 16 * w + 4 * q) = swish_pack<F16>(acc, ABL(64), 0.6931471805599453f);
+                        }
+                    };
+                    if (v0) put(col0, acc0);
+                    if (v1) put(col1, acc1);
+                } else {
+                    if (v0) *reinterpret_cast<uint2 *>(xo + (size_t)col0 * 64) = swish_pack<F16>(acc0, ABL(64), 0.6931471805599453f);
+                    if (v1) *reinterpret_cast<uint2 *>(xo + (size_t)col1 * 64) = swish_pack<F16>(acc1, ABL(64), 0.6931471805599453f);
+                }
             }
         }
         TS(7);
-        store_inputs(next_in);
+        if constexpr (WIN) __syncthreads();  // S4 read the window table that the next inputs' store rewrites
+        store_inputs(next_in, it + gridDim.x);
         TS(8);
     }
     TS_FLUSH;
@@ -631,9 +693,13 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
 // Chunks per block iteration and the LDS image for them: the largest count whose image leaves room for two blocks per CU
 // (RMR_FUSED_LDS_BUDGET) and whose input runs fit one element per thread (S0); a single chunk may take up to a whole CU's
 // LDS (long chunk contexts).  Returns 0 when not even one chunk fits — such shapes run through the unfused bf16 kernels.
-static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs &a, int &total) {
+static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs &a, int &total, int L_window = 0) {
     const int CG = (4 * m->desc.kmer_len + 7) / 8;
-    a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.P3 = m->P3; a.T = m->T;
+    if (L_window > 0) {  // the geometry of a position window of L_window samples (models/ConvLSTM_w_ref.py:41-50: 5, 5, 9 / 3 or 13 / 3, 5)
+        a.L = L_window; a.P1 = a.L - 4; a.P2 = a.P1 - 4; a.P3 = (a.P2 - 9) / 3 + 1; a.T = a.P3 - 4;
+    } else {
+        a.L = m->L; a.P1 = m->P1; a.P2 = m->P2; a.P3 = m->P3; a.T = m->T;
+    }
     auto up16 = [](int b) { return (b + 15) & ~15; };
     // RMR_FUSED_WAVES_EU blocks are resident per CU (one wave of each per SIMD): each gets its share of the 160 KB
     const int budget = tune_int("RMR_FUSED_LDS_BUDGET", (160 * 1024) / RMR_FUSED_WAVES_EU - 256);
@@ -646,6 +712,7 @@ static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs 
         a.o_map = off; off += 512;
         a.o_len = off; off += 16;
         a.o_tab = off; off += 64 * 16;  // the 16-byte one-hot piece of every pair of base codes
+        a.o_win = off; off += cb * 16;  // (windows only: 16 B per virtual chunk)
         a.o_col3 = off; off += up16(cb * a.P3 * 8);  // per output column of S3 / S4: where its operand rows begin
         a.o_col4 = off; off += up16(cb * a.T * 4);
         a.o_sig1 = off; off += up16((cb * a.P1 + 8) * 8);
@@ -662,15 +729,21 @@ static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs 
     return 0;
 }
 
+// Position windows for chunks that do not fit: 96 outputs per window (a multiple of 4, so that a window's first sample 3 * 96
+// * win is float4-aligned) need 3 * 96 + 26 = 314 -> 316 samples; consecutive windows overlap by 28 samples (9 %).
+static constexpr int FUSED_WINDOW_T = 96, FUSED_WINDOW_L = 316;
+
 bool fused_front_supported(const rmr_model *m, int seq_w, int map_w) {
     if (m->desc.arch != RMR_ARCH_CONV_LSTM || m->desc.size != 64 || m->nparts != 1) return false;
     if ((m->desc.kmer_len != 9 && m->desc.kmer_len != 6) || m->front.kw1 != 5) return false;  // the instantiated k-mer lengths
-    if (m->L % 4 || map_w - 1 > 62 || map_w < 2) return false;
+    // sequence and mapping rows travel one element per thread: at most 256 bases + context / 255 + 1 mapping entries per chunk
+    if (m->L % 4 || map_w < 2 || map_w > 256 || seq_w > 256) return false;
     if (seq_w < map_w - 1 + m->desc.kmer_len - 1) return false;
     if (m->fused.a_merge1 == nullptr) return false;
     FusedArgs probe;
     int total;
-    return fused_front_plan(m, seq_w, map_w, probe, total) >= 1;  // every limit the launcher enforces
+    // every limit the launcher enforces: whole chunks, or - chunks too long for a CU's LDS - position windows
+    return fused_front_plan(m, seq_w, map_w, probe, total) >= 1 || fused_front_plan(m, seq_w, map_w, probe, total, FUSED_WINDOW_L) >= 1;
 }
 
 int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
@@ -687,9 +760,18 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     a.x = x; a.n = n;
     a.seq_w = seq_w; a.map_w = map_w; a.maxlen = map_w - 1;
     int total = 0;
-    const int cb = fused_front_plan(m, seq_w, map_w, a, total);
+    int cb = fused_front_plan(m, seq_w, map_w, a, total);
+    a.nwin = 1; a.Tw = m->T; a.L_total = m->L; a.T_total = m->T;
+    const bool win = cb < 1 || tune_int("RMR_FUSED_WINDOWS", 0) != 0;  // (the knob: windows on shapes that would fit, for tests)
+    if (win) {
+        cb = fused_front_plan(m, seq_w, map_w, a, total, FUSED_WINDOW_L);
+        a.Tw = FUSED_WINDOW_T;
+        a.nwin = (m->T + a.Tw - 1) / a.Tw;
+        if (n * a.nwin >= (1 << 24)) RMR_FAIL(RMR_ERR_INVALID, "fused front: %lld chunks x %d windows per launch (sub-batch too large)", (long long)n, a.nwin);
+    }
     if (cb < 1) RMR_FAIL(RMR_ERR_INVALID, "fused front: one chunk of %d samples (sequence width %d) does not fit (%d B of LDS)", a.L, seq_w, total);
     a.cb = cb; a.lds_bytes = total;
+    a.d_nwin = make_fastdiv(a.nwin); a.d_L4 = make_fastdiv(a.L >> 2); a.d_seqw = make_fastdiv(seq_w); a.d_mapw = make_fastdiv(map_w);
     a.d_L = make_fastdiv(a.L); a.d_P1 = make_fastdiv(a.P1); a.d_P3 = make_fastdiv(a.P3); a.d_T = make_fastdiv(a.T);
     a.d_maxlen = make_fastdiv(a.maxlen);
     auto magic = [](int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };  // exact for x * d < 2^32
@@ -705,10 +787,14 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     }
 #endif
     // (4,4) and (2,3)-style k-mer contexts; bf16 or half operands
-    auto kern = m->f16 ? (m->desc.kmer_len == 9 ? fused_front_kernel<9, true> : fused_front_kernel<6, true>)
-                       : (m->desc.kmer_len == 9 ? fused_front_kernel<9, false> : fused_front_kernel<6, false>);
+    auto pick = [&](auto winc) {
+        constexpr bool W = decltype(winc)::value;
+        return m->f16 ? (m->desc.kmer_len == 9 ? fused_front_kernel<9, true, W> : fused_front_kernel<6, true, W>)
+                      : (m->desc.kmer_len == 9 ? fused_front_kernel<9, false, W> : fused_front_kernel<6, false, W>);
+    };
+    auto kern = win ? pick(std::true_type{}) : pick(std::false_type{});
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
-    const int64_t iters = (n + cb - 1) / cb;
+    const int64_t iters = (n * a.nwin + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 2 * RMR_FUSED_WAVES_EU);
     if (grid > iters) grid = iters;
     ProfScope ps(e, K_FUSED_FRONT);

@@ -179,17 +179,18 @@ def test_call_reads_mods_subbatch_pipeline_equals_one_batch(torch_cuda):
     assert sum(r[2].size for r in whole) > 5000
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("cc,msl", [((300, 300), 60), ((500, 500), 60), ((500, 500), 150), ((150, 150), 62)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("cc,msl", [((200, 200), 80), ((300, 300), 60), ((500, 500), 60), ((500, 500), 150), ((150, 150), 62)])
 def test_long_chunk_contexts_run_and_match(torch_cuda, O, dtype, cc, msl):
-    """Chunk contexts far beyond the benchmark shapes: the folded fp32 kernels and the fused bf16 kernel either fit one
-    chunk per block iteration in a CU's LDS or hand the shape to the unfused kernels — `*_supported()` must know every
-    limit its launcher enforces (round-2 advice: a 'supported' shape that then failed in the launcher).  One documented
-    limit remains: the fp32 merge_conv1 kernel stages a whole chunk (P3 x 128 floats + padding) in LDS, which a
-    1000-sample chunk exceeds - refused with a message, not a crash.  bf16: mean error at the bf16 level; its maximum grows
-    with the number of LSTM steps (T = 191 / 324 here) - see test_bf16_error_is_the_arithmetic_not_the_kernel."""
+    """Chunk contexts far beyond the benchmark shapes, starting with the reference's default chunk_context (200, 200) and its
+    max_seq_len 400 // 5 = 80 (src/remora/constants.py:7-8, prepare_train_data.py:165): the reference network is
+    length-agnostic (models/ConvLSTM_w_ref.py:39-58), so every shape must run.  The 16-bit pipelines stay on the fused kernel
+    (a chunk that does not fit a CU's LDS goes through it in position windows of 96 outputs), the fp32 merge_conv1 stages a
+    long chunk window by window.  16-bit: mean error at the format's level; the maximum grows with the number of LSTM steps
+    (T = 124 / 191 / 324 here) - see test_16bit_error_is_the_arithmetic_not_the_kernel."""
     from oracle import torch_ref
-    from remora_amd import RemoraError, synth
+    from remora_amd import synth
+    from remora_amd.engine import get_engine
     from remora_amd.model_util import model_from_state
 
     torch = torch_cuda
@@ -199,11 +200,13 @@ def test_long_chunk_contexts_run_and_match(torch_cuda, O, dtype, cc, msl):
     model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0, dtype=dtype)
     d = synth.synth_chunks(203, L, msl, (4, 4), seed=31)
     args = (d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
-    if dtype == "fp32" and L == 1000:
-        with pytest.raises(RemoraError, match="B of LDS"):
-            model.infer_chunks(*args)
-        return
+    eng = get_engine(0)
+    eng.profile_reset()
+    eng.profile_enable(True)
     out = model.infer_chunks(*args)
+    eng.profile_enable(False)
+    if dtype != "fp32":
+        assert "fused_front" in eng.profile(), (cc, msl, list(eng.profile()))
     enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
     with torch.no_grad():
         ref = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
@@ -211,8 +214,34 @@ def test_long_chunk_contexts_run_and_match(torch_cuda, O, dtype, cc, msl):
     err = np.abs(out - ref)
     if dtype == "fp32":
         assert err.max() <= 1e-4, (cc, err.max())
+    elif dtype == "f16":
+        assert err.mean() <= 5e-4 and err.max() <= 0.02, (cc, err.mean(), err.max())
     else:
         assert err.mean() <= 4e-3 and err.max() <= 0.15, (cc, err.mean(), err.max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg", ["C100", "C200"])
+def test_position_windows_are_bit_identical_to_whole_chunks(torch_cuda, cfg, dtype):
+    """RMR_FUSED_WINDOWS=1 sends shapes that fit through the window kernels (C100: one short window per chunk, T 24 < 96; C200:
+    T 58): every output is the same accumulation in the same order, so the logits must not move by a bit - including ragged
+    batches whose last iteration holds fewer virtual chunks than the block takes."""
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+    state = synth.synth_state("conv_lstm", 64, 9, num_out, seed=4)
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=dtype)
+    for n in (1, 7, 1001):
+        d = synth.synth_chunks_config(cfg, n, shard=40 + n)
+        args = (d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], kcb)
+        whole = model.infer_chunks(*args)
+        os.environ["RMR_FUSED_WINDOWS"] = "1"
+        try:
+            windows = model.infer_chunks(*args)
+        finally:
+            del os.environ["RMR_FUSED_WINDOWS"]
+        assert np.array_equal(whole, windows), (cfg, dtype, n, float(np.abs(whole - windows).max()))
 
 
 # ---- the 16-bit pipelines (bf16: BASELINE configs[3]/[4]; f16: the same kernels on IEEE half) --------------------------
