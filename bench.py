@@ -221,10 +221,10 @@ def precision_check(state, data, kcb, gpu_logits, full=None):
 
 def cpu_baseline(state, data, kcb, budget_s=12.0):
     """The reference CPU path timed on this box's host cores: single-thread C restatement of the Cython
-    encode + torch.nn restatement of the network, batch 2048, fp32.  Three forms of the network are timed — eager with
-    torch.set_num_threads(os.cpu_count()) (the survey's prescription), torch.jit.script with the same thread count (what
-    the reference's load_model returns, src/remora/model_util.py:115-117), and eager with the fastest thread count of a
-    probe — the headline `value` is the fastest of the three, its thread count is `cores`."""
+    encode + torch.nn restatement of the network, batch 2048, fp32.  `value` = eager with torch.set_num_threads(usable cores)
+    (the survey's prescription), median of three repeats; torch.jit.script at the same thread count (what the reference's
+    load_model returns, src/remora/model_util.py:115-117) and eager at the fastest thread count of a probe are timed once
+    each for the details file."""
     import torch
 
     from oracle import oracle as O
@@ -293,25 +293,34 @@ def cpu_baseline(state, data, kcb, budget_s=12.0):
     # >10 s on 256 cores): such a form is not re-timed — the probe's own batch IS its measurement, and the scripted form at
     # the same thread count is skipped with that reason (two more warm-up passes would cost a minute of the default run)
     slow_all = per_batch_s.get(host_cores, 0.0) > 2.0
+    # The line's `value` is ONE fixed form - eager, every usable core (the survey's prescription; with the cgroup's core count
+    # for os.cpu_count()) - as the MEDIAN of three repeats: the fastest-of-three-forms of round 3 flipped between eager and
+    # scripted from box to box (46.7 k vs 70.4 k chunks/s).  The scripted form and the probe's best thread count are timed once
+    # each and stay in the details file.  (A host whose all-cores pool collapses - >2 s per batch - is measured at the probe's
+    # best thread count instead, and says so.)
+    head_threads = best_threads if slow_all else host_cores
+    head = "eager_best_threads" if slow_all else "eager_all_cores"
+    repeats = [timed(net, head_threads, budget_s / 5) for _ in range(3)]
+    rates = sorted(r["chunks_per_s"] for r in repeats)
+    med = [r for r in repeats if r["chunks_per_s"] == rates[1]][0]
+    forms = {head: dict(med, repeats_chunks_per_s=[r["chunks_per_s"] for r in repeats], statistic="median of 3")}
     if slow_all:
-        forms = {"eager_all_cores": {"chunks_per_s": tuned[host_cores], "threads": host_cores, "chunks": npb, "warmup_batches": 0,
-                                     "note": f"one batch took {per_batch_s[host_cores]:.1f} s (network only, the thread probe's measurement)"},
-                 "jit_script_all_cores": {"skipped": f"eager at {host_cores} threads takes {per_batch_s[host_cores]:.1f} s per batch of {npb}"}}
+        forms["eager_all_cores"] = {"chunks_per_s": tuned[host_cores], "threads": host_cores, "chunks": npb, "warmup_batches": 0,
+                                    "note": f"one batch took {per_batch_s[host_cores]:.1f} s (network only, the thread probe's measurement)"}
+        forms["jit_script_all_cores"] = {"skipped": f"eager at {host_cores} threads takes {per_batch_s[host_cores]:.1f} s per batch of {npb}"}
     else:
-        forms = {"eager_all_cores": timed(net, host_cores, budget_s / 3)}
-        forms["jit_script_all_cores"] = timed(jit_net, host_cores, budget_s / 3) if jit_net is not None else {"error": jit_err}
-    forms["eager_best_threads"] = timed(net, best_threads, budget_s / 3)
-    ok = {k: v for k, v in forms.items() if "chunks_per_s" in v}
-    head = max(ok, key=lambda k: ok[k]["chunks_per_s"])
+        forms["jit_script_all_cores"] = timed(jit_net, host_cores, budget_s / 5) if jit_net is not None else {"error": jit_err}
+        forms["eager_best_threads"] = timed(net, best_threads, budget_s / 5) if best_threads != host_cores else {"same_as": "eager_all_cores"}
     return {
-        "value": ok[head]["chunks_per_s"], "unit": "chunks/s", "cores": ok[head]["threads"], "host_cores": host_cores,
+        "value": med["chunks_per_s"], "unit": "chunks/s", "cores": med["threads"], "host_cores": host_cores,
         "os_cpu_count": os.cpu_count(), "kind": "port",
-        "headline_form": head,
-        "sample": f"{ok[head]['chunks']} chunks in batches of {B}: C port of compute_encoded_kmer_batch (1 thread) + torch.nn "
-                  f"restatement of the network, fp32, form '{head}' with {ok[head]['threads']} torch threads ({host_cores} usable cores: "
+        "headline_form": head, "statistic": "median of 3 repeats of one fixed form",
+        "repeats_chunks_per_s": [r["chunks_per_s"] for r in repeats],
+        "sample": f"3 x {med['chunks']} chunks in batches of {B} (median): C port of compute_encoded_kmer_batch (1 thread) + torch.nn "
+                  f"restatement of the network, fp32, eager, {med['threads']} torch threads ({host_cores} usable cores: "
                   f"cgroup quota; os.cpu_count() {os.cpu_count()})",
         "forms": forms, "thread_probe_chunks_per_s": {str(k): v for k, v in tuned.items()},
-        "encode_chunks_per_s": ok[head].get("encode_chunks_per_s"), "model_chunks_per_s": ok[head].get("model_chunks_per_s"),
+        "encode_chunks_per_s": med.get("encode_chunks_per_s"), "model_chunks_per_s": med.get("model_chunks_per_s"),
     }
 
 
@@ -367,6 +376,29 @@ class Job:
     def step(self):
         self.logits = self.model.infer_chunks(*self.dev, self.kcb, label_counts=self.counts)
 
+    def host_buffers_leg(self, device_logits=None, reps=2, max_chunks=1 << 20):
+        """The same job handed over as HOST buffers (numpy, pageable) through the C-ABI boundary: host copy into pinned slots,
+        H2D, kernels, logits + label counts D2H - the PCIe-inclusive rate (never `value`: the task's contract times resident
+        inputs).  At 472 B (C100) / 932 B (C200) per chunk a PCIe Gen5 x16 link (63 GB/s spec) carries at most ~130 M / ~65 M
+        chunks/s: the 16-bit configs' resident rates are kernel rates, this leg is what a host-fed caller gets."""
+        n = min(self.n, max_chunks)
+        host = [self.data[k][:n] for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+        hc = np.zeros(self.num_out, np.int64)
+        self.model.infer_chunks(*host, self.kcb)  # warm-up (staging arenas, pinned slots)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lg_h = self.model.infer_chunks(*host, self.kcb, label_counts=hc)
+        t1 = time.perf_counter()
+        bpc = int(sum(a[0:1].nbytes for a in host) + 4 * self.num_out)
+        rate = reps * n / (t1 - t0)
+        leg = {"chunks_per_s": rate, "ms_per_step": (t1 - t0) / reps * 1e3, "chunks": n, "bytes_per_chunk_over_pcie": bpc,
+               "pcie_GBps": rate * bpc / 1e9, "pcie_gen5_x16_spec_GBps": 63.0,
+               "note": "numpy (pageable) chunk arrays in, logits + label counts out on the host; includes the host copy into "
+                       "pinned slots, H2D, kernels, D2H"}
+        if device_logits is not None:
+            leg["max_abs_diff_vs_device_path"] = float(np.abs(lg_h[:4096] - device_logits[:4096].cpu().numpy()).max())
+        return leg
+
     def run(self, steps, warmup):
         """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides; the count all-reduce is
         inside the timed region; elapsed = max over ranks."""
@@ -421,7 +453,16 @@ class Job:
         ent = ((traffic_table or {}).get(f"{self.workload}:{self.dtype}") or (traffic_table or {}).get(self.dtype) or {}).get(dom)
         if ent and (self.cfg == "C100" or f"{self.workload}:{self.dtype}" in (traffic_table or {})):
             traffic = ent["bytes_per_chunk"] * cpl
+            import hashlib
+
+            dom_file = {"fused_front": "k_fused.hip", "conv_merge1": "k_conv.hip", "lstm_head": "k_lstm_x16.hip" if self.dtype in ("bf16", "f16") else "k_lstm.hip"}.get(dom)
+            shas = ((traffic_table or {}).get(f"{self.workload}:{self.dtype}") or (traffic_table or {}).get(self.dtype) or {}).get("_kernel_file_sha") or {}
+            try:
+                now = hashlib.sha256(open(os.path.join(ROOT, "remora_amd", "csrc", dom_file), "rb").read()).hexdigest()[:16] if dom_file else None
+            except OSError:
+                now = None
             tsrc = {"file": "profiles/traffic.json", "profile": ent.get("source"), "commit": ent.get("commit"),
+                    "kernel_file": dom_file, "kernel_file_unchanged_since_profile": (shas.get(dom_file) == now) if (dom_file and now and shas) else None,
                     "profile_chunks_per_launch": ent.get("chunks_per_launch"),
                     "note": "rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this workload (MI355X_MICROARCH.md corrections), bytes per "
                             "chunk scaled to this run's chunks per launch; not re-measured in this run"}
@@ -459,19 +500,7 @@ def side_legs(job, args, model_logits):
     eng, model, dev, data = job.eng, job.model, job.dev, job.data
     # ---- the same job handed over as HOST buffers (numpy, pageable): PCIe-inclusive rate of the C-ABI boundary ----
     if not args.no_reads:
-        host = [data[k] for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
-        hc = np.zeros(job.num_out, np.int64)
-        model.infer_chunks(*host, kcb)  # warm-up (staging arenas, pinned slots)
-        th0 = time.perf_counter()
-        for _ in range(2):
-            lg_h = model.infer_chunks(*host, kcb, label_counts=hc)
-        th1 = time.perf_counter()
-        out["host_buffers_pcie_inclusive"] = {
-            "chunks_per_s": 2 * n / (th1 - th0), "ms_per_step": (th1 - th0) / 2 * 1e3,
-            "bytes_per_chunk_over_pcie": int(sum(a[0:1].nbytes for a in host) + 4 * job.num_out),
-            "max_abs_diff_vs_device_path": float(np.abs(lg_h[:4096] - model_logits[:4096].cpu().numpy()).max()),
-            "note": "numpy (pageable) chunk arrays in, logits + label counts out on the host; includes the host copy into "
-                    "pinned slots, H2D, kernels, D2H"}
+        out["host_buffers_pcie_inclusive"] = job.host_buffers_leg(model_logits)
     # ---- E1 standalone (materialised one-hot): HBM-write roofline ----
     if not args.no_encode:
         from remora_amd.encoded_kmers import compute_encoded_kmer_batch
@@ -801,6 +830,8 @@ def main():
                         kept[(wl, j.dtype)] = j.logits
                     others[key] = {k: r[k] for k in ("value", "unit", "ms_per_step", "dtype", "scaling", "config", "roofline", "kernels")}
                     others[key]["steps"] = min(args.steps, 5)
+                    if not args.no_reads:  # what a host-fed caller gets from this configuration (PCIe-inclusive; never `value`)
+                        others[key]["host_buffers_pcie_inclusive"] = j.host_buffers_leg(j.logits)
                     note(f"other config {key}: {r['value'] / 1e6:.2f} M chunks/s, {r['roofline']['kernel']} {r['roofline']['frac']:.2f} of peak")
                     del j
                     torch.cuda.empty_cache()

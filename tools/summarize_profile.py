@@ -72,6 +72,13 @@ def write_traffic(d, dtype, chunks_per_launch, path, commit=None, per_kernel_chu
     # not part of this pipeline: keep the kernels that ran (about) once per sub-batch
     most = max((e["launches"] for e in ent.values()), default=0)
     ent = {k: e for k, e in ent.items() if e["launches"] * 5 >= most}
+    # what was profiled: the hash of every kernel source next to the commit (bench.py compares the dominant kernel's file with
+    # the tree it runs from and says whether the table still describes it)
+    import hashlib
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "remora_amd", "csrc")
+    ent["_kernel_file_sha"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
+                               for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
     tj[dtype] = ent
     json.dump(tj, open(path, "w"), indent=1, sort_keys=True)
 
