@@ -330,6 +330,17 @@ int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int 
 int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
                      int64_t *counts, int mem);
 
+/* Validation tally of one batch of logits ON THE DEVICE (every pointer except label_of_column is device memory): what
+ * ValidationLogger.run_validation computes on the host per batch and at the end (src/remora/validate.py:208-259) -
+ * add_unmodeled_labels (:69-99: the model's num_out columns widened to the dataset's num_labels; label_of_column[c] = the
+ * model column of label c, -1 = not modelled -> -1000), util.softmax_axis1 in float32 (util.py:182-186), np.argmax, the
+ * confusion counts of compute_metrics (:42-45), CrossEntropyLoss.
+ *   confusion i64[num_labels * num_labels] (true x called) and loss_sum f64[1] (sum of the chunks' cross entropies) are
+ *   INCREMENTED; win_prob f32[n] (the called class's probability: what the filtered metrics take their quantile of) and
+ *   call u8[n] are written.  Asynchronous on the engine's stream. */
+int rmr_validation_tally(rmr_engine *e, const float *logits, const int64_t *labels, int64_t n, int num_out, int num_labels,
+                         const int32_t *label_of_column, int64_t *confusion, float *win_prob, uint8_t *call, double *loss_sum);
+
 /* ---- (e) multi-GPU: the ONE collective of the path, RCCL over xGMI called from the library ------- */
 /* replaces, in distributed form: the per-label tally of a run summed over the workers —
  * validate.compute_metrics' confusion/label tally (src/remora/validate.py:42-45) and get_label_counts

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rmr_forward": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
     "rmr_infer_chunks": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_int]),
     "rmr_count_labels": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int]),
+    "rmr_validation_tally": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rmr_comm_unique_id": (c_int, [c_vp]),
     "rmr_comm_init": (c_int, [c_vp, c_vp, c_int, c_int]),
     "rmr_comm_destroy": (c_int, [c_vp]),

@@ -1158,6 +1158,20 @@ int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,
     return 0;
 }
 
+int rmr_validation_tally(rmr_engine *e, const float *logits, const int64_t *labels, int64_t n, int num_out, int num_labels,
+                         const int32_t *label_of_column, int64_t *confusion, float *win_prob, uint8_t *call, double *loss_sum) {
+    if (!e || !logits || !labels || !label_of_column || !confusion || !win_prob || !call || !loss_sum)
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (num_out < 1 || num_out > 16 || num_labels < num_out || num_labels > 16)
+        RMR_FAIL(RMR_ERR_INVALID, "num_out %d / num_labels %d not in [1,16], num_labels >= num_out", num_out, num_labels);
+    for (int c = 0; c < num_labels; ++c)
+        if (label_of_column[c] < -1 || label_of_column[c] >= num_out) RMR_FAIL(RMR_ERR_INVALID, "label_of_column[%d] = %d", c, label_of_column[c]);
+    if (n <= 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    return launch_validation_tally(e, logits, labels, n, num_out, num_labels, label_of_column, confusion, win_prob, call, loss_sum);
+}
+
 static int check_motifs(const rmr_motif_set *motifs) {
     if (motifs->n_motifs < 1 || motifs->n_motifs > 8) RMR_FAIL(RMR_ERR_INVALID, "1..8 motifs supported");
     for (int m = 0; m < motifs->n_motifs; ++m)

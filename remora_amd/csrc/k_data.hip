@@ -694,6 +694,86 @@ int launch_motif_focus(rmr_engine *e, const int8_t *seq, const int64_t *seq_off,
     return 0;
 }
 
+// ---- validation tally (src/remora/validate.py:42-66, :69-99, :208-259 for one batch): per chunk the call, the winning
+// probability and the cross entropy; per batch the confusion counts and the loss sum.  The model's km output columns are
+// widened to the dataset's kf label columns first (add_unmodeled_labels: columns the model does not predict get -1000),
+// softmax in float32 in the reference's order of operations (util.softmax_axis1 on the float32 logits: subtract the row
+// maximum, exp, divide by the sequential sum), first maximum wins (np.argmax), cross entropy accumulated in double.
+struct TallyArgs {
+    const float *logits;      // [n][km]
+    const int64_t *labels;    // [n]
+    int64_t n;
+    int km, kf;
+    int colmap[16];           // full column -> model column, -1 = not modelled
+    unsigned long long *conf; // [kf][kf] true x called, incremented
+    float *win;               // [n] winning probability
+    uint8_t *pred;            // [n] call
+    double *loss_sum;         // [1] incremented by the batch's sum of cross entropies
+};
+
+__global__ __launch_bounds__(256) void validation_tally_kernel(TallyArgs a) {
+    __shared__ unsigned int bins[256];
+    __shared__ double loss_part[4];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    double loss = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *p = a.logits + i * a.km;
+        float v[16];
+        float mx = -3.0e38f;
+        int best = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < a.kf) {
+                v[c] = a.colmap[c] >= 0 ? p[a.colmap[c]] : -1000.0f;
+                if (v[c] > mx) { mx = v[c]; best = c; }
+            }
+        }
+        float s = 0.0f, eb = 0.0f;
+        double sd = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < a.kf) {
+                const float e = expf(v[c] - mx);
+                s += e;
+                sd += exp((double)v[c] - (double)mx);
+                if (c == best) eb = e;
+            }
+        }
+        a.win[i] = eb / s;
+        a.pred[i] = (uint8_t)best;
+        int lab = (int)a.labels[i];
+        lab = lab < 0 ? 0 : (lab >= a.kf ? a.kf - 1 : lab);
+        float vl = v[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c)
+            if (c == lab) vl = v[c];
+        loss += (double)mx + log(sd) - (double)vl;
+        atomicAdd(&bins[lab * a.kf + best], 1u);
+    }
+    // loss: lanes -> wave -> block -> one atomic per block
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_down(loss, off);
+    if ((threadIdx.x & 63) == 0) loss_part[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.loss_sum, loss_part[0] + loss_part[1] + loss_part[2] + loss_part[3]);
+    if (threadIdx.x < a.kf * a.kf && bins[threadIdx.x]) atomicAdd(&a.conf[threadIdx.x], (unsigned long long)bins[threadIdx.x]);
+}
+
+int launch_validation_tally(rmr_engine *e, const float *logits, const int64_t *labels, int64_t n, int km, int kf, const int *colmap,
+                            int64_t *conf, float *win, uint8_t *pred, double *loss_sum) {
+    if (n <= 0) return 0;
+    TallyArgs a;
+    a.logits = logits; a.labels = labels; a.n = n; a.km = km; a.kf = kf;
+    for (int c = 0; c < 16; ++c) a.colmap[c] = c < kf ? colmap[c] : -1;
+    a.conf = reinterpret_cast<unsigned long long *>(conf); a.win = win; a.pred = pred; a.loss_sum = loss_sum;
+    int64_t grid = (n + 255) / 256;
+    if (grid > (int64_t)e->num_cus * 4) grid = (int64_t)e->num_cus * 4;
+    ProfScope ps(e, K_COUNT);
+    hipLaunchKernelGGL(validation_tally_kernel, dim3((unsigned)grid), dim3(256), 0, e->stream, a);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts) {
     if (n <= 0) return 0;
     if (num_out > 16) RMR_FAIL(RMR_ERR_INVALID, "num_out %d > 16", num_out);

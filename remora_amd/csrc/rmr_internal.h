@@ -220,6 +220,8 @@ int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32
                 const float *sig, const int64_t *geo, float *signal, int8_t *seqs, int seq_w,
                 int16_t *maps, int map_w, int16_t *lens, int64_t *rfb);
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts);
+int launch_validation_tally(rmr_engine *e, const float *logits, const int64_t *labels, int64_t n, int km, int kf, const int *colmap,
+                            int64_t *conf, float *win, uint8_t *pred, double *loss_sum);
 int launch_vbz(rmr_engine *e, const uint8_t *svb, const int64_t *row_off, const int32_t *row_n, const int64_t *out_off,
                int64_t n_rows, int16_t *out, int32_t *status);
 int launch_motif_focus(rmr_engine *e, const int8_t *seq, const int64_t *seq_off, int n_reads, const rmr_motif_set &ms,

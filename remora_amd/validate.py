@@ -41,17 +41,22 @@ def compute_metrics(probs, labels, filt_frac):
     calls whose winning probability lies above the `filt_frac` quantile (validate.py:42-66)."""
     preds = np.argmax(probs, axis=1)
     conf = confusion_matrix(labels, preds)
-    right = preds == labels
-    acc = right.sum() / labels.size
+    acc = (preds == labels).sum() / labels.size
     win = np.take_along_axis(probs, preds[:, None], -1)[:, 0]
+    return (acc, conf) + filtered_metrics(win, preds, labels, filt_frac)
+
+
+def filtered_metrics(win, preds, labels, filt_frac):
+    """(filt_frac, filt_acc, filt_conf_mat, filt_thr) of the calls whose winning probability lies above the `filt_frac`
+    quantile of all winning probabilities (validate.py:47-66)."""
     thr = np.quantile(win, filt_frac)
     if thr == win.max():  # everything would be filtered: nudge the threshold below the maximum
         thr *= 0.999999
     sure = win > thr
     n_sure = int(sure.sum())
     if n_sure == 0:  # all probabilities NaN
-        return acc, conf, 1.0, np.nan, np.array([]), np.nan
-    return (acc, conf, 1 - n_sure / labels.size, right[sure].sum() / n_sure,
+        return 1.0, np.nan, np.array([]), np.nan
+    return (1 - n_sure / labels.size, int(((preds == labels) & sure).sum()) / n_sure,
             confusion_matrix(labels[sure], preds[sure]), thr)
 
 
@@ -114,6 +119,10 @@ class ValidationLogger:
         md = dataset.metadata
         unmodeled = np.array([i + 1 for i, mb in enumerate(md.mod_bases) if mb not in model_mod_bases])
         fused = isinstance(model, HipModel)
+        if fused and self.full_fh is None and type(criterion) is torch.nn.CrossEntropyLoss and criterion.weight is None \
+                and criterion.reduction == "mean" and criterion.label_smoothing == 0.0 and criterion.ignore_index == -100 \
+                and md.num_labels <= 16:
+            return self._run_validation_device(model, unmodeled, dataset, filt_frac, world)
         names = _RAW if fused else ("enc_kmers", "signal", "labels")
         dataset._ds_iters = None
         all_out, all_lab, losses = [], [], []
@@ -145,20 +154,138 @@ class ValidationLogger:
         return VAL_METRICS(loss=np.mean(losses), acc=acc, num_calls=labels.size, conf_mat=conf, filt_frac=ff,
                            filt_acc=facc, filt_conf_mat=fconf, filt_thresh=thr)
 
+    def _run_validation_device(self, model, unmodeled, dataset, filt_frac, world):
+        """run_validation with the per-chunk work on the GPU (the fused model, the default loss, no per-chunk results file).
+        A reader thread copies the batches' rows from the memmaps into a ring of pinned host slots (several copy threads: the
+        page faults of a freshly mapped file are the slowest part of the host side) while the GPU works on the previous
+        batch; the rows are uploaded on the engine's stream, inferred (fused kernels, logits stay on the device) and tallied
+        there (rmr_validation_tally: widening by the unmodelled labels, float32 softmax, call, confusion counts, cross
+        entropy); per chunk only the winning probability (4 B) and the call (1 B) come back, for the quantile of the
+        confidence-filtered columns.  Same numbers as the host path (tests/test_gpu_parity.py)."""
+        import ctypes
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        from . import _lib as L
+        from .util import effective_cpu_count
+
+        torch = _torch()
+        md = dataset.metadata
+        eng, dev = model.engine, model.engine.torch_device
+        kf, km = md.num_labels, model.num_out
+        col, label_of_column = 0, []
+        for c in range(kf):
+            if c in set(np.asarray(unmodeled).tolist()):
+                label_of_column.append(-1)
+            else:
+                label_of_column.append(col)
+                col += 1
+        if col != km:
+            from . import RemoraError
+
+            raise RemoraError(f"model has {km} outputs, the dataset's labels minus the unmodelled ones {col}")
+        colmap = (ctypes.c_int32 * kf)(*label_of_column)
+        conf = torch.zeros(kf * kf, dtype=torch.int64, device=dev)
+        loss_buf = torch.zeros(4096, dtype=torch.float64, device=dev)
+        lib = L.lib()
+
+        import os
+
+        depth = 3
+        nthreads = int(os.environ.get("RMR_VALIDATE_THREADS", "0")) or max(2, min(8, effective_cpu_count() // 2))
+        free, ready = queue.Queue(), queue.Queue(maxsize=depth)
+        slots = [None] * depth
+        for i in range(depth):
+            free.put(i)
+        pool = ThreadPoolExecutor(max_workers=nthreads)
+        dataset._ds_iters = None
+
+        def produce():
+            try:
+                for batch in dataset.iter_numpy_batches(return_arrays=_RAW, copy=False):
+                    n = int(np.asarray(batch[4]).shape[0])
+                    if n == 0:
+                        continue
+                    i = free.get()
+                    if slots[i] is None or any(t.shape[0] < n or t.shape[1:] != np.asarray(a).shape[1:] for t, a in zip(slots[i], batch)):
+                        slots[i] = [torch.empty(np.asarray(a).shape, dtype=torch.from_numpy(np.empty(0, np.asarray(a).dtype)).dtype,
+                                                pin_memory=True) for a in batch]
+                    parts = [(lo, min(lo + (n + nthreads - 1) // nthreads, n)) for lo in range(0, n, (n + nthreads - 1) // nthreads)]
+                    views = [t.numpy() for t in slots[i]]
+                    list(pool.map(lambda p: [np.copyto(v[p[0] : p[1]], a[p[0] : p[1]]) for v, a in zip(views, batch)], parts))
+                    ready.put((i, n))
+                ready.put(None)
+            except BaseException as e:  # noqa: BLE001 - handed to the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        main_stream, up_stream = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        wins, preds, labs, sizes = [], [], [], []
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                i, n = item
+                # upload on a stream of its own: batch b + 1 crosses PCIe under the kernels of batch b
+                with torch.cuda.stream(up_stream):
+                    sig, seq, smap, lens, lab = (t[:n].to(dev, non_blocking=True) for t in slots[i])
+                    up = torch.cuda.Event()
+                    up.record(up_stream)
+                main_stream.wait_event(up)
+                for t in (sig, seq, smap, lens, lab):
+                    t.record_stream(main_stream)
+                labs.append(slots[i][4][:n].numpy().copy())
+                logits = model.infer_chunks(sig, seq, smap, lens, md.kmer_context_bases)
+                win = torch.empty(n, dtype=torch.float32, device=dev)
+                pred = torch.empty(n, dtype=torch.uint8, device=dev)
+                b = len(sizes)
+                if b >= loss_buf.numel():
+                    loss_buf = torch.cat([loss_buf, torch.zeros_like(loss_buf)])
+                L.check(lib.rmr_validation_tally(eng.handle, logits.data_ptr(), lab.data_ptr(), n, km, kf, colmap, conf.data_ptr(),
+                                                 win.data_ptr(), pred.data_ptr(), loss_buf.data_ptr() + 8 * b))
+                wins.append(win)
+                preds.append(pred)
+                sizes.append(n)
+                up.synchronize()  # the uploads of this slot are done: the reader may refill it under the kernels
+                free.put(i)
+        finally:
+            dataset._ds_iters = None
+            pool.shutdown(wait=False)
+        torch.cuda.synchronize(dev)
+        win = torch.cat(wins).cpu().numpy()
+        pred = torch.cat(preds).cpu().numpy().astype(np.int64)
+        labels = np.concatenate(labs)
+        losses = list((loss_buf[: len(sizes)].cpu().numpy() / np.asarray(sizes, np.float64)))
+        full = conf.cpu().numpy().reshape(kf, kf)
+        if world > 1:
+            return self._global_metrics_from(kf, pred, win, labels, losses, filt_frac, local_conf=full.reshape(-1))
+        present = (full.sum(0) + full.sum(1)) > 0
+        ff, facc, fconf, thr = filtered_metrics(win, pred, labels, filt_frac)
+        return VAL_METRICS(loss=np.mean(losses), acc=np.trace(full) / labels.size, num_calls=labels.size,
+                           conf_mat=full[present][:, present], filt_frac=ff, filt_acc=facc, filt_conf_mat=fconf, filt_thresh=thr)
+
     @staticmethod
     def _global_metrics(probs, labels, losses, filt_frac):
         """This rank's calls -> the metrics of all ranks' calls (see run_validation)."""
+        preds = np.argmax(probs, axis=1)
+        win = np.take_along_axis(probs, preds[:, None], -1)[:, 0]
+        return ValidationLogger._global_metrics_from(probs.shape[1], preds, win, labels, losses, filt_frac)
+
+    @staticmethod
+    def _global_metrics_from(k, preds, win, labels, losses, filt_frac, local_conf=None):
         from . import dist as rdist
 
-        k = probs.shape[1]
-        preds = np.argmax(probs, axis=1)
-        local = np.bincount(labels.astype(np.int64) * k + preds, minlength=k * k).astype(np.int64)
-        full = np.asarray(rdist.allreduce_counts(local)).reshape(k, k)  # the collective: confusion counts over all GPUs
+        local = local_conf if local_conf is not None else np.bincount(labels.astype(np.int64) * k + preds, minlength=k * k)
+        full = np.asarray(rdist.allreduce_counts(np.asarray(local, np.int64))).reshape(k, k)  # the collective: confusion counts over all GPUs
         present = (full.sum(0) + full.sum(1)) > 0
         conf = full[present][:, present]
         total = int(full.sum())
         acc = np.trace(full) / total
-        win = np.take_along_axis(probs, preds[:, None], -1)[:, 0]
         lp = rdist.gather_arrays(np.stack([labels.astype(np.int64), preds.astype(np.int64)], axis=1))
         g_lab, g_pred, g_win = lp[:, 0], lp[:, 1], rdist.gather_arrays(win)  # win keeps its dtype: same quantile as one process
         loss = float(np.mean(rdist.gather_arrays(np.asarray(losses, np.float64).reshape(-1))))

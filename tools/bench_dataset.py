@@ -70,8 +70,9 @@ def measure(n_chunks=1 << 20, n_reads=2048, n_bases=5000, device=0, batch_size=1
         t_val = time.perf_counter() - t0
         out["validate"] = {"chunks": n_chunks, "chunks_per_s": n_chunks / t_val, "write_chunks_per_s": n_chunks / t_write,
                            "acc": float(ms.acc), "batch_size": batch_size,
-                           "note": "memmapped dataset rows -> RemoraDataset batches -> fused kernels -> logits on the host -> "
-                                   "loss / accuracy / confusion / filtered accuracy (ValidationLogger.run_validation)"}
+                           "note": "memmapped dataset rows -> pinned ring (reader thread) -> H2D on a copy stream -> fused kernels -> "
+                                   "rmr_validation_tally on the device (softmax, calls, confusion counts, cross entropy); 5 B per "
+                                   "chunk back for the filtered columns' quantile (ValidationLogger.run_validation)"}
         # ---- dataset prepare (without the file parsing) ----
         reads = synth_io_reads(n_reads, n_bases, seed=1)
         motifs = [Motif("CG", 0)]
