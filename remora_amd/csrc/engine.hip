@@ -79,6 +79,328 @@ int rmr_engine::ensure(Arena &a, size_t bytes) {
     return 0;
 }
 
+// ---- RMR_POISON (rmr_internal.h) -----------------------------------------------------------------------------------
+namespace rmr {
+__global__ __launch_bounds__(512) void poison_kernel(int lds_words) {
+    extern __shared__ unsigned poison_lds[];
+    for (int i = threadIdx.x; i < lds_words; i += 512) poison_lds[i] = 0xFFFFFFFFu;
+    // v16 .. v255 of the block's 8 waves (2 per SIMD x 256 registers = the whole file of a SIMD) and s40 .. s95
+    asm volatile("v_mov_b32 v16, -1\n\t"
+                 "v_mov_b32 v17, -1\n\t"
+                 "v_mov_b32 v18, -1\n\t"
+                 "v_mov_b32 v19, -1\n\t"
+                 "v_mov_b32 v20, -1\n\t"
+                 "v_mov_b32 v21, -1\n\t"
+                 "v_mov_b32 v22, -1\n\t"
+                 "v_mov_b32 v23, -1\n\t"
+                 "v_mov_b32 v24, -1\n\t"
+                 "v_mov_b32 v25, -1\n\t"
+                 "v_mov_b32 v26, -1\n\t"
+                 "v_mov_b32 v27, -1\n\t"
+                 "v_mov_b32 v28, -1\n\t"
+                 "v_mov_b32 v29, -1\n\t"
+                 "v_mov_b32 v30, -1\n\t"
+                 "v_mov_b32 v31, -1\n\t"
+                 "v_mov_b32 v32, -1\n\t"
+                 "v_mov_b32 v33, -1\n\t"
+                 "v_mov_b32 v34, -1\n\t"
+                 "v_mov_b32 v35, -1\n\t"
+                 "v_mov_b32 v36, -1\n\t"
+                 "v_mov_b32 v37, -1\n\t"
+                 "v_mov_b32 v38, -1\n\t"
+                 "v_mov_b32 v39, -1\n\t"
+                 "v_mov_b32 v40, -1\n\t"
+                 "v_mov_b32 v41, -1\n\t"
+                 "v_mov_b32 v42, -1\n\t"
+                 "v_mov_b32 v43, -1\n\t"
+                 "v_mov_b32 v44, -1\n\t"
+                 "v_mov_b32 v45, -1\n\t"
+                 "v_mov_b32 v46, -1\n\t"
+                 "v_mov_b32 v47, -1\n\t"
+                 "v_mov_b32 v48, -1\n\t"
+                 "v_mov_b32 v49, -1\n\t"
+                 "v_mov_b32 v50, -1\n\t"
+                 "v_mov_b32 v51, -1\n\t"
+                 "v_mov_b32 v52, -1\n\t"
+                 "v_mov_b32 v53, -1\n\t"
+                 "v_mov_b32 v54, -1\n\t"
+                 "v_mov_b32 v55, -1\n\t"
+                 "v_mov_b32 v56, -1\n\t"
+                 "v_mov_b32 v57, -1\n\t"
+                 "v_mov_b32 v58, -1\n\t"
+                 "v_mov_b32 v59, -1\n\t"
+                 "v_mov_b32 v60, -1\n\t"
+                 "v_mov_b32 v61, -1\n\t"
+                 "v_mov_b32 v62, -1\n\t"
+                 "v_mov_b32 v63, -1\n\t"
+                 "v_mov_b32 v64, -1\n\t"
+                 "v_mov_b32 v65, -1\n\t"
+                 "v_mov_b32 v66, -1\n\t"
+                 "v_mov_b32 v67, -1\n\t"
+                 "v_mov_b32 v68, -1\n\t"
+                 "v_mov_b32 v69, -1\n\t"
+                 "v_mov_b32 v70, -1\n\t"
+                 "v_mov_b32 v71, -1\n\t"
+                 "v_mov_b32 v72, -1\n\t"
+                 "v_mov_b32 v73, -1\n\t"
+                 "v_mov_b32 v74, -1\n\t"
+                 "v_mov_b32 v75, -1\n\t"
+                 "v_mov_b32 v76, -1\n\t"
+                 "v_mov_b32 v77, -1\n\t"
+                 "v_mov_b32 v78, -1\n\t"
+                 "v_mov_b32 v79, -1\n\t"
+                 "v_mov_b32 v80, -1\n\t"
+                 "v_mov_b32 v81, -1\n\t"
+                 "v_mov_b32 v82, -1\n\t"
+                 "v_mov_b32 v83, -1\n\t"
+                 "v_mov_b32 v84, -1\n\t"
+                 "v_mov_b32 v85, -1\n\t"
+                 "v_mov_b32 v86, -1\n\t"
+                 "v_mov_b32 v87, -1\n\t"
+                 "v_mov_b32 v88, -1\n\t"
+                 "v_mov_b32 v89, -1\n\t"
+                 "v_mov_b32 v90, -1\n\t"
+                 "v_mov_b32 v91, -1\n\t"
+                 "v_mov_b32 v92, -1\n\t"
+                 "v_mov_b32 v93, -1\n\t"
+                 "v_mov_b32 v94, -1\n\t"
+                 "v_mov_b32 v95, -1\n\t"
+                 "v_mov_b32 v96, -1\n\t"
+                 "v_mov_b32 v97, -1\n\t"
+                 "v_mov_b32 v98, -1\n\t"
+                 "v_mov_b32 v99, -1\n\t"
+                 "v_mov_b32 v100, -1\n\t"
+                 "v_mov_b32 v101, -1\n\t"
+                 "v_mov_b32 v102, -1\n\t"
+                 "v_mov_b32 v103, -1\n\t"
+                 "v_mov_b32 v104, -1\n\t"
+                 "v_mov_b32 v105, -1\n\t"
+                 "v_mov_b32 v106, -1\n\t"
+                 "v_mov_b32 v107, -1\n\t"
+                 "v_mov_b32 v108, -1\n\t"
+                 "v_mov_b32 v109, -1\n\t"
+                 "v_mov_b32 v110, -1\n\t"
+                 "v_mov_b32 v111, -1\n\t"
+                 "v_mov_b32 v112, -1\n\t"
+                 "v_mov_b32 v113, -1\n\t"
+                 "v_mov_b32 v114, -1\n\t"
+                 "v_mov_b32 v115, -1\n\t"
+                 "v_mov_b32 v116, -1\n\t"
+                 "v_mov_b32 v117, -1\n\t"
+                 "v_mov_b32 v118, -1\n\t"
+                 "v_mov_b32 v119, -1\n\t"
+                 "v_mov_b32 v120, -1\n\t"
+                 "v_mov_b32 v121, -1\n\t"
+                 "v_mov_b32 v122, -1\n\t"
+                 "v_mov_b32 v123, -1\n\t"
+                 "v_mov_b32 v124, -1\n\t"
+                 "v_mov_b32 v125, -1\n\t"
+                 "v_mov_b32 v126, -1\n\t"
+                 "v_mov_b32 v127, -1\n\t"
+                 "v_mov_b32 v128, -1\n\t"
+                 "v_mov_b32 v129, -1\n\t"
+                 "v_mov_b32 v130, -1\n\t"
+                 "v_mov_b32 v131, -1\n\t"
+                 "v_mov_b32 v132, -1\n\t"
+                 "v_mov_b32 v133, -1\n\t"
+                 "v_mov_b32 v134, -1\n\t"
+                 "v_mov_b32 v135, -1\n\t"
+                 "v_mov_b32 v136, -1\n\t"
+                 "v_mov_b32 v137, -1\n\t"
+                 "v_mov_b32 v138, -1\n\t"
+                 "v_mov_b32 v139, -1\n\t"
+                 "v_mov_b32 v140, -1\n\t"
+                 "v_mov_b32 v141, -1\n\t"
+                 "v_mov_b32 v142, -1\n\t"
+                 "v_mov_b32 v143, -1\n\t"
+                 "v_mov_b32 v144, -1\n\t"
+                 "v_mov_b32 v145, -1\n\t"
+                 "v_mov_b32 v146, -1\n\t"
+                 "v_mov_b32 v147, -1\n\t"
+                 "v_mov_b32 v148, -1\n\t"
+                 "v_mov_b32 v149, -1\n\t"
+                 "v_mov_b32 v150, -1\n\t"
+                 "v_mov_b32 v151, -1\n\t"
+                 "v_mov_b32 v152, -1\n\t"
+                 "v_mov_b32 v153, -1\n\t"
+                 "v_mov_b32 v154, -1\n\t"
+                 "v_mov_b32 v155, -1\n\t"
+                 "v_mov_b32 v156, -1\n\t"
+                 "v_mov_b32 v157, -1\n\t"
+                 "v_mov_b32 v158, -1\n\t"
+                 "v_mov_b32 v159, -1\n\t"
+                 "v_mov_b32 v160, -1\n\t"
+                 "v_mov_b32 v161, -1\n\t"
+                 "v_mov_b32 v162, -1\n\t"
+                 "v_mov_b32 v163, -1\n\t"
+                 "v_mov_b32 v164, -1\n\t"
+                 "v_mov_b32 v165, -1\n\t"
+                 "v_mov_b32 v166, -1\n\t"
+                 "v_mov_b32 v167, -1\n\t"
+                 "v_mov_b32 v168, -1\n\t"
+                 "v_mov_b32 v169, -1\n\t"
+                 "v_mov_b32 v170, -1\n\t"
+                 "v_mov_b32 v171, -1\n\t"
+                 "v_mov_b32 v172, -1\n\t"
+                 "v_mov_b32 v173, -1\n\t"
+                 "v_mov_b32 v174, -1\n\t"
+                 "v_mov_b32 v175, -1\n\t"
+                 "v_mov_b32 v176, -1\n\t"
+                 "v_mov_b32 v177, -1\n\t"
+                 "v_mov_b32 v178, -1\n\t"
+                 "v_mov_b32 v179, -1\n\t"
+                 "v_mov_b32 v180, -1\n\t"
+                 "v_mov_b32 v181, -1\n\t"
+                 "v_mov_b32 v182, -1\n\t"
+                 "v_mov_b32 v183, -1\n\t"
+                 "v_mov_b32 v184, -1\n\t"
+                 "v_mov_b32 v185, -1\n\t"
+                 "v_mov_b32 v186, -1\n\t"
+                 "v_mov_b32 v187, -1\n\t"
+                 "v_mov_b32 v188, -1\n\t"
+                 "v_mov_b32 v189, -1\n\t"
+                 "v_mov_b32 v190, -1\n\t"
+                 "v_mov_b32 v191, -1\n\t"
+                 "v_mov_b32 v192, -1\n\t"
+                 "v_mov_b32 v193, -1\n\t"
+                 "v_mov_b32 v194, -1\n\t"
+                 "v_mov_b32 v195, -1\n\t"
+                 "v_mov_b32 v196, -1\n\t"
+                 "v_mov_b32 v197, -1\n\t"
+                 "v_mov_b32 v198, -1\n\t"
+                 "v_mov_b32 v199, -1\n\t"
+                 "v_mov_b32 v200, -1\n\t"
+                 "v_mov_b32 v201, -1\n\t"
+                 "v_mov_b32 v202, -1\n\t"
+                 "v_mov_b32 v203, -1\n\t"
+                 "v_mov_b32 v204, -1\n\t"
+                 "v_mov_b32 v205, -1\n\t"
+                 "v_mov_b32 v206, -1\n\t"
+                 "v_mov_b32 v207, -1\n\t"
+                 "v_mov_b32 v208, -1\n\t"
+                 "v_mov_b32 v209, -1\n\t"
+                 "v_mov_b32 v210, -1\n\t"
+                 "v_mov_b32 v211, -1\n\t"
+                 "v_mov_b32 v212, -1\n\t"
+                 "v_mov_b32 v213, -1\n\t"
+                 "v_mov_b32 v214, -1\n\t"
+                 "v_mov_b32 v215, -1\n\t"
+                 "v_mov_b32 v216, -1\n\t"
+                 "v_mov_b32 v217, -1\n\t"
+                 "v_mov_b32 v218, -1\n\t"
+                 "v_mov_b32 v219, -1\n\t"
+                 "v_mov_b32 v220, -1\n\t"
+                 "v_mov_b32 v221, -1\n\t"
+                 "v_mov_b32 v222, -1\n\t"
+                 "v_mov_b32 v223, -1\n\t"
+                 "v_mov_b32 v224, -1\n\t"
+                 "v_mov_b32 v225, -1\n\t"
+                 "v_mov_b32 v226, -1\n\t"
+                 "v_mov_b32 v227, -1\n\t"
+                 "v_mov_b32 v228, -1\n\t"
+                 "v_mov_b32 v229, -1\n\t"
+                 "v_mov_b32 v230, -1\n\t"
+                 "v_mov_b32 v231, -1\n\t"
+                 "v_mov_b32 v232, -1\n\t"
+                 "v_mov_b32 v233, -1\n\t"
+                 "v_mov_b32 v234, -1\n\t"
+                 "v_mov_b32 v235, -1\n\t"
+                 "v_mov_b32 v236, -1\n\t"
+                 "v_mov_b32 v237, -1\n\t"
+                 "v_mov_b32 v238, -1\n\t"
+                 "v_mov_b32 v239, -1\n\t"
+                 "v_mov_b32 v240, -1\n\t"
+                 "v_mov_b32 v241, -1\n\t"
+                 "v_mov_b32 v242, -1\n\t"
+                 "v_mov_b32 v243, -1\n\t"
+                 "v_mov_b32 v244, -1\n\t"
+                 "v_mov_b32 v245, -1\n\t"
+                 "v_mov_b32 v246, -1\n\t"
+                 "v_mov_b32 v247, -1\n\t"
+                 "v_mov_b32 v248, -1\n\t"
+                 "v_mov_b32 v249, -1\n\t"
+                 "v_mov_b32 v250, -1\n\t"
+                 "v_mov_b32 v251, -1\n\t"
+                 "v_mov_b32 v252, -1\n\t"
+                 "v_mov_b32 v253, -1\n\t"
+                 "v_mov_b32 v254, -1\n\t"
+                 "v_mov_b32 v255, -1\n\t"
+                 "s_mov_b32 s40, -1\n\t"
+                 "s_mov_b32 s41, -1\n\t"
+                 "s_mov_b32 s42, -1\n\t"
+                 "s_mov_b32 s43, -1\n\t"
+                 "s_mov_b32 s44, -1\n\t"
+                 "s_mov_b32 s45, -1\n\t"
+                 "s_mov_b32 s46, -1\n\t"
+                 "s_mov_b32 s47, -1\n\t"
+                 "s_mov_b32 s48, -1\n\t"
+                 "s_mov_b32 s49, -1\n\t"
+                 "s_mov_b32 s50, -1\n\t"
+                 "s_mov_b32 s51, -1\n\t"
+                 "s_mov_b32 s52, -1\n\t"
+                 "s_mov_b32 s53, -1\n\t"
+                 "s_mov_b32 s54, -1\n\t"
+                 "s_mov_b32 s55, -1\n\t"
+                 "s_mov_b32 s56, -1\n\t"
+                 "s_mov_b32 s57, -1\n\t"
+                 "s_mov_b32 s58, -1\n\t"
+                 "s_mov_b32 s59, -1\n\t"
+                 "s_mov_b32 s60, -1\n\t"
+                 "s_mov_b32 s61, -1\n\t"
+                 "s_mov_b32 s62, -1\n\t"
+                 "s_mov_b32 s63, -1\n\t"
+                 "s_mov_b32 s64, -1\n\t"
+                 "s_mov_b32 s65, -1\n\t"
+                 "s_mov_b32 s66, -1\n\t"
+                 "s_mov_b32 s67, -1\n\t"
+                 "s_mov_b32 s68, -1\n\t"
+                 "s_mov_b32 s69, -1\n\t"
+                 "s_mov_b32 s70, -1\n\t"
+                 "s_mov_b32 s71, -1\n\t"
+                 "s_mov_b32 s72, -1\n\t"
+                 "s_mov_b32 s73, -1\n\t"
+                 "s_mov_b32 s74, -1\n\t"
+                 "s_mov_b32 s75, -1\n\t"
+                 "s_mov_b32 s76, -1\n\t"
+                 "s_mov_b32 s77, -1\n\t"
+                 "s_mov_b32 s78, -1\n\t"
+                 "s_mov_b32 s79, -1\n\t"
+                 "s_mov_b32 s80, -1\n\t"
+                 "s_mov_b32 s81, -1\n\t"
+                 "s_mov_b32 s82, -1\n\t"
+                 "s_mov_b32 s83, -1\n\t"
+                 "s_mov_b32 s84, -1\n\t"
+                 "s_mov_b32 s85, -1\n\t"
+                 "s_mov_b32 s86, -1\n\t"
+                 "s_mov_b32 s87, -1\n\t"
+                 "s_mov_b32 s88, -1\n\t"
+                 "s_mov_b32 s89, -1\n\t"
+                 "s_mov_b32 s90, -1\n\t"
+                 "s_mov_b32 s91, -1\n\t"
+                 "s_mov_b32 s92, -1\n\t"
+                 "s_mov_b32 s93, -1\n\t"
+                 "s_mov_b32 s94, -1\n\t"
+                 "s_mov_b32 s95, -1\n\t"
+                 
+                 :
+                 :
+                 : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+    __syncthreads();
+    if (poison_lds[threadIdx.x] != 0xFFFFFFFFu) __builtin_trap();  // (keeps the stores alive)
+}
+
+void poison_before_launch(rmr_engine *e, hipStream_t s) {
+    static const int on = tune_int("RMR_POISON", 0);
+    if (!on) return;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(poison_kernel, dim3((unsigned)e->num_cus * 2), dim3(512), (size_t)160 * 1024, s, 160 * 256);
+}
+}  // namespace rmr
+
 int rmr_engine::allow_big_lds(const void *kernel) {
     for (const void *k : lds_attr_set)
         if (k == kernel) return 0;
@@ -711,6 +1033,16 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
             RMR_TRY(launch_fused_front(m, signal + (size_t)c0 * m->L, seqs + (size_t)c0 * seq_w, seq_w,
                                        maps + (size_t)c0 * map_w, map_w, lens + c0, nb, x16));
+            if (const char *dump = getenv("RMR_FUSED_DUMP_X")) {  // diagnostics (tools/stress_determinism.py): x of every sub-batch, appended
+                std::vector<uint16_t> h(x_elems * nb);
+                RMR_HIP(hipStreamSynchronize(e->stream));
+                RMR_HIP(hipMemcpy(h.data(), x16, h.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+                if (FILE *f = fopen(dump, "ab")) {
+                    fwrite(h.data(), sizeof(uint16_t), h.size(), f);
+                    fclose(f);
+                }
+            }
+            if (tune_int("RMR_DEBUG_SKIP_LSTM", 0)) continue;  // diagnostics: the front kernel alone (x through RMR_FUSED_DUMP_X)
             RMR_TRY(launch_lstm_head_x16(m, x16, nb, logits + (size_t)c0 * m->desc.num_out));
         }
         return 0;
@@ -783,6 +1115,15 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
         else if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
         else if (sigfold) RMR_TRY(launch_sig3_front_mfma(m, signal + (size_t)c0 * L, nb, cat));
         else RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
+        if (const char *dump = fold ? getenv("RMR_DUMP_CAT") : nullptr) {  // diagnostics (tools/stress_determinism.py): cat [nb][P3][2 sz]
+            std::vector<float> h((size_t)nb * m->P3 * 2 * sz);
+            RMR_HIP(hipStreamSynchronize(e->stream));
+            RMR_HIP(hipMemcpy(h.data(), cat, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(dump, "wb")) {
+                fwrite(h.data(), sizeof(float), h.size(), f);
+                fclose(f);
+            }
+        }
         if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
             float *x = base; base += (size_t)nb * m->T * sz;
             if (fold) {

@@ -181,6 +181,9 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         f32x4 accN[4] = {bias[0], bias[1], bias[2], bias[3]};
         xproj<KS, G, RS>(xbuf[0], q, nn, Aih, accN);
+        // step 0 ends with xbuf[0] overwritten (x_2): every wave has to be past its x_0 reads first (k_lstm_x16.hip has the
+        // account of what happened without this barrier when processes shared the GPU)
+        __syncthreads();
         for (int t = 0; t < a.T; ++t) {
             // x_{t+2} (clamped: the last two fetches are redundant re-reads, never consumed)
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;

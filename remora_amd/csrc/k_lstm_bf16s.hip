@@ -152,6 +152,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         f32x4 accN[4] = {bias[0], bias[1], bias[2], bias[3]};
         mm_split<KS32, NP, SL>(xs[0], q, nn, Aih, accN);
+        __syncthreads();  // xs[0] is overwritten at the end of step 0: all x_0 reads first (see k_lstm_x16.hip)
         for (int t = 0; t < a.T; ++t) {
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
             const float4 xnext = xsrc[(size_t)tf * (H / 4)];

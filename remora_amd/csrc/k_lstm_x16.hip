@@ -130,6 +130,10 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) accN[t] = mfma16<F16>(Aih[t][ks], xs[0][q][nn][ks], accN[t]);
         }
+        // step 0 ends with the stagers overwriting xs[0] (x_2): every wave must have read x_0 above before any stager gets
+        // there.  Without this barrier a wave held up for longer than one step (other processes' waves on its SIMD) projected
+        // x_2 for x_0 in eight chunks: the runs that differed when several processes shared the GPU (profiles/NOTES_r04.md)
+        __syncthreads();
         for (int t = 0; t < a.T; ++t) {
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;  // x_{t+2} (the last two fetches are redundant re-reads)
             uint4 xnext = make_uint4(0, 0, 0, 0);

@@ -122,6 +122,15 @@ struct rmr_engine {
     int prof_collect();
 };
 
+namespace rmr {
+// Diagnostics (RMR_POISON=1): in front of EVERY kernel launch of the library a kernel fills the LDS and most of the vector
+// registers of every CU with 0xFFFFFFFF (NaN as fp32 / bf16 / half, -1 as an integer).  LDS and registers keep what the
+// previous workgroup left; a kernel that reads a word it never wrote normally finds the leftovers of its own kind (often
+// the very values it would have written) and only fails next to OTHER kernels - e.g. another process's on the same GPU.
+// With the poison such a read shows up in a single process: tests/test_gpu_poison.py.
+void poison_before_launch(rmr_engine *e, hipStream_t s);
+}  // namespace rmr
+
 // RAII-less helper: brackets one launch with events when profiling is on
 struct ProfScope {
     rmr_engine *e;
@@ -130,6 +139,7 @@ struct ProfScope {
     hipStream_t s;
     ProfScope(rmr_engine *eng, int id, hipStream_t st = nullptr, bool use_st = false)
         : e(eng), s(use_st ? st : eng->stream) {
+        rmr::poison_before_launch(e, s);
         if (e->profiling) on = (e->prof_begin(id, &t1, s) == 0);
     }
     ~ProfScope() {

@@ -22,7 +22,24 @@ __device__ __forceinline__ float swish_f(float x) { return x * sigmoid_f(x); }
 // VALU instruction saved in the fp32 pipeline is matrix time gained.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_splat(float x) { return f32x2{x, x}; }
+// pk_fma: the multiply-add of the VALU signal producers (front_sig_kernel, sig3_front_kernel).  As v_pk_fma_f32 those two
+// kernels - and only they - returned damaged activations in a few per cent of the calls while ANOTHER process kept the bf16
+// matrix cores busy (tools/ubench/neighbour mfma16; tools/stress_determinism.py): one lane's result off in scattered chunks,
+// never alone on the GPU, never beside VALU / LDS / HBM / fp32-MFMA loads, and never when built as the two v_fma_f32 below
+// (0 of 600 calls against 27 of 300; profiles/NOTES_r04.md has the whole account - a stand-alone v_pk_fma_f32 check beside
+// the same neighbour stays clean, so the cause is not pinned to the instruction).  The scalar pair is the shipped form:
+// bit-identical, front_sig_kernel 1.67 against 1.62 ns per chunk, sig3_front_kernel 5.81 against 5.47 (no longer the default
+// producer, k_conv_front.hip).  -DRMR_PACKED_F32_FMA restores the packed one.
+#ifndef RMR_PACKED_F32_FMA
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    float x, y;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(a.x), "v"(b.x), "v"(c.x));
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a.y), "v"(b.y), "v"(c.y));
+    return f32x2{x, y};
+}
+#else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 // swish of four values: the multiplies and the add packed, the four exp / rcp stay scalar (no packed transcendentals);
 // element for element the same operations as swish_f
 __device__ __forceinline__ void swish_pk(f32x2 &a, f32x2 &b) {
