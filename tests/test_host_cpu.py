@@ -308,6 +308,43 @@ def test_bam_and_pod5_parsers_on_reference_test_data():
     assert rio.revcomp("ACGTN") == "NACGT"
 
 
+@pytest.mark.parametrize("name", ["can", "mod"])
+def test_parsers_agree_with_numbers_other_programs_wrote(name):
+    """pysam and pod5 are not in the image, so the BAM / POD5 readers are checked against each other's second implementation
+    elsewhere (native vs Python reader, GPU vs numpy VBZ decoder).  What IS independent of this repository are numbers that the
+    basecaller (dorado), MinKNOW and the aligner wrote into the two files about the same read.  A reader that mis-parses a
+    field, a tag type, the 4-bit sequence, the qualities, the VBZ rows or the calibration breaks one of these:
+      ns tag (BAM)  ==  num_samples (POD5 reads table)  ==  sum of the signal rows' `samples`  ==  decoded signal length
+      du tag (seconds) x 4 kHz  ==  ns                      mv: stride 5, one entry per stride of [ts, ns), its ones == bases
+      qs tag  ==  rounded mean-error q-score of the decoded quality string
+      sm / sd tags (pA shift / scale)  ~  median / MAD of the decoded, calibrated signal      NM tag: test_reference_sequence_from_md..."""
+    from golden_util import pod5_reads_cpu
+    from remora_amd import io as rio
+
+    pod5_path = os.path.join(DATA, f"{name}_reads.pod5")
+    f = rio.Pod5File(pod5_path)
+    num_samples = dict(zip(f.read_ids, f._reads.column("num_samples").to_pylist()))
+    decoded = {p.read_id: p for p in pod5_reads_cpu(pod5_path)}
+    n = 0
+    for rec in rio.iter_bam_records(os.path.join(DATA, f"{name}_mappings.bam")):
+        t, p = dict(rec.tags), decoded[rec.query_name]
+        rows = f.signal_rows(rec.query_name)
+        assert t["ns"] == num_samples[rec.query_name] == sum(k for _, k in rows) == p.signal.size
+        assert abs(t["du"] * 4000.0 - t["ns"]) < 0.5
+        mv = np.asarray(t["mv"])
+        assert int(mv[0]) == 5 and mv.size - 1 == (t["ns"] - t["ts"]) // 5 and set(mv[1:].tolist()) <= {0, 1}
+        assert int(mv[1:].sum()) == len(rec.query_sequence) == len(rec.query_qualities)
+        q = np.frombuffer(bytes(rec.query_qualities), dtype=np.uint8).astype(np.float64)
+        assert abs(-10.0 * np.log10(np.mean(10.0 ** (-q / 10.0))) - t["qs"]) < 0.75
+        off, scale = f.calibration(rec.query_name)
+        pa = (p.signal[t["ts"] :].astype(np.float64) + off) * scale
+        med = np.median(pa)
+        # (dorado's shift / scale are quantile based: the same quantities to a quarter / a fifth of the scale)
+        assert abs(t["sm"] - med) < 0.25 * t["sd"] and abs(t["sd"] / (1.4826 * np.median(np.abs(pa - med))) - 1.0) < 0.2
+        n += 1
+    assert n == len(f.read_ids) >= 10
+
+
 def test_bam_writer_roundtrip(tmp_path):
     from remora_amd import io as rio
 
