@@ -138,6 +138,16 @@ int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int
 int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off,
                           const int64_t *sig_len, const int64_t *seq_len, int64_t n_reads, int check,
                           int reverse_signal, int64_t *q2s, int64_t *counts, int32_t *status, int mem);
+/* replaces: for a whole batch, the tail of io.Read.add_alignment and Read.into_remora_read (src/remora/io.py:2003-2012:
+ * the signal of an alignment is dacs[sp:][ts:ns]; :2123-2177: the read keeps dacs[q2s[0]:q2s[-1]] and the mapping q2s -
+ * q2s[0]) on arrays that are already resident: `signal` (device) holds the decoded samples of the batch back to back,
+ * read i's trimmed signal starts at signal[src_start[i]]; its move-table coordinates are the seq_len[i] + 1 values at
+ * q2s[q2s_off[i] ...] (device, as rmr_parse_moves_batch wrote them).  Written (device): dacs, s2s [sum(seq_len) + n_reads],
+ * d_sig_off / d_seq_off [n_reads + 1] - the rmr_reads layout; sig_off (host) receives the sample offsets.  src_start,
+ * q2s_off, seq_len are host arrays.  Lets the POD5 + BAM ingest hand batches to the extraction without per-read host work. */
+int rmr_assemble_reads(rmr_engine *e, int64_t n_reads, const int16_t *signal, const int64_t *src_start, const int64_t *q2s,
+                       const int64_t *q2s_off, const int64_t *seq_len, int16_t *dacs, int64_t dacs_cap, int64_t *s2s,
+                       int64_t *d_sig_off, int64_t *d_seq_off, int64_t *sig_off);
 
 /* ---- N1: BAM records for the POD5+BAM ingest (host code: BGZF inflate + record / tag decode) ---------- */
 /* replaces: what ReadIndexedBam / pysam hand to io.Read.add_alignment (src/remora/io.py:184-358, :1972-2084):

@@ -1318,6 +1318,40 @@ int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *m
     return 0;
 }
 
+int rmr_assemble_reads(rmr_engine *e, int64_t n_reads, const int16_t *signal, const int64_t *src_start, const int64_t *q2s,
+                       const int64_t *q2s_off, const int64_t *seq_len, int16_t *dacs, int64_t dacs_cap, int64_t *s2s,
+                       int64_t *d_sig_off, int64_t *d_seq_off, int64_t *sig_off) {
+    if (!e || !signal || !src_start || !q2s || !q2s_off || !seq_len || !dacs || !s2s || !d_sig_off || !d_seq_off || !sig_off)
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n_reads < 0) RMR_FAIL(RMR_ERR_INVALID, "bad sizes");
+    sig_off[0] = 0;
+    if (n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    const size_t n = (size_t)n_reads;
+    Stage st{e};
+    RMR_TRY(st.init(4 * Stage::pad(n * 8) + 4096));
+    int64_t *d_start = st.take<int64_t>(n), *d_qoff = st.take<int64_t>(n), *d_slen = st.take<int64_t>(n), *d_len = st.take<int64_t>(n);
+    H2D(d_start, src_start, n * 8);
+    H2D(d_qoff, q2s_off, n * 8);
+    H2D(d_slen, seq_len, n * 8);
+    RMR_TRY(launch_assemble_lengths(e, q2s, d_qoff, d_slen, n_reads, d_len));
+    std::vector<int64_t> len(n), seq_off(n + 1, 0);
+    D2H(len.data(), d_len, n * 8);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < n; ++i) {
+        if (len[i] < 0 || seq_len[i] < 0) RMR_FAIL(RMR_ERR_INVALID, "read %zu: a mapping that runs backwards", i);
+        sig_off[i + 1] = sig_off[i] + len[i];
+        seq_off[i + 1] = seq_off[i] + seq_len[i];
+    }
+    if (sig_off[n] > dacs_cap) RMR_FAIL(RMR_ERR_INVALID, "dacs capacity %lld < %lld samples", (long long)dacs_cap, (long long)sig_off[n]);
+    H2D(d_sig_off, sig_off, (n + 1) * 8);
+    H2D(d_seq_off, seq_off.data(), (n + 1) * 8);
+    RMR_TRY(launch_assemble_reads(e, signal, d_start, q2s, d_qoff, d_sig_off, d_seq_off, n_reads, dacs, s2s));
+    RMR_HIP(hipStreamSynchronize(e->stream));  // (the pageable offset vectors above are read by the copies)
+    return 0;
+}
+
 }  // extern "C"
 
 // ---- chunk extraction ------------------------------------------------------------------------

@@ -385,6 +385,47 @@ int launch_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_o
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Batch tail of io.Read.add_alignment + into_remora_read (src/remora/io.py:2003-2012, 2123-2177): read i keeps the samples
+// its move table maps, signal[src_start[i] + q2s_i[0] .. src_start[i] + q2s_i[last]), and its mapping re-based to 0.
+// Pass 1 (one thread per read): the kept length; pass 2 (grid = reads x segments): the copies, coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ void assemble_lengths_kernel(const int64_t *q2s, const int64_t *q2s_off, const int64_t *seq_len, int64_t n,
+                                        int64_t *len_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t *q = q2s + q2s_off[i];
+    len_out[i] = q[seq_len[i]] - q[0];
+}
+
+__global__ __launch_bounds__(256) void assemble_reads_kernel(const int16_t *signal, const int64_t *src_start, const int64_t *q2s,
+                                                             const int64_t *q2s_off, const int64_t *sig_off, const int64_t *seq_off,
+                                                             int16_t *dacs, int64_t *s2s) {
+    const int64_t i = blockIdx.x;
+    const int64_t *q = q2s + q2s_off[i];
+    const int64_t first = q[0], n_sig = sig_off[i + 1] - sig_off[i], n_map = seq_off[i + 1] - seq_off[i] + 1;
+    const int16_t *src = signal + src_start[i] + first;
+    int16_t *dst = dacs + sig_off[i];
+    const int64_t step = (int64_t)gridDim.y * blockDim.x, t0 = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    for (int64_t k = t0; k < n_sig; k += step) dst[k] = src[k];
+    int64_t *m = s2s + seq_off[i] + i;
+    for (int64_t k = t0; k < n_map; k += step) m[k] = q[k] - first;
+}
+
+int launch_assemble_lengths(rmr_engine *e, const int64_t *q2s, const int64_t *q2s_off, const int64_t *seq_len, int64_t n, int64_t *len_out) {
+    hipLaunchKernelGGL(assemble_lengths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, q2s, q2s_off, seq_len, n, len_out);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_assemble_reads(rmr_engine *e, const int16_t *signal, const int64_t *src_start, const int64_t *q2s, const int64_t *q2s_off,
+                          const int64_t *sig_off, const int64_t *seq_off, int64_t n, int16_t *dacs, int64_t *s2s) {
+    hipLaunchKernelGGL(assemble_reads_kernel, dim3((unsigned)n, 16), dim3(256), 0, e->stream, signal, src_start, q2s, q2s_off, sig_off,
+                       seq_off, dacs, s2s);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 // ======================================================================================
 // X1 + X2/X3 geometry.  Signal normalisation in float64 then one rounding to float32
 // (bit-exact with numpy); per chunk: focus clip, focus signal index, window with clipping,

@@ -223,6 +223,9 @@ int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_
 int launch_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off, const int64_t *sig_len,
                        const int64_t *seq_len, int64_t n, int check, int reverse, int64_t *q2s, int64_t *counts,
                        int32_t *status);
+int launch_assemble_lengths(rmr_engine *e, const int64_t *q2s, const int64_t *q2s_off, const int64_t *seq_len, int64_t n, int64_t *len_out);
+int launch_assemble_reads(rmr_engine *e, const int16_t *signal, const int64_t *src_start, const int64_t *q2s, const int64_t *q2s_off,
+                          const int64_t *sig_off, const int64_t *seq_off, int64_t n, int16_t *dacs, int64_t *s2s);
 int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
                     float *sig_out, int64_t total_sig, const int32_t *sig_read, int64_t *geo,
                     int *d_max_seq_len);

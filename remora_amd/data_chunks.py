@@ -269,6 +269,22 @@ class DeviceReads:
             nbytes = cnt * np.dtype(dt).itemsize
             setattr(self, name, dbuf[offs[name] : offs[name] + nbytes].view(getattr(torch, np.dtype(dt).name)))
 
+    @classmethod
+    def from_device(cls, engine, sig_off, seq_off, dacs, s2s, iseq, d_sig_off, d_seq_off, shift, scale):
+        """A batch whose arrays were assembled on the GPU (io.iter_ingest_batches: rmr_assemble_reads): CUDA tensors in the
+        rmr_reads layout, `sig_off` / `seq_off` the host copies of the offsets, `shift` / `scale` float64 host arrays."""
+        torch = _torch()
+        self = cls.__new__(cls)
+        self._ready = None
+        self.engine = engine
+        self.n_reads = int(len(sig_off) - 1)
+        self.sig_off, self.seq_off = np.ascontiguousarray(sig_off, np.int64), np.ascontiguousarray(seq_off, np.int64)
+        self.dacs, self.s2s, self.iseq, self.d_sig_off, self.d_seq_off = dacs, s2s, iseq, d_sig_off, d_seq_off
+        dev = engine.torch_device
+        self.shift = torch.from_numpy(np.ascontiguousarray(shift, np.float64)).to(dev)
+        self.scale = torch.from_numpy(np.ascontiguousarray(scale, np.float64)).to(dev)
+        return self
+
     def wait_ready(self):
         """Host wait for an asynchronous upload (no-op otherwise)."""
         if self._ready is not None:

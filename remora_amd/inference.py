@@ -293,60 +293,116 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     clock = {"prep": 0.0, "gpu": 0.0, "tags_write": 0.0, "wait_ingest": 0.0, "ingest": 0.0, "close": 0.0}  # RMR_INFER_TIMING=1 prints it
 
-    def flush(batch, writer):
+    def call(batch):
+        """Main thread: read preparation and the GPU passes of one batch -> a job for emit()."""
         tq = _time.perf_counter()
-        good = []
+        if isinstance(batch, rio.IngestBatch):  # arrays already on the GPU (io.iter_ingest_batches): nothing to prepare
+            for e in batch.err:
+                if e is not None:
+                    stats[e] += 1
+            clock["prep"] += _time.perf_counter() - tq
+            tg = _time.perf_counter()
+            res = call_reads_mods(batch.reads, models[0], mds[0], return_mod_probs=True, device_reads=batch.dr) if batch.good.size else []
+            clock["gpu"] += _time.perf_counter() - tg
+            return batch, None, [res]
+        items, good = [], []  # items: per input record None (callable: the next entry of `good`) or the record to copy
         for io_read, err in batch:
             if err is None:
                 try:
                     good.append((io_read, io_read.into_remora_read(ref_anchored)))
+                    items.append(None)
                     continue
                 except RemoraError as e:
                     err = f"Read prep error: {e}"
             stats[err] += 1
-            writer.write(rio.record_with_mod_tags(io_read.record, None, None))
-        if not good:
-            return
+            items.append(io_read.record)
         # one pass per model (the reference runs one model per canonical base, src/remora/inference.py:277-316);
         # every model works on its own copy of the reads because refinement rewrites their mappings
         per_model = []
         tg = _time.perf_counter()
         clock["prep"] += tg - tq
-        for mdl, md in zip(models, mds):
-            reads = [rr.copy() for _, rr in good] if len(models) > 1 else [rr for _, rr in good]
-            per_model.append(call_reads_mods(reads, mdl, md, return_mod_probs=True))
+        if good:
+            for mdl, md in zip(models, mds):
+                reads = [rr.copy() for _, rr in good] if len(models) > 1 else [rr for _, rr in good]
+                per_model.append(call_reads_mods(reads, mdl, md, return_mod_probs=True))
+        clock["gpu"] += _time.perf_counter() - tg
+        return items, good, per_model
+
+    def batch_tags(results, md, seq_bytes, seq_off):
+        """MM / ML of the callable reads of a batch in one native call -> (mm, mm_off, ml, ml_off, has uint8[n_good])."""
+        from .util import format_mm_ml_tags_batch
+
+        sizes = np.fromiter((r[2].size for r in results), np.int64, len(results))
+        live = [r for r in results if r[2].size]
+        pos = np.concatenate([r[2] for r in live]) if live else np.zeros(0, np.int64)
+        probs = np.concatenate([r[0] for r in live]) if live else np.zeros((0, len(md["mod_bases"])))
+        if pos.size:  # calls per label (0 = canonical): argmax over [1 - sum(p_mod), p_mod...], first maximum wins
+            full = np.concatenate([1.0 - probs.sum(axis=1, keepdims=True), probs], axis=1)
+            label_counts[0] += np.bincount(full.argmax(axis=1), minlength=label_counts[0].size)
+        call_off = np.zeros(len(results) + 1, np.int64)
+        np.cumsum(sizes, out=call_off[1:])
+        mm, mm_off, ml, ml_off = format_mm_ml_tags_batch(seq_bytes, seq_off, pos, probs, call_off, md["mod_bases"], md["can_base"])
+        has = (sizes > 0).astype(np.uint8)
+        n_ok = int(has.sum())
+        stats[None] += n_ok
+        if n_ok < len(results):
+            stats[f"No {md['can_base']} mod calls"] += len(results) - n_ok
+        return mm, mm_off, ml, ml_off, has
+
+    def spread(off_good, good_pos, n):
+        """Offsets int64[n + 1] for all n records of a batch from those of its callable ones (positions good_pos, ascending):
+        records in between own empty slices."""
+        full = np.zeros(n + 1, np.int64)
+        full[good_pos + 1] = off_good[1:]
+        return np.maximum.accumulate(full)
+
+    def emit(job, writer):
+        """Writer thread: MM/ML tags and output records of one batch, every record at its place in the input order
+        (uncallable reads and reads without calls are copied without modified-base tags)."""
+        items, good, per_model = job
         tw = _time.perf_counter()
-        clock["gpu"] += tw - tg
         clock["tags_write"] -= tw
+        if isinstance(items, rio.IngestBatch):
+            ib, n = items, len(items)
+            rb = ib.rb
+            has = np.zeros(n, np.uint8)
+            if ib.good.size:
+                mm, mm_off, ml, ml_off, has_g = batch_tags(per_model[0], mds[0], ib.seq, ib.seq_off)
+                has[ib.good] = has_g
+                mm_off, ml_off = spread(mm_off, ib.good, n), spread(ml_off, ib.good, n)
+            else:
+                mm, ml, mm_off, ml_off = np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+            writer.write(rio.records_with_mod_tags_flat(rb.raw, rb.raw_off[ib.keep], rb.raw_off[ib.keep + 1] - rb.raw_off[ib.keep],
+                                                        rb.tags_off[ib.keep], mm, mm_off, ml, ml_off, has))
+            clock["tags_write"] += _time.perf_counter()
+            return
+        n = len(items)
+        good_pos = np.asarray([k for k, it in enumerate(items) if it is None], np.int64)
         if len(mds) == 1 and not ref_anchored and os.environ.get("RMR_NATIVE_TAGS", "1") != "0":
             # one model, basecall-anchored (the common case): MM/ML strings and the rewritten records of the whole batch in
             # two native calls (rmr_format_mm_ml, rmr_records_with_mod_tags) - byte for byte the per-read Python path below
-            from .util import format_mm_ml_tags_batch
-
-            md, results = mds[0], per_model[0]
-            sizes = np.fromiter((r[2].size for r in results), np.int64, len(results))
-            live = [r for r in results if r[2].size]
-            pos = np.concatenate([r[2] for r in live]) if live else np.zeros(0, np.int64)
-            probs = np.concatenate([r[0] for r in live]) if live else np.zeros((0, len(md["mod_bases"])))
-            if pos.size:  # calls per label (0 = canonical): argmax over [1 - sum(p_mod), p_mod...], first maximum wins
-                full = np.concatenate([1.0 - probs.sum(axis=1, keepdims=True), probs], axis=1)
-                label_counts[0] += np.bincount(full.argmax(axis=1), minlength=label_counts[0].size)
-            seqs = [io_read.seq for io_read, _ in good]
-            seq_off = np.zeros(len(seqs) + 1, np.int64)
-            np.cumsum([len(x) for x in seqs], out=seq_off[1:])
-            call_off = np.zeros(len(seqs) + 1, np.int64)
-            np.cumsum(sizes, out=call_off[1:])
-            mm, mm_off, ml, ml_off = format_mm_ml_tags_batch("".join(seqs).encode("latin-1"), seq_off, pos, probs, call_off,
-                                                             md["mod_bases"], md["can_base"])
-            has = sizes > 0
-            writer.write(rio.records_with_mod_tags_batch([io_read.record for io_read, _ in good], mm, mm_off, ml, ml_off, has))
-            n_ok = int(has.sum())
-            stats[None] += n_ok
-            if n_ok < len(good):
-                stats[f"No {md['can_base']} mod calls"] += len(good) - n_ok
+            has = np.zeros(n, np.uint8)
+            if good:
+                seqs = [io_read.seq for io_read, _ in good]
+                seq_off = np.zeros(len(seqs) + 1, np.int64)
+                np.cumsum([len(x) for x in seqs], out=seq_off[1:])
+                mm, mm_off, ml, ml_off, has_g = batch_tags(per_model[0], mds[0], "".join(seqs).encode("latin-1"), seq_off)
+                has[good_pos] = has_g
+                mm_off, ml_off = spread(mm_off, good_pos, n), spread(ml_off, good_pos, n)
+            else:
+                mm, ml, mm_off, ml_off = np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+            it_good = iter(good)
+            records = [next(it_good)[0].record if it is None else it for it in items]
+            writer.write(rio.records_with_mod_tags_batch(records, mm, mm_off, ml, ml_off, has))
             clock["tags_write"] += _time.perf_counter()
             return
-        for k, (io_read, rr) in enumerate(good):
+        k = -1
+        for it in items:
+            if it is not None:
+                writer.write(rio.record_with_mod_tags(it, None, None))
+                continue
+            k += 1
+            io_read, rr = good[k]
             import array
 
             mm_all, ml_all, errs = [], array.array("B"), []
@@ -375,7 +431,26 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     label_counts = [np.zeros(len(md["mod_bases"]) + 1, np.int64) for md in mds]
 
+    refiner0 = mds[0].get("sig_map_refiner")
+    iterative = refiner0 is not None and getattr(refiner0, "is_loaded", False) and refiner0.scale_iters > 0
+    # one model, basecall-anchored, forward signal: the batch ingest (io.iter_ingest_batches) - trimming, move tables, scaling
+    # and the read arrays of a whole BAM batch on the GPU, no Python object per read; everything else read by read
+    batch_ingest = (len(models) == 1 and not ref_anchored and not reverse_signal and not iterative and
+                    os.environ.get("RMR_INFER_BATCH_INGEST", "1") != "0")
+
     def batches():
+        if batch_ingest:
+            seen = 0
+            for ib in rio.iter_ingest_batches(pod5_path, in_bam_path, pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
+                                              batch=reads_per_batch, shard=shard, device=models[0].engine.device):
+                if num_reads is not None and seen + len(ib) >= num_reads:
+                    left = num_reads - seen
+                    if left > 0:
+                        yield ib.head(left) if isinstance(ib, rio.IngestBatch) else ib[:left]
+                    return
+                seen += len(ib)
+                yield ib
+            return
         batch = []
         for i, item in enumerate(rio.iter_reads_from_pod5_and_bam(pod5_path, in_bam_path, reverse_signal=reverse_signal,
                                                                   pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
@@ -421,17 +496,45 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     t = threading.Thread(target=produce, daemon=True)
     t.start()
+    # tags + output of batch k run in a thread of their own while the main thread prepares batch k + 1 and waits for its
+    # GPU passes (ctypes and the BGZF pool release the GIL); jobs are taken in order, so the output does not change
+    wq = _queue.Queue(maxsize=2)
+    werr = []
+
+    def write_loop(writer):
+        while True:
+            job = wq.get()
+            if job is None:
+                return
+            if werr:
+                continue  # drain after a failure
+            try:
+                emit(job, writer)
+            except BaseException as e:  # noqa: BLE001 - re-raised by the main thread
+                werr.append(e)
+
     try:
         with rio.BamWriter(part_path, header if rank == 0 else b"", eof=world == 1, level=bam_level) as writer:
-            while True:
-                tq0 = _time.perf_counter()
-                b = q.get()
-                clock["wait_ingest"] += _time.perf_counter() - tq0
-                if b is None:
-                    break
-                if isinstance(b, BaseException):
-                    raise b
-                flush(b, writer)
+            wt = threading.Thread(target=write_loop, args=(writer,), daemon=True)
+            wt.start()
+            try:
+                while True:
+                    tq0 = _time.perf_counter()
+                    b = q.get()
+                    clock["wait_ingest"] += _time.perf_counter() - tq0
+                    if b is None:
+                        break
+                    if isinstance(b, BaseException):
+                        raise b
+                    job = call(b)
+                    if werr:
+                        break
+                    wq.put(job)
+            finally:
+                wq.put(None)
+                wt.join()
+            if werr:
+                raise werr[0]
             tc = _time.perf_counter()
         clock["close"] = _time.perf_counter() - tc
     except BaseException:

@@ -449,11 +449,36 @@ def bam_shard(bam_path, rank, world, every=64):
     return int(marks[m0]), int(min(m1 * every, n) - m0 * every)
 
 
-def _native_batches(lib, h, want_ref, batch, once=False, limit=None):
-    refs = {}
+class RawBamBatch:
+    """One rmr_bam_read_batch result as flat arrays (copies: the native buffers are reused by the next call): per record
+    flag, ref_id, pos, mapq, n_cigar, ts, ns, sp (int32), sm, sd (float32), has (bit set of the hot tags present), ref_ok,
+    tags_off, voffset (int64) and the offset arrays (int64[n + 1]) into the blobs raw (record bytes without block_size),
+    names, seq (ASCII bases), mv (int8 move tables), pi, refseq, cigar."""
+
+    __slots__ = ("n", "flag", "ref_id", "pos", "mapq", "n_cigar", "ts", "ns", "sp", "sm", "sd", "has", "ref_ok", "tags_off", "voffset",
+                 "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off", "cigar_off", "raw", "names", "seq", "mv", "pi",
+                 "refseq", "cigar", "want_ref")
+
+    def head(self, k):
+        """The first k records (offset arrays cut, blobs shared)."""
+        out = RawBamBatch()
+        for f in self.__slots__:
+            v = getattr(self, f)
+            if f == "n":
+                v = int(k)
+            elif f.endswith("_off") and f != "tags_off":
+                v = v[: k + 1]
+            elif isinstance(v, np.ndarray) and f not in ("mv", "cigar"):
+                v = v[:k]
+            setattr(out, f, v)
+        return out
+
+
+def _native_raw_batches(lib, h, want_ref, batch, once=False, limit=None):
     bb = L.BamBatch()
-    arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,))
+    arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,)).copy()
                                   if count else np.zeros(0, dt))  # noqa: E731
+    blob = lambda ptr, total: ctypes.string_at(ptr, total) if total else b""  # noqa: E731
     left = None if limit is None else int(limit)
     while True:
         if left is not None:
@@ -466,51 +491,72 @@ def _native_batches(lib, h, want_ref, batch, once=False, limit=None):
             return
         if left is not None:
             left -= n
-        i32 = lambda f: arr(getattr(bb, f), ctypes.c_int32, n).tolist()  # noqa: E731
-        off = lambda f: arr(getattr(bb, f), ctypes.c_int64, n + 1).tolist()  # noqa: E731
-        flag, ref_id, pos, mapq, n_cig = i32("flag"), i32("ref_id"), i32("pos"), i32("mapq"), i32("n_cigar")
-        ts, ns, sp = i32("ts"), i32("ns"), i32("sp")
-        sm, sd = arr(bb.sm, ctypes.c_float, n).tolist(), arr(bb.sd, ctypes.c_float, n).tolist()
-        has, ref_ok = arr(bb.has, ctypes.c_uint8, n).tolist(), arr(bb.ref_ok, ctypes.c_uint8, n).tolist()
-        raw_off, name_off, seq_off, mv_off, pi_off, rs_off, cig_off = (off(f) for f in (
-            "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off", "cigar_off"))
-        cigar = arr(bb.cigar, ctypes.c_uint32, cig_off[n]).copy()
-        tags_off = arr(bb.tags_off, ctypes.c_int64, n).tolist()
-        voff = arr(bb.voffset, ctypes.c_int64, n).tolist()
-        blob = lambda ptr, total: ctypes.string_at(ptr, total) if total else b""  # noqa: E731
-        # latin-1 is one character per byte: offsets stay valid whatever the bytes are (one odd record cannot
-        # take the whole batch down with a UnicodeDecodeError)
-        raw, names, seq = blob(bb.raw, raw_off[n]), blob(bb.names, name_off[n]).decode("latin-1"), blob(bb.seq, seq_off[n]).decode("latin-1")
-        pi, refseq = blob(bb.pi, pi_off[n]).decode("latin-1"), blob(bb.refseq, rs_off[n]).decode("latin-1")
-        mv = np.frombuffer(blob(bb.mv, mv_off[n]), np.int8)
-        for i in range(n):
-            h_i = has[i]
-            hot = {}
-            if h_i & 1:
-                hot["mv"] = mv[mv_off[i] : mv_off[i + 1]]
-            if h_i & 2:
-                hot["ts"] = ts[i]
-            if h_i & 4:
-                hot["ns"] = ns[i]
-            if h_i & 8:
-                hot["sp"] = sp[i]
-            if h_i & 16:
-                hot["sm"] = sm[i]
-            if h_i & 32:
-                hot["sd"] = sd[i]
-            if h_i & 64:
-                hot["pi"] = pi[pi_off[i] : pi_off[i + 1]]
-            rid = ref_id[i]
-            if rid >= 0 and rid not in refs:
-                nm = lib.rmr_bam_ref_name(h, rid)
-                refs[rid] = nm.decode() if nm is not None else None
-            yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
-                                   pos[i], mapq[i], seq[seq_off[i] : seq_off[i + 1]], raw[raw_off[i] : raw_off[i + 1]],
-                                   tags_off[i], n_cig[i], hot,
-                                   refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None, voff[i],
-                                   cigar[cig_off[i] : cig_off[i + 1]])
+        rb = RawBamBatch()
+        rb.n, rb.want_ref = n, bool(want_ref)
+        for f in ("flag", "ref_id", "pos", "mapq", "n_cigar", "ts", "ns", "sp"):
+            setattr(rb, f, arr(getattr(bb, f), ctypes.c_int32, n))
+        rb.sm, rb.sd = arr(bb.sm, ctypes.c_float, n), arr(bb.sd, ctypes.c_float, n)
+        rb.has, rb.ref_ok = arr(bb.has, ctypes.c_uint8, n), arr(bb.ref_ok, ctypes.c_uint8, n)
+        rb.tags_off, rb.voffset = arr(bb.tags_off, ctypes.c_int64, n), arr(bb.voffset, ctypes.c_int64, n)
+        for f in ("raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off", "cigar_off"):
+            setattr(rb, f, arr(getattr(bb, f), ctypes.c_int64, n + 1))
+        rb.cigar = arr(bb.cigar, ctypes.c_uint32, int(rb.cigar_off[n]))
+        rb.raw, rb.names, rb.seq = blob(bb.raw, int(rb.raw_off[n])), blob(bb.names, int(rb.name_off[n])), blob(bb.seq, int(rb.seq_off[n]))
+        rb.pi, rb.refseq = blob(bb.pi, int(rb.pi_off[n])), blob(bb.refseq, int(rb.refseq_off[n]))
+        rb.mv = arr(bb.mv, ctypes.c_int8, int(rb.mv_off[n]))
+        yield rb
         if n < batch or once:
             return
+
+
+def _records_of(rb, lib, h, refs):
+    """The _NativeBamRecord objects of a raw batch."""
+    n = rb.n
+    i32 = lambda f: getattr(rb, f).tolist()  # noqa: E731
+    flag, ref_id, pos, mapq, n_cig = i32("flag"), i32("ref_id"), i32("pos"), i32("mapq"), i32("n_cigar")
+    ts, ns, sp = i32("ts"), i32("ns"), i32("sp")
+    sm, sd = rb.sm.tolist(), rb.sd.tolist()
+    has, ref_ok = rb.has.tolist(), rb.ref_ok.tolist()
+    raw_off, name_off, seq_off, mv_off, pi_off, rs_off, cig_off = (i32(f) for f in (
+        "raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off", "cigar_off"))
+    cigar, tags_off, voff = rb.cigar, i32("tags_off"), i32("voffset")
+    # latin-1 is one character per byte: offsets stay valid whatever the bytes are (one odd record cannot
+    # take the whole batch down with a UnicodeDecodeError)
+    raw, names, seq = rb.raw, rb.names.decode("latin-1"), rb.seq.decode("latin-1")
+    pi, refseq = rb.pi.decode("latin-1"), rb.refseq.decode("latin-1")
+    mv, want_ref = rb.mv, rb.want_ref
+    for i in range(n):
+        h_i = has[i]
+        hot = {}
+        if h_i & 1:
+            hot["mv"] = mv[mv_off[i] : mv_off[i + 1]]
+        if h_i & 2:
+            hot["ts"] = ts[i]
+        if h_i & 4:
+            hot["ns"] = ns[i]
+        if h_i & 8:
+            hot["sp"] = sp[i]
+        if h_i & 16:
+            hot["sm"] = sm[i]
+        if h_i & 32:
+            hot["sd"] = sd[i]
+        if h_i & 64:
+            hot["pi"] = pi[pi_off[i] : pi_off[i + 1]]
+        rid = ref_id[i]
+        if rid >= 0 and rid not in refs:
+            nm = lib.rmr_bam_ref_name(h, rid)
+            refs[rid] = nm.decode() if nm is not None else None
+        yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
+                               pos[i], mapq[i], seq[seq_off[i] : seq_off[i + 1]], raw[raw_off[i] : raw_off[i + 1]],
+                               tags_off[i], n_cig[i], hot,
+                               refseq[rs_off[i] : rs_off[i + 1]] if (want_ref and ref_ok[i]) else None, voff[i],
+                               cigar[cig_off[i] : cig_off[i + 1]])
+
+
+def _native_batches(lib, h, want_ref, batch, once=False, limit=None):
+    refs = {}
+    for rb in _native_raw_batches(lib, h, want_ref, batch, once=once, limit=limit):
+        yield from _records_of(rb, lib, h, refs)
 
 
 def read_is_primary(read):
@@ -692,6 +738,51 @@ def iter_bam_records(bam_path, want_ref=False, batch=512, native=True, shard=Non
     yield from _iter_bam_records_py(bam_path)
 
 
+def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None):
+    """The alignments of a BAM file (or of a rank's share of it, `shard` as in iter_bam_records) as (RawBamBatch, records)
+    pairs - `records(rb)` builds the record objects of a batch when somebody needs them - straight from the native reader:
+    no Python object per record.  The batch form of iter_bam_records (same shares, same boundary check)."""
+    start = count = end = None
+    if shard is not None and (hasattr(shard, "result") or int(shard[1]) > 1):
+        got = shard.result() if hasattr(shard, "result") else shard_of(bam_path, int(shard[0]), int(shard[1]))
+        if len(got) == 3:  # ("bytes", start, end)
+            _, start, end = got
+            if start is None:
+                return
+        else:
+            start, count = got
+            if count is not None and not count:
+                return
+    lib = L.lib()
+    h = ctypes.c_void_p()
+    L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+    refs = {}
+    records = lambda rb: list(_records_of(rb, lib, h, refs))  # noqa: E731
+    try:
+        if start is not None:
+            L.check(lib.rmr_bam_seek(h, int(start)))
+        if end is None:
+            for rb in _native_raw_batches(lib, h, want_ref, batch, limit=count):
+                yield rb, records
+            return
+        end = int(end)
+        for rb in _native_raw_batches(lib, h, want_ref, batch):
+            past = np.nonzero(rb.voffset >= end)[0]
+            if past.size:
+                k = int(past[0])
+                if int(rb.voffset[k]) != end:
+                    raise RemoraError(f"{bam_path}: the records of this share run past virtual offset {end} without one "
+                                      f"starting there - the next share's start was guessed wrong (REMORA_AMD_BAM_SHARD=scan "
+                                      f"splits by an exact pass over the file instead)")
+                if k:
+                    yield rb.head(k), records
+                return
+            yield rb, records
+        raise RemoraError(f"{bam_path}: end of file before the record at virtual offset {end} where the next share begins")
+    finally:
+        lib.rmr_bam_close(h)
+
+
 def _iter_bam_records_py(bam_path):
     """Pure-Python BGZF/BAM reader (gzip + struct), one record in memory at a time."""
     with gzip.open(bam_path, "rb") as fh:  # BGZF members are valid concatenated gzip members
@@ -773,6 +864,42 @@ def _zstd_decompress(blob):
     import pyarrow as pa
 
     return pa.CompressedInputStream(pa.BufferReader(blob), "zstd").read()
+
+
+def vbz_decode_rows(addr, size, n_samples, engine=None):
+    """vbz_decode_batch for rows given by address and compressed size (Pod5File.rows_of_reads: pointers into the mapped
+    file, no bytes object per row); the samples stay on the GPU.  Returns (int16 CUDA tensor, row offsets int64[n + 1])."""
+    import torch
+
+    from .engine import get_engine
+
+    eng = engine if engine is not None else get_engine()
+    n = int(np.asarray(size).size)
+    src = np.ascontiguousarray(addr, np.uint64)
+    src_len = np.ascontiguousarray(size, np.int64)
+    out_off = np.zeros(n + 1, np.int64)
+    np.cumsum(np.asarray(n_samples, np.int64), out=out_off[1:])
+    dev = eng.torch_device
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int16, device=dev), out_off
+    sizes = np.zeros(n, np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.check(L.lib().rmr_zstd_frame_sizes(p(src), p(src_len), n, p(sizes)))
+    row_off = np.zeros(n + 1, np.int64)
+    np.cumsum(sizes, out=row_off[1:])
+    total = int(row_off[-1])
+    # the zstd layer inflates straight into pinned memory: one copy to the device, no pageable bounce
+    host = torch.empty(total + 16, dtype=torch.uint8, pin_memory=True)
+    host[total:] = 0
+    L.check(L.lib().rmr_zstd_rows(p(src), p(src_len), n, ctypes.c_void_p(host.data_ptr()), p(row_off), min(8, _eff_cpus())))
+    rn = np.ascontiguousarray(n_samples, np.int32)
+    d_buf = host.to(dev, non_blocking=True)
+    d_ro, d_rn = torch.from_numpy(row_off).to(dev), torch.from_numpy(rn).to(dev)
+    d_out = torch.empty(max(int(out_off[-1]), 1), dtype=torch.int16, device=dev)
+    torch.cuda.current_stream(dev).synchronize()  # the copies ran on torch's stream, the kernel runs on the engine's
+    L.check(L.lib().rmr_vbz_decode(eng.handle, d_buf.data_ptr(), d_ro.data_ptr(), d_rn.data_ptr(), n, d_out.data_ptr(), L.MEM_DEVICE))
+    eng.synchronize()
+    return d_out[: int(out_off[-1])], out_off
 
 
 def vbz_decode_batch(blobs, n_samples, engine=None, to_host=True):
@@ -930,6 +1057,41 @@ class Pod5File:
         self._sig_chunks, self._n_chunks = sig_col.chunks, n_col.chunks
         self._sig_starts = np.cumsum([0] + [len(c) for c in self._sig_chunks])
         self._n_starts = np.cumsum([0] + [len(c) for c in self._n_chunks])
+
+    def _row_index(self):
+        """Flat numpy views of the two tables, built on first use: per signal row its address in the mapped file, its
+        compressed size and its sample count; per read the range of its rows.  With them a batch of reads is located
+        by array arithmetic instead of one Arrow scalar (`.as_py()`, a bytes copy of the row) per cell."""
+        idx = getattr(self, "_ridx", None)
+        if idx is None:
+            addr, size = [], []
+            for c in self._sig_chunks:
+                _, offs, data = c.buffers()
+                wide = np.int64 if str(c.type).startswith("large") else np.int32
+                o = np.frombuffer(offs, dtype=wide, count=c.offset + len(c) + 1)[c.offset :].astype(np.int64)
+                addr.append(np.uint64(data.address) + o[:-1].astype(np.uint64))
+                size.append(np.diff(o))
+            samples = np.concatenate([c.to_numpy(zero_copy_only=False) for c in self._n_chunks]).astype(np.int64) if self._n_chunks else np.zeros(0, np.int64)
+            rr = self._read_rows.combine_chunks()
+            r_off = rr.offsets.to_numpy().astype(np.int64)
+            r_val = rr.values.to_numpy().astype(np.int64)
+            idx = self._ridx = (np.concatenate(addr) if addr else np.zeros(0, np.uint64), np.concatenate(size) if size else np.zeros(0, np.int64),
+                                samples, r_off - r_off[0], r_val[r_off[0] :] if r_off.size else r_val)
+        return idx
+
+    def rows_of_reads(self, read_rows):
+        """For reads given by their row numbers in the reads table: (row_first int64[n + 1] - read k's signal rows are
+        entries row_first[k] .. row_first[k + 1] of the next three arrays -, address uint64[], compressed size int64[],
+        samples int64[])."""
+        addr, size, samples, r_off, r_val = self._row_index()
+        read_rows = np.asarray(read_rows, np.int64)
+        cnt = r_off[read_rows + 1] - r_off[read_rows]
+        first = np.zeros(read_rows.size + 1, np.int64)
+        np.cumsum(cnt, out=first[1:])
+        # entry j of read k is r_val[r_off[read k] + j]
+        flat = np.repeat(r_off[read_rows] - first[:-1], cnt) + np.arange(int(first[-1]), dtype=np.int64)
+        rows = r_val[flat]
+        return first, addr[rows], size[rows], samples[rows]
 
     @staticmethod
     def _cell(chunks, starts, i):
@@ -1241,6 +1403,12 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
     from .engine import get_ingest_engine
 
     ingest_eng = get_ingest_engine(device) if decode_batch > 1 else None  # own stream: not behind the model's kernels
+    yield from _reads_of_records(iter_bam_records(bam_path, want_ref=parse_ref_align, shard=shard), signals, ingest_eng, reverse_signal,
+                                 pa_scaling, skip_non_primary, decode_batch, parse_ref_align)
+
+
+def _reads_of_records(records, signals, ingest_eng, reverse_signal, pa_scaling, skip_non_primary, decode_batch, parse_ref_align):
+    """(io.Read, error-or-None) for the records of an iterable whose signal is in `signals` (see iter_reads_from_pod5_and_bam)."""
 
     def emit(recs):
         if decode_batch > 1 and recs:
@@ -1268,12 +1436,13 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
                 read.add_alignment(rec, parse_ref_align=parse_ref_align, reverse_signal=reverse_signal,
                                    pa_scaling=pa_scaling, parsed_moves=mv)
             except RemoraError as e:
+                read.record = rec  # (add_alignment turns some records away before it stores them: the output still copies them)
                 yield read, str(e)
                 continue
             yield read, None
 
     pending = []
-    for rec in iter_bam_records(bam_path, want_ref=parse_ref_align, shard=shard):  # shard = (rank, world): this rank's records
+    for rec in records:
         if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
             continue
         rid = (rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)).get("pi", rec.query_name)
@@ -1284,6 +1453,199 @@ def iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=False, pa_s
             yield from emit(pending)
             pending = []
     yield from emit(pending)
+
+
+class ReadStub:
+    """What the batched call path reads from and writes back to a read object (inference.call_reads_mods, the refiner's
+    device passes) when the read itself only exists as rows of a DeviceReads batch."""
+
+    __slots__ = ("shift", "scale", "seq_to_sig_map", "focus_bases", "_sig", "read_id")
+
+    def __init__(self, shift, scale, read_id=None):
+        self.shift, self.scale, self.read_id = shift, scale, read_id
+        self.seq_to_sig_map, self.focus_bases, self._sig = _NO_MAP, None, None
+
+
+_NO_MAP = np.zeros(0, np.int64)
+_COMP_BYTES = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")  # the byte form of _COMP (revcomp)
+
+
+class IngestBatch:
+    """The kept alignments of one native BAM batch, ready for the GPU without a Python object per read:
+    `rb` / `keep` - the raw batch and the indices of its records that are handed on (primary, signal present), in input order;
+    `err[k]` - None or the reason record keep[k] cannot be called (the strings Read.add_alignment / into_remora_read raise);
+    `good` - positions in `keep` of the callable reads; for them `dr` (DeviceReads assembled on the GPU), `reads`
+    (ReadStub per good read), `seq` (their strand-oriented bases, ASCII, back to back) and `seq_off`."""
+
+    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "seq_off", "records")
+
+    def __len__(self):
+        return int(self.keep.size)
+
+    def head(self, k):
+        """The first k kept records (a `num_reads` limit that ends inside a batch): the callable ones among them keep their
+        rows of `dr`, which is cut as well."""
+        if k >= len(self):
+            return self
+        out = IngestBatch()
+        out.rb, out.records, out.keep, out.err = self.rb, self.records, self.keep[:k], self.err[:k]
+        g = int(np.searchsorted(self.good, k))
+        out.good, out.reads, out.seq_off = self.good[:g], self.reads[:g], self.seq_off[: g + 1]
+        out.seq = self.seq[: int(self.seq_off[g])]
+        dr = self.dr
+        if dr is not None and g:
+            from .data_chunks import DeviceReads
+
+            so, qo = dr.sig_off[: g + 1], dr.seq_off[: g + 1]
+            out.dr = DeviceReads.from_device(dr.engine, so, qo, dr.dacs, dr.s2s, dr.iseq, dr.d_sig_off[: g + 1], dr.d_seq_off[: g + 1],
+                                             dr.shift[:g].cpu().numpy(), dr.scale[:g].cpu().numpy())
+        else:
+            out.dr = None
+        return out
+
+
+def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
+    """IngestBatch of one raw BAM batch, or None when nothing of it is kept.  Everything Read.from_pod5 + add_alignment +
+    into_remora_read (basecall-anchored, forward signal) do per read, for the batch: trimming by sp / ts / ns, strand-aware
+    sequence, move tables -> query_to_signal (one launch), sm / sd composed with the calibration, the trim to the mapped span.
+    A batch that holds something the array form does not reproduce (negative trim tags, bases outside A-Z, reads without
+    sm / sd, which need the median / MAD of their signal) is returned as the string "slow": the caller sends its records
+    through the per-read path."""
+    import torch
+
+    from .data_chunks import DeviceReads
+
+    n_all = rb.n
+    flag = rb.flag
+    keep_mask = np.ones(n_all, bool) if not skip_non_primary else (flag & 0x900) == 0
+    # the read a record's signal belongs to: the parent (pi) of a split read, else the record's name
+    names, pi = rb.names, rb.pi
+    row_of, kept = signals._row, []
+    rows = []
+    has_pi = (rb.has & 64) != 0
+    no, po = rb.name_off.tolist(), rb.pi_off.tolist()
+    for i in np.nonzero(keep_mask)[0].tolist():
+        rid = (pi[po[i] : po[i + 1]] if has_pi[i] else names[no[i] : no[i + 1]]).decode("latin-1")
+        r = row_of.get(rid)
+        if r is not None:
+            kept.append(i)
+            rows.append(r)
+    if not kept:
+        return None
+    keep = np.asarray(kept, np.int64)
+    nk = keep.size
+    has = rb.has[keep]
+    sp = np.where(has & 8, rb.sp[keep], 0).astype(np.int64)
+    ts = np.where(has & 2, rb.ts[keep], 0).astype(np.int64)
+    ns = rb.ns[keep].astype(np.int64)
+    if (sp < 0).any() or (ts < 0).any() or (((has & 4) != 0) & (ns < 0)).any() or ((has & 48) != 48).any():
+        return "slow"
+    seq_len_all = np.diff(rb.seq_off)
+    sb = np.frombuffer(rb.seq, np.uint8)
+    if sb.size and (sb.min() < 65 or sb.max() > 90):
+        return "slow"
+    # ---- signals: every distinct read of the batch decoded once, on the GPU ----
+    uniq, inv = np.unique(np.asarray(rows, np.int64), return_inverse=True)
+    first, addr, size, samples = signals.rows_of_reads(uniq)
+    flat, row_out = vbz_decode_rows(addr, size, samples, eng)
+    read_start = row_out[first[:-1]]                      # where a distinct read's samples begin in `flat`
+    read_size = row_out[first[1:]] - read_start
+    size_k, base_k = read_size[inv], read_start[inv]
+    # dacs[sp:][ts:ns] (src/remora/io.py:2003-2012), python slice semantics for non-negative bounds
+    start = np.minimum(sp, size_k)
+    rem = size_k - start
+    a = np.minimum(ts, rem)
+    b = np.where(has & 4, np.minimum(ns, rem), rem)
+    sig_len = np.maximum(b - a, 0)
+    src_start = base_k + start + a
+    # ---- move tables of the whole raw batch in one launch (tables of records that are not kept: length 0 -> ignored) ----
+    sl_all = np.zeros(n_all, np.int64)
+    sl_all[keep] = sig_len
+    dev = eng.torch_device
+    total_mv = int(rb.mv_off[n_all])
+    d_mv = torch.from_numpy(rb.mv if total_mv else np.zeros(1, np.int8)).to(dev)
+    d_off, d_sl, d_ql = (torch.from_numpy(np.ascontiguousarray(x, np.int64)).to(dev) for x in (rb.mv_off, sl_all, seq_len_all))
+    d_q2s = torch.empty(max(total_mv, 1), dtype=torch.int64, device=dev)
+    d_cnt = torch.zeros(n_all, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(n_all, dtype=torch.int32, device=dev)
+    L.check(L.lib().rmr_parse_moves_batch(eng.handle, d_mv.data_ptr(), d_off.data_ptr(), d_sl.data_ptr(), d_ql.data_ptr(), n_all, 1, 0,
+                                          d_q2s.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), L.MEM_DEVICE))
+    eng.synchronize()
+    status = d_st.cpu().numpy()[keep]
+    # ---- who can be called, and why not (the texts of add_alignment / into_remora_read, in their order) ----
+    is_rev = (flag[keep] & 16) != 0
+    err = [None] * nk
+    mv_len = np.diff(rb.mv_off)[keep]
+    for k in range(nk):
+        if rb.ref_id[keep[k]] < 0 and is_rev[k]:
+            err[k] = "Unmapped reads cannot map to reverse strand."
+        elif not (has[k] & 1):
+            err[k] = "Read prep error: Missing query_to_signal (move table)"
+        elif status[k] != 0:
+            err[k] = _MOVE_ERRORS.get(int(status[k]), "empty move tag" if mv_len[k] < 1 else f"move table stride {int(rb.mv[rb.mv_off[keep[k]]])}")
+    good = np.asarray([k for k in range(nk) if err[k] is None], np.int64)
+    out = IngestBatch()
+    out.rb, out.records, out.keep, out.err, out.good = rb, records, keep, err, good
+    out.dr, out.reads, out.seq, out.seq_off = None, [], b"", np.zeros(1, np.int64)
+    if not good.size:
+        return out
+    gk = keep[good]
+    # ---- strand-aware bases (seq = revcomp(query_sequence) for reverse-strand records, :2023) ----
+    so = rb.seq_off.tolist()
+    pieces = [rb.seq[so[i] : so[i + 1]].translate(_COMP_BYTES)[::-1] if r else rb.seq[so[i] : so[i + 1]]
+              for i, r in zip(gk.tolist(), is_rev[good].tolist())]
+    out.seq = b"".join(pieces)
+    seq_len = seq_len_all[gk].astype(np.int64)
+    out.seq_off = np.zeros(good.size + 1, np.int64)
+    np.cumsum(seq_len, out=out.seq_off[1:])
+    from .util import _SEQ_LUT
+
+    iseq = np.take(_SEQ_LUT, np.frombuffer(out.seq, np.uint8)).astype(np.int8)
+    # ---- scaling: sm / sd composed with the calibration (:2036-2041, :2147-2153), float64 as on the per-read path ----
+    cal_off, cal_scale = signals._cal_off[uniq][inv][good].astype(np.float64), signals._cal_scale[uniq][inv][good].astype(np.float64)
+    if pa_scaling is None:
+        sm, sd = rb.sm[gk].astype(np.float64), rb.sd[gk].astype(np.float64)
+    else:
+        sm, sd = np.full(good.size, float(pa_scaling[0])), np.full(good.size, float(pa_scaling[1]))
+    shift, scale = cal_off + cal_scale * sm, cal_scale * sd
+    # ---- dacs = trimmed[q2s[0]:q2s[-1]], mapping re-based: assembled where the pieces already are ----
+    n_good = int(good.size)
+    n_seq = int(out.seq_off[-1])
+    dacs = torch.empty(max(int(sig_len[good].sum()), 1), dtype=torch.int16, device=dev)
+    s2s = torch.empty(n_seq + n_good, dtype=torch.int64, device=dev)
+    d_sig_off = torch.empty(n_good + 1, dtype=torch.int64, device=dev)
+    d_seq_off = torch.empty(n_good + 1, dtype=torch.int64, device=dev)
+    sig_off = np.zeros(n_good + 1, np.int64)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    ss, qo = np.ascontiguousarray(src_start[good], np.int64), np.ascontiguousarray(rb.mv_off[gk], np.int64)
+    L.check(L.lib().rmr_assemble_reads(eng.handle, n_good, flat.data_ptr(), p(ss), d_q2s.data_ptr(), p(qo), p(seq_len), dacs.data_ptr(),
+                                       dacs.numel(), s2s.data_ptr(), d_sig_off.data_ptr(), d_seq_off.data_ptr(), p(sig_off)))
+    d_iseq = torch.from_numpy(iseq).to(dev)
+    eng.synchronize()
+    from .engine import get_prep_engine
+
+    # the batch is used on the extraction engine (own stream, own mutex): not behind the ingest of the next batches
+    out.dr = DeviceReads.from_device(get_prep_engine(eng.device), sig_off, out.seq_off, dacs, s2s, d_iseq, d_sig_off, d_seq_off, shift, scale)
+    out.reads = [ReadStub(sh, sc) for sh, sc in zip(shift.tolist(), scale.tolist())]
+    return out
+
+
+def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=True, batch=256, shard=None, device=None):
+    """The batch form of iter_reads_from_pod5_and_bam for basecall-anchored calling of forward signal: IngestBatch objects
+    (arrays on the GPU) instead of (io.Read, error) pairs; a batch the array form does not cover comes as the list of
+    (io.Read, error) pairs the per-read path yields for its records."""
+    from .engine import get_ingest_engine
+
+    signals = Pod5File(pod5_path)
+    eng = get_ingest_engine(device)
+    for rb, records in iter_bam_raw_batches(bam_path, want_ref=False, batch=batch, shard=shard):
+        got = _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary)
+        if got is None:
+            continue
+        if isinstance(got, str):  # "slow": the per-read path for the records of this batch
+            yield list(_reads_of_records(records(rb), signals, eng, False, pa_scaling, skip_non_primary, max(batch, 2), False))
+            continue
+        yield got
 
 
 # ---- BAM output (SURVEY §8f row N3): the reference writes `pysam.AlignedSegment.from_dict(
@@ -1371,10 +1733,31 @@ def records_with_mod_tags_batch(records, mm, mm_off, ml, ml_off, has_tags):
     return out[: out_len.value].tobytes()
 
 
+def records_with_mod_tags_flat(raw, raw_start, raw_len, tags_off, mm, mm_off, ml, ml_off, has_tags):
+    """records_with_mod_tags_batch for records that lie in ONE bytes object (a RawBamBatch's `raw`): record r is
+    raw[raw_start[r] : raw_start[r] + raw_len[r]], its tags begin tags_off[r] bytes into it."""
+    n = int(np.asarray(raw_len).size)
+    base = ctypes.cast(ctypes.c_char_p(raw), ctypes.c_void_p).value or 0
+    ptrs = np.uint64(base) + np.ascontiguousarray(raw_start, np.int64).astype(np.uint64)
+    raw_len, tags_off = np.ascontiguousarray(raw_len, np.int64), np.ascontiguousarray(tags_off, np.int64)
+    has = np.ascontiguousarray(has_tags, np.uint8)
+    mm_off, ml_off = np.ascontiguousarray(mm_off, np.int64), np.ascontiguousarray(ml_off, np.int64)
+    out = np.empty(int(raw_len.sum()) + 16 * n + int(mm_off[-1]) + int(ml_off[-1]) + 16, np.uint8)
+    out_len = ctypes.c_int64()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.check(L.lib().rmr_records_with_mod_tags(n, p(ptrs), p(raw_len), p(tags_off), p(mm), p(mm_off), p(ml), p(ml_off), p(has), p(out),
+                                              out.size, ctypes.byref(out_len)))
+    return out[: out_len.value].tobytes()
+
+
 _BGZF_LEVEL = int(os.environ.get("RMR_BAM_LEVEL", "6"))  # htslib's default level
 # RMR_BAM_STRATEGY = huffman | rle: zlib's Z_HUFFMAN_ONLY / Z_RLE - 1.9x / 1.4x the speed of level 1 on BAM records with
 # move tables for a 19 % / 15 % larger file (still plain deflate: any reader takes it)
-_BGZF_STRATEGY = {"huffman": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE}.get(os.environ.get("RMR_BAM_STRATEGY", ""), zlib.Z_DEFAULT_STRATEGY)
+# Level 1 (`--bam-level 1`: "fast") takes Huffman-only unless RMR_BAM_STRATEGY says otherwise (default = zlib's own matcher):
+# 28.1 k -> 33.2 k reads/s file to file with six processes on 16 cores, 3.3 -> 3.9 GB of output
+# (profiles/r03_infer_cli_336k_byte_shares_huffman.log)
+_BGZF_STRATEGIES = {"huffman": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE, "default": zlib.Z_DEFAULT_STRATEGY}
+_BGZF_STRATEGY = _BGZF_STRATEGIES.get(os.environ.get("RMR_BAM_STRATEGY", ""))  # None: by level
 
 
 def _eff_cpus():
@@ -1385,7 +1768,9 @@ def _eff_cpus():
 
 def _bgzf_block(chunk, level=None):
     """One BGZF member (gzip with the BC extra field) for up to 64 KiB of payload."""
-    comp = zlib.compressobj(_BGZF_LEVEL if level is None else int(level), zlib.DEFLATED, -15, 9, _BGZF_STRATEGY)
+    level = _BGZF_LEVEL if level is None else int(level)
+    strategy = _BGZF_STRATEGY if _BGZF_STRATEGY is not None else (zlib.Z_HUFFMAN_ONLY if level == 1 else zlib.Z_DEFAULT_STRATEGY)
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
     cdata = comp.compress(chunk) + comp.flush()
     return b"".join((b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00", struct.pack("<H", len(cdata) + 25),
                      cdata, struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))))

@@ -1,0 +1,149 @@
+"""The batch ingest of `infer from_pod5_and_bam` (io.iter_ingest_batches: a whole BAM batch trimmed, mapped, scaled and laid
+out as read arrays on the GPU - rmr_assemble_reads - with no Python object per read) against the per-read path it replaces
+(io.Read.from_pod5 + add_alignment + into_remora_read, src/remora/io.py:1972-2177, which is pinned on reference-generated
+goldens): the same arrays bit for bit, the same reasons for the reads that cannot be called, the same output file."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+
+
+def _golden(name):
+    return np.load(os.path.join(HERE, "golden", name), allow_pickle=False)
+
+
+def _patch_tag(rec, name, value=None):
+    """Record bytes with tag `name` removed (value None) or its integer value replaced."""
+    raw = bytearray(rec.raw)
+    for tname, s, e in rec.tag_spans:
+        if tname != name:
+            continue
+        s, e = rec.tags_offset + s, rec.tags_offset + e
+        if value is None:
+            del raw[s:e]
+        else:
+            typ = chr(raw[s + 2])
+            fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[typ]
+            raw[s + 3 : e] = struct.pack(fmt, value)
+        return bytes(raw)
+    raise KeyError(name)
+
+
+def _dirty_bam(path, prefix):
+    """The reference's test alignments plus records of every kind the ingest has to turn away, in between them."""
+    from remora_amd import io as rio
+
+    src = os.path.join(DATA, f"{prefix}_mappings.bam")
+    recs = list(rio.iter_bam_records(src))
+    out = []
+    for k, r in enumerate(recs):
+        raw = bytes(r.raw)
+        if k == 1:  # a secondary alignment: skipped
+            raw = raw[:14] + struct.pack("<H", r.flag | 0x100) + raw[16:]
+        elif k == 3:  # unmapped and reverse: "Unmapped reads cannot map to reverse strand."
+            raw = struct.pack("<i", -1) + raw[4:14] + struct.pack("<H", r.flag | 16 | 4) + raw[16:]
+        elif k == 5:  # no move table
+            raw = _patch_tag(r, "mv")
+        elif k == 7:  # a read the POD5 file does not hold: skipped
+            name = b"0" * (raw[8] - 1)
+            raw = raw[:32] + name + raw[32 + len(name) :]
+        elif k == 9:  # a trim that leaves too little signal for the move table
+            raw = _patch_tag(r, "ts", 100)  # (ts is a one-byte tag here)
+        out.append(raw)
+        if k == 4:  # the same read twice in one batch (one decode, two alignments)
+            out.append(bytes(r.raw))
+    with rio.BamWriter(path, rio.read_bam_header_bytes(src)) as w:
+        for raw in out:
+            w.write(struct.pack("<i", len(raw)) + raw)
+    return len(out)
+
+
+@pytest.mark.parametrize("prefix", ["can", "mod"])
+def test_ingest_batches_equal_the_per_read_path(prefix, tmp_path):
+    import torch
+
+    from remora_amd import io as rio
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    pod5 = os.path.join(DATA, f"{prefix}_reads.pod5")
+    bam = str(tmp_path / "dirty.bam")
+    n_rec = _dirty_bam(bam, prefix)
+    for pa_scaling in (None, (87.5, 14.25)):
+        slow = list(rio.iter_reads_from_pod5_and_bam(pod5, bam, pa_scaling=pa_scaling, parse_ref_align=False, decode_batch=4))
+        want, want_err = [], []
+        for read, err in slow:
+            if err is None:
+                try:
+                    want.append(read.into_remora_read(False))
+                    want_err.append(None)
+                    continue
+                except rio.RemoraError as e:
+                    err = f"Read prep error: {e}"
+            want_err.append(err)
+        assert len(slow) == n_rec - 2 and sum(e is not None for e in want_err) == 3
+        got_err, k = [], 0
+        for ib in rio.iter_ingest_batches(pod5, bam, pa_scaling=pa_scaling, batch=4):
+            assert isinstance(ib, rio.IngestBatch)
+            got_err.extend(ib.err)
+            if not ib.good.size:
+                continue
+            dr = ib.dr
+            dacs, s2s, iseq = dr.dacs.cpu().numpy(), dr.s2s.cpu().numpy(), dr.iseq.cpu().numpy()
+            shift, scale = dr.shift.cpu().numpy(), dr.scale.cpu().numpy()
+            assert np.array_equal(dr.d_sig_off.cpu().numpy(), dr.sig_off) and np.array_equal(dr.d_seq_off.cpu().numpy(), dr.seq_off)
+            for g in range(ib.good.size):
+                rr = want[k]
+                k += 1
+                assert np.array_equal(dacs[dr.sig_off[g] : dr.sig_off[g + 1]], rr.dacs)
+                assert np.array_equal(s2s[dr.seq_off[g] + g : dr.seq_off[g + 1] + g + 1], rr.seq_to_sig_map)
+                assert np.array_equal(iseq[dr.seq_off[g] : dr.seq_off[g + 1]], rr.int_seq)
+                assert shift[g] == rr.shift and scale[g] == rr.scale  # the same float64 operations: equal, not close
+                assert ib.seq[ib.seq_off[g] : ib.seq_off[g + 1]].decode() == rr.str_seq
+                assert ib.reads[g].shift == rr.shift and ib.reads[g].scale == rr.scale
+        assert k == len(want) and got_err == want_err
+
+
+@pytest.mark.parametrize("prefix", ["can", "mod"])
+def test_infer_output_is_the_same_file_with_and_without_the_batch_ingest(prefix, tmp_path, monkeypatch):
+    import torch
+
+    from oracle import oracle as O
+    from remora_amd import io as rio
+    from remora_amd.inference import infer_from_pod5_and_bam
+    from remora_amd.model_util import load_model
+    from test_gpu_parity import _mint_pt, _real_reads_golden
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    model, md = load_model(_mint_pt(tmp_path, _real_reads_golden(prefix), O), device=0)
+    pod5 = os.path.join(DATA, f"{prefix}_reads.pod5")
+    dirty = str(tmp_path / "dirty.bam")
+    _dirty_bam(dirty, prefix)
+    for bam, n_ok in ((os.path.join(DATA, f"{prefix}_mappings.bam"), 14), (dirty, None)):
+        outs, stats, counts = [], [], []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
+            out = str(tmp_path / f"o{mode}.bam")
+            lc = {}
+            stats.append(infer_from_pod5_and_bam(pod5, bam, model, md, out, reads_per_batch=5, label_counts_out=lc))
+            outs.append(open(out, "rb").read())
+            counts.append({k: v.tolist() for k, v in lc.items()})
+        assert outs[0] == outs[1] and stats[0] == stats[1] and counts[0] == counts[1]
+        if n_ok is not None:
+            assert stats[0][None] == n_ok
+        else:  # the turned-away records are in the output, untouched, at their place
+            assert stats[0]["Unmapped reads cannot map to reverse strand."] == 1
+            assert stats[0]["Read prep error: Missing query_to_signal (move table)"] == 1
+            assert stats[0]["Move table discordant with signal"] == 1
+            names_in = [r.query_name for r in rio.iter_bam_records(bam) if not r.is_secondary and r.query_name != "0" * 36]
+            assert [r.query_name for r in rio.iter_bam_records(str(tmp_path / "o1.bam"))] == names_in
+        # a limit that ends inside a batch
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
+            infer_from_pod5_and_bam(pod5, bam, model, md, str(tmp_path / f"l{mode}.bam"), reads_per_batch=5, num_reads=7)
+        assert open(tmp_path / "l1.bam", "rb").read() == open(tmp_path / "l0.bam", "rb").read()
