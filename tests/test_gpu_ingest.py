@@ -147,3 +147,30 @@ def test_infer_output_is_the_same_file_with_and_without_the_batch_ingest(prefix,
             monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
             infer_from_pod5_and_bam(pod5, bam, model, md, str(tmp_path / f"l{mode}.bam"), reads_per_batch=5, num_reads=7)
         assert open(tmp_path / "l1.bam", "rb").read() == open(tmp_path / "l0.bam", "rb").read()
+
+
+@pytest.mark.parametrize("scale_iters", [-1, 0])
+def test_batch_ingest_with_a_signal_mapping_refiner(scale_iters, tmp_path, monkeypatch):
+    """Models with a k-mer level table re-scale (and with scale_iters 0 re-map) every read before the extraction: the
+    refiner's device passes work on the assembled batch as they do on an uploaded one - same output file either way."""
+    import torch
+
+    from oracle import oracle as O
+    from remora_amd.inference import infer_from_pod5_and_bam
+    from remora_amd.model_util import load_model
+    from remora_amd.refine_signal_map import SigMapRefiner
+    from test_gpu_parity import _mint_pt, _real_reads_golden
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    model, md = load_model(_mint_pt(tmp_path, _real_reads_golden("can"), O), device=0)
+    md = dict(md, sig_map_refiner=SigMapRefiner(kmer_model_filename=os.path.join(DATA, "levels_4mer.txt"), do_rough_rescale=True,
+                                                scale_iters=scale_iters, do_fix_guage=True))
+    assert md["sig_map_refiner"].is_loaded
+    pod5, bam = os.path.join(DATA, "can_reads.pod5"), os.path.join(DATA, "can_mappings.bam")
+    outs, stats = [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
+        out = str(tmp_path / f"r{mode}.bam")
+        stats.append(infer_from_pod5_and_bam(pod5, bam, model, md, out, reads_per_batch=5))
+        outs.append(open(out, "rb").read())
+    assert stats[0] == stats[1] and stats[0][None] == 14 and outs[0] == outs[1]
