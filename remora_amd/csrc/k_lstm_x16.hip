@@ -15,6 +15,8 @@
 // W_hh h_{t-1} (4 MFMAs) sits on the recurrent critical path.  x_{t+2} is fetched from HBM while step t runs.
 // Gate rows of W and b are pre-scaled on the host (i,f,o by -log2 e, g by 2 log2 e): sigmoid(a) = 1/(1+2^a'),
 // tanh(a) = 1 - 2/(1+2^a').  bf16 operands, fp32 accumulation, fp32 cell state.
+#include <type_traits>
+
 #include "rmr_internal.h"
 #include "rmr_math.h"
 
@@ -134,7 +136,10 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
         // there.  Without this barrier a wave held up for longer than one step (other processes' waves on its SIMD) projected
         // x_2 for x_0 in eight chunks: the runs that differed when several processes shared the GPU (profiles/NOTES_r04.md)
         __syncthreads();
-        for (int t = 0; t < a.T; ++t) {
+        // one time step; LAST (the step whose h feeds lstm2 through a swish, models/ConvLSTM_w_ref.py:52) is a compile-time
+        // flag: as a run-time test hipcc turned it into selects and every step paid the swish's two exp + two rcp
+        auto step = [&](const int t, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;  // x_{t+2} (the last two fetches are redundant re-reads)
             uint4 xnext = make_uint4(0, 0, 0, 0);
             if (stager) xnext = xsrc[(size_t)tf * 8];
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
             }
             const f32x2 hh = lstm_cell2(acc[0], acc[1], c[0], c[1]);
             float h0 = hh.x, h1 = hh.y;
-            if (t + 1 == a.T) {  // lstm2 consumes swish(h1[T-1]) (models/ConvLSTM_w_ref.py:52)
+            if constexpr (LAST) {  // lstm2 consumes swish(h1[T-1])
                 h0 = swish_f(h0);
                 h1 = swish_f(h1);
             }
@@ -166,7 +171,9 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
             reinterpret_cast<unsigned *>(&hs[t & 1][h_plane][nn][h_slot])[q] = hp;
             if (stager) xs[t & 1][st_c8 & 3][st_row][st_c8 >> 2] = xnext;  // the buffer whose last reader was step t-1
             __syncthreads();
-        }
+        };
+        for (int t = 0; t + 1 < a.T; ++t) step(t, std::false_type{});
+        step(a.T - 1, std::true_type{});
         // ---- lstm2: one step on swish(h1[T-1]) with zero state (the f gate meets c0 = 0) ----
         f32x4 acc2[2];
         {
@@ -205,6 +212,150 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
     }
 }
 
+// Two 16-chunk groups per block iteration (round 4, the default; RMR_LSTMX_GROUPS=1 selects the kernel above): a wave issues
+// the MFMAs of both groups before the gate math of the first, so the matrix pipe works on group B while the VALU works on
+// group A, every dependent chain (LDS read -> MFMA -> gates -> LDS write) has an independent twin to fill its bubbles, and a
+// block barrier is paid once per two groups.  Per chunk the same operations in the same order: bit-identical logits.
+// 128 VGPRs (two spilled), still four waves per SIMD.
+template <bool F16>
+__global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
+    __shared__ uint4 xs[2][2][4][16][3];  // [buffer][group][plane][chunk row][slot]
+    __shared__ uint4 hs[2][2][4][16][3];
+    __shared__ float part[2][8][16][16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+
+    uint4 Aih[2][2], Ahh[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Aih[t][ks] = a.a_ih[((w * 2 + t) * 2 + ks) * 64 + lane];
+            Ahh[t][ks] = a.a_hh[((w * 2 + t) * 2 + ks) * 64 + lane];
+        }
+    f32x4 bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4 *>(a.b1 + ((w * 2 + t) * 4 + q) * 4);
+
+    // x staging: threads 0..255, 128 per group (waves 0,1 -> group 0; waves 2,3 -> group 1)
+    const bool stager = tid < 256;
+    const int sg = (tid >> 7) & 1, st = tid & 127, st_row = st >> 3, st_c8 = st & 7;
+    const int h_plane = w & 3, h_slot = w >> 2;
+
+    const int64_t n_pairs = (a.n + 31) / 32;
+    for (int64_t pr = blockIdx.x; pr < n_pairs; pr += gridDim.x) {
+        const int64_t chunk0 = pr * 32;
+        int64_t st_chunk = chunk0 + sg * 16 + st_row;
+        if (st_chunk >= a.n) st_chunk = a.n - 1;
+        const uint4 *xsrc = reinterpret_cast<const uint4 *>(a.x + (size_t)st_chunk * a.T * 64) + st_c8;
+        __syncthreads();
+        if (stager) {
+            xs[0][sg][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[0];
+            xs[1][sg][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[(size_t)(a.T > 1 ? 1 : 0) * 8];
+        }
+        __syncthreads();
+
+        float c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        f32x4 accN[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                accN[g][t] = bias[t];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) accN[g][t] = mfma16<F16>(Aih[t][ks], xs[0][g][q][nn][ks], accN[g][t]);
+            }
+        __syncthreads();  // x_0 read by every wave before step 0 overwrites its tile
+        auto step = [&](const int t, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
+            const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
+            uint4 xnext = make_uint4(0, 0, 0, 0);
+            if (stager) xnext = xsrc[(size_t)tf * 8];
+            f32x4 acc[2][2];
+            uint4 bx[2][2], bh[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                bx[g][0] = xs[(t + 1) & 1][g][q][nn][0];
+                bx[g][1] = xs[(t + 1) & 1][g][q][nn][1];
+                if (t > 0) {
+                    bh[g][0] = hs[(t - 1) & 1][g][q][nn][0];
+                    bh[g][1] = hs[(t - 1) & 1][g][q][nn][1];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[g][u] = accN[g][u];
+                    if (t > 0) {
+                        acc[g][u] = mfma16<F16>(Ahh[u][0], bh[g][0], acc[g][u]);
+                        acc[g][u] = mfma16<F16>(Ahh[u][1], bh[g][1], acc[g][u]);
+                    }
+                }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    accN[g][u] = mfma16<F16>(Aih[u][0], bx[g][0], bias[u]);
+                    accN[g][u] = mfma16<F16>(Aih[u][1], bx[g][1], accN[g][u]);
+                }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x2 hh = lstm_cell2(acc[g][0], acc[g][1], c[g][0], c[g][1]);
+                float h0 = hh.x, h1 = hh.y;
+                if constexpr (LAST) {
+                    h0 = swish_f(h0);
+                    h1 = swish_f(h1);
+                }
+                unsigned hp;
+                if constexpr (F16) hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)h0, (_Float16)h1});
+                else hp = __builtin_bit_cast(unsigned, bf16x2{(__bf16)h0, (__bf16)h1});
+                reinterpret_cast<unsigned *>(&hs[t & 1][g][h_plane][nn][h_slot])[q] = hp;
+            }
+            if (stager) xs[t & 1][sg][st_c8 & 3][st_row][st_c8 >> 2] = xnext;
+            __syncthreads();
+        };
+        for (int t = 0; t + 1 < a.T; ++t) step(t, std::false_type{});
+        step(a.T - 1, std::true_type{});
+        // ---- lstm2 (one step) + fc, per group ----
+        const int u0 = 8 * w + 2 * q;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 acc2[2];
+            const uint4 bh0 = hs[(a.T - 1) & 1][g][q][nn][0], bh1 = hs[(a.T - 1) & 1][g][q][nn][1];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc2[u] = *reinterpret_cast<const f32x4 *>(a.b2 + ((w * 2 + u) * 4 + q) * 4);
+                acc2[u] = mfma16<F16>(a.a_ih2[((w * 2 + u) * 2 + 0) * 64 + lane], bh0, acc2[u]);
+                acc2[u] = mfma16<F16>(a.a_ih2[((w * 2 + u) * 2 + 1) * 64 + lane], bh1, acc2[u]);
+            }
+            float y[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float c2 = 0.f;
+                y[u] = swish_f(lstm_cell(acc2[u], c2));
+            }
+            for (int o = 0; o < a.num_out; ++o) {
+                float p = a.w_fc[(size_t)o * 64 + u0] * y[0] + a.w_fc[(size_t)o * 64 + u0 + 1] * y[1];
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                if (q == 0) part[g][w][nn][o] = p;
+            }
+        }
+        __syncthreads();
+        if (tid < 32 * a.num_out) {
+            const int g = tid / (16 * a.num_out), r = tid - g * 16 * a.num_out;
+            const int ch = r / a.num_out, o = r - ch * a.num_out;
+            if (chunk0 + g * 16 + ch < a.n) {
+                float s = a.b_fc[o];
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) s += part[g][ww][ch][o];
+                a.logits[(size_t)(chunk0 + g * 16 + ch) * a.num_out + o] = s;
+            }
+        }
+    }
+}
+
 int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logits) {
     rmr_engine *e = m->eng;
     if (m->desc.size != 64 || m->nparts != 1 || !m->lstm.x_ih) RMR_FAIL(RMR_ERR_INVALID, "bf16-activation LSTM: size 64, plain bf16 only");
@@ -218,6 +369,15 @@ int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logi
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTMX_BLOCKS_PER_CU", 4);
     if (grid > groups) grid = groups;
     ProfScope ps(e, K_LSTM_HEAD);
+    if (tune_int("RMR_LSTMX_GROUPS", 2) == 2) {  // (1 = the one-group kernel: 2.38 against 2.22 ns per chunk at C100, 5.58 against 4.84 at C200)
+        const int64_t pairs = (n + 31) / 32;
+        int64_t grid2 = (int64_t)e->num_cus * tune_int("RMR_LSTMX_BLOCKS_PER_CU", 4);
+        if (grid2 > pairs) grid2 = pairs;
+        if (m->f16) hipLaunchKernelGGL(lstm_x16_g2_kernel<true>, dim3((unsigned)grid2), dim3(512), 0, e->stream, a);
+        else hipLaunchKernelGGL(lstm_x16_g2_kernel<false>, dim3((unsigned)grid2), dim3(512), 0, e->stream, a);
+        RMR_HIP(hipGetLastError());
+        return 0;
+    }
     if (m->f16) hipLaunchKernelGGL(lstm_x16_kernel<true>, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
     else hipLaunchKernelGGL(lstm_x16_kernel<false>, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
