@@ -543,7 +543,7 @@ def _records_of(rb, lib, h, refs):
         if h_i & 64:
             hot["pi"] = pi[pi_off[i] : pi_off[i + 1]]
         rid = ref_id[i]
-        if rid >= 0 and rid not in refs:
+        if rid >= 0 and rid not in refs and lib is not None:
             nm = lib.rmr_bam_ref_name(h, rid)
             refs[rid] = nm.decode() if nm is not None else None
         yield _NativeBamRecord(names[name_off[i] : name_off[i + 1]], flag[i], rid, refs.get(rid) if rid >= 0 else None,
@@ -757,16 +757,25 @@ def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None):
     h = ctypes.c_void_p()
     L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
     refs = {}
-    records = lambda rb: list(_records_of(rb, lib, h, refs))  # noqa: E731
+
+    def named(rb):  # reference names are looked up while the file is open: `records` stays usable after the iteration ends
+        for rid in np.unique(rb.ref_id).tolist():
+            if rid >= 0 and rid not in refs:
+                nm = lib.rmr_bam_ref_name(h, rid)
+                refs[rid] = nm.decode() if nm is not None else None
+        return rb
+
+    records = lambda rb: list(_records_of(rb, None, None, refs))  # noqa: E731
     try:
         if start is not None:
             L.check(lib.rmr_bam_seek(h, int(start)))
         if end is None:
             for rb in _native_raw_batches(lib, h, want_ref, batch, limit=count):
-                yield rb, records
+                yield named(rb), records
             return
         end = int(end)
         for rb in _native_raw_batches(lib, h, want_ref, batch):
+            named(rb)
             past = np.nonzero(rb.voffset >= end)[0]
             if past.size:
                 k = int(past[0])

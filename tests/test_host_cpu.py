@@ -1730,6 +1730,83 @@ def test_bam_byte_shares_partition_the_records_and_verify_their_ends(tmp_path):
         list(rio._iter_bam_records_native(big, False, 64, start_voffset=vos[0], end_voffset=(size + 5) << 16))
 
 
+def test_raw_bam_batches_are_the_records_of_iter_bam_records(tmp_path, monkeypatch):
+    """io.iter_bam_raw_batches (flat arrays per native batch: what the batch ingest of `infer` runs on) hands out exactly
+    the records iter_bam_records does - whole file, shares by byte range and by record count, any batch size - and a share
+    whose end mark is not a record start is refused the same way; RawBamBatch.head cuts a batch without copying its blobs."""
+    import struct
+
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    big = str(tmp_path / "big.bam")
+    recs = list(rio.iter_bam_records(os.path.join(DATA, "can_mappings.bam"))) + list(rio.iter_bam_records(os.path.join(DATA, "mod_mappings.bam")))
+    with rio.BamWriter(big, rio.read_bam_header_bytes(os.path.join(DATA, "can_mappings.bam")), level=1) as w:
+        for _ in range(6):
+            for r in recs:
+                raw = bytes(r.raw)
+                w.write(struct.pack("<i", len(raw)) + raw)
+
+    def key(r):
+        return (r.query_name, r.flag, r.voffset, bytes(r.raw), r.tags_offset, r.query_sequence, tuple(sorted((k, np.asarray(v).tobytes() if k == "mv" else v)
+                                                                                                            for k, v in r.hot_tags().items())))
+
+    def from_raw(path, batch, shard=None):
+        out = []
+        for rb, records in rio.iter_bam_raw_batches(path, batch=batch, shard=shard):
+            assert rb.n == rb.flag.size == rb.voffset.size == rb.raw_off.size - 1 and int(rb.raw_off[-1]) <= len(rb.raw)
+            got = records(rb)
+            assert len(got) == rb.n
+            # the flat arrays say what the record objects say
+            for i, r in enumerate(got):
+                assert rb.raw[rb.raw_off[i] : rb.raw_off[i + 1]] == bytes(r.raw) and rb.seq[rb.seq_off[i] : rb.seq_off[i + 1]].decode() == r.query_sequence
+                assert int(rb.tags_off[i]) == r.tags_offset and int(rb.flag[i]) == r.flag
+                assert np.array_equal(rb.mv[rb.mv_off[i] : rb.mv_off[i + 1]], r.hot_tags().get("mv", np.zeros(0, np.int8)))
+            out += [key(r) for r in got]
+        return out
+
+    whole = [key(r) for r in rio.iter_bam_records(big)]
+    for batch in (1, 7, 64, 512):
+        assert from_raw(big, batch) == whole
+    for mode in ("bytes", "scan"):
+        monkeypatch.setenv("REMORA_AMD_BAM_SHARD", mode)
+        for world in (2, 3, 5):
+            parts = [from_raw(big, 16, shard=(rank, world)) for rank in range(world)]
+            assert [k for p in parts for k in p] == whole, (mode, world)
+            assert parts == [[key(r) for r in rio.iter_bam_records(big, shard=(rank, world))] for rank in range(world)]
+    monkeypatch.delenv("REMORA_AMD_BAM_SHARD")
+    rb, records = next(iter(rio.iter_bam_raw_batches(big, batch=9)))
+    cut = rb.head(4)
+    assert cut.n == 4 and cut.raw is rb.raw and cut.raw_off.size == 5 and [key(r) for r in records(cut)] == whole[:4]
+
+    class Share:  # a byte-range share whose end is one byte behind a record start
+        def result(self):
+            return ("bytes", whole[0][2], whole[20][2] + 1)
+
+    with pytest.raises(RemoraError, match="guessed wrong"):
+        list(rio.iter_bam_raw_batches(big, batch=8, shard=Share()))
+
+
+def test_pod5_rows_located_by_array_arithmetic():
+    """Pod5File.rows_of_reads (addresses into the mapped Arrow buffers, no bytes object per row) names the same bytes and
+    sample counts as the per-cell access of signal_rows, for any order and repetition of reads."""
+    import ctypes
+
+    from remora_amd import io as rio
+
+    for name in ("can", "mod"):
+        f = rio.Pod5File(os.path.join(DATA, f"{name}_reads.pod5"))
+        order = list(range(len(f.read_ids))) + [3, 3, 0]
+        first, addr, size, samples = f.rows_of_reads([f._row[f.read_ids[k]] for k in order])
+        assert first[0] == 0 and first.size == len(order) + 1
+        for j, k in enumerate(order):
+            want = f.signal_rows(f.read_ids[k])
+            got = [(ctypes.string_at(int(addr[i]), int(size[i])), int(samples[i])) for i in range(first[j], first[j + 1])]
+            assert got == [(bytes(b), int(n)) for b, n in want]
+        e = f.rows_of_reads([])
+        assert e[0].tolist() == [0] and all(x.size == 0 for x in e[1:])
+
+
 def test_bam_shard_partitions_the_records_in_order(monkeypatch):
     """io.bam_shard (rmr_bam_scan + rmr_bam_seek): for any number of workers and any mark spacing the workers' shares are
     contiguous, in rank order, and together exactly the records of the file; shares differ by less than one mark spacing
