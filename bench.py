@@ -54,6 +54,7 @@ OTHER_CONFIGS = [
     ("convlstm_c200_f16", "convlstm_c200_bf16", "f16", None),
     ("convlstm_c100_bf16x6", "convlstm_c100", "bf16x6", None),
     ("convlstm_c100_bf16x3", "convlstm_c100", "bf16x3", None),
+    ("convlstm_c100_f16x3", "convlstm_c100", "f16x3", None),
 ]
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0
@@ -447,7 +448,7 @@ class Job:
         achieved = flops[dom] * cpl / (kern[dom]["avg_ms"] * 1e-3) / 1e12
         # fp32 MFMA: 157.3 TF.  bf16 MFMA with split operands executes NPROD bf16 products per algorithmic MAC, so the
         # matrix-pipe ceiling for algorithmic flops is 2.5 PF / NPROD
-        nprod = {"fp32": None, "bf16": 1, "f16": 1, "bf16x3": 3, "bf16x6": 6}[self.dtype]
+        nprod = {"fp32": None, "bf16": 1, "f16": 1, "bf16x3": 3, "f16x3": 3, "bf16x6": 6}[self.dtype]
         peak = PEAK_FP32_MFMA_TFLOPS if nprod is None else PEAK_BF16_MFMA_TFLOPS / nprod
         traffic, tsrc = None, None
         ent = ((traffic_table or {}).get(f"{self.workload}:{self.dtype}") or (traffic_table or {}).get(self.dtype) or {}).get(dom)
@@ -677,7 +678,7 @@ def main():
                     help="'all' = the default headline plus every other BASELINE config (what a plain 1-GPU run does anyway)")
     ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU per step (weak) / in total (strong); 0 = the workload's")
     ap.add_argument("--subbatch", type=int, default=0)
-    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16x6", "bf16x3", "bf16", "f16"],
+    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16x6", "bf16x3", "f16x3", "bf16", "f16"],
                     help="GEMM arithmetic (default: the workload's): fp32 MFMA or bf16 MFMA with 1 / 2 / 3-part operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the standalone encode-kernel roofline leg")

@@ -86,7 +86,9 @@ typedef struct {
     int32_t dtype;      /* 0 = fp32 MFMA (exact fp32); bf16 MFMA with fp32 accumulate and split operands:
                            1 = bf16, 2 = bf16x3 (2-part split, ~2^-16), 3 = bf16x6 (3-part split, fp32 class);
                            4 = f16: IEEE-half operands, fp32 accumulate, on the fused kernels (conv_lstm, size 64,
-                           k-mer length 9 or 6; rmr_infer_chunks only) - the 16-bit pipeline with 10 mantissa bits */
+                           k-mer length 9 or 6; rmr_infer_chunks only) - the 16-bit pipeline with 10 mantissa bits;
+                           5 = f16x3: operands split into two IEEE-half parts, three products (hi hi, hi lo, lo hi) on the
+                           half MFMA, fp32 accumulate - 22 significand bits (fp32 class) at bf16x3's cost */
 } rmr_model_desc;
 
 /* `weights`: host fp32 blob, the torch state_dict tensors flattened in forward order —

@@ -585,7 +585,17 @@ static inline uint32_t to_op16(float v, bool f16) {
     memcpy(&hb, &h, 2);
     return (uint32_t)hb << 16;
 }
-static void split_parts_host(float x, int np, uint32_t *p) {
+static void split_parts_host(float x, int np, uint32_t *p, bool f16 = false) {
+    if (f16) {  // dtype f16x3: hi = half(x), lo = half(x - hi) (split_parts<2, true> in k_lstm_bf16s.hip)
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        uint16_t hb, lb;
+        memcpy(&hb, &hi, 2);
+        memcpy(&lb, &lo, 2);
+        p[0] = (uint32_t)hb << 16;
+        p[1] = (uint32_t)lb << 16;
+        return;
+    }
     if (np == 1) { p[0] = rne_bf16(f2u(x)); return; }
     float r = x;
     for (int i = 0; i < np; ++i) {
@@ -597,7 +607,7 @@ static void split_parts_host(float x, int np, uint32_t *p) {
 
 // [rows][K] row-major fp32 (row = gates[gi]*H + 16*wv + m) -> bf16x8 A fragments
 // [H/16 waves][ngates][K/32][np][64 lanes][4 dwords]; lane (q, m) holds k = 32ks + 8q + j
-std::vector<float> pack_split_a(const std::vector<float> &w, int K, int nw, const int *rowbase, int ngates, int np) {
+std::vector<float> pack_split_a(const std::vector<float> &w, int K, int nw, const int *rowbase, int ngates, int np, bool f16 = false) {
     const int KS32 = K / 32;
     std::vector<uint32_t> out((size_t)nw * ngates * KS32 * np * 64 * 4);
     for (int wv = 0; wv < nw; ++wv)
@@ -607,7 +617,7 @@ std::vector<float> pack_split_a(const std::vector<float> &w, int K, int nw, cons
                     const int q = lane >> 4, mm = lane & 15;
                     const int row = rowbase[gi] + 16 * wv + mm;
                     uint32_t parts[8][3];
-                    for (int j = 0; j < 8; ++j) split_parts_host(w[(size_t)row * K + 32 * ks + 8 * q + j], np, parts[j]);
+                    for (int j = 0; j < 8; ++j) split_parts_host(w[(size_t)row * K + 32 * ks + 8 * q + j], np, parts[j], f16);
                     for (int p = 0; p < np; ++p)
                         for (int i = 0; i < 4; ++i)
                             out[(((((size_t)wv * ngates + gi) * KS32 + ks) * np + p) * 64 + lane) * 4 + i] =
@@ -623,7 +633,7 @@ bool desc_ok(const rmr_model_desc &d) {
     if (d.size != 16 && d.size != 32 && d.size != 64) return false;
     if (d.kmer_len < 1 || d.kmer_len > 64) return false;
     if (d.num_out < 1 || d.num_out > 16) return false;
-    if (d.dtype < 0 || d.dtype > 4) return false;
+    if (d.dtype < 0 || d.dtype > 5) return false;  // 5 = f16x3: two-part IEEE half split on the unfused kernels
     if (d.dtype == 4 && (d.size != 64 || (d.kmer_len != 9 && d.kmer_len != 6))) return false;  // half: the fused kernels only
     if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || d.size % 32)) return false;
     return true;
@@ -693,6 +703,7 @@ static inline double lstm1_gate_scale(int gate) {
 // conv weights -> split-bf16 A fragments [oc/16][steps][np][64 lanes][4 dwords]
 // (k-slot mapping documented at the top of k_conv_bf16s.hip)
 int pack_conv_split(rmr_model *m, const Folded &f, int np, ConvLayer *out) {
+    out->split_f16 = m->split_f16;
     const ConvSpec &s = f.s;
     const bool pair = (s.ic == 16);
     if (!pair && s.ic % 32) RMR_FAIL(RMR_ERR_INVALID, "split conv needs ic 16 or a multiple of 32 (got %d)", s.ic);
@@ -710,7 +721,7 @@ int pack_conv_split(rmr_model *m, const Folded &f, int np, ConvLayer *out) {
                     if (pair) { tap = 2 * st + (q >> 1); ch = 8 * (q & 1) + j; }
                     else { tap = st / KS; ch = 32 * (st % KS) + 8 * q + j; }
                     const float v = tap < s.kw ? f.w[((size_t)oc * s.ic + ch) * s.kw + tap] : 0.0f;
-                    split_parts_host(v, np, parts[j]);
+                    split_parts_host(v, np, parts[j], m->split_f16);
                 }
                 for (int p = 0; p < np; ++p)
                     for (int i = 0; i < 4; ++i)
@@ -845,7 +856,8 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
     std::unique_ptr<rmr_model, void (*)(rmr_model *)> m(new rmr_model(), rmr_model_destroy);
     m->eng = e;
     m->desc = *desc;
-    m->nparts = desc->dtype == 4 ? 1 : desc->dtype;  // 0 fp32 MFMA; 1 bf16; 2 bf16x3 (2-part split); 3 bf16x6 (3-part split)
+    m->nparts = desc->dtype == 4 ? 1 : (desc->dtype == 5 ? 2 : desc->dtype);  // 0 fp32 MFMA; 1 bf16; 2 bf16x3 (2-part split); 3 bf16x6 (3-part split)
+    m->split_f16 = desc->dtype == 5;  // f16x3: the two parts are IEEE half
     m->f16 = desc->dtype == 4;                       // 4: one-part operands as IEEE half (fused kernels)
     const int sz = desc->size, K = desc->kmer_len, L = desc->chunk_len;
 
@@ -959,8 +971,8 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
                     sh[(size_t)r * H + k] = (float)((double)whh1[(size_t)r * H + k] * lstm1_gate_scale(r / H));
                 }
             const int rb[4] = {0, H, 2 * H, 3 * H};
-            RMR_TRY(upload(m.get(), pack_split_a(si, H, H / 16, rb, 4, m->nparts), &m->lstm.s_ih1));
-            RMR_TRY(upload(m.get(), pack_split_a(sh, H, H / 16, rb, 4, m->nparts), &m->lstm.s_hh1));
+            RMR_TRY(upload(m.get(), pack_split_a(si, H, H / 16, rb, 4, m->nparts, m->split_f16), &m->lstm.s_ih1));
+            RMR_TRY(upload(m.get(), pack_split_a(sh, H, H / 16, rb, 4, m->nparts, m->split_f16), &m->lstm.s_hh1));
         }
         if (m->nparts == 1 && H == 64) {
             RMR_TRY(upload(m.get(), pack_lstm_x16(wih1, false, m->f16), &m->lstm.x_ih));

@@ -21,9 +21,18 @@ namespace rmr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NP>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 (dtype f16x3, NP = 2): two IEEE half parts instead of bf16 parts (k_lstm_bf16s.hip, split_parts)
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void split_parts_c(float x, unsigned (&p)[NP]) {
-    if (NP == 1) {
+    if constexpr (F16) {
+        static_assert(NP == 2, "the half split has two parts");
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        p[0] = (unsigned)__builtin_bit_cast(unsigned short, hi) << 16;
+        p[1] = (unsigned)__builtin_bit_cast(unsigned short, lo) << 16;
+    } else if (NP == 1) {
         const unsigned b = __float_as_uint(x);
         p[0] = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
     } else {
@@ -54,7 +63,7 @@ struct ConvSArgs {
     FastDiv div_pout;
 };
 
-template <int IC, int KW, int STRIDE, int NP>
+template <int IC, int KW, int STRIDE, int NP, bool F16>
 __global__ __launch_bounds__(256) void conv_bf16s_kernel(ConvSArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 sm4[];
     constexpr bool PAIR = (IC == 16);            // two taps per k-step
@@ -107,10 +116,10 @@ __global__ __launch_bounds__(256) void conv_bf16s_kernel(ConvSArgs a) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     unsigned e[8][NP];
-                    split_parts_c<NP>(v0[u].x, e[0]); split_parts_c<NP>(v0[u].y, e[1]);
-                    split_parts_c<NP>(v0[u].z, e[2]); split_parts_c<NP>(v0[u].w, e[3]);
-                    split_parts_c<NP>(v1[u].x, e[4]); split_parts_c<NP>(v1[u].y, e[5]);
-                    split_parts_c<NP>(v1[u].z, e[6]); split_parts_c<NP>(v1[u].w, e[7]);
+                    split_parts_c<NP, F16>(v0[u].x, e[0]); split_parts_c<NP, F16>(v0[u].y, e[1]);
+                    split_parts_c<NP, F16>(v0[u].z, e[2]); split_parts_c<NP, F16>(v0[u].w, e[3]);
+                    split_parts_c<NP, F16>(v1[u].x, e[4]); split_parts_c<NP, F16>(v1[u].y, e[5]);
+                    split_parts_c<NP, F16>(v1[u].z, e[6]); split_parts_c<NP, F16>(v1[u].w, e[7]);
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
                         sm4[(size_t)p * a.part + dsto[u]] =
@@ -145,9 +154,15 @@ __global__ __launch_bounds__(256) void conv_bf16s_kernel(ConvSArgs a) {
                 }
 #pragma unroll
                 for (int pr = 0; pr < P::N; ++pr) {
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, A[s][P::A[pr]]);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x0[P::B[pr]], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x1[P::B[pr]], acc1, 0, 0, 0);
+                    if constexpr (F16) {
+                        const f16x8 af = __builtin_bit_cast(f16x8, A[s][P::A[pr]]);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, x0[P::B[pr]]), acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, x1[P::B[pr]]), acc1, 0, 0, 0);
+                    } else {
+                        const bf16x8 af = __builtin_bit_cast(bf16x8, A[s][P::A[pr]]);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x0[P::B[pr]], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x1[P::B[pr]], acc1, 0, 0, 0);
+                    }
                 }
             }
             if (v0) {
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_bf16s_kernel(ConvSArgs a) {
     }
 }
 
-template <int IC, int KW, int STRIDE, int NP>
+template <int IC, int KW, int STRIDE, int NP, bool F16 = false>
 static int launch_conv_s_t(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out,
                            int out_row, int out_coff, int pout, int64_t n) {
     constexpr bool PAIR = (IC == 16);
@@ -190,7 +205,7 @@ static int launch_conv_s_t(rmr_engine *e, const ConvLayer &c, const float *in, i
     int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONVS_BLOCKS_PER_CU", 2);
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
-    auto kern = conv_bf16s_kernel<IC, KW, STRIDE, NP>;
+    auto kern = conv_bf16s_kernel<IC, KW, STRIDE, NP, F16>;
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     ProfScope ps(e, c.kid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (c.oc / 16)), lds, e->stream, a);
@@ -203,6 +218,7 @@ int launch_conv_split(rmr_engine *e, const ConvLayer &c, int np, const float *in
     if (in_row != c.ic) RMR_FAIL(RMR_ERR_INVALID, "conv input row %d != ic %d", in_row, c.ic);
 #define RMR_CONVS_CASE(IC_, KW_, ST_)                                                                  \
     if (c.ic == IC_ && c.kw == KW_ && c.stride == ST_) {                                               \
+        if (c.split_f16) return launch_conv_s_t<IC_, KW_, ST_, 2, true>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n); \
         if (np == 1) return launch_conv_s_t<IC_, KW_, ST_, 1>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n); \
         if (np == 2) return launch_conv_s_t<IC_, KW_, ST_, 2>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n); \
         if (np == 3) return launch_conv_s_t<IC_, KW_, ST_, 3>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n); \

@@ -22,10 +22,20 @@ namespace rmr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// split x into NP bf16 parts, returned as fp32 bit patterns whose low 16 bits are zero
-template <int NP>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// split x into NP bf16 parts, returned as fp32 bit patterns whose low 16 bits are zero.  F16 (dtype f16x3, NP = 2): two IEEE
+// half parts instead - hi = half(x), lo = half(x - hi), each in the high 16 bits of its word like the bf16 parts: 22
+// significand bits from three products (hi hi, hi lo, lo hi), where two bf16 parts carry 16
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void split_parts(float x, unsigned (&p)[NP]) {
-    if (NP == 1) {  // round to nearest even
+    if constexpr (F16) {
+        static_assert(NP == 2, "the half split has two parts");
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        p[0] = (unsigned)__builtin_bit_cast(unsigned short, hi) << 16;
+        p[1] = (unsigned)__builtin_bit_cast(unsigned short, lo) << 16;
+    } else if (NP == 1) {  // round to nearest even
         const unsigned b = __float_as_uint(x);
         p[0] = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
     } else {
@@ -52,8 +62,14 @@ template <> struct Prod<1> { static constexpr int N = 1; static constexpr int A[
 template <> struct Prod<2> { static constexpr int N = 3; static constexpr int A[3] = {0, 0, 1}; static constexpr int B[3] = {0, 1, 0}; };
 template <> struct Prod<3> { static constexpr int N = 6; static constexpr int A[6] = {0, 0, 1, 0, 2, 1}; static constexpr int B[6] = {0, 1, 0, 2, 0, 1}; };
 
+template <bool F16>
+__device__ __forceinline__ f32x4 mma_part(const uint4 a, const bf16x8 b, const f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+}
+
 // acc[gt] += sum over k-steps and part products of A[gt][ks][pa] * B(img)[ks][pb]
-template <int KS32, int NP, int SL>
+template <int KS32, int NP, int SL, bool F16>
 __device__ __forceinline__ void mm_split_impl(const uint4 (&img)[NP][4][16][SL], int q, int nn,
                                               const uint4 (&A)[4][KS32][NP], f32x4 (&acc)[4]) {
     using P = Prod<NP>;
@@ -66,14 +82,13 @@ __device__ __forceinline__ void mm_split_impl(const uint4 (&img)[NP][4][16][SL],
         for (int pr = 0; pr < P::N; ++pr)
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
-                acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[gt][ks][P::A[pr]]),
-                                                                 b[P::B[pr]], acc[gt], 0, 0, 0);
+                acc[gt] = mma_part<F16>(A[gt][ks][P::A[pr]], b[P::B[pr]], acc[gt]);
     }
 }
-template <int KS32, int NP, int SL>
+template <int KS32, int NP, int SL, bool F16>
 __device__ __forceinline__ void mm_split(const uint4 (&img)[NP][4][16][SL], int q, int nn,
                                          const uint4 (&A)[4][KS32][NP], f32x4 (&acc)[4]) {
-    mm_split_impl<KS32, NP, SL>(img, q, nn, A, acc);
+    mm_split_impl<KS32, NP, SL, F16>(img, q, nn, A, acc);
 }
 
 struct LstmSArgs {
@@ -86,7 +101,7 @@ struct LstmSArgs {
     int T, num_out;
 };
 
-template <int H, int NP>
+template <int H, int NP, bool F16>
 __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
     constexpr int NW = H / 16;
     constexpr int KS32 = H / 32;                 // bf16 k-steps of 32 channels
@@ -126,8 +141,8 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
 
     auto stage_x = [&](int buf, const float4 v) {
         unsigned e[4][NP];
-        split_parts<NP>(v.x, e[0]); split_parts<NP>(v.y, e[1]);
-        split_parts<NP>(v.z, e[2]); split_parts<NP>(v.w, e[3]);
+        split_parts<NP, F16>(v.x, e[0]); split_parts<NP, F16>(v.y, e[1]);
+        split_parts<NP, F16>(v.z, e[2]); split_parts<NP, F16>(v.w, e[3]);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             uint2 wv = make_uint2(pack2(e[0][p], e[1][p]), pack2(e[2][p], e[3][p]));
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         // in order: without the interleave the matrix pipe idles while the wave does its VALU work).
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         f32x4 accN[4] = {bias[0], bias[1], bias[2], bias[3]};
-        mm_split<KS32, NP, SL>(xs[0], q, nn, Aih, accN);
+        mm_split<KS32, NP, SL, F16>(xs[0], q, nn, Aih, accN);
         __syncthreads();  // xs[0] is overwritten at the end of step 0: all x_0 reads first (see k_lstm_x16.hip)
         for (int t = 0; t < a.T; ++t) {
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
             for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) bxn[ks][p] = __builtin_bit_cast(bf16x8, xs[(t + 1) & 1][p][q][nn][ks]);
-            if (t > 0) mm_split<KS32, NP, SL>(hs[(t - 1) & 1], q, nn, Ahh, acc);  // recurrent critical path
+            if (t > 0) mm_split<KS32, NP, SL, F16>(hs[(t - 1) & 1], q, nn, Ahh, acc);  // recurrent critical path
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) accN[gt] = bias[gt];
             f32x4 h;
@@ -176,8 +191,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
 #pragma unroll
                 for (int mi = s * NM / 16; mi < (s + 1) * NM / 16; ++mi) {
                     const int gt = mi & 3, pr = (mi >> 2) % P::N, ks = (mi >> 2) / P::N;
-                    accN[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, Aih[gt][ks][P::A[pr]]), bxn[ks][P::B[pr]], accN[gt], 0, 0, 0);
+                    accN[gt] = mma_part<F16>(Aih[gt][ks][P::A[pr]], bxn[ks][P::B[pr]], accN[gt]);
                 }
                 const int r = s >> 2, st = s & 3;
                 if (st == 0) ig[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
             {
                 unsigned e[4][NP];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) split_parts<NP>(h[r], e[r]);
+                for (int r = 0; r < 4; ++r) split_parts<NP, F16>(h[r], e[r]);
                 const int grp8 = 2 * w + (q >> 1);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
     }
 }
 
-template <int H, int NP>
+template <int H, int NP, bool F16 = false>
 static int launch_lstm_s_t(rmr_model *m, const float *x, int64_t n, float *logits) {
     rmr_engine *e = m->eng;
     LstmSArgs a;
@@ -268,13 +282,17 @@ static int launch_lstm_s_t(rmr_model *m, const float *x, int64_t n, float *logit
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);
-    hipLaunchKernelGGL((lstm_bf16s_kernel<H, NP>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    hipLaunchKernelGGL((lstm_bf16s_kernel<H, NP, F16>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_lstm_head_split(rmr_model *m, const float *x, int64_t n, float *logits) {
     const int np = m->nparts;
+    if (m->split_f16) {  // dtype f16x3: two half parts
+        if (m->desc.size == 64) return launch_lstm_s_t<64, 2, true>(m, x, n, logits);
+        if (m->desc.size == 32) return launch_lstm_s_t<32, 2, true>(m, x, n, logits);
+    }
     if (m->desc.size == 64) {
         if (np == 1) return launch_lstm_s_t<64, 1>(m, x, n, logits);
         if (np == 2) return launch_lstm_s_t<64, 2>(m, x, n, logits);

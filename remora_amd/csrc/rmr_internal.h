@@ -157,6 +157,7 @@ struct ConvLayer {
     float *spack = nullptr;  // device, split-bf16 fragments [oc/16][steps][nparts][64] x 16 B (dtype != 0)
     float *bias = nullptr;   // device, folded bias [oc]
     int kid = 0;             // profiling id
+    bool split_f16 = false;  // spack holds two IEEE half parts (dtype f16x3) instead of bf16 parts
 };
 
 struct FrontWeights {
@@ -198,6 +199,7 @@ struct rmr_model {
     rmr_engine *eng = nullptr;
     rmr_model_desc desc{};
     int nparts = 0;  // 0: fp32 MFMA path; 1..3: bf16 MFMA with 1 / 2 / 3-part split operands
+    bool split_f16 = false;  // dtype f16x3: nparts == 2 and the parts are IEEE half (hi, lo)
     bool f16 = false;  // dtype 4: nparts == 1 with IEEE-half operands in the fused kernels (k_fused.hip, k_lstm_x16.hip)
     std::vector<void *> dev_allocs;
     rmr::FrontWeights front;

@@ -207,7 +207,7 @@ class HipModel:
     callers use (src/remora/data_chunks.py:528-533, src/remora/inference.py:286,311-315,390,
     src/remora/model_util.py:559-562) — plus the fused `infer_chunks` fast path."""
 
-    DTYPES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16": 4, "fp16": 4}
+    DTYPES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16": 4, "fp16": 4, "f16x3": 5}
 
     def __init__(self, state, chunk_len, device=None, engine=None, dtype="fp32"):
         torch = _torch()
