@@ -780,6 +780,29 @@ std::vector<float> pack_lstm_x16(const float *w, bool skip_f, bool f16 = false) 
     memcpy(f.data(), o.data(), o.size() * 4);
     return f;
 }
+// the same fragments as NP split parts (k_lstm_x16s.hip): [8][2][2 k-steps][np][64 lanes][4 dwords]
+std::vector<float> pack_lstm_x16_split(const float *w, bool skip_f, int np, bool f16) {
+    const int H = 64;
+    std::vector<uint32_t> o((size_t)8 * 2 * 2 * np * 64 * 4);
+    for (int wv = 0; wv < 8; ++wv)
+        for (int t = 0; t < 2; ++t)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int ql = lane >> 4, mm = lane & 15, gate = mm & 3, unit = 8 * wv + 2 * (mm >> 2) + t;
+                    uint32_t parts[8][3];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * ks + 8 * ql + j;
+                        const double v = (skip_f && gate == 1) ? 0.0 : (double)w[(size_t)(gate * H + unit) * H + k] * lstm1_gate_scale(gate);
+                        split_parts_host((float)v, np, parts[j], f16);
+                    }
+                    for (int p = 0; p < np; ++p)
+                        for (int i = 0; i < 4; ++i)
+                            o[(((((size_t)wv * 2 + t) * 2 + ks) * np + p) * 64 + lane) * 4 + i] = (parts[2 * i][p] >> 16) | parts[2 * i + 1][p];
+                }
+    std::vector<float> f(o.size());
+    memcpy(f.data(), o.data(), o.size() * 4);
+    return f;
+}
 // matching biases [8][2][4 q][4 gates]: (b_ih + b_hh) of unit 8 wv + 2 q + t, pre-scaled
 std::vector<float> pack_bias_x16(const float *bih, const float *bhh, bool skip_f) {
     const int H = 64;
@@ -974,6 +997,13 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
             RMR_TRY(upload(m.get(), pack_split_a(si, H, H / 16, rb, 4, m->nparts, m->split_f16), &m->lstm.s_ih1));
             RMR_TRY(upload(m.get(), pack_split_a(sh, H, H / 16, rb, 4, m->nparts, m->split_f16), &m->lstm.s_hh1));
         }
+        if (m->nparts >= 2 && H == 64) {  // split operands in the x16 layout (k_lstm_x16s.hip)
+            RMR_TRY(upload(m.get(), pack_lstm_x16_split(wih1, false, m->nparts, m->split_f16), &m->lstm.xs_ih));
+            RMR_TRY(upload(m.get(), pack_lstm_x16_split(whh1, false, m->nparts, m->split_f16), &m->lstm.xs_hh));
+            RMR_TRY(upload(m.get(), pack_lstm_x16_split(wih2, true, m->nparts, m->split_f16), &m->lstm.xs_ih2));
+            RMR_TRY(upload(m.get(), pack_bias_x16(bih1, bhh1, false), &m->lstm.x_b1));
+            RMR_TRY(upload(m.get(), pack_bias_x16(bih2, bhh2, true), &m->lstm.x_b2));
+        }
         if (m->nparts == 1 && H == 64) {
             RMR_TRY(upload(m.get(), pack_lstm_x16(wih1, false, m->f16), &m->lstm.x_ih));
             RMR_TRY(upload(m.get(), pack_lstm_x16(whh1, false, m->f16), &m->lstm.x_hh));
@@ -1153,7 +1183,9 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                 RMR_HIP(hipStreamWaitEvent(fs, e->ev_done[slot], 0));
                 RMR_TRY(front(c0 + sb, nn, slot ^ 1));
             }
-            if (m->nparts > 0) RMR_TRY(launch_lstm_head_split(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
+            if (m->nparts > 0 && lstm_x16s_supported(m) && tune_int("RMR_LSTM_SPLIT_X16", 1))
+                RMR_TRY(launch_lstm_head_x16s(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
+            else if (m->nparts > 0) RMR_TRY(launch_lstm_head_split(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
             else RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
         } else {
             float *seq2 = base; base += (size_t)nb * m->PQ2 * 32;

@@ -191,6 +191,7 @@ struct LstmWeights {
     // k_lstm_x16.hip (plain bf16, size 64): unit-major tiles [8 waves][2 tiles][2 k-steps][64 lanes] x 16 B, biases
     // [8][2][4 q][4 gates]; lstm2 with a zero f row
     float *x_ih = nullptr, *x_hh = nullptr, *x_ih2 = nullptr, *x_b1 = nullptr, *x_b2 = nullptr;
+    float *xs_ih = nullptr, *xs_hh = nullptr, *xs_ih2 = nullptr;  // the same fragments as NP split parts (k_lstm_x16s.hip)
 };
 
 }  // namespace rmr
@@ -267,6 +268,8 @@ int launch_fc_head(rmr_model *m, const float *m4, int64_t n, float *logits);
 bool fused_front_supported(const rmr_model *m, int seq_w, int map_w);
 int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w, const int16_t *maps, int map_w,
                        const int16_t *lens, int64_t n, uint16_t *x);
+bool lstm_x16s_supported(const rmr_model *m);
+int launch_lstm_head_x16s(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logits);
 
 // integer tuning knob from the environment (read once per call site; for experiments only)
