@@ -338,17 +338,55 @@ def bam_byte_shard(bam_path, rank, world):
     """(start_voffset, end_voffset) of rank `rank`'s share when `world` workers split `bam_path` by BYTE ranges: the
     records that start in BGZF members at or behind byte size * rank / world and in front of size * (rank + 1) / world.
     No pass over the file and no coordinator: both ends come from `bam_guess_start`, a pure function of the file, so
-    rank r's end IS rank r + 1's start.  end None = to the end of the file; start None = nothing for this rank.  The
-    guess is verified by the worker in front: its chain of records, exact from the file's first record on, has to end
-    on it (`_iter_bam_records_native`)."""
+    rank r's end IS rank r + 1's start.  end None = to the end of the file; start None = nothing for this rank.  Both
+    marks are verified before the rank starts (`_verify_share_mark`: an independent guess 1 MiB in front, chained forward,
+    has to land on the mark) and again by the chain of the worker in front, which has to end on it
+    (`_iter_bam_records_native`)."""
     if world <= 1:
         return bam_guess_start(bam_path, 0), None
     size = os.path.getsize(bam_path)
-    start = bam_guess_start(bam_path, size * int(rank) // int(world))
+    cut = lambda r: size * int(r) // int(world)  # noqa: E731
+    start = bam_guess_start(bam_path, cut(rank))
     if start is None:
         return None, None
-    end = None if rank == world - 1 else bam_guess_start(bam_path, size * (int(rank) + 1) // int(world))
-    return (None, None) if end is not None and end == start else (start, end)
+    end = None if rank == world - 1 else bam_guess_start(bam_path, cut(rank + 1))
+    if end is not None and end == start:
+        return None, None
+    if os.environ.get("REMORA_AMD_BAM_SHARD_VERIFY", "1") != "0":
+        # both ends checked BEFORE any work is done (the chain of the worker in front would only find a wrong guess at the
+        # very end of its share, behind all of its GPU work): a second, independent guess a little in front of the mark is
+        # chained forward record by record and has to arrive exactly on it
+        for mark, at in ((start, cut(rank)), (end, cut(rank + 1))):
+            if mark is not None and at > 0:
+                _verify_share_mark(bam_path, mark, at)
+    return start, end
+
+
+def _verify_share_mark(bam_path, mark, file_offset, back=1 << 20):
+    """Raise unless the records chained from an independent starting point in front of byte `file_offset` (the guess `back`
+    bytes earlier, or the file's first record) meet virtual offset `mark` exactly."""
+    first = bam_guess_start(bam_path, 0)
+    probe = bam_guess_start(bam_path, max(int(file_offset) - back, 0)) if file_offset > back else first
+    if probe is None or probe >= mark:  # nothing in front of the mark inside the window: start from the file's first record
+        probe = first
+    if probe is None or probe == mark:
+        return
+    lib = L.lib()
+    h = ctypes.c_void_p()
+    L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+    try:
+        L.check(lib.rmr_bam_seek(h, int(probe)))
+        for rb in _native_raw_batches(lib, h, False, 64):
+            past = np.nonzero(rb.voffset >= mark)[0]
+            if past.size:
+                if int(rb.voffset[int(past[0])]) == mark:
+                    return
+                break
+        raise RemoraError(f"{bam_path}: the share boundary guessed at byte {file_offset} (virtual offset {mark}) is not a record start "
+                          f"(records chained from virtual offset {probe} pass it) - REMORA_AMD_BAM_SHARD=scan splits by an exact "
+                          f"pass over the file instead")
+    finally:
+        lib.rmr_bam_close(h)
 
 
 def bam_scan(bam_path, every=64):

@@ -1730,6 +1730,40 @@ def test_bam_byte_shares_partition_the_records_and_verify_their_ends(tmp_path):
         list(rio._iter_bam_records_native(big, False, 64, start_voffset=vos[0], end_voffset=(size + 5) << 16))
 
 
+def test_a_wrong_share_boundary_is_refused_before_any_work(tmp_path, monkeypatch):
+    """bam_byte_shard checks both of its marks against an independent chain of records before the rank starts (round 3
+    found a wrong guess only at the END of the share in front, behind all of its GPU work): a guess that is no record start
+    raises at once, naming the scan mode; the true marks pass, with or without the check."""
+    import struct
+
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+
+    big = str(tmp_path / "big.bam")
+    recs = list(rio.iter_bam_records(os.path.join(DATA, "can_mappings.bam")))
+    with rio.BamWriter(big, rio.read_bam_header_bytes(os.path.join(DATA, "can_mappings.bam")), level=1) as w:
+        for _ in range(40):
+            for r in recs:
+                raw = bytes(r.raw)
+                w.write(struct.pack("<i", len(raw)) + raw)
+    honest = [rio.bam_byte_shard(big, r, 4) for r in range(4)]
+    assert all(honest[r][1] == honest[r + 1][0] for r in range(3)) and honest[3][1] is None
+    monkeypatch.setenv("REMORA_AMD_BAM_SHARD_VERIFY", "0")
+    assert [rio.bam_byte_shard(big, r, 4) for r in range(4)] == honest
+    monkeypatch.delenv("REMORA_AMD_BAM_SHARD_VERIFY")
+    real, size = rio.bam_guess_start, os.path.getsize(big)
+
+    def off_by_some(path, file_offset):  # the mark of rank 2 lands inside a record
+        v = real(path, file_offset)
+        return v + 7 if file_offset == size * 2 // 4 else v
+
+    monkeypatch.setattr(rio, "bam_guess_start", off_by_some)
+    for rank in (1, 2):  # rank 1's end and rank 2's start are that mark
+        with pytest.raises(RemoraError, match="not a record start.*REMORA_AMD_BAM_SHARD=scan"):
+            rio.bam_byte_shard(big, rank, 4)
+    assert rio.bam_byte_shard(big, 0, 4) == honest[0] and rio.bam_byte_shard(big, 3, 4) == honest[3]
+
+
 def test_raw_bam_batches_are_the_records_of_iter_bam_records(tmp_path, monkeypatch):
     """io.iter_bam_raw_batches (flat arrays per native batch: what the batch ingest of `infer` runs on) hands out exactly
     the records iter_bam_records does - whole file, shares by byte range and by record count, any batch size - and a share
