@@ -6,8 +6,8 @@
  * return code of the library is printed with rmr_last_error().  This is the interface that stands in for
  * encoded_kmers.pyx:13-45 + models/ConvLSTM_w_ref.py:39-58 (include/remora_hip.h), with no Python in the process.
  *
- *     infer_from_c FIXTURE.bin [dtype]        dtype: 0 fp32 (default), 1 bf16, 2 bf16x3, 3 bf16x6; tolerance 1e-4 for
- *                                             fp32 / bf16x6, 5e-4 for bf16x3, 3e-2 for bf16 */
+ *     infer_from_c FIXTURE.bin [dtype]        dtype: 0 fp32 (default), 1 bf16, 2 bf16x3, 3 bf16x6, 4 f16, 5 f16x3; tolerance
+ *                                             1e-4 for fp32 / bf16x6 / f16x3, 5e-4 for bf16x3, 3e-2 for bf16, 4e-3 for f16 */
 #include "remora_hip.h"
 #include <math.h>
 #include <stdio.h>
@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
         return 3;
     }
     dtype = argc > 2 ? atoi(argv[2]) : 0;
-    tol = dtype == 1 ? 3e-2 : dtype == 2 ? 5e-4 : 1e-4;
+    tol = dtype == 1 ? 3e-2 : dtype == 2 ? 5e-4 : dtype == 4 ? 4e-3 : 1e-4;
     fh = fopen(argv[1], "rb");
     if (fh == NULL || fread(magic, 1, 4, fh) != 4 || memcmp(magic, "RMRC", 4) != 0 || fread(h, 4, 9, fh) != 9 || fread(nn, 8, 2, fh) != 2) {
         fprintf(stderr, "fixture: cannot read the header of %s\n", argv[1]);

@@ -30,7 +30,7 @@ def infer_exe(tmp_path_factory):
 
 @pytest.mark.parametrize("name,dtype", [("model_convlstm_s64_l100_o2", 0), ("model_convlstm_s64_l200_o3", 0),
                                         ("model_conv_s64_l100_o2", 0), ("model_convlstm_s64_l100_o2", 3),
-                                        ("model_convlstm_s64_l100_o2", 1)])
+                                        ("model_convlstm_s64_l100_o2", 1), ("model_convlstm_s64_l200_o3", 5)])
 def test_c_program_infers_reference_logits(infer_exe, tmp_path, name, dtype):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import export_c_fixture
