@@ -1551,6 +1551,18 @@ class IngestBatch:
         return out
 
 
+def _trim_span(size, sp, ts, ns, has_ns):
+    """(offset, length) of dacs[sp:][ts:ns] inside dacs for arrays of non-negative bounds (src/remora/io.py:2003-2012: the
+    signal of an alignment), python slice semantics: bounds beyond the end clip, an end in front of the start leaves
+    nothing; `ns` counts where `has_ns`."""
+    size, sp, ts, ns = (np.asarray(x, np.int64) for x in (size, sp, ts, ns))
+    start = np.minimum(sp, size)
+    rem = size - start
+    a = np.minimum(ts, rem)
+    b = np.where(has_ns, np.minimum(ns, rem), rem)
+    return start + a, np.maximum(b - a, 0)
+
+
 def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     """IngestBatch of one raw BAM batch, or None when nothing of it is kept.  Everything Read.from_pod5 + add_alignment +
     into_remora_read (basecall-anchored, forward signal) do per read, for the batch: trimming by sp / ts / ns, strand-aware
@@ -1598,13 +1610,8 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     read_start = row_out[first[:-1]]                      # where a distinct read's samples begin in `flat`
     read_size = row_out[first[1:]] - read_start
     size_k, base_k = read_size[inv], read_start[inv]
-    # dacs[sp:][ts:ns] (src/remora/io.py:2003-2012), python slice semantics for non-negative bounds
-    start = np.minimum(sp, size_k)
-    rem = size_k - start
-    a = np.minimum(ts, rem)
-    b = np.where(has & 4, np.minimum(ns, rem), rem)
-    sig_len = np.maximum(b - a, 0)
-    src_start = base_k + start + a
+    off, sig_len = _trim_span(size_k, sp, ts, ns, (has & 4) != 0)
+    src_start = base_k + off
     # ---- move tables of the whole raw batch in one launch (tables of records that are not kept: length 0 -> ignored) ----
     sl_all = np.zeros(n_all, np.int64)
     sl_all[keep] = sig_len

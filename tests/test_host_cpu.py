@@ -1821,6 +1821,24 @@ def test_raw_bam_batches_are_the_records_of_iter_bam_records(tmp_path, monkeypat
         list(rio.iter_bam_raw_batches(big, batch=8, shard=Share()))
 
 
+def test_batch_trimming_is_python_slicing():
+    """io._trim_span (the sp / ts / ns trimming of a whole batch, the array form of `dacs[sp:][ts:ns]` in
+    Read.add_alignment, src/remora/io.py:2003-2012) against the slices themselves, bounds beyond every edge included."""
+    from remora_amd import io as rio
+
+    rng = np.random.default_rng(11)
+    n = 4000
+    size = rng.integers(0, 50, n)
+    sp, ts, ns = (rng.integers(0, 70, n) for _ in range(3))
+    has_ns = rng.random(n) < 0.7
+    off, length = rio._trim_span(size, sp, ts, ns, has_ns)
+    for k in range(n):
+        want = range(int(size[k]))[int(sp[k]) :][int(ts[k]) : (int(ns[k]) if has_ns[k] else None)]
+        assert len(want) == length[k]
+        if len(want):
+            assert want[0] == off[k]
+
+
 def test_pod5_rows_located_by_array_arithmetic():
     """Pod5File.rows_of_reads (addresses into the mapped Arrow buffers, no bytes object per row) names the same bytes and
     sample counts as the per-cell access of signal_rows, for any order and repetition of reads."""
