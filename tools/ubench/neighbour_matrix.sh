@@ -3,6 +3,8 @@
 mkdir -p gpurun_out
 KIND=${1:-mfma16}; REPS=${2:-300}; shift 2
 N=tools/ubench/bin/neighbour
+mkdir -p tools/ubench/bin
+[ -x $N ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ubench/neighbour.hip -o $N
 for spec in "$@"; do
   $N $KIND 60000 2 32 > /dev/null & P1=$!
   $N $KIND 60000 2 32 > /dev/null & P2=$!
