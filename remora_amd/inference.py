@@ -303,6 +303,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             clock["prep"] += _time.perf_counter() - tq
             tg = _time.perf_counter()
             res = call_reads_mods(batch.reads, models[0], mds[0], return_mod_probs=True, device_reads=batch.dr) if batch.good.size else []
+            batch.dr, batch.reads = None, []  # the results are host arrays: the batch's device memory is free for the next one
             clock["gpu"] += _time.perf_counter() - tg
             return batch, None, [res]
         items, good = [], []  # items: per input record None (callable: the next entry of `good`) or the record to copy
