@@ -74,15 +74,24 @@ def map_ref_to_signal(*, query_to_signal, ref_to_query_knots):
 
 def make_sequence_coordinate_mapping(cigar):
     """Query coordinate (float) of every reference position 0..ref_len from the cigartuples: exact inside
-    match runs, linearly interpolated across insertions / deletions (src/remora/data_chunks.py:77-115)."""
-    cigar = list(cigar)
-    while cigar and not MATCH_OPS[cigar[-1][0]]:
-        cigar.pop()
-    if not cigar:
-        raise RemoraError("No match operations found in alignment cigar")
-    ops, lens = (np.array(x) for x in zip(*cigar))
-    if ops.min() < 0 or ops.max() > 8:
+    match runs, linearly interpolated across insertions / deletions (src/remora/data_chunks.py:77-115).
+    `cigar`: [(op, length), ...] as pysam gives it, or the same as an int array of shape (n, 2) / a pair of arrays
+    (ops, lengths) - what the native BAM reader holds; no Python tuple per operation then."""
+    if isinstance(cigar, np.ndarray) and cigar.ndim == 2 and cigar.shape[1] == 2:
+        ops, lens = cigar[:, 0].astype(np.int64), cigar[:, 1].astype(np.int64)
+    elif isinstance(cigar, tuple) and len(cigar) == 2 and isinstance(cigar[0], np.ndarray):
+        ops, lens = np.asarray(cigar[0], np.int64), np.asarray(cigar[1], np.int64)
+    else:
+        cigar = list(cigar)
+        if not cigar:
+            raise RemoraError("No match operations found in alignment cigar")
+        ops, lens = (np.array(x) for x in zip(*cigar))
+    if ops.size and (ops.min() < 0 or ops.max() > 8):
         raise RemoraError("Invalid cigar op(s)")
+    matched = np.nonzero(MATCH_OPS[ops])[0] if ops.size else np.zeros(0, np.int64)
+    if not matched.size:  # (the reference pops the non-match operations off the end until it finds a match or nothing)
+        raise RemoraError("No match operations found in alignment cigar")
+    ops, lens = ops[: matched[-1] + 1], lens[: matched[-1] + 1]
     if lens.min() < 0:
         raise RemoraError("Cigar lengths may not be negative")
     is_match = MATCH_OPS[ops]

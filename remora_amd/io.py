@@ -1362,7 +1362,13 @@ class Read:
                 self.ref_seq = revcomp(self.ref_seq)
             self.cigar = self.cigar[::-1]
         if self.ref_reg.ctg is not None and self.ref_seq is not None and self.query_to_signal is not None:
-            self.ref_to_signal = compute_ref_to_signal(query_to_signal=self.query_to_signal, cigar=self.cigar)
+            cig = getattr(rec, "_cigar", None)  # the native reader's uint32 operations: no tuple per operation on the way
+            if isinstance(cig, np.ndarray) and cig.size == len(self.cigar):
+                ops, lens = (cig & 0xF).astype(np.int64), (cig >> 4).astype(np.int64)
+                cig = (ops[::-1], lens[::-1]) if rec.is_reverse else (ops, lens)
+            else:
+                cig = self.cigar
+            self.ref_to_signal = compute_ref_to_signal(query_to_signal=self.query_to_signal, cigar=cig)
             if self.ref_to_signal.size != len(self.ref_seq) + 1:  # knots include the end of the last base
                 raise RemoraError("Discordant ref seq lengths")
             self.ref_reg.end = self.ref_reg.start + self.ref_to_signal.size - 1
