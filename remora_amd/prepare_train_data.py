@@ -28,7 +28,8 @@ def _training_read(io_read, int_label, motifs, focus_ref_pos, basecall_anchor):
                                                                    select_focus_reference_positions=focus_ref_pos)
         rr.labels = np.full(len(io_read.seq), int_label, dtype=int)
         return rr
-    io_read.ref_to_signal = compute_ref_to_signal(io_read.query_to_signal, io_read.cigar)
+    if io_read.ref_to_signal is None:  # (add_alignment already composed move table and CIGAR when it parsed the alignment)
+        io_read.ref_to_signal = compute_ref_to_signal(io_read.query_to_signal, io_read.cigar)
     if io_read.ref_to_signal.size != len(io_read.ref_seq) + 1:
         raise RemoraError(f"discordant ref seq lengths: move+cigar:{io_read.ref_to_signal.size} "
                           f"ref_seq:{len(io_read.ref_seq)}")
