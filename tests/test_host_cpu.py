@@ -1821,6 +1821,48 @@ def test_raw_bam_batches_are_the_records_of_iter_bam_records(tmp_path, monkeypat
         list(rio.iter_bam_raw_batches(big, batch=8, shard=Share()))
 
 
+@pytest.mark.parametrize("name", ["can", "mod"])
+def test_reference_anchored_host_path_from_cigar_arrays(name):
+    """Reference-anchored reads on the host: Read.add_alignment feeds the native reader's CIGAR arrays to
+    make_sequence_coordinate_mapping (src/remora/data_chunks.py:77-115) - the knots, ref_to_signal and the training reads of
+    `dataset prepare` (prepare_train_data.py:53-91) equal those of the tuple form, which the reference-generated goldens pin
+    on the GPU side; a random CIGAR maps the same through every accepted form, errors included."""
+    from golden_util import pod5_reads_cpu
+    from oracle import oracle as O
+    from remora_amd import RemoraError, util
+    from remora_amd import io as rio
+    from remora_amd.data_chunks import compute_ref_to_signal, make_sequence_coordinate_mapping
+    from remora_amd.prepare_train_data import _training_read
+
+    motifs = [util.Motif("CG", 0)]
+    pods = {p.read_id: p for p in pod5_reads_cpu(os.path.join(DATA, f"{name}_reads.pod5"))}
+    for rec in rio.iter_bam_records(os.path.join(DATA, f"{name}_mappings.bam"), want_ref=True):
+        t, sig = rec.hot_tags(), pods[rec.query_name].signal
+        sl = len(range(sig.size)[t.get("sp", 0) :][t.get("ts", 0) : t.get("ns", None)])
+        mv = O.parse_move_tag(np.asarray(t["mv"], np.int8), sl, seq_len=len(rec.query_sequence))
+        r = rio.Read.from_pod5(pods[rec.query_name])
+        r.add_alignment(rec, parse_ref_align=True, parsed_moves=mv)
+        assert np.array_equal(r.ref_to_signal, compute_ref_to_signal(r.query_to_signal, r.cigar))  # arrays == tuples
+        again = rio.Read.from_pod5(pods[rec.query_name])
+        again.add_alignment(rec, parse_ref_align=True, parsed_moves=mv)
+        again.ref_to_signal = None  # what prepare_train_data computed itself before it reused add_alignment's
+        a, b = _training_read(r, 1, motifs, None, False), _training_read(again, 1, motifs, None, False)
+        assert np.array_equal(a.dacs, b.dacs) and np.array_equal(a.seq_to_sig_map, b.seq_to_sig_map) and a.str_seq == b.str_seq
+        assert np.array_equal(a.focus_bases, b.focus_bases) and (a.shift, a.scale) == (b.shift, b.scale)
+    rng = np.random.default_rng(5)
+    for _ in range(500):
+        n = int(rng.integers(0, 30))
+        ops, lens = rng.integers(0, 9, n), rng.integers(0, 30, n)
+        forms = ([(int(o), int(l)) for o, l in zip(ops, lens)], (ops, lens), np.stack([ops, lens], 1).reshape(n, 2))
+        got = []
+        for f in forms:
+            try:
+                got.append(make_sequence_coordinate_mapping(f).tolist())
+            except RemoraError as e:
+                got.append(str(e))
+        assert got[0] == got[1] == got[2]
+
+
 def test_batch_trimming_is_python_slicing():
     """io._trim_span (the sp / ts / ns trimming of a whole batch, the array form of `dacs[sp:][ts:ns]` in
     Read.add_alignment, src/remora/io.py:2003-2012) against the slices themselves, bounds beyond every edge included."""
