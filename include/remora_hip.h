@@ -223,6 +223,15 @@ int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const 
                               const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
                               const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len);
 
+/* ---- N3: BGZF members for the output BAM (host code) ------------------------------------------------ */
+/* replaces: the deflate step of pysam / htslib below AlignmentFile.write (src/remora/inference.py:619-623), for the
+ * writer's fast mode (`--bam-level 1`).  src[0..n) is cut into payloads of 0xFF00 bytes (the last one shorter); each
+ * becomes one BGZF member (gzip + BC extra field, SAM spec 4.1) whose deflate stream is a single dynamic-Huffman block
+ * over the literals - no LZ77 matches - or a stored block when that would not shrink it; CRC32 and ISIZE as gzip wants
+ * them.  Members are written to `out` back to back (out_cap >= 65311 bytes per payload), *out_len = their total size;
+ * `n_threads` payloads are coded side by side.  No end-of-file marker is appended. */
+int rmr_bgzf_huffman(const uint8_t *src, int64_t n, int n_threads, uint8_t *out, int64_t out_cap, int64_t *out_len);
+
 /* ---- N1: POD5 signal rows, the zstd layer (host code, parallel over rows) ----------------------------- */
 /* replaces: the zstd step of pod5's signal reader under io.iter_signal (src/remora/io.py:441-474).  `src[i]`
  * points at row i's compressed bytes (one zstd frame, src_len[i] bytes).  rmr_zstd_frame_sizes reads the

@@ -1836,6 +1836,17 @@ def _bgzf_block(chunk, level=None):
                      cdata, struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))))
 
 
+def _bgzf_huffman_native(chunk):
+    """BGZF members (Huffman-only deflate, rmr_bgzf_huffman) for a run of payload bytes: one member per 0xFF00 bytes."""
+    n = len(chunk)
+    out = np.empty(max((n + 0xFEFF) // 0xFF00, 1) * 65311, np.uint8)
+    out_len = ctypes.c_int64()
+    src = (ctypes.c_char * n).from_buffer_copy(chunk) if n else None
+    L.check(L.lib().rmr_bgzf_huffman(ctypes.cast(src, ctypes.c_void_p) if n else None, n, 1, out.ctypes.data_as(ctypes.c_void_p), out.size,
+                                     ctypes.byref(out_len)))
+    return out[: out_len.value].tobytes()
+
+
 class BamWriter:
     """Minimal BGZF/BAM writer: header bytes copied from the template BAM, records appended.  Blocks are deflated
     by a small thread pool (zlib releases the GIL) and written in order, so compression - ~1 ms per 5 kb read with
@@ -1866,6 +1877,10 @@ class BamWriter:
         self._buf = bytearray()
         self._pool = ThreadPoolExecutor(max_workers=max(int(threads), 1))
         self._pending, self._max_pending = deque(), int(max_pending)
+        # level 1 with the default strategy (Huffman coding only): the library's own encoder, 2.5x zlib's on BAM records;
+        # whole runs of 16 payloads per job instead of one payload per job (RMR_BGZF_NATIVE=0: zlib for these too)
+        lvl = _BGZF_LEVEL if level is None else int(level)
+        self._native = lvl == 1 and _BGZF_STRATEGY is None and os.environ.get("RMR_BGZF_NATIVE", "1") != "0"
         # the header goes through write(): one with many reference sequences (hg38 with alt / decoy contigs: > 64 KiB) is
         # split into members of at most 0xFF00 bytes like everything else (a BGZF member holds at most 64 KiB)
         self.write(bytes(header_bytes))
@@ -1880,6 +1895,19 @@ class BamWriter:
 
     def write(self, record_bytes):
         """Append record bytes (one record or a whole batch of them); full 0xFF00-byte blocks go to the deflate pool."""
+        if self._native:
+            buf = self._buf
+            buf += record_bytes
+            run = 16 * 0xFF00
+            if len(buf) >= run:  # whole payloads only: the members are cut exactly where the per-block path cuts them
+                k = len(buf) // 0xFF00 * 0xFF00
+                view = memoryview(buf)
+                for a in range(0, k, run):
+                    self._pending.append(self._pool.submit(_bgzf_huffman_native, bytes(view[a : min(a + run, k)])))
+                del view
+                self._buf = bytearray(buf[k:])
+                self._drain(self._max_pending)
+            return
         buf = self._buf
         if len(buf) + len(record_bytes) < 0xFF00:
             buf += record_bytes
@@ -1901,7 +1929,10 @@ class BamWriter:
         if self._fh is None:
             return
         if self._buf:
-            self._flush_block(self._buf)
+            if self._native:
+                self._pending.append(self._pool.submit(_bgzf_huffman_native, bytes(self._buf)))
+            else:
+                self._flush_block(self._buf)
             self._buf = bytearray()
         self._drain(0)
         self._pool.shutdown()

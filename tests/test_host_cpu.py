@@ -1994,6 +1994,77 @@ def test_bam_parts_join_into_one_valid_bam(tmp_path):
     assert [r.query_name for r in back] == [r.query_name for r in recs]
 
 
+def test_native_huffman_bgzf_members_are_valid_deflate(tmp_path):
+    """rmr_bgzf_huffman (the writer's encoder at `--bam-level 1`: one dynamic-Huffman block per 0xFF00 bytes of payload, no
+    LZ77 matches, stored when that would not shrink) against Python's zlib / gzip as the independent inflater: every member
+    has the BGZF header fields, BSIZE, a raw-deflate stream that inflates to ISIZE bytes with the trailer's CRC32, and fits
+    64 KiB - for empty, one-byte, constant, two-symbol, uniform (stored), geometric and Fibonacci-skewed payloads (the last
+    needs the 15-bit length limit); BamWriter cuts the same members and writes the same stream with and without it."""
+    import ctypes
+    import gzip
+    import struct
+    import zlib
+
+    from remora_amd import _lib as L
+    from remora_amd import io as rio
+
+    def compress(data, threads):
+        n = len(data)
+        out = np.empty(max((n + 0xFEFF) // 0xFF00, 1) * 65311, np.uint8)
+        out_len = ctypes.c_int64()
+        src = np.frombuffer(data, np.uint8) if n else np.zeros(1, np.uint8)
+        L.check(L.lib().rmr_bgzf_huffman(src.ctypes.data_as(ctypes.c_void_p), n, threads, out.ctypes.data_as(ctypes.c_void_p), out.size,
+                                         ctypes.byref(out_len)))
+        return out[: out_len.value].tobytes()
+
+    def members(buf):
+        pos, payloads = 0, []
+        while pos < len(buf):
+            assert buf[pos : pos + 4] == b"\x1f\x8b\x08\x04" and buf[pos + 10 : pos + 16] == b"\x06\x00BC\x02\x00"
+            size = struct.unpack("<H", buf[pos + 16 : pos + 18])[0] + 1
+            assert size <= 65536
+            raw = zlib.decompress(buf[pos + 18 : pos + size - 8], -15)
+            crc, isize = struct.unpack("<II", buf[pos + size - 8 : pos + size])
+            assert crc == zlib.crc32(raw) & 0xFFFFFFFF and isize == len(raw) <= 0xFF00
+            payloads.append(raw)
+            pos += size
+        return payloads
+
+    rng = np.random.default_rng(1)
+    fib = [1, 1]
+    while sum(fib) < 60000:
+        fib.append(fib[-1] + fib[-2])
+    cases = [b"", b"a", b"ab" * 5, bytes(70000), bytes([7]) * 0xFF00, rng.integers(0, 256, 200000, dtype=np.uint8).tobytes(),
+             rng.integers(0, 4, 300000, dtype=np.uint8).tobytes(), (rng.geometric(0.02, 400000) % 256).astype(np.uint8).tobytes(),
+             b"".join(bytes([i]) * c for i, c in enumerate(fib)), open(os.path.join(DATA, "can_mappings.bam"), "rb").read()]
+    for data in cases:
+        for threads in (1, 3):
+            z = compress(data, threads)
+            got = members(z)
+            assert b"".join(got) == data and [len(x) for x in got[:-1]] == [0xFF00] * max(len(got) - 1, 0)
+        if data:
+            assert gzip.decompress(z) == data
+    assert len(compress(cases[5], 1)) < len(cases[5]) * 1.002  # incompressible: stored blocks
+    assert len(compress(cases[4], 1)) < 8400                   # one symbol: a bit per byte
+    # the writer: same members, same stream, whichever encoder
+    src = os.path.join(DATA, "can_mappings.bam")
+    recs, header, outs = list(rio.iter_bam_records(src)), rio.read_bam_header_bytes(src), {}
+    for mode in ("1", "0"):
+        os.environ["RMR_BGZF_NATIVE"] = mode
+        try:
+            path = str(tmp_path / f"o{mode}.bam")
+            with rio.BamWriter(path, header, level=1, threads=2) as w:
+                for _ in range(90):
+                    for r in recs:
+                        raw = bytes(r.raw)
+                        w.write(struct.pack("<i", len(raw)) + raw)
+            outs[mode] = open(path, "rb").read()
+        finally:
+            os.environ.pop("RMR_BGZF_NATIVE", None)
+    a, b = members(outs["1"][:-28]), members(outs["0"][:-28])
+    assert a == b and outs["1"][-28:] == outs["0"][-28:] and len(list(rio.iter_bam_records(str(tmp_path / "o1.bam")))) == 90 * len(recs)
+
+
 def test_bam_writer_splits_a_header_larger_than_one_bgzf_member(tmp_path):
     """A header with thousands of reference sequences (hg38 with alt / decoy contigs) is larger than the 64 KiB a BGZF member
     may hold: every member the writer emits must inflate to at most 65536 bytes (ISIZE), whatever the header's size, and the
