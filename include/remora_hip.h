@@ -223,6 +223,12 @@ int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const 
                               const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
                               const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len);
 
+/* The native BAM reader's own inflater for BGZF members, alone (host code; replaces zlib's inflate under
+ * rmr_bam_read_batch, which itself stands in for htslib below pysam, src/remora/io.py:184-358): a raw RFC 1951 stream
+ * src[0..n) into exactly out[0..out_len); RMR_ERR_INVALID when the stream is malformed, ends elsewhere or does not fill
+ * the output exactly.  Inside the reader every member's CRC32 is checked and zlib takes what this decoder refuses. */
+int rmr_inflate_raw(const uint8_t *src, int64_t n, uint8_t *out, int64_t out_len);
+
 /* ---- N3: BGZF members for the output BAM (host code) ------------------------------------------------ */
 /* replaces: the deflate step of pysam / htslib below AlignmentFile.write (src/remora/inference.py:619-623), for the
  * writer's fast mode (`--bam-level 1`).  src[0..n) is cut into payloads of 0xFF00 bytes (the last one shorter); each

@@ -76,6 +76,7 @@ SIGNATURES = {
     "rmr_format_mm_ml": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.c_char_p, ctypes.c_char, ctypes.c_char, c_vp, c_i64,
                                  c_vp, c_vp, c_i64, c_vp]),
     "rmr_records_with_mod_tags": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    "rmr_inflate_raw": (c_int, [c_vp, c_i64, c_vp, c_i64]),
     "rmr_bgzf_huffman": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "rmr_zstd_frame_sizes": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "rmr_zstd_rows": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),

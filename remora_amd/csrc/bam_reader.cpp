@@ -25,6 +25,8 @@
 
 #include "../../include/remora_hip.h"
 #include "rmr_internal.h"
+#include "fast_inflate.h"
+#include "crc32_fast.h"
 
 using rmr::set_error;
 
@@ -48,6 +50,7 @@ struct rmr_bam {
         int64_t file_off = 0;
         z_stream zs{};
         bool zs_init = false;
+        std::unique_ptr<rmr_inflate::Tables> tables;  // decode tables of the one-shot inflater (fast_inflate.h)
         bool check = true;  // verify the member's CRC32 (off during rmr_bam_scan: whoever reads the records verifies them)
         int rc = 0;
     } slot[kSlots];
@@ -108,7 +111,7 @@ int read_member(rmr_bam *b, rmr_bam::Slot &sl) {
         set_error("corrupt BGZF block size");
         return RMR_ERR_INVALID;
     }
-    sl.cbuf.resize((size_t)sl.clen + 8);
+    sl.cbuf.resize((size_t)sl.clen + 8 + 8);  // + the trailer, + padding the one-shot inflater may read into (fast_inflate.h: 16 bytes)
     if (fread(sl.cbuf.data(), 1, (size_t)sl.clen + 8, b->fh) != (size_t)sl.clen + 8) {
         set_error("truncated BAM file");
         return RMR_ERR_INVALID;
@@ -124,6 +127,15 @@ void inflate_member(rmr_bam::Slot &sl) {
     sl.out.resize(sl.isize);
     sl.rc = 0;
     if (sl.isize == 0) return;  // empty member (e.g. the EOF marker)
+    // the one-shot decoder first (2-3x zlib on BAM records); only where the member's CRC32 is verified anyway, so that a
+    // stream it refuses - or ever got wrong - goes through zlib below
+    static const bool fast = !(getenv("RMR_FAST_INFLATE") && atoi(getenv("RMR_FAST_INFLATE")) == 0);
+    if (fast && sl.check) {
+        if (!sl.tables) sl.tables.reset(new rmr_inflate::Tables);
+        if (rmr_inflate::inflate_raw(sl.cbuf.data(), (size_t)sl.clen, sl.out.data(), sl.isize, *sl.tables) &&
+            rmr_crc::crc32(sl.out.data(), sl.isize) == sl.crc)
+            return;
+    }
     if (!sl.zs_init) {
         if (inflateInit2(&sl.zs, -15) != Z_OK) { sl.rc = 1; return; }
         sl.zs_init = true;
@@ -135,7 +147,7 @@ void inflate_member(rmr_bam::Slot &sl) {
     sl.zs.next_out = sl.out.data();
     sl.zs.avail_out = sl.isize;
     if (inflate(&sl.zs, Z_FINISH) != Z_STREAM_END || sl.zs.avail_out != 0) { sl.rc = 1; return; }
-    if (sl.check && (uint32_t)crc32(crc32(0L, Z_NULL, 0), sl.out.data(), sl.isize) != sl.crc) sl.rc = 2;
+    if (sl.check && rmr_crc::crc32(sl.out.data(), sl.isize) != sl.crc) sl.rc = 2;
 }
 
 // worker w inflates slot w of every generation that has that many members
@@ -739,3 +751,12 @@ int rmr_bam_seek(rmr_bam *b, int64_t voffset) {
 }
 
 }  // extern "C"
+
+// one-shot inflate of a raw deflate stream (tests: the decoder alone, no zlib behind it)
+extern "C" int rmr_inflate_raw(const uint8_t *src, int64_t n, uint8_t *out, int64_t out_len) {
+    if ((!src && n > 0) || (!out && out_len > 0) || n < 0 || out_len < 0) return RMR_ERR_INVALID;
+    std::vector<uint8_t> padded((size_t)n + 16, 0);
+    if (n) memcpy(padded.data(), src, (size_t)n);
+    std::unique_ptr<rmr_inflate::Tables> tb(new rmr_inflate::Tables);
+    return rmr_inflate::inflate_raw(padded.data(), (size_t)n, out, (size_t)out_len, *tb) ? 0 : RMR_ERR_INVALID;
+}

@@ -12,8 +12,6 @@
 // with one code of zero bits = "all literals"), code lengths sent with the plain 4-bit code-length code (symbols 0..15,
 // complete; no run-length symbols: 129 bytes of header per block, 0.2 %); a block that would not shrink is stored
 // (BTYPE 00).  Any inflater reads it; the bytes differ from zlib's Z_HUFFMAN_ONLY output (another, equally valid code).
-#include <zlib.h>
-
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -21,6 +19,7 @@
 #include <vector>
 
 #include "../../include/remora_hip.h"
+#include "crc32_fast.h"
 
 namespace {
 
@@ -155,7 +154,7 @@ size_t bgzf_member(const uint8_t *src, size_t n, uint8_t *out) {
         bw.put(cw[256], len[256]);
         end = bw.finish();
     }
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n), isize = (uint32_t)n;
+    const uint32_t crc = rmr_crc::crc32(src, n), isize = (uint32_t)n;
     memcpy(end, &crc, 4);
     memcpy(end + 4, &isize, 4);
     const size_t total = (size_t)(end + 8 - out);

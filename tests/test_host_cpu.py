@@ -1994,6 +1994,62 @@ def test_bam_parts_join_into_one_valid_bam(tmp_path):
     assert [r.query_name for r in back] == [r.query_name for r in recs]
 
 
+def test_one_shot_inflater_equals_zlib_on_every_kind_of_stream(tmp_path):
+    """rmr_inflate_raw (the native BAM reader's inflater for BGZF members, fast_inflate.h) against zlib: streams of every
+    block type (stored, fixed, dynamic), level and strategy, several blocks per stream, small windows, literal-only and
+    match-heavy data inflate to the same bytes; a wrong output size, a truncated or a bit-flipped stream is refused or -
+    at worst - yields the right NUMBER of bytes (the reader checks the member's CRC32 and falls back to zlib); and the
+    reader gives the same records with and without it."""
+    import ctypes
+    import zlib
+
+    from remora_amd import _lib as L
+    from remora_amd import io as rio
+
+    lib = L.lib()
+
+    def inflate(z, n):
+        out = np.empty(max(n, 1), np.uint8)
+        src = np.frombuffer(z, np.uint8) if len(z) else np.zeros(1, np.uint8)
+        rc = lib.rmr_inflate_raw(src.ctypes.data_as(ctypes.c_void_p), len(z), out.ctypes.data_as(ctypes.c_void_p), n)
+        return rc, out[:n].tobytes()
+
+    rng = np.random.default_rng(3)
+    raw = next(iter(rio.iter_bam_raw_batches(os.path.join(DATA, "mod_mappings.bam"), batch=14)))[0].raw
+    datasets = [b"", b"a", b"ab", bytes(100000), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+                rng.integers(0, 4, 90000, dtype=np.uint8).tobytes(), (rng.geometric(0.05, 120000) % 256).astype(np.uint8).tobytes(),
+                (rng.geometric(0.5, 120001) % 256).astype(np.uint8).tobytes(), b"abcabcabcd" * 7000,
+                b"".join(bytes([i % 256]) * (i % 37 + 1) for i in range(5000)), raw[:300000],
+                open(os.path.join(DATA, "can_mappings.bam"), "rb").read()[:150000]]
+    for data in datasets:
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for wbits in ((-15, -9) if len(data) < 100000 else (-15,)):
+                    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+                    z = b"".join([c.compress(data[: len(data) // 3]), c.flush(zlib.Z_SYNC_FLUSH), c.compress(data[len(data) // 3 :]), c.flush()])
+                    rc, got = inflate(z, len(data))
+                    assert rc == 0 and got == data, (len(data), level, strategy, wbits)
+                    assert inflate(z, len(data) + 1)[0] != 0 and (not data or inflate(z, len(data) - 1)[0] != 0)
+    data = datasets[-2][:60000]
+    z = zlib.compress(data, 6)[2:-4]
+    for _ in range(400):  # nothing here may crash or write beyond the buffer it was given
+        bad = bytearray(z)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        rc, got = inflate(bytes(bad), len(data))
+        assert rc != 0 or len(got) == len(data)
+        assert inflate(z[: int(rng.integers(0, len(z)))], len(data))[0] != 0
+    # the reader: same records whichever inflater (a fresh process per setting: the switch is read once)
+    import subprocess
+    import sys
+
+    prog = ("import sys, hashlib; sys.path.insert(0, %r); from remora_amd import io as rio; h = hashlib.sha256();\n"
+            "for p in sys.argv[1:]:\n    for r in rio.iter_bam_records(p): h.update(bytes(r.raw))\nprint(h.hexdigest())" % ROOT)
+    paths = [os.path.join(DATA, "can_mappings.bam"), os.path.join(DATA, "mod_mappings.bam")]
+    digests = [subprocess.run([sys.executable, "-c", prog] + paths, env=dict(os.environ, RMR_FAST_INFLATE=v), capture_output=True, text=True,
+                              timeout=300).stdout.strip() for v in ("1", "0")]
+    assert digests[0] == digests[1] and len(digests[0]) == 64
+
+
 def test_native_huffman_bgzf_members_are_valid_deflate(tmp_path):
     """rmr_bgzf_huffman (the writer's encoder at `--bam-level 1`: one dynamic-Huffman block per 0xFF00 bytes of payload, no
     LZ77 matches, stored when that would not shrink) against Python's zlib / gzip as the independent inflater: every member
