@@ -17,11 +17,12 @@ namespace rmr_inflate {
 
 constexpr int LIT_PRIMARY = 11, DIST_PRIMARY = 8;
 constexpr int LIT_TABLE = (1 << LIT_PRIMARY) + 288 * 16, DIST_TABLE = (1 << DIST_PRIMARY) + 32 * 128;
-enum Kind : uint32_t { LITERAL = 0, LENGTH = 1, END = 2, LINK = 3, INVALID = 4, DISTANCE = 5, DOUBLE = 6 };
+enum Kind : uint32_t { LITERAL = 0, LENGTH = 1, END = 2, LINK = 3, INVALID = 4, DISTANCE = 5 };
 
 // entry: bits 0-7 code bits consumed by this lookup, 8-11 kind, 12-15 extra bits (lengths / distances; LINK: bits of the
 // second-level table), 16-31 payload (literal, base length, base distance, or first index of the second-level table;
-// DOUBLE: two literals whose codes fit the primary bits together, the first in bits 16-23, the second in 24-31)
+// LITERAL: `extra` = how many literals the entry decodes - one, or two whose codes fit the primary bits together: the first in
+// bits 16-23, the second in 24-31 - so that the decoder's loop has no branch on which of the two it met)
 inline uint32_t entry(uint32_t nbits, uint32_t kind, uint32_t extra, uint32_t payload) {
     return nbits | (kind << 8) | (extra << 12) | (payload << 16);
 }
@@ -119,14 +120,14 @@ inline void add_double_literals(uint32_t *lit) {
         if (((e1 >> 8) & 15) != LITERAL || n1 == 0 || n1 >= (uint32_t)LIT_PRIMARY) continue;
         const uint32_t e2 = single[idx >> n1], n2 = e2 & 255;
         if (((e2 >> 8) & 15) != LITERAL || n2 == 0 || n1 + n2 > (uint32_t)LIT_PRIMARY) continue;
-        lit[idx] = (n1 + n2) | ((uint32_t)DOUBLE << 8) | ((e1 >> 16) & 255) << 16 | ((e2 >> 16) & 255) << 24;
+        lit[idx] = entry(n1 + n2, LITERAL, 2, ((e1 >> 16) & 255) | ((e2 >> 16) & 255) << 8);
     }
 }
 
 inline uint32_t litlen_entry(int s) {
     static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    if (s < 256) return entry(0, LITERAL, 0, (uint32_t)s);
+    if (s < 256) return entry(0, LITERAL, 1, (uint32_t)s);
     if (s == 256) return entry(0, END, 0, 0);
     if (s > 285) return entry(0, INVALID, 0, 0);
     return entry(0, LENGTH, extra[s - 257], base[s - 257]);
@@ -245,22 +246,21 @@ inline bool inflate_raw(const uint8_t *src, size_t n, uint8_t *out, size_t out_l
             for (;;) {
                 if (overrun()) return false;
                 refill();
-                // up to four lookups of literals out of one refill (each consumes at most the 11 primary bits)
+                // up to four lookups of literals out of one refill (each consumes at most the primary bits); one or two
+                // literals per lookup, written as two bytes either way (no branch on the data)
                 uint32_t e = tb.lit[bits & ((1u << LIT_PRIMARY) - 1)];
                 int quick = 0;
                 for (; quick < 4; ++quick) {
-                    const unsigned k = (e >> 8) & 15;
-                    if (k == DOUBLE) {
-                        if (o_end - o < 2) break;
+                    if (((e >> 8) & 15) != LITERAL || (e & 255) == 0) break;
+                    const unsigned nlit = (e >> 12) & 15;
+                    if (o_end - o >= 2) {
                         o[0] = (uint8_t)(e >> 16);
                         o[1] = (uint8_t)(e >> 24);
-                        o += 2;
-                    } else if (k == LITERAL && (e & 255) != 0) {
-                        if (o >= o_end) return false;
-                        *o++ = (uint8_t)(e >> 16);
-                    } else {
-                        break;
+                    } else {  // the last byte of the member
+                        if (nlit > (unsigned)(o_end - o)) return false;
+                        o[0] = (uint8_t)(e >> 16);
                     }
+                    o += nlit;
                     bits >>= (e & 255);
                     cnt -= (e & 255);
                     e = tb.lit[bits & ((1u << LIT_PRIMARY) - 1)];
@@ -271,7 +271,6 @@ inline bool inflate_raw(const uint8_t *src, size_t n, uint8_t *out, size_t out_l
                     refill();
                     e = tb.lit[bits & ((1u << LIT_PRIMARY) - 1)];
                 }
-                if (((e >> 8) & 15) == DOUBLE) return false;  // two more literals are coded and one byte of room is left: not this member's size
                 if (((e >> 8) & 15) == LINK) {
                     bits >>= LIT_PRIMARY;
                     cnt -= LIT_PRIMARY;
@@ -280,7 +279,7 @@ inline bool inflate_raw(const uint8_t *src, size_t n, uint8_t *out, size_t out_l
                 const unsigned kind = (e >> 8) & 15;
                 bits >>= (e & 255);
                 cnt -= (e & 255);
-                if (kind == LITERAL) {
+                if (kind == LITERAL) {  // (a literal with a long code, out of a second-level table)
                     if (o >= o_end || (e & 255) == 0) return false;
                     *o++ = (uint8_t)(e >> 16);
                     continue;
