@@ -112,7 +112,18 @@ size_t bgzf_member(const uint8_t *src, size_t n, uint8_t *out) {
     memcpy(out, head, 16);
     uint8_t *body = out + 18, *end = nullptr;
     uint32_t freq[NSYM] = {0};
-    for (size_t i = 0; i < n; ++i) ++freq[src[i]];
+    {   // four histograms side by side: runs of equal bytes (qualities, move tables) would otherwise serialise on one counter
+        uint32_t h[4][256] = {{0}};
+        size_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            ++h[0][src[i]];
+            ++h[1][src[i + 1]];
+            ++h[2][src[i + 2]];
+            ++h[3][src[i + 3]];
+        }
+        for (; i < n; ++i) ++h[0][src[i]];
+        for (int s = 0; s < 256; ++s) freq[s] = h[0][s] + h[1][s] + h[2][s] + h[3][s];
+    }
     freq[256] = 1;
     uint8_t len[NSYM];
     code_lengths(freq, len);
@@ -150,7 +161,16 @@ size_t bgzf_member(const uint8_t *src, size_t n, uint8_t *out) {
         for (int i = 0; i < 19; ++i) bw.put(order[i] < 16 ? 4 : 0, 3);  // symbols 0..15: 4 bits each (a complete code), 16-18 unused
         for (int s = 0; s < NSYM; ++s) bw.put(bit_reverse(len[s], 4), 4);  // the code of length value v is v itself
         bw.put(bit_reverse(0, 4), 4);                                      // the one distance code: length 0
-        for (size_t i = 0; i < n; ++i) bw.put(cw[src[i]], len[src[i]]);
+        // code and length of a literal in one word; the bit buffer takes two literals (<= 30 bits) per flush test
+        uint32_t lit[256];
+        for (int s = 0; s < 256; ++s) lit[s] = cw[s] | ((uint32_t)len[s] << 16);
+        size_t i = 0;
+        for (; i + 2 <= n; i += 2) {
+            const uint32_t a = lit[src[i]], b = lit[src[i + 1]];
+            const unsigned la = a >> 16, lb = b >> 16;
+            bw.put((a & 0xFFFFu) | ((b & 0xFFFFu) << la), la + lb);
+        }
+        if (i < n) bw.put(cw[src[i]], len[src[i]]);
         bw.put(cw[256], len[256]);
         end = bw.finish();
     }
