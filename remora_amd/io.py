@@ -1841,10 +1841,9 @@ def _bgzf_huffman_native(chunk):
     n = len(chunk)
     out = np.empty(max((n + 0xFEFF) // 0xFF00, 1) * 65311, np.uint8)
     out_len = ctypes.c_int64()
-    src = (ctypes.c_char * n).from_buffer_copy(chunk) if n else None
-    L.check(L.lib().rmr_bgzf_huffman(ctypes.cast(src, ctypes.c_void_p) if n else None, n, 1, out.ctypes.data_as(ctypes.c_void_p), out.size,
-                                     ctypes.byref(out_len)))
-    return out[: out_len.value].tobytes()
+    src = ctypes.cast(ctypes.c_char_p(chunk), ctypes.c_void_p) if n else None  # (`chunk` is a bytes object: read in place)
+    L.check(L.lib().rmr_bgzf_huffman(src, n, 1, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(out_len)))
+    return memoryview(out)[: out_len.value]  # written to the file as it is (no copy into a bytes object)
 
 
 class BamWriter:
