@@ -518,8 +518,11 @@ class RemoraRead:
                              motifs=None):
         fbs = self.focus_bases
         if motifs is not None and fbs is not None:
-            keep = [fb for fb in fbs if any(m.match(self.int_seq, fb) for m in motifs)]
-            saved, self.focus_bases = fbs, np.asarray(keep, dtype=np.int64)
+            fbs_arr = np.asarray(fbs, dtype=np.int64)
+            on_motif = np.zeros(fbs_arr.size, bool)
+            for m in motifs:
+                on_motif |= m.match_many(self.int_seq, fbs_arr)
+            saved, self.focus_bases = fbs, fbs_arr[on_motif]
             try:
                 arrs, _ = extract_chunk_arrays([self], chunk_context, kmer_context_bases, base_start_justify, offset)
             finally:

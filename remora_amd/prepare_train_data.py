@@ -112,7 +112,11 @@ def extract_chunk_arrays_from_reads(read_errs, int_label, motifs, focus_ref_pos,
         foc_off = np.zeros(len(checked) + 1, np.int64)
         for i, (slot, rr) in enumerate(checked):
             fbs = np.asarray(rr.focus_bases if rr.focus_bases is not None else [], dtype=np.int64)
-            fbs = np.asarray([fb for fb in fbs if any(m.match(rr.int_seq, fb) for m in motifs)], dtype=np.int64)
+            if fbs.size:
+                on_motif = np.zeros(fbs.size, bool)
+                for m in motifs:
+                    on_motif |= m.match_many(rr.int_seq, fbs)
+                fbs = fbs[on_motif]
             focus_list.append(fbs)
             labels_list.append(np.asarray(rr.labels)[fbs] if fbs.size else np.zeros(0, np.int64))
             ids += [rr.read_id] * fbs.size

@@ -151,6 +151,19 @@ class Motif:
             pat, en = pat[: len(pat) - en + int_seq.size], int_seq.size
         return all(base in allowed for allowed, base in zip(pat, int_seq[st:en].tolist()))
 
+    def match_many(self, int_seq, positions):
+        """`match` for an array of positions at once -> bool array (same rule at the ends of the sequence)."""
+        positions = np.asarray(positions, dtype=np.int64)
+        ok = np.ones(positions.size, dtype=bool)
+        if not positions.size:
+            return ok
+        last = int_seq.size - 1
+        for po, allowed in enumerate(_allowed_lut(self.raw_motif)):
+            idx = positions + (po - self.focus_pos)
+            inside = (idx >= 0) & (idx <= last)
+            ok &= ~inside | allowed[int_seq[np.clip(idx, 0, max(last, 0))]]
+        return ok
+
     @property
     def possible_kmers(self):
         return ["".join(bs) for bs in product(*(SINGLE_LETTER_CODE[c] for c in self.raw_motif))]

@@ -111,6 +111,28 @@ def test_motif_errors_and_match():
     assert m.focus_base == "C" and m.num_bases_after_focus == 1
 
 
+def test_motif_match_many_equals_match():
+    """The vectorised form used per batch of focus bases agrees with `match` everywhere, motifs hanging over either end
+    and motifs whose focus sits in stripped leading Ns included."""
+    from remora_amd import RemoraError, util
+
+    rng = np.random.default_rng(5)
+    checked = 0
+    for _ in range(1500):
+        n = int(rng.integers(1, 12))
+        seq = rng.integers(-1, 4, n).astype(np.int64)
+        raw = "".join(rng.choice(list("ACGTNRYWH"), int(rng.integers(1, 6))))
+        try:
+            m = util.Motif(raw, int(rng.integers(0, len(raw))))
+        except RemoraError:
+            continue
+        pos = rng.integers(0, n, 6)
+        assert np.array_equal(m.match_many(seq, pos), np.array([m.match(seq, int(p)) for p in pos], bool)), (raw, seq, pos)
+        checked += 1
+    assert checked > 1000
+    assert util.Motif("CG", 0).match_many(seq, np.zeros(0, np.int64)).size == 0
+
+
 def test_post_process_golden():
     from remora_amd import util
 
