@@ -223,6 +223,16 @@ int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const 
                               const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
                               const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len);
 
+/* The signal coordinate of every reference position of one alignment (host code).
+ * replaces: compute_ref_to_signal = map_ref_to_signal(make_sequence_coordinate_mapping(cigar)), src/remora/data_chunks.py:60-122
+ * (called from io.Read.add_alignment, src/remora/io.py:2070-2080), with np.interp's float64 arithmetic: the same integers.
+ * cigar u32[n_ops] as stored in a BAM record (length << 4 | op), taken back to front when `reverse` (a reverse-strand
+ * record: the read-oriented CIGAR); query_to_signal i64[n_knots] (the expanded move table, seq_len + 1 entries).
+ * ref_to_signal receives *n_out = reference length + 1 entries (RMR_ERR_INVALID and *n_out set when cap is smaller).
+ * Errors (RMR_ERR_INVALID, the reference's texts): "Invalid cigar op(s)", "No match operations found in alignment cigar". */
+int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int reverse, const int64_t *query_to_signal, int64_t n_knots,
+                      int64_t *ref_to_signal, int64_t cap, int64_t *n_out);
+
 /* The native BAM reader's own inflater for BGZF members, alone (host code; replaces zlib's inflate under
  * rmr_bam_read_batch, which itself stands in for htslib below pysam, src/remora/io.py:184-358): a raw RFC 1951 stream
  * src[0..n) into exactly out[0..out_len); RMR_ERR_INVALID when the stream is malformed, ends elsewhere or does not fill

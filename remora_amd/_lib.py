@@ -84,6 +84,7 @@ SIGNATURES = {
     "rmr_motif_flags": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),
     "rmr_motif_focus_counts": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rmr_motif_focus_fill": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rmr_ref_to_signal": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "rmr_pack_reads": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),
     "rmr_chunk_fill": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int]),

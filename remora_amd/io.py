@@ -1246,6 +1246,32 @@ def parse_bed(bed_path):
     return regs
 
 
+def _ref_to_signal_of_bam_cigar(cig, is_reverse, query_to_signal, expect):
+    """compute_ref_to_signal for a CIGAR in BAM's uint32 form: one native walk (rmr_ref_to_signal, np.interp's arithmetic: the
+    same integers) instead of two interpolations over arrays of the read's length.  `expect`: the usual size of the result
+    (reference sequence + 1), the first buffer tried."""
+    from .data_chunks import compute_ref_to_signal
+
+    cig = np.ascontiguousarray(cig, dtype=np.uint32)
+    q2s = np.ascontiguousarray(query_to_signal, dtype=np.int64)
+    n = ctypes.c_int64(0)
+    cap = int(expect)
+    for _ in range(2):
+        out = np.empty(max(cap, 1), np.int64)
+        rc = L.lib().rmr_ref_to_signal(cig.ctypes.data, cig.size, int(bool(is_reverse)), q2s.ctypes.data, q2s.size, out.ctypes.data,
+                                       out.size, ctypes.byref(n))
+        if rc == 0:
+            return out[: n.value]
+        if n.value <= out.size:  # not a matter of room
+            break
+        cap = int(n.value)
+    msg = (L.lib().rmr_last_error() or b"").decode(errors="replace")
+    if msg.startswith("cigar with an empty match run"):  # never in a valid BAM; the array form does what numpy does with it
+        ops, lens = (cig & 0xF).astype(np.int64), (cig >> 4).astype(np.int64)
+        return compute_ref_to_signal(query_to_signal=query_to_signal, cigar=(ops[::-1], lens[::-1]) if is_reverse else (ops, lens))
+    raise RemoraError(msg or "rmr_ref_to_signal failed")
+
+
 @dataclasses.dataclass
 class Read:
     """Signal + basecalls + their mapping for one read: the subset of remora.io.Read
@@ -1364,11 +1390,9 @@ class Read:
         if self.ref_reg.ctg is not None and self.ref_seq is not None and self.query_to_signal is not None:
             cig = getattr(rec, "_cigar", None)  # the native reader's uint32 operations: no tuple per operation on the way
             if isinstance(cig, np.ndarray) and cig.size == len(self.cigar):
-                ops, lens = (cig & 0xF).astype(np.int64), (cig >> 4).astype(np.int64)
-                cig = (ops[::-1], lens[::-1]) if rec.is_reverse else (ops, lens)
+                self.ref_to_signal = _ref_to_signal_of_bam_cigar(cig, rec.is_reverse, self.query_to_signal, len(self.ref_seq) + 1)
             else:
-                cig = self.cigar
-            self.ref_to_signal = compute_ref_to_signal(query_to_signal=self.query_to_signal, cigar=cig)
+                self.ref_to_signal = compute_ref_to_signal(query_to_signal=self.query_to_signal, cigar=self.cigar)
             if self.ref_to_signal.size != len(self.ref_seq) + 1:  # knots include the end of the last base
                 raise RemoraError("Discordant ref seq lengths")
             self.ref_reg.end = self.ref_reg.start + self.ref_to_signal.size - 1

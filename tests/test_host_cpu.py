@@ -1885,6 +1885,51 @@ def test_reference_anchored_host_path_from_cigar_arrays(name):
         assert got[0] == got[1] == got[2]
 
 
+def test_native_ref_to_signal_equals_the_two_interpolations():
+    """rmr_ref_to_signal (one walk over BAM's uint32 CIGAR) against compute_ref_to_signal (np.interp twice + floor,
+    src/remora/data_chunks.py:60-122) on random alignments: every operation, zero-length non-match operations, both strands,
+    long deletions / skips (fractional query coordinates), move tables shorter and longer than the CIGAR's query length
+    (np.interp's clamping), a buffer that is too small first; the same integers and the same error texts."""
+    from remora_amd import RemoraError
+    from remora_amd import io as rio
+    from remora_amd.data_chunks import compute_ref_to_signal
+
+    rng = np.random.default_rng(11)
+    compared = 0
+    for trial in range(4000):
+        n_ops = int(rng.integers(1, 14))
+        ops = rng.choice(9, n_ops, p=[0.4, 0.12, 0.12, 0.04, 0.08, 0.04, 0.02, 0.09, 0.09])
+        top = 400 if trial % 7 == 0 else 9
+        lens = rng.integers(1, top, n_ops)
+        if trial % 10 == 0:
+            lens[~np.isin(ops, [0, 7, 8])] = rng.integers(0, 3, int((~np.isin(ops, [0, 7, 8])).sum()))
+        cig = ((lens.astype(np.uint32) << 4) | ops.astype(np.uint32)).astype(np.uint32)
+        rev = bool(rng.integers(0, 2))
+        q_len = int(lens[np.isin(ops, [0, 1, 4, 7, 8])].sum())
+        q2s = np.cumsum(rng.integers(0, 12, max(1, q_len + 1 + int(rng.choice([0, 0, 0, -2, 3]))))).astype(np.int64)
+        o, ln = (ops[::-1], lens[::-1]) if rev else (ops, lens)
+        try:
+            want = compute_ref_to_signal(q2s, (o.astype(np.int64), ln.astype(np.int64)))
+        except RemoraError as e:
+            want = str(e)
+        try:
+            got = rio._ref_to_signal_of_bam_cigar(cig, rev, q2s, expect=int(rng.integers(1, 50)) if trial % 3 == 0 else
+                                                  int(lens[np.isin(ops, [0, 2, 3, 7, 8])].sum()) + 1)
+        except RemoraError as e:
+            got = str(e)
+        if isinstance(want, str) or isinstance(got, str):
+            assert want == got, (ops, lens)
+        else:
+            assert got.dtype == np.int64 and np.array_equal(want, got), (ops, lens, rev)
+            compared += 1
+    assert compared > 3000
+    bad = np.array([(5 << 4) | 9], np.uint32)
+    with pytest.raises(RemoraError, match="Invalid cigar op"):
+        rio._ref_to_signal_of_bam_cigar(bad, False, np.arange(6), 6)
+    with pytest.raises(RemoraError, match="No match operations"):
+        rio._ref_to_signal_of_bam_cigar(np.array([(5 << 4) | 4], np.uint32), False, np.arange(6), 6)
+
+
 def test_batch_trimming_is_python_slicing():
     """io._trim_span (the sp / ts / ns trimming of a whole batch, the array form of `dacs[sp:][ts:ns]` in
     Read.add_alignment, src/remora/io.py:2003-2012) against the slices themselves, bounds beyond every edge included."""
