@@ -135,9 +135,12 @@ class Motif:
         nwin = int_seq.size - m + 1
         if nwin <= 0:
             return np.zeros(0, dtype=np.int64)
-        hit = np.ones(nwin, dtype=bool)
-        for po, allowed in enumerate(_allowed_lut(self.raw_motif)):
-            hit &= allowed[int_seq[po : po + nwin]]  # 5-entry table; index -1 (= N) is never allowed
+        hit = None
+        for po, (codes, allowed) in enumerate(zip(_int_pattern(self.raw_motif), _allowed_lut(self.raw_motif))):
+            window = int_seq[po : po + nwin]
+            # one allowed base: a comparison; several: the 5-entry table, whose index -1 (= N in the sequence) is never allowed
+            here = window == codes[0] if codes.size == 1 else allowed[window]
+            hit = here if hit is None else hit & here
         return np.flatnonzero(hit)
 
     def match(self, int_seq, pos):
