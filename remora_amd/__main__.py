@@ -4,8 +4,8 @@
 --num-reads; `python -m remora_amd validate from_remora_dataset DATASET --model MODEL.pt` (:1800-1960):
 the stored chunks of an on-disk dataset (directory or config) through the model with the model's chunk /
 k-mer contexts, the reference's validation summary line against the stored labels; and `python -m remora_amd dataset prepare`
-(:64-337), the ETL into the on-disk chunk format.  The rest of the reference's `dataset` sub-commands (inspect, make_config,
-merge, head, copy) are bookkeeping outside the hot path and are not rebuilt (SURVEY §2 #16)."""
+(:64-337), the ETL into the on-disk chunk format, with the bookkeeping verbs around that format (`dataset inspect |
+make_config | merge | head | copy`, :359-727: host code over `CoreRemoraDataset` / `RemoraDataset`, no kernel involved)."""
 import argparse
 import os
 import sys
@@ -92,6 +92,135 @@ def _dataset_prepare(args):
         print(f"{cnt:>7,} : {reason}")
     print(f"Extracted {dataset.size:,} chunks -> {args.output_path}")
     print(f"Label distribution: {dataset.label_summary}")
+    return 0
+
+
+def _dataset_inspect(args):
+    """src/remora/parsers.py:359-376."""
+    import json
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+
+    paths, props, hashes = load_dataset(args.remora_dataset_path)
+    dataset = RemoraDataset([CoreRemoraDataset(p, do_check_super_batches=True) for p in paths], props, hashes)
+    print(f"Dataset summary:\n{dataset.summary}")
+    if args.out_path is not None:
+        with open(args.out_path, "w") as fh:
+            json.dump(dataset.get_config(), fh)
+    return 0
+
+
+def _dataset_make_config(args):
+    """src/remora/parsers.py:414-458: default weights are the dataset sizes (chunks drawn uniformly overall)."""
+    import json
+
+    import numpy as np
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+
+    if args.dataset_weights is not None:
+        if len(args.dataset_weights) != len(args.dataset_paths):
+            raise RemoraError("Weights must be same length as input datasets.")
+        if any(w <= 0 for w in args.dataset_weights):
+            raise RemoraError("Weights must be positive.")
+    core_paths, core_weights, core_hashes = [], [], []
+    for i, ds_path in enumerate(args.dataset_paths):
+        paths, weights, hashes = load_dataset(ds_path)
+        core_paths.extend(paths)
+        scale = sum(CoreRemoraDataset(p).size for p in paths) if args.dataset_weights is None else args.dataset_weights[i]
+        core_weights.extend(weights * scale)
+        if hashes is None or core_hashes is None:
+            core_hashes = None
+        else:
+            core_hashes.extend(hashes)
+    core_weights = np.array(core_weights)
+    dataset = RemoraDataset([CoreRemoraDataset(p) for p in core_paths], core_weights / core_weights.sum(), core_hashes)
+    with open(args.out_path, "w") as fh:
+        json.dump(dataset.get_config(), fh)
+    print(dataset.summary)
+    return 0
+
+
+def _dataset_merge(args):
+    """src/remora/parsers.py:493-572: all rows of several datasets (labels converted to the merged label set)
+    copied into one new dataset, optionally capped at --max-size in proportion, then shuffled."""
+    import numpy as np
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, compute_best_split, load_dataset
+    from .util import prepare_out_dir
+
+    prepare_out_dir(args.out_path, args.overwrite)
+    paths = [sub for ds_path in args.dataset_paths for sub in load_dataset(ds_path)[0]]
+    dataset = RemoraDataset([CoreRemoraDataset(p, infinite_iter=False, do_check_super_batches=True) for p in paths],
+                            np.ones(len(paths)) / len(paths))
+    sizes = np.array([ds.size for ds in dataset.datasets])
+    if args.max_size is not None and sizes.sum() > args.max_size:
+        sizes = compute_best_split(args.max_size, sizes / sizes.sum())
+    md = dataset.metadata.copy()
+    md.allocate_size, md.max_seq_len = int(sizes.sum()), max(ds.metadata.max_seq_len for ds in dataset.datasets)
+    md.dataset_start = md.dataset_end = 0
+    merged = CoreRemoraDataset(data_path=args.out_path, mode="w", metadata=md)
+    for ds, size in zip(dataset.datasets, sizes):
+        ds.metadata.dataset_end = ds.metadata.dataset_start + int(size)
+        ds.adjust_batch_params()
+        for sb in ds.iter_super_batches():
+            merged.write_batch(sb)
+        merged.flush()
+    merged.shuffle()
+    merged.flush()
+    print(f"Saved core dataset:\n{merged.summary}")
+    return 0
+
+
+def _dataset_head(args):
+    """src/remora/parsers.py:604-655: the first `num_chunks` rows of a core dataset as a new (shuffled) dataset."""
+    from .data_chunks import CoreRemoraDataset
+    from .util import prepare_out_dir
+
+    prepare_out_dir(args.out_path, args.overwrite)
+    src = CoreRemoraDataset(args.in_path, infinite_iter=False, do_check_super_batches=True)
+    md = src.metadata.copy()
+    md.allocate_size, md.dataset_start, md.dataset_end = args.num_chunks, 0, 0
+    head = CoreRemoraDataset(data_path=args.out_path, mode="w", metadata=md)
+    src.adjust_batch_params()
+    for sb in src.iter_super_batches():
+        room = args.num_chunks - head.metadata.dataset_end
+        if sb["labels"].size >= room:
+            head.write_batch({n: a[:room] for n, a in sb.items()})
+            break
+        head.write_batch(sb)
+    head.flush()
+    head.shuffle()
+    head.flush()
+    print(f"Saved core dataset:\n{head.summary}")
+    return 0
+
+
+def _dataset_copy(args):
+    """src/remora/parsers.py:684-727: every core dataset of a dataset / config copied to OUT/dataset_NNN, with
+    OUT/dataset.cfg pointing at the copies and OUT/sources.txt recording where they came from."""
+    import json
+    import os
+    import shutil
+
+    from .data_chunks import CoreRemoraDataset, RemoraDataset, load_dataset
+    from .util import prepare_out_dir
+
+    prepare_out_dir(args.out_path, args.overwrite)
+    paths, props, hashes = load_dataset(args.in_path)
+    out_dirs = []
+    with open(os.path.join(args.out_path, "sources.txt"), "w") as src_fh:
+        for i, src in enumerate(paths):
+            if any(os.path.isdir(os.path.join(src, item)) for item in os.listdir(src)):
+                raise RemoraError(f"Source dataset has nested directory: {src}")
+            dst = os.path.join(args.out_path, f"dataset_{i:03}")
+            src_fh.write(f"{src}\t{dst}\n")
+            shutil.copytree(src, dst)
+            out_dirs.append(dst)
+    dataset = RemoraDataset([CoreRemoraDataset(d) for d in out_dirs], props, hashes)
+    with open(os.path.join(args.out_path, "dataset.cfg"), "w") as fh:
+        json.dump(dataset.get_config(), fh)
+    print(dataset.summary)
     return 0
 
 
@@ -216,6 +345,33 @@ def main(argv=None):
                    help="one process per GPU, each extracts the chunks of its own share of the BAM; the parts become one dataset")
     d.add_argument("--procs-per-gpu", type=int, default=1)
     d.set_defaults(func=_dataset_prepare)
+    di = dset.add_parser("inspect", help="Summary of a dataset directory or config")
+    di.add_argument("remora_dataset_path")
+    di.add_argument("--out-path", help="write the expanded config (with hashes) here")
+    di.set_defaults(func=_dataset_inspect)
+    dm = dset.add_parser("make_config", help="Config drawing from several datasets at fixed proportions (no data copied)")
+    dm.add_argument("out_path")
+    dm.add_argument("dataset_paths", nargs="+")
+    dm.add_argument("--dataset-weights", type=float, nargs="+")
+    dm.set_defaults(func=_dataset_make_config)
+
+    dg = dset.add_parser("merge", help="Copy several datasets into one new core dataset (shuffled)")
+    dg.add_argument("out_path")
+    dg.add_argument("dataset_paths", nargs="+")
+    dg.add_argument("--max-size", type=int)
+    dg.add_argument("--overwrite", action="store_true")
+    dg.set_defaults(func=_dataset_merge)
+    dh = dset.add_parser("head", help="New core dataset from the first chunks of another")
+    dh.add_argument("out_path")
+    dh.add_argument("in_path")
+    dh.add_argument("num_chunks", type=int)
+    dh.add_argument("--overwrite", action="store_true")
+    dh.set_defaults(func=_dataset_head)
+    dc = dset.add_parser("copy", help="Copy a dataset (all its core datasets + a new config) to a new location")
+    dc.add_argument("in_path")
+    dc.add_argument("out_path")
+    dc.add_argument("--overwrite", action="store_true")
+    dc.set_defaults(func=_dataset_copy)
 
     args = ap.parse_args(argv)
     nranks = getattr(args, "gpus", 1) * max(getattr(args, "procs_per_gpu", 1), 1)

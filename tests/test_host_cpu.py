@@ -985,6 +985,53 @@ def test_map_ref_to_signal_known_answers_of_the_reference_tests():
         np.testing.assert_array_equal(got, want)
 
 
+def test_dataset_cli_merge_head_copy(tmp_path):
+    """`dataset merge`, `dataset head`, `dataset copy` (src/remora/parsers.py:493-727) on three prepared datasets
+    with two different modified bases: the merged dataset holds exactly the union of the rows with the labels
+    converted to the merged label set, `--max-size` caps it in proportion, head takes the first rows, copy
+    reproduces directories + config (hashes verify)."""
+    from golden_util import dataset_rows
+    from remora_amd.__main__ import main
+    from remora_amd.data_chunks import CoreRemoraDataset, RemoraDataset
+
+    dirs = _materialise(tmp_path, ["can_ctrl", "mod_m", "mod_h"])
+    cfg = str(tmp_path / "two.cfg")
+    json.dump([[dirs["mod_m"], 1], [dirs["mod_h"], 1]], open(cfg, "w"))
+    merged = str(tmp_path / "merged")
+    np.random.seed(3)
+    assert main(["dataset", "merge", merged, dirs["can_ctrl"], cfg]) == 0
+    ds = CoreRemoraDataset(merged, infinite_iter=False)
+    assert ds.size == 205 + 210 + 84 and ds.metadata.mod_bases == ["h", "m"] and ds.metadata.max_seq_len == 20
+    np.testing.assert_array_equal(ds.get_label_counts(), [205, 84, 210])
+    _, got = dataset_rows(merged)
+    key = lambda r: sorted(zip(r["read_ids"].tolist(), r["read_focus_bases"].tolist(), r["labels"].tolist(),
+                               r["sequence_lengths"].tolist(), [s.tobytes() for s in r["signal"]]))
+    want = []
+    for name, conv in (("can_ctrl", {0: 0}), ("mod_m", {1: 2}), ("mod_h", {1: 1})):
+        _, rows = dataset_rows(dirs[name])
+        rows["labels"] = np.array([conv[int(x)] for x in rows["labels"]])
+        want += key(rows)
+    assert key(got) == sorted(want)
+    assert main(["dataset", "merge", merged, dirs["can_ctrl"], cfg]) == 1  # exists
+    assert main(["dataset", "merge", merged, dirs["can_ctrl"], cfg, "--overwrite", "--max-size", "100"]) == 0
+    small = CoreRemoraDataset(merged)
+    assert small.size == 100 and list(small.get_label_counts()) == [41, 17, 42]
+    head = str(tmp_path / "head")
+    assert main(["dataset", "head", head, dirs["mod_m"], "37"]) == 0
+    _, hrows = dataset_rows(head)
+    _, src = dataset_rows(dirs["mod_m"])
+    assert sorted(zip(hrows["read_ids"].tolist(), hrows["read_focus_bases"].tolist())) == \
+        sorted(zip(src["read_ids"][:37].tolist(), src["read_focus_bases"][:37].tolist()))
+    copied = str(tmp_path / "copied")
+    three = str(tmp_path / "three.cfg")
+    json.dump([[dirs["can_ctrl"], 2], [cfg, 3]], open(three, "w"))
+    assert main(["dataset", "copy", three, copied]) == 0
+    assert sorted(os.listdir(copied)) == ["dataset.cfg", "dataset_000", "dataset_001", "dataset_002", "sources.txt"]
+    back = RemoraDataset.from_config(os.path.join(copied, "dataset.cfg"), batch_size=50)  # hashes are verified on load
+    np.testing.assert_allclose(back.props, [0.4, 0.3, 0.3])
+    assert back.size == 499 and list(back.get_label_counts()) == [205, 84, 210]
+
+
 def test_batch_params_and_seeded_subsampling_match_reference(tmp_path):
     """adjust_batch_params over a grid of batch / super-batch sizes and sample fractions, and the batches of a
     seeded iteration with super_batch_sample_frac (np.random.choice inside every super batch), finite (including
