@@ -711,6 +711,12 @@ def main():
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own warnings/errors on stderr: the first multi-rank run must be diagnosable
+    # a rank of a multi-GPU run goes onto the socket of its GPU before the process group, its threads or any pinned buffer
+    # exist (dist.bind_rank: NUMA node of the device from sysfs; a single process keeps every core it was given)
+    binding = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        dev0 = args.force_device if args.force_device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+        binding = rdist.bind_rank(dev0)
     ti0 = time.perf_counter()
     try:
         rank, world, local = rdist.init_process_group(args.dist_backend, set_device=args.force_device is None, timeout_s=args.dist_timeout)
@@ -742,7 +748,14 @@ def main():
               f"collective), allreduce_ms {job.allreduce_ms:.3f} (int64[{job.num_out}] label counts, in the timed region)",
               file=sys.stderr, flush=True)
         ms = rdist.allgather_floats([rccl_init_ms, job.allreduce_ms])
-        coll = {"backend": backend, "rccl_init_ms_per_rank": [float(r[0]) for r in ms], "allreduce_ms_per_rank": [float(r[1]) for r in ms]}
+        b = binding or {}
+        print(f"[bench rank {rank}/{world} cuda:{local}] pci {b.get('pci')} numa node {b.get('numa_node')} bound {b.get('bound')} "
+              f"cores {len(b.get('cpus') or [])} helper threads {b.get('threads')}", file=sys.stderr, flush=True)
+        placement = rdist.gather_objects({"rank": rank, "device": local, "pci": b.get("pci"), "numa_node": b.get("numa_node"),
+                                          "bound": b.get("bound"), "cores": len(b.get("cpus") or []), "threads": b.get("threads"),
+                                          "error": b.get("error")})
+        coll = {"backend": backend, "rccl_init_ms_per_rank": [float(r[0]) for r in ms], "allreduce_ms_per_rank": [float(r[1]) for r in ms],
+                "placement_per_rank": placement}
     if rank == 0:
         note(f"timed region done: {job.total_chunks_per_step * args.steps / elapsed / 1e6:.2f} M chunks/s")
     try:

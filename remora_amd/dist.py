@@ -9,6 +9,9 @@ import os
 import numpy as np
 
 
+LAST_BINDING = None  # what bind_rank did for this process (setup_ranks / bench.py), for reports
+
+
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -170,6 +173,132 @@ def launch_ranks(argv, n, scan_bam=None, command=None):
             os.unlink(scan_path)
 
 
+# ---- rank placement: a rank (its helper threads, its pinned staging rings) on the socket its GPU hangs off ----------------
+# The reference has one reader process and nothing to place (src/remora/inference.py:488-519); here every rank feeds its own
+# GPU from host memory (`infer` / `validate` / `dataset prepare` with --gpus N), so on a two-socket node a rank that runs on
+# the far socket crosses the inter-socket link with every H2D byte.  Linux allocates first-touch on the node of the
+# touching thread: binding the rank BEFORE it creates threads or pinned buffers places both.
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of sysfs cpulist files)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_pci_address(device):
+    """'dddd:bb:dd.f' of torch device `device` (from the HIP device properties), or None when the build does not tell."""
+    import torch
+
+    try:
+        p = torch.cuda.get_device_properties(int(device))
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    except Exception:  # noqa: BLE001 - placement is best effort
+        return None
+
+
+def numa_of_pci(addr, sysfs="/sys"):
+    """(numa node, its cpus) of the PCI device `addr`; (-1, []) when sysfs does not say (single socket, VM, container)."""
+    if not addr:
+        return -1, []
+    base = os.path.join(sysfs, "bus", "pci", "devices", addr)
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return -1, []
+    cpus = []
+    if node >= 0:
+        try:
+            cpus = parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+        except (OSError, ValueError):
+            pass
+    if not cpus:
+        try:
+            cpus = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+        except (OSError, ValueError):
+            cpus = []
+    return node, cpus
+
+
+def plan_rank_binding(gpu_addrs, procs_per_gpu=1, allowed_cpus=None, sysfs="/sys", cpu_budget=None):
+    """Placement of every local rank of a `--gpus len(gpu_addrs) --procs-per-gpu P` run, as a pure function of the sysfs
+    tree: [{rank, device, pci, numa_node, cpus, threads}] for local ranks 0 .. G*P-1 (device = rank // P).
+    `cpus`: the allowed cores of the GPU's NUMA node (every allowed core when the node is unknown or none of its cores is
+    allowed); `threads`: helper threads of the rank (OpenMP, the batch gather) = the cores its socket offers it - the
+    node's allowed cores divided by the ranks placed on that node, also bounded by this process's CPU budget (cgroup
+    quota) divided by all ranks - between 2 and 8."""
+    allowed = sorted(set(allowed_cpus)) if allowed_cpus is not None else sorted(os.sched_getaffinity(0))
+    n_ranks = len(gpu_addrs) * max(int(procs_per_gpu), 1)
+    plan = []
+    for r in range(n_ranks):
+        dev = r // max(int(procs_per_gpu), 1)
+        node, cpus = numa_of_pci(gpu_addrs[dev], sysfs)
+        mine = [c for c in cpus if c in set(allowed)]
+        if node < 0 or not mine:
+            node, mine = (node if mine else -1), list(allowed)
+        plan.append(dict(rank=r, device=dev, pci=gpu_addrs[dev], numa_node=node, cpus=mine))
+    on_node = {}
+    for p in plan:
+        on_node[p["numa_node"]] = on_node.get(p["numa_node"], 0) + 1
+    budget = int(cpu_budget) if cpu_budget else len(allowed)
+    for p in plan:
+        share = min(len(p["cpus"]) // on_node[p["numa_node"]], max(budget // max(n_ranks, 1), 1))
+        p["threads"] = max(2, min(8, share))
+    return plan
+
+
+def bind_rank(device, local_rank=None, local_world=None, procs_per_gpu=1, sysfs="/sys", gpu_addrs=None):
+    """Bind THIS process to the cores of the NUMA node of its GPU and size its helper-thread pools for its share of that
+    socket; call it before any thread or pinned buffer exists.  Returns the rank's entry of plan_rank_binding plus
+    `bound` (whether sched_setaffinity was applied).  REMORA_AMD_RANK_BINDING=0 turns it off; never raises.
+    `gpu_addrs` replaces the PCI addresses asked of the HIP runtime (tests)."""
+    info = dict(rank=local_rank, device=device, pci=None, numa_node=-1, cpus=[], threads=None, bound=False)
+    if os.environ.get("REMORA_AMD_RANK_BINDING", "1") == "0":
+        return info
+    try:
+        import torch
+
+        from .util import effective_cpu_count
+
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else int(local_world)
+        n_gpus = max(local_world // max(int(procs_per_gpu), 1), 1)
+        forced = os.environ.get("REMORA_AMD_FORCE_DEVICE")
+        addrs = gpu_addrs if gpu_addrs is not None else [
+            gpu_pci_address(int(forced) if forced is not None else d) if (forced is not None or d < torch.cuda.device_count())
+            else None for d in range(n_gpus)]
+        plan = plan_rank_binding(addrs, procs_per_gpu, sysfs=sysfs, cpu_budget=effective_cpu_count())
+        me = dict(plan[min(local_rank, len(plan) - 1)])
+        me["bound"] = False
+        if me["numa_node"] >= 0 and me["cpus"]:
+            os.sched_setaffinity(0, me["cpus"])
+            # threads that already exist (the HIP runtime's, started by the device query above) do not inherit: bind them too
+            try:
+                for tid in os.listdir("/proc/self/task"):
+                    try:
+                        os.sched_setaffinity(int(tid), me["cpus"])
+                    except (OSError, ValueError):
+                        pass
+            except OSError:
+                pass
+            me["bound"] = True
+        # the thread pools read these when they are created / per call; the launcher's values were sized without the topology
+        os.environ["OMP_NUM_THREADS"] = os.environ["RMR_PACK_THREADS"] = str(me["threads"])
+        try:
+            torch.set_num_threads(me["threads"])
+        except Exception:  # noqa: BLE001
+            pass
+        return me
+    except Exception as e:  # noqa: BLE001 - placement must never cost a run
+        info["error"] = f"{type(e).__name__}: {e}"
+        return info
+
+
 def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):
     """(rank, world, device) of this process for a `--gpus N [--procs-per-gpu P]` command line: (0, 1, None) for a single
     process; under a launcher the process group is created and the device is LOCAL_RANK // P.  P > 1 puts several
@@ -194,6 +323,14 @@ def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):
 
     if torch.cuda.is_available():  # whatever the transport: everything that resolves "the current device" must land on this rank's GPU
         torch.cuda.set_device(device)
+        global LAST_BINDING
+        LAST_BINDING = bind_rank(device, local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), procs_per_gpu)
+        if os.environ.get("RMR_INFER_TIMING") or os.environ.get("REMORA_AMD_PRINT_BINDING"):
+            import sys
+
+            b = LAST_BINDING
+            print(f"[rank {rank}/{world}] cuda:{device} pci {b.get('pci')} numa node {b.get('numa_node')} bound {b.get('bound')} "
+                  f"cores {len(b.get('cpus') or [])} helper threads {b.get('threads')}", file=sys.stderr, flush=True)
     init_process_group(backend, set_device=False, timeout_s=timeout_s)
     return rank, world, device
 

@@ -1650,8 +1650,11 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     d_mv = torch.from_numpy(rb.mv if total_mv else np.zeros(1, np.int8)).to(dev)
     d_off, d_sl, d_ql = (torch.from_numpy(np.ascontiguousarray(x, np.int64)).to(dev) for x in (rb.mv_off, sl_all, seq_len_all))
     d_q2s = torch.empty(max(total_mv, 1), dtype=torch.int64, device=dev)
-    d_cnt = torch.zeros(n_all, dtype=torch.int64, device=dev)
-    d_st = torch.zeros(n_all, dtype=torch.int32, device=dev)
+    # torch.empty, not zeros: a fill would be queued on this thread's torch stream while the kernel runs on the ingest
+    # engine's own (unordered) stream and could land AFTER it; moves_batch_kernel writes counts[b] and status[b] of every
+    # record, tables of length 0 included
+    d_cnt = torch.empty(n_all, dtype=torch.int64, device=dev)
+    d_st = torch.empty(n_all, dtype=torch.int32, device=dev)
     L.check(L.lib().rmr_parse_moves_batch(eng.handle, d_mv.data_ptr(), d_off.data_ptr(), d_sl.data_ptr(), d_ql.data_ptr(), n_all, 1, 0,
                                           d_q2s.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), L.MEM_DEVICE))
     eng.synchronize()

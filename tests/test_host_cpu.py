@@ -2557,3 +2557,84 @@ def test_bam_shares_from_a_c_program(tmp_path, workers):
     assert run.returncode == 0, (run.stdout, run.stderr)
     assert f"{20 * len(recs)} records in the file, {20 * len(recs)} in the shares" in run.stdout
     assert len([ln for ln in run.stdout.splitlines() if ln.startswith("worker ")]) == workers
+
+
+# ---- rank placement (dist.plan_rank_binding / bind_rank): a rank on the socket of its GPU, from a sysfs tree ----
+def _fake_sysfs(root, n_gpus=8):
+    """A two-socket node as sysfs shows it: GPUs 0-3 on node 0, 4-7 on node 1; 256 hardware threads, the second hyperthread
+    of a core 128 above the first (node0 = 0-63,128-191; node1 = 64-127,192-255)."""
+    addrs = []
+    for g in range(n_gpus):
+        addr = f"0000:{0x05 + 0x10 * g:02x}:00.0"
+        d = root / "bus" / "pci" / "devices" / addr
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{g // 4}\n")
+        addrs.append(addr)
+    for k, cl in enumerate(("0-63,128-191", "64-127,192-255")):
+        d = root / "devices" / "system" / "node" / f"node{k}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    return addrs
+
+
+def test_rank_binding_plan_for_8_gpus_x_1_and_x_6(tmp_path):
+    from remora_amd import dist as rdist
+
+    addrs = _fake_sysfs(tmp_path)
+    node_cpus = [set(range(0, 64)) | set(range(128, 192)), set(range(64, 128)) | set(range(192, 256))]
+    # one process per GPU, every core allowed: rank r -> GPU r -> node r // 4, all 128 threads of that socket, 8 helpers
+    plan = rdist.plan_rank_binding(addrs, 1, allowed_cpus=range(256), sysfs=str(tmp_path))
+    assert [p["device"] for p in plan] == list(range(8)) and [p["numa_node"] for p in plan] == [0] * 4 + [1] * 4
+    assert all(set(p["cpus"]) == node_cpus[p["numa_node"]] for p in plan) and all(p["threads"] == 8 for p in plan)
+    # six processes per GPU: 48 ranks, device = rank // 6, 24 ranks per socket share its 128 threads -> 5 helpers each
+    plan = rdist.plan_rank_binding(addrs, 6, allowed_cpus=range(256), sysfs=str(tmp_path))
+    assert len(plan) == 48 and [p["device"] for p in plan] == [r // 6 for r in range(48)]
+    assert [p["numa_node"] for p in plan] == [0] * 24 + [1] * 24 and all(p["threads"] == 5 for p in plan)
+    assert all(set(p["cpus"]) == node_cpus[p["numa_node"]] for p in plan)
+    # a CPU quota of 16 cores (the GPU boxes of this pool): binding as before, helpers = the quota's share, floor 2
+    plan = rdist.plan_rank_binding(addrs, 1, allowed_cpus=range(256), sysfs=str(tmp_path), cpu_budget=16)
+    assert [p["numa_node"] for p in plan] == [0] * 4 + [1] * 4 and all(p["threads"] == 2 for p in plan)
+    # a cpuset that only holds cores of node 0: node-1 ranks are not bound to cores they may not use
+    plan = rdist.plan_rank_binding(addrs, 1, allowed_cpus=range(16), sysfs=str(tmp_path))
+    assert [p["numa_node"] for p in plan] == [0] * 4 + [-1] * 4 and all(p["cpus"] == list(range(16)) for p in plan)
+    # no topology in sysfs (single socket, VM): nobody is bound, every rank sees every allowed core
+    plan = rdist.plan_rank_binding([None] * 8, 1, allowed_cpus=range(32), sysfs=str(tmp_path))
+    assert all(p["numa_node"] == -1 and p["cpus"] == list(range(32)) and p["threads"] == 4 for p in plan)
+    assert rdist.numa_of_pci("0000:ff:00.0", str(tmp_path)) == (-1, [])
+
+
+def test_bind_rank_applies_the_plan_to_the_process(tmp_path):
+    """bind_rank in a child process (its affinity must not leak into the test runner): the node of the rank's GPU holds half
+    of the cores the child may use; afterwards the child - and a thread it starts - may run on exactly those."""
+    import subprocess
+
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("needs two usable cores")
+    half = allowed[: len(allowed) // 2]
+    for g in range(2):
+        d = tmp_path / "bus" / "pci" / "devices" / f"0000:0{g}:00.0"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{g}\n")
+    for k, cpus in enumerate((half, allowed[len(allowed) // 2:])):
+        d = tmp_path / "devices" / "system" / "node" / f"node{k}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    code = (
+        "import os, sys, json, threading; sys.path.insert(0, %r)\n"
+        "from remora_amd import dist as rdist\n"
+        "b = rdist.bind_rank(0, local_rank=0, local_world=2, sysfs=%r, gpu_addrs=['0000:00:00.0', '0000:01:00.0'])\n"
+        "seen = []\n"
+        "t = threading.Thread(target=lambda: seen.append(sorted(os.sched_getaffinity(0)))); t.start(); t.join()\n"
+        "print(json.dumps(dict(b=b, mine=sorted(os.sched_getaffinity(0)), thread=seen[0], omp=os.environ['OMP_NUM_THREADS'],"
+        " pack=os.environ['RMR_PACK_THREADS'])))\n" % (ROOT, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["b"]["bound"] and got["b"]["numa_node"] == 0 and got["mine"] == half and got["thread"] == half
+    assert got["omp"] == got["pack"] == str(got["b"]["threads"]) and 2 <= got["b"]["threads"] <= 8
+    # switched off: nothing is touched
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, REMORA_AMD_RANK_BINDING="0", OMP_NUM_THREADS="3", RMR_PACK_THREADS="3"))
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert not got["b"]["bound"] and got["mine"] == allowed and got["omp"] == "3"
