@@ -48,8 +48,8 @@ OTHER_CONFIGS = [
     ("conv_c100", "conv_c100", None, None),
     ("convlstm_c100_bf16", "convlstm_c100", "bf16", None),
     ("convlstm_c100_bf16_10m", "convlstm_c100_bf16_10m", None, None),
+    ("convlstm_c200_fp32", "convlstm_c200_bf16", "fp32", None),  # before the 16-bit runs of its shape: their parity block compares with it
     ("convlstm_c200_bf16", "convlstm_c200_bf16", None, None),
-    ("convlstm_c200_fp32", "convlstm_c200_bf16", "fp32", None),
     ("convlstm_c100_f16", "convlstm_c100", "f16", None),
     ("convlstm_c200_f16", "convlstm_c200_bf16", "f16", None),
     ("convlstm_c100_bf16x6", "convlstm_c100", "bf16x6", None),
@@ -323,6 +323,58 @@ def cpu_baseline(state, data, kcb, budget_s=12.0):
         "forms": forms, "thread_probe_chunks_per_s": {str(k): v for k, v in tuned.items()},
         "encode_chunks_per_s": med.get("encode_chunks_per_s"), "model_chunks_per_s": med.get("model_chunks_per_s"),
     }
+
+# Specified parity gates per dtype (round-4 review item 7; SURVEY §7 "hard parts"): fp32-class paths by the logit error against
+# the oracle's fp32 forward, 16-bit paths by the share of confident calls (fp32 margin > 2e-2) they reproduce.
+PARITY_GATES = {
+    "fp32": {"max_abs_vs_oracle": 1e-4}, "bf16x6": {"max_abs_vs_oracle": 1e-4}, "f16x3": {"max_abs_vs_oracle": 1e-4},
+    "bf16x3": {"max_abs_vs_oracle": 5e-4},
+    "f16": {"argmax_agreement_margin_gt_2e-2": 0.9999}, "bf16": {"argmax_agreement_margin_gt_2e-2": 0.998},
+}
+PARITY_SAMPLE = 20_000
+
+
+def config_parity(job, fp32_logits=None):
+    """`parity` of one configuration: its logits on the first PARITY_SAMPLE chunks of rank 0's data against the ORACLE's fp32
+    forward (CPU: C restatement of the encode + torch.nn restatement of the network - not this library), and, where the fp32
+    GPU path of the same workload ran in this process (`fp32_logits`, device), over EVERY chunk of the step against it; the
+    gate of the dtype (PARITY_GATES) and whether it is met."""
+    import torch
+
+    from oracle import oracle as O
+    from oracle import torch_ref
+    from remora_amd.util import effective_cpu_count
+
+    k = min(PARITY_SAMPLE, job.n)
+    d = job.data
+    enc = O.compute_encoded_kmer_batch(job.kcb[0], job.kcb[1], d["sequence"][:k], d["sequence_to_signal_mapping"][:k], d["sequence_lengths"][:k])
+    torch.set_num_threads(min(32, effective_cpu_count()))
+    with torch.no_grad():
+        ref = torch_ref.from_state(job.state)(torch.from_numpy(d["signal"][:k]), torch.from_numpy(enc)).numpy()
+    got = job.logits[:k].cpu().numpy()
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-2
+    agree = got.argmax(1) == ref.argmax(1)
+    out = {"comparand": "oracle fp32 forward (CPU restatement)", "sample_chunks": int(k), "max_abs_vs_oracle": float(np.abs(got - ref).max()),
+           "mean_abs_vs_oracle": float(np.abs(got - ref).mean()), "sample_chunks_with_margin_gt_2e-2": int(clear.sum()),
+           "sample_argmax_agreement_margin_gt_2e-2": float(agree[clear].mean()) if clear.any() else None}
+    if fp32_logits is not None and fp32_logits.shape == job.logits.shape and job.dtype != "fp32":
+        top = fp32_logits.topk(2, dim=1).values
+        clr = (top[:, 0] - top[:, 1]) > 2e-2
+        ag = job.logits.argmax(1) == fp32_logits.argmax(1)
+        dd = (job.logits - fp32_logits).abs()
+        out.update({"all_chunks": int(job.logits.shape[0]), "all_chunks_comparand": "fp32 GPU path of the same workload",
+                    "max_abs_vs_fp32_path": float(dd.max()), "chunks_with_margin_gt_2e-2": int(clr.sum()),
+                    "argmax_agreement_margin_gt_2e-2": float(ag[clr].float().mean()) if bool(clr.any()) else None,
+                    "argmax_agreement_all": float(ag.float().mean())})
+    gate = PARITY_GATES.get(job.dtype, {})
+    out["gate"] = gate
+    met = True
+    for key, lim in gate.items():
+        val = out.get(key, out.get("sample_" + key))
+        met = met and val is not None and (val <= lim if key.startswith("max_abs") else val >= lim)
+    out["gate_met"] = bool(met)
+    return out
 
 
 class Job:
@@ -844,6 +896,8 @@ def main():
                         kept[(wl, j.dtype)] = j.logits
                     others[key] = {k: r[k] for k in ("value", "unit", "ms_per_step", "dtype", "scaling", "config", "roofline", "kernels")}
                     others[key]["steps"] = min(args.steps, 5)
+                    if not args.no_cpu_baseline:  # the oracle is the checker here, never the thing measured
+                        others[key]["parity"] = config_parity(j, kept.get((wl, "fp32")) if j.n <= BLOCK else None)
                     if not args.no_reads:  # what a host-fed caller gets from this configuration (PCIe-inclusive; never `value`)
                         others[key]["host_buffers_pcie_inclusive"] = j.host_buffers_leg(j.logits)
                     note(f"other config {key}: {r['value'] / 1e6:.2f} M chunks/s, {r['roofline']['kernel']} {r['roofline']['frac']:.2f} of peak")

@@ -331,6 +331,9 @@ typedef struct {
     const int64_t *focus_bases; /* concatenated, read-local */
     const int64_t *focus_off;   /* [n_reads+1] */
     int32_t cc_before, cc_after, kb, ka, base_start_justify, offset;
+    /* base_start_justify == 2: focus_bases holds SIGNAL indices (the focus_sig_idx argument of RemoraRead.extract_chunk,
+     * src/remora/data_chunks.py:331-343) and `offset` is the read_focus_base the chunks report - no clipping, no mapping
+     * look-up */
     /* optional (all three or NULL): HOST copies of sig_off / seq_off / focus_off for callers whose arrays are device
      * memory - the library needs the offsets on the host (launch sizes, staging) and otherwise fetches them with three
      * small device-to-host copies per call (about 60 us of a single-read call) */
@@ -362,6 +365,30 @@ int rmr_forward(rmr_model *m, const float *sigs, const float *seqs, int64_t n, f
 int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int seq_w,
                      const int16_t *maps, int map_w, const int16_t *lens, int kb, int ka,
                      int64_t n, float *logits, int64_t *label_counts, int mem);
+
+/* ---- one read, one call ------------------------------------------------------------------- */
+/* replaces: what `call_read_mods` does for ONE read between its motif search and its return
+ * (src/remora/inference.py:661-712): RemoraRead.prepare_batches -> an in-memory CoreRemoraDataset of the read's chunks
+ * (src/remora/data_chunks.py:468-514: sig :191-197, iter_chunks :425-466, extract_chunk :331-423, write_chunk
+ * :1376-1418, compute_encoded_kmer_batch) and RemoraRead.run_model (:516-540) - staging, signal normalisation, chunk
+ * geometry and rows, and the network in one call with ONE stream synchronisation (the chunk geometry is integer arithmetic on
+ * the mapping and is computed on the host while the arrays cross PCIe), no Python in between.
+ * All pointers are HOST memory.  focus_bases: read-local base indices in the order the caller wants the chunks (the
+ * reference's python-set order is the caller's business); logits f32[n_focus, num_out] and read_focus_bases
+ * i64[n_focus] (the focus base after `offset`, clipped into the read, :443-446) are written in that order. */
+typedef struct {
+    const int16_t *dacs;        /* [n_sig] */
+    int64_t n_sig;
+    const int64_t *seq_to_sig;  /* [n_bases + 1] */
+    const void *int_seq;        /* [n_bases] integers of seq_itemsize bytes (1, 2, 4 or 8), values -1..3 */
+    int32_t seq_itemsize, _pad;
+    int64_t n_bases;
+    double shift, scale;
+    const int64_t *focus_bases; /* [n_focus] */
+    int64_t n_focus;
+    int32_t cc_before, cc_after, kb, ka, base_start_justify, offset;
+} rmr_read;
+int rmr_call_read(rmr_model *m, const rmr_read *read, float *logits, int64_t *read_focus_bases);
 
 /* argmax histogram of existing logits (same rule), counts[num_out] incremented. */
 int rmr_count_labels(rmr_engine *e, const float *logits, int64_t n, int num_out,

@@ -38,6 +38,14 @@ class MotifSet(ctypes.Structure):
                 ("mask", (ctypes.c_uint8 * 16) * 8)]
 
 
+class Read(ctypes.Structure):
+    """rmr_read (include/remora_hip.h): one read for rmr_call_read, host pointers."""
+    _fields_ = [("dacs", c_vp), ("n_sig", c_i64), ("seq_to_sig", c_vp), ("int_seq", c_vp), ("seq_itemsize", ctypes.c_int32),
+                ("_pad", ctypes.c_int32), ("n_bases", c_i64), ("shift", ctypes.c_double), ("scale", ctypes.c_double),
+                ("focus_bases", c_vp), ("n_focus", c_i64), ("cc_before", ctypes.c_int32), ("cc_after", ctypes.c_int32),
+                ("kb", ctypes.c_int32), ("ka", ctypes.c_int32), ("base_start_justify", ctypes.c_int32), ("offset", ctypes.c_int32)]
+
+
 class Reads(ctypes.Structure):
     _fields_ = [
         ("n_reads", c_i64), ("dacs", c_vp), ("sig_off", c_vp), ("seq_to_sig", c_vp),
@@ -90,6 +98,7 @@ SIGNATURES = {
     "rmr_chunk_fill": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int]),
     "rmr_forward": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int]),
     "rmr_infer_chunks": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_int]),
+    "rmr_call_read": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "rmr_count_labels": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int]),
     "rmr_validation_tally": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rmr_comm_unique_id": (c_int, [c_vp]),

@@ -8,6 +8,7 @@
 // are rebuilt from query + CIGAR + MD (what pysam's get_reference_sequence returns, mismatches in lower case).
 //
 // Host code only (no device work): plain C++17 + zlib, part of libremora_hip.so.
+#include <array>
 #include <zlib.h>
 
 #include <algorithm>
@@ -62,6 +63,13 @@ struct rmr_bam {
     uint64_t generation = 0;
     int n_active = 0, n_pending = 0;
     bool stop = false;
+    // one generation of members is inflated AHEAD of the parser: dispatched when the previous one has been appended to ubuf,
+    // collected when the parser runs out of bytes (the parse of a batch - copies, base decoding, tag walk - is serial and
+    // costs as much as the inflate; before, the two took turns)
+    bool inflight = false;
+    int inflight_n = 0;
+    int dispatch_err = 0;
+    std::string dispatch_msg;
     std::vector<uint8_t> header;  // everything before the first record (magic, text, references)
     int64_t first_voffset = -1;   // of the first record (-1: the file holds none)
     std::vector<std::string> refs;
@@ -170,9 +178,8 @@ void worker_loop(rmr_bam *b, int w) {
     }
 }
 
-// reads up to kSlots members, inflates them in parallel, appends the bytes to b->ubuf in file order;
-// returns the number of members read (0 = clean EOF) or a negative error
-int next_blocks(rmr_bam *b) {
+// reads up to nslots members and hands them to the workers; returns their number (0 = clean EOF) or a negative error
+int dispatch(rmr_bam *b) {
     int n = 0, rc = 1;
     while (n < b->nslots) {
         rc = read_member(b, b->slot[n]);
@@ -182,23 +189,49 @@ int next_blocks(rmr_bam *b) {
     }
     if (rc < 0) return rc;
     if (n == 0) return 0;
-    if (n > 1) {
-        if (b->workers.empty()) {
-            for (int w = 1; w < b->nslots; ++w) b->workers.emplace_back(worker_loop, b, w);
-        }
-        {
-            std::lock_guard<std::mutex> lk(b->mu);
-            b->n_active = n;
-            b->n_pending = n - 1;
-            ++b->generation;
-        }
-        b->cv_work.notify_all();
-        inflate_member(b->slot[0]);
+    if (b->workers.empty())
+        for (int w = 0; w < b->nslots; ++w) b->workers.emplace_back(worker_loop, b, w);
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->n_active = n;
+        b->n_pending = n;
+        ++b->generation;
+    }
+    b->cv_work.notify_all();
+    b->inflight = true;
+    b->inflight_n = n;
+    return n;
+}
+
+// waits for the generation in flight (if any) and forgets it: in front of every reposition of the file
+void drop_inflight(rmr_bam *b) {
+    if (b->inflight) {
         std::unique_lock<std::mutex> lk(b->mu);
         b->cv_done.wait(lk, [&] { return b->n_pending == 0; });
-    } else {
-        inflate_member(b->slot[0]);
+        b->inflight = false;
     }
+    b->dispatch_err = 0;
+}
+
+// appends the next generation of inflated members to b->ubuf in file order and sends the one after it on its way;
+// returns the number of members appended (0 = clean EOF) or a negative error
+int next_blocks(rmr_bam *b) {
+    if (b->dispatch_err) {  // the read-ahead failed last time: reported now that the parser has come this far
+        const int rc = b->dispatch_err;
+        b->dispatch_err = 0;
+        set_error("%s", b->dispatch_msg.c_str());
+        return rc;
+    }
+    if (!b->inflight) {
+        const int rc = dispatch(b);
+        if (rc <= 0) return rc;
+    }
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv_done.wait(lk, [&] { return b->n_pending == 0; });
+    }
+    b->inflight = false;
+    const int n = b->inflight_n;
     if (b->upos > 0 && b->upos >= b->ubuf.size() / 2) {  // compact the consumed prefix before growing
         const size_t cut = b->upos;
         b->ubuf.erase(b->ubuf.begin(), b->ubuf.begin() + (ptrdiff_t)cut);
@@ -219,6 +252,11 @@ int next_blocks(rmr_bam *b) {
         }
         if (b->slot[k].isize) b->segs.push_back({b->ubuf.size(), b->slot[k].file_off, b->slot[k].isize});
         b->ubuf.insert(b->ubuf.end(), b->slot[k].out.begin(), b->slot[k].out.end());
+    }
+    const int ahead = dispatch(b);  // the slots are free again: the next generation inflates while the caller parses this one
+    if (ahead < 0) {
+        b->dispatch_err = ahead;
+        b->dispatch_msg = rmr_last_error();
     }
     return n;
 }
@@ -440,6 +478,7 @@ bool rebuild_reference(const char *query, size_t l_seq, const uint32_t *cig, siz
 }
 
 void stop_workers(rmr_bam *b) {
+    drop_inflight(b);
     {
         std::lock_guard<std::mutex> lk(b->mu);
         b->stop = true;
@@ -565,13 +604,21 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         b->name_off.push_back((int64_t)b->names.size());
         p += l_read_name;
         const size_t cig0 = b->cigar.size();
-        for (int k = 0; k < n_cig; ++k) b->cigar.push_back(rd_u32(p + 4 * k));
+        b->cigar.resize(cig0 + (size_t)n_cig);
+        if (n_cig) memcpy(b->cigar.data() + cig0, p, 4 * (size_t)n_cig);  // (BAM is little-endian, as every host this builds for)
         p += 4 * (size_t)n_cig;
         const size_t seq0 = b->seq.size();
         b->seq.resize(seq0 + (size_t)l_seq);
-        for (int64_t k = 0; k < l_seq; ++k) {
-            const uint8_t byte = p[k >> 1];
-            b->seq[seq0 + (size_t)k] = NT16[(k & 1) ? (byte & 0xF) : (byte >> 4)];
+        {   // two bases per packed byte through a 256-entry table of character pairs
+            static const std::array<uint16_t, 256> pair = [] {
+                std::array<uint16_t, 256> t{};
+                for (int v = 0; v < 256; ++v) t[(size_t)v] = (uint16_t)((uint8_t)NT16[v >> 4] | ((uint16_t)(uint8_t)NT16[v & 0xF] << 8));
+                return t;
+            }();
+            char *dst = b->seq.data() + seq0;
+            const int64_t full = l_seq >> 1;
+            for (int64_t k = 0; k < full; ++k) memcpy(dst + 2 * k, &pair[p[k]], 2);
+            if (l_seq & 1) dst[l_seq - 1] = NT16[p[full] >> 4];
         }
         b->seq_off.push_back((int64_t)b->seq.size());
         p += (l_seq + 1) / 2 + l_seq;  // packed bases + qualities
@@ -696,6 +743,7 @@ int rmr_bam_guess_start(rmr_bam *b, int64_t file_offset, int64_t *voffset) {
         *voffset = b->first_voffset;
         return rmr_bam_seek(b, b->first_voffset);
     }
+    drop_inflight(b);
     if (fseeko(b->fh, 0, SEEK_END) != 0) RMR_FAIL(RMR_ERR_INVALID, "seek failed");
     const int64_t fsize = (int64_t)ftello(b->fh);
     if (file_offset >= fsize) return 0;
@@ -737,6 +785,7 @@ int rmr_bam_guess_start(rmr_bam *b, int64_t file_offset, int64_t *voffset) {
 
 int rmr_bam_seek(rmr_bam *b, int64_t voffset) {
     if (!b || voffset < 0) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    drop_inflight(b);
     if (fseeko(b->fh, (off_t)(voffset >> 16), SEEK_SET) != 0) RMR_FAIL(RMR_ERR_INVALID, "seek failed");
     b->ubuf.clear();
     b->segs.clear();

@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "rmr_internal.h"
+#include "rmr_geometry.h"
 
 namespace rmr {
 
@@ -57,6 +58,25 @@ int rmr_engine::ensure_pinned(size_t bytes) {
         return RMR_ERR_HIP;
     }
     pinned_cap = bytes;
+    return 0;
+}
+
+int rmr_engine::ensure_pin_call(size_t bytes) {
+    if (bytes <= pin_call_cap) return 0;
+    if (pin_call) {
+        RMR_HIP(hipStreamSynchronize(stream));
+        RMR_HIP(hipHostFree(pin_call));
+        pin_call = nullptr;
+        pin_call_cap = 0;
+    }
+    bytes = bytes + bytes / 2 + (1 << 16);
+    hipError_t err = hipHostMalloc(&pin_call, bytes, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        pin_call = nullptr;
+        set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return RMR_ERR_HIP;
+    }
+    pin_call_cap = bytes;
     return 0;
 }
 
@@ -446,7 +466,7 @@ int rmr_engine::prof_collect() {
 extern "C" {
 
 const char *rmr_last_error(void) { return g_err.c_str(); }
-const char *rmr_version(void) { return "remora_hip 0.3 (gfx950)"; }  // 0.3: rmr_bam_scan
+const char *rmr_version(void) { return "remora_hip 0.4 (gfx950)"; }  // 0.4: rmr_call_read
 
 int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
     if (!out) RMR_FAIL(RMR_ERR_INVALID, "out is NULL");
@@ -497,6 +517,7 @@ void rmr_engine_destroy(rmr_engine *e) {
         e->comm = nullptr;
     }
     if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->pin_call) (void)hipHostFree(e->pin_call);
     for (auto &r : e->recs) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->act.ptr) (void)hipFree(e->act.ptr);
@@ -1840,6 +1861,99 @@ int rmr_forward(rmr_model *m, const float *sigs, const float *seqs, int64_t n, f
     RMR_TRY(run_pipeline(m, ds, dq, nullptr, 0, nullptr, 0, nullptr, 0, 0, n, dl));
     D2H(logits, dl, n * no * 4);
     RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ---- one read, one call: staging + X1-X3 + the network, ONE stream synchronisation -------------------------------------
+int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_focus_bases) {
+    if (!m || !r || !logits || !read_focus_bases) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (r->n_focus <= 0) return 0;
+    if (!r->dacs || !r->seq_to_sig || !r->int_seq || !r->focus_bases) RMR_FAIL(RMR_ERR_INVALID, "NULL array in rmr_read");
+    if (r->n_sig <= 0 || r->n_bases <= 0) RMR_FAIL(RMR_ERR_INVALID, "empty read");
+    if (r->seq_itemsize != 1 && r->seq_itemsize != 2 && r->seq_itemsize != 4 && r->seq_itemsize != 8)
+        RMR_FAIL(RMR_ERR_INVALID, "int_seq itemsize %d not in {1,2,4,8}", r->seq_itemsize);
+    if (r->kb < 0 || r->ka < 0 || r->kb + r->ka + 1 != m->desc.kmer_len)
+        RMR_FAIL(RMR_ERR_INVALID, "kmer context (%d,%d) does not match model kmer_len %d", r->kb, r->ka, m->desc.kmer_len);
+    if (r->cc_before + r->cc_after != m->L)
+        RMR_FAIL(RMR_ERR_INVALID, "chunk context (%d,%d) does not match model chunk_len %d", r->cc_before, r->cc_after, m->L);
+    rmr_engine *e = m->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    const int64_t ns = r->n_sig, nb = r->n_bases, nc = r->n_focus;
+    const int no = m->desc.num_out, L = m->L;
+    // one blob, host (pinned) and device images with the same offsets: everything the extraction kernels read
+    size_t off = 0;
+    auto seg = [&off](size_t bytes) { const size_t o = off; off += Stage::pad(bytes); return o; };
+    const size_t o_dacs = seg(ns * 2 + 16), o_map = seg((nb + 1) * 8), o_seq = seg(nb + 16), o_foc = seg(nc * 8), o_off = seg(6 * 8),
+                 o_sc = seg(2 * 8), o_cr = seg((nc + 1) * 4), o_geo = seg(nc * 48), in_bytes = off;
+    const size_t out_bytes = Stage::pad((size_t)nc * no * 4) + 256;
+    RMR_TRY(e->ensure_pin_call(in_bytes + out_bytes));
+    char *hp = reinterpret_cast<char *>(e->pin_call);
+    // the big pieces first and on their way; the geometry of the chunks (integer arithmetic on the mapping: the function the
+    // geometry kernel runs, rmr_geometry.h) is computed on the host while they cross PCIe - the widths of the chunk rows are
+    // then known without asking the GPU, and the whole call is queued behind one another with a single wait at the end
+    Stage st{e};
+    memcpy(hp + o_dacs, r->dacs, (size_t)ns * 2);
+    memcpy(hp + o_map, r->seq_to_sig, (size_t)(nb + 1) * 8);
+    const int64_t *map = reinterpret_cast<const int64_t *>(hp + o_map);
+    {
+        int8_t *q = reinterpret_cast<int8_t *>(hp + o_seq);
+        switch (r->seq_itemsize) {
+        case 1: memcpy(q, r->int_seq, (size_t)nb); break;
+        case 2: { const int16_t *s = reinterpret_cast<const int16_t *>(r->int_seq); for (int64_t i = 0; i < nb; ++i) q[i] = (int8_t)s[i]; } break;
+        case 4: { const int32_t *s = reinterpret_cast<const int32_t *>(r->int_seq); for (int64_t i = 0; i < nb; ++i) q[i] = (int8_t)s[i]; } break;
+        default: { const int64_t *s = reinterpret_cast<const int64_t *>(r->int_seq); for (int64_t i = 0; i < nb; ++i) q[i] = (int8_t)s[i]; } break;
+        }
+    }
+    memcpy(hp + o_foc, r->focus_bases, (size_t)nc * 8);
+    int64_t *ho = reinterpret_cast<int64_t *>(hp + o_off);
+    ho[0] = 0; ho[1] = ns; ho[2] = 0; ho[3] = nb; ho[4] = 0; ho[5] = nc;
+    double *hs = reinterpret_cast<double *>(hp + o_sc);
+    hs[0] = r->shift; hs[1] = r->scale;
+    memset(hp + o_cr, 0, (size_t)(nc + 1) * 4);  // every chunk belongs to read 0
+    int64_t *hgeo = reinterpret_cast<int64_t *>(hp + o_geo);
+    int64_t msl = 0;
+    for (int64_t i = 0; i < nc; ++i) {
+        const int64_t sl = chunk_geometry_row(map, nb, ns, r->focus_bases[i], r->base_start_justify, r->offset, r->cc_before, r->cc_after,
+                                              hgeo + i * 6);
+        msl = sl > msl ? sl : msl;
+        read_focus_bases[i] = hgeo[i * 6 + 3];
+    }
+    if (msl > nb + 1 || msl > 32000) RMR_FAIL(RMR_ERR_INVALID, "chunk of %lld bases", (long long)msl);
+    const int seq_w = (int)std::max<int64_t>(msl + r->kb + r->ka, r->kb + r->ka + 1), map_w = (int)std::max<int64_t>(msl + 1, 2);
+    RMR_TRY(st.init(in_bytes + Stage::pad(ns * 4 + 16) + Stage::pad((size_t)nc * L * 4) + Stage::pad((size_t)nc * seq_w) +
+                    Stage::pad((size_t)nc * map_w * 2) + Stage::pad(nc * 2) + Stage::pad(nc * 8) + Stage::pad((size_t)nc * no * 4) + 8192));
+    char *dp = st.take<char>(in_bytes);
+    RMR_HIP(hipMemcpyAsync(dp, hp, in_bytes, hipMemcpyHostToDevice, e->stream));
+    rmr_reads d{};
+    d.n_reads = 1;
+    d.dacs = reinterpret_cast<const int16_t *>(dp + o_dacs);
+    d.seq_to_sig = reinterpret_cast<const int64_t *>(dp + o_map);
+    d.int_seq = reinterpret_cast<const int8_t *>(dp + o_seq);
+    d.focus_bases = reinterpret_cast<const int64_t *>(dp + o_foc);
+    d.sig_off = reinterpret_cast<const int64_t *>(dp + o_off);
+    d.seq_off = d.sig_off + 2;
+    d.focus_off = d.sig_off + 4;
+    d.shift = reinterpret_cast<const double *>(dp + o_sc);
+    d.scale = d.shift + 1;
+    d.cc_before = r->cc_before; d.cc_after = r->cc_after; d.kb = r->kb; d.ka = r->ka;
+    d.base_start_justify = r->base_start_justify; d.offset = r->offset;
+    const int32_t *chunk_read = reinterpret_cast<const int32_t *>(dp + o_cr);
+    const int64_t *dgeo = reinterpret_cast<const int64_t *>(dp + o_geo);
+    float *dsig = st.take<float>(ns + 4);
+    float *dsignal = st.take<float>((size_t)nc * L);
+    int8_t *dseqs = st.take<int8_t>((size_t)nc * seq_w);
+    int16_t *dmaps = st.take<int16_t>((size_t)nc * map_w);
+    int16_t *dlens = st.take<int16_t>(nc);
+    int64_t *drfb = st.take<int64_t>(nc);
+    float *dlog = st.take<float>((size_t)nc * no);
+    RMR_TRY(launch_geometry(e, d, 0, chunk_read, dsig, ns, nullptr, nullptr, nullptr));  // n_chunks 0: the signal normalisation alone
+    RMR_TRY(launch_fill(e, d, nc, chunk_read, dsig, dgeo, dsignal, dseqs, seq_w, dmaps, map_w, dlens, drfb));
+    RMR_TRY(run_pipeline(m, dsignal, nullptr, dseqs, seq_w, dmaps, map_w, dlens, r->kb, r->ka, nc, dlog));
+    float *hlog = reinterpret_cast<float *>(hp + in_bytes);
+    RMR_HIP(hipMemcpyAsync(hlog, dlog, (size_t)nc * no * 4, hipMemcpyDeviceToHost, e->stream));
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    memcpy(logits, hlog, (size_t)nc * no * 4);
     return 0;
 }
 

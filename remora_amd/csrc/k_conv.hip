@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, conv_min_waves(IC, KW)) void conv_mfma_kernel(
             rows = a.pin_total - pbase * STRIDE < a.pin ? a.pin_total - pbase * STRIDE : a.pin;
             src_row = (size_t)chunk0 * a.pin_total + (size_t)pbase * STRIDE;
         }
-        __syncthreads();  // all reads of the previous iteration are done
+        RMR_SYNC();  // all reads of the previous iteration are done
         {                 // stage `rows` rows of IC floats into the 4 planes
             constexpr int R4 = IC / 4;
             constexpr int UNR = 8;  // loads in flight per thread before the first LDS write
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, conv_min_waves(IC, KW)) void conv_mfma_kernel(
                 for (int u = 0; u < UNR; ++u) *reinterpret_cast<float4 *>(smem + dsto[u]) = v[u];
             }
         }
-        __syncthreads();
+        RMR_SYNC();
         const int ntiles = (ncols + 15) >> 4;
         for (int tile = 0; tile < ntiles; tile += 2) {
             // an odd last tile runs alone (wave-uniform): no MFMA is spent on a padding tile

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_bf16s_kernel(ConvSArgs a) {
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
-        __syncthreads();
+        RMR_SYNC();
         {   // stage: 8 channels (two float4) per item -> NP 16-byte slots
             constexpr int C8 = IC / 8;
             constexpr int UNR = 4;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_bf16s_kernel(ConvSArgs a) {
                 }
             }
         }
-        __syncthreads();
+        RMR_SYNC();
         const int ncols = nch * a.pout;
         const int ntiles = (ncols + 15) >> 4;
         for (int tile = 0; tile < ntiles; tile += 2) {

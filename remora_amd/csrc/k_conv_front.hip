@@ -33,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 __device__ __forceinline__ void wave_sync() {
+    RMR_JITTER_POINT();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
-        __syncthreads();  // the matrix phase of the previous iteration has read the planes
+        RMR_SYNC();  // the matrix phase of the previous iteration has read the planes
         for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
             float *s_sig = smem + a.o_front + (size_t)c * a.per_chunk;
             float *s_sig1 = s_sig + ((a.L + 3) & ~3);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void sig3_front_kernel(ConvFrontArgs a) {
             }
         }
         prefetch(it + gridDim.x);
-        __syncthreads();
+        RMR_SYNC();
         if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
     }
 }
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, (KW1 <= 5 ? 3 : 2)) void sig3_front_mfma_kerne
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
-        __syncthreads();  // the matrix phase of the previous iteration has read the planes
+        RMR_SYNC();  // the matrix phase of the previous iteration has read the planes
         for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
             wave_sync();
             const float *src = a.signal + (size_t)(chunk0 + c) * a.L;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, (KW1 <= 5 ? 3 : 2)) void sig3_front_mfma_kerne
                 }
             }
         }
-        __syncthreads();
+        RMR_SYNC();
         if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
     }
 }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
-        __syncthreads();  // planes free again; (first iteration) gather table visible
+        RMR_SYNC();  // planes free again; (first iteration) gather table visible
         for (int c = w; c < (CF_ABL(1) ? 0 : nch); c += 4) {
             const int64_t chunk = chunk0 + c;
             float *cbase = smem + a.o_front + wt_words + (size_t)c * a.per_chunk;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
             }
         }
         prefetch(it + gridDim.x);
-        __syncthreads();
+        RMR_SYNC();
         if (!CF_ABL(2)) mfma_phase<KW>(a, smem, A, b4, chunk0, nch, w, q, nn);
     }
 }

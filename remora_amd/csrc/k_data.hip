@@ -6,6 +6,7 @@
 //   X2/X3 geometry + fill   src/remora/data_chunks.py:425-466, :331-423, :1376-1418
 //   label tally       src/remora/validate.py:42-45 (argmax), data_chunks.py:1074-1082
 #include "rmr_internal.h"
+#include "rmr_geometry.h"
 
 namespace rmr {
 
@@ -472,17 +473,6 @@ struct GeoArgs {
     int64_t n_chunks;
 };
 
-__device__ __forceinline__ int64_t ub_right(const int64_t *a, int64_t n, int64_t v) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-__device__ __forceinline__ int64_t lb_left(const int64_t *a, int64_t n, int64_t v) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
 __global__ void geometry_kernel(GeoArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int sl_i = 0;
@@ -491,25 +481,9 @@ __global__ void geometry_kernel(GeoArgs a) {
         const int64_t nb = a.d.seq_off[r + 1] - a.d.seq_off[r];
         const int64_t *map = a.d.seq_to_sig + a.d.seq_off[r] + r;  // nb + 1 entries
         const int64_t sig_len = a.d.sig_off[r + 1] - a.d.sig_off[r];
-        int64_t fb = a.d.focus_bases[i] + a.d.offset;
-        if (fb > nb - 1) fb = nb - 1;   // map.size - 2
-        if (fb < 0) fb = 0;
-        const int64_t fsig = a.d.base_start_justify ? map[fb] : (map[fb] + map[fb + 1]) / 2;
-        const int64_t sig_start0 = fsig - a.d.cc_before;
-        int64_t sig_start = sig_start0, sig_end = fsig + a.d.cc_after;
-        if (sig_start < 0) sig_start = 0;
-        if (sig_end > sig_len) sig_end = sig_len;
-        const int64_t seq_start = ub_right(map, nb + 1, sig_start) - 1;
-        const int64_t seq_end = lb_left(map, nb + 1, sig_end);
-        const int64_t sl = seq_end - seq_start;
-        int64_t *g = a.geo + i * 6;
-        g[0] = sl;
-        g[1] = fsig - sig_start;
-        g[2] = fb - seq_start;
-        g[3] = fb;
-        g[4] = seq_start;
-        g[5] = sig_start0;
-        sl_i = (int)sl;
+        // (rmr_geometry.h: the same function runs on the host for the single-read entry, rmr_call_read)
+        sl_i = (int)chunk_geometry_row(map, nb, sig_len, a.d.focus_bases[i], a.d.base_start_justify, a.d.offset, a.d.cc_before,
+                                       a.d.cc_after, a.geo + i * 6);
     }
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(sl_i, o); sl_i = v > sl_i ? v : sl_i; }
     if ((threadIdx.x & 63) == 0) atomicMax(a.max_seq_len, sl_i);

@@ -24,6 +24,7 @@ namespace rmr {
 // boundary.  No block-wide barrier -> the 4 waves of a block drift apart and hide each
 // other's LDS / global latency.
 __device__ __forceinline__ void wave_sync() {
+    RMR_JITTER_POINT();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void front_seq_kernel(FrontSeqArgs a) {
     if (!DIRECT)
         for (int i = sub; i < KW * 16; i += 32) s_u[(size_t)a.maxlen * KW * 16 + i] = 0.0f;
     const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
-    __syncthreads();  // gather table visible to every wave
+    RMR_SYNC();  // gather table visible to every wave
 
     const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(512, 4) void front_seq_tap_kernel(FrontSeqArgs a) {
     for (int i = tid; i < wt_words; i += blockDim.x) s_wt[i] = a.wt5[i];
     if (lane < 16) s_ut[(size_t)a.maxlen * 16 + lane] = 0.0f;
     const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
-    __syncthreads();  // gather table visible to every wave
+    RMR_SYNC();  // gather table visible to every wave
 
     const int n_items = a.P1 * 4;  // (position, quad) pairs of a chunk; item i = lane + 64 j has quad = lane & 3
     for (int64_t chunk = (int64_t)blockIdx.x * nw + w; chunk < a.n; chunk += (int64_t)gridDim.x * nw) {
@@ -457,10 +458,10 @@ __global__ __launch_bounds__(256) void seq1_dense_kernel(DenseArgs a) {
     const int tid = threadIdx.x;
     for (int i = tid; i < a.kw * a.EC * 16; i += blockDim.x) s_w[i] = a.wd[i];
     for (int64_t c = blockIdx.x; c < a.n; c += gridDim.x) {
-        __syncthreads();
+        RMR_SYNC();
         const float *src = a.enc + (size_t)c * a.EC * a.L;
         for (int i = tid; i < a.EC * a.L; i += blockDim.x) s_x[i] = src[i];
-        __syncthreads();
+        RMR_SYNC();
         for (int i = tid; i < a.P1 * 4; i += blockDim.x) {
             const int quad = i & 3, pos = i >> 2;
             float4 acc = *reinterpret_cast<const float4 *>(a.bias + 4 * quad);

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             }
         }
     };
-    __syncthreads();  // the zero fill is done before the first inputs land
+    RMR_SYNC();  // the zero fill is done before the first inputs land
     // column (chunk, position) -> operand row, once per block instead of a division and four multiply-adds per lane and
     // tile pair: the column tiles of the M = 64 layers run across chunk boundaries
     for (int col = tid; col < a.cb * a.P3; col += 256) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         const int64_t chunk0 = it * a.cb;
         const int nch = (int)((n_items - chunk0) < a.cb ? (n_items - chunk0) : a.cb);
         TS(9);
-        __syncthreads();  // inputs of this iteration are in LDS; merge_conv1 of the previous one has read CAT (OH aliases it)
+        RMR_SYNC();  // inputs of this iteration are in LDS; merge_conv1 of the previous one has read CAT (OH aliases it)
         // A fragments of the two M = 16 layers: fetched (L2-resident, 8 KB) at the top of every iteration and dead
         // after S2, so that they do not occupy 32 VGPRs while merge_conv1 runs
         TS(0);
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             if (CG > 4) put(4, p4);
         }
         TS(1);
-        __syncthreads();
+        RMR_SYNC();
         TS(2);
         // ---- S2: sig_conv2 and seq_conv1 (M = 16): the waves split the column-tile pairs ----
         {
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         // A fragments of sig_conv3 / seq_conv2 (this wave's 16 output channels): on their way while the block gathers
         TS(3);
         if (!RMR_FUSED_RES_MID) load_mid();
-        __syncthreads();
+        RMR_SYNC();
         TS(4);
         // ---- S3: sig_conv3 and seq_conv2 (stride 3, M = 64: wave w = channels 16w..16w+15) -> CAT ----
         {
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
         const f32x4 b_m1 = *reinterpret_cast<const f32x4 *>(a.b_merge1 + 16 * w + 4 * q);
         if (RMR_FUSED_STREAM_M1) load_m1();
         const InRegs next_in = fetch_inputs(it + gridDim.x);
-        __syncthreads();
+        RMR_SYNC();
         TS(6);
         // ---- S4: merge_conv1 (K = 5 taps x 128 channels) -> x, bf16 channel-last in HBM ----
         {
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256, RMR_FUSED_WAVES_EU) void fused_front_kernel(Fu
             }
         }
         TS(7);
-        if constexpr (WIN) __syncthreads();  // S4 read the window table that the next inputs' store rewrites
+        if constexpr (WIN) RMR_SYNC();  // S4 read the window table that the next inputs' store rewrites
         store_inputs(next_in, it + gridDim.x);
         TS(8);
     }

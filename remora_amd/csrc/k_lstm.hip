@@ -168,11 +168,11 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
         int64_t st_chunk = chunk0 + st_row;
         if (st_chunk >= a.n) st_chunk = a.n - 1;  // clamp ragged tail (results masked)
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.x + (size_t)st_chunk * a.T * H) + st_c4;
-        __syncthreads();  // previous group's LDS traffic is done
+        RMR_SYNC();  // previous group's LDS traffic is done
         *reinterpret_cast<float4 *>(&xbuf[0][st_q][st_row][4 * st_g]) = xsrc[0];
         // second x tile (prefetch distance 2: x_{t+2} is fetched while step t runs)
         *reinterpret_cast<float4 *>(&xbuf[1][st_q][st_row][4 * st_g]) = xsrc[(size_t)(a.T > 1 ? 1 : 0) * (H / 4)];
-        __syncthreads();
+        RMR_SYNC();
 
         // Software pipeline: the input projection of step t+1 (accN = b + W_ih x_{t+1}) does not
         // depend on h_t, so its 4*KS MFMAs are issued in the same basic block as the gate
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
         xproj<KS, G, RS>(xbuf[0], q, nn, Aih, accN);
         // step 0 ends with xbuf[0] overwritten (x_2): every wave has to be past its x_0 reads first (k_lstm_x16.hip has the
         // account of what happened without this barrier when processes shared the GPU)
-        __syncthreads();
+        RMR_SYNC();
         for (int t = 0; t < a.T; ++t) {
             // x_{t+2} (clamped: the last two fetches are redundant re-reads, never consumed)
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
                 lstm_step<H, true, false, ABL>(xbuf[(t + 1) & 1], hbuf[(t + 1) & 1], q, nn, Aih, Ahh, bias, accN, c, h);
             *reinterpret_cast<f32x4 *>(&hbuf[t & 1][q][nn][4 * w]) = h;
             *reinterpret_cast<float4 *>(&xbuf[t & 1][st_q][st_row][4 * st_g]) = xnext;
-            if (!(ABL & 2)) __syncthreads();  // ABL&2: timing ablation without the per-step barrier
+            if (!(ABL & 2)) RMR_SYNC();  // ABL&2: timing ablation without the per-step barrier
         }
 
         // ---- lstm2: one step on swish(h1[T-1]), gates i, g, o only (c0 = 0 kills f) ----
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
             p += __shfl_xor(p, 32);
             if (q == 0) part[w][nn][o] = p;
         }
-        __syncthreads();
+        RMR_SYNC();
         if (tid < 16 * a.num_out) {
             const int ch = tid / a.num_out, o = tid - ch * a.num_out;
             if (chunk0 + ch < a.n) {

@@ -156,10 +156,10 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         int64_t st_chunk = chunk0 + st_row;
         if (st_chunk >= a.n) st_chunk = a.n - 1;
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.x + (size_t)st_chunk * a.T * H) + st_c4;
-        __syncthreads();
+        RMR_SYNC();
         stage_x(0, xsrc[0]);
         stage_x(1, xsrc[(size_t)(a.T > 1 ? 1 : 0) * (H / 4)]);
-        __syncthreads();
+        RMR_SYNC();
 
         // Software pipeline as in k_lstm.hip: accN = b + W_ih x_{t+1} is issued in slices between
         // the gate-math slices of step t (bf16 MFMA and VALU are separate pipes, but a wave issues
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         f32x4 accN[4] = {bias[0], bias[1], bias[2], bias[3]};
         mm_split<KS32, NP, SL, F16>(xs[0], q, nn, Aih, accN);
-        __syncthreads();  // xs[0] is overwritten at the end of step 0: all x_0 reads first (see k_lstm_x16.hip)
+        RMR_SYNC();  // xs[0] is overwritten at the end of step 0: all x_0 reads first (see k_lstm_x16.hip)
         for (int t = 0; t < a.T; ++t) {
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
             const float4 xnext = xsrc[(size_t)tf * (H / 4)];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
             }
             if (t + 1 == a.T) *reinterpret_cast<f32x4 *>(&hlast[q][nn][4 * w]) = h;
             stage_x(t & 1, xnext);  // x_{t+2} into the buffer whose last reader was step t-1
-            __syncthreads();
+            RMR_SYNC();
         }
 
         // ---- lstm2: one step on swish(h1[T-1]), fp32 MFMA (48 instructions per group) ----
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bf16s_kernel(LstmSArgs a) {
             p += __shfl_xor(p, 32);
             if (q == 0) part[w][nn][o] = p;
         }
-        __syncthreads();
+        RMR_SYNC();
         if (tid < 16 * a.num_out) {
             const int ch = tid / a.num_out, o = tid - ch * a.num_out;
             if (chunk0 + ch < a.n) {

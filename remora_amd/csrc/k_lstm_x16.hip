@@ -117,12 +117,12 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
         int64_t st_chunk = chunk0 + st_row;
         if (st_chunk >= a.n) st_chunk = a.n - 1;  // ragged tail: clamp (results masked)
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(a.x + (size_t)st_chunk * a.T * 64) + st_c8;
-        __syncthreads();  // the previous group's LDS traffic is done
+        RMR_SYNC();  // the previous group's LDS traffic is done
         if (stager) {
             xs[0][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[0];
             xs[1][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[(size_t)(a.T > 1 ? 1 : 0) * 8];
         }
-        __syncthreads();
+        RMR_SYNC();
 
         float c[2] = {0.f, 0.f};
         f32x4 accN[2];  // bias + W_ih x_t of the step about to run
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
         // step 0 ends with the stagers overwriting xs[0] (x_2): every wave must have read x_0 above before any stager gets
         // there.  Without this barrier a wave held up for longer than one step (other processes' waves on its SIMD) projected
         // x_2 for x_0 in eight chunks: the runs that differed when several processes shared the GPU (profiles/NOTES_r04.md)
-        __syncthreads();
+        RMR_SYNC();
         // one time step; LAST (the step whose h feeds lstm2 through a swish, models/ConvLSTM_w_ref.py:52) is a compile-time
         // flag: as a run-time test hipcc turned it into selects and every step paid the swish's two exp + two rcp
         auto step = [&](const int t, auto last_c) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
             else hp = __builtin_bit_cast(unsigned, bf16x2{(__bf16)h0, (__bf16)h1});
             reinterpret_cast<unsigned *>(&hs[t & 1][h_plane][nn][h_slot])[q] = hp;
             if (stager) xs[t & 1][st_c8 & 3][st_row][st_c8 >> 2] = xnext;  // the buffer whose last reader was step t-1
-            __syncthreads();
+            RMR_SYNC();
         };
         for (int t = 0; t + 1 < a.T; ++t) step(t, std::false_type{});
         step(a.T - 1, std::true_type{});
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
             p += __shfl_xor(p, 32);
             if (q == 0) part[w][nn][o] = p;
         }
-        __syncthreads();
+        RMR_SYNC();
         if (tid < 16 * a.num_out) {
             const int ch = tid / a.num_out, o = tid - ch * a.num_out;
             if (chunk0 + ch < a.n) {
@@ -248,12 +248,12 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
         int64_t st_chunk = chunk0 + sg * 16 + st_row;
         if (st_chunk >= a.n) st_chunk = a.n - 1;
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(a.x + (size_t)st_chunk * a.T * 64) + st_c8;
-        __syncthreads();
+        RMR_SYNC();
         if (stager) {
             xs[0][sg][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[0];
             xs[1][sg][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[(size_t)(a.T > 1 ? 1 : 0) * 8];
         }
-        __syncthreads();
+        RMR_SYNC();
 
         float c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         f32x4 accN[2][2];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) accN[g][t] = mfma16<F16>(Aih[t][ks], xs[0][g][q][nn][ks], accN[g][t]);
             }
-        __syncthreads();  // x_0 read by every wave before step 0 overwrites its tile
+        RMR_SYNC();  // x_0 read by every wave before step 0 overwrites its tile
         auto step = [&](const int t, auto last_c) {
             constexpr bool LAST = decltype(last_c)::value;
             const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
                 reinterpret_cast<unsigned *>(&hs[t & 1][g][h_plane][nn][h_slot])[q] = hp;
             }
             if (stager) xs[t & 1][sg][st_c8 & 3][st_row][st_c8 >> 2] = xnext;
-            __syncthreads();
+            RMR_SYNC();
         };
         for (int t = 0; t + 1 < a.T; ++t) step(t, std::false_type{});
         step(a.T - 1, std::true_type{});
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
                 if (q == 0) part[g][w][nn][o] = p;
             }
         }
-        __syncthreads();
+        RMR_SYNC();
         if (tid < 32 * a.num_out) {
             const int g = tid / (16 * a.num_out), r = tid - g * 16 * a.num_out;
             const int ch = r / a.num_out, o = r - ch * a.num_out;

@@ -131,13 +131,13 @@ __global__ __launch_bounds__(512, NP == 2 ? 4 : 2) void lstm_x16s_kernel(LstmXsA
         int64_t st_chunk = chunk0 + st_row;
         if (st_chunk >= a.n) st_chunk = a.n - 1;  // ragged tail: clamp (results masked)
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.x + (size_t)st_chunk * a.T * 64) + 2 * st_c8;
-        __syncthreads();  // the previous group's LDS traffic is done
+        RMR_SYNC();  // the previous group's LDS traffic is done
         if (stager) {
             stage_x(0, xsrc[0], xsrc[1]);
             const size_t o1 = (size_t)(a.T > 1 ? 1 : 0) * 16;
             stage_x(1, xsrc[o1], xsrc[o1 + 1]);
         }
-        __syncthreads();
+        RMR_SYNC();
 
         float c[2] = {0.f, 0.f};
         f32x4 accN[2];  // bias + W_ih x_t of the step about to run
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, NP == 2 ? 4 : 2) void lstm_x16s_kernel(LstmXsA
 #pragma unroll
                 for (int pr = 0; pr < P::N; ++pr) accN[u] = mma16<F16>(Aih[u][ks][P::A[pr]], xs[0][P::B[pr]][q][nn][ks], accN[u]);
         }
-        __syncthreads();  // x_0 read by every wave before step 0 ends with its tile overwritten (k_lstm_x16.hip)
+        RMR_SYNC();  // x_0 read by every wave before step 0 ends with its tile overwritten (k_lstm_x16.hip)
 
         auto step = [&](const int t, auto last_c) {
             constexpr bool LAST = decltype(last_c)::value;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, NP == 2 ? 4 : 2) void lstm_x16s_kernel(LstmXsA
 #pragma unroll
             for (int p = 0; p < NP; ++p) reinterpret_cast<unsigned *>(&hs[t & 1][p][h_plane][nn][h_slot])[q] = (e0[p] >> 16) | e1[p];
             if (stager) stage_x(t & 1, xn0, xn1);  // the buffer whose last reader was step t-1
-            __syncthreads();
+            RMR_SYNC();
         };
         for (int t = 0; t + 1 < a.T; ++t) step(t, std::false_type{});
         step(a.T - 1, std::true_type{});
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, NP == 2 ? 4 : 2) void lstm_x16s_kernel(LstmXsA
             p += __shfl_xor(p, 32);
             if (q == 0) part[w][nn][o] = p;
         }
-        __syncthreads();
+        RMR_SYNC();
         if (tid < 16 * a.num_out) {
             const int ch = tid / a.num_out, o = tid - ch * a.num_out;
             if (chunk0 + ch < a.n) {

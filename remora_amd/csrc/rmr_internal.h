@@ -102,6 +102,11 @@ struct rmr_engine {
     size_t pinned_cap = 0;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};
     int ensure_pinned(size_t bytes);
+    // pinned staging of rmr_call_read (one read in, its logits out): its own small buffer, so that a single-read call
+    // never re-allocates the two big slots above under an upload
+    void *pin_call = nullptr;
+    size_t pin_call_cap = 0;
+    int ensure_pin_call(size_t bytes);
 
     // kernels whose dynamic-LDS limit was raised ON THIS DEVICE (hipFuncSetAttribute is per device: a flag per
     // process would skip the second engine of a multi-GPU process); guarded by `mu` like every launch

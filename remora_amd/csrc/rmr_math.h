@@ -37,6 +37,15 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a.y), "v"(b.y), "v"(c.y));
     return f32x2{x, y};
 }
+#elif RMR_PACKED_F32_FMA + 0 == 2
+// experiment build: the packed instruction under the SAME scheduling constraints as the shipped scalar pair (volatile asm):
+// if this form is damaged beside a bf16-MFMA tenant and the scalar pair is not, the difference is the instruction, not the
+// schedule the compiler picks around it (profiles/NOTES_r05.md)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 #else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
@@ -49,5 +58,39 @@ __device__ __forceinline__ void swish_pk(f32x2 &a, f32x2 &b) {
     a = a * f32x2{__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
     b = b * f32x2{__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
 }
+
+// ---- RMR_SYNC: the block barrier of the model kernels -----------------------------------------------------------------
+// Plain __syncthreads() in the shipped library.  `make jitter` (-DRMR_JITTER, libremora_hip_jitter.so) puts a per-wave
+// pseudo-random sleep in front of and behind every barrier and in front of every intra-wave LDS hand-off (wave_sync): most
+// waves go straight on, a fifth are held for 0.2-3 us, one in thirty-two for 7-14 us - longer than a whole
+// stage of any of these kernels.  A hand-off through LDS that relies on timing instead of a barrier (round 4's LSTM bug:
+// a wave still reading x_0 while the stager wrote x_2, visible only when foreign waves held it up) then goes wrong with
+// the kernel ALONE on the GPU; a correctly synchronised kernel returns the same bits as the shipped build
+// (tests/test_gpu_jitter.py, tools/stress_determinism.py --jitter).
+#ifdef RMR_JITTER
+__device__ __forceinline__ void jitter() {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_ID: wave / SIMD / CU / SE of this wave
+    unsigned h = ((unsigned)t ^ (unsigned)(t >> 21) ^ (id * 0x9E3779B9u)) * 2654435761u;
+    h = __builtin_amdgcn_readfirstlane(h) >> 26;  // 0..63, one value per wave
+    if (h >= 62) {
+        for (unsigned i = 61; i < h; ++i) {  // 1..2 x 2 x 8128 cycles: 7-14 us
+            __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+        }
+    } else if (h >= 48) {
+        for (unsigned i = 47; i < h; ++i) __builtin_amdgcn_s_sleep(8);  // 1..14 x 512 cycles: 0.2-3 us
+    }
+}
+#define RMR_SYNC()           \
+    do {                     \
+        ::rmr::jitter();     \
+        __syncthreads();     \
+        ::rmr::jitter();     \
+    } while (0)
+#define RMR_JITTER_POINT() ::rmr::jitter()
+#else
+#define RMR_SYNC() __syncthreads()
+#define RMR_JITTER_POINT() ((void)0)
+#endif
 
 }  // namespace rmr

@@ -206,6 +206,56 @@ def _validated_int16_dacs(r):
     return ai
 
 
+_GLUE = None
+
+
+def _glue():
+    """_pyglue.so (csrc/pyglue.c) through ctypes.PyDLL - called with the GIL held, takes Python objects."""
+    global _GLUE
+    if _GLUE is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pyglue.so")
+        if not os.path.exists(path):
+            raise RemoraError(f"{path} not found - build it first: python -c 'import __graft_entry__ as g; g.build()'")
+        g = ctypes.PyDLL(path)
+        g.rmr_py_collect_reads.restype = ctypes.c_int64
+        g.rmr_py_collect_reads.argtypes = [ctypes.py_object, ctypes.c_int64] + [ctypes.c_void_p] * 8
+        _GLUE = g
+    return _GLUE
+
+
+def _collect_reads(reads):
+    """Per read: addresses of dacs / seq_to_sig_map / int_seq, their sizes, the bases' itemsize, shift and scale - what
+    rmr_pack_reads gathers from.  -> (p_dacs u64[n], sig_n i64[n], p_maps u64[n], p_seqs u64[n], seq_n i64[n], itemsize i32[n],
+    shift f64[n], scale f64[n], keep) where `keep` holds whatever had to be converted.  Reads whose arrays are already in the
+    gather's layout (int16 dacs, int64 mapping, integer bases, all C-contiguous - what io.Read.into_remora_read and the
+    reference's constructors produce) are walked through the C API (csrc/pyglue.c, 0.3 us a read); anything else by the
+    interpreter, which converts what it can and refuses the rest with the messages of RemoraRead.check."""
+    nr = len(reads)
+    p_d, p_m, p_s = np.empty(nr, np.uint64), np.empty(nr, np.uint64), np.empty(nr, np.uint64)
+    sig_n, seq_n, isz = np.empty(nr, np.int64), np.empty(nr, np.int64), np.empty(nr, np.int32)
+    shift, scale = np.empty(nr, np.float64), np.empty(nr, np.float64)
+    if nr and os.environ.get("RMR_PY_GLUE", "1") != "0":
+        got = _glue().rmr_py_collect_reads(reads if isinstance(reads, (list, tuple)) else list(reads), nr, p_d.ctypes.data,
+                                           sig_n.ctypes.data, p_m.ctypes.data, p_s.ctypes.data, seq_n.ctypes.data, isz.ctypes.data,
+                                           shift.ctypes.data, scale.ctypes.data)
+        if got == nr:
+            return p_d, sig_n, p_m, p_s, seq_n, isz, shift, scale, None
+    keep = []
+    for i, r in enumerate(reads):
+        if r.seq_to_sig_map.size != r.int_seq.size + 1:
+            raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
+        d = np.ascontiguousarray(_validated_int16_dacs(r))
+        mp = np.ascontiguousarray(r.seq_to_sig_map, dtype=np.int64).ravel()
+        sq = np.ascontiguousarray(r.int_seq).ravel()
+        if sq.dtype.kind not in "iu" or sq.dtype.itemsize not in (1, 2, 4, 8):
+            sq = sq.astype(np.int64)
+        keep.append((d, mp, sq))
+        p_d[i], p_m[i], p_s[i] = d.ctypes.data, mp.ctypes.data, sq.ctypes.data
+        sig_n[i], seq_n[i], isz[i] = d.size, sq.size, sq.dtype.itemsize
+        shift[i], scale[i] = float(r.shift), float(r.scale)
+    return p_d, sig_n, p_m, p_s, seq_n, isz, shift, scale, keep
+
+
 class DeviceReads:
     """The arrays of a batch of reads, concatenated and resident in HBM (the rmr_reads layout of
     include/remora_hip.h) - uploaded once and shared by the motif scan, the signal-mapping refinement
@@ -222,13 +272,11 @@ class DeviceReads:
         dev = self.engine.torch_device
         nr = len(reads)
         self.n_reads = nr
+        p_d, sig_n, p_m, p_s, seq_n, isz, shift, scale, keep = _collect_reads(reads)
         self.sig_off = np.zeros(nr + 1, np.int64)
         self.seq_off = np.zeros(nr + 1, np.int64)
-        for i, r in enumerate(reads):
-            self.sig_off[i + 1] = self.sig_off[i] + r.dacs.size
-            self.seq_off[i + 1] = self.seq_off[i] + r.int_seq.size
-            if r.seq_to_sig_map.size != r.int_seq.size + 1:
-                raise RemoraError(f"Invalid read: seq ({r.int_seq.size}) and mapping ({r.seq_to_sig_map.size}) sizes incompatible")
+        np.cumsum(sig_n, out=self.sig_off[1:])
+        np.cumsum(seq_n, out=self.seq_off[1:])
         n_sig, n_seq = int(self.sig_off[-1]), int(self.seq_off[-1])
         segs = [("s2s", np.int64, n_seq + nr), ("d_sig_off", np.int64, nr + 1), ("d_seq_off", np.int64, nr + 1),
                 ("shift", np.float64, nr), ("scale", np.float64, nr), ("dacs", np.int16, n_sig), ("iseq", np.int8, n_seq)]
@@ -240,34 +288,18 @@ class DeviceReads:
         buf = _pinned_bytes(max(total, 256), slot)
         host = buf.numpy()
         view = {name: host[offs[name] : offs[name] + cnt * np.dtype(dt).itemsize].view(dt) for name, dt, cnt in segs}
-        # the per-read arrays are gathered into the pinned buffer by native threads (rmr_pack_reads): the python loop
-        # only collects pointers (a per-read numpy slice copy cost 25-30 us: two thirds of a batch's wall time)
-        keep, p_d, p_m, p_s, isz = [], [], [], [], []
-        for r in reads:
-            d = np.ascontiguousarray(_validated_int16_dacs(r))
-            mp = np.ascontiguousarray(r.seq_to_sig_map, dtype=np.int64).ravel()
-            sq = np.ascontiguousarray(r.int_seq).ravel()
-            if sq.dtype.kind not in "iu" or sq.dtype.itemsize not in (1, 2, 4, 8):
-                sq = sq.astype(np.int64)
-            keep.append((d, mp, sq))
-            p_d.append(d.__array_interface__["data"][0])
-            p_m.append(mp.__array_interface__["data"][0])
-            p_s.append(sq.__array_interface__["data"][0])
-            isz.append(sq.dtype.itemsize)
+        # the per-read arrays are gathered into the pinned buffer by native threads (rmr_pack_reads); their addresses and
+        # sizes come from _collect_reads (C API walk; a per-read numpy slice copy cost 25-30 us, the interpreter's walk 5-8)
         lib = L.lib()
-        vp = lambda lst: (ctypes.c_void_p * max(len(lst), 1))(*lst)  # noqa: E731
-        sig_n = np.diff(self.sig_off)
-        seq_n = np.diff(self.seq_off)
-        isz = np.asarray(isz, np.int32)
         so, qo = np.empty(nr + 1, np.int64), np.empty(nr + 1, np.int64)
-        L.check(lib.rmr_pack_reads(nr, vp(p_d), sig_n.ctypes.data, vp(p_m), vp(p_s), seq_n.ctypes.data, isz.ctypes.data,
-                                   view["dacs"].ctypes.data, view["s2s"].ctypes.data, view["iseq"].ctypes.data,
+        L.check(lib.rmr_pack_reads(nr, p_d.ctypes.data, sig_n.ctypes.data, p_m.ctypes.data, p_s.ctypes.data, seq_n.ctypes.data,
+                                   isz.ctypes.data, view["dacs"].ctypes.data, view["s2s"].ctypes.data, view["iseq"].ctypes.data,
                                    so.ctypes.data, qo.ctypes.data, int(os.environ.get("RMR_PACK_THREADS", "8"))))
         del keep
         view["d_sig_off"][:] = self.sig_off
         view["d_seq_off"][:] = self.seq_off
-        view["shift"][:] = [float(r.shift) for r in reads]
-        view["scale"][:] = [float(r.scale) for r in reads]
+        view["shift"][:] = shift
+        view["scale"][:] = scale
         dbuf = buf[: max(total, 256)].to(dev, non_blocking=True)
         if ready is not None:
             ready.record(torch.cuda.current_stream(dev))
@@ -361,7 +393,8 @@ def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_
     rs = L.Reads(dr.n_reads, dr.dacs.data_ptr(), dr.d_sig_off.data_ptr(), dr.s2s.data_ptr(), dr.iseq.data_ptr(),
                  dr.d_seq_off.data_ptr(), dr.shift.data_ptr(), dr.scale.data_ptr(), focus.data_ptr(),
                  d_foc_off.data_ptr(), int(chunk_context[0]), int(chunk_context[1]),
-                 int(kmer_context_bases[0]), int(kmer_context_bases[1]), int(bool(base_start_justify)), int(offset))
+                 int(kmer_context_bases[0]), int(kmer_context_bases[1]),
+                 2 if base_start_justify == 2 else int(bool(base_start_justify)), int(offset))
     h_foc = np.ascontiguousarray(foc_off, np.int64)
     if dr.sig_off.dtype == np.int64 and dr.seq_off.dtype == np.int64:  # host copies of the offsets: no fetch per call
         rs.host_sig_off, rs.host_seq_off, rs.host_focus_off = dr.sig_off.ctypes.data, dr.seq_off.ctypes.data, h_foc.ctypes.data
@@ -530,6 +563,29 @@ class RemoraRead:
             return arrs
         arrs, _ = extract_chunk_arrays([self], chunk_context, kmer_context_bases, base_start_justify, offset)
         return arrs
+
+    def extract_chunk(self, focus_sig_idx, chunk_context, kmer_context_bases, label=-1, read_focus_base=-1, check_chunk=False,
+                      signal_padding=False):
+        """One chunk around a SIGNAL position, with the reference's arguments and return value (:331-423): the window
+        `focus_sig_idx - chunk_context[0] .. + chunk_context[1]`, zero-padded where it leaves the read, the bases it covers
+        with their k-mer context (-1 outside the read) and the mapping re-based to the chunk.  The same two kernels as the
+        batch path (geometry + fill) for one focus position; `signal_padding` (mirrored signal instead of zeros, which no
+        caller of the reference passes) is not built."""
+        if signal_padding:
+            raise RemoraError("extract_chunk: signal_padding is not supported by the GPU extraction path")
+        dr = DeviceReads([self])
+        arrs, _ = _extract_device(dr, np.array([int(focus_sig_idx)], np.int64), np.array([0, 1], np.int64), chunk_context,
+                                  kmer_context_bases, 2, int(read_focus_base))
+        sl = int(arrs.geo[0, 0])
+        ctx = sum(arrs.kmer_context_bases)
+        geo = arrs.geo.cpu().numpy()[0]
+        ch = Chunk(signal=arrs.signal.cpu().numpy()[0, 0], seq_w_context=arrs.sequence.cpu().numpy()[0, : sl + ctx],
+                   seq_to_sig_map=arrs.mapping.cpu().numpy()[0, : sl + 1].astype(np.int32), kmer_context_bases=arrs.kmer_context_bases,
+                   chunk_sig_focus_idx=int(geo[1]), chunk_focus_base=int(geo[2]), read_focus_base=int(read_focus_base),
+                   read_id=self.read_id, label=label)
+        if check_chunk:
+            ch.check()
+        return ch
 
     def iter_chunks(self, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,
                     check_chunks=False, motifs=None):

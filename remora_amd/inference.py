@@ -13,20 +13,62 @@ from .engine import _torch
 from .util import Motif, format_mm_ml_tags, softmax_axis1
 
 
+def _native_call_read(read, model, model_metadata):
+    """(nn_out f32[N,num_out], labels i64[N], pos i64[N]) of one read whose focus bases are set, through ONE native call
+    (rmr_call_read: staging, signal normalisation, chunk geometry and rows, the network, logits back; one stream synchronisation) - what
+    RemoraRead.prepare_batches + run_model do between them (src/remora/data_chunks.py:468-540)."""
+    import ctypes
+
+    from . import _lib as L
+    from .data_chunks import _validated_int16_dacs
+
+    focus = np.ascontiguousarray(read.focus_bases, dtype=np.int64).ravel()
+    n = focus.size
+    dacs = np.ascontiguousarray(_validated_int16_dacs(read))
+    s2s = np.ascontiguousarray(read.seq_to_sig_map, dtype=np.int64).ravel()
+    seq = np.ascontiguousarray(read.int_seq).ravel()
+    if seq.dtype.kind not in "iu" or seq.dtype.itemsize not in (1, 2, 4, 8):
+        seq = seq.astype(np.int64)
+    if s2s.size != seq.size + 1:
+        raise RemoraError(f"Invalid read: seq ({seq.size}) and mapping ({s2s.size}) sizes incompatible")
+    cc, kcb = model_metadata["chunk_context"], model_metadata["kmer_context_bases"]
+    rd = L.Read(dacs.ctypes.data, dacs.size, s2s.ctypes.data, seq.ctypes.data, seq.dtype.itemsize, 0, seq.size,
+                float(read.shift), float(read.scale), focus.ctypes.data, n, int(cc[0]), int(cc[1]), int(kcb[0]), int(kcb[1]),
+                int(bool(model_metadata["base_start_justify"])), int(model_metadata["offset"]))
+    nn_out = np.empty((n, model.num_out), np.float32)
+    pos = np.empty(n, np.int64)
+    L.check(L.lib().rmr_call_read(model._h, ctypes.byref(rd), nn_out.ctypes.data, pos.ctypes.data))
+    labels = np.full(n, -1, np.int64)
+    if read.labels is not None:
+        labels[:] = np.asarray(read.labels)[focus]
+    return nn_out, labels, pos
+
+
 def call_read_mods(read, model, model_metadata, batch_size=DEFAULT_BATCH_SIZE, focus_offset=None,
                    return_mm_ml_tags=False, return_mod_probs=False):
     """Call modified bases on one read; arguments and return values as in the reference:
     (nn_out f32[N,num_out], labels i64[N], pos i64[N]) by default;
     (probs f64[N,num_mods], labels, pos) with return_mod_probs; (MM str, ML array('B')) with
-    return_mm_ml_tags; three empty arrays when the read yields no chunk (:698-699)."""
+    return_mm_ml_tags; three empty arrays when the read yields no chunk (:698-699).
+    With a HipModel the read goes through one native call (`_native_call_read`; `read.batches` is then not filled in -
+    RMR_NATIVE_CALL_READ=0 selects prepare_batches + run_model, which give the same bits)."""
+    from .engine import HipModel
+
     if focus_offset is None:
         read.set_motif_focus_bases([Motif(*m) for m in model_metadata["motifs"]])
     else:
         read.focus_bases = np.array([focus_offset])
-    read.prepare_batches(model_metadata, batch_size)
-    if len(read.batches) == 0:
-        return np.array([]), np.array([]), np.array([])
-    nn_out, labels, pos = read.run_model(model)
+    if isinstance(model, HipModel) and os.environ.get("RMR_NATIVE_CALL_READ", "1") != "0":
+        read.batches = []
+        read.refine_signal_mapping(model_metadata.get("sig_map_refiner"))
+        if read.focus_bases is None or len(read.focus_bases) == 0:
+            return np.array([]), np.array([]), np.array([])
+        nn_out, labels, pos = _native_call_read(read, model, model_metadata)
+    else:
+        read.prepare_batches(model_metadata, batch_size)
+        if len(read.batches) == 0:
+            return np.array([]), np.array([]), np.array([])
+        nn_out, labels, pos = read.run_model(model)
     if not return_mod_probs and not return_mm_ml_tags:
         return nn_out, labels, pos
     probs = softmax_axis1(nn_out)[:, 1:].astype(np.float64)

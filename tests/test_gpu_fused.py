@@ -308,6 +308,49 @@ def test_16bit_pipelines_against_the_fp32_path_100k(torch_cuda, O, cfg, dtype, m
     assert p999 <= p999_max, stats + (p999,)
 
 
+# ---- SPECIFIED gates of the 16-bit configurations (round-4 review item 7; SURVEY §7 "hard parts": the 16-bit configs need a
+# tolerance of their own): fixed numbers, not measured levels with a margin.  Over 1 M chunks of the BASELINE configs[3] /
+# configs[4] shapes a 16-bit pipeline must reproduce the fp32 path's call on at least this share of the CONFIDENT chunks
+# (fp32 margin between the two largest logits > 2e-2), and on the first 20 000 chunks the same against the ORACLE's fp32
+# forward.  Round 4 measured 1.0 / 0.999995 (f16, C100 / C200) and 0.99993 / 0.99813 (bf16): bf16 at configs[4] flips 0.19 %
+# of the confident calls of this deliberately amplified network - the README says so and recommends f16.
+SPECIFIED_AGREEMENT = {"f16": 0.9999, "bf16": 0.998}
+
+
+@pytest.mark.parametrize("cfg", ["C100", "C200"])
+def test_16bit_configs_meet_their_specified_argmax_gates_over_1m_chunks(torch_cuda, O, cfg):
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    n, k = 1_000_000, 20_000
+    cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+    state = synth.synth_state("conv_lstm", 64, 9, num_out, seed=0)
+    md = dict(chunk_context=cc, kmer_context_bases=kcb)
+    d = synth.synth_chunks_config(cfg, n, shard=3)
+    dev = [torch.from_numpy(d[key]).cuda() for key in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+    ref = model_from_state(state, md, device=0, dtype="fp32").infer_chunks(*dev, kcb)
+    med = ref.median(dim=0).values  # centred as bench.py centres them: random weights otherwise call one class throughout
+    ref = ref - med
+    top = ref.topk(2, dim=1).values
+    clear = (top[:, 0] - top[:, 1]) > 2e-2
+    assert int(clear.sum()) > 500_000
+    enc = torch.from_numpy(O.compute_encoded_kmer_batch(kcb[0], kcb[1], d["sequence"][:k], d["sequence_to_signal_mapping"][:k], d["sequence_lengths"][:k]))
+    with torch.no_grad():
+        oracle = torch_ref.from_state(state)(torch.from_numpy(d["signal"][:k]), enc) - med.cpu()
+    otop = oracle.topk(2, dim=1).values
+    oclear = (otop[:, 0] - otop[:, 1]) > 2e-2
+    assert float((ref[:k].cpu() - oracle).abs().max()) <= 1e-4  # the fp32 path is the oracle's equal on the sample
+    for dtype, gate in SPECIFIED_AGREEMENT.items():
+        out = model_from_state(state, md, device=0, dtype=dtype).infer_chunks(*dev, kcb) - med
+        agreement = float((out.argmax(1) == ref.argmax(1))[clear].float().mean())
+        sample = float((out[:k].cpu().argmax(1) == oracle.argmax(1))[oclear].float().mean())
+        assert agreement >= gate, (cfg, dtype, agreement, int(clear.sum()))
+        assert sample >= gate, (cfg, dtype, sample, int(oclear.sum()))
+
+
+
 @pytest.mark.parametrize("cfg,n", [("C100", 4096), ("C200", 2048)])
 def test_16bit_error_is_the_arithmetic_not_the_kernel(torch_cuda, O, cfg, n):
     """The kernels against (a) the float64 network and (b) the float64 network with round-to-nearest-even to bf16 / half at

@@ -244,6 +244,56 @@ def test_extract_chunks_golden(torch_cuda):
                 assert len(chunks) == n and chunks[0].seq_len == sl[0]
 
 
+def test_extract_chunk_one_signal_position_golden(torch_cuda):
+    """RemoraRead.extract_chunk(focus_sig_idx, chunk_context, kmer_context_bases, label, read_focus_base, check_chunk) -
+    the reference's own method (src/remora/data_chunks.py:331-423), one chunk around a SIGNAL index - against the chunks the
+    reference cut with it from the golden reads (iter_chunks calls it once per focus base, :455): first, last and middle
+    chunk of every read / configuration, which covers both padding branches of the short reads."""
+    from remora_amd import RemoraError
+    from remora_amd.data_chunks import RemoraRead
+
+    g = golden("extract_chunks.npz")
+    checked = padded = 0
+    for rname in g["read_names"]:
+        rname = str(rname)
+        shift, scale = (float(x) for x in g[f"{rname}_shift_scale"])
+        smap = g[f"{rname}_map"]
+        read = RemoraRead(dacs=g[f"{rname}_dacs"], shift=shift, scale=scale, seq_to_sig_map=smap, int_seq=g[f"{rname}_int_seq"],
+                          read_id=rname)
+        for ci, cfg in enumerate(g["configs"]):
+            cc, kcb, bsj = (int(cfg[0]), int(cfg[1])), (int(cfg[2]), int(cfg[3])), bool(cfg[4])
+            pre = f"{rname}_CG_c{ci}_"
+            if pre + "misc" not in g:
+                continue
+            misc, sl = g[pre + "misc"], g[pre + "seq_len"]
+            n = misc.shape[0]
+            for i in sorted({0, n // 2, n - 1}):
+                fb = int(misc[i, 2])
+                fsig = int(smap[fb]) if bsj else int((smap[fb] + smap[fb + 1]) // 2)
+                ch = read.extract_chunk(fsig, cc, kcb, label=1, read_focus_base=fb, check_chunk=True)
+                assert np.array_equal(ch.signal.view(np.uint32), g[pre + "signal"][i].view(np.uint32)), (rname, ci, i)
+                assert np.array_equal(ch.seq_w_context, g[pre + "seq_w_context"][i, : sl[i] + sum(kcb)])
+                assert ch.seq_to_sig_map.dtype == np.int32 and np.array_equal(ch.seq_to_sig_map, g[pre + "seq_to_sig_map"][i, : sl[i] + 1])
+                assert (ch.chunk_sig_focus_idx, ch.chunk_focus_base, ch.read_focus_base) == tuple(int(x) for x in misc[i])
+                assert ch.label == 1 and ch.read_id == rname and ch.seq_len == sl[i]
+                checked += 1
+                padded += int(fsig - cc[0] < 0 or fsig + cc[1] > read.dacs.size)
+    assert checked >= 30 and padded >= 4
+    # a signal index that is no base's centre: the window of the index itself, and the default read_focus_base of -1
+    rname = str(g["read_names"][0])
+    shift, scale = (float(x) for x in g[f"{rname}_shift_scale"])
+    read = RemoraRead(dacs=g[f"{rname}_dacs"], shift=shift, scale=scale, seq_to_sig_map=g[f"{rname}_map"], int_seq=g[f"{rname}_int_seq"])
+    mid = int(read.dacs.size // 2) + 1
+    ch = read.extract_chunk(mid, (50, 50), (4, 4))
+    assert np.array_equal(ch.signal.view(np.uint32), read.sig[mid - 50 : mid + 50].view(np.uint32)) and ch.read_focus_base == -1
+    s0 = int(np.searchsorted(read.seq_to_sig_map, mid - 50, side="right") - 1)
+    s1 = int(np.searchsorted(read.seq_to_sig_map, mid + 50, side="left"))
+    assert ch.seq_len == s1 - s0 and ch.chunk_sig_focus_idx == 50 and ch.chunk_focus_base == -1 - s0
+    assert np.array_equal(ch.seq_w_context[4:-4], read.int_seq[s0:s1])
+    with pytest.raises(RemoraError, match="signal_padding"):
+        read.extract_chunk(mid, (50, 50), (4, 4), signal_padding=True)
+
+
 def test_extract_multi_read_batch_vs_oracle(torch_cuda, O):
     from remora_amd import synth
     from remora_amd.data_chunks import RemoraRead, extract_chunk_arrays
@@ -684,6 +734,64 @@ def test_batched_call_reads_mods_matches_single_read_api(torch_cuda, O):
         assert np.array_equal(p, sp[order])
         if p.size:
             assert np.array_equal(o, so[order]), "same chunks must give bit-identical logits in any batch"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16x3"])
+def test_native_call_read_equals_prepare_batches_and_run_model(torch_cuda, O, monkeypatch, dtype):
+    """call_read_mods through the ONE native entry (rmr_call_read: staging, normalisation, geometry, rows, network, two
+    stream synchronisations) against the two-step path of the reference's shape (RemoraRead.prepare_batches + run_model,
+    src/remora/data_chunks.py:468-540): the same bits, positions and labels - for reads shorter than a chunk (both padding
+    branches), with N bases, int8 / int32 bases, labels, an offset, base_start_justify, a single focus_offset, no motif hit;
+    and the fp32 logits against the CPU oracle."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.data_chunks import RemoraRead
+    from remora_amd.inference import call_read_mods
+    from remora_amd.model_util import model_from_state
+
+    net = torch_ref.random_model("conv_lstm", 64, 9, 2, seed=5)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    rng = np.random.default_rng(11)
+
+    def mk(i, nb, seq_dtype=np.int64, n_bases=0, labels=False):
+        r = synth.synth_read(nb, idx=i)
+        seq = r["int_seq"].astype(seq_dtype)
+        if n_bases:
+            seq[rng.choice(nb, n_bases, replace=False)] = -1
+        return RemoraRead(dacs=r["dacs"], shift=r["shift"] + i, scale=r["scale"] - i, seq_to_sig_map=r["seq_to_sig_map"], int_seq=seq,
+                          read_id=f"r{i}", labels=rng.integers(0, 2, nb) if labels else None)
+
+    reads = [mk(0, 900), mk(1, 6), mk(2, 40, np.int8), mk(3, 2500, np.int32, n_bases=60), mk(4, 700, labels=True), mk(5, 5000),
+             RemoraRead(dacs=np.full(60, 500, np.int16), shift=500.0, scale=80.0, seq_to_sig_map=np.arange(0, 61, 10),
+                        int_seq=np.array([0, 0, 3, 3, 0, 0]), read_id="nocg")]
+    for bsj, offset in ((False, 0), (True, 1), (False, -2)):
+        md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)], mod_bases=["m"], mod_long_names=["5mC"],
+                  can_base="C", base_start_justify=bsj, offset=offset, sig_map_refiner=None)
+        model = model_from_state(state, md, device=0, dtype=dtype)
+        for rd in reads:
+            monkeypatch.setenv("RMR_NATIVE_CALL_READ", "1")
+            a = call_read_mods(rd.copy(), model, md)
+            monkeypatch.setenv("RMR_NATIVE_CALL_READ", "0")
+            b = call_read_mods(rd.copy(), model, md)
+            assert len(a) == len(b) == 3 and a[0].shape == b[0].shape, rd.read_id
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (rd.read_id, bsj, offset)
+            if rd.labels is not None:
+                assert (a[1] >= 0).all()
+            if rd.int_seq.size > 100:
+                monkeypatch.setenv("RMR_NATIVE_CALL_READ", "1")
+                fo = int(rd.int_seq.size // 2)
+                a1 = call_read_mods(rd.copy(), model, md, focus_offset=fo)
+                monkeypatch.setenv("RMR_NATIVE_CALL_READ", "0")
+                b1 = call_read_mods(rd.copy(), model, md, focus_offset=fo)
+                assert a1[0].shape == (1, 2) and all(np.array_equal(x, y) for x, y in zip(a1, b1))
+        if dtype == "fp32" and not bsj and offset == 0:
+            monkeypatch.setenv("RMR_NATIVE_CALL_READ", "1")
+            rd = reads[0]
+            out, _, pos = call_read_mods(rd.copy(), model, md)
+            o_out, _, o_pos = O.call_read_mods(rd.dacs, rd.shift, rd.scale, rd.seq_to_sig_map, rd.int_seq, state, md)
+            assert np.array_equal(pos, o_pos) and np.abs(out - o_out).max() <= 1e-4
+        del model
 
 
 def test_fused_edge_cases_vs_oracle(torch_cuda, O):

@@ -2638,3 +2638,47 @@ def test_bind_rank_applies_the_plan_to_the_process(tmp_path):
                          env=dict(os.environ, REMORA_AMD_RANK_BINDING="0", OMP_NUM_THREADS="3", RMR_PACK_THREADS="3"))
     got = json.loads(out.stdout.strip().splitlines()[-1])
     assert not got["b"]["bound"] and got["mine"] == allowed and got["omp"] == "3"
+
+
+def test_collect_reads_c_api_walk_equals_the_interpreters(monkeypatch):
+    """data_chunks._collect_reads: the C-API walk over a batch of RemoraRead objects (csrc/pyglue.c) hands rmr_pack_reads
+    the same addresses, sizes and scalars as the interpreter's walk; reads it does not take as they are (float dacs, strided
+    arrays, int32 mappings) fall to the interpreter, which converts them, and an inconsistent read is refused with the
+    reference's message either way."""
+    from remora_amd import RemoraError, synth
+    from remora_amd.data_chunks import RemoraRead, _collect_reads
+
+    def mk(i, nb, seq_dtype=np.int64):
+        r = synth.synth_read(nb, idx=i)
+        return RemoraRead(dacs=r["dacs"], shift=np.float32(r["shift"] + i), scale=r["scale"] - i, seq_to_sig_map=r["seq_to_sig_map"],
+                          int_seq=r["int_seq"].astype(seq_dtype), read_id=f"r{i}")
+
+    reads = [mk(0, 300), mk(1, 7, np.int8), mk(2, 1200, np.int32), mk(3, 50, np.uint8)]
+    monkeypatch.setenv("RMR_PY_GLUE", "1")
+    a = _collect_reads(reads)
+    assert a[-1] is None, "the C-API walk must take these reads as they are"
+    monkeypatch.setenv("RMR_PY_GLUE", "0")
+    b = _collect_reads(reads)
+    assert b[-1] is not None
+    for x, y in zip(a[:-1], b[:-1]):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    assert list(a[0]) == [r.dacs.ctypes.data for r in reads] and list(a[5]) == [8, 1, 4, 1]
+    assert a[6][2] == float(reads[2].shift) and a[7][3] == float(reads[3].scale)
+    # what the C walk leaves to the interpreter
+    monkeypatch.setenv("RMR_PY_GLUE", "1")
+    odd = [mk(0, 300), RemoraRead.test_read()]                       # float zeros as dacs
+    assert _collect_reads(odd)[-1] is not None
+    strided = mk(4, 200)
+    strided.dacs = np.repeat(strided.dacs, 2)[::2]                      # a view with a stride
+    assert not strided.dacs.flags.c_contiguous
+    got = _collect_reads([strided])
+    assert got[-1] is not None and np.array_equal(got[-1][0][0], strided.dacs)
+    m32 = mk(5, 100)
+    m32.seq_to_sig_map = m32.seq_to_sig_map.astype(np.int32)
+    got = _collect_reads([m32])
+    assert got[-1] is not None and got[-1][0][1].dtype == np.int64
+    bad = mk(6, 100)
+    bad.seq_to_sig_map = bad.seq_to_sig_map[:-1]
+    with pytest.raises(RemoraError, match="sizes incompatible"):
+        _collect_reads([reads[0], bad])
+    assert _collect_reads([])[1].size == 0

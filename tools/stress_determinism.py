@@ -22,7 +22,7 @@ def child(args):
     from remora_amd.model_util import model_from_state
 
     cc, kcb, _, num_out, _ = synth.CONFIGS[args.cfg]
-    state = synth.synth_state("conv_lstm", 64, 9, num_out, seed=0)
+    state = synth.synth_state(args.arch, 64, 9, num_out, seed=0)
     model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=args.dtype)
     d = synth.synth_chunks_config(args.cfg, args.n, shard=7)
     dev = [torch.from_numpy(d[k]).cuda() for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
@@ -90,6 +90,38 @@ def child(args):
     print("RESULT " + json.dumps({"hashes": hashes, "differing_reps": bad[:6], "cat": catinfo}))
 
 
+def child_specs(args):
+    """Every pipeline 'dtype[:cfg[:arch]]' of --child-specs in turn: REPS calls each, the logits of every call hashed."""
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch
+
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    out = {}
+    for spec in args.child_specs.split(","):
+        parts = spec.split(":")
+        dt, cfg, arch = parts[0], (parts[1] if len(parts) > 1 else "C100"), (parts[2] if len(parts) > 2 else "conv_lstm")
+        cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+        state = synth.synth_state(arch, 64, 9, num_out, seed=0)
+        model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=dt)
+        d = synth.synth_chunks_config(cfg, args.n, shard=7)
+        dev = [torch.from_numpy(d[k]).cuda() for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+        hashes = {}
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            lg = model.infer_chunks(*dev, kcb).cpu().numpy()
+            h = hashlib.sha256(lg.tobytes()).hexdigest()[:16]
+            hashes[h] = hashes.get(h, 0) + 1
+        out[spec] = {"hashes": hashes, "ms_per_call": (time.perf_counter() - t0) / args.reps * 1e3}
+        print(f"  [{os.environ.get('REMORA_HIP_LIB', 'shipped library').split('/')[-1]}] {spec}: {args.reps} calls, {out[spec]['ms_per_call']:.2f} ms each, "
+              f"{len(hashes)} distinct result(s)", file=sys.stderr, flush=True)
+        del model, dev
+    print("RESULT " + json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=3)
@@ -102,9 +134,46 @@ def main():
     ap.add_argument("--detail", action="store_true")
     ap.add_argument("--json", action="store_true", help="--mix: one JSON line with the verdict per process (tests/test_gpu_shared_gpu.py)")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--arch", default="conv_lstm", choices=["conv_lstm", "conv_only"])
+    ap.add_argument("--child-specs", default="", help="internal: run these pipelines in turn in this process")
+    ap.add_argument("--jitter", default="", help="comma list of pipelines 'dtype[:cfg[:arch]]': each runs ALONE on the GPU, two calls with the shipped "
+                    "library and --reps calls with the jitter build (make jitter: random per-wave sleeps around every barrier); every call "
+                    "of both must return the same bits")
     args = ap.parse_args()
     if args.child:
         return child(args)
+    if args.child_specs:
+        return child_specs(args)
+    if args.jitter:
+        # two processes, one per library, each running every pipeline in turn (alone on the GPU at any moment of its run)
+        jit = os.environ.get("RMR_JITTER_LIB") or os.path.join(ROOT, "remora_amd", "libremora_hip_jitter.so")
+        got = []
+        for lib, reps in ((None, 2), (jit, args.reps)):
+            env = dict(os.environ)
+            env.pop("REMORA_HIP_LIB", None)
+            if lib:
+                env["REMORA_HIP_LIB"] = lib
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-specs", args.jitter, "--reps", str(reps), "--n", str(args.n)],
+                               stdout=subprocess.PIPE, text=True, env=env, timeout=1500)  # (progress of the child: its stderr, not captured)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+            if not line:
+                print(f"  jitter: child with {lib or 'the shipped library'} FAILED rc={p.returncode}", flush=True)
+                if args.json:
+                    print("JSON " + json.dumps([{"pipeline": "*", "ok": False, "error": f"child rc {p.returncode}"}]), flush=True)
+                return
+            got.append(json.loads(line[-1][7:]))
+        verdicts = []
+        for spec in args.jitter.split(","):
+            ref, jh = got[0][spec]["hashes"], got[1][spec]["hashes"]
+            ok = len(ref) == 1 and set(jh) == set(ref)
+            nbad = sum(c for h, c in jh.items() if h not in ref)
+            verdicts.append({"pipeline": spec, "ok": ok, "shipped_hashes": ref, "jitter_hashes": jh, "differing_runs": nbad, "runs": sum(jh.values()),
+                             "ms_per_call_shipped": got[0][spec]["ms_per_call"], "ms_per_call_jitter": got[1][spec]["ms_per_call"]})
+            print(f"  jitter {spec}: {'same bits as the shipped build in' if ok else 'DIFFERS:'} {sum(jh.values()) - nbad} of {sum(jh.values())} calls "
+                  f"({got[0][spec]['ms_per_call']:.2f} -> {got[1][spec]['ms_per_call']:.2f} ms per call)" + ("" if ok else f" {jh} vs {ref}"), flush=True)
+        if args.json:
+            print("JSON " + json.dumps(verdicts), flush=True)
+        return
     if args.mix:
         dts = args.mix.split(",")
         def env_of(spec):  # "fp32@KEY=VAL@KEY2=VAL2"
