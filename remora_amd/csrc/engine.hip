@@ -1881,21 +1881,17 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     RMR_HIP(hipSetDevice(e->device));
     const int64_t ns = r->n_sig, nb = r->n_bases, nc = r->n_focus;
     const int no = m->desc.num_out, L = m->L;
-    // one blob, host (pinned) and device images with the same offsets: everything the extraction kernels read
+    // one blob, host (pinned) and device images with the same offsets: everything the extraction kernels read; the
+    // geometry rows behind it travel in a second, small copy
     size_t off = 0;
     auto seg = [&off](size_t bytes) { const size_t o = off; off += Stage::pad(bytes); return o; };
     const size_t o_dacs = seg(ns * 2 + 16), o_map = seg((nb + 1) * 8), o_seq = seg(nb + 16), o_foc = seg(nc * 8), o_off = seg(6 * 8),
-                 o_sc = seg(2 * 8), o_cr = seg((nc + 1) * 4), o_geo = seg(nc * 48), in_bytes = off;
+                 o_sc = seg(2 * 8), o_cr = seg((nc + 1) * 4), blob_bytes = off, o_geo = seg(nc * 48), in_bytes = off;
     const size_t out_bytes = Stage::pad((size_t)nc * no * 4) + 256;
     RMR_TRY(e->ensure_pin_call(in_bytes + out_bytes));
     char *hp = reinterpret_cast<char *>(e->pin_call);
-    // the big pieces first and on their way; the geometry of the chunks (integer arithmetic on the mapping: the function the
-    // geometry kernel runs, rmr_geometry.h) is computed on the host while they cross PCIe - the widths of the chunk rows are
-    // then known without asking the GPU, and the whole call is queued behind one another with a single wait at the end
-    Stage st{e};
     memcpy(hp + o_dacs, r->dacs, (size_t)ns * 2);
     memcpy(hp + o_map, r->seq_to_sig, (size_t)(nb + 1) * 8);
-    const int64_t *map = reinterpret_cast<const int64_t *>(hp + o_map);
     {
         int8_t *q = reinterpret_cast<int8_t *>(hp + o_seq);
         switch (r->seq_itemsize) {
@@ -1911,20 +1907,19 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     double *hs = reinterpret_cast<double *>(hp + o_sc);
     hs[0] = r->shift; hs[1] = r->scale;
     memset(hp + o_cr, 0, (size_t)(nc + 1) * 4);  // every chunk belongs to read 0
-    int64_t *hgeo = reinterpret_cast<int64_t *>(hp + o_geo);
-    int64_t msl = 0;
-    for (int64_t i = 0; i < nc; ++i) {
-        const int64_t sl = chunk_geometry_row(map, nb, ns, r->focus_bases[i], r->base_start_justify, r->offset, r->cc_before, r->cc_after,
-                                              hgeo + i * 6);
-        msl = sl > msl ? sl : msl;
-        read_focus_bases[i] = hgeo[i * 6 + 3];
-    }
-    if (msl > nb + 1 || msl > 32000) RMR_FAIL(RMR_ERR_INVALID, "chunk of %lld bases", (long long)msl);
-    const int seq_w = (int)std::max<int64_t>(msl + r->kb + r->ka, r->kb + r->ka + 1), map_w = (int)std::max<int64_t>(msl + 1, 2);
-    RMR_TRY(st.init(in_bytes + Stage::pad(ns * 4 + 16) + Stage::pad((size_t)nc * L * 4) + Stage::pad((size_t)nc * seq_w) +
-                    Stage::pad((size_t)nc * map_w * 2) + Stage::pad(nc * 2) + Stage::pad(nc * 8) + Stage::pad((size_t)nc * no * 4) + 8192));
+    // The arena is sized before the widths of the chunk rows are known, for chunks of up to `cap` bases (a chunk of L samples
+    // holds more only where bases have no samples of their own: then it grows to the exact number below, before anything that
+    // depends on it is queued).
+    Stage st{e};
+    const int64_t cap = std::min<int64_t>(nb + 1, 2 * (int64_t)L + 8);
+    auto arena_bytes = [&](int64_t msl_) {
+        return in_bytes + Stage::pad(ns * 4 + 16) + Stage::pad((size_t)nc * L * 4) + Stage::pad((size_t)nc * (msl_ + r->kb + r->ka + 1)) +
+               Stage::pad((size_t)nc * (msl_ + 2) * 2) + Stage::pad(nc * 2) + Stage::pad(nc * 8) + Stage::pad((size_t)nc * no * 4) + 8192;
+    };
+    // the read's arrays first and on their way ...
+    RMR_TRY(st.init(arena_bytes(cap)));
     char *dp = st.take<char>(in_bytes);
-    RMR_HIP(hipMemcpyAsync(dp, hp, in_bytes, hipMemcpyHostToDevice, e->stream));
+    RMR_HIP(hipMemcpyAsync(dp, hp, blob_bytes, hipMemcpyHostToDevice, e->stream));
     rmr_reads d{};
     d.n_reads = 1;
     d.dacs = reinterpret_cast<const int16_t *>(dp + o_dacs);
@@ -1941,13 +1936,51 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     const int32_t *chunk_read = reinterpret_cast<const int32_t *>(dp + o_cr);
     const int64_t *dgeo = reinterpret_cast<const int64_t *>(dp + o_geo);
     float *dsig = st.take<float>(ns + 4);
+    RMR_TRY(launch_geometry(e, d, 0, chunk_read, dsig, ns, nullptr, nullptr, nullptr));  // n_chunks 0: the signal normalisation alone
+    // ... then, while they cross PCIe and the signal is normalised, the geometry of the chunks on the host: integer
+    // arithmetic on the mapping - the function the geometry kernel runs (rmr_geometry.h), its searches started at the focus
+    // base when the mapping is monotone.  The widths of the chunk rows are then known without asking the GPU: the whole call
+    // is queued behind one another and waited for once.
+    const int64_t *map = reinterpret_cast<const int64_t *>(hp + o_map);
+    bool monotone = true;
+    for (int64_t i = 0; i < nb; ++i) monotone &= map[i + 1] >= map[i];
+    int64_t *hgeo = reinterpret_cast<int64_t *>(hp + o_geo);
+    int64_t msl = 0;
+    for (int64_t i = 0; i < nc; ++i) {
+        const int64_t sl = chunk_geometry_row(map, nb, ns, r->focus_bases[i], r->base_start_justify, r->offset, r->cc_before, r->cc_after,
+                                              hgeo + i * 6, monotone);
+        msl = sl > msl ? sl : msl;
+        read_focus_bases[i] = hgeo[i * 6 + 3];
+    }
+    if (msl > nb + 1 || msl > 32000) RMR_FAIL(RMR_ERR_INVALID, "chunk of %lld bases", (long long)msl);
+    if (msl > cap) {  // zero-dwell bases made a chunk wider than the arena was sized for: start over with the exact size
+        RMR_HIP(hipStreamSynchronize(e->stream));
+        st = Stage{e};
+        RMR_TRY(st.init(arena_bytes(msl)));
+        dp = st.take<char>(in_bytes);
+        RMR_HIP(hipMemcpyAsync(dp, hp, blob_bytes, hipMemcpyHostToDevice, e->stream));
+        d.dacs = reinterpret_cast<const int16_t *>(dp + o_dacs);
+        d.seq_to_sig = reinterpret_cast<const int64_t *>(dp + o_map);
+        d.int_seq = reinterpret_cast<const int8_t *>(dp + o_seq);
+        d.focus_bases = reinterpret_cast<const int64_t *>(dp + o_foc);
+        d.sig_off = reinterpret_cast<const int64_t *>(dp + o_off);
+        d.seq_off = d.sig_off + 2;
+        d.focus_off = d.sig_off + 4;
+        d.shift = reinterpret_cast<const double *>(dp + o_sc);
+        d.scale = d.shift + 1;
+        chunk_read = reinterpret_cast<const int32_t *>(dp + o_cr);
+        dgeo = reinterpret_cast<const int64_t *>(dp + o_geo);
+        dsig = st.take<float>(ns + 4);
+        RMR_TRY(launch_geometry(e, d, 0, chunk_read, dsig, ns, nullptr, nullptr, nullptr));
+    }
+    RMR_HIP(hipMemcpyAsync(dp + o_geo, hp + o_geo, (size_t)nc * 48, hipMemcpyHostToDevice, e->stream));
+    const int seq_w = (int)std::max<int64_t>(msl + r->kb + r->ka, r->kb + r->ka + 1), map_w = (int)std::max<int64_t>(msl + 1, 2);
     float *dsignal = st.take<float>((size_t)nc * L);
     int8_t *dseqs = st.take<int8_t>((size_t)nc * seq_w);
     int16_t *dmaps = st.take<int16_t>((size_t)nc * map_w);
     int16_t *dlens = st.take<int16_t>(nc);
     int64_t *drfb = st.take<int64_t>(nc);
     float *dlog = st.take<float>((size_t)nc * no);
-    RMR_TRY(launch_geometry(e, d, 0, chunk_read, dsig, ns, nullptr, nullptr, nullptr));  // n_chunks 0: the signal normalisation alone
     RMR_TRY(launch_fill(e, d, nc, chunk_read, dsig, dgeo, dsignal, dseqs, seq_w, dmaps, map_w, dlens, drfb));
     RMR_TRY(run_pipeline(m, dsignal, nullptr, dseqs, seq_w, dmaps, map_w, dlens, r->kb, r->ka, nc, dlog));
     float *hlog = reinterpret_cast<float *>(hp + in_bytes);

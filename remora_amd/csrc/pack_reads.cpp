@@ -3,6 +3,9 @@
 // few native threads.  The reference has no counterpart (it processes reads one at a time in Python,
 // src/remora/inference.py:62-137); in this engine the per-read Python copies of this step were 55 of the 83 ms that a
 // batch of 2048 x 5 kb reads took end to end.
+#include <emmintrin.h>
+
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -15,6 +18,51 @@ template <typename T>
 void narrow_to_i8(const void *src, int64_t n, int8_t *dst) {
     const T *s = static_cast<const T *>(src);
     for (int64_t i = 0; i < n; ++i) dst[i] = (int8_t)s[i];
+}
+
+// int64 bases (what util.seq_to_int and the reference hand over: 8 bytes a base) -> int8, sixteen at a time: the low dwords of
+// eight 16-byte loads, then the two saturating packs (base codes are -1..3; anything wider is clamped instead of wrapped,
+// and refused downstream either way).  The scalar loop cost 5 us per 5 kb read - more than the copy of its 100 KB of signal.
+void narrow_i64_to_i8(const void *src, int64_t n, int8_t *dst) {
+    const int64_t *s = static_cast<const int64_t *>(src);
+    int64_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        __m128i d[4];
+        for (int k = 0; k < 4; ++k) {
+            const __m128 a = _mm_castsi128_ps(_mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 4 * k)));
+            const __m128 b = _mm_castsi128_ps(_mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 4 * k + 2)));
+            d[k] = _mm_castps_si128(_mm_shuffle_ps(a, b, _MM_SHUFFLE(2, 0, 2, 0)));  // low dwords of four int64: exact for |v| < 2^31
+        }
+        const __m128i w0 = _mm_packs_epi32(d[0], d[1]), w1 = _mm_packs_epi32(d[2], d[3]);
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), _mm_packs_epi16(w0, w1));
+    }
+    for (; i < n; ++i) dst[i] = (int8_t)s[i];
+}
+
+// Copy into the pinned staging buffer with streaming stores: the destination is written once and next read by the GPU's DMA
+// engine, never by this CPU - ordinary stores first READ every destination line into the cache (a third of the memory
+// traffic of the gather, which runs at the memory's rate, not the cores': profiles/r05_reads_timeline.md).
+void stream_copy(void *dst, const void *src, size_t n) {
+    char *d = static_cast<char *>(dst);
+    const char *s = static_cast<const char *>(src);
+    static const bool stream = !(getenv("RMR_PACK_STREAM") && atoi(getenv("RMR_PACK_STREAM")) == 0);  // 0: plain memcpy (A/B)
+    if (n < 2048 || !stream) {
+        memcpy(d, s, n);
+        return;
+    }
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    memcpy(d, s, head);
+    d += head; s += head; n -= head;
+    const size_t blocks = n / 64;
+    for (size_t i = 0; i < blocks; ++i, s += 64, d += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + 16));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + 32)), e = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i *>(d), a);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(d + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(d + 32), c);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(d + 48), e);
+    }
+    memcpy(d, s, n - blocks * 64);
 }
 
 }  // namespace
@@ -38,16 +86,17 @@ extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const in
     // reads are dealt to the threads in contiguous ranges of about equal signal volume
     auto work = [&](int64_t r0, int64_t r1) {
         for (int64_t i = r0; i < r1; ++i) {
-            memcpy(dst_dacs + sig_off[i], dacs[i], (size_t)sig_n[i] * sizeof(int16_t));
-            memcpy(dst_maps + seq_off[i] + i, maps[i], (size_t)(seq_n[i] + 1) * sizeof(int64_t));  // n + 1 entries per read
+            stream_copy(dst_dacs + sig_off[i], dacs[i], (size_t)sig_n[i] * sizeof(int16_t));
+            stream_copy(dst_maps + seq_off[i] + i, maps[i], (size_t)(seq_n[i] + 1) * sizeof(int64_t));  // n + 1 entries per read
             int8_t *d = dst_seq + seq_off[i];
             switch (seq_itemsize[i]) {
                 case 1: memcpy(d, seqs[i], (size_t)seq_n[i]); break;
                 case 2: narrow_to_i8<int16_t>(seqs[i], seq_n[i], d); break;
                 case 4: narrow_to_i8<int32_t>(seqs[i], seq_n[i], d); break;
-                default: narrow_to_i8<int64_t>(seqs[i], seq_n[i], d); break;
+                default: narrow_i64_to_i8(seqs[i], seq_n[i], d); break;
             }
         }
+        _mm_sfence();  // the streamed lines are globally visible before the caller queues the upload
     };
     if (threads == 1 || n_reads < 2 * threads) {
         work(0, n_reads);

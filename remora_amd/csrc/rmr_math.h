@@ -72,7 +72,8 @@ __device__ __forceinline__ void jitter() {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
     const unsigned id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_ID: wave / SIMD / CU / SE of this wave
     unsigned h = ((unsigned)t ^ (unsigned)(t >> 21) ^ (id * 0x9E3779B9u)) * 2654435761u;
-    h = __builtin_amdgcn_readfirstlane(h) >> 26;  // 0..63, one value per wave
+    h = (unsigned)__builtin_amdgcn_readfirstlane((int)h) >> 26;  // 0..63, one value per wave (unsigned: the builtin returns int,
+                                                                 // whose arithmetic shift made half the draws a 4-billion-round sleep)
     if (h >= 62) {
         for (unsigned i = 61; i < h; ++i) {  // 1..2 x 2 x 8128 cycles: 7-14 us
             __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);

@@ -221,18 +221,32 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
                 pass
 
 
-def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
-    """One large batch through `_pipelined_parts`, cut into sub-batches of `sub` reads after two short ones (the GPU
-    starts after the staging of `sub / 4` reads instead of `sub`)."""
+def _subbatch_cuts(n, sub):
+    """[(start, stop)] of the sub-batches of a batch of n reads: two short ones first (the GPU starts after the staging of
+    `sub / 4` reads instead of `sub`), whole ones in the middle, and the rest in two tapering pieces - what is left to do when
+    the stager has finished is the work on the LAST sub-batch, so that one is small."""
     cuts, pos = [], 0
     for size in (max(1, sub // 4), max(1, sub // 2)):
-        cuts.append((pos, pos + size))
-        pos += size
-    while pos < len(reads):
-        cuts.append((pos, min(pos + sub, len(reads))))
+        if pos < n:
+            cuts.append((pos, min(pos + size, n)))
+            pos = cuts[-1][1]
+    while n - pos > sub + sub // 2:
+        cuts.append((pos, pos + sub))
         pos += sub
+    left = n - pos
+    if left > sub // 2:
+        first = (left * 3 + 4) // 5
+        cuts.append((pos, pos + first))
+        pos += first
+    if pos < n:
+        cuts.append((pos, n))
+    return cuts
+
+
+def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
+    """One large batch through `_pipelined_parts`, cut into sub-batches by `_subbatch_cuts`."""
     out = []
-    for _, res in _pipelined_parts((reads[a:b] for a, b in cuts), model, model_metadata, return_mod_probs):
+    for _, res in _pipelined_parts((reads[a:b] for a, b in _subbatch_cuts(len(reads), sub)), model, model_metadata, return_mod_probs):
         out.extend(res)
     return out
 
@@ -270,17 +284,24 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     focus, foc_off = dr.motif_focus_bases(motifs)
     arrs, _ = _extract_device(dr, focus, foc_off, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
                               model_metadata["base_start_justify"], model_metadata["offset"])
-    focus_host = device_to_numpy(focus) if int(foc_off[-1]) else np.zeros(0, np.int64)
     bounds = [int(x) for x in foc_off]  # per-read slices of the concatenated results (np.split costs 5 us a piece)
+    if len(arrs) == 0:
+        for r in reads:
+            r.focus_bases = np.zeros(0, np.int64)
+        return [(np.array([]), np.array([]), np.array([])) for _ in reads]
+    # the network is queued BEFORE anything is fetched back: the copy of the focus bases (1.3 MB for 512 reads) then runs
+    # under its kernels instead of in front of them (profiles/r05_reads_timeline.md: 1.7 ms of GPU idle time per sub-batch)
+    out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
+    focus_host = device_to_numpy(focus)
     for i, r in enumerate(reads):
         r.focus_bases = focus_host[bounds[i] : bounds[i + 1]]
-    if len(arrs) == 0:
-        return [(np.array([]), np.array([]), np.array([])) for _ in reads]
-    out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
+    # the chunks' positions: the focus base after the model's offset, clipped into the read (data_chunks.py:443-446) - known
+    # on the host, no second copy back
+    last = np.repeat(np.diff(dr.seq_off) - 1, np.diff(foc_off))
+    pos = np.clip(focus_host + int(model_metadata["offset"]), 0, last)
     if hasattr(model, "engine"):
-        model.engine.wait_submitted()  # the copies below may run on another stream than the engine's (pipelined callers)
+        model.engine.wait_submitted()  # the copy below may run on another stream than the engine's (pipelined callers)
     out = device_to_numpy(out)
-    pos = device_to_numpy(arrs.read_focus_bases)
     if return_mod_probs:
         out = softmax_axis1(out)[:, 1:].astype(np.float64)
     labels, res = arrs.labels, []

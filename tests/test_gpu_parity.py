@@ -274,7 +274,7 @@ def test_extract_chunk_one_signal_position_golden(torch_cuda):
                 assert np.array_equal(ch.signal.view(np.uint32), g[pre + "signal"][i].view(np.uint32)), (rname, ci, i)
                 assert np.array_equal(ch.seq_w_context, g[pre + "seq_w_context"][i, : sl[i] + sum(kcb)])
                 assert ch.seq_to_sig_map.dtype == np.int32 and np.array_equal(ch.seq_to_sig_map, g[pre + "seq_to_sig_map"][i, : sl[i] + 1])
-                assert (ch.chunk_sig_focus_idx, ch.chunk_focus_base, ch.read_focus_base) == tuple(int(x) for x in misc[i])
+                assert (ch.chunk_sig_focus_idx, ch.chunk_focus_base, ch.read_focus_base) == tuple(int(x) for x in misc[i, :3])
                 assert ch.label == 1 and ch.read_id == rname and ch.seq_len == sl[i]
                 checked += 1
                 padded += int(fsig - cc[0] < 0 or fsig + cc[1] > read.dacs.size)

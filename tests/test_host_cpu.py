@@ -2682,3 +2682,35 @@ def test_collect_reads_c_api_walk_equals_the_interpreters(monkeypatch):
     with pytest.raises(RemoraError, match="sizes incompatible"):
         _collect_reads([reads[0], bad])
     assert _collect_reads([])[1].size == 0
+
+
+def test_chunk_geometry_searches_from_a_hint_equal_bisection(tmp_path):
+    """rmr_geometry.h is ONE function for the geometry kernel and for the host side of rmr_call_read; the host calls it with
+    searches that gallop outwards from the focus base (a handful of cache-local probes instead of log2(n_bases) scattered
+    ones).  tests/c/geometry_searches.cpp: 1.3 M random searches and 150 k whole rows - both forms agree everywhere."""
+    import shutil
+
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the image"
+    (tmp_path / "hip").mkdir()
+    (tmp_path / "hip" / "hip_runtime.h").write_text("#pragma once\n#define __host__\n#define __device__\n")
+    exe = str(tmp_path / "geo")
+    cc = subprocess.run([gxx, "-O2", "-std=c++17", "-Wall", "-I", str(tmp_path), "-I", os.path.join(ROOT, "remora_amd", "csrc"),
+                         os.path.join(ROOT, "tests", "c", "geometry_searches.cpp"), "-o", exe], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip().endswith("0 mismatches"), run.stdout + run.stderr
+
+
+def test_subbatch_cuts_partition_a_batch_of_reads():
+    """inference._subbatch_cuts: contiguous, complete, non-empty pieces for any batch size; a short start (the GPU gets work
+    after a quarter sub-batch has been staged) and a short end (what remains to be done when the stager is finished)."""
+    from remora_amd.inference import _subbatch_cuts
+
+    for sub in (512, 64, 7, 1):
+        for n in list(range(1, 70)) + [511, 512, 513, 1024, 1100, 2048, 5000, 100_003]:
+            cuts = _subbatch_cuts(n, sub)
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(b > a for a, b in cuts)
+            assert max(b - a for a, b in cuts) <= max(sub, 1) + sub // 2
+    assert [b - a for a, b in _subbatch_cuts(2048, 512)] == [128, 256, 512, 512, 384, 256]

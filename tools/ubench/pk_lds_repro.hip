@@ -17,6 +17,7 @@ constexpr int KW = 5, L = 100, P1 = L - KW + 1;
 
 __device__ __forceinline__ float row(unsigned chunk, int s, unsigned it) { return 0.001f * (float)((chunk * 131u + s * 17u + it * 7u) & 1023u) - 0.5f; }
 __device__ __forceinline__ float sfma(float a, float b, float c) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float sadd(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -57,6 +58,13 @@ __global__ __launch_bounds__(512) void repro(unsigned long long *bad, unsigned l
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop %0" ::"n"(NOPS) : "memory");
 #endif
                 float x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#ifdef PAIR_ADD  // v_pk_add_f32 on the ALIGNED register pairs of the LDS read (no op_sel): what seq2_front_kernel ships
+                lo = lo + f32x2{xv.x, xv.y};
+                hi = hi + f32x2{xv.z, xv.w};
+                r0 = sadd(r0, row(chunk, (pos + t) * 4 + 0, u)); r1 = sadd(r1, row(chunk, (pos + t) * 4 + 1, u));
+                r2 = sadd(r2, row(chunk, (pos + t) * 4 + 2, u)); r3 = sadd(r3, row(chunk, (pos + t) * 4 + 3, u));
+                continue;
+#endif
 #pragma unroll
                 for (int ic = 0; ic < 4; ++ic) {
 #ifdef FROM_REG  // the operand from registers (the value the row holds), not from the LDS read
@@ -115,6 +123,8 @@ int main(int argc, char **argv) {
     const char *form = "v_pk_fma_f32 op_sel, operand from registers instead of the LDS read";
 #elif defined(NOPS)
     const char *form = "v_pk_fma_f32 op_sel, s_waitcnt + s_nop behind the LDS read";
+#elif defined(PAIR_ADD)
+    const char *form = "v_pk_add_f32 on the aligned pairs of the LDS read (no op_sel)";
 #else
     const char *form = "v_pk_fma_f32";
 #endif
