@@ -335,8 +335,8 @@ PARITY_SAMPLE = 20_000
 
 
 def config_parity(job, fp32_logits=None):
-    """`parity` of one configuration: its logits on the first PARITY_SAMPLE chunks of rank 0's data against the ORACLE's fp32
-    forward (CPU: C restatement of the encode + torch.nn restatement of the network - not this library), and, where the fp32
+    """`parity` of one configuration: its logits on the first PARITY_SAMPLE chunks of rank 0's data against the ORACLE's
+    forward in float64 (CPU: C restatement of the encode + torch.nn restatement of the network - not this library), and, where the fp32
     GPU path of the same workload ran in this process (`fp32_logits`, device), over EVERY chunk of the step against it; the
     gate of the dtype (PARITY_GATES) and whether it is met."""
     import torch
@@ -349,13 +349,13 @@ def config_parity(job, fp32_logits=None):
     d = job.data
     enc = O.compute_encoded_kmer_batch(job.kcb[0], job.kcb[1], d["sequence"][:k], d["sequence_to_signal_mapping"][:k], d["sequence_lengths"][:k])
     torch.set_num_threads(min(32, effective_cpu_count()))
-    with torch.no_grad():
-        ref = torch_ref.from_state(job.state)(torch.from_numpy(d["signal"][:k]), torch.from_numpy(enc)).numpy()
-    got = job.logits[:k].cpu().numpy()
+    with torch.no_grad():  # float64: the comparand's own rounding (1e-4 at C200 in fp32) stays out of the fp32-class gates
+        ref = torch_ref.from_state(job.state).double()(torch.from_numpy(d["signal"][:k]).double(), torch.from_numpy(enc).double()).numpy()
+    got = job.logits[:k].cpu().numpy().astype(np.float64)
     srt = np.sort(ref, axis=1)
     clear = (srt[:, -1] - srt[:, -2]) > 2e-2
     agree = got.argmax(1) == ref.argmax(1)
-    out = {"comparand": "oracle fp32 forward (CPU restatement)", "sample_chunks": int(k), "max_abs_vs_oracle": float(np.abs(got - ref).max()),
+    out = {"comparand": "oracle network evaluated in float64 (CPU restatement)", "sample_chunks": int(k), "max_abs_vs_oracle": float(np.abs(got - ref).max()),
            "mean_abs_vs_oracle": float(np.abs(got - ref).mean()), "sample_chunks_with_margin_gt_2e-2": int(clear.sum()),
            "sample_argmax_agreement_margin_gt_2e-2": float(agree[clear].mean()) if clear.any() else None}
     if fp32_logits is not None and fp32_logits.shape == job.logits.shape and job.dtype != "fp32":

@@ -72,6 +72,11 @@ enum rmr_engine_flags { RMR_ENGINE_OWN_STREAM = 0, RMR_ENGINE_USE_STREAM = 1 };
 int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out);
 void rmr_engine_destroy(rmr_engine *e);
 int rmr_engine_synchronize(rmr_engine *e);
+/* Stream-ordered hand-over between two engines of one device: everything queued on `producer` so far is finished before
+ * anything queued on `waiter` from now on starts - an event, no host wait.  (A caller that extracts chunks on one engine
+ * and runs the network on another - the reads pipeline - needs no hipStreamSynchronize in between.)
+ * replaces: nothing in the reference (one stream, one thread: src/remora/inference.py:277-316). */
+int rmr_engine_wait_for(rmr_engine *waiter, rmr_engine *producer);
 /* chunks per internal sub-batch of the fused pipeline (scratch = ~33 KB/chunk); 0 = default */
 int rmr_engine_set_subbatch(rmr_engine *e, int64_t chunks);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "rmr_engine_create": (c_int, [c_int, c_vp, c_int, ctypes.POINTER(c_vp)]),
     "rmr_engine_destroy": (None, [c_vp]),
     "rmr_engine_synchronize": (c_int, [c_vp]),
+    "rmr_engine_wait_for": (c_int, [c_vp, c_vp]),
     "rmr_engine_set_subbatch": (c_int, [c_vp, c_i64]),
     "rmr_model_create": (c_int, [c_vp, ctypes.POINTER(ModelDesc), c_vp, ctypes.c_size_t, ctypes.POINTER(c_vp)]),
     "rmr_model_destroy": (None, [c_vp]),

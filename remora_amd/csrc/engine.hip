@@ -466,7 +466,7 @@ int rmr_engine::prof_collect() {
 extern "C" {
 
 const char *rmr_last_error(void) { return g_err.c_str(); }
-const char *rmr_version(void) { return "remora_hip 0.4 (gfx950)"; }  // 0.4: rmr_call_read
+const char *rmr_version(void) { return "remora_hip 0.5 (gfx950)"; }  // 0.5: rmr_call_read, rmr_engine_wait_for
 
 int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
     if (!out) RMR_FAIL(RMR_ERR_INVALID, "out is NULL");
@@ -487,11 +487,18 @@ int rmr_engine_create(int device, void *stream, int flags, rmr_engine **out) {
     if (flags & RMR_ENGINE_USE_STREAM) {
         e->stream = reinterpret_cast<hipStream_t>(stream);
     } else {
-        RMR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        // an engine with a stream of its own is a helper beside the model's engine (chunk extraction, ingest decodes): short
+        // kernels whose results somebody waits for - the highest priority the device offers, so that they are dispatched
+        // ahead of queued work of the long model kernels wherever the hardware has a choice
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess)
+            RMR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->owns_stream = true;
     }
     RMR_HIP(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
     RMR_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    RMR_HIP(hipEventCreateWithFlags(&e->ev_handoff, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) {
         RMR_HIP(hipEventCreateWithFlags(&e->ev_front[k], hipEventDisableTiming));
         RMR_HIP(hipEventCreateWithFlags(&e->ev_done[k], hipEventDisableTiming));
@@ -507,6 +514,7 @@ void rmr_engine_destroy(rmr_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_handoff) (void)hipEventDestroy(e->ev_handoff);
     for (int k = 0; k < 2; ++k) {
         if (e->ev_front[k]) (void)hipEventDestroy(e->ev_front[k]);
         if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
@@ -529,6 +537,20 @@ void rmr_engine_destroy(rmr_engine *e) {
 int rmr_engine_synchronize(rmr_engine *e) {
     if (!e) RMR_FAIL(RMR_ERR_INVALID, "engine is NULL");
     RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int rmr_engine_wait_for(rmr_engine *waiter, rmr_engine *producer) {
+    if (!waiter || !producer) RMR_FAIL(RMR_ERR_INVALID, "engine is NULL");
+    if (waiter == producer || waiter->stream == producer->stream) return 0;
+    if (waiter->device != producer->device) RMR_FAIL(RMR_ERR_INVALID, "engines on different devices");
+    {
+        std::lock_guard<std::mutex> lk(producer->mu);
+        RMR_HIP(hipSetDevice(producer->device));
+        RMR_HIP(hipEventRecord(producer->ev_handoff, producer->stream));
+    }
+    std::lock_guard<std::mutex> lk(waiter->mu);
+    RMR_HIP(hipStreamWaitEvent(waiter->stream, producer->ev_handoff, 0));
     return 0;
 }
 
@@ -1462,11 +1484,17 @@ int stage_reads(rmr_engine *e, Stage &st, const rmr_reads *r, int mem, bool need
     o->total_bases = seq_off[nr];
     o->n_chunks = foc_off[nr];
     o->d = *r;
-    // read index per chunk / per sample (host-built, tiny next to the data itself)
-    std::vector<int32_t> cr((size_t)o->n_chunks), sr;
+    o->chunk_read = st.take<int32_t>(o->n_chunks + 1);
+    if (mem == RMR_MEM_DEVICE) {
+        // device-resident batch: the read index of every chunk comes from the offsets where they are - no host loop, no
+        // upload, no wait (a batch of the reads pipeline paid two of these round trips per extraction, each behind whatever
+        // the GPU was running)
+        return launch_chunk_read(e, r->focus_off, nr, o->n_chunks, o->chunk_read);
+    }
+    // read index per chunk (host-built, tiny next to the data itself)
+    std::vector<int32_t> cr((size_t)o->n_chunks);
     for (int64_t k = 0; k < nr; ++k)
         for (int64_t i = foc_off[k]; i < foc_off[k + 1]; ++i) cr[(size_t)i] = (int32_t)k;
-    o->chunk_read = st.take<int32_t>(o->n_chunks + 1);
     H2D(o->chunk_read, cr.data(), cr.size() * 4);
     if (mem == RMR_MEM_HOST) {
 #define STAGE_ARR(field, T, count)                                        \

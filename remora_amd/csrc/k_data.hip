@@ -584,6 +584,24 @@ int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32
     return 0;
 }
 
+// read index of every chunk from the chunk offsets of the reads (device arrays): chunk i belongs to the read r with
+// focus_off[r] <= i < focus_off[r + 1].  Was a host loop + upload + stream synchronisation in front of every geometry and
+// fill launch of a device-resident batch.
+__global__ void chunk_read_kernel(const int64_t *__restrict__ focus_off, int64_t n_reads, int64_t n_chunks, int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks) return;
+    int64_t lo = 0, hi = n_reads;  // last r with focus_off[r] <= i
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (focus_off[mid] <= i) lo = mid; else hi = mid; }
+    out[i] = (int32_t)lo;
+}
+
+int launch_chunk_read(rmr_engine *e, const int64_t *focus_off, int64_t n_reads, int64_t n_chunks, int32_t *out) {
+    if (n_chunks <= 0) return 0;
+    hipLaunchKernelGGL(chunk_read_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, e->stream, focus_off, n_reads, n_chunks, out);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 // ======================================================================================
 // label tally: argmax (first maximum) histogram, block-level LDS bins then one atomic per bin
 // ======================================================================================

@@ -81,6 +81,7 @@ struct rmr_engine {
     // i+1 run under the matrix kernels of sub-batch i)
     hipStream_t aux = nullptr;
     hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_handoff = nullptr;  // rmr_engine_wait_for: recorded on this engine's stream, waited for by another's
     int num_cus = 256;
     std::mutex mu;
     int64_t subbatch = 0;
@@ -240,6 +241,7 @@ int launch_geometry(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const i
 int launch_fill(rmr_engine *e, const rmr_reads &d, int64_t n_chunks, const int32_t *chunk_read,
                 const float *sig, const int64_t *geo, float *signal, int8_t *seqs, int seq_w,
                 int16_t *maps, int map_w, int16_t *lens, int64_t *rfb);
+int launch_chunk_read(rmr_engine *e, const int64_t *focus_off, int64_t n_reads, int64_t n_chunks, int32_t *out);
 int launch_count(rmr_engine *e, const float *logits, int64_t n, int num_out, int64_t *counts);
 int launch_validation_tally(rmr_engine *e, const float *logits, const int64_t *labels, int64_t n, int km, int kf, const int *colmap,
                             int64_t *conf, float *win, uint8_t *pred, double *loss_sum);

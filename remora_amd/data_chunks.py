@@ -376,8 +376,10 @@ class DeviceReads:
         return focus[:n_hits], foc_off
 
 
-def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset, labels=None):
-    """Chunk extraction for device-resident reads and focus bases (see extract_chunk_arrays)."""
+def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset, labels=None, sync=True):
+    """Chunk extraction for device-resident reads and focus bases (see extract_chunk_arrays).  `sync=False`: return with the
+    fill kernel still queued on the reads' engine (`dr.engine`) - for a caller that hands the arrays to another engine with
+    Engine.wait_for instead of a host wait; the kernels' inputs stay referenced by the returned arrays until those are dropped."""
     torch = _torch()
     eng, lib = dr.engine, L.lib()
     dev = eng.torch_device
@@ -418,11 +420,14 @@ def _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_
         L.check(lib.rmr_chunk_fill(eng.handle, ctypes.byref(rs), sig.data_ptr(), geo.data_ptr(), signal.data_ptr(),
                                    sequence.data_ptr(), sequence.shape[1], mapping.data_ptr(), mapping.shape[1],
                                    lengths.data_ptr(), rfb.data_ptr(), L.MEM_DEVICE))
-    # the kernels above read the staged inputs: keep them alive until the stream drains
-    eng.synchronize()
     if labels is None:
         labels = np.full(n_chunks, -1, np.int64)
-    return ChunkArrays(signal, sequence, mapping, lengths, rfb, labels, geo, kmer_context_bases, chunk_context), sig
+    arrs = ChunkArrays(signal, sequence, mapping, lengths, rfb, labels, geo, kmer_context_bases, chunk_context)
+    if sync:
+        eng.synchronize()  # the kernels above read the staged inputs: keep them alive until the stream drains
+    else:
+        arrs._inputs = (d_foc_off, focus, sig, dr)  # ... or for as long as the arrays they are turned into
+    return arrs, sig
 
 
 def extract_chunk_arrays(reads, chunk_context, kmer_context_bases, base_start_justify=False, offset=0,

@@ -60,6 +60,11 @@ class Engine:
     def synchronize(self):
         L.check(self._lib.rmr_engine_synchronize(self._h))
 
+    def wait_for(self, producer):
+        """Everything queued on `producer` (another Engine of this GPU) so far finishes before anything queued on this engine
+        from now on starts: an event between the two streams, no host wait (rmr_engine_wait_for)."""
+        L.check(self._lib.rmr_engine_wait_for(self._h, producer._h))
+
     def wait_submitted(self):
         """Block until the work submitted to the engine's stream SO FAR is done (an event, not a stream drain: work
         another thread queues behind it is not waited for).  A caller whose torch current stream is not the engine's

@@ -129,17 +129,17 @@ def iter_call_reads_mods(read_batches, model, model_metadata, return_mod_probs=F
             cur = nxt
 
 
-_PIPE = {}  # GPU index -> the pipeline's torch streams (upload, 2 workers) and its two thread pools
+_PIPE = {}  # GPU index -> the pipeline's torch streams (upload, 3 workers) and its two thread pools
 _PIPE_LOCK = threading.Lock()
 
 
 def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
-    """call_reads_mods for every batch of reads of the iterable `parts`, on three threads: one stages (gather into
-    pinned memory + upload on its own stream, two pinned buffers taking turns), two alternate over the staged batches
+    """call_reads_mods for every batch of reads of the iterable `parts`, on four threads: one stages (gather into
+    pinned memory + upload on its own stream, two pinned buffers taking turns), three take turns over the staged batches
     (motif scan, extraction, inference, per-read split), so that the kernels of one batch run under the host work of
     its neighbours.  Each engine serialises its GPU calls (one mutex per engine: extraction runs on a second engine
     with its own stream); every C call and every copy releases the GIL.  Yields (batch, results) in order, results
-    identical to the unpipelined call.  At most four batches are resident and six in flight at a time.  A single-pass
+    identical to the unpipelined call.  At most five batches are resident and six in flight at a time.  A single-pass
     signal-mapping refiner (scale_iters <= 0) can run per batch inside the workers (opt-in, see call_reads_mods);
     iterative re-scaling (scale_iters > 0) rewrites the reads on the host first and never comes here."""
     import collections
@@ -158,23 +158,23 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
     refiner = model_metadata.get("sig_map_refiner")
     if refiner is not None and getattr(refiner, "is_loaded", False):
         refiner._device_refiner(prep.device)  # created once, here, not by whichever worker comes first
-    slots = threading.BoundedSemaphore(4)
-    # the three torch streams and the threads are made once per GPU: torch's caching allocator keeps its free blocks per
+    slots = threading.BoundedSemaphore(5)
+    # the four torch streams and the threads are made once per GPU: torch's caching allocator keeps its free blocks per
     # stream (fresh streams on every call would turn every allocation of the call into a hipMalloc) and the stager's
     # pinned buffers belong to its thread
     key = prep.device
     with _PIPE_LOCK:
         if key not in _PIPE:
-            streams = [torch.cuda.Stream(device=tdev) for _ in range(3)]
+            streams = [torch.cuda.Stream(device=tdev) for _ in range(4)]
             # the worker streams are handed out through ONE queue per GPU: two generators alive at once (two threads in
-            # call_reads_mods, interleaved iter_call_reads_mods iterators) share the two worker threads, and whichever
+            # call_reads_mods, interleaved iter_call_reads_mods iterators) share the three worker threads, and whichever
             # worker runs takes a stream nobody else holds; the single stager thread serialises their uploads
             fs = queue.SimpleQueue()
             for st in streams[1:]:
                 fs.put(st)
             _PIPE[key] = dict(streams=streams, free_streams=fs,
                               stager=ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmr-stage"),
-                              workers=ThreadPoolExecutor(max_workers=2, thread_name_prefix="rmr-work"))
+                              workers=ThreadPoolExecutor(max_workers=3, thread_name_prefix="rmr-work"))
             import atexit
 
             atexit.register(lambda p=_PIPE[key]: (p["stager"].shutdown(wait=False), p["workers"].shutdown(wait=False)))
@@ -282,16 +282,23 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     if loaded and refiner.scale_iters == 0:
         refiner.refine_device_reads(dr, reads)  # one banded-DP pass on the resident arrays
     focus, foc_off = dr.motif_focus_bases(motifs)
+    handoff = hasattr(model, "engine") and model.engine is not dr.engine  # extraction and network on engines of their own
     arrs, _ = _extract_device(dr, focus, foc_off, model_metadata["chunk_context"], model_metadata["kmer_context_bases"],
-                              model_metadata["base_start_justify"], model_metadata["offset"])
+                              model_metadata["base_start_justify"], model_metadata["offset"], sync=not handoff)
     bounds = [int(x) for x in foc_off]  # per-read slices of the concatenated results (np.split costs 5 us a piece)
     if len(arrs) == 0:
+        dr.engine.synchronize()
         for r in reads:
             r.focus_bases = np.zeros(0, np.int64)
         return [(np.array([]), np.array([]), np.array([])) for _ in reads]
-    # the network is queued BEFORE anything is fetched back: the copy of the focus bases (1.3 MB for 512 reads) then runs
-    # under its kernels instead of in front of them (profiles/r05_reads_timeline.md: 1.7 ms of GPU idle time per sub-batch)
+    # the network is queued BEFORE anything is fetched back - and, when the extraction ran on an engine of its own, behind an
+    # event of that engine's stream instead of a host wait: the copy of the focus bases (1.3 MB for 512 reads) runs under the
+    # network's kernels instead of in front of them (profiles/r05_reads_timeline.md: 1.7 ms of GPU idle time per sub-batch)
+    if handoff:
+        model.engine.wait_for(dr.engine)
     out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
+    if handoff:
+        dr.engine.synchronize()  # the focus bases are final (their kernel ran in front of the extraction's)
     focus_host = device_to_numpy(focus)
     for i, r in enumerate(reads):
         r.focus_bases = focus_host[bounds[i] : bounds[i + 1]]
