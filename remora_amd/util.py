@@ -24,6 +24,8 @@ BASES_TO_CODES = {v: k for k, v in SINGLE_LETTER_CODE.items()}
 _SEQ_LUT = np.full(256, -1, dtype=int)
 for _i, _b in enumerate(CAN_ALPHABET):
     _SEQ_LUT[ord(_b)] = _i
+# the same table for bytes.translate (C speed, one pass, one byte out per base: 255 = -1 as int8)
+_SEQ_TRANS = bytes((int(v) & 0xFF) for v in _SEQ_LUT)
 
 
 def seq_to_int(seq):

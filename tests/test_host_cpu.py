@@ -2714,3 +2714,24 @@ def test_subbatch_cuts_partition_a_batch_of_reads():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(b > a for a, b in cuts)
             assert max(b - a for a, b in cuts) <= max(sub, 1) + sub // 2
     assert [b - a for a, b in _subbatch_cuts(2048, 512)] == [128, 256, 512, 512, 384, 256]
+
+
+def test_built_library_has_no_packed_fp32_op_sel_on_lds_fed_registers():
+    """tools/lint_pk_lds.py on the built library: no v_pk_fma / mul / add_f32 whose op_sel / op_sel_hi modifier re-selects the
+    halves of an operand that an LDS read wrote - the instruction pattern tools/ubench/pk_lds_repro.hip shows returning wrong
+    values in lanes 32-63 beside 16-bit MFMAs on gfx950 (profiles/NOTES_r05.md section 2).  hipcc's SLP vectoriser used to
+    produce it from scalar code in fused_front_kernel, seq1_dense_kernel and refine_dp_kernel (95 instructions); the library is
+    built with -fno-slp-vectorize since."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lint_pk_lds
+
+    if not os.path.exists(lint_pk_lds.OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    for name in ("libremora_hip.so", "libremora_hip_jitter.so"):
+        lib = os.path.join(ROOT, "remora_amd", name)
+        if not os.path.exists(lib):
+            assert name != "libremora_hip.so"
+            continue
+        res = lint_pk_lds.lint(lib)
+        assert res["kernels"] > 50 and res["packed_f32"] > 500, res  # the walk saw the kernels and their packed math
+        assert res["flagged"] == [], res["flagged"][:5]
