@@ -134,8 +134,8 @@ _PIPE_LOCK = threading.Lock()
 
 
 def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
-    """call_reads_mods for every batch of reads of the iterable `parts`, on four threads: one stages (gather into
-    pinned memory + upload on its own stream, two pinned buffers taking turns), three take turns over the staged batches
+    """call_reads_mods for every batch of reads of the iterable `parts`, on five threads: two stage (gather into
+    pinned memory + upload on the upload stream, two pinned buffers each taking turns), three take turns over the staged batches
     (motif scan, extraction, inference, per-read split), so that the kernels of one batch run under the host work of
     its neighbours.  Each engine serialises its GPU calls (one mutex per engine: extraction runs on a second engine
     with its own stream); every C call and every copy releases the GIL.  Yields (batch, results) in order, results
@@ -168,12 +168,16 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
             streams = [torch.cuda.Stream(device=tdev) for _ in range(4)]
             # the worker streams are handed out through ONE queue per GPU: two generators alive at once (two threads in
             # call_reads_mods, interleaved iter_call_reads_mods iterators) share the three worker threads, and whichever
-            # worker runs takes a stream nobody else holds; the single stager thread serialises their uploads
+            # worker runs takes a stream nobody else holds; the stager threads queue their uploads on the one upload stream
             fs = queue.SimpleQueue()
             for st in streams[1:]:
                 fs.put(st)
             _PIPE[key] = dict(streams=streams, free_streams=fs,
-                              stager=ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmr-stage"),
+                              # two stagers: the gather of a sub-batch into pinned memory runs at the rate of its copy threads
+                              # (70 GB/s with eight), far below the host memory's; with one stager the 16-bit pipeline waited
+                              # for it 0.7 of the time (profiles/r05_reads_timeline_*.md).  Each has pinned buffers of its own.
+                              stager=ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("RMR_READS_STAGERS", "2"))),
+                                                        thread_name_prefix="rmr-stage"),
                               workers=ThreadPoolExecutor(max_workers=3, thread_name_prefix="rmr-work"))
             import atexit
 
