@@ -173,6 +173,17 @@ def device_to_numpy(t):
     return host.numpy().copy()
 
 
+def device_to_pinned_async(t, slot):
+    """Queue the copy of a CUDA tensor into this thread's pinned staging buffer `slot` on the current stream and return the
+    pinned view WITHOUT waiting: the caller synchronises the stream once for several such copies and then takes
+    `.numpy().copy()` of each (device_to_numpy = this + the wait, for one tensor)."""
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    host = _pinned_bytes(max(nbytes, 1), slot=slot)[:nbytes].view(t.dtype).view(t.shape)
+    host.copy_(t, non_blocking=True)
+    return host
+
+
 def _pinned_slot_async():
     """(slot, event) for an upload that is NOT waited for by its issuer: two staging buffers of this thread take turns;
     the event of a slot is that of the last upload out of it, to be waited for before the buffer is written again."""

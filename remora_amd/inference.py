@@ -261,7 +261,7 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     on the resident arrays (the reference processes reads one by one in Python,
     src/remora/inference.py:62-137, 661-712).  Returns a list of per-read (nn_out | probs, labels, pos) tuples;
     pos ascending within a read.  `read.focus_bases` is left holding the read's motif hits."""
-    from .data_chunks import DeviceReads, _extract_device, device_to_numpy
+    from .data_chunks import DeviceReads, _extract_device, device_to_pinned_async
 
     if len(reads) == 0:
         return []
@@ -303,16 +303,21 @@ def call_reads_mods(reads, model, model_metadata, return_mod_probs=False, device
     out = model.infer_chunks(arrs.signal, arrs.sequence, arrs.mapping, arrs.lengths, arrs.kmer_context_bases)
     if handoff:
         dr.engine.synchronize()  # the focus bases are final (their kernel ran in front of the extraction's)
-    focus_host = device_to_numpy(focus)
+    # both results come back through pinned buffers of this thread with ONE wait: the copy of the focus bases is queued now
+    # and crosses PCIe under the network's kernels (behind the next sub-batch's upload it took 1-2 ms of a worker's time)
+    torch = _torch()
+    h_focus = device_to_pinned_async(focus, 4)
+    if hasattr(model, "engine"):
+        model.engine.wait_submitted()  # the copy below may run on another stream than the engine's (pipelined callers)
+    h_out = device_to_pinned_async(out, 3)
+    torch.cuda.current_stream(out.device).synchronize()
+    focus_host, out = h_focus.numpy().copy(), h_out.numpy().copy()
     for i, r in enumerate(reads):
         r.focus_bases = focus_host[bounds[i] : bounds[i + 1]]
     # the chunks' positions: the focus base after the model's offset, clipped into the read (data_chunks.py:443-446) - known
     # on the host, no second copy back
     last = np.repeat(np.diff(dr.seq_off) - 1, np.diff(foc_off))
     pos = np.clip(focus_host + int(model_metadata["offset"]), 0, last)
-    if hasattr(model, "engine"):
-        model.engine.wait_submitted()  # the copy below may run on another stream than the engine's (pipelined callers)
-    out = device_to_numpy(out)
     if return_mod_probs:
         out = softmax_axis1(out)[:, 1:].astype(np.float64)
     labels, res = arrs.labels, []

@@ -66,6 +66,8 @@ def instrument():
     dc.DeviceReads.motif_focus_bases = timed("motif scan", dc.DeviceReads.motif_focus_bases)
     dc._extract_device = timed("extract (geometry + fill)", dc._extract_device)
     dc.device_to_numpy = timed("D2H", dc.device_to_numpy)
+    if hasattr(dc, "device_to_pinned_async"):
+        dc.device_to_pinned_async = timed("D2H queued", dc.device_to_pinned_async)
     eng.HipModel.infer_chunks = timed("infer_chunks (launch)", eng.HipModel.infer_chunks)
     eng.Engine.wait_submitted = timed("wait kernels", eng.Engine.wait_submitted)
     if hasattr(inf, "_native_call_reads"):
