@@ -605,17 +605,6 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
         hipLaunchKernelGGL(sig3_front_kernel, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
         RMR_HIP(hipGetLastError());
     }
-    // A small batch (a single read's few hundred chunks) leaves most of the GPU idle and is bound by the latency of its
-    // launches one after another: the two branches are independent until merge_conv1, so the sequence branch of such a batch
-    // runs on the engine's second stream beside the signal branch (21 us under 12.5 for 312 chunks: profiles/NOTES_r05.md).
-    // A large batch fills the GPU with either kernel; there the two share one stream as before.
-    const bool side = n <= tune_int("RMR_CONV_FRONT_SIDE_STREAM_MAX", 8192) && e->aux != nullptr && e->aux != e->stream;
-    hipStream_t seq_stream = e->stream;
-    if (side) {
-        RMR_HIP(hipEventRecord(e->ev_in, e->stream));  // the chunk rows were produced on the main stream
-        RMR_HIP(hipStreamWaitEvent(e->aux, e->ev_in, 0));
-        seq_stream = e->aux;
-    }
     {   // ---- sequence branch ----
         ConvFrontArgs a{};
         a.seqs = seqs; a.maps = maps; a.lens = lens; a.wt5 = m->front.wt5_seq1; a.b_seq1 = m->front.b_seq1;
@@ -648,15 +637,9 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
         int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
         if (grid > iters) grid = iters;
         RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(seq2_front_kernel<9>)));
-        {
-            ProfScope ps(e, K_SEQ2_FRONT, seq_stream, true);
-            hipLaunchKernelGGL(seq2_front_kernel<9>, dim3((unsigned)grid), dim3(256), lds, seq_stream, a);
-            RMR_HIP(hipGetLastError());
-        }
-        if (side) {  // merge_conv1 (main stream) reads both halves of cat
-            RMR_HIP(hipEventRecord(e->ev_front[0], e->aux));
-            RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_front[0], 0));
-        }
+        ProfScope ps(e, K_SEQ2_FRONT);
+        hipLaunchKernelGGL(seq2_front_kernel<9>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        RMR_HIP(hipGetLastError());
     }
     return 0;
 }

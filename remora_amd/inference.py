@@ -173,18 +173,24 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
             for st in streams[1:]:
                 fs.put(st)
             _PIPE[key] = dict(streams=streams, free_streams=fs,
-                              # two stagers: the gather of a sub-batch into pinned memory runs at the rate of its copy threads
-                              # (70 GB/s with eight), far below the host memory's; with one stager the 16-bit pipeline waited
-                              # for it 0.7 of the time (profiles/r05_reads_timeline_*.md).  Each has pinned buffers of its own.
-                              stager=ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("RMR_READS_STAGERS", "2"))),
-                                                        thread_name_prefix="rmr-stage"),
+                              # a pool of one stager thread and a pool of two: a call picks one (below); every thread
+                              # has pinned buffers of its own
+                              stager={1: ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmr-stage"),
+                                      2: ThreadPoolExecutor(max_workers=2, thread_name_prefix="rmr-stage2")},
                               workers=ThreadPoolExecutor(max_workers=3, thread_name_prefix="rmr-work"))
             import atexit
 
-            atexit.register(lambda p=_PIPE[key]: (p["stager"].shutdown(wait=False), p["workers"].shutdown(wait=False)))
+            atexit.register(lambda p=_PIPE[key]: ([x.shutdown(wait=False) for x in p["stager"].values()], p["workers"].shutdown(wait=False)))
         pipe = _PIPE[key]
     upload = pipe["streams"][0]
     free_streams = pipe["free_streams"]
+
+    # How many sub-batches are gathered into pinned memory side by side.  The gather runs at the rate of its copy threads
+    # (70 GB/s with eight), well below the host memory's: with a 16-bit model, whose kernels need 4 us a read, ONE stager was
+    # busy 0.7 of the call and two are worth +10 % (150 -> 165 k reads/s); the fp32 model is bound by its kernels (15 us a
+    # read) and loses 9 % to a second stager's threads (64.5 -> 58.8 k reads/s: profiles/r05_ab_reads_*.log).
+    n_stagers = int(os.environ.get("RMR_READS_STAGERS", "0")) or (2 if getattr(model, "dtype", "fp32") in ("bf16", "f16") else 1)
+    stager = pipe["stager"][2 if n_stagers >= 2 else 1]
 
     def stage(part):
         slots.acquire()
@@ -210,7 +216,7 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
     flight = collections.deque()
     try:
         for part in parts:
-            flight.append((part, pipe["workers"].submit(work, part, pipe["stager"].submit(stage, part))))
+            flight.append((part, pipe["workers"].submit(work, part, stager.submit(stage, part))))
             if len(flight) >= 6:
                 done, fut = flight.popleft()
                 yield done, fut.result()

@@ -154,25 +154,3 @@ def test_conv_w_ref_full_size_properties():
     with torch.no_grad():
         ref = net(torch.from_numpy(d["signal"][idx]), torch.from_numpy(enc)).numpy()
     assert np.abs(out[torch.from_numpy(idx).cuda()].cpu().numpy() - ref).max() <= 1e-4
-
-
-def test_small_batches_on_the_side_stream_equal_one_stream(monkeypatch):
-    """Batches of up to 8192 chunks (a single read's worth) run the sequence branch on the engine's second stream beside the
-    signal branch (k_conv_front.hip, launch_conv_front): the same bits as both on one stream, call after call with changing
-    inputs and sizes (the hand-over is two events per call)."""
-    import torch
-
-    from remora_amd import synth
-    from remora_amd.model_util import model_from_state
-
-    assert torch.cuda.is_available(), "GPU tests need a GPU"
-    state = synth.synth_state("conv_lstm", 64, 9, 2, seed=2)
-    model = model_from_state(state, dict(chunk_context=(50, 50), kmer_context_bases=(4, 4)), device=0, dtype="fp32")
-    for rep, n in enumerate([312, 1, 5000, 8192, 77, 312, 2048, 9000, 312] * 3):
-        d = synth.synth_chunks_config("C100", n, shard=300 + rep)
-        args = (d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
-        monkeypatch.setenv("RMR_CONV_FRONT_SIDE_STREAM_MAX", "8192")
-        a = model.infer_chunks(*args)
-        monkeypatch.setenv("RMR_CONV_FRONT_SIDE_STREAM_MAX", "0")
-        b = model.infer_chunks(*args)
-        assert np.array_equal(a, b), (rep, n, float(np.abs(a - b).max()))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of the reads paths inside ONE process (the boxes of the pool differ by 20 % and so do consecutive calls):
-single-read call_read_mods with and without the side stream for the sequence branch, batched call_reads_mods as median /
-best of several calls.   python tools/ab_reads.py [--dtypes fp32,bf16] [--calls 7]"""
+"""The reads paths timed as medians inside ONE process (the boxes of the pool differ by 20 % and so do consecutive calls):
+single-read call_read_mods over six rounds of 64 reads, batched call_reads_mods over several calls of 2048 reads.  Knobs are
+environment variables (RMR_READS_STAGERS, RMR_PACK_THREADS, RMR_READS_SUBBATCH, RMR_PACK_STREAM): one process per setting.
+    python tools/ab_reads.py [--dtypes fp32,bf16] [--calls 7]"""
 import argparse
 import os
 import statistics
@@ -35,17 +36,13 @@ def main():
         model = model_from_state(st, md, device=0, dtype=dt)
         for r in rs[:16]:
             call_read_mods(r, model, md)
-        res = {"8192": [], "0": []}
+        res = []
         for rnd in range(6):
-            for side in ("8192", "0"):
-                os.environ["RMR_CONV_FRONT_SIDE_STREAM_MAX"] = side
-                t = time.perf_counter()
-                for r in rs[64 * rnd : 64 * rnd + 64]:
-                    call_read_mods(r, model, md)
-                res[side].append((time.perf_counter() - t) / 64 * 1e6)
-        os.environ.pop("RMR_CONV_FRONT_SIDE_STREAM_MAX")
-        print(f"{dt} single read: side stream {statistics.median(res['8192']):.0f} us (best {min(res['8192']):.0f}), one stream "
-              f"{statistics.median(res['0']):.0f} us (best {min(res['0']):.0f})")
+            t = time.perf_counter()
+            for r in rs[64 * rnd : 64 * rnd + 64]:
+                call_read_mods(r, model, md)
+            res.append((time.perf_counter() - t) / 64 * 1e6)
+        print(f"{dt} single read: {statistics.median(res):.0f} us (best {min(res):.0f}) = {1e3 / statistics.median(res):.2f} k reads/s")
         call_reads_mods(rs, model, md)
         ts = []
         for _ in range(args.calls):
