@@ -227,6 +227,14 @@ int rmr_format_mm_ml(int64_t n_reads, const char *seq, const int64_t *seq_off, c
 int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off,
                               const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
                               const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len);
+/* The same for reference-anchored calling (`infer --reference-anchored`): a record that gets tags and owns a non-empty slice
+ * ref_seq[ref_off[r] .. ref_off[r+1]) - the reference bases of its alignment, forward strand - is written in the form the
+ * reference writes there: CIGAR <len>M, that sequence, qualities 0xff (src/remora/inference.py:452-458); every other record
+ * as rmr_records_with_mod_tags writes it.  The caller's `out` needs 4 + (len + 1) / 2 + len more bytes per such record. */
+int rmr_records_with_mod_tags_ref(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off,
+                                  const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
+                                  const uint8_t *has_tags, const char *ref_seq, const int64_t *ref_off, uint8_t *out, int64_t out_cap,
+                                  int64_t *out_len);
 
 /* The signal coordinate of every reference position of one alignment (host code).
  * replaces: compute_ref_to_signal = map_ref_to_signal(make_sequence_coordinate_mapping(cigar)), src/remora/data_chunks.py:60-122
@@ -237,6 +245,19 @@ int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const 
  * Errors (RMR_ERR_INVALID, the reference's texts): "Invalid cigar op(s)", "No match operations found in alignment cigar". */
 int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int reverse, const int64_t *query_to_signal, int64_t n_knots,
                       int64_t *ref_to_signal, int64_t cap, int64_t *n_out);
+/* The reference-anchored half of a BAM batch's ingest, per record on native threads: io.parse_move_tag
+ * (src/remora/io.py:394-407: mv -> query_to_signal, with its two checks) followed by compute_ref_to_signal
+ * (src/remora/data_chunks.py:118-122) as Read.add_alignment composes them (io.py:2066-2084).  Record i: move table
+ * mv[mv_off[i] .. mv_off[i+1]) (first entry = stride), trimmed signal length sig_len[i], seq_len[i] bases, CIGAR words
+ * cigar[cigar_off[i] .. cigar_off[i+1]) in BAM order (reverse[i]: walked backwards, the read's orientation), ref_len[i]
+ * reference bases (< 0: no reference sequence - status 9 once its move table has passed the checks).  Its ref_to_signal goes
+ * to r2s[r2s_off[i] .. +ref_len[i]+1).
+ * status[i]: 0 done; RMR_ERR_INVALID (empty table / stride <= 0), RMR_ERR_DISCORDANT_SEQ, RMR_ERR_DISCORDANT_SIG as
+ * rmr_parse_moves_batch; 1 "Discordant ref seq lengths" (io.py:2078-2079); 2 "Invalid cigar op(s)"; 3 "No match operations
+ * found in alignment cigar"; 4 a CIGAR with an empty match run; 8 no move table; 9 no reference sequence. */
+int rmr_ref_anchor_batch(int64_t n, const int8_t *mv, const int64_t *mv_off, const int64_t *sig_len, const int64_t *seq_len,
+                         const uint32_t *cigar, const int64_t *cigar_off, const uint8_t *reverse, const int64_t *ref_len,
+                         int64_t *r2s, const int64_t *r2s_off, int32_t *status, int threads);
 
 /* The native BAM reader's own inflater for BGZF members, alone (host code; replaces zlib's inflate under
  * rmr_bam_read_batch, which itself stands in for htslib below pysam, src/remora/io.py:184-358): a raw RFC 1951 stream

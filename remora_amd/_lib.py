@@ -85,6 +85,7 @@ SIGNATURES = {
     "rmr_format_mm_ml": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.c_char_p, ctypes.c_char, ctypes.c_char, c_vp, c_i64,
                                  c_vp, c_vp, c_i64, c_vp]),
     "rmr_records_with_mod_tags": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    "rmr_records_with_mod_tags_ref": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rmr_inflate_raw": (c_int, [c_vp, c_i64, c_vp, c_i64]),
     "rmr_bgzf_huffman": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "rmr_zstd_frame_sizes": (c_int, [c_vp, c_vp, c_i64, c_vp]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "rmr_motif_focus_counts": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rmr_motif_focus_fill": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rmr_ref_to_signal": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "rmr_ref_anchor_batch": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rmr_pack_reads": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),
     "rmr_chunk_fill": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int]),

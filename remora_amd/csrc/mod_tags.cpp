@@ -11,6 +11,7 @@
 #include "../../include/remora_hip.h"
 #include "rmr_internal.h"
 
+#include <array>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -151,11 +152,24 @@ int rmr_format_mm_ml(int64_t n_reads, const char *seq, const int64_t *seq_off, c
     return 0;
 }
 
-int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off,
-                              const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
-                              const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len) {
+}  // extern "C"
+
+namespace {
+
+// the records of a batch re-emitted with their new modified-base tags; ref_seq != nullptr: a record that gets tags and owns
+// a slice of ref_seq leaves in the reference-anchored form (see rmr_records_with_mod_tags_ref)
+int rewrite_records(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off, const char *mm,
+                    const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off, const uint8_t *has_tags, const char *ref_seq,
+                    const int64_t *ref_off, uint8_t *out, int64_t out_cap, int64_t *out_len) {
     if (n_reads < 0 || !out_len || (n_reads > 0 && (!raw || !raw_len || !tags_off || !has_tags || !out)))
         RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    static const std::array<uint8_t, 256> nt16 = [] {  // base letter -> BAM's 4-bit code; anything else -> 15 (N)
+        std::array<uint8_t, 256> t;
+        t.fill(15);
+        const char *letters = "=ACMGRSVTWYHKDBN";
+        for (int i = 0; i < 16; ++i) t[(uint8_t)letters[i]] = (uint8_t)i;
+        return t;
+    }();
     int64_t w = 0;
     for (int64_t r = 0; r < n_reads; ++r) {
         const uint8_t *rec = raw[r];
@@ -163,10 +177,33 @@ int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const 
         if (!rec || to < 32 || to > len) RMR_FAIL(RMR_ERR_INVALID, "record %lld: bad tag offset", (long long)r);
         const int64_t mml = has_tags[r] ? mm_off[r + 1] - mm_off[r] : 0, mll = has_tags[r] ? ml_off[r + 1] - ml_off[r] : 0;
         const int64_t extra = has_tags[r] ? 3 + mml + 1 + 4 + 4 + mll : 0;
-        if (w + 4 + len + extra > out_cap) RMR_FAIL(RMR_ERR_INVALID, "output buffer too small");
+        const int64_t nref = (ref_seq && ref_off && has_tags[r]) ? ref_off[r + 1] - ref_off[r] : 0;
+        if (w + 4 + len + extra + (nref ? 4 + (nref + 1) / 2 + nref : 0) > out_cap) RMR_FAIL(RMR_ERR_INVALID, "output buffer too small");
         uint8_t *body = out + w + 4;
-        memcpy(body, rec, (size_t)to);
-        int64_t b = to;
+        int64_t b;
+        if (nref > 0) {
+            // the reference-anchored record the reference writes (src/remora/inference.py:452-458): CIGAR <n>M, the reference
+            // bases of the alignment (forward strand), no qualities; every other fixed field and the name as they are
+            const int64_t l_name = rec[8];
+            if (32 + l_name > to) RMR_FAIL(RMR_ERR_INVALID, "record %lld: name runs into the tags", (long long)r);
+            memcpy(body, rec, (size_t)(32 + l_name));
+            const uint16_t one = 1;
+            const int32_t l_seq = (int32_t)nref;
+            memcpy(body + 12, &one, 2);
+            memcpy(body + 16, &l_seq, 4);
+            b = 32 + l_name;
+            const uint32_t cig = ((uint32_t)nref << 4) | 0u;
+            memcpy(body + b, &cig, 4);
+            b += 4;
+            const uint8_t *q = reinterpret_cast<const uint8_t *>(ref_seq) + ref_off[r];
+            for (int64_t k = 0; k + 1 < nref; k += 2) body[b++] = (uint8_t)((nt16[q[k]] << 4) | nt16[q[k + 1]]);
+            if (nref & 1) body[b++] = (uint8_t)(nt16[q[nref - 1]] << 4);
+            memset(body + b, 0xff, (size_t)nref);
+            b += nref;
+        } else {
+            memcpy(body, rec, (size_t)to);
+            b = to;
+        }
         const uint8_t *tags = rec + to, *end = rec + len;
         // records that carry no modified-base tag keep their tag bytes as they are; only a record in which one of the four
         // tag headers occurs (as a tag, or by chance inside another tag's data) is walked tag by tag
@@ -208,6 +245,24 @@ int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const 
     }
     *out_len = w;
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmr_records_with_mod_tags(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off,
+                              const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
+                              const uint8_t *has_tags, uint8_t *out, int64_t out_cap, int64_t *out_len) {
+    return rewrite_records(n_reads, raw, raw_len, tags_off, mm, mm_off, ml, ml_off, has_tags, nullptr, nullptr, out, out_cap, out_len);
+}
+
+int rmr_records_with_mod_tags_ref(int64_t n_reads, const uint8_t *const *raw, const int64_t *raw_len, const int64_t *tags_off,
+                                  const char *mm, const int64_t *mm_off, const uint8_t *ml, const int64_t *ml_off,
+                                  const uint8_t *has_tags, const char *ref_seq, const int64_t *ref_off, uint8_t *out, int64_t out_cap,
+                                  int64_t *out_len) {
+    if (n_reads > 0 && (!ref_seq || !ref_off)) RMR_FAIL(RMR_ERR_INVALID, "bad argument");
+    return rewrite_records(n_reads, raw, raw_len, tags_off, mm, mm_off, ml, ml_off, has_tags, ref_seq, ref_off, out, out_cap, out_len);
 }
 
 }  // extern "C"

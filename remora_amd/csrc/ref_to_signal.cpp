@@ -14,14 +14,19 @@
 //   (q2s[k+1] - q2s[k]) * (y - k) + q2s[k].
 #include <cmath>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "rmr_internal.h"
 
-extern "C" int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int reverse, const int64_t *query_to_signal, int64_t n_knots,
-                                 int64_t *ref_to_signal, int64_t cap, int64_t *n_out) {
+namespace {
+
+enum { R2S_OK = 0, R2S_ROOM = 1, R2S_BAD_OP = 2, R2S_NO_MATCH = 3, R2S_EMPTY_RUN = 4 };
+
+// the walk itself; a code instead of a message, so that a batch can run it on worker threads (rmr_ref_anchor_batch)
+int ref_to_signal_core(const uint32_t *cigar, int64_t n_ops, int reverse, const int64_t *query_to_signal, int64_t n_knots,
+                       int64_t *ref_to_signal, int64_t cap, int64_t *n_out) {
 #pragma STDC FP_CONTRACT OFF
-    if (!cigar || n_ops < 0 || !query_to_signal || n_knots < 1 || !ref_to_signal || !n_out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
     // M I D N S H P = X: aligns a base / consumes the query / consumes the reference
     static const bool MATCH[9] = {true, false, false, false, false, false, false, true, true};
     static const bool QUERY[9] = {true, true, false, false, true, false, false, true, true};
@@ -30,10 +35,10 @@ extern "C" int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int rever
     int64_t last_match = -1;
     for (int64_t i = 0; i < n_ops; ++i) {
         const uint32_t op = op_at(i) & 0xF;
-        if (op > 8) RMR_FAIL(RMR_ERR_INVALID, "Invalid cigar op(s)");
+        if (op > 8) return R2S_BAD_OP;
         if (MATCH[op]) last_match = i;
     }
-    if (last_match < 0) RMR_FAIL(RMR_ERR_INVALID, "No match operations found in alignment cigar");
+    if (last_match < 0) return R2S_NO_MATCH;
     // the knots
     std::vector<int64_t> xs, ys;
     xs.reserve(2 * (size_t)n_ops + 2);
@@ -57,9 +62,9 @@ extern "C" int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int rever
     ys.push_back(q);
     const int64_t total = r + 1;
     *n_out = total;
-    if (cap < total) RMR_FAIL(RMR_ERR_INVALID, "ref_to_signal needs %lld entries, %lld given", (long long)total, (long long)cap);
+    if (cap < total) return R2S_ROOM;
     for (size_t j = 1; j < xs.size(); ++j)  // np.interp wants ascending x; a run of length 0 behind nothing would break that
-        if (xs[j] < xs[j - 1]) RMR_FAIL(RMR_ERR_INVALID, "cigar with an empty match run");
+        if (xs[j] < xs[j - 1]) return R2S_EMPTY_RUN;
     const int64_t last_knot = n_knots - 1;
     auto signal_at = [&](double y) -> int64_t {
         if (y >= (double)last_knot) return query_to_signal[last_knot];
@@ -87,5 +92,69 @@ extern "C" int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int rever
         }
     }
     ref_to_signal[r] = signal_at((double)ys[nk - 1]);  // x == the last knot: its y
+    return R2S_OK;
+}
+
+}  // namespace
+
+extern "C" int rmr_ref_to_signal(const uint32_t *cigar, int64_t n_ops, int reverse, const int64_t *query_to_signal, int64_t n_knots,
+                                 int64_t *ref_to_signal, int64_t cap, int64_t *n_out) {
+    if (!cigar || n_ops < 0 || !query_to_signal || n_knots < 1 || !ref_to_signal || !n_out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    switch (ref_to_signal_core(cigar, n_ops, reverse, query_to_signal, n_knots, ref_to_signal, cap, n_out)) {
+    case R2S_OK: return RMR_OK;
+    case R2S_BAD_OP: RMR_FAIL(RMR_ERR_INVALID, "Invalid cigar op(s)");
+    case R2S_NO_MATCH: RMR_FAIL(RMR_ERR_INVALID, "No match operations found in alignment cigar");
+    case R2S_ROOM: RMR_FAIL(RMR_ERR_INVALID, "ref_to_signal needs %lld entries, %lld given", (long long)*n_out, (long long)cap);
+    default: RMR_FAIL(RMR_ERR_INVALID, "cigar with an empty match run");
+    }
+}
+
+// ---- a batch of alignments: move table -> query_to_signal -> ref_to_signal, per record, on native threads ----------------
+// replaces, for the records of one BAM batch: io.parse_move_tag (src/remora/io.py:394-407) followed by compute_ref_to_signal
+// (src/remora/data_chunks.py:118-122) inside Read.add_alignment (io.py:2066-2084) - the reference-anchored half of the batch
+// ingest (remora_amd.io._ingest_batch).  Record i: move table mv[mv_off[i] .. mv_off[i+1]) (first entry = stride), trimmed
+// signal length sig_len[i], seq_len[i] bases, CIGAR words cigar[cigar_off[i] .. cigar_off[i+1]) in BAM order (reverse[i]: the
+// read-oriented walk runs it backwards), ref_len[i] reference bases (< 0: no reference sequence - the record is skipped with
+// status 9).  ref_to_signal of record i goes to r2s[r2s_off[i] .. r2s_off[i] + ref_len[i] + 1).
+// status[i]: 0 done; RMR_ERR_INVALID (empty table / stride <= 0), RMR_ERR_DISCORDANT_SEQ, RMR_ERR_DISCORDANT_SIG as
+// rmr_parse_moves_batch; 1 "Discordant ref seq lengths" (io.py:2078-2079); 2 "Invalid cigar op(s)"; 3 "No match operations
+// found in alignment cigar"; 4 a CIGAR with an empty match run (the caller's array form handles it); 8 no move table;
+// 9 move table fine, no reference sequence.
+extern "C" int rmr_ref_anchor_batch(int64_t n, const int8_t *mv, const int64_t *mv_off, const int64_t *sig_len, const int64_t *seq_len,
+                                    const uint32_t *cigar, const int64_t *cigar_off, const uint8_t *reverse, const int64_t *ref_len,
+                                    int64_t *r2s, const int64_t *r2s_off, int32_t *status, int threads) {
+    if (n < 0 || !mv_off || !sig_len || !seq_len || !cigar_off || !reverse || !ref_len || !r2s_off || !status || (n > 0 && (!mv || !r2s)))
+        RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    auto work = [&](int64_t i0, int64_t i1) {
+        std::vector<int64_t> q2s;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int8_t *m = mv + mv_off[i];
+            const int64_t len = mv_off[i + 1] - mv_off[i];
+            if (len < 1) { status[i] = 8; continue; }  // no move table: the caller's business
+            if (m[0] <= 0) { status[i] = RMR_ERR_INVALID; continue; }
+            const int64_t stride = m[0], nmv = len - 1;
+            q2s.clear();
+            for (int64_t k = 0; k < nmv; ++k)
+                if (m[1 + k] != 0) q2s.push_back(k * stride);
+            const int64_t cnt = (int64_t)q2s.size();
+            q2s.push_back(sig_len[i]);
+            if (seq_len[i] >= 0 && cnt != seq_len[i]) { status[i] = RMR_ERR_DISCORDANT_SEQ; continue; }
+            if (nmv != sig_len[i] / stride) { status[i] = RMR_ERR_DISCORDANT_SIG; continue; }
+            if (ref_len[i] < 0) { status[i] = 9; continue; }  // (the move table is checked first, as add_alignment does)
+            int64_t n_out = 0;
+            const int rc = ref_to_signal_core(cigar + cigar_off[i], cigar_off[i + 1] - cigar_off[i], reverse[i] != 0, q2s.data(), (int64_t)q2s.size(),
+                                              r2s + r2s_off[i], ref_len[i] + 1, &n_out);
+            status[i] = rc == R2S_OK ? (n_out == ref_len[i] + 1 ? 0 : 1) : rc == R2S_ROOM ? 1 : rc;
+        }
+    };
+    if (threads < 1) threads = 1;
+    if (threads > 32) threads = 32;
+    if (threads == 1 || n < 2 * threads) {
+        work(0, n);
+        return RMR_OK;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+    for (auto &th : pool) th.join();
     return RMR_OK;
 }

@@ -459,7 +459,8 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             else:
                 mm, ml, mm_off, ml_off = np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
             writer.write(rio.records_with_mod_tags_flat(rb.raw, rb.raw_off[ib.keep], rb.raw_off[ib.keep + 1] - rb.raw_off[ib.keep],
-                                                        rb.tags_off[ib.keep], mm, mm_off, ml, ml_off, has))
+                                                        rb.tags_off[ib.keep], mm, mm_off, ml, ml_off, has,
+                                                        ref_seq=ib.ref_fwd if ref_anchored else None, ref_off=ib.ref_fwd_off))
             clock["tags_write"] += _time.perf_counter()
             return
         n = len(items)
@@ -519,16 +520,16 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     refiner0 = mds[0].get("sig_map_refiner")
     iterative = refiner0 is not None and getattr(refiner0, "is_loaded", False) and refiner0.scale_iters > 0
-    # one model, basecall-anchored, forward signal: the batch ingest (io.iter_ingest_batches) - trimming, move tables, scaling
+    # one model, forward signal, either anchor: the batch ingest (io.iter_ingest_batches) - trimming, move tables, scaling
     # and the read arrays of a whole BAM batch on the GPU, no Python object per read; everything else read by read
-    batch_ingest = (len(models) == 1 and not ref_anchored and not reverse_signal and not iterative and
-                    os.environ.get("RMR_INFER_BATCH_INGEST", "1") != "0")
+    batch_ingest = (len(models) == 1 and not reverse_signal and not iterative and os.environ.get("RMR_INFER_BATCH_INGEST", "1") != "0")
 
     def batches():
         if batch_ingest:
             seen = 0
             for ib in rio.iter_ingest_batches(pod5_path, in_bam_path, pa_scaling=pa_scaling, skip_non_primary=skip_non_primary,
-                                              batch=reads_per_batch, shard=shard, device=models[0].engine.device):
+                                              batch=reads_per_batch, shard=shard, device=models[0].engine.device,
+                                              ref_anchored=ref_anchored):
                 if num_reads is not None and seen + len(ib) >= num_reads:
                     left = num_reads - seen
                     if left > 0:

@@ -1544,7 +1544,7 @@ class ReadStub:
 
 
 _NO_MAP = np.zeros(0, np.int64)
-_COMP_BYTES = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")  # the byte form of _COMP (revcomp)
+_COMP_BYTES = bytes.maketrans(b"ACGTBVDHKMRYacgt", b"TGCAVBHDMKYRtgca")  # the byte form of _COMP (revcomp): the same letters
 
 
 class IngestBatch:
@@ -1552,9 +1552,12 @@ class IngestBatch:
     `rb` / `keep` - the raw batch and the indices of its records that are handed on (primary, signal present), in input order;
     `err[k]` - None or the reason record keep[k] cannot be called (the strings Read.add_alignment / into_remora_read raise);
     `good` - positions in `keep` of the callable reads; for them `dr` (DeviceReads assembled on the GPU), `reads`
-    (ReadStub per good read), `seq` (their strand-oriented bases, ASCII, back to back) and `seq_off`."""
+    (ReadStub per good read), `seq` (their strand-oriented bases, ASCII, back to back) and `seq_off`.  Reference-anchored
+    batches: `seq` holds the reference bases of the alignments in read orientation (what the reads are anchored on), and
+    `ref_fwd` / `ref_fwd_off` (int64[len(keep) + 1]) the same bases in forward-strand orientation per KEPT record (empty for
+    records that cannot be called) - what the output records are rewritten with; None otherwise."""
 
-    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "seq_off", "records")
+    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "seq_off", "records", "ref_fwd", "ref_fwd_off")
 
     def __len__(self):
         return int(self.keep.size)
@@ -1566,6 +1569,7 @@ class IngestBatch:
             return self
         out = IngestBatch()
         out.rb, out.records, out.keep, out.err = self.rb, self.records, self.keep[:k], self.err[:k]
+        out.ref_fwd, out.ref_fwd_off = self.ref_fwd, (None if self.ref_fwd_off is None else self.ref_fwd_off[: k + 1])
         g = int(np.searchsorted(self.good, k))
         out.good, out.reads, out.seq_off = self.good[:g], self.reads[:g], self.seq_off[: g + 1]
         out.seq = self.seq[: int(self.seq_off[g])]
@@ -1593,10 +1597,17 @@ def _trim_span(size, sp, ts, ns, has_ns):
     return start + a, np.maximum(b - a, 0)
 
 
-def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
+_REF_ANCHOR_ERRORS = {1: "Discordant ref seq lengths", 2: "Invalid cigar op(s)", 3: "No match operations found in alignment cigar"}
+
+
+def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=False):
     """IngestBatch of one raw BAM batch, or None when nothing of it is kept.  Everything Read.from_pod5 + add_alignment +
-    into_remora_read (basecall-anchored, forward signal) do per read, for the batch: trimming by sp / ts / ns, strand-aware
+    into_remora_read (forward signal) do per read, for the batch: trimming by sp / ts / ns, strand-aware
     sequence, move tables -> query_to_signal (one launch), sm / sd composed with the calibration, the trim to the mapped span.
+    `ref_anchored` (`infer --reference-anchored`; `rb` read with want_ref): the reads are anchored on the reference bases of
+    their alignments instead of their basecalls - move table and CIGAR composed per record by native threads
+    (rmr_ref_anchor_batch: src/remora/io.py:2066-2084), the reference sequence rebuilt from MD by the native reader, and
+    the same assembly kernel cuts signal and mapping (ref_to_signal in place of query_to_signal).
     A batch that holds something the array form does not reproduce (negative trim tags, bases outside A-Z, reads without
     sm / sd, which need the median / MAD of their signal) is returned as the string "slow": the caller sends its records
     through the per-read path."""
@@ -1642,23 +1653,49 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     size_k, base_k = read_size[inv], read_start[inv]
     off, sig_len = _trim_span(size_k, sp, ts, ns, (has & 4) != 0)
     src_start = base_k + off
-    # ---- move tables of the whole raw batch in one launch (tables of records that are not kept: length 0 -> ignored) ----
     sl_all = np.zeros(n_all, np.int64)
     sl_all[keep] = sig_len
     dev = eng.torch_device
     total_mv = int(rb.mv_off[n_all])
-    d_mv = torch.from_numpy(rb.mv if total_mv else np.zeros(1, np.int8)).to(dev)
-    d_off, d_sl, d_ql = (torch.from_numpy(np.ascontiguousarray(x, np.int64)).to(dev) for x in (rb.mv_off, sl_all, seq_len_all))
-    d_q2s = torch.empty(max(total_mv, 1), dtype=torch.int64, device=dev)
-    # torch.empty, not zeros: a fill would be queued on this thread's torch stream while the kernel runs on the ingest
-    # engine's own (unordered) stream and could land AFTER it; moves_batch_kernel writes counts[b] and status[b] of every
-    # record, tables of length 0 included
-    d_cnt = torch.empty(n_all, dtype=torch.int64, device=dev)
-    d_st = torch.empty(n_all, dtype=torch.int32, device=dev)
-    L.check(L.lib().rmr_parse_moves_batch(eng.handle, d_mv.data_ptr(), d_off.data_ptr(), d_sl.data_ptr(), d_ql.data_ptr(), n_all, 1, 0,
-                                          d_q2s.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), L.MEM_DEVICE))
-    eng.synchronize()
-    status = d_st.cpu().numpy()[keep]
+    is_rev_all = (flag & 16) != 0
+    if ref_anchored:
+        # ---- move table and alignment composed per record on native threads: ref_to_signal of every record with a reference ----
+        if not getattr(rb, "want_ref", False):
+            raise RemoraError("reference-anchored ingest needs BAM batches read with want_ref")
+        ref_len_all = np.full(n_all, -1, np.int64)
+        mapped_ref = (rb.ref_id[keep] >= 0) & (rb.ref_ok[keep] != 0) & ((flag[keep] & 4) == 0)
+        if (mapped_ref & ((has & 1) == 0)).any():
+            return "slow"  # an aligned record without a move table: the per-read path's business
+        ref_len_all[keep[mapped_ref]] = np.diff(rb.refseq_off)[keep[mapped_ref]]
+        r2s_off = np.zeros(n_all + 1, np.int64)
+        np.cumsum(np.maximum(ref_len_all, -1) + 1, out=r2s_off[1:])
+        r2s = np.empty(max(int(r2s_off[-1]), 1), np.int64)
+        status_all = np.zeros(n_all, np.int32)
+        pp = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        mv_arr = rb.mv if total_mv else np.zeros(1, np.int8)
+        cig_arr = np.ascontiguousarray(rb.cigar, np.uint32) if rb.cigar.size else np.zeros(1, np.uint32)
+        rev8 = np.ascontiguousarray(is_rev_all, np.uint8)
+        L.check(L.lib().rmr_ref_anchor_batch(n_all, pp(mv_arr), pp(np.ascontiguousarray(rb.mv_off, np.int64)), pp(sl_all),
+                                             pp(np.ascontiguousarray(seq_len_all, np.int64)), pp(cig_arr),
+                                             pp(np.ascontiguousarray(rb.cigar_off, np.int64)), pp(rev8), pp(ref_len_all), pp(r2s),
+                                             pp(r2s_off), pp(status_all), int(os.environ.get("RMR_PACK_THREADS", "8"))))
+        status = status_all[keep]
+        if (status == 4).any():
+            return "slow"  # a CIGAR with an empty match run: the array form of the per-read path does what numpy does with it
+    else:
+        # ---- move tables of the whole raw batch in one launch (tables of records that are not kept: length 0 -> ignored) ----
+        d_mv = torch.from_numpy(rb.mv if total_mv else np.zeros(1, np.int8)).to(dev)
+        d_off, d_sl, d_ql = (torch.from_numpy(np.ascontiguousarray(x, np.int64)).to(dev) for x in (rb.mv_off, sl_all, seq_len_all))
+        d_q2s = torch.empty(max(total_mv, 1), dtype=torch.int64, device=dev)
+        # torch.empty, not zeros: a fill would be queued on this thread's torch stream while the kernel runs on the ingest
+        # engine's own (unordered) stream and could land AFTER it; moves_batch_kernel writes counts[b] and status[b] of every
+        # record, tables of length 0 included
+        d_cnt = torch.empty(n_all, dtype=torch.int64, device=dev)
+        d_st = torch.empty(n_all, dtype=torch.int32, device=dev)
+        L.check(L.lib().rmr_parse_moves_batch(eng.handle, d_mv.data_ptr(), d_off.data_ptr(), d_sl.data_ptr(), d_ql.data_ptr(), n_all, 1, 0,
+                                              d_q2s.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), L.MEM_DEVICE))
+        eng.synchronize()
+        status = d_st.cpu().numpy()[keep]
     # ---- who can be called, and why not (the texts of add_alignment / into_remora_read, in their order) ----
     is_rev = (flag[keep] & 16) != 0
     err = [None] * nk
@@ -1666,6 +1703,14 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     for k in range(nk):
         if rb.ref_id[keep[k]] < 0 and is_rev[k]:
             err[k] = "Unmapped reads cannot map to reverse strand."
+        elif ref_anchored:
+            st = int(status[k])
+            if st in (8, 9):  # no move table / no reference sequence: nothing to anchor the read on (io.py:2131-2137)
+                err[k] = "Read prep error: Missing reference alignment"
+            elif st > 0:
+                err[k] = _REF_ANCHOR_ERRORS[st]
+            elif st < 0:
+                err[k] = _MOVE_ERRORS.get(st, "empty move tag" if mv_len[k] < 1 else f"move table stride {int(rb.mv[rb.mv_off[keep[k]]])}")
         elif not (has[k] & 1):
             err[k] = "Read prep error: Missing query_to_signal (move table)"
         elif status[k] != 0:
@@ -1674,15 +1719,28 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     out = IngestBatch()
     out.rb, out.records, out.keep, out.err, out.good = rb, records, keep, err, good
     out.dr, out.reads, out.seq, out.seq_off = None, [], b"", np.zeros(1, np.int64)
+    out.ref_fwd, out.ref_fwd_off = (b"", np.zeros(nk + 1, np.int64)) if ref_anchored else (None, None)
     if not good.size:
         return out
     gk = keep[good]
-    # ---- strand-aware bases (seq = revcomp(query_sequence) for reverse-strand records, :2023) ----
-    so = rb.seq_off.tolist()
-    pieces = [rb.seq[so[i] : so[i + 1]].translate(_COMP_BYTES)[::-1] if r else rb.seq[so[i] : so[i + 1]]
-              for i, r in zip(gk.tolist(), is_rev[good].tolist())]
+    if ref_anchored:
+        # ---- the reference bases of the alignments: forward strand for the output records, read orientation for the reads
+        #      (ref_seq = revcomp for reverse-strand records, io.py:2058-2060) ----
+        ro = rb.refseq_off.tolist()
+        fwd = [bytes(rb.refseq[ro[i] : ro[i + 1]]).upper() for i in gk.tolist()]
+        pieces = [f.translate(_COMP_BYTES)[::-1] if r else f for f, r in zip(fwd, is_rev[good].tolist())]
+        seq_len = np.asarray([len(f) for f in fwd], np.int64)
+        out.ref_fwd = b"".join(fwd)
+        per_kept = np.zeros(nk, np.int64)
+        per_kept[good] = seq_len
+        np.cumsum(per_kept, out=out.ref_fwd_off[1:])
+    else:
+        # ---- strand-aware bases (seq = revcomp(query_sequence) for reverse-strand records, :2023) ----
+        so = rb.seq_off.tolist()
+        pieces = [rb.seq[so[i] : so[i + 1]].translate(_COMP_BYTES)[::-1] if r else rb.seq[so[i] : so[i + 1]]
+                  for i, r in zip(gk.tolist(), is_rev[good].tolist())]
+        seq_len = seq_len_all[gk].astype(np.int64)
     out.seq = b"".join(pieces)
-    seq_len = seq_len_all[gk].astype(np.int64)
     out.seq_off = np.zeros(good.size + 1, np.int64)
     np.cumsum(seq_len, out=out.seq_off[1:])
     from .util import _SEQ_TRANS
@@ -1697,17 +1755,24 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     else:
         sm, sd = np.full(good.size, float(pa_scaling[0])), np.full(good.size, float(pa_scaling[1]))
     shift, scale = cal_off + cal_scale * sm, cal_scale * sd
-    # ---- dacs = trimmed[q2s[0]:q2s[-1]], mapping re-based: assembled where the pieces already are ----
+    # ---- dacs = trimmed[map[0]:map[-1]], mapping re-based: assembled where the pieces already are ----
     n_good = int(good.size)
     n_seq = int(out.seq_off[-1])
-    dacs = torch.empty(max(int(sig_len[good].sum()), 1), dtype=torch.int16, device=dev)
+    if ref_anchored:  # ref_to_signal of the good records takes query_to_signal's place
+        d_q2s = torch.from_numpy(r2s).to(dev)
+        map_off = np.ascontiguousarray(r2s_off[gk], np.int64)
+        sig_total = int((r2s[r2s_off[gk] + seq_len] - r2s[r2s_off[gk]]).sum())
+    else:
+        map_off = np.ascontiguousarray(rb.mv_off[gk], np.int64)
+        sig_total = int(sig_len[good].sum())
+    dacs = torch.empty(max(sig_total, 1), dtype=torch.int16, device=dev)
     s2s = torch.empty(n_seq + n_good, dtype=torch.int64, device=dev)
     d_sig_off = torch.empty(n_good + 1, dtype=torch.int64, device=dev)
     d_seq_off = torch.empty(n_good + 1, dtype=torch.int64, device=dev)
     sig_off = np.zeros(n_good + 1, np.int64)
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    ss, qo = np.ascontiguousarray(src_start[good], np.int64), np.ascontiguousarray(rb.mv_off[gk], np.int64)
-    L.check(L.lib().rmr_assemble_reads(eng.handle, n_good, flat.data_ptr(), p(ss), d_q2s.data_ptr(), p(qo), p(seq_len), dacs.data_ptr(),
+    ss = np.ascontiguousarray(src_start[good], np.int64)
+    L.check(L.lib().rmr_assemble_reads(eng.handle, n_good, flat.data_ptr(), p(ss), d_q2s.data_ptr(), p(map_off), p(seq_len), dacs.data_ptr(),
                                        dacs.numel(), s2s.data_ptr(), d_sig_off.data_ptr(), d_seq_off.data_ptr(), p(sig_off)))
     d_iseq = torch.from_numpy(iseq).to(dev)
     eng.synchronize()
@@ -1719,20 +1784,22 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary):
     return out
 
 
-def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=True, batch=256, shard=None, device=None):
-    """The batch form of iter_reads_from_pod5_and_bam for basecall-anchored calling of forward signal: IngestBatch objects
+def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=True, batch=256, shard=None, device=None,
+                        ref_anchored=False):
+    """The batch form of iter_reads_from_pod5_and_bam for calling of forward signal, anchored on the basecalls or (`ref_anchored`)
+    on the reference bases of the alignments: IngestBatch objects
     (arrays on the GPU) instead of (io.Read, error) pairs; a batch the array form does not cover comes as the list of
     (io.Read, error) pairs the per-read path yields for its records."""
     from .engine import get_ingest_engine
 
     signals = Pod5File(pod5_path)
     eng = get_ingest_engine(device)
-    for rb, records in iter_bam_raw_batches(bam_path, want_ref=False, batch=batch, shard=shard):
-        got = _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary)
+    for rb, records in iter_bam_raw_batches(bam_path, want_ref=bool(ref_anchored), batch=batch, shard=shard):
+        got = _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=ref_anchored)
         if got is None:
             continue
         if isinstance(got, str):  # "slow": the per-read path for the records of this batch
-            yield list(_reads_of_records(records(rb), signals, eng, False, pa_scaling, skip_non_primary, max(batch, 2), False))
+            yield list(_reads_of_records(records(rb), signals, eng, False, pa_scaling, skip_non_primary, max(batch, 2), bool(ref_anchored)))
             continue
         yield got
 
@@ -1822,18 +1889,28 @@ def records_with_mod_tags_batch(records, mm, mm_off, ml, ml_off, has_tags):
     return out[: out_len.value].tobytes()
 
 
-def records_with_mod_tags_flat(raw, raw_start, raw_len, tags_off, mm, mm_off, ml, ml_off, has_tags):
+def records_with_mod_tags_flat(raw, raw_start, raw_len, tags_off, mm, mm_off, ml, ml_off, has_tags, ref_seq=None, ref_off=None):
     """records_with_mod_tags_batch for records that lie in ONE bytes object (a RawBamBatch's `raw`): record r is
-    raw[raw_start[r] : raw_start[r] + raw_len[r]], its tags begin tags_off[r] bytes into it."""
+    raw[raw_start[r] : raw_start[r] + raw_len[r]], its tags begin tags_off[r] bytes into it.  `ref_seq` / `ref_off`
+    (reference-anchored calling): a record that gets tags and owns a non-empty slice of `ref_seq` - the forward-strand reference
+    bases of its alignment - is written as record_with_mod_tags(..., ref_anchored_seq=...) writes it
+    (rmr_records_with_mod_tags_ref)."""
     n = int(np.asarray(raw_len).size)
     base = ctypes.cast(ctypes.c_char_p(raw), ctypes.c_void_p).value or 0
     ptrs = np.uint64(base) + np.ascontiguousarray(raw_start, np.int64).astype(np.uint64)
     raw_len, tags_off = np.ascontiguousarray(raw_len, np.int64), np.ascontiguousarray(tags_off, np.int64)
     has = np.ascontiguousarray(has_tags, np.uint8)
     mm_off, ml_off = np.ascontiguousarray(mm_off, np.int64), np.ascontiguousarray(ml_off, np.int64)
-    out = np.empty(int(raw_len.sum()) + 16 * n + int(mm_off[-1]) + int(ml_off[-1]) + 16, np.uint8)
     out_len = ctypes.c_int64()
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    if ref_seq is not None:
+        ref_off = np.ascontiguousarray(ref_off, np.int64)
+        ref_arr = np.frombuffer(ref_seq, np.uint8) if len(ref_seq) else np.zeros(1, np.uint8)
+        out = np.empty(int(raw_len.sum()) + 24 * n + int(mm_off[-1]) + int(ml_off[-1]) + 2 * int(ref_off[-1]) + 16, np.uint8)
+        L.check(L.lib().rmr_records_with_mod_tags_ref(n, p(ptrs), p(raw_len), p(tags_off), p(mm), p(mm_off), p(ml), p(ml_off), p(has),
+                                                      p(ref_arr), p(ref_off), p(out), out.size, ctypes.byref(out_len)))
+        return out[: out_len.value].tobytes()
+    out = np.empty(int(raw_len.sum()) + 16 * n + int(mm_off[-1]) + int(ml_off[-1]) + 16, np.uint8)
     L.check(L.lib().rmr_records_with_mod_tags(n, p(ptrs), p(raw_len), p(tags_off), p(mm), p(mm_off), p(ml), p(ml_off), p(has), p(out),
                                               out.size, ctypes.byref(out_len)))
     return out[: out_len.value].tobytes()

@@ -5,7 +5,7 @@ processes).  Input: the reference's 14 test alignments REP times over (same read
 signals per batch; BAM parse, move tables, normalisation, extraction, inference, MM/ML formatting and BAM output are per
 record).  Test infrastructure (mints the model file from the oracle's torch restatement); run by hand on a GPU box.
 
-    python tests/manual/prof_infer_cli.py [REP=600] [procs list=1,2,4,8,16] [dtype=fp32]"""
+    python tests/manual/prof_infer_cli.py [REP=600] [procs list=1,2,4,8,16] [dtype=fp32] [bam level=6] ["--reference-anchored"]"""
 import json
 import os
 import re
@@ -29,6 +29,7 @@ REP = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 PROCS = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8,16").split(",")]
 DT = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 LEVEL = sys.argv[4] if len(sys.argv) > 4 else "6"
+EXTRA = sys.argv[5].split() if len(sys.argv) > 5 else []  # e.g. "--reference-anchored"
 data = os.path.join(ROOT, "tests", "golden", "data")
 pod5, bam = os.path.join(data, "can_reads.pod5"), os.path.join(data, "can_mappings.bam")
 tmp = tempfile.mkdtemp()
@@ -49,7 +50,7 @@ for p in PROCS:
     out = os.path.join(tmp, f"out{p}.bam")
     t = time.perf_counter()
     r = subprocess.run([sys.executable, "-m", "remora_amd", "infer", "from_pod5_and_bam", pod5, big, "--model", pt, "--out-bam", out,
-                        "--dtype", DT, "--procs-per-gpu", str(p), "--reads-per-batch", "512", "--bam-level", LEVEL], cwd=ROOT, capture_output=True, text=True)
+                        "--dtype", DT, "--procs-per-gpu", str(p), "--reads-per-batch", "512", "--bam-level", LEVEL] + EXTRA, cwd=ROOT, capture_output=True, text=True)
     wall = time.perf_counter() - t
     if os.environ.get("RMR_INFER_TIMING"):
         print("\n".join(ln for ln in r.stderr.splitlines() if ln.startswith("[")), flush=True)

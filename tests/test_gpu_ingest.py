@@ -35,7 +35,7 @@ def _patch_tag(rec, name, value=None):
     raise KeyError(name)
 
 
-def _dirty_bam(path, prefix):
+def _dirty_bam(path, prefix, with_missing_moves=True):
     """The reference's test alignments plus records of every kind the ingest has to turn away, in between them."""
     from remora_amd import io as rio
 
@@ -48,7 +48,7 @@ def _dirty_bam(path, prefix):
             raw = raw[:14] + struct.pack("<H", r.flag | 0x100) + raw[16:]
         elif k == 3:  # unmapped and reverse: "Unmapped reads cannot map to reverse strand."
             raw = struct.pack("<i", -1) + raw[4:14] + struct.pack("<H", r.flag | 16 | 4) + raw[16:]
-        elif k == 5:  # no move table
+        elif k == 5 and with_missing_moves:  # no move table
             raw = _patch_tag(r, "mv")
         elif k == 7:  # a read the POD5 file does not hold: skipped
             name = b"0" * (raw[8] - 1)
@@ -64,8 +64,12 @@ def _dirty_bam(path, prefix):
     return len(out)
 
 
+@pytest.mark.parametrize("ref_anchored", [False, True])
 @pytest.mark.parametrize("prefix", ["can", "mod"])
-def test_ingest_batches_equal_the_per_read_path(prefix, tmp_path):
+def test_ingest_batches_equal_the_per_read_path(prefix, ref_anchored, tmp_path):
+    """Both anchors: the basecalls (move table) and the reference bases of the alignment (move table composed with the CIGAR,
+    reference sequence from MD; a record without a move table sends its whole batch down the per-read path, so the file of
+    this case has none)."""
     import torch
 
     from remora_amd import io as rio
@@ -73,22 +77,22 @@ def test_ingest_batches_equal_the_per_read_path(prefix, tmp_path):
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     pod5 = os.path.join(DATA, f"{prefix}_reads.pod5")
     bam = str(tmp_path / "dirty.bam")
-    n_rec = _dirty_bam(bam, prefix)
+    n_rec = _dirty_bam(bam, prefix, with_missing_moves=not ref_anchored)
     for pa_scaling in (None, (87.5, 14.25)):
-        slow = list(rio.iter_reads_from_pod5_and_bam(pod5, bam, pa_scaling=pa_scaling, parse_ref_align=False, decode_batch=4))
+        slow = list(rio.iter_reads_from_pod5_and_bam(pod5, bam, pa_scaling=pa_scaling, parse_ref_align=ref_anchored, decode_batch=4))
         want, want_err = [], []
         for read, err in slow:
             if err is None:
                 try:
-                    want.append(read.into_remora_read(False))
+                    want.append(read.into_remora_read(ref_anchored))
                     want_err.append(None)
                     continue
                 except rio.RemoraError as e:
                     err = f"Read prep error: {e}"
             want_err.append(err)
-        assert len(slow) == n_rec - 2 and sum(e is not None for e in want_err) == 3
+        assert len(slow) == n_rec - 2 and sum(e is not None for e in want_err) == (2 if ref_anchored else 3)
         got_err, k = [], 0
-        for ib in rio.iter_ingest_batches(pod5, bam, pa_scaling=pa_scaling, batch=4):
+        for ib in rio.iter_ingest_batches(pod5, bam, pa_scaling=pa_scaling, batch=4, ref_anchored=ref_anchored):
             assert isinstance(ib, rio.IngestBatch)
             got_err.extend(ib.err)
             if not ib.good.size:
@@ -106,7 +110,53 @@ def test_ingest_batches_equal_the_per_read_path(prefix, tmp_path):
                 assert shift[g] == rr.shift and scale[g] == rr.scale  # the same float64 operations: equal, not close
                 assert ib.seq[ib.seq_off[g] : ib.seq_off[g + 1]].decode() == rr.str_seq
                 assert ib.reads[g].shift == rr.shift and ib.reads[g].scale == rr.scale
+                if ref_anchored:  # the forward-strand reference bases the output record is rewritten with
+                    kk = int(ib.good[g])
+                    fwd = ib.ref_fwd[ib.ref_fwd_off[kk] : ib.ref_fwd_off[kk + 1]].decode()
+                    rec_rev = bool(ib.rb.flag[ib.keep[kk]] & 16)
+                    assert fwd == (rio.revcomp(rr.str_seq) if rec_rev else rr.str_seq)
+            if ref_anchored:
+                assert ib.ref_fwd_off.size == len(ib) + 1 and int(ib.ref_fwd_off[-1]) == len(ib.ref_fwd)
         assert k == len(want) and got_err == want_err
+
+
+@pytest.mark.parametrize("prefix", ["can", "mod"])
+def test_reference_anchored_infer_output_is_the_same_file_with_and_without_the_batch_ingest(prefix, tmp_path, monkeypatch):
+    """`infer --reference-anchored`: reads anchored on the reference bases of their alignments, output records rewritten to
+    `<len>M` + those bases (src/remora/inference.py:452-458) - batch ingest + native record rewrite against the per-read path,
+    byte for byte, on the reference's test files and on the file with records that have to be turned away."""
+    import torch
+
+    from oracle import oracle as O
+    from remora_amd import io as rio
+    from remora_amd.inference import infer_from_pod5_and_bam
+    from remora_amd.model_util import load_model
+    from test_gpu_parity import _mint_pt, _real_reads_golden
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    model, md = load_model(_mint_pt(tmp_path, _real_reads_golden(prefix), O), device=0)
+    pod5 = os.path.join(DATA, f"{prefix}_reads.pod5")
+    dirty = str(tmp_path / "dirty.bam")
+    _dirty_bam(dirty, prefix, with_missing_moves=False)
+    for bam in (os.path.join(DATA, f"{prefix}_mappings.bam"), dirty):
+        outs, stats, counts = [], [], []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
+            out = str(tmp_path / f"ra{mode}.bam")
+            lc = {}
+            stats.append(infer_from_pod5_and_bam(pod5, bam, model, md, out, reads_per_batch=5, ref_anchored=True, label_counts_out=lc))
+            outs.append(open(out, "rb").read())
+            counts.append({k: v.tolist() for k, v in lc.items()})
+        assert stats[0] == stats[1] and counts[0] == counts[1]
+        assert outs[0] == outs[1]
+        assert stats[0][None] >= 10
+        called = [r for r in rio.iter_bam_records(str(tmp_path / "ra1.bam")) if "MM" in dict(r.tags)]
+        assert len(called) == stats[0][None] and all(len(r.cigartuples) == 1 and r.cigartuples[0][0] == 0 for r in called)
+    # a limit that ends inside a batch
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
+        infer_from_pod5_and_bam(pod5, dirty, model, md, str(tmp_path / f"rl{mode}.bam"), reads_per_batch=5, num_reads=7, ref_anchored=True)
+    assert open(tmp_path / "rl1.bam", "rb").read() == open(tmp_path / "rl0.bam", "rb").read()
 
 
 @pytest.mark.parametrize("prefix", ["can", "mod"])

@@ -2735,3 +2735,112 @@ def test_built_library_has_no_packed_fp32_op_sel_on_lds_fed_registers():
         res = lint_pk_lds.lint(lib)
         assert res["kernels"] > 50 and res["packed_f32"] > 500, res  # the walk saw the kernels and their packed math
         assert res["flagged"] == [], res["flagged"][:5]
+
+
+def test_ref_anchor_batch_equals_move_table_then_ref_to_signal_per_record():
+    """rmr_ref_anchor_batch (the reference-anchored half of a BAM batch's ingest: io.parse_move_tag, then compute_ref_to_signal,
+    per record on native threads) against the per-record forms on the reference's own aligned reads (both test BAMs, both
+    strands) and on their move tables made discordant; the statuses are the per-read path's errors in its order."""
+    import ctypes
+
+    from remora_amd import _lib as L
+    from remora_amd import io as rio
+
+    pp = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    checked = 0
+    for name in ("can_mappings.bam", "mod_mappings.bam"):
+        rb = next(iter(rio.iter_bam_raw_batches(os.path.join(DATA, name), want_ref=True, batch=64)))[0]
+        n = rb.n
+        mv_len = np.diff(rb.mv_off)
+        seq_len = np.diff(rb.seq_off).astype(np.int64)
+        stride = np.array([int(rb.mv[rb.mv_off[i]]) if mv_len[i] else 1 for i in range(n)])
+        sig_len = ((mv_len - 1) * stride + 3).astype(np.int64)  # any length with sig_len // stride == entries
+        rev = np.ascontiguousarray((rb.flag & 16) != 0, np.uint8)
+        ref_len = np.where((rb.ref_ok != 0) & (rb.ref_id >= 0), np.diff(rb.refseq_off), -1).astype(np.int64)
+        assert (ref_len > 0).sum() >= 10
+        for variant in ("as is", "one base short", "signal short", "no reference", "threads"):
+            sl, ql, rl = sig_len.copy(), seq_len.copy(), ref_len.copy()
+            if variant == "one base short":
+                ql[::2] -= 1
+            if variant == "signal short":
+                sl[1::3] -= 40
+            if variant == "no reference":
+                rl[::4] = -1
+            r2s_off = np.zeros(n + 1, np.int64)
+            np.cumsum(np.maximum(rl, -1) + 1, out=r2s_off[1:])
+            r2s = np.full(int(r2s_off[-1]) + 1, -7, np.int64)
+            status = np.full(n, 77, np.int32)
+            L.check(L.lib().rmr_ref_anchor_batch(n, pp(rb.mv), pp(np.ascontiguousarray(rb.mv_off, np.int64)), pp(sl), pp(ql),
+                                                 pp(np.ascontiguousarray(rb.cigar, np.uint32)), pp(np.ascontiguousarray(rb.cigar_off, np.int64)),
+                                                 pp(rev), pp(rl), pp(r2s), pp(r2s_off), pp(status), 5 if variant == "threads" else 1))
+            for i in range(n):
+                mv = rb.mv[rb.mv_off[i] : rb.mv_off[i + 1]]
+                if mv.size == 0:
+                    assert status[i] == 8
+                    continue
+                q2s = np.concatenate([np.nonzero(mv[1:])[0] * int(mv[0]), [sl[i]]]).astype(np.int64)  # io.py:397-400
+                if q2s.size - 1 != ql[i]:
+                    assert status[i] == L.ERR_DISCORDANT_SEQ, (variant, i)
+                elif mv.size - 1 != sl[i] // int(mv[0]):
+                    assert status[i] == L.ERR_DISCORDANT_SIG, (variant, i)
+                elif rl[i] < 0:
+                    assert status[i] == 9, (variant, i)
+                else:
+                    cig = rb.cigar[rb.cigar_off[i] : rb.cigar_off[i + 1]]
+                    want = rio._ref_to_signal_of_bam_cigar(cig, bool(rev[i]), q2s, int(rl[i]) + 1)
+                    assert status[i] == (0 if want.size == rl[i] + 1 else 1), (variant, i, int(status[i]))
+                    if status[i] == 0:
+                        assert np.array_equal(r2s[r2s_off[i] : r2s_off[i + 1]], want), (variant, i)
+                        checked += 1
+            assert r2s[-1] == -7
+    assert checked >= 60
+    # the reference's own error texts for alignments without a usable CIGAR, and a declared reference length that is not the CIGAR's
+    mv = np.array([5, 1, 0, 1, 1, 0, 1], np.int8)
+    for cig, rl, want in (([(4 << 4) | 4], 4, 3), ([(4 << 4) | 9], 4, 2), ([(4 << 4) | 0], 7, 1), ([(4 << 4) | 0], 4, 0)):
+        status, r2s = np.zeros(1, np.int32), np.zeros(16, np.int64)
+        L.check(L.lib().rmr_ref_anchor_batch(1, pp(mv), pp(np.array([0, 7], np.int64)), pp(np.array([31], np.int64)), pp(np.array([4], np.int64)),
+                                             pp(np.array(cig, np.uint32)), pp(np.array([0, 1], np.int64)), pp(np.zeros(1, np.uint8)),
+                                             pp(np.array([rl], np.int64)), pp(r2s), pp(np.array([0, rl + 1], np.int64)), pp(status), 1))
+        assert status[0] == want, (cig, rl, int(status[0]))
+    assert r2s[:5].tolist() == [0, 10, 15, 25, 31]
+    assert rio._REF_ANCHOR_ERRORS == {1: "Discordant ref seq lengths", 2: "Invalid cigar op(s)", 3: "No match operations found in alignment cigar"}
+
+
+def test_reference_anchored_records_in_one_native_call(tmp_path):
+    """rmr_records_with_mod_tags_ref (io.records_with_mod_tags_flat with reference sequences) against record_with_mod_tags per
+    record: a record that gets tags and owns reference bases leaves as `<len>M` + those bases + 0xff qualities
+    (src/remora/inference.py:452-458), every other record as before; odd and even lengths, letters outside ACGT."""
+    from remora_amd import io as rio
+
+    rb, records = next(iter(rio.iter_bam_raw_batches(os.path.join(DATA, "can_mappings.bam"), want_ref=True, batch=64)))
+    recs = records(rb)
+    rng = np.random.default_rng(4)
+    n = rb.n
+    refs, has, mms, mls = [], np.zeros(n, np.uint8), [], []
+    for i in range(n):
+        k = [0, 1, 2, 7, 8, 501][i % 6]
+        refs.append("".join(rng.choice(list("ACGTNRacgt"), k)) if i % 5 else "")
+        has[i] = i % 3 != 1
+        mms.append(f"C+m?,{i},{2 * i};" if has[i] else "")
+        mls.append(rng.integers(0, 256, 2 if has[i] else 0).astype(np.uint8))
+    mm = np.frombuffer("".join(mms).encode(), np.uint8)
+    mm_off = np.concatenate([[0], np.cumsum([len(x) for x in mms])]).astype(np.int64)
+    ml = np.concatenate(mls) if n else np.zeros(0, np.uint8)
+    ml_off = np.concatenate([[0], np.cumsum([x.size for x in mls])]).astype(np.int64)
+    ref_off = np.concatenate([[0], np.cumsum([len(x) for x in refs])]).astype(np.int64)
+    got = rio.records_with_mod_tags_flat(rb.raw, rb.raw_off[:-1], np.diff(rb.raw_off), rb.tags_off, mm if mm.size else np.zeros(1, np.uint8),
+                                         mm_off, ml if ml.size else np.zeros(1, np.uint8), ml_off, has, ref_seq="".join(refs).encode(),
+                                         ref_off=ref_off)
+    want = b"".join(rio.record_with_mod_tags(recs[i], mms[i] if has[i] else None, mls[i] if has[i] else None,
+                                             ref_anchored_seq=(refs[i] if has[i] and refs[i] else None)) for i in range(n))
+    assert got == want
+    # ... and the parsed result is a record of that length with one M operation
+    rec0 = next(i for i in range(n) if has[i] and len(refs[i]) > 2)
+    one = rio.records_with_mod_tags_flat(rb.raw, rb.raw_off[rec0 : rec0 + 1], np.diff(rb.raw_off)[rec0 : rec0 + 1], rb.tags_off[rec0 : rec0 + 1],
+                                         mm, mm_off[rec0 : rec0 + 2] - 0, ml, ml_off[rec0 : rec0 + 2], has[rec0 : rec0 + 1],
+                                         ref_seq="".join(refs).encode(), ref_off=ref_off[rec0 : rec0 + 2])
+    path = tmp_path / "one.bam"
+    with rio.BamWriter(str(path), rio.read_bam_header_bytes(os.path.join(DATA, "can_mappings.bam"))) as w:
+        w.write(one)
+    back = list(rio.iter_bam_records(str(path)))
+    assert len(back) == 1 and back[0].cigartuples == [(0, len(refs[rec0]))] and len(back[0].query_sequence) == len(refs[rec0])
