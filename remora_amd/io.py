@@ -1555,9 +1555,10 @@ class IngestBatch:
     (ReadStub per good read), `seq` (their strand-oriented bases, ASCII, back to back) and `seq_off`.  Reference-anchored
     batches: `seq` holds the reference bases of the alignments in read orientation (what the reads are anchored on), and
     `ref_fwd` / `ref_fwd_off` (int64[len(keep) + 1]) the same bases in forward-strand orientation per KEPT record (empty for
-    records that cannot be called) - what the output records are rewritten with; None otherwise."""
+    records that cannot be called) - what the output records are rewritten with; None otherwise.  `per_read()` - the same
+    records as (io.Read, error) pairs of the per-read path, built on demand."""
 
-    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "seq_off", "records", "ref_fwd", "ref_fwd_off")
+    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "seq_off", "records", "ref_fwd", "ref_fwd_off", "per_read")
 
     def __len__(self):
         return int(self.keep.size)
@@ -1570,6 +1571,7 @@ class IngestBatch:
         out = IngestBatch()
         out.rb, out.records, out.keep, out.err = self.rb, self.records, self.keep[:k], self.err[:k]
         out.ref_fwd, out.ref_fwd_off = self.ref_fwd, (None if self.ref_fwd_off is None else self.ref_fwd_off[: k + 1])
+        out.per_read = (lambda pr=self.per_read, kk=k: pr()[:kk]) if self.per_read is not None else None
         g = int(np.searchsorted(self.good, k))
         out.good, out.reads, out.seq_off = self.good[:g], self.reads[:g], self.seq_off[: g + 1]
         out.seq = self.seq[: int(self.seq_off[g])]
@@ -1720,6 +1722,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     out.rb, out.records, out.keep, out.err, out.good = rb, records, keep, err, good
     out.dr, out.reads, out.seq, out.seq_off = None, [], b"", np.zeros(1, np.int64)
     out.ref_fwd, out.ref_fwd_off = (b"", np.zeros(nk + 1, np.int64)) if ref_anchored else (None, None)
+    out.per_read = None
     if not good.size:
         return out
     gk = keep[good]
@@ -1798,9 +1801,12 @@ def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=T
         got = _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=ref_anchored)
         if got is None:
             continue
+        per_read = lambda rb=rb: list(_reads_of_records(records(rb), signals, eng, False, pa_scaling, skip_non_primary,  # noqa: E731
+                                                        max(batch, 2), bool(ref_anchored)))
         if isinstance(got, str):  # "slow": the per-read path for the records of this batch
-            yield list(_reads_of_records(records(rb), signals, eng, False, pa_scaling, skip_non_primary, max(batch, 2), bool(ref_anchored)))
+            yield per_read()
             continue
+        got.per_read = per_read  # for a consumer that finds it cannot use the batch after all (dataset prepare: a refiner's band error)
         yield got
 
 

@@ -9,6 +9,7 @@ What is different is the execution shape: reads are joined BAM-stream against PO
 `reads_per_batch` at a time - ONE upload, ONE banded-DP refinement launch, ONE extraction launch per batch
 (`extract_chunk_arrays`) whose outputs already are the dataset's row layout and go to the memmaps with
 `write_chunk_arrays` - instead of one Python `Chunk` object per focus base across three process pools."""
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -130,6 +131,59 @@ def extract_chunk_arrays_from_reads(read_errs, int_label, motifs, focus_ref_pos,
     return arrs, ids, keep, [tuple(r) for r in results if r is not None]
 
 
+def extract_chunk_arrays_from_ingest(ib, int_label, motifs, sig_map_refiner, max_chunks_per_read, chunk_context,
+                                     kmer_context_bases, base_start_justify, offset):
+    """`extract_chunk_arrays_from_reads` for a reference-anchored io.IngestBatch (reads assembled on the GPU, no io.Read /
+    RemoraRead object per read): the same four return values, or None when the batch has to go read by read after all (a
+    refiner that rejects a read's band).  What stays per read on the host is what decides the bytes of the dataset: the focus
+    bases in the reference's python-set order (util.find_focus_bases_in_int_sequence, src/remora/util.py:413-426) and their
+    down-sampling with numpy's global generator in read order (prepare_train_data.py:80-91)."""
+    from . import util
+
+    torch = _torch()
+    results = []
+    for e in ib.err:
+        if e == "Read prep error: Missing reference alignment":  # (the text of infer's into_remora_read; prepare's is this one)
+            e = "No reference sequence (missing MD tag)"
+        results.append([e, None])
+    arrs, ids, keep = None, [], np.zeros(0, bool)
+    if not ib.good.size:
+        return arrs, ids, keep, [tuple(r) for r in results]
+    dr, stubs = ib.dr, ib.reads
+    refiner = sig_map_refiner
+    loaded = refiner is not None and getattr(refiner, "is_loaded", False)
+    if loaded:
+        try:
+            if refiner.do_rough_rescale:
+                refiner.rough_rescale_device(dr, stubs)
+            if refiner.scale_iters == 0:
+                refiner.refine_device_reads(dr, stubs)
+        except RemoraError:
+            return None
+    iseq = np.frombuffer(ib.seq.translate(util._SEQ_TRANS), np.int8)
+    so = ib.seq_off.tolist()
+    rb = ib.rb
+    has_pi = (rb.has & 64) != 0
+    focus_list = []
+    foc_off = np.zeros(ib.good.size + 1, np.int64)
+    for g, k in enumerate(ib.good.tolist()):
+        fbs = util.find_focus_bases_in_int_sequence(iseq[so[g] : so[g + 1]], motifs)
+        if fbs.size > max_chunks_per_read:  # RemoraRead.downsample_focus_bases
+            fbs = np.random.choice(fbs, size=max_chunks_per_read, replace=False)
+        focus_list.append(fbs.astype(np.int64, copy=False))
+        foc_off[g + 1] = foc_off[g] + fbs.size
+        i = int(ib.keep[k])
+        rid = (rb.pi[rb.pi_off[i] : rb.pi_off[i + 1]] if has_pi[i] else rb.names[rb.name_off[i] : rb.name_off[i + 1]]).decode("latin-1")
+        ids += [rid] * fbs.size
+        results[k][1] = (int(foc_off[g]), int(foc_off[g + 1]))
+    if foc_off[-1] > 0:
+        focus = torch.from_numpy(np.concatenate(focus_list)).to(dr.engine.torch_device)
+        arrs, _ = _extract_device(dr, focus, foc_off, chunk_context, kmer_context_bases, base_start_justify, offset,
+                                  np.full(int(foc_off[-1]), int_label, np.int64))
+        keep = ~torch.isnan(arrs.signal).any(dim=2).any(dim=1).cpu().numpy()  # Chunk.check: "Signal contains NaN"
+    return arrs, ids, keep, [tuple(r) for r in results]
+
+
 def extract_chunks(read_errs, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read, chunk_context,
                    kmer_context_bases, base_start_justify, offset, basecall_anchor, engine=None):
     """The reference's signature and return shape (prepare_train_data.py:33-118): a list of
@@ -234,9 +288,17 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
 
     def run(batch):
         nonlocal next_save
-        arrs, ids, keep, results = extract_chunk_arrays_from_reads(
-            batch, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read, chunk_context,
-            kmer_context_bases, base_start_justify, offset, basecall_anchor, engine)
+        got = None
+        if isinstance(batch, rio.IngestBatch):
+            got = extract_chunk_arrays_from_ingest(batch, int_label, motifs, sig_map_refiner, max_chunks_per_read, chunk_context,
+                                                   kmer_context_bases, base_start_justify, offset)
+            if got is None:
+                batch = batch.per_read()
+        if got is None:
+            got = extract_chunk_arrays_from_reads(
+                batch, int_label, motifs, focus_ref_pos, sig_map_refiner, max_chunks_per_read, chunk_context,
+                kmer_context_bases, base_start_justify, offset, basecall_anchor, engine)
+        arrs, ids, keep, results = got
         for err, _rows in results:
             if err is not None:
                 errs[err] += 1
@@ -252,19 +314,35 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
             dataset.flush()
             next_save += save_every
 
-    batch, seen = [], 0
-    for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,
-                                                     skip_non_primary=skip_non_primary, shard=shard,
-                                                     device=engine.device if engine is not None else None):
-        if seen >= num_reads:
-            break
-        seen += 1
-        batch.append(read_err)
-        if len(batch) >= reads_per_batch:
+    refiner_iterative = (sig_map_refiner is not None and getattr(sig_map_refiner, "is_loaded", False) and sig_map_refiner.scale_iters > 0)
+    # reference anchor, motif-selected focus bases, forward signal: the batch ingest of `infer --reference-anchored`
+    # (io.iter_ingest_batches: the reads of a BAM batch assembled on the GPU) - everything else read by read
+    if (not basecall_anchor and focus_ref_pos is None and not rev_sig and not refiner_iterative and
+            os.environ.get("RMR_PREPARE_BATCH_INGEST", "1") != "0"):
+        seen = 0
+        # (pa_scaling only travels in the dataset's metadata: training reads are scaled by sm / sd, prepare_train_data.py:66-72)
+        for ib in rio.iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=skip_non_primary, batch=reads_per_batch,
+                                          shard=shard, device=engine.device if engine is not None else None, ref_anchored=True):
+            if seen >= num_reads:
+                break
+            if seen + len(ib) > num_reads:
+                ib = ib.head(num_reads - seen) if isinstance(ib, rio.IngestBatch) else ib[: num_reads - seen]
+            seen += len(ib)
+            run(ib)
+    else:
+        batch, seen = [], 0
+        for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,
+                                                         skip_non_primary=skip_non_primary, shard=shard,
+                                                         device=engine.device if engine is not None else None):
+            if seen >= num_reads:
+                break
+            seen += 1
+            batch.append(read_err)
+            if len(batch) >= reads_per_batch:
+                run(batch)
+                batch = []
+        if batch:
             run(batch)
-            batch = []
-    if batch:
-        run(batch)
     errs = {k: v for k, v in errs.items() if v}
     if world == 1:
         dataset.write_metadata()

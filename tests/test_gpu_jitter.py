@@ -26,7 +26,7 @@ def test_jittered_barriers_change_no_bit_in_any_pipeline():
                           "--json"], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("JSON ")][-1][5:])
-    assert [r["pipeline"] for r in res] == PIPELINES.split(",")
+    assert [r["pipeline"] for r in res] == PIPELINES.split(","), res
     for r in res:
         assert r["ok"], r
         assert r["runs"] == 12 and r["differing_runs"] == 0, r

@@ -1315,6 +1315,32 @@ def test_dataset_prepare_matches_reference(torch_cuda, tmp_path, name):
     assert max(np.unique(rows["read_ids"], return_counts=True)[1]) <= kw["max_chunks_per_read"]
 
 
+@pytest.mark.parametrize("name", ["can_ctrl", "can_refine", "mod_h"])
+def test_dataset_prepare_batch_ingest_and_per_read_path_write_the_same_dataset(torch_cuda, tmp_path, monkeypatch, name):
+    """Reference-anchored, motif-selected `dataset prepare` runs on the batch ingest since round 5 (reads assembled on the GPU,
+    focus bases and their down-sampling still per read on the host, in the reference's order): it is the path the golden test
+    above exercises for these configurations - checked here by counting its calls - and the per-read path
+    (RMR_PREPARE_BATCH_INGEST=0) still writes the same bytes."""
+    import remora_amd.prepare_train_data as ptd
+    from golden_util import dataset_rows
+
+    calls = []
+    real = ptd.extract_chunk_arrays_from_ingest
+    monkeypatch.setattr(ptd, "extract_chunk_arrays_from_ingest", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    _run_prepare(name, str(tmp_path / "batch"))
+    assert len(calls) >= 2, "the batch ingest did not run"
+    n_batch_calls = len(calls)
+    monkeypatch.setenv("RMR_PREPARE_BATCH_INGEST", "0")
+    _run_prepare(name, str(tmp_path / "reads"))
+    assert len(calls) == n_batch_calls
+    (md_a, rows_a), (md_b, rows_b) = dataset_rows(str(tmp_path / "batch")), dataset_rows(str(tmp_path / "reads"))
+    assert open(tmp_path / "batch" / "metadata.jsn").read() == open(tmp_path / "reads" / "metadata.jsn").read()
+    assert sorted(rows_a) == sorted(rows_b)
+    for k in rows_a:
+        assert rows_a[k].shape == rows_b[k].shape and (np.array_equal(rows_a[k].view(np.uint32), rows_b[k].view(np.uint32))
+                                                       if k == "signal" else np.array_equal(rows_a[k], rows_b[k])), k
+
+
 def test_extract_chunks_reference_signature(torch_cuda):
     """prepare_train_data.extract_chunks with the reference's arguments and return shape: per read a list of
     Chunk objects (or an error), equal to the rows the dataset writer got."""

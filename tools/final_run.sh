@@ -3,7 +3,7 @@
 set -x
 TAG=${1:-r03}
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_final.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_final.txt
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_final.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_final.txt
 grep -E "passed|failed|rc=" gpurun_out/pytest_gpu_final.txt | tail -3
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.txt 2>&1; tail -2 gpurun_out/smoke.txt
 ( time timeout 900 python bench.py --steps 20 --warmup 5 --details gpurun_out/bench_${TAG}_details.json > gpurun_out/bench_${TAG}_final.json 2> gpurun_out/bench_${TAG}_final.err ) 2> gpurun_out/bench_${TAG}_final.time

@@ -154,12 +154,13 @@ def main():
             if lib:
                 env["REMORA_HIP_LIB"] = lib
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-specs", args.jitter, "--reps", str(reps), "--n", str(args.n)],
-                               stdout=subprocess.PIPE, text=True, env=env, timeout=1500)  # (progress of the child: its stderr, not captured)
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=1500)
+            sys.stderr.write(p.stderr)  # the child's progress lines
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
             if not line:
-                print(f"  jitter: child with {lib or 'the shipped library'} FAILED rc={p.returncode}", flush=True)
+                print(f"  jitter: child with {lib or 'the shipped library'} FAILED rc={p.returncode}: {p.stderr[-800:]}", flush=True)
                 if args.json:
-                    print("JSON " + json.dumps([{"pipeline": "*", "ok": False, "error": f"child rc {p.returncode}"}]), flush=True)
+                    print("JSON " + json.dumps([{"pipeline": "*", "ok": False, "error": f"child rc {p.returncode}: {p.stderr[-800:]}"}]), flush=True)
                 return
             got.append(json.loads(line[-1][7:]))
         verdicts = []
