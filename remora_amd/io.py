@@ -366,10 +366,23 @@ def _verify_share_mark(bam_path, mark, file_offset, back=1 << 20):
     """Raise unless the records chained from an independent starting point in front of byte `file_offset` (the guess `back`
     bytes earlier, or the file's first record) meet virtual offset `mark` exactly."""
     first = bam_guess_start(bam_path, 0)
-    probe = bam_guess_start(bam_path, max(int(file_offset) - back, 0)) if file_offset > back else first
-    if probe is None or probe >= mark:  # nothing in front of the mark inside the window: start from the file's first record
-        probe = first
-    if probe is None or probe == mark:
+    probe = None
+    # a starting point in front of the mark: 1, 4, 16, 64 MiB back (records are tens of KiB: the first window almost always
+    # holds one); only a file smaller than the window is chained from its first record - never a whole large BAM per rank
+    # and mark (the rank in front verifies the boundary once more when it gets there, which stays the authoritative check)
+    for k in range(4):
+        window = back << (2 * k)
+        if file_offset <= window:
+            probe = first
+            break
+        probe = bam_guess_start(bam_path, max(int(file_offset) - window, 0))
+        if probe is not None and probe < mark:
+            break
+        probe = None
+    if probe is None:
+        raise RemoraError(f"{bam_path}: no record start found within {back << 6} bytes in front of the share boundary at byte "
+                          f"{file_offset} - REMORA_AMD_BAM_SHARD=scan splits by an exact pass over the file instead")
+    if probe == mark:
         return
     lib = L.lib()
     h = ctypes.c_void_p()

@@ -131,6 +131,49 @@ def extract_chunk_arrays_from_reads(read_errs, int_label, motifs, focus_ref_pos,
     return arrs, ids, keep, [tuple(r) for r in results if r is not None]
 
 
+def _prefetched(iterable, device, depth=2):
+    """`iterable` consumed in a thread of its own, `depth` items ahead (the ingest of the next BAM batches - BGZF inflate, zstd,
+    the decode and assembly kernels on the ingest engine - runs under the extraction and the dataset writes of the current
+    one; the role the reference gives its reader processes, src/remora/prepare_train_data.py:190-235).  Exceptions of the
+    producer surface in the consumer; a consumer that leaves early stops the producer."""
+    import queue
+    import threading
+
+    q, stop, end = queue.Queue(maxsize=max(int(depth), 1)), threading.Event(), object()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                return q.put(item, timeout=0.1)
+            except queue.Full:
+                continue
+
+    def produce():
+        try:
+            if device is not None:
+                _torch().cuda.set_device(device)  # a new thread starts on device 0
+            for item in iterable:
+                put(item)
+                if stop.is_set():
+                    return
+            put(end)
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    try:
+        while True:
+            item = q.get()
+            if item is end:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+
+
 def extract_chunk_arrays_from_ingest(ib, int_label, motifs, sig_map_refiner, max_chunks_per_read, chunk_context,
                                      kmer_context_bases, base_start_justify, offset):
     """`extract_chunk_arrays_from_reads` for a reference-anchored io.IngestBatch (reads assembled on the GPU, no io.Read /
@@ -223,12 +266,14 @@ def count_reads(pod5_path, bam_path, skip_non_primary=True, shard=None):
     rank's share of the BAM only."""
     signals = rio.Pod5File(pod5_path)
     total = both = 0
-    for rec in rio.iter_bam_records(bam_path, shard=shard):
-        if skip_non_primary and (rec.is_secondary or rec.is_supplementary):
-            continue
-        total += 1
-        tags = rec.hot_tags() if hasattr(rec, "hot_tags") else dict(rec.tags)  # (the native reader's: no Python walk over mv)
-        both += tags.get("pi", rec.query_name) in signals
+    for rb, _ in rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard):  # flat arrays: no object per record
+        keep = np.nonzero((rb.flag & 0x900) == 0)[0] if skip_non_primary else np.arange(rb.n)
+        total += int(keep.size)
+        has_pi = (rb.has & 64) != 0
+        no, po = rb.name_off.tolist(), rb.pi_off.tolist()
+        for i in keep.tolist():
+            rid = (rb.pi[po[i] : po[i + 1]] if has_pi[i] else rb.names[no[i] : no[i + 1]]).decode("latin-1")
+            both += rid in signals
     return both, total
 
 
@@ -286,8 +331,13 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
     int_label = 0 if mod_base_control else 1
     next_save = save_every
 
+    import time as _time
+
+    clock = {"ingest": 0.0, "extract": 0.0, "write": 0.0}  # RMR_INFER_TIMING=1 prints it
+
     def run(batch):
         nonlocal next_save
+        t0 = _time.perf_counter()
         got = None
         if isinstance(batch, rio.IngestBatch):
             got = extract_chunk_arrays_from_ingest(batch, int_label, motifs, sig_map_refiner, max_chunks_per_read, chunk_context,
@@ -306,10 +356,13 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
         if arrs is None:
             return
         errs["Sequence too long"] += int(((arrs.lengths.cpu().numpy() > max_seq_len) & keep).sum())
+        t1 = _time.perf_counter()
+        clock["extract"] += t1 - t0
         try:
             dataset.write_chunk_arrays(arrs, keep=keep, read_ids=ids)
         except RemoraError as e:
             errs[str(e)] += 1
+        clock["write"] += _time.perf_counter() - t1
         if dataset.size >= next_save:
             dataset.flush()
             next_save += save_every
@@ -321,14 +374,19 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
             os.environ.get("RMR_PREPARE_BATCH_INGEST", "1") != "0"):
         seen = 0
         # (pa_scaling only travels in the dataset's metadata: training reads are scaled by sm / sd, prepare_train_data.py:66-72)
-        for ib in rio.iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=skip_non_primary, batch=reads_per_batch,
-                                          shard=shard, device=engine.device if engine is not None else None, ref_anchored=True):
+        dev_idx = engine.device if engine is not None else _torch().cuda.current_device()
+        for ib in _prefetched(rio.iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=skip_non_primary,
+                                                      batch=reads_per_batch, shard=shard, device=dev_idx, ref_anchored=True), dev_idx):
             if seen >= num_reads:
                 break
             if seen + len(ib) > num_reads:
                 ib = ib.head(num_reads - seen) if isinstance(ib, rio.IngestBatch) else ib[: num_reads - seen]
             seen += len(ib)
             run(ib)
+        if os.environ.get("RMR_INFER_TIMING"):
+            import sys as _sys
+
+            print(f"[prepare rank {rank}/{world}] {seen} reads: extract {clock['extract']:.2f}s write {clock['write']:.2f}s", file=_sys.stderr, flush=True)
     else:
         batch, seen = [], 0
         for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,

@@ -201,27 +201,50 @@ class ValidationLogger:
         pool = ThreadPoolExecutor(max_workers=nthreads)
         dataset._ds_iters = None
 
+        stop = threading.Event()  # set by the consumer when it leaves early: the reader must not stay parked on a queue
+
+        def take_free():
+            while not stop.is_set():
+                try:
+                    return free.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+            return None
+
+        def hand_over(item):
+            while not stop.is_set():
+                try:
+                    return ready.put(item, timeout=0.1)
+                except queue.Full:
+                    continue
+
         def produce():
             try:
                 for batch in dataset.iter_numpy_batches(return_arrays=_RAW, copy=False):
                     n = int(np.asarray(batch[4]).shape[0])
                     if n == 0:
                         continue
-                    i = free.get()
+                    i = take_free()
+                    if i is None:
+                        return
                     if slots[i] is None or any(t.shape[0] < n or t.shape[1:] != np.asarray(a).shape[1:] for t, a in zip(slots[i], batch)):
                         slots[i] = [torch.empty(np.asarray(a).shape, dtype=torch.from_numpy(np.empty(0, np.asarray(a).dtype)).dtype,
                                                 pin_memory=True) for a in batch]
                     parts = [(lo, min(lo + (n + nthreads - 1) // nthreads, n)) for lo in range(0, n, (n + nthreads - 1) // nthreads)]
                     views = [t.numpy() for t in slots[i]]
                     list(pool.map(lambda p: [np.copyto(v[p[0] : p[1]], a[p[0] : p[1]]) for v, a in zip(views, batch)], parts))
-                    ready.put((i, n))
-                ready.put(None)
+                    hand_over((i, n))
+                hand_over(None)
             except BaseException as e:  # noqa: BLE001 - handed to the consumer
-                ready.put(e)
+                hand_over(e)
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        main_stream, up_stream = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        # the kernels run on the ENGINE's stream: that is the stream the uploads have to be ordered in front of (the caller's
+        # current torch stream is the same one unless somebody changed it after the engine was made)
+        main_stream = (torch.cuda.ExternalStream(eng.stream_ptr, device=dev) if getattr(eng, "stream_ptr", None)
+                       else torch.cuda.current_stream(dev))
+        up_stream = torch.cuda.Stream(dev)
         wins, preds, labs, sizes = [], [], [], []
         try:
             while True:
@@ -254,8 +277,10 @@ class ValidationLogger:
                 up.synchronize()  # the uploads of this slot are done: the reader may refill it under the kernels
                 free.put(i)
         finally:
+            stop.set()  # a consumer that raised leaves no reader behind holding pinned slots and open memmaps
+            th.join(timeout=30.0)
             dataset._ds_iters = None
-            pool.shutdown(wait=False)
+            pool.shutdown(wait=True)
         torch.cuda.synchronize(dev)
         win = torch.cat(wins).cpu().numpy()
         pred = torch.cat(preds).cpu().numpy().astype(np.int64)
