@@ -234,6 +234,74 @@ def _glue():
     return _GLUE
 
 
+_SET_ORDER = None
+_SET_SCRATCH = threading.local()
+
+
+def _set_order_glue():
+    """csrc/pyset_order.c through ctypes.CDLL (no CPython API in there: the GIL is released during the call), or False when
+    its restatement of the interpreter's set does not reproduce THIS interpreter's iteration order on a fixed sample (checked
+    once; callers then keep util.find_focus_bases_in_int_sequence)."""
+    global _SET_ORDER
+    if _SET_ORDER is None:
+        if os.environ.get("RMR_PY_GLUE", "1") == "0":
+            _SET_ORDER = False
+            return _SET_ORDER
+        _glue()  # existence check + message
+        g = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pyglue.so"))
+        g.rmr_py_set_order.restype = ctypes.c_int64
+        g.rmr_py_set_order.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        g.rmr_py_focus_bases_set_order.restype = ctypes.c_int64
+        g.rmr_py_focus_bases_set_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 5 + [ctypes.c_int32]
+        ok = True
+        rng = np.random.RandomState(7)
+        for n, top in ((3, 10), (5, 40), (40, 5000), (700, 6000), (3000, 1 << 20), (70000, 1 << 22)):
+            keys = np.ascontiguousarray(rng.randint(0, top, n), np.int64)
+            out = np.empty(n, np.int64)
+            cnt = g.rmr_py_set_order(keys.ctypes.data, n, out.ctypes.data)
+            s = set()
+            s.update(keys.tolist())
+            ok = ok and cnt == len(s) and out[:cnt].tolist() == list(s)
+        _SET_ORDER = g if ok else False
+    return _SET_ORDER
+
+
+def focus_bases_set_order(iseq, seq_off, motifs, threads=4):
+    """util.find_focus_bases_in_int_sequence for every read of a batch in one native call (int8 base codes `iseq`, read g at
+    seq_off[g]:seq_off[g+1]) -> (focus i64[F] read-local, in the interpreter's set order inside each read; foc_off i64[n+1]),
+    or None when the native restatement is unavailable for these motifs / this interpreter."""
+    g = _set_order_glue()
+    if not g or not 1 <= len(motifs) <= 64:
+        return None
+    nm = len(motifs)
+    ln = np.zeros(nm, np.int32)
+    fp = np.zeros(nm, np.int32)
+    mask = np.zeros((nm, 16), np.uint8)
+    for m, mot in enumerate(motifs):
+        if len(mot.raw_motif) > 16:
+            return None
+        ln[m], fp[m] = len(mot.raw_motif), int(mot.focus_pos)
+        for k, allowed in enumerate(mot.int_pattern):
+            mask[m, k] = int(sum(1 << int(b) for b in allowed))
+    iseq = np.ascontiguousarray(iseq, np.int8)
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    n = seq_off.size - 1
+    # scratch with room for one entry per base, kept between calls (20 MB for a batch of 512 x 5 kb reads: touching fresh pages
+    # every call cost more than the scan)
+    need = max(int(seq_off[-1]), 1)
+    focus = getattr(_SET_SCRATCH, "buf", None)
+    if focus is None or focus.size < need:
+        focus = _SET_SCRATCH.buf = np.empty(need + need // 4, np.int64)
+    foc_off = np.zeros(n + 1, np.int64)
+    tot = g.rmr_py_focus_bases_set_order(iseq.ctypes.data, seq_off.ctypes.data, n, nm, ln.ctypes.data, fp.ctypes.data,
+                                         mask.ctypes.data, focus.ctypes.data, foc_off.ctypes.data, threads)
+    if tot == -3:
+        return None
+    if tot < 0:
+        raise MemoryError("rmr_py_focus_bases_set_order")
+    return focus[:tot].copy(), foc_off
+
+
 def _collect_reads(reads):
     """Per read: addresses of dacs / seq_to_sig_map / int_seq, their sizes, the bases' itemsize, shift and scale - what
     rmr_pack_reads gathers from.  -> (p_dacs u64[n], sig_n i64[n], p_maps u64[n], p_seqs u64[n], seq_n i64[n], itemsize i32[n],

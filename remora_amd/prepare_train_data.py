@@ -209,10 +209,21 @@ def extract_chunk_arrays_from_ingest(ib, int_label, motifs, sig_map_refiner, max
     has_pi = (rb.has & 64) != 0
     focus_list = []
     foc_off = np.zeros(ib.good.size + 1, np.int64)
+    # all reads' focus bases in the interpreter's set order by one native call (csrc/pyset_order.c); None: these motifs / this
+    # interpreter are outside what it restates -> util.find_focus_bases_in_int_sequence read by read
+    from .data_chunks import focus_bases_set_order
+
+    native = focus_bases_set_order(iseq, ib.seq_off, motifs, threads=int(os.environ.get("RMR_PACK_THREADS", "4") or 4))
+    if native is not None:
+        all_fbs, all_off = native
+        all_off = all_off.tolist()
     for g, k in enumerate(ib.good.tolist()):
-        fbs = util.find_focus_bases_in_int_sequence(iseq[so[g] : so[g + 1]], motifs)
-        if fbs.size > max_chunks_per_read:  # RemoraRead.downsample_focus_bases
-            fbs = np.random.choice(fbs, size=max_chunks_per_read, replace=False)
+        if native is not None:
+            fbs = all_fbs[all_off[g] : all_off[g + 1]]
+        else:
+            fbs = util.find_focus_bases_in_int_sequence(iseq[so[g] : so[g + 1]], motifs)
+        if fbs.size > max_chunks_per_read:  # RemoraRead.downsample_focus_bases: np.random.choice(fbs, size, replace=False),
+            fbs = fbs[np.random.permutation(fbs.size)[:max_chunks_per_read]]  # which is this draw (legacy RandomState.choice)
         focus_list.append(fbs.astype(np.int64, copy=False))
         foc_off[g + 1] = foc_off[g] + fbs.size
         i = int(ib.keep[k])
@@ -300,7 +311,11 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
     shard = (rank, world) if world > 1 else None
     if world > 1 and num_reads is not None:
         raise RemoraError("--num-reads names the FIRST reads of the file: not available when the file is split over ranks")
+    import time as _time
+
+    t_start = _time.perf_counter()
     num_both, num_records = count_reads(pod5_path, bam_path, skip_non_primary, shard=shard)
+    t_counted = _time.perf_counter()
     if world > 1:
         shares = rdist.gather_objects((num_both, num_records))
         num_records, total_both = sum(x[1] for x in shares), sum(x[0] for x in shares)
@@ -330,8 +345,6 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
     errs = defaultdict(int)
     int_label = 0 if mod_base_control else 1
     next_save = save_every
-
-    import time as _time
 
     clock = {"ingest": 0.0, "extract": 0.0, "write": 0.0}  # RMR_INFER_TIMING=1 prints it
 
@@ -372,7 +385,7 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
     # (io.iter_ingest_batches: the reads of a BAM batch assembled on the GPU) - everything else read by read
     if (not basecall_anchor and focus_ref_pos is None and not rev_sig and not refiner_iterative and
             os.environ.get("RMR_PREPARE_BATCH_INGEST", "1") != "0"):
-        seen = 0
+        seen, t_loop = 0, _time.perf_counter()
         # (pa_scaling only travels in the dataset's metadata: training reads are scaled by sm / sd, prepare_train_data.py:66-72)
         dev_idx = engine.device if engine is not None else _torch().cuda.current_device()
         for ib in _prefetched(rio.iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=skip_non_primary,
@@ -386,7 +399,9 @@ def extract_chunk_dataset(bam_path, pod5_path, out_path, mod_base, mod_base_cont
         if os.environ.get("RMR_INFER_TIMING"):
             import sys as _sys
 
-            print(f"[prepare rank {rank}/{world}] {seen} reads: extract {clock['extract']:.2f}s write {clock['write']:.2f}s", file=_sys.stderr, flush=True)
+            print(f"[prepare rank {rank}/{world}] {seen} reads: count_reads {t_counted - t_start:.2f}s, batches {_time.perf_counter() - t_loop:.2f}s "
+                  f"of which extract {clock['extract']:.2f}s write {clock['write']:.2f}s (the rest: waiting for the ingest thread)",
+                  file=_sys.stderr, flush=True)
     else:
         batch, seen = [], 0
         for read_err in rio.iter_reads_from_pod5_and_bam(pod5_path, bam_path, reverse_signal=rev_sig, pa_scaling=pa_scaling,

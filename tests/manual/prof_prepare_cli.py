@@ -35,4 +35,7 @@ for p in PROCS:
                        cwd=ROOT, capture_output=True, text=True)
     wall = time.perf_counter() - t
     last = [ln for ln in r.stdout.splitlines() if ln.startswith("Extracted")]
+    for ln in r.stderr.splitlines():
+        if ln.startswith("[prepare"):
+            print("    " + ln, flush=True)
     print(f"procs/gpu {p:3d}: {n / wall:8.0f} reads/s incl. start-up ({wall:.1f} s)  {last[-1] if last else r.stderr[-400:]}", flush=True)

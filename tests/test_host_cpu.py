@@ -2844,3 +2844,48 @@ def test_reference_anchored_records_in_one_native_call(tmp_path):
         w.write(one)
     back = list(rio.iter_bam_records(str(path)))
     assert len(back) == 1 and back[0].cigartuples == [(0, len(refs[rec0]))] and len(back[0].query_sequence) == len(refs[rec0])
+
+
+def test_native_focus_bases_follow_the_interpreters_set_order():
+    """csrc/pyset_order.c restates CPython's set (insertion, growth, iteration order) on raw arrays so that `dataset prepare` can
+    keep the reference's chunk order (src/remora/util.py:413-426 iterates a python set) without a set per read; here against
+    the interpreter's own set: plain key lists across the table sizes, and motif hits of ragged batches (empty reads, N bases,
+    several motifs whose hits overlap, one to five native threads)."""
+    import ctypes
+
+    from remora_amd import data_chunks as dc, util
+
+    g = dc._set_order_glue()
+    assert g, "the restatement must match this interpreter (otherwise prepare silently takes the slow path)"
+    rng = np.random.RandomState(11)
+    for n, top in ((0, 5), (1, 5), (4, 9), (5, 9), (6, 64), (19, 64), (20, 4096), (77, 100), (400, 1 << 30), (12000, 13000), (120000, 1 << 40)):
+        keys = np.ascontiguousarray(rng.randint(0, top, n), np.int64)
+        out = np.empty(max(n, 1), np.int64)
+        cnt = g.rmr_py_set_order(keys.ctypes.data, n, out.ctypes.data)
+        s = set()
+        s.update(keys.tolist())
+        assert out[:cnt].tolist() == list(s), (n, top)
+    motif_sets = [[util.Motif("CG", 0)], [util.Motif("C", 0)], [util.Motif("CG", 0), util.Motif("CHH", 0), util.Motif("CHG", 0)],
+                  [util.Motif("N", 0)], [util.Motif("DRACH", 2), util.Motif("A", 0)], [util.Motif("GATC", 1), util.Motif("CCWGG", 1)],
+                  [util.Motif("ACGTACGTACGTACGT", 15), util.Motif("T", 0)]]
+    for trial in range(70):
+        n_reads = int(rng.randint(1, 40))
+        lens = rng.randint(0, 2500, n_reads) if trial % 3 else rng.randint(0, 12, n_reads)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        iseq = rng.randint(-1 if trial % 5 == 0 else 0, 4, off[-1]).astype(np.int8)
+        mots = motif_sets[trial % len(motif_sets)]
+        focus, foc_off = dc.focus_bases_set_order(iseq, off, mots, threads=1 + trial % 5)
+        assert foc_off[0] == 0 and foc_off[-1] == focus.size
+        for k in range(n_reads):
+            want = util.find_focus_bases_in_int_sequence(iseq[off[k] : off[k + 1]].astype(np.int64), mots)
+            assert np.array_equal(want, focus[foc_off[k] : foc_off[k + 1]]), (trial, k)
+    # a focus position in front of the motif (leading N stripped): keys could be negative -> not restated, the caller keeps the interpreter
+    assert dc.focus_bases_set_order(np.zeros(8, np.int8), np.array([0, 8]), [util.Motif("NCG", 0)]) is None
+    # the down-sampling draw of prepare's batch path is numpy's legacy choice(replace=False), value and generator state
+    a = np.arange(1000, 1400) * 3
+    np.random.seed(5)
+    x = np.random.choice(a, size=15, replace=False)
+    after = np.random.random()
+    np.random.seed(5)
+    y = a[np.random.permutation(a.size)[:15]]
+    assert np.array_equal(x, y) and after == np.random.random()
