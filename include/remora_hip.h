@@ -328,6 +328,15 @@ int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const int64_t *sig_
                    const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
                    int64_t *dst_maps, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads);
 
+/* The bases of selected records of a BAM batch in read orientation, back to back, with their integer codes (host code, native
+ * threads).  Record i: src[start[i] .. start[i] + len[i]); `upper` != 0 folds ASCII lower case first; rev[i] != 0: reversed and
+ * mapped through comp[256]; codes[j] = code[256] of the oriented byte; fwd (NULL allowed): the folded bases un-reversed.  Output
+ * offset of record i = len[0] + ... + len[i-1] in all three.
+ * replaces: per read, revcomp(query_sequence) / revcomp(ref_seq) in io.Read.add_alignment (src/remora/io.py:2023, :2058-2060)
+ * and util.seq_to_int (src/remora/util.py:131-142). */
+int rmr_orient_bases(const uint8_t *src, const int64_t *start, const int64_t *len, const uint8_t *rev, int64_t n, int upper,
+                     const uint8_t *comp, const int8_t *code, uint8_t *fwd, uint8_t *oriented, int8_t *codes, int threads);
+
 
 /* ---- X1 + X2 + X3 (+X6): chunk extraction for a batch of reads --------------------------- */
 /* replaces: RemoraRead.sig (src/remora/data_chunks.py:191-197), iter_chunks (:425-466),

@@ -116,3 +116,59 @@ extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const in
     for (auto &th : pool) th.join();
     return 0;
 }
+
+// The bases of the selected records of a BAM batch in read orientation, back to back, with their integer codes - what
+// Read.add_alignment (seq = revcomp(query_sequence) for reverse-strand records, src/remora/io.py:2023; ref_seq likewise,
+// :2058-2060) and util.seq_to_int (src/remora/util.py:131-142) do per read.  Record i: src[start[i] .. start[i] + len[i]);
+// `upper`: ASCII lower case folded first (pysam's reference sequence marks mismatches in lower case); rev[i]: reversed and
+// mapped through comp[256]; codes = code[256] of the oriented byte.  fwd (may be NULL): the folded, un-reversed bases.
+// Output position of record i: the running sum of len.  The tables are the caller's: one definition of the alphabet.
+extern "C" int rmr_orient_bases(const uint8_t *src, const int64_t *start, const int64_t *len, const uint8_t *rev, int64_t n, int upper,
+                                const uint8_t *comp, const int8_t *code, uint8_t *fwd, uint8_t *oriented, int8_t *codes, int threads) {
+    if (n < 0 || (n > 0 && (!src || !start || !len || !rev || !comp || !code || !oriented || !codes))) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (len[i] < 0 || start[i] < 0) RMR_FAIL(RMR_ERR_INVALID, "record %lld: negative extent", (long long)i);
+        off[i + 1] = off[i] + len[i];
+    }
+    uint8_t fold[256], comp_fold[256];
+    for (int c = 0; c < 256; ++c) {
+        fold[c] = (uint8_t)((upper && c >= 'a' && c <= 'z') ? c - 32 : c);
+        comp_fold[c] = comp[fold[c]];
+    }
+    auto work = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            const uint8_t *s = src + start[i];
+            const int64_t m = len[i];
+            uint8_t *o = oriented + off[i];
+            int8_t *k = codes + off[i];
+            if (fwd) {
+                uint8_t *f = fwd + off[i];
+                for (int64_t j = 0; j < m; ++j) f[j] = fold[s[j]];
+            }
+            if (rev[i]) {
+                for (int64_t j = 0; j < m; ++j) {
+                    const uint8_t b = comp_fold[s[m - 1 - j]];
+                    o[j] = b;
+                    k[j] = code[b];
+                }
+            } else {
+                for (int64_t j = 0; j < m; ++j) {
+                    const uint8_t b = fold[s[j]];
+                    o[j] = b;
+                    k[j] = code[b];
+                }
+            }
+        }
+    };
+    if (threads < 1) threads = 1;
+    if (threads > 32) threads = 32;
+    if (threads == 1 || n < 4 * threads) {
+        work(0, n);
+        return 0;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+    for (auto &th : pool) th.join();
+    return 0;
+}

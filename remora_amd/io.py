@@ -525,7 +525,9 @@ class RawBamBatch:
         return out
 
 
-def _native_raw_batches(lib, h, want_ref, batch, once=False, limit=None):
+def _native_raw_batches(lib, h, want_ref, batch, once=False, limit=None, light=False):
+    """`light`: flags, names and pi tags only - the blobs nobody reads when records are merely counted (record bytes, bases,
+    move tables, reference bases, CIGARs: 16 KB a record) stay where they are."""
     bb = L.BamBatch()
     arr = lambda ptr, dt, count: (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(dt)), shape=(count,)).copy()
                                   if count else np.zeros(0, dt))  # noqa: E731
@@ -551,10 +553,14 @@ def _native_raw_batches(lib, h, want_ref, batch, once=False, limit=None):
         rb.tags_off, rb.voffset = arr(bb.tags_off, ctypes.c_int64, n), arr(bb.voffset, ctypes.c_int64, n)
         for f in ("raw_off", "name_off", "seq_off", "mv_off", "pi_off", "refseq_off", "cigar_off"):
             setattr(rb, f, arr(getattr(bb, f), ctypes.c_int64, n + 1))
-        rb.cigar = arr(bb.cigar, ctypes.c_uint32, int(rb.cigar_off[n]))
-        rb.raw, rb.names, rb.seq = blob(bb.raw, int(rb.raw_off[n])), blob(bb.names, int(rb.name_off[n])), blob(bb.seq, int(rb.seq_off[n]))
-        rb.pi, rb.refseq = blob(bb.pi, int(rb.pi_off[n])), blob(bb.refseq, int(rb.refseq_off[n]))
-        rb.mv = arr(bb.mv, ctypes.c_int8, int(rb.mv_off[n]))
+        rb.names, rb.pi = blob(bb.names, int(rb.name_off[n])), blob(bb.pi, int(rb.pi_off[n]))
+        if light:
+            rb.cigar, rb.mv, rb.raw, rb.seq, rb.refseq = np.zeros(0, np.uint32), np.zeros(0, np.int8), b"", b"", b""
+        else:
+            rb.cigar = arr(bb.cigar, ctypes.c_uint32, int(rb.cigar_off[n]))
+            rb.raw, rb.seq = blob(bb.raw, int(rb.raw_off[n])), blob(bb.seq, int(rb.seq_off[n]))
+            rb.refseq = blob(bb.refseq, int(rb.refseq_off[n]))
+            rb.mv = arr(bb.mv, ctypes.c_int8, int(rb.mv_off[n]))
         yield rb
         if n < batch or once:
             return
@@ -789,7 +795,7 @@ def iter_bam_records(bam_path, want_ref=False, batch=512, native=True, shard=Non
     yield from _iter_bam_records_py(bam_path)
 
 
-def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None):
+def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None, light=False):
     """The alignments of a BAM file (or of a rank's share of it, `shard` as in iter_bam_records) as (RawBamBatch, records)
     pairs - `records(rb)` builds the record objects of a batch when somebody needs them - straight from the native reader:
     no Python object per record.  The batch form of iter_bam_records (same shares, same boundary check)."""
@@ -821,11 +827,11 @@ def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None):
         if start is not None:
             L.check(lib.rmr_bam_seek(h, int(start)))
         if end is None:
-            for rb in _native_raw_batches(lib, h, want_ref, batch, limit=count):
+            for rb in _native_raw_batches(lib, h, want_ref, batch, limit=count, light=light):
                 yield named(rb), records
             return
         end = int(end)
-        for rb in _native_raw_batches(lib, h, want_ref, batch):
+        for rb in _native_raw_batches(lib, h, want_ref, batch, light=light):
             named(rb)
             past = np.nonzero(rb.voffset >= end)[0]
             if past.size:
@@ -1571,7 +1577,7 @@ class IngestBatch:
     records that cannot be called) - what the output records are rewritten with; None otherwise.  `per_read()` - the same
     records as (io.Read, error) pairs of the per-read path, built on demand."""
 
-    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "seq_off", "records", "ref_fwd", "ref_fwd_off", "per_read")
+    __slots__ = ("rb", "keep", "err", "good", "dr", "reads", "seq", "iseq", "seq_off", "records", "ref_fwd", "ref_fwd_off", "per_read")
 
     def __len__(self):
         return int(self.keep.size)
@@ -1588,6 +1594,7 @@ class IngestBatch:
         g = int(np.searchsorted(self.good, k))
         out.good, out.reads, out.seq_off = self.good[:g], self.reads[:g], self.seq_off[: g + 1]
         out.seq = self.seq[: int(self.seq_off[g])]
+        out.iseq = self.iseq[: int(self.seq_off[g])]
         dr = self.dr
         if dr is not None and g:
             from .data_chunks import DeviceReads
@@ -1715,8 +1722,10 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     is_rev = (flag[keep] & 16) != 0
     err = [None] * nk
     mv_len = np.diff(rb.mv_off)[keep]
-    for k in range(nk):
-        if rb.ref_id[keep[k]] < 0 and is_rev[k]:
+    unmapped_rev = (rb.ref_id[keep] < 0) & is_rev
+    no_mv = np.zeros(nk, bool) if ref_anchored else (has & 1) == 0
+    for k in np.nonzero(unmapped_rev | no_mv | (status != 0))[0].tolist():  # (the reads with nothing to report are not visited)
+        if unmapped_rev[k]:
             err[k] = "Unmapped reads cannot map to reverse strand."
         elif ref_anchored:
             st = int(status[k])
@@ -1726,44 +1735,44 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
                 err[k] = _REF_ANCHOR_ERRORS[st]
             elif st < 0:
                 err[k] = _MOVE_ERRORS.get(st, "empty move tag" if mv_len[k] < 1 else f"move table stride {int(rb.mv[rb.mv_off[keep[k]]])}")
-        elif not (has[k] & 1):
+        elif no_mv[k]:
             err[k] = "Read prep error: Missing query_to_signal (move table)"
         elif status[k] != 0:
             err[k] = _MOVE_ERRORS.get(int(status[k]), "empty move tag" if mv_len[k] < 1 else f"move table stride {int(rb.mv[rb.mv_off[keep[k]]])}")
     good = np.asarray([k for k in range(nk) if err[k] is None], np.int64)
     out = IngestBatch()
     out.rb, out.records, out.keep, out.err, out.good = rb, records, keep, err, good
-    out.dr, out.reads, out.seq, out.seq_off = None, [], b"", np.zeros(1, np.int64)
+    out.dr, out.reads, out.seq, out.seq_off, out.iseq = None, [], b"", np.zeros(1, np.int64), np.zeros(0, np.int8)
     out.ref_fwd, out.ref_fwd_off = (b"", np.zeros(nk + 1, np.int64)) if ref_anchored else (None, None)
     out.per_read = None
     if not good.size:
         return out
     gk = keep[good]
+    # ---- strand-aware bases and their integer codes, one native pass (rmr_orient_bases): seq = revcomp(query_sequence) for
+    #      reverse-strand records (:2023); reference anchor: the reference bases of the alignments instead - forward strand,
+    #      upper case, for the output records (ref_fwd), read orientation for the reads (ref_seq, :2058-2060) ----
+    from .util import _SEQ_TRANS
+
+    src_blob, src_off = (rb.refseq, rb.refseq_off) if ref_anchored else (rb.seq, rb.seq_off)
+    start = np.ascontiguousarray(src_off[gk], np.int64)
+    seq_len = np.ascontiguousarray(src_off[gk + 1] - src_off[gk], np.int64)
+    out.seq_off = np.zeros(good.size + 1, np.int64)
+    np.cumsum(seq_len, out=out.seq_off[1:])
+    n_bases = max(int(out.seq_off[-1]), 1)
+    oriented, iseq = np.empty(n_bases, np.uint8), np.empty(n_bases, np.int8)
+    fwd = np.empty(n_bases, np.uint8) if ref_anchored else None
+    rev_good = np.ascontiguousarray(is_rev[good], np.uint8)
+    pq = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.check(L.lib().rmr_orient_bases(src_blob if src_blob else b"\0", pq(start), pq(seq_len), pq(rev_good), int(good.size), int(bool(ref_anchored)),
+                                     _COMP_BYTES, _SEQ_TRANS, pq(fwd) if fwd is not None else None, pq(oriented), pq(iseq),
+                                     int(os.environ.get("RMR_PACK_THREADS", "8"))))
+    oriented, iseq = oriented[: int(out.seq_off[-1])], iseq[: int(out.seq_off[-1])]
+    out.seq, out.iseq = oriented.tobytes(), iseq
     if ref_anchored:
-        # ---- the reference bases of the alignments: forward strand for the output records, read orientation for the reads
-        #      (ref_seq = revcomp for reverse-strand records, io.py:2058-2060) ----
-        ro = rb.refseq_off.tolist()
-        fwd = [bytes(rb.refseq[ro[i] : ro[i + 1]]).upper() for i in gk.tolist()]
-        pieces = [f.translate(_COMP_BYTES)[::-1] if r else f for f, r in zip(fwd, is_rev[good].tolist())]
-        seq_len = np.asarray([len(f) for f in fwd], np.int64)
-        out.ref_fwd = b"".join(fwd)
+        out.ref_fwd = fwd[: int(out.seq_off[-1])].tobytes()
         per_kept = np.zeros(nk, np.int64)
         per_kept[good] = seq_len
         np.cumsum(per_kept, out=out.ref_fwd_off[1:])
-    else:
-        # ---- strand-aware bases (seq = revcomp(query_sequence) for reverse-strand records, :2023) ----
-        so = rb.seq_off.tolist()
-        pieces = [rb.seq[so[i] : so[i + 1]].translate(_COMP_BYTES)[::-1] if r else rb.seq[so[i] : so[i + 1]]
-                  for i, r in zip(gk.tolist(), is_rev[good].tolist())]
-        seq_len = seq_len_all[gk].astype(np.int64)
-    out.seq = b"".join(pieces)
-    out.seq_off = np.zeros(good.size + 1, np.int64)
-    np.cumsum(seq_len, out=out.seq_off[1:])
-    from .util import _SEQ_TRANS
-
-    # (bytes.translate: 0.4 ms for the 4.6 MB of a batch; np.take through the int64 table + astype took 3.4 - a fifth of the
-    #  ingest thread's time per record, profiles/r05_prof_ingest_batches.log)
-    iseq = np.frombuffer(bytearray(out.seq.translate(_SEQ_TRANS)), np.int8)  # (bytearray: a writable buffer for torch.from_numpy)
     # ---- scaling: sm / sd composed with the calibration (:2036-2041, :2147-2153), float64 as on the per-read path ----
     cal_off, cal_scale = signals._cal_off[uniq][inv][good].astype(np.float64), signals._cal_scale[uniq][inv][good].astype(np.float64)
     if pa_scaling is None:
@@ -1800,6 +1809,52 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     return out
 
 
+def _readahead(gen, depth=2):
+    """`gen` iterated by a thread of its own, up to `depth` items ahead of the consumer (the native BAM reader releases the
+    GIL while it parses a batch: reading batch k + 1 overlaps the assembly of batch k).  Exceptions of the generator are
+    raised in the consumer; closing this generator stops the thread and closes `gen` there."""
+    import queue
+    import threading
+
+    q = queue.Queue(maxsize=max(int(depth), 1))
+    stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def run():
+        try:
+            for item in gen:
+                if not put(("item", item)):
+                    return
+            put(("end", None))
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            put(("error", e))
+        finally:
+            if hasattr(gen, "close"):
+                gen.close()
+
+    th = threading.Thread(target=run, name="rmr-bam-readahead", daemon=True)
+    th.start()
+    try:
+        while True:
+            kind, value = q.get()
+            if kind == "end":
+                return
+            if kind == "error":
+                raise value
+            yield value
+    finally:
+        stop.set()
+        th.join()
+
+
 def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=True, batch=256, shard=None, device=None,
                         ref_anchored=False):
     """The batch form of iter_reads_from_pod5_and_bam for calling of forward signal, anchored on the basecalls or (`ref_anchored`)
@@ -1810,7 +1865,10 @@ def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=T
 
     signals = Pod5File(pod5_path)
     eng = get_ingest_engine(device)
-    for rb, records in iter_bam_raw_batches(bam_path, want_ref=bool(ref_anchored), batch=batch, shard=shard):
+    raw_batches = iter_bam_raw_batches(bam_path, want_ref=bool(ref_anchored), batch=batch, shard=shard)
+    if os.environ.get("RMR_BAM_READAHEAD", "1") != "0":
+        raw_batches = _readahead(raw_batches, 2)
+    for rb, records in raw_batches:
         got = _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=ref_anchored)
         if got is None:
             continue

@@ -203,7 +203,7 @@ def extract_chunk_arrays_from_ingest(ib, int_label, motifs, sig_map_refiner, max
                 refiner.refine_device_reads(dr, stubs)
         except RemoraError:
             return None
-    iseq = np.frombuffer(ib.seq.translate(util._SEQ_TRANS), np.int8)
+    iseq = ib.iseq  # the reads' base codes, back to back (io._ingest_batch)
     so = ib.seq_off.tolist()
     rb = ib.rb
     has_pi = (rb.has & 64) != 0
@@ -277,7 +277,7 @@ def count_reads(pod5_path, bam_path, skip_non_primary=True, shard=None):
     rank's share of the BAM only."""
     signals = rio.Pod5File(pod5_path)
     total = both = 0
-    for rb, _ in rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard):  # flat arrays: no object per record
+    for rb, _ in rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard, light=True):  # flags and names only
         keep = np.nonzero((rb.flag & 0x900) == 0)[0] if skip_non_primary else np.arange(rb.n)
         total += int(keep.size)
         has_pi = (rb.has & 64) != 0

@@ -2889,3 +2889,76 @@ def test_native_focus_bases_follow_the_interpreters_set_order():
     np.random.seed(5)
     y = a[np.random.permutation(a.size)[:15]]
     assert np.array_equal(x, y) and after == np.random.random()
+
+
+def test_orient_bases_native_against_the_interpreters_string_operations():
+    """rmr_orient_bases (strand-aware bases + integer codes of a batch of records in one native pass) against what the per-read
+    path does with bytes.upper / translate / [::-1] and util.seq_to_int's table (src/remora/io.py:2023, :2058-2060;
+    src/remora/util.py:131-142): ragged and empty records, lower-case mismatch marks, ambiguity codes, one and several threads."""
+    import ctypes
+
+    from remora_amd import _lib as L, io as rio
+    from remora_amd.util import _SEQ_TRANS
+
+    lib = L.lib()
+    rng = np.random.RandomState(3)
+    letters = np.frombuffer(b"ACGTacgtNnRYKMBVDH=", np.uint8)
+    for trial in range(12):
+        n_rec = int(rng.randint(1, 60))
+        lens = rng.randint(0, 400, n_rec)
+        lens[rng.randint(0, n_rec)] = 0
+        blob = letters[rng.randint(0, letters.size if trial % 2 else 4, int(lens.sum()) + 7)].tobytes()
+        off = np.concatenate([[0], np.cumsum(lens)])
+        pick = np.sort(rng.choice(n_rec, size=max(1, n_rec // 2), replace=False))
+        start, ln = np.ascontiguousarray(off[pick], np.int64), np.ascontiguousarray(lens[pick], np.int64)
+        rev = np.ascontiguousarray(rng.randint(0, 2, pick.size), np.uint8)
+        for upper in (0, 1):
+            total = int(ln.sum())
+            fwd, ori, codes = (np.zeros(total + 1, np.uint8), np.zeros(total + 1, np.uint8), np.zeros(total + 1, np.int8))
+            p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+            L.check(lib.rmr_orient_bases(blob, p(start), p(ln), p(rev), pick.size, upper, rio._COMP_BYTES, _SEQ_TRANS, p(fwd), p(ori), p(codes),
+                                         1 + trial % 4))
+            want_f, want_o = [], []
+            for s0, m, r in zip(start.tolist(), ln.tolist(), rev.tolist()):
+                f = blob[s0 : s0 + m].upper() if upper else blob[s0 : s0 + m]
+                want_f.append(f)
+                want_o.append(f.translate(rio._COMP_BYTES)[::-1] if r else f)
+            want_o = b"".join(want_o)
+            assert fwd[:total].tobytes() == b"".join(want_f)
+            assert ori[:total].tobytes() == want_o
+            assert codes[:total].tobytes() == want_o.translate(_SEQ_TRANS)
+
+
+def test_readahead_hands_over_items_errors_and_stops_when_closed():
+    from remora_amd.io import _readahead
+
+    assert list(_readahead(iter(range(50)), 2)) == list(range(50))
+    closed = []
+
+    def failing():
+        try:
+            yield 1
+            yield 2
+            raise ValueError("from the producer")
+        finally:
+            closed.append(True)
+
+    got = []
+    with pytest.raises(ValueError, match="from the producer"):
+        for x in _readahead(failing(), 2):
+            got.append(x)
+    assert got == [1, 2] and closed == [True]
+
+    def endless():
+        try:
+            k = 0
+            while True:
+                yield k
+                k += 1
+        finally:
+            closed.append("endless")
+
+    g = _readahead(endless(), 2)
+    assert [next(g), next(g), next(g)] == [0, 1, 2]
+    g.close()  # stops the thread and closes the producer's generator in it
+    assert closed[-1] == "endless"
