@@ -165,7 +165,10 @@ int rmr_assemble_reads(rmr_engine *e, int64_t n_reads, const int16_t *signal, co
  * CIGAR disagree).  Records arrive `max_records` at a time as flat arrays with [n+1] offset tables; every
  * pointer of the batch stays valid until the next rmr_bam_read_batch / rmr_bam_close on the same handle.
  * `has` bit i set = tag present: 0 mv (B:c), 1 ts, 2 ns, 3 sp, 4 sm, 5 sd, 6 pi, 7 MD.  `mv` excludes nothing:
- * [stride, m0, m1, ...] as stored.  n_records < max_records means end of file. */
+ * [stride, m0, m1, ...] as stored.  n_records < max_records means end of file.
+ * want_ref: bit 0 = rebuild the reference bases; bit 1 = identifiers only (flags, positions, names, the scalar tags, pi and
+ * `has`; record bytes, bases, CIGAR, move table, MD and reference stay empty - their offset tables are all zero): what a
+ * pass that only counts records against the signal file needs (get_read_ids, src/remora/io.py:362-391). */
 typedef struct rmr_bam rmr_bam;
 typedef struct rmr_bam_batch {
     int64_t n_records;

@@ -598,18 +598,21 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         b->voff.push_back(vo);
         b->flag.push_back(flag); b->ref_id.push_back(ref_id); b->pos.push_back(pos); b->mapq.push_back(mapq);
         b->l_seq.push_back((int32_t)l_seq); b->n_cigar.push_back(n_cig);
-        b->raw.insert(b->raw.end(), rec, end);
+        const bool ids_only = (want_ref & 2) != 0;  // flags, names and tags scalars; no record bytes, bases, CIGAR, move table
+        if (!ids_only) b->raw.insert(b->raw.end(), rec, end);
         b->raw_off.push_back((int64_t)b->raw.size());
         b->names.insert(b->names.end(), (const char *)p, (const char *)p + l_read_name - 1);
         b->name_off.push_back((int64_t)b->names.size());
         p += l_read_name;
         const size_t cig0 = b->cigar.size();
-        b->cigar.resize(cig0 + (size_t)n_cig);
-        if (n_cig) memcpy(b->cigar.data() + cig0, p, 4 * (size_t)n_cig);  // (BAM is little-endian, as every host this builds for)
+        if (!ids_only) {
+            b->cigar.resize(cig0 + (size_t)n_cig);
+            if (n_cig) memcpy(b->cigar.data() + cig0, p, 4 * (size_t)n_cig);  // (BAM is little-endian, as every host this builds for)
+        }
         p += 4 * (size_t)n_cig;
         const size_t seq0 = b->seq.size();
-        b->seq.resize(seq0 + (size_t)l_seq);
-        {   // two bases per packed byte through a 256-entry table of character pairs
+        if (!ids_only) b->seq.resize(seq0 + (size_t)l_seq);
+        if (!ids_only) {   // two bases per packed byte through a 256-entry table of character pairs
             static const std::array<uint16_t, 256> pair = [] {
                 std::array<uint16_t, 256> t{};
                 for (int v = 0; v < 256; ++v) t[(size_t)v] = (uint16_t)((uint8_t)NT16[v >> 4] | ((uint16_t)(uint8_t)NT16[v & 0xF] << 8));
@@ -638,7 +641,7 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
             if (sz < 0 || val + sz > end) RMR_FAIL(RMR_ERR_INVALID, "corrupt BAM tag %c%c", t0, t1);
             if (t0 == 'm' && t1 == 'v' && ty == 'B' && (val[0] == 'c' || val[0] == 'C')) {
                 const int64_t cnt = rd_i32(val + 1);
-                b->mv.insert(b->mv.end(), (const int8_t *)val + 5, (const int8_t *)val + 5 + cnt);
+                if (!ids_only) b->mv.insert(b->mv.end(), (const int8_t *)val + 5, (const int8_t *)val + 5 + cnt);
                 has |= 1;
             } else if (t0 == 't' && t1 == 's' && tag_int(ty, val, &ts)) has |= 2;
             else if (t0 == 'n' && t1 == 's' && tag_int(ty, val, &ns)) has |= 4;
@@ -648,7 +651,7 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
             else if (t0 == 'p' && t1 == 'i' && ty == 'Z') { b->pi.insert(b->pi.end(), (const char *)val, (const char *)val + sz - 1); has |= 64; }
             else if (t0 == 'M' && t1 == 'D' && ty == 'Z') {
                 md = (const char *)val; md_len = (size_t)sz - 1;
-                b->md.insert(b->md.end(), md, md + md_len);
+                if (!ids_only) b->md.insert(b->md.end(), md, md + md_len);
                 has |= 128;
             } else if (t0 == 'C' && t1 == 'G' && ty == 'B' && val[0] == 'I') {
                 cg = val + 5;
@@ -660,7 +663,7 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         // SAM spec 4.2.2: a CIGAR that does not fit the 16-bit count is stored in CG and the record carries the
         // placeholder <l_seq>S<ref_len>N (htslib / pysam resolve this transparently)
         // (htslib's bam_tag2cigar looks at the first operation only, on mapped records)
-        if (cg && cg_n > 0 && n_cig >= 1 && ref_id >= 0 && pos >= 0 && (b->cigar[cig0] & 0xF) == 4 &&
+        if (!ids_only && cg && cg_n > 0 && n_cig >= 1 && ref_id >= 0 && pos >= 0 && (b->cigar[cig0] & 0xF) == 4 &&
             (int64_t)(b->cigar[cig0] >> 4) == l_seq) {
             b->cigar.resize(cig0);
             for (int64_t k = 0; k < cg_n; ++k) b->cigar.push_back(rd_u32(cg + 4 * k));  // n_cigar keeps the record's own count (byte offsets)
@@ -672,7 +675,7 @@ int rmr_bam_read_batch(rmr_bam *b, int64_t max_records, int want_ref, rmr_bam_ba
         b->ts.push_back(ts); b->ns.push_back(ns); b->sp.push_back(sp); b->sm.push_back(sm); b->sd.push_back(sd);
         b->has.push_back(has);
         uint8_t ok = 0;
-        if (want_ref && md && !(flag & 4))
+        if ((want_ref & 1) && !ids_only && md && !(flag & 4))
             ok = rebuild_reference(b->seq.data() + seq0, (size_t)l_seq, b->cigar.data() + cig0, b->cigar.size() - cig0, md,
                                    md_len, cols, b->refseq) ? 1 : 0;
         b->ref_ok.push_back(ok);

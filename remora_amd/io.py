@@ -538,7 +538,7 @@ def _native_raw_batches(lib, h, want_ref, batch, once=False, limit=None, light=F
             if left <= 0:
                 return
             batch = min(batch, left)
-        L.check(lib.rmr_bam_read_batch(h, batch, int(bool(want_ref)), ctypes.byref(bb)))
+        L.check(lib.rmr_bam_read_batch(h, batch, 2 if light else int(bool(want_ref)), ctypes.byref(bb)))
         n = int(bb.n_records)
         if n == 0:
             return

@@ -2962,3 +2962,19 @@ def test_readahead_hands_over_items_errors_and_stops_when_closed():
     assert [next(g), next(g), next(g)] == [0, 1, 2]
     g.close()  # stops the thread and closes the producer's generator in it
     assert closed[-1] == "endless"
+
+
+def test_bam_batches_identifiers_only_mode_matches_the_full_parse():
+    """iter_bam_raw_batches(light=True) (rmr_bam_read_batch with want_ref bit 1: what count_reads runs on) gives the same
+    flags, names, parent ids, tag bits and virtual offsets as the full parse, and empty blobs."""
+    from remora_amd import io as rio
+
+    for stem in ("can", "mod"):
+        bam = os.path.join(DATA, f"{stem}_mappings.bam")
+        pick = lambda rb: (rb.n, rb.flag.tolist(), rb.ref_id.tolist(), rb.pos.tolist(), rb.names, rb.name_off.tolist(), rb.pi, rb.pi_off.tolist(),  # noqa: E731
+                           rb.has.tolist(), rb.voffset.tolist(), rb.sm.tolist(), rb.sp.tolist())
+        light = [pick(rb) for rb, _ in rio.iter_bam_raw_batches(bam, light=True, batch=5)]
+        full = [pick(rb) for rb, _ in rio.iter_bam_raw_batches(bam, batch=5)]
+        assert light == full and sum(x[0] for x in light) == 14
+        for rb, _ in rio.iter_bam_raw_batches(bam, light=True, batch=5):
+            assert rb.raw == b"" and rb.seq == b"" and rb.mv.size == 0 and int(rb.mv_off[-1]) == 0 and int(rb.seq_off[-1]) == 0
