@@ -1918,6 +1918,14 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     const size_t out_bytes = Stage::pad((size_t)nc * no * 4) + 256;
     RMR_TRY(e->ensure_pin_call(in_bytes + out_bytes));
     char *hp = reinterpret_cast<char *>(e->pin_call);
+    // The staging buffer is pinned host memory the GPU can address: for ONE read the kernels fetch the read's arrays from it
+    // across PCIe themselves and write the logits back into it (150 KB in, 2.5 KB out) instead of three queued copies, each
+    // of which cost a launch on the host and a blit kernel + a dependency gap on the stream - a sixth of the call
+    // (profiles/NOTES_r05.md section 1d).  RMR_CALL_READ_ZERO_COPY: bit 0 the read's arrays, bit 1 the chunk geometry,
+    // bit 2 the logits; 0 = the copies.
+    static const int zc = tune_int("RMR_CALL_READ_ZERO_COPY", 7);
+    char *hp_dev = nullptr;
+    if (zc) RMR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&hp_dev), hp, 0));
     memcpy(hp + o_dacs, r->dacs, (size_t)ns * 2);
     memcpy(hp + o_map, r->seq_to_sig, (size_t)(nb + 1) * 8);
     {
@@ -1947,7 +1955,9 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     // the read's arrays first and on their way ...
     RMR_TRY(st.init(arena_bytes(cap)));
     char *dp = st.take<char>(in_bytes);
-    RMR_HIP(hipMemcpyAsync(dp, hp, blob_bytes, hipMemcpyHostToDevice, e->stream));
+    char *arena_in = dp;
+    if (zc & 1) dp = hp_dev;
+    else RMR_HIP(hipMemcpyAsync(dp, hp, blob_bytes, hipMemcpyHostToDevice, e->stream));
     rmr_reads d{};
     d.n_reads = 1;
     d.dacs = reinterpret_cast<const int16_t *>(dp + o_dacs);
@@ -1962,7 +1972,7 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     d.cc_before = r->cc_before; d.cc_after = r->cc_after; d.kb = r->kb; d.ka = r->ka;
     d.base_start_justify = r->base_start_justify; d.offset = r->offset;
     const int32_t *chunk_read = reinterpret_cast<const int32_t *>(dp + o_cr);
-    const int64_t *dgeo = reinterpret_cast<const int64_t *>(dp + o_geo);
+    const int64_t *dgeo = reinterpret_cast<const int64_t *>(((zc & 2) ? hp_dev : arena_in) + o_geo);
     float *dsig = st.take<float>(ns + 4);
     RMR_TRY(launch_geometry(e, d, 0, chunk_read, dsig, ns, nullptr, nullptr, nullptr));  // n_chunks 0: the signal normalisation alone
     // ... then, while they cross PCIe and the signal is normalised, the geometry of the chunks on the host: integer
@@ -1986,7 +1996,9 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
         st = Stage{e};
         RMR_TRY(st.init(arena_bytes(msl)));
         dp = st.take<char>(in_bytes);
-        RMR_HIP(hipMemcpyAsync(dp, hp, blob_bytes, hipMemcpyHostToDevice, e->stream));
+        arena_in = dp;
+        if (zc & 1) dp = hp_dev;
+        else RMR_HIP(hipMemcpyAsync(dp, hp, blob_bytes, hipMemcpyHostToDevice, e->stream));
         d.dacs = reinterpret_cast<const int16_t *>(dp + o_dacs);
         d.seq_to_sig = reinterpret_cast<const int64_t *>(dp + o_map);
         d.int_seq = reinterpret_cast<const int8_t *>(dp + o_seq);
@@ -1997,11 +2009,11 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
         d.shift = reinterpret_cast<const double *>(dp + o_sc);
         d.scale = d.shift + 1;
         chunk_read = reinterpret_cast<const int32_t *>(dp + o_cr);
-        dgeo = reinterpret_cast<const int64_t *>(dp + o_geo);
+        dgeo = reinterpret_cast<const int64_t *>(((zc & 2) ? hp_dev : arena_in) + o_geo);
         dsig = st.take<float>(ns + 4);
         RMR_TRY(launch_geometry(e, d, 0, chunk_read, dsig, ns, nullptr, nullptr, nullptr));
     }
-    RMR_HIP(hipMemcpyAsync(dp + o_geo, hp + o_geo, (size_t)nc * 48, hipMemcpyHostToDevice, e->stream));
+    if (!(zc & 2)) RMR_HIP(hipMemcpyAsync(arena_in + o_geo, hp + o_geo, (size_t)nc * 48, hipMemcpyHostToDevice, e->stream));
     const int seq_w = (int)std::max<int64_t>(msl + r->kb + r->ka, r->kb + r->ka + 1), map_w = (int)std::max<int64_t>(msl + 1, 2);
     float *dsignal = st.take<float>((size_t)nc * L);
     int8_t *dseqs = st.take<int8_t>((size_t)nc * seq_w);
@@ -2009,10 +2021,11 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     int16_t *dlens = st.take<int16_t>(nc);
     int64_t *drfb = st.take<int64_t>(nc);
     float *dlog = st.take<float>((size_t)nc * no);
+    float *hlog = reinterpret_cast<float *>(hp + in_bytes);
+    if (zc & 4) dlog = reinterpret_cast<float *>(hp_dev + in_bytes);
     RMR_TRY(launch_fill(e, d, nc, chunk_read, dsig, dgeo, dsignal, dseqs, seq_w, dmaps, map_w, dlens, drfb));
     RMR_TRY(run_pipeline(m, dsignal, nullptr, dseqs, seq_w, dmaps, map_w, dlens, r->kb, r->ka, nc, dlog));
-    float *hlog = reinterpret_cast<float *>(hp + in_bytes);
-    RMR_HIP(hipMemcpyAsync(hlog, dlog, (size_t)nc * no * 4, hipMemcpyDeviceToHost, e->stream));
+    if (!(zc & 4)) RMR_HIP(hipMemcpyAsync(hlog, dlog, (size_t)nc * no * 4, hipMemcpyDeviceToHost, e->stream));
     RMR_HIP(hipStreamSynchronize(e->stream));
     memcpy(logits, hlog, (size_t)nc * no * 4);
     return 0;
