@@ -145,6 +145,16 @@ int rmr_parse_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int
 int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off,
                           const int64_t *sig_len, const int64_t *seq_len, int64_t n_reads, int check,
                           int reverse_signal, int64_t *q2s, int64_t *counts, int32_t *status, int mem);
+/* Counting half of the median / MAD scaling of reads without sm / sd tags (io.Read.compute_pa_to_norm_scaling,
+ * src/remora/io.py:1851-1856: np.median of the pA signal and of its absolute deviations - order statistics of a function of the
+ * int16 samples, so counts are all the GPU has to deliver).  `signal`: device-resident decoded samples; span i = signal[start[i]
+ * .. start[i] + len[i]) (start, len: host arrays).  Called twice, like the motif scan: with hist == NULL it writes the smallest
+ * and largest sample of every span to lo / hi (host int32[n]; an empty span gets lo > hi); with hist != NULL the caller passes
+ * those lo / hi back, hist_off (host int64[n + 1], the running sum of hi - lo + 1, 0 for empty spans) and receives
+ * hist[hist_off[i] + (v - lo[i])] = the number of samples of span i equal to v (host uint32[hist_off[n]]).  Synchronous. */
+int rmr_signal_histograms(rmr_engine *e, const int16_t *signal, const int64_t *start, const int64_t *len, int64_t n, int32_t *lo,
+                          int32_t *hi, const int64_t *hist_off, uint32_t *hist);
+
 /* replaces: for a whole batch, the tail of io.Read.add_alignment and Read.into_remora_read (src/remora/io.py:2003-2012:
  * the signal of an alignment is dacs[sp:][ts:ns]; :2123-2177: the read keeps dacs[q2s[0]:q2s[-1]] and the mapping q2s -
  * q2s[0]) on arrays that are already resident: `signal` (device) holds the decoded samples of the batch back to back,

@@ -1405,6 +1405,53 @@ int rmr_parse_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *m
     return 0;
 }
 
+int rmr_signal_histograms(rmr_engine *e, const int16_t *signal, const int64_t *start, const int64_t *len, int64_t n, int32_t *lo, int32_t *hi,
+                          const int64_t *hist_off, uint32_t *hist) {
+    if (!e || !signal || !start || !len || !lo || !hi || (hist != nullptr) != (hist_off != nullptr)) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (n < 0 || n > (int64_t)1 << 24) RMR_FAIL(RMR_ERR_INVALID, "bad n");
+    if (n == 0) return 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (start[i] < 0 || len[i] < 0) RMR_FAIL(RMR_ERR_INVALID, "span %lld: negative extent", (long long)i);
+    std::lock_guard<std::mutex> lk(e->mu);
+    RMR_HIP(hipSetDevice(e->device));
+    const size_t nn = (size_t)n;
+    Stage st{e};
+    if (!hist) {  // pass 1: the range of every span
+        RMR_TRY(st.init(2 * Stage::pad(nn * 8) + 2 * Stage::pad(nn * 4) + 4096));
+        int64_t *d_start = st.take<int64_t>(nn), *d_len = st.take<int64_t>(nn);
+        int32_t *d_lo = st.take<int32_t>(nn), *d_hi = st.take<int32_t>(nn);
+        H2D(d_start, start, nn * 8);
+        H2D(d_len, len, nn * 8);
+        RMR_TRY(launch_signal_range(e, signal, d_start, d_len, n, d_lo, d_hi));
+        D2H(lo, d_lo, nn * 4);
+        D2H(hi, d_hi, nn * 4);
+        RMR_HIP(hipStreamSynchronize(e->stream));
+        return 0;
+    }
+    // pass 2: counts over [lo, hi] of every span, at the offsets the caller summed up
+    if (hist_off[0] != 0) RMR_FAIL(RMR_ERR_INVALID, "hist_off[0] != 0");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t width = len[i] > 0 ? (int64_t)hi[i] - lo[i] + 1 : 0;
+        if (hist_off[i + 1] - hist_off[i] != (width > 0 ? width : 0)) RMR_FAIL(RMR_ERR_INVALID, "span %lld: hist_off does not match hi - lo + 1", (long long)i);
+    }
+    const size_t total = (size_t)hist_off[n];
+    if (total == 0) return 0;
+    RMR_TRY(st.init(2 * Stage::pad(nn * 8) + Stage::pad(nn * 4) + Stage::pad((nn + 1) * 8) + Stage::pad(total * 4) + 4096));
+    int64_t *d_start = st.take<int64_t>(nn), *d_len = st.take<int64_t>(nn);
+    int32_t *d_lo = st.take<int32_t>(nn);
+    int64_t *d_off = st.take<int64_t>(nn + 1);
+    uint32_t *d_hist = st.take<uint32_t>(total);
+    H2D(d_start, start, nn * 8);
+    H2D(d_len, len, nn * 8);
+    H2D(d_lo, lo, nn * 4);
+    H2D(d_off, hist_off, (nn + 1) * 8);
+    RMR_HIP(hipMemsetAsync(d_hist, 0, total * 4, e->stream));
+    RMR_TRY(launch_signal_hist(e, signal, d_start, d_len, d_lo, d_off, n, d_hist));
+    D2H(hist, d_hist, total * 4);
+    RMR_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 int rmr_assemble_reads(rmr_engine *e, int64_t n_reads, const int16_t *signal, const int64_t *src_start, const int64_t *q2s,
                        const int64_t *q2s_off, const int64_t *seq_len, int16_t *dacs, int64_t dacs_cap, int64_t *s2s,
                        int64_t *d_sig_off, int64_t *d_seq_off, int64_t *sig_off) {

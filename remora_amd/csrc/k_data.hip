@@ -413,6 +413,79 @@ __global__ __launch_bounds__(256) void assemble_reads_kernel(const int16_t *sign
     for (int64_t k = t0; k < n_map; k += step) m[k] = q[k] - first;
 }
 
+// ---------------------------------------------------------------------------------------
+// Reads without sm / sd tags are scaled by the median and the median absolute deviation of their trimmed signal
+// (io.Read.compute_pa_to_norm_scaling, src/remora/io.py:1851-1856).  Both are order statistics of a function of the int16
+// samples, so the GPU only has to count: per span of the decoded signal its smallest and largest sample, then the histogram
+// over that range (a few hundred to a few thousand bins); the float64 arithmetic on the occupied bins stays on the host,
+// operation for operation what numpy does on the samples.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void signal_range_kernel(const int16_t *signal, const int64_t *start, const int64_t *len, int32_t *lo,
+                                                           int32_t *hi) {
+    const int64_t r = blockIdx.x, n = len[r];
+    const int16_t *s = signal + start[r];
+    int mn = 32767, mx = -32768;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = s[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __shared__ int w_mn[4], w_mx[4];
+    if ((threadIdx.x & 63) == 0) { w_mn[threadIdx.x >> 6] = mn; w_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mn = w_mn[w] < mn ? w_mn[w] : mn;
+            mx = w_mx[w] > mx ? w_mx[w] : mx;
+        }
+        lo[r] = mn;  // an empty span: lo = 32767 > hi = -32768
+        hi[r] = mx;
+    }
+}
+
+constexpr int HIST_LDS_BINS = 8192;
+
+// grid (spans, parts): every block counts its share of the span in LDS when the range fits, then adds its non-empty bins
+__global__ __launch_bounds__(256) void signal_hist_kernel(const int16_t *signal, const int64_t *start, const int64_t *len, const int32_t *lo,
+                                                          const int64_t *hist_off, unsigned int *hist) {
+    __shared__ unsigned int bins[HIST_LDS_BINS];
+    const int64_t r = blockIdx.x, n = len[r];
+    const int64_t width = hist_off[r + 1] - hist_off[r];
+    if (width <= 0 || n <= 0) return;
+    const int16_t *s = signal + start[r];
+    const int base = lo[r];
+    unsigned int *out = hist + hist_off[r];
+    const int64_t step = (int64_t)gridDim.y * blockDim.x, t0 = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (width <= HIST_LDS_BINS) {
+        for (int k = threadIdx.x; k < (int)width; k += blockDim.x) bins[k] = 0u;
+        __syncthreads();
+        for (int64_t i = t0; i < n; i += step) atomicAdd(&bins[(int)s[i] - base], 1u);
+        __syncthreads();
+        for (int k = threadIdx.x; k < (int)width; k += blockDim.x)
+            if (bins[k]) atomicAdd(&out[k], bins[k]);
+    } else {
+        for (int64_t i = t0; i < n; i += step) atomicAdd(&out[(int)s[i] - base], 1u);
+    }
+}
+
+int launch_signal_range(rmr_engine *e, const int16_t *signal, const int64_t *start, const int64_t *len, int64_t n, int32_t *lo, int32_t *hi) {
+    hipLaunchKernelGGL(signal_range_kernel, dim3((unsigned)n), dim3(256), 0, e->stream, signal, start, len, lo, hi);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_signal_hist(rmr_engine *e, const int16_t *signal, const int64_t *start, const int64_t *len, const int32_t *lo,
+                       const int64_t *hist_off, int64_t n, unsigned int *hist) {
+    hipLaunchKernelGGL(signal_hist_kernel, dim3((unsigned)n, 8), dim3(256), 0, e->stream, signal, start, len, lo, hist_off, hist);
+    RMR_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_assemble_lengths(rmr_engine *e, const int64_t *q2s, const int64_t *q2s_off, const int64_t *seq_len, int64_t n, int64_t *len_out) {
     hipLaunchKernelGGL(assemble_lengths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, q2s, q2s_off, seq_len, n, len_out);
     RMR_HIP(hipGetLastError());

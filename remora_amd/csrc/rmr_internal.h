@@ -232,6 +232,9 @@ int launch_moves(rmr_engine *e, const int8_t *mv_tag, int64_t mv_tag_len, int64_
 int launch_moves_batch(rmr_engine *e, const int8_t *mv_tags, const int64_t *mv_off, const int64_t *sig_len,
                        const int64_t *seq_len, int64_t n, int check, int reverse, int64_t *q2s, int64_t *counts,
                        int32_t *status);
+int launch_signal_range(rmr_engine *e, const int16_t *signal, const int64_t *start, const int64_t *len, int64_t n, int32_t *lo, int32_t *hi);
+int launch_signal_hist(rmr_engine *e, const int16_t *signal, const int64_t *start, const int64_t *len, const int32_t *lo,
+                       const int64_t *hist_off, int64_t n, unsigned int *hist);
 int launch_assemble_lengths(rmr_engine *e, const int64_t *q2s, const int64_t *q2s_off, const int64_t *seq_len, int64_t n, int64_t *len_out);
 int launch_assemble_reads(rmr_engine *e, const int16_t *signal, const int64_t *src_start, const int64_t *q2s, const int64_t *q2s_off,
                           const int64_t *sig_off, const int64_t *seq_off, int64_t n, int16_t *dacs, int64_t *s2s);

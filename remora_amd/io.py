@@ -1622,6 +1622,46 @@ def _trim_span(size, sp, ts, ns, has_ns):
 _REF_ANCHOR_ERRORS = {1: "Discordant ref seq lengths", 2: "Invalid cigar op(s)", 3: "No match operations found in alignment cigar"}
 
 
+def _weighted_median(values, counts):
+    """np.median of an array that holds values[i] counts[i] times (float64), without building it: the middle order statistic,
+    or numpy's mean of the two middle ones."""
+    order = np.argsort(values, kind="stable")
+    v, c = values[order], np.cumsum(counts[order])
+    n = int(c[-1])
+    kth = lambda k: v[np.searchsorted(c, k, side="right")]  # noqa: E731 - k-th smallest, zero-based
+    return np.mean(np.asarray([kth(n // 2)] if n % 2 else [kth(n // 2 - 1), kth(n // 2)], np.float64))
+
+
+def _median_mad_scaling(flat, start, length, cal_off, cal_scale, eng):
+    """(shift_pa_to_norm, scale_pa_to_norm) float64[n] of io.Read.compute_pa_to_norm_scaling (src/remora/io.py:1851-1856:
+    np.median of the pA signal, max(1, np.median(|pA - median|) * factor)) for n spans flat[start : start + length] of the
+    device-resident decoded signal.  The GPU counts (rmr_signal_histograms: range, then histogram of every span); the float64
+    arithmetic runs here on the occupied bins - the operations numpy applies to the samples, on every distinct sample once."""
+    n = int(np.asarray(start).size)
+    start, length = np.ascontiguousarray(start, np.int64), np.ascontiguousarray(length, np.int64)
+    lo, hi = np.empty(n, np.int32), np.empty(n, np.int32)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    lib = L.lib()
+    L.check(lib.rmr_signal_histograms(eng.handle, flat.data_ptr(), p(start), p(length), n, p(lo), p(hi), None, None))
+    hist_off = np.zeros(n + 1, np.int64)
+    np.cumsum(np.maximum(hi.astype(np.int64) - lo + 1, 0), out=hist_off[1:])
+    hist = np.zeros(max(int(hist_off[-1]), 1), np.uint32)
+    L.check(lib.rmr_signal_histograms(eng.handle, flat.data_ptr(), p(start), p(length), n, p(lo), p(hi), p(hist_off), p(hist)))
+    sm, sd = np.empty(n, np.float64), np.empty(n, np.float64)
+    for i in range(n):
+        h = hist[hist_off[i] : hist_off[i + 1]]
+        occ = np.nonzero(h)[0]
+        counts = h[occ].astype(np.int64)
+        if int(counts.sum()) != int(length[i]):
+            raise RemoraError("signal histogram does not add up to the span's length")
+        dacs = (occ + int(lo[i])).astype(np.int16)
+        pa = (dacs - float(cal_off[i])) / float(cal_scale[i])  # Read.pa_signal: int16 array with Python floats -> float64
+        med = _weighted_median(pa, counts)
+        sm[i] = med
+        sd[i] = max(1.0, _weighted_median(np.abs(pa - med), counts) * PA_TO_NORM_SCALING_FACTOR)
+    return sm, sd
+
+
 def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=False):
     """IngestBatch of one raw BAM batch, or None when nothing of it is kept.  Everything Read.from_pod5 + add_alignment +
     into_remora_read (forward signal) do per read, for the batch: trimming by sp / ts / ns, strand-aware
@@ -1660,7 +1700,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     sp = np.where(has & 8, rb.sp[keep], 0).astype(np.int64)
     ts = np.where(has & 2, rb.ts[keep], 0).astype(np.int64)
     ns = rb.ns[keep].astype(np.int64)
-    if (sp < 0).any() or (ts < 0).any() or (((has & 4) != 0) & (ns < 0)).any() or ((has & 48) != 48).any():
+    if (sp < 0).any() or (ts < 0).any() or (((has & 4) != 0) & (ns < 0)).any():
         return "slow"
     seq_len_all = np.diff(rb.seq_off)
     sb = np.frombuffer(rb.seq, np.uint8)
@@ -1675,6 +1715,16 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     size_k, base_k = read_size[inv], read_start[inv]
     off, sig_len = _trim_span(size_k, sp, ts, ns, (has & 4) != 0)
     src_start = base_k + off
+    # ---- norm scaling: the sm / sd tags, or - for records without both - median and MAD of the trimmed signal (:2036-2041);
+    #      unused when the caller overrides the scaling (into_remora_read, :2147-2153) ----
+    sm_k, sd_k = rb.sm[keep].astype(np.float64), rb.sd[keep].astype(np.float64)
+    untagged = np.nonzero((has & 48) != 48)[0]
+    if untagged.size and pa_scaling is None:
+        if (sig_len[untagged] <= 0).any():
+            return "slow"  # the median of nothing: numpy's warning and NaN belong to the per-read path
+        row = uniq[inv][untagged]
+        sm_k[untagged], sd_k[untagged] = _median_mad_scaling(flat, src_start[untagged], sig_len[untagged], signals._cal_off[row],
+                                                             signals._cal_scale[row], eng)
     sl_all = np.zeros(n_all, np.int64)
     sl_all[keep] = sig_len
     dev = eng.torch_device
@@ -1776,7 +1826,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     # ---- scaling: sm / sd composed with the calibration (:2036-2041, :2147-2153), float64 as on the per-read path ----
     cal_off, cal_scale = signals._cal_off[uniq][inv][good].astype(np.float64), signals._cal_scale[uniq][inv][good].astype(np.float64)
     if pa_scaling is None:
-        sm, sd = rb.sm[gk].astype(np.float64), rb.sd[gk].astype(np.float64)
+        sm, sd = sm_k[good], sd_k[good]
     else:
         sm, sd = np.full(good.size, float(pa_scaling[0])), np.full(good.size, float(pa_scaling[1]))
     shift, scale = cal_off + cal_scale * sm, cal_scale * sd

@@ -35,12 +35,26 @@ def _patch_tag(rec, name, value=None):
     raise KeyError(name)
 
 
-def _dirty_bam(path, prefix, with_missing_moves=True):
+def _reparsed(raw, header):
+    """The record object of record bytes (for a second _patch_tag on the same record)."""
+    import tempfile
+
+    from remora_amd import io as rio
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "one.bam")
+        with rio.BamWriter(path, header) as w:
+            w.write(struct.pack("<i", len(raw)) + raw)
+        return next(iter(rio.iter_bam_records(path)))
+
+
+def _dirty_bam(path, prefix, with_missing_moves=True, without_scaling_tags=False):
     """The reference's test alignments plus records of every kind the ingest has to turn away, in between them."""
     from remora_amd import io as rio
 
     src = os.path.join(DATA, f"{prefix}_mappings.bam")
     recs = list(rio.iter_bam_records(src))
+    src_header = rio.read_bam_header_bytes(src)
     out = []
     for k, r in enumerate(recs):
         raw = bytes(r.raw)
@@ -55,6 +69,11 @@ def _dirty_bam(path, prefix, with_missing_moves=True):
             raw = raw[:32] + name + raw[32 + len(name) :]
         elif k == 9:  # a trim that leaves too little signal for the move table
             raw = _patch_tag(r, "ts", 100)  # (ts is a one-byte tag here)
+        if without_scaling_tags and k in (2, 6, 8, 10):  # no sm, neither, no sd, neither: median / MAD of the trimmed signal
+            stripped = r
+            for name in {2: ("sm",), 6: ("sm", "sd"), 8: ("sd",), 10: ("sd", "sm")}[k]:
+                raw = _patch_tag(stripped, name)
+                stripped = _reparsed(raw, src_header)
         out.append(raw)
         if k == 4:  # the same read twice in one batch (one decode, two alignments)
             out.append(bytes(r.raw))
@@ -118,6 +137,49 @@ def test_ingest_batches_equal_the_per_read_path(prefix, ref_anchored, tmp_path):
             if ref_anchored:
                 assert ib.ref_fwd_off.size == len(ib) + 1 and int(ib.ref_fwd_off[-1]) == len(ib.ref_fwd)
         assert k == len(want) and got_err == want_err
+
+
+@pytest.mark.parametrize("ref_anchored", [False, True])
+@pytest.mark.parametrize("prefix", ["can", "mod"])
+def test_reads_without_scaling_tags_stay_on_the_batch_ingest(prefix, ref_anchored, tmp_path):
+    """Records without sm / sd (either or both) are scaled by median and MAD of their trimmed signal
+    (io.Read.compute_pa_to_norm_scaling, src/remora/io.py:1851-1856).  The batch ingest counts on the GPU
+    (rmr_signal_histograms) and does the float64 order statistics on the occupied bins: shift and scale equal the per-read
+    path's np.median values, every batch stays an IngestBatch."""
+    import torch
+
+    from remora_amd import io as rio
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    pod5 = os.path.join(DATA, f"{prefix}_reads.pod5")
+    bam = str(tmp_path / "untagged.bam")
+    _dirty_bam(bam, prefix, with_missing_moves=False, without_scaling_tags=True)
+    untagged_seen = 0
+    for rec in rio.iter_bam_records(bam):
+        tags = dict(rec.tags)
+        untagged_seen += not ("sm" in tags and "sd" in tags)
+    assert untagged_seen == 4
+    for pa_scaling in (None, (87.5, 14.25)):
+        want = []
+        for read, err in rio.iter_reads_from_pod5_and_bam(pod5, bam, pa_scaling=pa_scaling, parse_ref_align=ref_anchored, decode_batch=4):
+            if err is None:
+                try:
+                    want.append(read.into_remora_read(ref_anchored))
+                except rio.RemoraError:
+                    pass
+        k = 0
+        for ib in rio.iter_ingest_batches(pod5, bam, pa_scaling=pa_scaling, batch=5, ref_anchored=ref_anchored):
+            assert isinstance(ib, rio.IngestBatch)
+            if not ib.good.size:
+                continue
+            dr = ib.dr
+            dacs, shift, scale = dr.dacs.cpu().numpy(), dr.shift.cpu().numpy(), dr.scale.cpu().numpy()
+            for g in range(ib.good.size):
+                rr = want[k]
+                k += 1
+                assert np.array_equal(dacs[dr.sig_off[g] : dr.sig_off[g + 1]], rr.dacs)
+                assert shift[g] == rr.shift and scale[g] == rr.scale, (k, shift[g], rr.shift, scale[g], rr.scale)
+        assert k == len(want) and k >= 10
 
 
 @pytest.mark.parametrize("prefix", ["can", "mod"])

@@ -2978,3 +2978,25 @@ def test_bam_batches_identifiers_only_mode_matches_the_full_parse():
         assert light == full and sum(x[0] for x in light) == 14
         for rb, _ in rio.iter_bam_raw_batches(bam, light=True, batch=5):
             assert rb.raw == b"" and rb.seq == b"" and rb.mv.size == 0 and int(rb.mv_off[-1]) == 0 and int(rb.seq_off[-1]) == 0
+
+
+def test_weighted_median_is_numpys_median_of_the_expanded_array():
+    """io._weighted_median (host half of the median / MAD scaling of reads without sm / sd tags: the GPU hands over a histogram
+    of the int16 samples) against np.median on the samples themselves, through Read.pa_signal's arithmetic - equal, not close:
+    odd and even counts, ties, a negative calibration scale (the order of the pA values reverses)."""
+    from remora_amd import io as rio
+
+    rng = np.random.RandomState(0)
+    for t in range(600):
+        vals = np.unique(rng.randint(-500, 2000, rng.randint(1, 40))).astype(np.int16)
+        cnt = rng.randint(1, 6, vals.size)
+        off = float(np.float32(rng.uniform(-300, 300)))
+        sc = float(np.float32(rng.uniform(0.1, 0.3))) * (1 if t % 7 else -1)
+        dacs = np.repeat(vals, cnt)
+        rng.shuffle(dacs)
+        pa = (dacs - off) / sc
+        med = np.median(pa)
+        mad = np.median(np.abs(pa - med))
+        pv = (vals - off) / sc
+        got = rio._weighted_median(pv, cnt)
+        assert got == med and rio._weighted_median(np.abs(pv - got), cnt) == mad
