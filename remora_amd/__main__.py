@@ -290,7 +290,7 @@ def main(argv=None):
                         "Python and scales with processes; each takes its own contiguous share of the alignments")
     p.add_argument("--bam-level", type=int, default=None, help="zlib level of the output BAM (default 6, as htslib; 1 = fast: Huffman coding only, about a fifth larger, half the CPU time of zlib's level 1)")
     p.add_argument("--num-reads", type=int, default=None)
-    p.add_argument("--reads-per-batch", type=int, default=256)
+    p.add_argument("--reads-per-batch", type=int, default=512)
     p.add_argument("--dtype", default=None, help="fp32 (default) | f16x3 | bf16x6 | bf16x3 | bf16 | f16")
     p.add_argument("--reference-anchored", action="store_true",
                    help="call at reference positions; output records become <len>M with the reference sequence")
@@ -339,7 +339,7 @@ def main(argv=None):
     d.add_argument("--rough-rescale-method", default="least_squares", choices=("least_squares", "theil_sen"))
     d.add_argument("--mod-base", nargs=2, metavar=("SHORT_NAME", "LONG_NAME"))
     d.add_argument("--mod-base-control", action="store_true")
-    d.add_argument("--reads-per-batch", type=int, default=256)
+    d.add_argument("--reads-per-batch", type=int, default=512)
     d.add_argument("--device", type=int, default=0)
     d.add_argument("--gpus", type=int, default=1,
                    help="one process per GPU, each extracts the chunks of its own share of the BAM; the parts become one dataset")

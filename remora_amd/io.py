@@ -1662,6 +1662,37 @@ def _median_mad_scaling(flat, start, length, cal_off, cal_scale, eng):
     return sm, sd
 
 
+_SCRATCH = threading.local()
+
+
+def _scratch(name, count, dtype):
+    """A per-thread array of at least `count` items that lives across calls: the ingest's per-batch work buffers (10 MB of
+    reference-to-signal knots, the bases of a batch) cost more in first-touch page faults than in the work done on them when
+    they were allocated fresh for every batch."""
+    buf = getattr(_SCRATCH, name, None)
+    if buf is None or buf.size < count or buf.dtype != np.dtype(dtype):
+        buf = np.empty(int(count) + int(count) // 4 + 1024, dtype)
+        setattr(_SCRATCH, name, buf)
+    return buf[:count]
+
+
+INGEST_CLOCK = {}
+
+
+def _section_clock():
+    """clock(name): the time since the previous call is added to INGEST_CLOCK[name]."""
+    import time
+
+    last = [time.perf_counter()]
+
+    def clock(name):
+        now = time.perf_counter()
+        INGEST_CLOCK[name] = INGEST_CLOCK.get(name, 0.0) + now - last[0]
+        last[0] = now
+
+    return clock
+
+
 def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=False):
     """IngestBatch of one raw BAM batch, or None when nothing of it is kept.  Everything Read.from_pod5 + add_alignment +
     into_remora_read (forward signal) do per read, for the batch: trimming by sp / ts / ns, strand-aware
@@ -1670,13 +1701,15 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     their alignments instead of their basecalls - move table and CIGAR composed per record by native threads
     (rmr_ref_anchor_batch: src/remora/io.py:2066-2084), the reference sequence rebuilt from MD by the native reader, and
     the same assembly kernel cuts signal and mapping (ref_to_signal in place of query_to_signal).
-    A batch that holds something the array form does not reproduce (negative trim tags, bases outside A-Z, reads without
-    sm / sd, which need the median / MAD of their signal) is returned as the string "slow": the caller sends its records
-    through the per-read path."""
+    Reads without sm / sd tags get the median / MAD scaling from GPU histograms of their trimmed signal (_median_mad_scaling).
+    A batch that holds something the array form does not reproduce (negative trim tags, bases outside A-Z, an aligned record
+    without a move table) is returned as the string "slow": the caller sends its records through the per-read path.
+    RMR_INGEST_TIMING=1: seconds per section accumulate in io.INGEST_CLOCK (tools/prof_ingest_batches.py prints them)."""
     import torch
 
     from .data_chunks import DeviceReads
 
+    clock = _section_clock() if os.environ.get("RMR_INGEST_TIMING") else (lambda name: None)
     n_all = rb.n
     flag = rb.flag
     keep_mask = np.ones(n_all, bool) if not skip_non_primary else (flag & 0x900) == 0
@@ -1692,6 +1725,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
         if r is not None:
             kept.append(i)
             rows.append(r)
+    clock("ids")
     if not kept:
         return None
     keep = np.asarray(kept, np.int64)
@@ -1706,10 +1740,12 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     sb = np.frombuffer(rb.seq, np.uint8)
     if sb.size and (sb.min() < 65 or sb.max() > 90):
         return "slow"
+    clock("tags")
     # ---- signals: every distinct read of the batch decoded once, on the GPU ----
     uniq, inv = np.unique(np.asarray(rows, np.int64), return_inverse=True)
     first, addr, size, samples = signals.rows_of_reads(uniq)
     flat, row_out = vbz_decode_rows(addr, size, samples, eng)
+    clock("vbz_decode")
     read_start = row_out[first[:-1]]                      # where a distinct read's samples begin in `flat`
     read_size = row_out[first[1:]] - read_start
     size_k, base_k = read_size[inv], read_start[inv]
@@ -1741,7 +1777,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
         ref_len_all[keep[mapped_ref]] = np.diff(rb.refseq_off)[keep[mapped_ref]]
         r2s_off = np.zeros(n_all + 1, np.int64)
         np.cumsum(np.maximum(ref_len_all, -1) + 1, out=r2s_off[1:])
-        r2s = np.empty(max(int(r2s_off[-1]), 1), np.int64)
+        r2s = _scratch("r2s", max(int(r2s_off[-1]), 1), np.int64)  # (uploaded before this function returns)
         status_all = np.zeros(n_all, np.int32)
         pp = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
         mv_arr = rb.mv if total_mv else np.zeros(1, np.int8)
@@ -1768,6 +1804,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
                                               d_q2s.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), L.MEM_DEVICE))
         eng.synchronize()
         status = d_st.cpu().numpy()[keep]
+    clock("moves_or_ref_anchor")
     # ---- who can be called, and why not (the texts of add_alignment / into_remora_read, in their order) ----
     is_rev = (flag[keep] & 16) != 0
     err = [None] * nk
@@ -1798,6 +1835,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     if not good.size:
         return out
     gk = keep[good]
+    clock("errors")
     # ---- strand-aware bases and their integer codes, one native pass (rmr_orient_bases): seq = revcomp(query_sequence) for
     #      reverse-strand records (:2023); reference anchor: the reference bases of the alignments instead - forward strand,
     #      upper case, for the output records (ref_fwd), read orientation for the reads (ref_seq, :2058-2060) ----
@@ -1809,8 +1847,8 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     out.seq_off = np.zeros(good.size + 1, np.int64)
     np.cumsum(seq_len, out=out.seq_off[1:])
     n_bases = max(int(out.seq_off[-1]), 1)
-    oriented, iseq = np.empty(n_bases, np.uint8), np.empty(n_bases, np.int8)
-    fwd = np.empty(n_bases, np.uint8) if ref_anchored else None
+    oriented, iseq = _scratch("oriented", n_bases, np.uint8), np.empty(n_bases, np.int8)  # (oriented, fwd: copied into bytes below)
+    fwd = _scratch("fwd", n_bases, np.uint8) if ref_anchored else None
     rev_good = np.ascontiguousarray(is_rev[good], np.uint8)
     pq = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     L.check(L.lib().rmr_orient_bases(src_blob if src_blob else b"\0", pq(start), pq(seq_len), pq(rev_good), int(good.size), int(bool(ref_anchored)),
@@ -1823,6 +1861,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
         per_kept = np.zeros(nk, np.int64)
         per_kept[good] = seq_len
         np.cumsum(per_kept, out=out.ref_fwd_off[1:])
+    clock("orient_bases")
     # ---- scaling: sm / sd composed with the calibration (:2036-2041, :2147-2153), float64 as on the per-read path ----
     cal_off, cal_scale = signals._cal_off[uniq][inv][good].astype(np.float64), signals._cal_scale[uniq][inv][good].astype(np.float64)
     if pa_scaling is None:
@@ -1840,6 +1879,7 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     else:
         map_off = np.ascontiguousarray(rb.mv_off[gk], np.int64)
         sig_total = int(sig_len[good].sum())
+    clock("upload_mapping")
     dacs = torch.empty(max(sig_total, 1), dtype=torch.int16, device=dev)
     s2s = torch.empty(n_seq + n_good, dtype=torch.int64, device=dev)
     d_sig_off = torch.empty(n_good + 1, dtype=torch.int64, device=dev)
@@ -1849,8 +1889,10 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     ss = np.ascontiguousarray(src_start[good], np.int64)
     L.check(L.lib().rmr_assemble_reads(eng.handle, n_good, flat.data_ptr(), p(ss), d_q2s.data_ptr(), p(map_off), p(seq_len), dacs.data_ptr(),
                                        dacs.numel(), s2s.data_ptr(), d_sig_off.data_ptr(), d_seq_off.data_ptr(), p(sig_off)))
+    clock("assemble_launch")
     d_iseq = torch.from_numpy(iseq).to(dev)
     eng.synchronize()
+    clock("assemble_wait")
     from .engine import get_prep_engine
 
     # the batch is used on the extraction engine (own stream, own mutex): not behind the ingest of the next batches
