@@ -286,3 +286,34 @@ def test_batch_ingest_with_a_signal_mapping_refiner(scale_iters, tmp_path, monke
         stats.append(infer_from_pod5_and_bam(pod5, bam, model, md, out, reads_per_batch=5))
         outs.append(open(out, "rb").read())
     assert stats[0] == stats[1] and stats[0][None] == 14 and outs[0] == outs[1]
+
+
+def test_median_mad_scaling_from_gpu_histograms_equals_numpy_on_the_samples():
+    """io._median_mad_scaling (rmr_signal_histograms + float64 order statistics on the occupied bins) against
+    io.Read.compute_pa_to_norm_scaling's numpy on the samples themselves (src/remora/io.py:1851-1856) - equal, not close - on
+    synthetic spans: narrow ranges (counted in LDS), the full int16 range (more than 8192 bins: global atomics), one sample,
+    odd and even lengths, a constant signal (MAD 0 -> scale 1.0), spans that overlap, a negative calibration scale."""
+    import torch
+
+    from remora_amd import io as rio
+    from remora_amd.engine import get_ingest_engine
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    eng = get_ingest_engine(0)
+    rng = np.random.RandomState(5)
+    pieces = [rng.randint(300, 900, 50001), rng.randint(-32768, 32768, 70000), np.full(4000, 417), rng.randint(-5, 6, 1),
+              (rng.standard_normal(30000) * 90 + 500).astype(np.int64), rng.randint(-20000, 20000, 12345)]
+    flat_host = np.concatenate(pieces).astype(np.int16)
+    bounds = np.concatenate([[0], np.cumsum([p.size for p in pieces])])
+    start = list(bounds[:-1]) + [10, 50000, 60000]
+    length = [p.size for p in pieces] + [50000, 30001, 2]
+    cal_off = np.asarray([3.0, -241.0, 10.5, 0.0, -17.25, 100.0, 3.0, -1.5, 8.0])
+    cal_scale = np.asarray([0.17, 0.21, 0.5, 1.0, 0.125, -0.3, 0.17, 0.19, 0.2])
+    flat = torch.from_numpy(flat_host).to(eng.torch_device)
+    sm, sd = rio._median_mad_scaling(flat, np.asarray(start), np.asarray(length), cal_off, cal_scale, eng)
+    for i, (s0, n) in enumerate(zip(start, length)):
+        pa = (flat_host[s0 : s0 + n] - float(cal_off[i])) / float(cal_scale[i])
+        med = np.median(pa)
+        assert sm[i] == med, (i, sm[i], med)
+        assert sd[i] == max(1.0, np.median(np.abs(pa - med)) * rio.PA_TO_NORM_SCALING_FACTOR), i
+    assert sd[2] == 1.0 and sd[3] == 1.0
