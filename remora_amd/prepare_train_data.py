@@ -277,7 +277,17 @@ def count_reads(pod5_path, bam_path, skip_non_primary=True, shard=None):
     rank's share of the BAM only."""
     signals = rio.Pod5File(pod5_path)
     total = both = 0
-    for rb, _ in rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard, light=True):  # flags and names only
+    # the pass is bound by the inflate of the file: nothing else runs in this process yet, so every core it may use inflates
+    prev = os.environ.get("RMR_BAM_INFLATE_THREADS")
+    if prev is None:
+        os.environ["RMR_BAM_INFLATE_THREADS"] = str(max(8, min(16, rio._eff_cpus())))
+    batches = rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard, light=True)  # flags and names only
+    first = next(batches, None)  # (the reader reads the variable when it opens the file)
+    if prev is None:
+        os.environ.pop("RMR_BAM_INFLATE_THREADS", None)
+    import itertools
+
+    for rb, _ in itertools.chain([first] if first is not None else [], batches):
         keep = np.nonzero((rb.flag & 0x900) == 0)[0] if skip_non_primary else np.arange(rb.n)
         total += int(keep.size)
         has_pi = (rb.has & 64) != 0
