@@ -14,4 +14,4 @@ export RMR_BAM_LEVEL=1 RMR_INFER_TIMING=1
 ( timeout 900 python tests/manual/prof_infer_cli.py $REP 6,1 fp32 1 "--reference-anchored" ) 2>&1 | grep -E 'procs/gpu|infer rank 0|identical|records' > gpurun_out/${TAG}_infer_cli_ref_anchored.log
 ( timeout 900 python tests/manual/prof_prepare_cli.py $((REP / 2)) 1,6 ) 2>&1 | grep -v amdgpu | tail -12 > gpurun_out/${TAG}_prepare_cli.log
 ( RMR_PREPARE_BATCH_INGEST=0 timeout 900 python tests/manual/prof_prepare_cli.py $((REP / 8)) 1,6 ) 2>&1 | grep -v amdgpu | tail -4 > gpurun_out/${TAG}_prepare_cli_per_read.log
-tail -4 gpurun_out/${TAG}_infer_cli.log gpurun_out/${TAG}_infer_cli_zlib.log gpurun_out/${TAG}_infer_cli_ref_anchored.log gpurun_out/${TAG}_prepare_cli.log gpurun_out/${TAG}_prepare_cli_per_read.log
+tail -n 4 gpurun_out/${TAG}_infer_cli.log gpurun_out/${TAG}_infer_cli_zlib.log gpurun_out/${TAG}_infer_cli_ref_anchored.log gpurun_out/${TAG}_prepare_cli.log gpurun_out/${TAG}_prepare_cli_per_read.log
