@@ -231,12 +231,18 @@ def _pipelined_parts(parts, model, model_metadata, return_mod_probs):
                 pass
 
 
-def _subbatch_cuts(n, sub):
-    """[(start, stop)] of the sub-batches of a batch of n reads: two short ones first (the GPU starts after the staging of
+def _subbatch_cuts(n, sub, lead=None):
+    """[(start, stop)] of the sub-batches of a batch of n reads: short ones first (the GPU starts after the staging of
     `sub / 4` reads instead of `sub`), whole ones in the middle, and the rest in two tapering pieces - what is left to do when
-    the stager has finished is the work on the LAST sub-batch, so that one is small."""
+    the stager has finished is the work on the LAST sub-batch, so that one is small.  `lead`: sizes of the leading sub-batches
+    (default sub / 4, sub / 2; the 16-bit models, whose kernels outrun the staging, start on sub / 8:
+    profiles/r05_ab_reads_lead_cuts.log)."""
     cuts, pos = [], 0
-    for size in (max(1, sub // 4), max(1, sub // 2)):
+    env = os.environ.get("RMR_READS_LEAD_CUTS")  # (experiments: e.g. "64,192")
+    if env:
+        lead = [int(x) for x in env.split(",")]
+    for size in (lead or (sub // 4, sub // 2)):
+        size = max(1, int(size))
         if pos < n:
             cuts.append((pos, min(pos + size, n)))
             pos = cuts[-1][1]
@@ -256,7 +262,8 @@ def _subbatch_cuts(n, sub):
 def _call_reads_mods_pipelined(reads, sub, model, model_metadata, return_mod_probs):
     """One large batch through `_pipelined_parts`, cut into sub-batches by `_subbatch_cuts`."""
     out = []
-    for _, res in _pipelined_parts((reads[a:b] for a, b in _subbatch_cuts(len(reads), sub)), model, model_metadata, return_mod_probs):
+    lead = (sub // 8, sub // 4, sub // 2) if getattr(model, "dtype", "fp32") in ("bf16", "f16") else None
+    for _, res in _pipelined_parts((reads[a:b] for a, b in _subbatch_cuts(len(reads), sub, lead)), model, model_metadata, return_mod_probs):
         out.extend(res)
     return out
 

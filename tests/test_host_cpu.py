@@ -2714,6 +2714,10 @@ def test_subbatch_cuts_partition_a_batch_of_reads():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(b > a for a, b in cuts)
             assert max(b - a for a, b in cuts) <= max(sub, 1) + sub // 2
     assert [b - a for a, b in _subbatch_cuts(2048, 512)] == [128, 256, 512, 512, 384, 256]
+    assert [b - a for a, b in _subbatch_cuts(2048, 512, (64, 128, 256))] == [64, 128, 256, 512, 512, 346, 230]  # the 16-bit models' lead
+    for n in (0, 1, 63, 64, 65, 500, 2048, 5000):
+        cuts = _subbatch_cuts(n, 512, (64, 128, 256))
+        assert [a for a, _ in cuts] == [0] * bool(n) + [b for _, b in cuts][:-1] and (not n or cuts[-1][1] == n) and all(b > a for a, b in cuts)
 
 
 def test_built_library_has_no_packed_fp32_op_sel_on_lds_fed_registers():
