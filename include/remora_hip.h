@@ -93,7 +93,9 @@ typedef struct {
                            4 = f16: IEEE-half operands, fp32 accumulate, on the fused kernels (conv_lstm, size 64,
                            k-mer length 9 or 6; rmr_infer_chunks only) - the 16-bit pipeline with 10 mantissa bits;
                            5 = f16x3: operands split into two IEEE-half parts, three products (hi hi, hi lo, lo hi) on the
-                           half MFMA, fp32 accumulate - 22 significand bits (fp32 class) at bf16x3's cost */
+                           half MFMA, fp32 accumulate - 22 significand bits (fp32 class) at bf16x3's cost, in IEEE half's
+                           RANGE: an input or folded weight beyond +-65504 becomes infinity (NaN logits), values below
+                           2^-3 keep fewer than 22 bits (the low part is a half subnormal); bf16x6 has fp32's exponent range */
 } rmr_model_desc;
 
 /* `weights`: host fp32 blob, the torch state_dict tensors flattened in forward order —

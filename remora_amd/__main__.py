@@ -291,7 +291,8 @@ def main(argv=None):
     p.add_argument("--bam-level", type=int, default=None, help="zlib level of the output BAM (default 6, as htslib; 1 = fast: Huffman coding only, about a fifth larger, half the CPU time of zlib's level 1)")
     p.add_argument("--num-reads", type=int, default=None)
     p.add_argument("--reads-per-batch", type=int, default=512)
-    p.add_argument("--dtype", default=None, help="fp32 (default) | f16x3 | bf16x6 | bf16x3 | bf16 | f16")
+    p.add_argument("--dtype", default=None, help="fp32 (default) | f16x3 (fp32-class accuracy inside IEEE half's range: inputs and folded weights beyond +-65504 overflow) | "
+                        "bf16x6 (fp32 class, fp32 range) | bf16x3 | bf16 | f16")
     p.add_argument("--reference-anchored", action="store_true",
                    help="call at reference positions; output records become <len>M with the reference sequence")
     p.set_defaults(func=_infer)
