@@ -342,6 +342,12 @@ int rmr_motif_focus_fill(rmr_engine *e, const int8_t *int_seq, const int64_t *se
 int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
                    const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
                    int64_t *dst_maps, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads);
+/* The same gather with the mapping narrowed to int32 (dst_maps32, same offsets) - a seventh less to carry across PCIe; the
+ * caller widens it on the device.  *maps_fit = 0 when some mapping value does not fit int32 (the buffer's mapping is then
+ * not usable: gather again with rmr_pack_reads). */
+int rmr_pack_reads_narrow(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
+                          const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
+                          int32_t *dst_maps32, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads, int *maps_fit);
 
 /* The bases of selected records of a BAM batch in read orientation, back to back, with their integer codes (host code, native
  * threads).  Record i: src[start[i] .. start[i] + len[i]); `upper` != 0 folds ASCII lower case first; rev[i] != 0: reversed and

@@ -98,6 +98,7 @@ SIGNATURES = {
     "rmr_ref_anchor_batch": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rmr_pack_reads": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rmr_signal_histograms": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "rmr_pack_reads_narrow": (c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "rmr_orient_bases": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rmr_chunk_geometry": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, ctypes.POINTER(c_i64), c_int]),
     "rmr_chunk_fill": (c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int]),

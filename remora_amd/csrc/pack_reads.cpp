@@ -5,6 +5,7 @@
 // batch of 2048 x 5 kb reads took end to end.
 #include <emmintrin.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -65,14 +66,39 @@ void stream_copy(void *dst, const void *src, size_t n) {
     memcpy(d, s, n - blocks * 64);
 }
 
+
+// The mapping of a read as int32 (sample indices inside one read's signal: they fit whenever the signal has fewer than 2^31
+// samples - always, for int16 samples in memory): half the bytes of the int64 form on the way across PCIe, widened again on
+// the device.  Returns false when a value does not survive the narrowing (the caller then ships int64).
+bool narrow_i64_to_i32(const void *src, int64_t n, int32_t *dst) {
+    const int64_t *s = static_cast<const int64_t *>(src);
+    __m128i bad = _mm_setzero_si128();
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 2));
+        const __m128i lo = _mm_castps_si128(_mm_shuffle_ps(_mm_castsi128_ps(a), _mm_castsi128_ps(b), _MM_SHUFFLE(2, 0, 2, 0)));
+        const __m128i hi = _mm_castps_si128(_mm_shuffle_ps(_mm_castsi128_ps(a), _mm_castsi128_ps(b), _MM_SHUFFLE(3, 1, 3, 1)));
+        bad = _mm_or_si128(bad, _mm_xor_si128(hi, _mm_srai_epi32(lo, 31)));  // the high dword must be the sign of the low one
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), lo);
+    }
+    bool ok = _mm_movemask_epi8(_mm_cmpeq_epi32(bad, _mm_setzero_si128())) == 0xFFFF;
+    for (; i < n; ++i) {
+        dst[i] = (int32_t)s[i];
+        ok = ok && (int64_t)dst[i] == s[i];
+    }
+    return ok;
+}
+
 }  // namespace
 
-extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
-                              const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
-                              int64_t *dst_maps, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads) {
-    if (n_reads < 0 || !dacs || !sig_n || !maps || !seqs || !seq_n || !seq_itemsize || !dst_dacs || !dst_maps || !dst_seq ||
+static int pack_reads_impl(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
+                           const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
+                           int64_t *dst_maps, int32_t *dst_maps32, int *maps_fit, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off,
+                           int threads) {
+    if (n_reads < 0 || !dacs || !sig_n || !maps || !seqs || !seq_n || !seq_itemsize || !dst_dacs || (!dst_maps && !dst_maps32) || !dst_seq ||
         !sig_off || !seq_off)
         RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    std::atomic<int> fit{1};
     sig_off[0] = seq_off[0] = 0;
     for (int64_t i = 0; i < n_reads; ++i) {
         if (sig_n[i] < 0 || seq_n[i] < 0) RMR_FAIL(RMR_ERR_INVALID, "read %lld: negative size", (long long)i);
@@ -87,7 +113,11 @@ extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const in
     auto work = [&](int64_t r0, int64_t r1) {
         for (int64_t i = r0; i < r1; ++i) {
             stream_copy(dst_dacs + sig_off[i], dacs[i], (size_t)sig_n[i] * sizeof(int16_t));
-            stream_copy(dst_maps + seq_off[i] + i, maps[i], (size_t)(seq_n[i] + 1) * sizeof(int64_t));  // n + 1 entries per read
+            if (dst_maps32) {  // n + 1 entries per read
+                if (!narrow_i64_to_i32(maps[i], seq_n[i] + 1, dst_maps32 + seq_off[i] + i)) fit.store(0);
+            } else {
+                stream_copy(dst_maps + seq_off[i] + i, maps[i], (size_t)(seq_n[i] + 1) * sizeof(int64_t));
+            }
             int8_t *d = dst_seq + seq_off[i];
             switch (seq_itemsize[i]) {
                 case 1: memcpy(d, seqs[i], (size_t)seq_n[i]); break;
@@ -100,6 +130,7 @@ extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const in
     };
     if (threads == 1 || n_reads < 2 * threads) {
         work(0, n_reads);
+        if (maps_fit) *maps_fit = fit.load();
         return 0;
     }
     std::vector<std::thread> pool;
@@ -114,7 +145,24 @@ extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const in
         r0 = r1;
     }
     for (auto &th : pool) th.join();
+    if (maps_fit) *maps_fit = fit.load();
     return 0;
+}
+
+extern "C" int rmr_pack_reads(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
+                              const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
+                              int64_t *dst_maps, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads) {
+    if (!dst_maps) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    return pack_reads_impl(n_reads, dacs, sig_n, maps, seqs, seq_n, seq_itemsize, dst_dacs, dst_maps, nullptr, nullptr, dst_seq, sig_off, seq_off,
+                           threads);
+}
+
+extern "C" int rmr_pack_reads_narrow(int64_t n_reads, const void *const *dacs, const int64_t *sig_n, const void *const *maps,
+                                     const void *const *seqs, const int64_t *seq_n, const int32_t *seq_itemsize, int16_t *dst_dacs,
+                                     int32_t *dst_maps32, int8_t *dst_seq, int64_t *sig_off, int64_t *seq_off, int threads, int *maps_fit) {
+    if (!dst_maps32 || !maps_fit) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    return pack_reads_impl(n_reads, dacs, sig_n, maps, seqs, seq_n, seq_itemsize, dst_dacs, nullptr, dst_maps32, maps_fit, dst_seq, sig_off,
+                           seq_off, threads);
 }
 
 // The bases of the selected records of a BAM batch in read orientation, back to back, with their integer codes - what

@@ -341,11 +341,15 @@ class DeviceReads:
     and the chunk extraction.  All arrays travel in ONE pinned buffer / ONE copy (256-byte aligned segments);
     the device tensors are typed views of that allocation."""
 
-    def __init__(self, reads, engine=None, async_upload=False):
+    def __init__(self, reads, engine=None, async_upload=False, _narrow_maps=None):
         """`async_upload`: return once the copy is queued on the current torch stream (the staging buffer is one of two
         that take turns); whoever uses the arrays calls `wait_ready()` first.  Lets a staging thread gather batch k+1
-        while batch k is still crossing PCIe."""
+        while batch k is still crossing PCIe.
+        The mapping crosses PCIe as int32 (sample indices inside a read: a seventh of the batch's bytes less) and is widened to
+        the int64 of the rmr_reads layout by a cast queued behind the copy on the same stream; a batch with a value that does
+        not fit is gathered again as int64 (RMR_READS_NARROW_MAPS=0: always int64)."""
         torch = _torch()
+        narrow = (os.environ.get("RMR_READS_NARROW_MAPS", "1") != "0") if _narrow_maps is None else bool(_narrow_maps)
         self._ready = None
         self.engine = engine if engine is not None else get_engine()
         dev = self.engine.torch_device
@@ -357,7 +361,7 @@ class DeviceReads:
         np.cumsum(sig_n, out=self.sig_off[1:])
         np.cumsum(seq_n, out=self.seq_off[1:])
         n_sig, n_seq = int(self.sig_off[-1]), int(self.seq_off[-1])
-        segs = [("s2s", np.int64, n_seq + nr), ("d_sig_off", np.int64, nr + 1), ("d_seq_off", np.int64, nr + 1),
+        segs = [("s2s", np.int32 if narrow else np.int64, n_seq + nr), ("d_sig_off", np.int64, nr + 1), ("d_seq_off", np.int64, nr + 1),
                 ("shift", np.float64, nr), ("scale", np.float64, nr), ("dacs", np.int16, n_sig), ("iseq", np.int8, n_seq)]
         offs, total = {}, 0
         for name, dt, cnt in segs:
@@ -371,15 +375,31 @@ class DeviceReads:
         # sizes come from _collect_reads (C API walk; a per-read numpy slice copy cost 25-30 us, the interpreter's walk 5-8)
         lib = L.lib()
         so, qo = np.empty(nr + 1, np.int64), np.empty(nr + 1, np.int64)
-        L.check(lib.rmr_pack_reads(nr, p_d.ctypes.data, sig_n.ctypes.data, p_m.ctypes.data, p_s.ctypes.data, seq_n.ctypes.data,
-                                   isz.ctypes.data, view["dacs"].ctypes.data, view["s2s"].ctypes.data, view["iseq"].ctypes.data,
-                                   so.ctypes.data, qo.ctypes.data, int(os.environ.get("RMR_PACK_THREADS", "8"))))
+        if narrow:
+            fit = ctypes.c_int(1)
+            L.check(lib.rmr_pack_reads_narrow(nr, p_d.ctypes.data, sig_n.ctypes.data, p_m.ctypes.data, p_s.ctypes.data, seq_n.ctypes.data,
+                                              isz.ctypes.data, view["dacs"].ctypes.data, view["s2s"].ctypes.data, view["iseq"].ctypes.data,
+                                              so.ctypes.data, qo.ctypes.data, int(os.environ.get("RMR_PACK_THREADS", "8")), ctypes.byref(fit)))
+            if not fit.value:  # (the slot's previous upload was waited for above; nothing of this one is queued yet)
+                if ready is not None:
+                    _PINNED.turn["next"] = slot  # hand the slot back: the retry takes it again
+                    _PINNED.turn["events"].pop(slot, None)
+                self.__init__(reads, engine, async_upload, _narrow_maps=False)
+                return
+        else:
+            L.check(lib.rmr_pack_reads(nr, p_d.ctypes.data, sig_n.ctypes.data, p_m.ctypes.data, p_s.ctypes.data, seq_n.ctypes.data,
+                                       isz.ctypes.data, view["dacs"].ctypes.data, view["s2s"].ctypes.data, view["iseq"].ctypes.data,
+                                       so.ctypes.data, qo.ctypes.data, int(os.environ.get("RMR_PACK_THREADS", "8"))))
         del keep
         view["d_sig_off"][:] = self.sig_off
         view["d_seq_off"][:] = self.seq_off
         view["shift"][:] = shift
         view["scale"][:] = scale
         dbuf = buf[: max(total, 256)].to(dev, non_blocking=True)
+        s2s_wide = None
+        if narrow:  # widened on the stream of the copy, in front of the event / the wait below
+            nb32 = (n_seq + nr) * 4
+            s2s_wide = dbuf[offs["s2s"] : offs["s2s"] + nb32].view(torch.int32).to(torch.int64)
         if ready is not None:
             ready.record(torch.cuda.current_stream(dev))
             self._ready = ready
@@ -388,6 +408,8 @@ class DeviceReads:
         for name, dt, cnt in segs:
             nbytes = cnt * np.dtype(dt).itemsize
             setattr(self, name, dbuf[offs[name] : offs[name] + nbytes].view(getattr(torch, np.dtype(dt).name)))
+        if s2s_wide is not None:
+            self.s2s = s2s_wide
 
     @classmethod
     def from_device(cls, engine, sig_off, seq_off, dacs, s2s, iseq, d_sig_off, d_seq_off, shift, scale):

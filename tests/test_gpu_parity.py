@@ -1619,3 +1619,41 @@ def test_library_can_be_touched_before_torch(torch_cuda):
             "get_engine().synchronize(); print('ok', n)\n") % (root, os.path.join(root, "tests", "golden", "data", "can_mappings.bam"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok 14", r.stderr[-1500:]
+
+
+def test_device_reads_mapping_crosses_pcie_as_int32_and_arrives_as_int64(torch_cuda, monkeypatch):
+    """DeviceReads ships the mapping as int32 and widens it on the device (rmr_pack_reads_narrow + a cast behind the copy): the
+    resident arrays equal the reads' own, synchronous and asynchronous upload; a batch with a mapping value beyond int32 is
+    gathered again as int64 (also from the asynchronous path, whose staging slot it hands back); RMR_READS_NARROW_MAPS=0
+    ships int64 from the start."""
+    from remora_amd.data_chunks import DeviceReads, RemoraRead
+
+    rng = np.random.default_rng(3)
+
+    def batch(big=None):
+        reads = []
+        for i, n in enumerate((300, 1, 2, 77, 1200)):
+            m = np.concatenate([[0], np.cumsum(rng.integers(1, 9, n))]).astype(np.int64)
+            if big is not None and i == 3:
+                m[-1] = big
+            reads.append(RemoraRead(dacs=rng.integers(-900, 900, 20 + int(min(m[-1], 20000))).astype(np.int16), shift=1.5, scale=2.0,
+                                    seq_to_sig_map=m, int_seq=rng.integers(0, 4, n).astype(np.int64)))
+        return reads
+
+    def check(dr, reads):
+        dr.wait_ready()
+        torch_cuda.cuda.synchronize()
+        assert dr.s2s.dtype == torch_cuda.int64
+        assert np.array_equal(dr.s2s.cpu().numpy(), np.concatenate([r.seq_to_sig_map for r in reads]))
+        assert np.array_equal(dr.dacs.cpu().numpy(), np.concatenate([r.dacs for r in reads]))
+        assert np.array_equal(dr.iseq.cpu().numpy(), np.concatenate([r.int_seq for r in reads]).astype(np.int8))
+        assert np.array_equal(dr.d_seq_off.cpu().numpy(), dr.seq_off)
+
+    for big in (None, (1 << 31) + 5, -(1 << 31) - 1):
+        reads = batch(big)
+        check(DeviceReads(reads), reads)
+        for _ in range(3):  # the two staging slots take turns; a retry must not leave one of them lost
+            check(DeviceReads(reads, async_upload=True), reads)
+    monkeypatch.setenv("RMR_READS_NARROW_MAPS", "0")
+    reads = batch()
+    check(DeviceReads(reads), reads)

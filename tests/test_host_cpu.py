@@ -1595,6 +1595,25 @@ def test_pack_reads_native_gather_equals_numpy():
     bad[3] = 3
     assert lib.rmr_pack_reads(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, bad.ctypes.data, dacs.ctypes.data,
                               maps.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, 2) != 0
+    # the narrow form: the mapping as int32 at the same offsets, and the flag when a value does not fit
+    for threads in (1, 5):
+        maps32 = np.full(int(seq_n.sum()) + nr + 1, -5, np.int32)
+        fit = ctypes.c_int(-1)
+        L.check(lib.rmr_pack_reads_narrow(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, isz.ctypes.data, dacs.ctypes.data,
+                                          maps32.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, threads, ctypes.byref(fit)))
+        assert fit.value == 1 and np.array_equal(maps32[:-1], np.concatenate([r[1] for r in reads])) and maps32[-1] == -5
+        assert np.array_equal(dacs[:-1], np.concatenate([r[0] for r in reads]))
+    for where, value in ((0, 1 << 31), (-1, -(1 << 31) - 1), (2, 1 << 40)):
+        keep = reads[20][1][where]
+        reads[20][1][where] = value
+        L.check(lib.rmr_pack_reads_narrow(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, isz.ctypes.data, dacs.ctypes.data,
+                                          maps32.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, 3, ctypes.byref(fit)))
+        assert fit.value == 0, (where, value)
+        reads[20][1][where] = keep
+    reads[20][1][0] = -(1 << 31)  # the smallest value that fits
+    L.check(lib.rmr_pack_reads_narrow(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, isz.ctypes.data, dacs.ctypes.data,
+                                      maps32.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, 3, ctypes.byref(fit)))
+    assert fit.value == 1 and maps32[qo[20] + 20] == -(1 << 31)
 
 
 def test_format_mm_ml_tags_equals_oracle_on_random_reads(O):
