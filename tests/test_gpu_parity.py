@@ -1636,7 +1636,7 @@ def test_device_reads_mapping_crosses_pcie_as_int32_and_arrives_as_int64(torch_c
             m = np.concatenate([[0], np.cumsum(rng.integers(1, 9, n))]).astype(np.int64)
             if big is not None and i == 3:
                 m[-1] = big
-            reads.append(RemoraRead(dacs=rng.integers(-900, 900, 20 + int(min(m[-1], 20000))).astype(np.int16), shift=1.5, scale=2.0,
+            reads.append(RemoraRead(dacs=rng.integers(-900, 900, 20 + int(min(max(m[-1], 0), 20000))).astype(np.int16), shift=1.5, scale=2.0,
                                     seq_to_sig_map=m, int_seq=rng.integers(0, 4, n).astype(np.int64)))
         return reads
 
