@@ -3023,3 +3023,18 @@ def test_weighted_median_is_numpys_median_of_the_expanded_array():
         pv = (vals - off) / sc
         got = rio._weighted_median(pv, cnt)
         assert got == med and rio._weighted_median(np.abs(pv - got), cnt) == mad
+
+
+def test_count_reads_shares_add_up_to_the_file():
+    """prepare's counting pass (identifiers-only BAM batches, every core inflating) over the ranks' shares of a BAM: the shares
+    are disjoint and complete for any world size, with and without the primary filter (get_read_ids, src/remora/io.py:362-391)."""
+    from remora_amd import prepare_train_data as p
+
+    for stem in ("can", "mod"):
+        pod5, bam = os.path.join(DATA, f"{stem}_reads.pod5"), os.path.join(DATA, f"{stem}_mappings.bam")
+        whole = p.count_reads(pod5, bam)
+        assert whole == (14, 14) and p.count_reads(pod5, bam, skip_non_primary=False) == (14, 14)
+        for world in (2, 3, 5, 16):
+            parts = [p.count_reads(pod5, bam, shard=(r, world)) for r in range(world)]
+            assert (sum(x[0] for x in parts), sum(x[1] for x in parts)) == whole, (world, parts)
+    assert "RMR_BAM_INFLATE_THREADS" not in os.environ  # the pass hands the variable back
