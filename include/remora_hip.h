@@ -201,6 +201,11 @@ typedef struct rmr_bam_batch {
     const int64_t *voffset;                            /* [n] BGZF virtual offset of the record (for rmr_bam_seek) */
 } rmr_bam_batch;
 int rmr_bam_open(const char *path, rmr_bam **out);
+/* the same with the number of BGZF inflate workers of this handle given by the caller (>= 1; 0 = rmr_bam_open's default:
+ * RMR_BAM_INFLATE_THREADS, else 8) - a caller that sizes its thread pools per rank passes the count instead of setting
+ * an environment variable in a process whose native threads read the environment (pysam's `threads=` of
+ * AlignmentFile, src/remora/io.py:236) */
+int rmr_bam_open_threads(const char *path, int inflate_threads, rmr_bam **out);
 void rmr_bam_close(rmr_bam *b);
 /* everything before the first record (magic, header text, reference dictionary), uncompressed */
 int rmr_bam_header(rmr_bam *b, const uint8_t **bytes, int64_t *n_bytes, int64_t *n_refs);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "rmr_parse_moves_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int]),
     "rmr_assemble_reads": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rmr_bam_open": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "rmr_bam_open_threads": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_vp)]),
     "rmr_bam_close": (None, [c_vp]),
     "rmr_bam_header": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "rmr_bam_ref_name": (ctypes.c_char_p, [c_vp, c_i64]),

@@ -492,12 +492,16 @@ void stop_workers(rmr_bam *b) {
 
 extern "C" {
 
-int rmr_bam_open(const char *path, rmr_bam **out) {
+int rmr_bam_open(const char *path, rmr_bam **out) { return rmr_bam_open_threads(path, 0, out); }
+
+int rmr_bam_open_threads(const char *path, int inflate_threads, rmr_bam **out) {
     if (!path || !out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
     std::unique_ptr<rmr_bam> b(new rmr_bam());
     b->fh = fopen(path, "rb");
     if (!b->fh) RMR_FAIL(RMR_ERR_INVALID, "cannot open %s", path);
-    if (const char *ev = getenv("RMR_BAM_INFLATE_THREADS")) {
+    if (inflate_threads >= 1) {
+        b->nslots = inflate_threads > rmr_bam::kSlots ? rmr_bam::kSlots : inflate_threads;
+    } else if (const char *ev = getenv("RMR_BAM_INFLATE_THREADS")) {
         const int v = atoi(ev);
         if (v >= 1) b->nslots = v > rmr_bam::kSlots ? rmr_bam::kSlots : v;
     }

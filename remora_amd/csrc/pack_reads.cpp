@@ -3,7 +3,9 @@
 // few native threads.  The reference has no counterpart (it processes reads one at a time in Python,
 // src/remora/inference.py:62-137); in this engine the per-read Python copies of this step were 55 of the 83 ms that a
 // batch of 2048 x 5 kb reads took end to end.
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 #include <atomic>
 #include <cstdlib>
@@ -22,22 +24,33 @@ void narrow_to_i8(const void *src, int64_t n, int8_t *dst) {
 }
 
 // int64 bases (what util.seq_to_int and the reference hand over: 8 bytes a base) -> int8, sixteen at a time: the low dwords of
-// eight 16-byte loads, then the two saturating packs (base codes are -1..3; anything wider is clamped instead of wrapped,
-// and refused downstream either way).  The scalar loop cost 5 us per 5 kb read - more than the copy of its 100 KB of signal.
+// eight 16-byte loads, then the two saturating packs.  Base codes are -1..3; a value outside int8 must not become a valid
+// code: the packs clamp whatever fits in 32 bits to -128 / 127, and a value whose HIGH dword is not the sign extension of its
+// low dword (|v| >= 2^31, which the low dword alone would wrap - 2^32 + 1 -> 1) is forced to 127 / -128 by its sign as well; the scalar tail
+// clamps the same way.  Everything outside -1..3 is refused downstream (RemoraRead.check's message).  The scalar loop cost
+// 5 us per 5 kb read - more than the copy of its 100 KB of signal.
+inline int8_t clamp_i64_to_i8(int64_t v) { return (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v)); }
 void narrow_i64_to_i8(const void *src, int64_t n, int8_t *dst) {
     const int64_t *s = static_cast<const int64_t *>(src);
     int64_t i = 0;
+#if defined(__SSE2__)
     for (; i + 16 <= n; i += 16) {
         __m128i d[4];
         for (int k = 0; k < 4; ++k) {
             const __m128 a = _mm_castsi128_ps(_mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 4 * k)));
             const __m128 b = _mm_castsi128_ps(_mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 4 * k + 2)));
-            d[k] = _mm_castps_si128(_mm_shuffle_ps(a, b, _MM_SHUFFLE(2, 0, 2, 0)));  // low dwords of four int64: exact for |v| < 2^31
+            const __m128i lo = _mm_castps_si128(_mm_shuffle_ps(a, b, _MM_SHUFFLE(2, 0, 2, 0)));  // low dwords of four int64
+            const __m128i hi = _mm_castps_si128(_mm_shuffle_ps(a, b, _MM_SHUFFLE(3, 1, 3, 1)));  // their high dwords
+            const __m128i wide = _mm_xor_si128(hi, _mm_srai_epi32(lo, 31));  // non-zero where hi is not lo's sign extension
+            const __m128i fits = _mm_cmpeq_epi32(wide, _mm_setzero_si128());
+            const __m128i sat = _mm_xor_si128(_mm_set1_epi32(0x7fff), _mm_srai_epi32(hi, 31));  // 32767 or -32768 by the value's sign
+            d[k] = _mm_or_si128(_mm_and_si128(fits, lo), _mm_andnot_si128(fits, sat));
         }
         const __m128i w0 = _mm_packs_epi32(d[0], d[1]), w1 = _mm_packs_epi32(d[2], d[3]);
         _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), _mm_packs_epi16(w0, w1));
     }
-    for (; i < n; ++i) dst[i] = (int8_t)s[i];
+#endif
+    for (; i < n; ++i) dst[i] = clamp_i64_to_i8(s[i]);
 }
 
 // Copy into the pinned staging buffer with streaming stores: the destination is written once and next read by the GPU's DMA
@@ -47,6 +60,10 @@ void stream_copy(void *dst, const void *src, size_t n) {
     char *d = static_cast<char *>(dst);
     const char *s = static_cast<const char *>(src);
     static const bool stream = !(getenv("RMR_PACK_STREAM") && atoi(getenv("RMR_PACK_STREAM")) == 0);  // 0: plain memcpy (A/B)
+#if !defined(__SSE2__)
+    memcpy(d, s, n);  // no streaming stores on this host: the plain copy
+    return;
+#else
     if (n < 2048 || !stream) {
         memcpy(d, s, n);
         return;
@@ -64,6 +81,7 @@ void stream_copy(void *dst, const void *src, size_t n) {
         _mm_stream_si128(reinterpret_cast<__m128i *>(d + 48), e);
     }
     memcpy(d, s, n - blocks * 64);
+#endif
 }
 
 
@@ -72,8 +90,10 @@ void stream_copy(void *dst, const void *src, size_t n) {
 // the device.  Returns false when a value does not survive the narrowing (the caller then ships int64).
 bool narrow_i64_to_i32(const void *src, int64_t n, int32_t *dst) {
     const int64_t *s = static_cast<const int64_t *>(src);
-    __m128i bad = _mm_setzero_si128();
     int64_t i = 0;
+    bool ok = true;
+#if defined(__SSE2__)
+    __m128i bad = _mm_setzero_si128();
     for (; i + 4 <= n; i += 4) {
         const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 2));
         const __m128i lo = _mm_castps_si128(_mm_shuffle_ps(_mm_castsi128_ps(a), _mm_castsi128_ps(b), _MM_SHUFFLE(2, 0, 2, 0)));
@@ -81,7 +101,8 @@ bool narrow_i64_to_i32(const void *src, int64_t n, int32_t *dst) {
         bad = _mm_or_si128(bad, _mm_xor_si128(hi, _mm_srai_epi32(lo, 31)));  // the high dword must be the sign of the low one
         _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), lo);
     }
-    bool ok = _mm_movemask_epi8(_mm_cmpeq_epi32(bad, _mm_setzero_si128())) == 0xFFFF;
+    ok = _mm_movemask_epi8(_mm_cmpeq_epi32(bad, _mm_setzero_si128())) == 0xFFFF;
+#endif
     for (; i < n; ++i) {
         dst[i] = (int32_t)s[i];
         ok = ok && (int64_t)dst[i] == s[i];

@@ -23,9 +23,16 @@ static int int_format(const char *f, Py_ssize_t itemsize, const char *allowed) {
 /* Returns the number of reads collected (= n) on success; -2 when a read's arrays are not in the layout the native gather
  * takes as it is (int16 C-contiguous dacs, int64 C-contiguous mapping of n_bases + 1 entries, integer C-contiguous bases):
  * the caller then walks the batch in Python, which converts or refuses with the reference's messages; -1 with a Python
- * exception set (not a sequence, missing attribute). */
+ * exception set (not a sequence, missing attribute).
+ * `keep` (a list): every attribute object whose buffer address is handed back is appended to it - the CALLER holds that list
+ * until rmr_pack_reads has copied from the addresses, so an array that a property computed for this call, or that another
+ * thread replaces on the read meanwhile, stays alive (the buffer itself is released here: numpy arrays do not move). */
 int64_t rmr_py_collect_reads(PyObject *reads, int64_t n, void **p_dacs, int64_t *sig_n, void **p_maps, void **p_seqs,
-                             int64_t *seq_n, int32_t *seq_itemsize, double *shift, double *scale) {
+                             int64_t *seq_n, int32_t *seq_itemsize, double *shift, double *scale, PyObject *keep) {
+    if (!keep || !PyList_Check(keep)) {
+        PyErr_SetString(PyExc_TypeError, "rmr_py_collect_reads: keep must be a list");
+        return -1;
+    }
     static PyObject *s_dacs, *s_map, *s_seq, *s_shift, *s_scale;
     if (!s_dacs) {
         s_dacs = PyUnicode_InternFromString("dacs");
@@ -60,7 +67,8 @@ int64_t rmr_py_collect_reads(PyObject *reads, int64_t n, void **p_dacs, int64_t 
                 ptr[k] = v.buf;
                 isz[k] = v.itemsize;
                 count[k] = v.itemsize ? v.len / v.itemsize : 0;
-                PyBuffer_Release(&v); /* the array stays alive through the read the caller holds */
+                PyBuffer_Release(&v);
+                if (rc == n && PyList_Append(keep, a) != 0) rc = -1; /* ownership of the array travels with its address */
             }
             Py_DECREF(a);
         }

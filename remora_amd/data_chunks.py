@@ -229,7 +229,7 @@ def _glue():
             raise RemoraError(f"{path} not found - build it first: python -c 'import __graft_entry__ as g; g.build()'")
         g = ctypes.PyDLL(path)
         g.rmr_py_collect_reads.restype = ctypes.c_int64
-        g.rmr_py_collect_reads.argtypes = [ctypes.py_object, ctypes.c_int64] + [ctypes.c_void_p] * 8
+        g.rmr_py_collect_reads.argtypes = [ctypes.py_object, ctypes.c_int64] + [ctypes.c_void_p] * 8 + [ctypes.py_object]
         _GLUE = g
     return _GLUE
 
@@ -314,11 +314,12 @@ def _collect_reads(reads):
     sig_n, seq_n, isz = np.empty(nr, np.int64), np.empty(nr, np.int64), np.empty(nr, np.int32)
     shift, scale = np.empty(nr, np.float64), np.empty(nr, np.float64)
     if nr and os.environ.get("RMR_PY_GLUE", "1") != "0":
+        keep = []  # the glue appends every array whose address it hands back: owned here until the gather has copied from it
         got = _glue().rmr_py_collect_reads(reads if isinstance(reads, (list, tuple)) else list(reads), nr, p_d.ctypes.data,
                                            sig_n.ctypes.data, p_m.ctypes.data, p_s.ctypes.data, seq_n.ctypes.data, isz.ctypes.data,
-                                           shift.ctypes.data, scale.ctypes.data)
+                                           shift.ctypes.data, scale.ctypes.data, keep)
         if got == nr:
-            return p_d, sig_n, p_m, p_s, seq_n, isz, shift, scale, None
+            return p_d, sig_n, p_m, p_s, seq_n, isz, shift, scale, keep
     keep = []
     for i, r in enumerate(reads):
         if r.seq_to_sig_map.size != r.int_seq.size + 1:

@@ -10,6 +10,8 @@ import numpy as np
 
 
 LAST_BINDING = None  # what bind_rank did for this process (setup_ranks / bench.py), for reports
+_HOST_GROUP = None  # gloo side channel beside an nccl (= RCCL) default group: agreement on failures, and the fallback transport
+_FALLBACK = None  # why the collectives of this process run over the gloo side channel instead of RCCL (None: they do not)
 
 
 def env_rank_world():
@@ -27,6 +29,36 @@ def _collective():
     import torch.distributed as dist
 
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_forced())
+
+
+def _on_device():
+    """True when the collectives of this process move DEVICE tensors through RCCL; False for gloo (tests, shared GPUs) and
+    after `first_collective_ms` found that RCCL does not work on this node (every rank then uses the gloo side channel)."""
+    import torch.distributed as dist
+
+    return dist.get_backend() == "nccl" and _FALLBACK is None
+
+
+def _group():
+    """The process group the helpers talk to: the default one, or the gloo side channel after an RCCL failure."""
+    return _HOST_GROUP if _FALLBACK is not None else None
+
+
+def note_fallback(reason):
+    """Record that this process's collectives run over gloo because RCCL could not be used (`reason`), for `transport()`."""
+    global _FALLBACK
+    _FALLBACK = str(reason)
+
+
+def transport():
+    """What carries this process's collectives, for reports: 'nccl', 'gloo', 'gloo (RCCL failed: ...)' or None."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if _FALLBACK is not None:
+        return f"gloo (RCCL failed: {_FALLBACK})"
+    return str(dist.get_backend())
 
 
 def shard_range(n, rank, world):
@@ -60,7 +92,22 @@ def init_process_group(backend=None, set_device=True, timeout_s=None):
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
         kw = {"timeout": datetime.timedelta(seconds=float(timeout_s))} if timeout_s else {}
+        if backend == "nccl":
+            # a collective that cannot complete raises in the caller after the timeout (instead of the watchdog taking the
+            # process down): first_collective_ms turns that into the gloo fallback
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost") and os.path.isdir("/sys/class/net/lo"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: never resolve the container's hostname
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        global _HOST_GROUP
+        if backend == "nccl" and world > 1 and _HOST_GROUP is None and os.environ.get("REMORA_AMD_DIST_SIDE_CHANNEL", "1") != "0":
+            try:  # rendezvous over the store only: no RCCL traffic
+                _HOST_GROUP = dist.new_group(backend="gloo", **kw)
+            except Exception as e:  # noqa: BLE001 - without it a failing RCCL is simply a failed run, as before
+                import sys
+
+                print(f"[remora_amd.dist] no gloo side channel: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                _HOST_GROUP = None
     return rank, world, local
 
 
@@ -74,15 +121,37 @@ def first_collective_ms():
 
     if not _collective():
         return 0.0
-    t = torch.ones(1, dtype=torch.int64)
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
+    global _FALLBACK
     t0 = time.perf_counter()
-    dist.all_reduce(t)
-    if t.is_cuda:
-        torch.cuda.synchronize()
-    if int(t.item()) != dist.get_world_size():
-        raise RuntimeError(f"first all-reduce returned {int(t.item())}, expected the world size {dist.get_world_size()}")
+    err = None
+    try:
+        if os.environ.get("REMORA_AMD_DIST_FAIL_FIRST") == "1" and dist.get_backend() == "nccl":  # tests: the fallback below
+            raise RuntimeError("REMORA_AMD_DIST_FAIL_FIRST")
+        t = torch.ones(1, dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        if int(t.item()) != dist.get_world_size():
+            raise RuntimeError(f"first all-reduce returned {int(t.item())}, expected the world size {dist.get_world_size()}")
+    except Exception as e:  # noqa: BLE001
+        if _HOST_GROUP is None:
+            raise
+        err = f"{type(e).__name__}: {str(e).splitlines()[0][:200] if str(e) else ''}"
+    if _HOST_GROUP is not None:
+        # every rank learns whether RCCL worked for ALL of them: one failed rank moves the whole job onto the side channel
+        ok = torch.tensor([0 if err else 1], dtype=torch.int64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=_HOST_GROUP)
+        if int(ok.item()) == 0:
+            reasons = [None] * dist.get_world_size()
+            dist.all_gather_object(reasons, err, group=_HOST_GROUP)
+            _FALLBACK = next((f"rank {i}: {r}" for i, r in enumerate(reasons) if r), "unknown")
+            import sys
+
+            if dist.get_rank() == 0:
+                print(f"[remora_amd.dist] RCCL did not complete its first all-reduce ({_FALLBACK}); the collectives of this run "
+                      f"(int64 label counts, clocks) go over gloo instead", file=sys.stderr, flush=True)
     return (time.perf_counter() - t0) * 1e3
 
 
@@ -94,10 +163,10 @@ def allgather_floats(xs):
     t = torch.tensor([float(x) for x in xs], dtype=torch.float64)
     if not _collective():
         return t.numpy()[None, :].copy()
-    if dist.get_backend() == "nccl":
+    if _on_device():
         t = t.cuda()
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
+    dist.all_gather(out, t, group=_group())
     return torch.stack(out).cpu().numpy()
 
 
@@ -128,8 +197,10 @@ def launch_ranks(argv, n, scan_bam=None, command=None):
     from .util import effective_cpu_count
 
     per_rank = str(max(2, min(8, effective_cpu_count() // max(n, 1))))
-    env.setdefault("OMP_NUM_THREADS", per_rank)
-    env.setdefault("RMR_PACK_THREADS", per_rank)
+    sized = [v for v in ("OMP_NUM_THREADS", "RMR_PACK_THREADS") if v not in env]
+    for v in sized:
+        env[v] = per_rank
+    env["REMORA_AMD_LAUNCHER_SIZED"] = ",".join(sized)  # bind_rank may refine these, never a value the user gave
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     scan_path = None
     if scan_bam is not None:
@@ -287,10 +358,16 @@ def bind_rank(device, local_rank=None, local_world=None, procs_per_gpu=1, sysfs=
             except OSError:
                 pass
             me["bound"] = True
-        # the thread pools read these when they are created / per call; the launcher's values were sized without the topology
-        os.environ["OMP_NUM_THREADS"] = os.environ["RMR_PACK_THREADS"] = str(me["threads"])
+        # the thread pools read these when they are created / per call.  A value the USER set stays (launch_ranks marks the
+        # ones it sized itself, without the topology, in REMORA_AMD_LAUNCHER_SIZED: those are replaced by the plan's)
+        sized = set(os.environ.get("REMORA_AMD_LAUNCHER_SIZED", "").split(","))
+        if "TORCHELASTIC_RUN_ID" in os.environ and os.environ.get("OMP_NUM_THREADS") == "1":
+            sized.add("OMP_NUM_THREADS")  # torch.distributed.run's own default for a variable nobody set
+        for var in ("OMP_NUM_THREADS", "RMR_PACK_THREADS"):
+            if var not in os.environ or var in sized:
+                os.environ[var] = str(me["threads"])
         try:
-            torch.set_num_threads(me["threads"])
+            torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
         except Exception:  # noqa: BLE001
             pass
         return me
@@ -339,7 +416,7 @@ def barrier():
     import torch.distributed as dist
 
     if _collective():
-        dist.barrier()
+        dist.barrier(group=_group())
 
 
 def gather_objects(obj):
@@ -350,7 +427,7 @@ def gather_objects(obj):
     if not _collective():
         return [obj]
     out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, obj)
+    dist.all_gather_object(out, obj, group=_group())
     return out
 
 
@@ -362,11 +439,11 @@ def gather_arrays(arr):
     arr = np.ascontiguousarray(arr)
     if not _collective():
         return arr
-    on_gpu = dist.get_backend() == "nccl"
+    on_gpu = _on_device()
     n = torch.tensor([arr.shape[0]], dtype=torch.int64)
     n = n.cuda() if on_gpu else n
     sizes = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
-    dist.all_gather(sizes, n)
+    dist.all_gather(sizes, n, group=_group())
     sizes = [int(x.item()) for x in sizes]
     width = max(sizes)
     pad = np.zeros((width,) + arr.shape[1:], arr.dtype)
@@ -374,7 +451,7 @@ def gather_arrays(arr):
     t = torch.from_numpy(pad)
     t = t.cuda() if on_gpu else t
     parts = [torch.empty_like(t) for _ in sizes]
-    dist.all_gather(parts, t)
+    dist.all_gather(parts, t, group=_group())
     return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, sizes)], axis=0)
 
 
@@ -388,16 +465,16 @@ def allreduce_counts(counts):
         return counts
     if isinstance(counts, np.ndarray):
         t = torch.from_numpy(np.ascontiguousarray(counts, np.int64))
-        if dist.get_backend() == "nccl":
+        if _on_device():
             t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group())
         return t.cpu().numpy()
-    if counts.is_cuda and dist.get_backend() != "nccl":  # gloo (tests): reduce through the host
+    if counts.is_cuda and not _on_device():  # gloo (tests, shared GPUs, RCCL fallback): reduce through the host
         t = counts.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group())
         counts.copy_(t)
         return counts
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=_group())
     return counts
 
 
@@ -409,9 +486,9 @@ def allreduce_max_float(x):
     if not _collective():
         return float(x)
     t = torch.tensor([float(x)], dtype=torch.float64)
-    if dist.get_backend() == "nccl":
+    if _on_device():
         t = t.cuda()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_group())
     return float(t.item())
 
 
@@ -424,12 +501,12 @@ def allgather_counts(counts):
     t = counts if hasattr(counts, "is_cuda") else torch.from_numpy(np.ascontiguousarray(counts, np.int64))
     if not _collective():
         return t.detach().cpu().numpy()[None, :].copy()
-    if dist.get_backend() == "nccl":
+    if _on_device():
         t = t.cuda() if not t.is_cuda else t
     else:
         t = t.cpu()
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t.contiguous())
+    dist.all_gather(out, t.contiguous(), group=_group())
     return torch.stack(out).cpu().numpy()
 
 
@@ -455,9 +532,9 @@ def init_cabi_comm(engine, rank=None, world=None):
         L.check(lib.rmr_comm_unique_id(ident))
     if world > 1:
         t = torch.tensor(list(ident), dtype=torch.uint8)
-        if dist.get_backend() == "nccl":
+        if _on_device():
             t = t.to(engine.torch_device)  # the rank's own GPU (the current device is per thread)
-        dist.broadcast(t, src=0)
+        dist.broadcast(t, src=0, group=_group())
         ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
     L.check(lib.rmr_comm_init(engine.handle, ident, int(rank), int(world)))
     return True
@@ -487,8 +564,8 @@ def cabi_allreduce_check(engine, per_rank, rank, world, timeout_s=60.0):
     import torch
     import torch.distributed as dist
 
-    if world > 1 and (not dist.is_initialized() or dist.get_backend() != "nccl"):
-        return {"status": "skipped", "reason": "ranks do not own distinct GPUs (backend is not nccl)"}
+    if world > 1 and (not dist.is_initialized() or not _on_device()):
+        return {"status": "skipped", "reason": f"ranks do not talk RCCL (transport: {transport()})"}
     res = {}
 
     def work():

@@ -380,6 +380,9 @@ def _verify_share_mark(bam_path, mark, file_offset, back=1 << 20):
             break
         probe = None
     if probe is None:
+        if file_offset <= (back << 6):
+            return  # a small file whose first record cannot be guessed either: nothing independent to chain from (the rank in
+            # front verifies the boundary when it gets there, which stays the authoritative check)
         raise RemoraError(f"{bam_path}: no record start found within {back << 6} bytes in front of the share boundary at byte "
                           f"{file_offset} - REMORA_AMD_BAM_SHARD=scan splits by an exact pass over the file instead")
     if probe == mark:
@@ -402,14 +405,15 @@ def _verify_share_mark(bam_path, mark, file_offset, back=1 << 20):
         lib.rmr_bam_close(h)
 
 
-def bam_scan(bam_path, every=64):
+def bam_scan(bam_path, every=64, inflate_threads=0):
     """(marks, n_records): the BGZF virtual offset of records 0, every, 2 every, ... of `bam_path` and the number of
-    records.  One light pass over the file (rmr_bam_scan: BGZF inflate + the block_size fields)."""
+    records.  One light pass over the file (rmr_bam_scan: BGZF inflate + the block_size fields).  `inflate_threads`: BGZF
+    inflate workers of the pass (0 = the reader's default)."""
     lib = L.lib()
     cap = 1 << 16
     while True:  # rmr_bam_open leaves the handle at the first record
         h = ctypes.c_void_p()
-        L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+        L.check(lib.rmr_bam_open_threads(str(bam_path).encode(), int(inflate_threads), ctypes.byref(h)))
         try:
             marks = np.empty(cap, np.int64)
             n = ctypes.c_int64()
@@ -435,17 +439,14 @@ def write_bam_scan(bam_path, out_path, every=64):
     through REMORA_AMD_BAM_SCAN).  The file appears atomically; a scan that fails leaves a marker instead, and the ranks
     scan for themselves (and report the error in their own words)."""
     tmp = f"{out_path}.tmp{os.getpid()}"
-    prev = os.environ.get("RMR_BAM_INFLATE_THREADS")
     try:
-        if prev is None:  # this process has nothing else to do while its ranks start: every core it may use inflates
-            os.environ["RMR_BAM_INFLATE_THREADS"] = str(max(8, min(32, _eff_cpus())))
-        marks, n = bam_scan(bam_path, every)
+        # this process has nothing else to do while its ranks start: every core it may use inflates (unless the user said
+        # how many: RMR_BAM_INFLATE_THREADS, which the reader reads for a count of 0)
+        threads = 0 if os.environ.get("RMR_BAM_INFLATE_THREADS") else max(8, min(32, _eff_cpus()))
+        marks, n = bam_scan(bam_path, every, inflate_threads=threads)
         payload = dict(key=_scan_key(bam_path, every), marks=marks, n=np.int64(n))
     except Exception:  # noqa: BLE001 - whatever it is, the ranks will meet it themselves
         payload = dict(key=np.zeros(3, np.int64), marks=np.zeros(0, np.int64), n=np.int64(-1))
-    finally:
-        if prev is None:
-            os.environ.pop("RMR_BAM_INFLATE_THREADS", None)
     with open(tmp, "wb") as fh:
         np.savez(fh, **payload)
     os.replace(tmp, out_path)
@@ -795,10 +796,11 @@ def iter_bam_records(bam_path, want_ref=False, batch=512, native=True, shard=Non
     yield from _iter_bam_records_py(bam_path)
 
 
-def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None, light=False):
+def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None, light=False, inflate_threads=0):
     """The alignments of a BAM file (or of a rank's share of it, `shard` as in iter_bam_records) as (RawBamBatch, records)
     pairs - `records(rb)` builds the record objects of a batch when somebody needs them - straight from the native reader:
-    no Python object per record.  The batch form of iter_bam_records (same shares, same boundary check)."""
+    no Python object per record.  The batch form of iter_bam_records (same shares, same boundary check).
+    `inflate_threads`: BGZF inflate workers of this reader (0 = its default)."""
     start = count = end = None
     if shard is not None and (hasattr(shard, "result") or int(shard[1]) > 1):
         got = shard.result() if hasattr(shard, "result") else shard_of(bam_path, int(shard[0]), int(shard[1]))
@@ -812,7 +814,7 @@ def iter_bam_raw_batches(bam_path, want_ref=False, batch=512, shard=None, light=
                 return
     lib = L.lib()
     h = ctypes.c_void_p()
-    L.check(lib.rmr_bam_open(str(bam_path).encode(), ctypes.byref(h)))
+    L.check(lib.rmr_bam_open_threads(str(bam_path).encode(), int(inflate_threads), ctypes.byref(h)))
     refs = {}
 
     def named(rb):  # reference names are looked up while the file is open: `records` stays usable after the iteration ends

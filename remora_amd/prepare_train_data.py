@@ -138,6 +138,7 @@ def _prefetched(iterable, device, depth=2):
     producer surface in the consumer; a consumer that leaves early stops the producer."""
     import queue
     import threading
+    import time
 
     q, stop, end = queue.Queue(maxsize=max(int(depth), 1)), threading.Event(), object()
 
@@ -171,7 +172,15 @@ def _prefetched(iterable, device, depth=2):
                 raise item
             yield item
     finally:
+        # the producer runs GPU ingest and owns the native BAM handle: it is stopped AND joined before the caller goes on
+        # (write_metadata, interpreter exit), as io._readahead and validate.py do - drain the queue so a blocked put returns
         stop.set()
+        deadline = time.monotonic() + 30.0
+        while th.is_alive() and time.monotonic() < deadline:
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                th.join(0.02)
 
 
 def extract_chunk_arrays_from_ingest(ib, int_label, motifs, sig_map_refiner, max_chunks_per_read, chunk_context,
@@ -277,14 +286,18 @@ def count_reads(pod5_path, bam_path, skip_non_primary=True, shard=None):
     rank's share of the BAM only."""
     signals = rio.Pod5File(pod5_path)
     total = both = 0
-    # the pass is bound by the inflate of the file: nothing else runs in this process yet, so every core it may use inflates
-    prev = os.environ.get("RMR_BAM_INFLATE_THREADS")
-    if prev is None:
-        os.environ["RMR_BAM_INFLATE_THREADS"] = str(max(8, min(16, rio._eff_cpus())))
-    batches = rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard, light=True)  # flags and names only
-    first = next(batches, None)  # (the reader reads the variable when it opens the file)
-    if prev is None:
-        os.environ.pop("RMR_BAM_INFLATE_THREADS", None)
+    # the pass is bound by the inflate of the file: nothing else runs in this process yet, so the cores this RANK was given
+    # inflate (dist.bind_rank's plan when there is one; RMR_BAM_INFLATE_THREADS, read by the reader itself, when the user set it)
+    from . import dist as rdist
+
+    if os.environ.get("RMR_BAM_INFLATE_THREADS"):
+        threads = 0
+    elif rdist.LAST_BINDING and rdist.LAST_BINDING.get("threads"):
+        threads = max(2, 2 * int(rdist.LAST_BINDING["threads"]))
+    else:
+        threads = max(8, min(16, rio._eff_cpus()))
+    batches = rio.iter_bam_raw_batches(bam_path, want_ref=False, batch=2048, shard=shard, light=True, inflate_threads=threads)  # flags and names only
+    first = next(batches, None)
     import itertools
 
     for rb, _ in itertools.chain([first] if first is not None else [], batches):

@@ -75,6 +75,52 @@ def test_bench_strong_sharding_partitions_the_same_data_set():
     assert [sum(r) for r in two["label_counts_per_rank"]] == [15001, 15000]
 
 
+def test_bench_eight_ranks_on_one_gpu_weak():
+    """The driver's 8-GPU form rehearsed on what a 1-GPU lease offers: EIGHT ranks (torch.distributed.run, gloo, every rank
+    on device 0) of the headline workload.  World-8 rank arithmetic of the weak branch (rank r = data blocks of rank r),
+    the per-rank tallies, their sum, the placement record of every rank and the exit code."""
+    n = 6000
+    args = ["--steps", "2", "--warmup", "1", "--chunks", str(n), "--no-cpu-baseline", "--no-encode", "--no-reads", "--no-others", "--no-refine"]
+    eight, p = _bench(["--gpus", "8", "--force-device", "0", "--dist-backend", "gloo", "--logits-hash"] + args)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["config"]["chunks_per_step_all_gpus"] == 8 * n
+    per_rank = np.asarray(eight["label_counts_per_rank"])
+    assert per_rank.shape == (8, 2) and np.array_equal(per_rank.sum(0), eight["label_counts"])
+    assert all(int(r.sum()) == 2 * n for r in per_rank) and sum(eight["label_counts"]) == 8 * 2 * n
+    assert len({tuple(r) for r in per_rank.tolist()}) > 4  # the ranks worked on different chunks
+    coll = eight["collective"]
+    assert coll["backend"] == "gloo" and len(coll["allreduce_ms_per_rank"]) == 8 and len(coll["rccl_init_ms_per_rank"]) == 8
+    assert [pl["rank"] for pl in coll["placement_per_rank"]] == list(range(8)) and all(pl["device"] == 0 for pl in coll["placement_per_rank"])
+    assert eight["value"] == pytest.approx(8 * n * 2 / (eight["ms_per_step"] * 2e-3), rel=1e-6)
+    for r in (0, 5, 7):  # a rank's tally = a single-rank run over that rank's blocks of the data set
+        one, _ = _bench(["--gpus", "1", "--shard-base", str(r)] + args)
+        assert one["label_counts"] == [int(x) for x in per_rank[r]], (r, one["label_counts"], per_rank[r])
+
+
+def test_bench_eight_ranks_on_one_gpu_strong_same_logits_as_one_rank():
+    """configs[3] (bf16, ONE data set cut into contiguous ranges, dist.shard_range) with eight ranks: the ranges tile the
+    data set, and the logits of all ranks in rank order are the single-rank run's, bit for bit."""
+    total = 80_003
+    args = ["--workload", "convlstm_c100_bf16_10m", "--steps", "1", "--warmup", "1", "--chunks", str(total), "--no-cpu-baseline",
+            "--no-encode", "--no-reads", "--no-others", "--no-refine", "--logits-hash"]
+    one, _ = _bench(["--gpus", "1"] + args)
+    eight, _ = _bench(["--gpus", "8", "--force-device", "0", "--dist-backend", "gloo"] + args)
+    assert eight["scaling"] == "strong" and eight["n_gpus"] == 8
+    assert [sum(r) for r in eight["label_counts_per_rank"]] == [10001, 10001, 10001] + [10000] * 5
+    assert one["label_counts"] == eight["label_counts"] and sum(one["label_counts"]) == total
+    assert one["logits_sha256"] and one["logits_sha256"] == eight["logits_sha256"]
+
+
+def test_bench_falls_back_to_gloo_when_rccl_cannot_reduce():
+    """The default backend (nccl = RCCL) with a first all-reduce that fails (REMORA_AMD_DIST_FAIL_FIRST: RCCL itself refuses
+    two ranks on one device, which a 1-GPU box cannot get past): every rank agrees over the gloo side channel, the run's
+    collectives move there, the line is printed, `collective.backend` says what happened, rc 0."""
+    two, p = _bench(["--gpus", "2", "--force-device", "0"] + FAST, env_extra={"REMORA_AMD_DIST_FAIL_FIRST": "1"})
+    assert two["n_gpus"] == 2 and sum(two["label_counts"]) == 2 * 20000 * 2
+    assert two["collective"]["backend"].startswith("gloo (RCCL failed: rank 0: RuntimeError"), two["collective"]["backend"]
+    assert np.array_equal(np.asarray(two["label_counts_per_rank"]).sum(0), two["label_counts"])
+    assert "go over gloo instead" in p.stderr
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     _, p = _bench(["--gpus", "2"] + FAST, env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_rc=2)
     assert "refusing" in p.stderr and not p.stdout.strip()
@@ -163,6 +209,7 @@ def test_bench_one_rank_through_rccl_reproduces_the_plain_run():
     all-reduce of the device-resident label counts, the max-over-ranks clock and the per-rank gather run through RCCL and
     leave the numbers of the plain single-process run."""
     plain, _ = _bench(["--gpus", "1"] + FAST)
+    assert plain["allreduce_counts_c_abi"]["status"] == "ok", plain["allreduce_counts_c_abi"]
     forced, p = _bench(["--gpus", "1"] + FAST, env_extra={"REMORA_AMD_DIST_SINGLE": "1", "RANK": "0", "WORLD_SIZE": "1",
                                                          "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1"})
     assert forced["label_counts"] == plain["label_counts"] and forced["label_counts_per_rank"] == plain["label_counts_per_rank"]

@@ -1614,6 +1614,18 @@ def test_pack_reads_native_gather_equals_numpy():
     L.check(lib.rmr_pack_reads_narrow(nr, vp(0), sig_n.ctypes.data, vp(1), vp(2), seq_n.ctypes.data, isz.ctypes.data, dacs.ctypes.data,
                                       maps32.ctypes.data, seq.ctypes.data, so.ctypes.data, qo.ctypes.data, 3, ctypes.byref(fit)))
     assert fit.value == 1 and maps32[qo[20] + 20] == -(1 << 31)
+    # int64 bases far outside int8 never narrow to a valid base code (2^32 + 1 kept only its low dword once): clamped to the
+    # int8 range on the vector path (16 at a time) and in the scalar tail alike, so RemoraRead.check's range test sees them
+    wide = np.array([0, 1, (1 << 32) + 1, -(1 << 32), 3, 1 << 40, 300, -300, 2, (1 << 31), -(1 << 31) - 1, 1, 0, 3, 2, -1,
+                     (1 << 32) + 2, -1, 127, -128], np.int64)
+    one = lambda a: (ctypes.c_void_p * 1)(a.ctypes.data)  # noqa: E731
+    d1, m1 = np.zeros(4, np.int16), np.arange(wide.size + 1, dtype=np.int64)
+    out8 = np.zeros(wide.size, np.int8)
+    n_sig, n_seq, w8 = np.array([4], np.int64), np.array([wide.size], np.int64), np.array([8], np.int32)
+    o_d, o_m, o_so, o_qo = np.zeros(4, np.int16), np.zeros(wide.size + 1, np.int64), np.zeros(2, np.int64), np.zeros(2, np.int64)
+    L.check(lib.rmr_pack_reads(1, one(d1), n_sig.ctypes.data, one(m1), one(wide), n_seq.ctypes.data, w8.ctypes.data, o_d.ctypes.data,
+                               o_m.ctypes.data, out8.ctypes.data, o_so.ctypes.data, o_qo.ctypes.data, 1))
+    assert np.array_equal(out8, np.clip(wide, -128, 127).astype(np.int8)), out8
 
 
 def test_format_mm_ml_tags_equals_oracle_on_random_reads(O):
@@ -2674,11 +2686,15 @@ def test_collect_reads_c_api_walk_equals_the_interpreters(monkeypatch):
 
     reads = [mk(0, 300), mk(1, 7, np.int8), mk(2, 1200, np.int32), mk(3, 50, np.uint8)]
     monkeypatch.setenv("RMR_PY_GLUE", "1")
+    def by_interpreter(res):  # the interpreter's walk keeps (dacs, mapping, bases) tuples, the C walk the attribute objects
+        return bool(res[-1]) and isinstance(res[-1][0], tuple)
+
     a = _collect_reads(reads)
-    assert a[-1] is None, "the C-API walk must take these reads as they are"
+    assert not by_interpreter(a), "the C-API walk must take these reads as they are"
+    assert len(a[-1]) == 3 * len(reads) and a[-1][0] is reads[0].dacs and a[-1][5] is reads[1].int_seq  # owned until the gather is done
     monkeypatch.setenv("RMR_PY_GLUE", "0")
     b = _collect_reads(reads)
-    assert b[-1] is not None
+    assert by_interpreter(b)
     for x, y in zip(a[:-1], b[:-1]):
         assert x.dtype == y.dtype and np.array_equal(x, y)
     assert list(a[0]) == [r.dacs.ctypes.data for r in reads] and list(a[5]) == [8, 1, 4, 1]
@@ -2686,21 +2702,45 @@ def test_collect_reads_c_api_walk_equals_the_interpreters(monkeypatch):
     # what the C walk leaves to the interpreter
     monkeypatch.setenv("RMR_PY_GLUE", "1")
     odd = [mk(0, 300), RemoraRead.test_read()]                       # float zeros as dacs
-    assert _collect_reads(odd)[-1] is not None
+    assert by_interpreter(_collect_reads(odd))
     strided = mk(4, 200)
     strided.dacs = np.repeat(strided.dacs, 2)[::2]                      # a view with a stride
     assert not strided.dacs.flags.c_contiguous
     got = _collect_reads([strided])
-    assert got[-1] is not None and np.array_equal(got[-1][0][0], strided.dacs)
+    assert by_interpreter(got) and np.array_equal(got[-1][0][0], strided.dacs)
     m32 = mk(5, 100)
     m32.seq_to_sig_map = m32.seq_to_sig_map.astype(np.int32)
     got = _collect_reads([m32])
-    assert got[-1] is not None and got[-1][0][1].dtype == np.int64
+    assert by_interpreter(got) and got[-1][0][1].dtype == np.int64
     bad = mk(6, 100)
     bad.seq_to_sig_map = bad.seq_to_sig_map[:-1]
     with pytest.raises(RemoraError, match="sizes incompatible"):
         _collect_reads([reads[0], bad])
     assert _collect_reads([])[1].size == 0
+
+    # duck-typed reads whose arrays are computed per access (properties): nothing but the returned `keep` owns them, and the
+    # addresses must still hold the read's values after other allocations have had their chance to reuse freed memory
+    class Lazy:
+        def __init__(self, i):
+            self._r = synth.synth_read(400 + i, idx=i)
+            self.shift, self.scale = 1.0 + i, 2.0
+
+        dacs = property(lambda self: self._r["dacs"].copy())
+        seq_to_sig_map = property(lambda self: self._r["seq_to_sig_map"].astype(np.int64))
+        int_seq = property(lambda self: self._r["int_seq"].astype(np.int64))
+
+    import ctypes
+    import gc
+
+    lazy = [Lazy(i) for i in range(64)]
+    got = _collect_reads(lazy)
+    assert not by_interpreter(got) and len(got[-1]) == 3 * 64
+    gc.collect()
+    junk = [np.full(400 + i, -7, np.int16) for i in range(64)] + [np.full(401 + i, -7, np.int64) for i in range(128)]  # noqa: F841
+    for i, r in enumerate(lazy):
+        d = np.ctypeslib.as_array(ctypes.cast(int(got[0][i]), ctypes.POINTER(ctypes.c_int16)), (int(got[1][i]),))
+        m = np.ctypeslib.as_array(ctypes.cast(int(got[2][i]), ctypes.POINTER(ctypes.c_int64)), (int(got[4][i]) + 1,))
+        assert np.array_equal(d, r._r["dacs"]) and np.array_equal(m, r._r["seq_to_sig_map"])
 
 
 def test_chunk_geometry_searches_from_a_hint_equal_bisection(tmp_path):
