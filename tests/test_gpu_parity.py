@@ -330,7 +330,9 @@ def test_extract_multi_read_batch_vs_oracle(torch_cuda, O):
 
 # ---- F1 / F2 ------------------------------------------------------------------------------------
 MODELS = ["convlstm_s64_l100_o2", "convlstm_s64_l200_o3", "convlstm_s16_l100_o2",
-          "convlstm_s64_l100_k23", "conv_s64_l100_o2", "conv_s64_l100_o3"]
+          "convlstm_s64_l100_k23", "conv_s64_l100_o2", "conv_s64_l100_o3",
+          # any `--size` (src/remora/parsers.py:858-862): streamed-weight kernels above 64, zero-padded channels otherwise
+          "convlstm_s96_l100_o2", "convlstm_s128_l100_o2", "conv_s96_l100_o2", "convlstm_s40_l100_o2", "conv_s24_l100_o3"]
 
 
 def _model_from_golden(g, O):

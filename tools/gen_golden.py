@@ -444,6 +444,13 @@ def gen_model_logits(R, out):
         ("convlstm_s64_l100_k23", "ConvLSTM_w_ref", 64, (2, 3), 100, 4, 16),
         ("conv_s64_l100_o2", "Conv_w_ref", 64, (4, 4), 100, 2, 48),
         ("conv_s64_l100_o3", "Conv_w_ref", 64, (4, 4), 100, 3, 16),
+        # round 6: `--size` is any int in the reference (src/remora/parsers.py:858-862); sizes outside {16, 32, 64} -
+        # multiples of 16 above 64 (streamed-weight kernels) and sizes that are padded with zero channels (40 -> 64, 24 -> 32)
+        ("convlstm_s96_l100_o2", "ConvLSTM_w_ref", 96, (4, 4), 100, 2, 24),
+        ("convlstm_s128_l100_o2", "ConvLSTM_w_ref", 128, (4, 4), 100, 2, 24),
+        ("conv_s96_l100_o2", "Conv_w_ref", 96, (4, 4), 100, 2, 24),
+        ("convlstm_s40_l100_o2", "ConvLSTM_w_ref", 40, (4, 4), 100, 2, 24),
+        ("conv_s24_l100_o3", "Conv_w_ref", 24, (4, 4), 100, 3, 16),
     ]
     for si, (name, arch, size, (kb, ka), L, num_out, n) in enumerate(specs):
         K = kb + ka + 1
