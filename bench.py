@@ -39,6 +39,10 @@ WORKLOADS = {
     "convlstm_c100_bf16_10m": dict(arch="conv_lstm", cfg="C100", dtype="bf16", chunks=10_000_000, scaling="strong", baseline_config=3,
                                    desc="synthetic 10M 100-sig-pt CG chunks read-sharded over the ranks, ConvLSTM_w_ref bf16 "
                                         "(BASELINE configs[3])"),
+    # a network of 128 channels (`--size 128`, src/remora/parsers.py:858-862): the streamed-weight kernels (k_stream.hip)
+    "convlstm_c100_s128": dict(arch="conv_lstm", cfg="C100", dtype="fp32", chunks=500_000, scaling="weak", baseline_config=None, size=128,
+                               desc="synthetic 100-sig-pt CG chunks, ConvLSTM_w_ref size 128 k-mer (4,4) 2-class (the shape of "
+                                    "BASELINE configs[2] at twice the channels)"),
     "convlstm_c200_bf16": dict(arch="conv_lstm", cfg="C200", dtype="bf16", chunks=1_000_000, scaling="weak", baseline_config=4,
                                desc="synthetic 200-sig-pt all-context chunks, 3-class 5mC+5hmC ConvLSTM_w_ref bf16 "
                                     "(BASELINE configs[4])"),
@@ -55,6 +59,7 @@ OTHER_CONFIGS = [
     ("convlstm_c100_bf16x6", "convlstm_c100", "bf16x6", None),
     ("convlstm_c100_bf16x3", "convlstm_c100", "bf16x3", None),
     ("convlstm_c100_f16x3", "convlstm_c100", "f16x3", None),
+    ("convlstm_c100_s128_fp32", "convlstm_c100_s128", None, None),
 ]
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0
@@ -399,7 +404,7 @@ class Job:
 
         w = WORKLOADS[workload]
         self.w, self.workload, self.dtype = w, workload, dtype or w["dtype"]
-        self.arch, self.cfg = w["arch"], w["cfg"]
+        self.arch, self.cfg, self.size = w["arch"], w["cfg"], int(w.get("size", 64))
         self.cc, self.kcb, _, self.num_out, _ = synth.CONFIGS[self.cfg]
         self.L = sum(self.cc)
         self.rank, self.world, self.local = rank, world, local
@@ -418,7 +423,7 @@ class Job:
         if subbatch:
             self.eng.set_subbatch(subbatch)
         self.md = dict(chunk_context=self.cc, kmer_context_bases=self.kcb)
-        state = synth.synth_state(self.arch, 64, sum(self.kcb) + 1, self.num_out, seed=0)
+        state = synth.synth_state(self.arch, self.size, sum(self.kcb) + 1, self.num_out, seed=0)
         # centre the class logits (random weights otherwise call one class for every chunk): shift fc.bias by the per-class
         # median of the logits of a FIXED probe set (block 0 of the data set, first 8192 chunks) — every rank computes the
         # same shift from the same data with the same kernels, no broadcast needed
@@ -493,8 +498,8 @@ class Job:
         return elapsed, self.eng.profile(), per_rank
 
     def report(self, steps, warmup, elapsed, prof, traffic_table=None):
-        flops = kernel_flops_per_chunk(self.arch, self.L, 64, sum(self.kcb) + 1, self.num_out)
-        alg_b = kernel_alg_bytes_per_chunk(self.arch, self.L, self.dtype, 64, self.num_out, self.dev[1].shape[1], self.dev[2].shape[1])
+        flops = kernel_flops_per_chunk(self.arch, self.L, self.size, sum(self.kcb) + 1, self.num_out)
+        alg_b = kernel_alg_bytes_per_chunk(self.arch, self.L, self.dtype, self.size, self.num_out, self.dev[1].shape[1], self.dev[2].shape[1])
         n, total = self.n, self.total_chunks_per_step * steps
         kern = {}
         for name, (ms, launches) in prof.items():

@@ -84,7 +84,10 @@ int rmr_engine_set_subbatch(rmr_engine *e, int64_t chunks);
 
 typedef struct {
     int32_t arch;       /* rmr_arch */
-    int32_t size;       /* model_params["size"]: 16, 32 or 64 (constants.py:1 default 64) */
+    int32_t size;       /* model_params["size"]: any int >= 1 (src/remora/parsers.py:858-862; constants.py:1 default 64).  The
+                           kernels run at 16 / 32 / 64 channels (weight slices resident in registers) or, above 64, at the next
+                           multiple of 16 up to 256 (weights streamed from L2, fp32 only); a size in between is run at the next
+                           of those with zero-weight channels added (rmr_model_padded_size) - same logits */
     int32_t kmer_len;   /* kmer_context_bases[0] + [1] + 1 */
     int32_t num_out;    /* len(mod_bases) + 1, <= 16 */
     int32_t chunk_len;  /* sum(chunk_context) */
@@ -114,6 +117,14 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
 void rmr_model_destroy(rmr_model *m);
 /* number of floats rmr_model_create expects for `desc` (0 if desc is unsupported) */
 size_t rmr_model_weight_count(const rmr_model_desc *desc);
+/* The channel count the kernels run a network of desc->size channels at (0 if desc is unsupported), and the network's blob
+ * at that size: `weights` (rmr_model_weight_count(desc) floats) with zero-weight channels added -> `out` (out == NULL: only
+ * *out_n and *padded_desc are set).  rmr_model_create applies this itself; the entry exists so that a host can see - and a
+ * test can check against the reference's forward - exactly which network the kernels evaluate.
+ * replaces: nothing (models/ConvLSTM_w_ref.py:11-37 builds layers of any `size`; torch needs no padding). */
+int rmr_model_padded_size(const rmr_model_desc *desc);
+int rmr_model_pad_weights(const rmr_model_desc *desc, const float *weights, size_t n_floats, rmr_model_desc *padded_desc,
+                          float *out, size_t out_cap, size_t *out_n);
 
 /* ---- E1: k-mer one-hot encode with move-table expansion ------------------------------ */
 /* replaces: encoded_kmers.compute_encoded_kmer_batch, src/remora/encoded_kmers.pyx:13-45.

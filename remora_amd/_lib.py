@@ -69,6 +69,9 @@ SIGNATURES = {
     "rmr_model_create": (c_int, [c_vp, ctypes.POINTER(ModelDesc), c_vp, ctypes.c_size_t, ctypes.POINTER(c_vp)]),
     "rmr_model_destroy": (None, [c_vp]),
     "rmr_model_weight_count": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc)]),
+    "rmr_model_padded_size": (c_int, [ctypes.POINTER(ModelDesc)]),
+    "rmr_model_pad_weights": (c_int, [ctypes.POINTER(ModelDesc), c_vp, ctypes.c_size_t, ctypes.POINTER(ModelDesc), c_vp, ctypes.c_size_t,
+                                      ctypes.POINTER(ctypes.c_size_t)]),
     "rmr_encode_kmers": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_int]),
     "rmr_trim_chunk_context": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_int]),
     "rmr_parse_moves": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, ctypes.POINTER(c_i64), c_int]),

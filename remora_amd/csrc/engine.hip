@@ -671,15 +671,91 @@ std::vector<float> pack_split_a(const std::vector<float> &w, int K, int nw, cons
     return f;
 }
 
+// The channel count the kernels run a network of `size` channels at (models/ConvLSTM_w_ref.py:11-37 and Conv_w_ref.py:11-42
+// are parametric in `size`, the CLI takes any int: src/remora/parsers.py:858-862).  Up to 64 the kernels with register-resident
+// weight slices exist for 16 / 32 / 64; above, the streamed-weight kernels (k_stream.hip) take any multiple of 16 up to 256.
+// Channels between `size` and the padded count carry zero weights and zero bias: swish(0) = 0 and an LSTM unit with zero
+// weights stays at c = h = 0 exactly, and a zero product added to an fp32 sum leaves it unchanged - the logits are those of
+// the unpadded network (pad_model_blob below; rmr_model_pad_weights exposes the transform).
+int padded_size(int size) {
+    if (size <= 16) return 16;
+    if (size <= 32) return 32;
+    if (size <= 64) return 64;
+    return (size + 15) & ~15;
+}
+constexpr int kMaxPaddedSize = 256;
+
 bool desc_ok(const rmr_model_desc &d) {
     if (d.arch != RMR_ARCH_CONV_LSTM && d.arch != RMR_ARCH_CONV_ONLY) return false;
-    if (d.size != 16 && d.size != 32 && d.size != 64) return false;
+    if (d.size < 1 || padded_size(d.size) > kMaxPaddedSize) return false;
+    const int sp = padded_size(d.size);
     if (d.kmer_len < 1 || d.kmer_len > 64) return false;
     if (d.num_out < 1 || d.num_out > 16) return false;
     if (d.dtype < 0 || d.dtype > 5) return false;  // 5 = f16x3: two-part IEEE half split on the unfused kernels
-    if (d.dtype == 4 && (d.size != 64 || (d.kmer_len != 9 && d.kmer_len != 6))) return false;  // half: the fused kernels only
-    if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || d.size % 32)) return false;
+    if (d.dtype == 4 && (sp != 64 || (d.kmer_len != 9 && d.kmer_len != 6))) return false;  // half: the fused kernels only
+    if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || sp % 32 || sp > 64)) return false;  // 16-bit operands: up to 64 channels
     return true;
+}
+
+// The canonical blob (include/remora_hip.h, rmr_model_create) of the same network with `sp` channels where `d` has d.size:
+// zero weights / bias for the added output channels (BatchNorm of an added channel: gamma 1, beta 0, mean 0, var 1 - it folds
+// to weight 0, bias 0), zero columns for the added input channels; merge_conv1 reads cat = [signal branch | sequence branch],
+// so its input channel sz + c moves to sp + c.
+std::vector<float> pad_model_blob(const rmr_model_desc &d, const float *w, int sp) {
+    const int sz = d.size;
+    rmr_model_desc pd = d;
+    pd.size = sp;
+    const std::vector<ConvSpec> ts = conv_specs(d), ps = conv_specs(pd);
+    size_t total = 0;
+    for (auto &s : ps) total += conv_count(s);
+    const size_t H = sz, HP = sp;
+    if (d.arch == RMR_ARCH_CONV_LSTM) total += 2 * (2 * 4 * HP * HP + 2 * 4 * HP) + (size_t)d.num_out * HP + d.num_out;
+    else total += (size_t)d.num_out * HP * 3 + d.num_out;
+    std::vector<float> o(total, 0.0f);
+    const float *p = w;
+    float *q = o.data();
+    const size_t merge1 = d.arch == RMR_ARCH_CONV_LSTM ? 5 : 6;
+    for (size_t li = 0; li < ts.size(); ++li) {
+        const ConvSpec &t = ts[li], &u = ps[li];
+        for (int oc = 0; oc < t.oc; ++oc)
+            for (int ic = 0; ic < t.ic; ++ic) {
+                const int icp = (li == merge1 && ic >= sz) ? sp + (ic - sz) : ic;
+                memcpy(q + ((size_t)oc * u.ic + icp) * u.kw, p + ((size_t)oc * t.ic + ic) * t.kw, (size_t)t.kw * sizeof(float));
+            }
+        p += (size_t)t.oc * t.ic * t.kw;
+        q += (size_t)u.oc * u.ic * u.kw;
+        for (int part = 0; part < 5; ++part) {  // bias, gamma, beta, mean, var
+            memcpy(q, p, (size_t)t.oc * sizeof(float));
+            if (part == 1 || part == 4)
+                for (int oc = t.oc; oc < u.oc; ++oc) q[oc] = 1.0f;
+            p += t.oc;
+            q += u.oc;
+        }
+    }
+    if (d.arch == RMR_ARCH_CONV_LSTM) {
+        for (int l = 0; l < 2; ++l) {
+            for (int m = 0; m < 2; ++m) {  // weight_ih, weight_hh: [4H][H], row = gate * H + unit
+                for (int g = 0; g < 4; ++g)
+                    for (size_t r = 0; r < H; ++r) memcpy(q + ((size_t)g * HP + r) * HP, p + ((size_t)g * H + r) * H, H * sizeof(float));
+                p += 4 * H * H;
+                q += 4 * HP * HP;
+            }
+            for (int m = 0; m < 2; ++m) {  // bias_ih, bias_hh: [4H]
+                for (int g = 0; g < 4; ++g) memcpy(q + (size_t)g * HP, p + (size_t)g * H, H * sizeof(float));
+                p += 4 * H;
+                q += 4 * HP;
+            }
+        }
+        for (int oo = 0; oo < d.num_out; ++oo) memcpy(q + (size_t)oo * HP, p + (size_t)oo * H, H * sizeof(float));
+        p += (size_t)d.num_out * H;
+        q += (size_t)d.num_out * HP;
+    } else {  // fc over flatten([size][3]): index c * 3 + t, channels first - the added channels sit behind the real ones
+        for (int oo = 0; oo < d.num_out; ++oo) memcpy(q + (size_t)oo * HP * 3, p + (size_t)oo * H * 3, H * 3 * sizeof(float));
+        p += (size_t)d.num_out * H * 3;
+        q += (size_t)d.num_out * HP * 3;
+    }
+    memcpy(q, p, (size_t)d.num_out * sizeof(float));
+    return o;
 }
 
 Folded fold(const ConvSpec &s, const float *&p) {
@@ -718,6 +794,22 @@ int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
     const ConvSpec &s = f.s;
     if (s.ic % 16 || s.oc % 16) RMR_FAIL(RMR_ERR_INVALID, "conv %dx%d not MFMA-tileable", s.ic, s.oc);
     const int G = s.ic / 16, S = s.kw * s.ic / 4, W = s.oc / 16;
+    if (s.oc > 64 || s.ic > 128) {  // a layer of a network with more than 64 channels: the streamed kernel's order (k_stream.hip)
+        std::vector<float> ap((size_t)W * s.kw * G * 64 * 4);
+        for (int w = 0; w < W; ++w)
+            for (int tap = 0; tap < s.kw; ++tap)
+                for (int g = 0; g < G; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int q = lane >> 4, mm = lane & 15;
+                            const int oc = 16 * w + mm, ic = 16 * g + 4 * q + j;
+                            ap[((((size_t)w * s.kw + tap) * G + g) * 64 + lane) * 4 + j] = f.w[((size_t)oc * s.ic + ic) * s.kw + tap];
+                        }
+        out->ic = s.ic; out->oc = s.oc; out->kw = s.kw; out->stride = s.stride; out->kid = kid;
+        RMR_TRY(upload(m, ap, &out->apack4));
+        RMR_TRY(upload(m, f.b, &out->bias));
+        return 0;
+    }
     std::vector<float> ap((size_t)W * S * 64);
     for (int w = 0; w < W; ++w)
         for (int tap = 0; tap < s.kw; ++tap)
@@ -861,6 +953,23 @@ std::vector<float> pack_bias_x16(const float *bih, const float *bhh, bool skip_f
     return o;
 }
 
+// [4H][H] row-major -> [H/16 waves][H/16 k groups][ngates][64 lanes][4] (k_stream.hip: one 16-byte fragment per gate and group)
+std::vector<float> pack_lstm_stream(const float *w, int H, const int *gates, int ngates, bool prescale) {
+    const int G = H / 16, W = H / 16;
+    std::vector<float> ap((size_t)W * G * ngates * 64 * 4);
+    for (int wv = 0; wv < W; ++wv)
+        for (int g = 0; g < G; ++g)
+            for (int gi = 0; gi < ngates; ++gi)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = lane >> 4, mm = lane & 15;
+                        const int row = gates[gi] * H + 16 * wv + mm, k = 16 * g + 4 * q + j;
+                        const double sc = prescale ? lstm1_gate_scale(gates[gi]) : 1.0;
+                        ap[((((size_t)wv * G + g) * ngates + gi) * 64 + lane) * 4 + j] = (float)((double)w[(size_t)row * H + k] * sc);
+                    }
+    return ap;
+}
+
 // [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
 std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates, bool prescale = false) {
     const int KS = H / 4, G = H / 16, W = H / 16;
@@ -906,6 +1015,31 @@ void rmr_model_destroy(rmr_model *m) {
     delete m;
 }
 
+int rmr_model_padded_size(const rmr_model_desc *d) { return (d && desc_ok(*d)) ? padded_size(d->size) : 0; }
+
+int rmr_model_pad_weights(const rmr_model_desc *desc, const float *weights, size_t n_floats, rmr_model_desc *padded_desc,
+                          float *out, size_t out_cap, size_t *out_n) {
+    if (!desc || !weights || !padded_desc || !out_n) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
+    if (!desc_ok(*desc)) RMR_FAIL(RMR_ERR_INVALID, "unsupported model description");
+    if (rmr_model_weight_count(desc) != n_floats)
+        RMR_FAIL(RMR_ERR_INVALID, "weight blob has %zu floats, expected %zu", n_floats, rmr_model_weight_count(desc));
+    *padded_desc = *desc;
+    padded_desc->size = padded_size(desc->size);
+    *out_n = rmr_model_weight_count(padded_desc);
+    if (!out) return 0;  // size query
+    if (out_cap < *out_n) RMR_FAIL(RMR_ERR_INVALID, "output holds %zu floats, %zu needed", out_cap, *out_n);
+    if (padded_desc->size == desc->size) {
+        memcpy(out, weights, n_floats * sizeof(float));
+        return 0;
+    }
+    const std::vector<float> o = pad_model_blob(*desc, weights, padded_desc->size);
+    if (o.size() != *out_n) RMR_FAIL(RMR_ERR_INVALID, "internal: padded blob has %zu floats, expected %zu", o.size(), *out_n);
+    memcpy(out, o.data(), o.size() * sizeof(float));
+    return 0;
+}
+
+static int model_create_at_kernel_size(rmr_engine *e, const rmr_model_desc *desc, const float *weights, size_t n_floats, rmr_model **out);
+
 int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *weights,
                      size_t n_floats, rmr_model **out) {
     if (!e || !desc || !weights || !out) RMR_FAIL(RMR_ERR_INVALID, "NULL argument");
@@ -913,15 +1047,31 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
     if (!desc_ok(*desc))
         RMR_FAIL(RMR_ERR_INVALID,
                  "unsupported model: arch=%d size=%d kmer_len=%d num_out=%d dtype=%d "
-                 "(size must be 16/32/64, num_out<=16, fp32)",
-                 desc->arch, desc->size, desc->kmer_len, desc->num_out, desc->dtype);
+                 "(size 1..%d; num_out <= 16; the 16-bit dtypes need conv_lstm with at most 64 channels - f16 exactly 33..64 and "
+                 "k-mer length 9 or 6; larger networks run in fp32)",
+                 desc->arch, desc->size, desc->kmer_len, desc->num_out, desc->dtype, kMaxPaddedSize);
     const size_t want = rmr_model_weight_count(desc);
     if (want != n_floats) RMR_FAIL(RMR_ERR_INVALID, "weight blob has %zu floats, expected %zu", n_floats, want);
+    const int sp = padded_size(desc->size);
+    if (sp == desc->size) return model_create_at_kernel_size(e, desc, weights, n_floats, out);
+    rmr_model_desc pd = *desc;
+    pd.size = sp;
+    const std::vector<float> blob = pad_model_blob(*desc, weights, sp);
+    RMR_TRY(model_create_at_kernel_size(e, &pd, blob.data(), blob.size(), out));
+    (*out)->true_size = desc->size;
+    return 0;
+}
+
+// `desc->size` is a size the kernels run at (padded_size is the identity on it)
+static int model_create_at_kernel_size(rmr_engine *e, const rmr_model_desc *desc, const float *weights, size_t n_floats, rmr_model **out) {
+    const size_t want = rmr_model_weight_count(desc);
+    if (want != n_floats) RMR_FAIL(RMR_ERR_INVALID, "internal: padded weight blob has %zu floats, expected %zu", n_floats, want);
     std::lock_guard<std::mutex> lk(e->mu);
     RMR_HIP(hipSetDevice(e->device));
     std::unique_ptr<rmr_model, void (*)(rmr_model *)> m(new rmr_model(), rmr_model_destroy);
     m->eng = e;
     m->desc = *desc;
+    m->true_size = desc->size;
     m->nparts = desc->dtype == 4 ? 1 : (desc->dtype == 5 ? 2 : desc->dtype);  // 0 fp32 MFMA; 1 bf16; 2 bf16x3 (2-part split); 3 bf16x6 (3-part split)
     m->split_f16 = desc->dtype == 5;  // f16x3: the two parts are IEEE half
     m->f16 = desc->dtype == 4;                       // 4: one-part operands as IEEE half (fused kernels)
@@ -1026,9 +1176,15 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
         const float *wfc = p; p += (size_t)desc->num_out * H;
         const float *bfc = p; p += desc->num_out;
         const int g4[4] = {0, 1, 2, 3}, g3[3] = {0, 2, 3};
-        RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4, true), &m->lstm.a_ih1));
-        RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4, true), &m->lstm.a_hh1));
-        RMR_TRY(upload(m.get(), pack_lstm(wih2, H, g3, 3), &m->lstm.a_ih2));
+        if (H > 64) {  // k_stream.hip
+            RMR_TRY(upload(m.get(), pack_lstm_stream(wih1, H, g4, 4, true), &m->lstm.t_ih1));
+            RMR_TRY(upload(m.get(), pack_lstm_stream(whh1, H, g4, 4, true), &m->lstm.t_hh1));
+            RMR_TRY(upload(m.get(), pack_lstm_stream(wih2, H, g3, 3, false), &m->lstm.t_ih2));
+        } else {
+            RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4, true), &m->lstm.a_ih1));
+            RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4, true), &m->lstm.a_hh1));
+            RMR_TRY(upload(m.get(), pack_lstm(wih2, H, g3, 3), &m->lstm.a_ih2));
+        }
         if (m->nparts > 0) {
             std::vector<float> si((size_t)4 * H * H), sh((size_t)4 * H * H);
             for (int r = 0; r < 4 * H; ++r)

@@ -267,6 +267,7 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                 float *out, int out_row, int out_coff, int pout, int64_t n) {
     if (in_row != c.ic) RMR_FAIL(RMR_ERR_INVALID, "conv input row %d != ic %d", in_row, c.ic);
+    if (c.apack4) return launch_conv_stream(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);  // > 64 channels: k_stream.hip
 #define RMR_CONV_CASE(IC_, KW_, ST_)                                  \
     if (c.ic == IC_ && c.kw == KW_ && c.stride == ST_)                \
         return launch_conv_t<IC_, KW_, ST_>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);

@@ -275,6 +275,7 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
 }
 
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits) {
+    if (m->desc.size > 64) return launch_lstm_stream(m, x, n, logits);  // k_stream.hip
     switch (m->desc.size) {
         case 64: return launch_lstm_t<64>(m, x, n, logits);
         case 32: return launch_lstm_t<32>(m, x, n, logits);

@@ -160,6 +160,7 @@ namespace rmr {
 struct ConvLayer {
     int ic = 0, oc = 0, kw = 0, stride = 1;
     float *apack = nullptr;  // device, fragment order [oc/16][kw*ic/4][64]
+    float *apack4 = nullptr; // device, streamed-kernel order [oc/16][kw*ic/16][64][4] (k_stream.hip; layers of networks with > 64 channels)
     float *spack = nullptr;  // device, split-bf16 fragments [oc/16][steps][nparts][64] x 16 B (dtype != 0)
     float *bias = nullptr;   // device, folded bias [oc]
     int kid = 0;             // profiling id
@@ -198,13 +199,16 @@ struct LstmWeights {
     // [8][2][4 q][4 gates]; lstm2 with a zero f row
     float *x_ih = nullptr, *x_hh = nullptr, *x_ih2 = nullptr, *x_b1 = nullptr, *x_b2 = nullptr;
     float *xs_ih = nullptr, *xs_hh = nullptr, *xs_ih2 = nullptr;  // the same fragments as NP split parts (k_lstm_x16s.hip)
+    // k_stream.hip (more than 64 hidden units, fp32): [H/16 waves][H/16 k groups][4 gates (lstm2: 3)][64 lanes][4]
+    float *t_ih1 = nullptr, *t_hh1 = nullptr, *t_ih2 = nullptr;
 };
 
 }  // namespace rmr
 
 struct rmr_model {
     rmr_engine *eng = nullptr;
-    rmr_model_desc desc{};
+    rmr_model_desc desc{};  // desc.size: the channel count the kernels run at (engine.hip padded_size)
+    int true_size = 0;      // the network's own `size` (model_params["size"]); channels beyond it carry zero weights
     int nparts = 0;  // 0: fp32 MFMA path; 1..3: bf16 MFMA with 1 / 2 / 3-part split operands
     bool split_f16 = false;  // dtype f16x3: nparts == 2 and the parts are IEEE half (hi, lo)
     bool f16 = false;  // dtype 4: nparts == 1 with IEEE-half operands in the fused kernels (k_fused.hip, k_lstm_x16.hip)
@@ -270,6 +274,10 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                 float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
+// k_stream.hip: the same layers with the weights streamed from L2 (channel counts above 64, any multiple of 16 up to 256)
+int launch_conv_stream(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out, int out_row, int out_coff,
+                       int pout, int64_t n);
+int launch_lstm_stream(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_lstm_head_split(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_conv_split(rmr_engine *e, const ConvLayer &c, int np, const float *in, int in_row, int pin,
                       float *out, int out_row, int out_coff, int pout, int64_t n);

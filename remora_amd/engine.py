@@ -229,13 +229,15 @@ class HipModel:
         want = lib.rmr_model_weight_count(ctypes.byref(desc))
         if want == 0:
             raise RemoraError(f"model not supported by the HIP engine: arch={arch} size={size} "
-                              f"kmer_len={kmer_len} num_out={num_out} dtype={dtype} (size must be 16, 32 or 64; "
-                              "bf16* dtypes need conv_lstm with size 32/64)")
+                              f"kmer_len={kmer_len} num_out={num_out} dtype={dtype} (size 1..256 in fp32; the 16-bit dtypes "
+                              "need conv_lstm with at most 64 channels - f16 / bf16 on the fused kernels 33..64 and a k-mer "
+                              "length of 9 or 6; larger networks run in fp32)")
         if want != blob.size:
             raise RemoraError(f"weight blob has {blob.size} floats, engine expects {want}")
         h = ctypes.c_void_p()
         L.check(lib.rmr_model_create(self.engine.handle, ctypes.byref(desc), blob.ctypes.data, blob.size, ctypes.byref(h)))
         self._h, self._lib = h, lib
+        self.kernel_size = int(lib.rmr_model_padded_size(ctypes.byref(desc)))  # channels the kernels run at (zero-weight padding)
         # a device-resident token so that `next(model.parameters()).device` works
         self._param = torch.nn.Parameter(torch.zeros(1, device=self.engine.torch_device), requires_grad=False)
         self.training = False

@@ -394,6 +394,61 @@ def test_fused_logits_oracle_synth(torch_cuda, O, arch, cfg, num_out):
         assert np.abs(out - ref).max() <= 1e-4, (arch, cfg, n)
 
 
+@pytest.mark.parametrize("arch,cfg,size,num_out", [("conv_lstm", "C100", 128, 2), ("conv_lstm", "C100", 80, 3), ("conv_lstm", "C200", 96, 3),
+                                                   ("conv_lstm", "C100", 256, 2), ("conv_lstm", "C100", 100, 2), ("conv_only", "C100", 128, 2),
+                                                   ("conv_only", "C100", 176, 3), ("conv_lstm", "C100", 50, 2), ("conv_only", "C100", 7, 2)])
+def test_any_model_size_oracle_synth(torch_cuda, O, arch, cfg, size, num_out):
+    """`--size` is any int in the reference (src/remora/parsers.py:858-862, models/ConvLSTM_w_ref.py:11-37): above 64 the
+    streamed-weight kernels (k_stream.hip: every multiple of 16 up to 256, both architectures, ragged batch sizes around the
+    16- and 64-chunk groups of the LSTM kernel), sizes in between through zero-weight channels.  Random networks against the
+    oracle's torch.nn restatement, the north star's 1e-4; position independence and determinism over a batch larger than a grid."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    net = torch_ref.random_model(arch, size, 9, num_out, seed=size)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    cc = synth.CONFIGS[cfg][0]
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0)
+    assert model.size == size and model.kernel_size >= size and model.kernel_size % 16 == 0
+    for n in (1, 33, 63, 64, 65, 1000):
+        d = synth.synth_chunks_config(cfg, n, shard=n)
+        out = model.infer_chunks(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
+        enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+        with torch.no_grad():
+            ref = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
+        assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-4, (arch, cfg, size, n, float(np.abs(out - ref).max()))
+        if n == 1000:  # the dense-tensor entry (model(sigs, enc_kmers)) of the same network
+            dense = model(torch.from_numpy(d["signal"]).cuda(), torch.from_numpy(enc).cuda()).cpu().numpy()
+            assert np.abs(dense - ref).max() <= 1e-4
+    if size in (128, 176):
+        n = 40_000
+        d = synth.synth_chunks_config(cfg, n, shard=3)
+        dev = [torch.from_numpy(d[k]).cuda() for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
+        a, b = model.infer_chunks(*dev, (4, 4)), model.infer_chunks(*dev, (4, 4))
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+        assert torch.equal(model.infer_chunks(*[t[perm].contiguous() for t in dev], (4, 4)), a[perm])
+
+
+def test_model_sizes_the_engine_refuses(torch_cuda):
+    from oracle import torch_ref
+    from remora_amd import RemoraError
+    from remora_amd.model_util import model_from_state
+
+    md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4))
+    st = lambda size: {k: v.numpy() for k, v in torch_ref.random_model("conv_lstm", size, 9, 2, seed=1).state_dict().items()}  # noqa: E731
+    with pytest.raises(RemoraError, match="size 1..256"):
+        model_from_state(st(272), md, device=0)
+    for dtype in ("bf16", "f16", "f16x3"):  # 16-bit operands: up to 64 channels
+        with pytest.raises(RemoraError, match="at most 64 channels"):
+            model_from_state(st(96), md, device=0, dtype=dtype)
+    # a padded size in the 16-bit pipeline: 40 channels run the fused kernels at 64
+    m = model_from_state(st(40), md, device=0, dtype="f16")
+    assert m.kernel_size == 64
+
+
 def test_full_size_properties(torch_cuda, O):
     """BASELINE config 3 size (1M C100 chunks, ConvLSTM_w_ref fp32): determinism, permutation
     equivariance across sub-batch / tile boundaries, exact label tally, and a 20k-chunk sample

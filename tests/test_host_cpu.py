@@ -3078,3 +3078,69 @@ def test_count_reads_shares_add_up_to_the_file():
             parts = [p.count_reads(pod5, bam, shard=(r, world)) for r in range(world)]
             assert (sum(x[0] for x in parts), sum(x[1] for x in parts)) == whole, (world, parts)
     assert "RMR_BAM_INFLATE_THREADS" not in os.environ  # the pass hands the variable back
+
+
+@pytest.mark.parametrize("name,padded", [("convlstm_s40_l100_o2", 64), ("conv_s24_l100_o3", 32), ("convlstm_s96_l100_o2", 96),
+                                         ("convlstm_s16_l100_o2", 16)])
+def test_padded_network_is_the_same_function(O, name, padded):
+    """`--size` is any int in the reference (src/remora/parsers.py:858-862); the kernels run at 16 / 32 / 64 or a multiple of 16
+    above, so rmr_model_create adds zero-weight channels.  rmr_model_pad_weights is that transform: the padded blob, read back
+    as a state dict and evaluated by the ORACLE's forward, returns the reference's logits of the unpadded network (the
+    reference-generated golden models), and a size the kernels take as it is comes back unchanged."""
+    import ctypes
+
+    from conftest import golden
+    from remora_amd import _lib as L
+    from remora_amd.engine import _CONV_ORDER, state_to_blob
+
+    g = golden(f"model_{name}.npz")
+    state = O.state_from_npz(g)
+    size, kb, ka, Lc, num_out = (int(x) for x in g["params"])
+    arch, sz, kmer_len, n_out, blob = state_to_blob(state)
+    assert sz == size
+    lib = L.lib()
+    desc = L.ModelDesc(L.ARCH_CONV_LSTM if arch == "conv_lstm" else L.ARCH_CONV_ONLY, size, kmer_len, n_out, Lc, 0)
+    assert lib.rmr_model_padded_size(ctypes.byref(desc)) == padded
+    pdesc, n_pad = L.ModelDesc(), ctypes.c_size_t()
+    L.check(lib.rmr_model_pad_weights(ctypes.byref(desc), blob.ctypes.data, blob.size, ctypes.byref(pdesc), None, 0, ctypes.byref(n_pad)))
+    assert pdesc.size == padded and n_pad.value == lib.rmr_model_weight_count(ctypes.byref(pdesc))
+    out = np.full(n_pad.value, np.nan, np.float32)
+    L.check(lib.rmr_model_pad_weights(ctypes.byref(desc), blob.ctypes.data, blob.size, ctypes.byref(pdesc), out.ctypes.data, out.size,
+                                      ctypes.byref(n_pad)))
+    assert np.isfinite(out).all()
+    if padded == size:
+        assert np.array_equal(out, blob)
+        return
+    # blob -> state dict at the padded size (the inverse of state_to_blob)
+    P, ec = padded, 4 * kmer_len
+    shapes = {"sig_conv1": (4, 1), "sig_conv2": (16, 4), "sig_conv3": (P, 16), "seq_conv1": (16, ec),
+              "seq_conv2": (P, 16) if arch == "conv_lstm" else (32, 16), "seq_conv3": (P, 32),
+              "merge_conv1": (P, 2 * P), "merge_conv2": (P, P), "merge_conv3": (P, P), "merge_conv4": (P, P)}
+    pstate, at = {}, 0
+
+    def take(shape):
+        nonlocal at
+        n = int(np.prod(shape))
+        v = out[at : at + n].reshape(shape).copy()
+        at += n
+        return v
+
+    for conv, bn in _CONV_ORDER[arch]:
+        kw = np.asarray(state[f"{conv}.weight"]).shape[2]
+        oc, ic = shapes[conv]
+        pstate[f"{conv}.weight"] = take((oc, ic, kw))
+        for key in (f"{conv}.bias", f"{bn}.weight", f"{bn}.bias", f"{bn}.running_mean", f"{bn}.running_var"):
+            pstate[key] = take((oc,))
+    if arch == "conv_lstm":
+        for l in ("lstm1", "lstm2"):
+            pstate[f"{l}.weight_ih_l0"], pstate[f"{l}.weight_hh_l0"] = take((4 * P, P)), take((4 * P, P))
+            pstate[f"{l}.bias_ih_l0"], pstate[f"{l}.bias_hh_l0"] = take((4 * P,)), take((4 * P,))
+        pstate["fc.weight"] = take((num_out, P))
+    else:
+        pstate["fc.weight"] = take((num_out, 3 * P))
+    pstate["fc.bias"] = take((num_out,))
+    assert at == out.size
+    enc = O.compute_encoded_kmer_batch(kb, ka, g["seqs"], g["maps"], g["lens"])
+    got = O.forward(pstate, g["sigs"], enc)
+    assert np.abs(got - g["logits"]).max() < 2e-5, float(np.abs(got - g["logits"]).max())
+    assert np.abs(got - O.forward(state, g["sigs"], enc)).max() < 1e-6  # zero channels change nothing but the summation tree
