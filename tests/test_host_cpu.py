@@ -165,14 +165,16 @@ def test_state_to_blob_layout_matches_engine_count():
     from remora_amd import synth
     from remora_amd.engine import detect_arch, state_to_blob
 
-    for arch, size, K, no in (("conv_lstm", 64, 9, 2), ("conv_lstm", 16, 6, 4), ("conv_only", 64, 9, 3), ("conv_only", 32, 9, 2)):
+    for arch, size, K, no in (("conv_lstm", 64, 9, 2), ("conv_lstm", 16, 6, 4), ("conv_only", 64, 9, 3), ("conv_only", 32, 9, 2),
+                              ("conv_lstm", 48, 9, 2), ("conv_lstm", 128, 9, 2), ("conv_only", 200, 9, 2), ("conv_lstm", 1, 9, 2)):
         st = synth.synth_state(arch, size, K, no)
         a, s, k, n, blob = state_to_blob(st)
         assert (a, s, k, n) == (arch, size, K, no)
         desc = L.ModelDesc(0 if arch == "conv_lstm" else 1, size, K, no, 100, 0)
         assert L.lib().rmr_model_weight_count(ctypes.byref(desc)) == blob.size
-    bad = L.ModelDesc(0, 48, 9, 2, 100, 0)
-    assert L.lib().rmr_model_weight_count(ctypes.byref(bad)) == 0
+    for bad in (L.ModelDesc(0, 257, 9, 2, 100, 0), L.ModelDesc(0, 0, 9, 2, 100, 0), L.ModelDesc(0, 96, 9, 2, 100, 1),
+                L.ModelDesc(1, 64, 9, 2, 100, 1), L.ModelDesc(0, 64, 9, 17, 100, 0)):  # too wide; empty; 16-bit above 64; 16-bit conv_only
+        assert L.lib().rmr_model_weight_count(ctypes.byref(bad)) == 0 and L.lib().rmr_model_padded_size(ctypes.byref(bad)) == 0
     from remora_amd import RemoraError
 
     with pytest.raises(RemoraError):
