@@ -1265,7 +1265,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     if (!enc && fused_front_supported(m, seq_w, map_w) && (m->f16 || tune_int("RMR_FUSED", 1))) {
         // plain-bf16 ConvLSTM: two launches per sub-batch, x (bf16, 3 KB/chunk @C100) is the only intermediate in
         // HBM; sub-batches are sized so that x stays in the 256 MiB Infinity Cache between producer and consumer
-        int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_FUSED_SUBBATCH", 65536);
+        int64_t sb = e->subbatch > 0 ? e->subbatch : 65536;
         if (sb > n) sb = n;
         const size_t x_elems = (size_t)m->T * m->desc.size;
         RMR_TRY(e->ensure(e->act, x_elems * sb * sizeof(uint16_t)));
@@ -1274,7 +1274,8 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
             RMR_TRY(launch_fused_front(m, signal + (size_t)c0 * m->L, seqs + (size_t)c0 * seq_w, seq_w,
                                        maps + (size_t)c0 * map_w, map_w, lens + c0, nb, x16));
-            if (const char *dump = getenv("RMR_FUSED_DUMP_X")) {  // diagnostics (tools/stress_determinism.py): x of every sub-batch, appended
+#ifdef RMR_TIMING_ABLATIONS  // experiment build only (make abl; tools/stress_determinism.py): x of every sub-batch, appended
+            if (const char *dump = getenv("RMR_FUSED_DUMP_X")) {
                 std::vector<uint16_t> h(x_elems * nb);
                 RMR_HIP(hipStreamSynchronize(e->stream));
                 RMR_HIP(hipMemcpy(h.data(), x16, h.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
@@ -1283,7 +1284,8 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                     fclose(f);
                 }
             }
-            if (tune_int("RMR_DEBUG_SKIP_LSTM", 0)) continue;  // diagnostics: the front kernel alone (x through RMR_FUSED_DUMP_X)
+            if (abl_int("RMR_DEBUG_SKIP_LSTM", 0)) continue;  // the front kernel alone (x through RMR_FUSED_DUMP_X)
+#endif
             RMR_TRY(launch_lstm_head_x16(m, x16, nb, logits + (size_t)c0 * m->desc.num_out));
         }
         return 0;
@@ -1291,72 +1293,45 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
     const size_t per = act_floats_per_chunk(m);
     // 262144 chunks per sub-batch: the tail of every persistent-block kernel is paid half as often as with 131072
     // (+1.2 % measured; 524288: +0.2 % more for twice the 5.5 GB arena)
-    int64_t sb = e->subbatch > 0 ? e->subbatch : tune_int("RMR_SUBBATCH", 262144);
+    int64_t sb = e->subbatch > 0 ? e->subbatch : 262144;
     if (sb > n) sb = n;
     const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;
-    // front outputs (seq1, sig2) are double-buffered so that the front kernels of sub-batch i+1
-    // can run on the aux stream while the matrix kernels of sub-batch i run on the main stream
     // fp32 ConvLSTM size 64 straight from the chunk arrays: sig_conv1/2 and seq_conv1 are produced inside the staging of
-    // sig_conv3 / seq_conv2 (k_conv_front.hip); sig2 / seq1 never exist in HBM
-    const bool fold = !enc && tune_int("RMR_TWO_STREAM", 0) == 0 && tune_int("RMR_CONV_FRONT", 1) &&
-                      conv_front_supported(m, kb, ka, seq_w, map_w);
+    // sig_conv3 / seq_conv2 (k_conv_front.hip); sig2 / seq1 never exist in HBM.  (RMR_CONV_FRONT=0: the separate front
+    // kernels - the comparand of tests/test_gpu_conv_front.py)
+    const bool fold = !enc && tune_int("RMR_CONV_FRONT", 1) && conv_front_supported(m, kb, ka, seq_w, map_w);
     // every other fp32 path (Conv_w_ref; ConvLSTM shapes the two-branch fold does not cover): the signal branch alone is
     // folded - sig_conv1 / sig_conv2 (matrix cores) produced inside the staging of sig_conv3, sig2 never in HBM
-    const bool sigfold = !fold && m->nparts == 0 && tune_int("RMR_TWO_STREAM", 0) == 0 && sig3_front_mfma_supported(m);
+    const bool sigfold = !fold && m->nparts == 0 && sig3_front_mfma_supported(m);
+    // (Running the front kernels of sub-batch i + 1 on a second stream under the matrix kernels of sub-batch i was measured in
+    //  rounds 1-2 in two forms and gained nothing - they share the CUs with conv_sig3, or half a register file under the LSTM -
+    //  and is gone; profiles/NOTES_r03.md.)
     const size_t front_fl = fold ? 0 : (size_t)(m->P1 + m->P2) * 16;
     RMR_TRY(e->ensure(e->act, (per + front_fl) * sb * sizeof(float)));
-    // RMR_TWO_STREAM: 1 = front kernels of sub-batch i+1 on the aux stream from the start of sub-batch i (they then share
-    // the CUs with conv_sig3: no gain measured); 2 = released when merge_conv1 of sub-batch i is done, i.e. under its
-    // LSTM kernel (2 blocks of 4 waves per CU, half of the register file and 112 KB of LDS free)
-    const int ts_mode = n > sb ? tune_int("RMR_TWO_STREAM", 0) : 0;
-    const bool two_stream = ts_mode != 0, under_lstm = ts_mode == 2;
-    hipStream_t fs = two_stream ? e->aux : e->stream;
     float *arena = reinterpret_cast<float *>(e->act.ptr);
-    float *front_buf[2] = {arena, arena + front_fl * sb};
-    float *rest = arena + 2 * front_fl * sb;
-    if (two_stream) {  // inputs were produced on the main stream
-        RMR_HIP(hipEventRecord(e->ev_in, e->stream));
-        RMR_HIP(hipStreamWaitEvent(e->aux, e->ev_in, 0));
-    }
-    auto front = [&](int64_t c0, int64_t nb, int slot) -> int {
-        float *seq1 = front_buf[slot], *sig2 = seq1 + (size_t)nb * m->P1 * 16;
-        const float *sig_b = signal + (size_t)c0 * L;
-        if (enc) {
-            if (!sigfold) RMR_TRY(launch_front(m, fs, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
-            if (two_stream) {  // the dense seq_conv1 kernel runs on the main stream
-                RMR_HIP(hipEventRecord(e->ev_front[slot], fs));
-                RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_front[slot], 0));
-            }
-            RMR_TRY(launch_seq1_dense(m, enc + (size_t)c0 * EC * L, nb, seq1));
-        } else {
-            RMR_TRY(launch_front(m, fs, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
-                                 map_w, lens + c0, kb, ka, nb, sigfold ? nullptr : sig2, seq1));
-            if (two_stream) RMR_HIP(hipEventRecord(e->ev_front[slot], fs));
-        }
-        return 0;
-    };
-    int64_t idx = 0;
-    if (n > 0 && !fold) RMR_TRY(front(0, n < sb ? n : sb, 0));
-    for (int64_t c0 = 0; c0 < n; c0 += sb, ++idx) {
+    float *seq1 = arena, *rest = arena + front_fl * sb;
+    const bool split_conv = m->nparts > 0;
+    for (int64_t c0 = 0; c0 < n; c0 += sb) {
         const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
-        const int slot = (int)(idx & 1);
-        // launch the NEXT sub-batch's front kernels before this sub-batch's matrix kernels
-        if (c0 + sb < n && !under_lstm) {
-            const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
-            if (two_stream && idx >= 1) RMR_HIP(hipStreamWaitEvent(fs, e->ev_done[slot ^ 1], 0));
-            if (two_stream) RMR_TRY(front(c0 + sb, nn, slot ^ 1));
+        float *sig2 = seq1 + (size_t)nb * m->P1 * 16;
+        const float *sig_b = signal + (size_t)c0 * L;
+        if (!fold) {  // sig_conv1/2 -> sig2, seq_conv1 -> seq1 (k_front.hip)
+            if (enc) {
+                if (!sigfold) RMR_TRY(launch_front(m, e->stream, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
+                RMR_TRY(launch_seq1_dense(m, enc + (size_t)c0 * EC * L, nb, seq1));
+            } else {
+                RMR_TRY(launch_front(m, e->stream, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w, map_w, lens + c0, kb, ka,
+                                     nb, sigfold ? nullptr : sig2, seq1));
+            }
         }
-        if (two_stream && !enc) RMR_HIP(hipStreamWaitEvent(e->stream, e->ev_front[slot], 0));
-        float *seq1 = front_buf[slot], *sig2 = seq1 + (size_t)nb * m->P1 * 16;
         float *base = rest;
         float *cat = base; base += (size_t)nb * m->P3 * 2 * sz;
-        const bool split_conv = m->nparts > 0 && tune_int("RMR_SPLIT_CONV", 1);
-        if (fold) RMR_TRY(launch_conv_front(m, signal + (size_t)c0 * L, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w,
-                                            map_w, lens + c0, nb, cat));
+        if (fold) RMR_TRY(launch_conv_front(m, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w, map_w, lens + c0, nb, cat));
         else if (split_conv) RMR_TRY(launch_conv_split(e, m->sig3, m->nparts, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
-        else if (sigfold) RMR_TRY(launch_sig3_front_mfma(m, signal + (size_t)c0 * L, nb, cat));
+        else if (sigfold) RMR_TRY(launch_sig3_front_mfma(m, sig_b, nb, cat));
         else RMR_TRY(launch_conv(e, m->sig3, sig2, 16, m->P2, cat, 2 * sz, 0, m->P3, nb));
-        if (const char *dump = fold ? getenv("RMR_DUMP_CAT") : nullptr) {  // diagnostics (tools/stress_determinism.py): cat [nb][P3][2 sz]
+#ifdef RMR_TIMING_ABLATIONS  // experiment build only (tools/stress_determinism.py): cat [nb][P3][2 sz] of the last sub-batch
+        if (const char *dump = fold ? getenv("RMR_DUMP_CAT") : nullptr) {
             std::vector<float> h((size_t)nb * m->P3 * 2 * sz);
             RMR_HIP(hipStreamSynchronize(e->stream));
             RMR_HIP(hipMemcpy(h.data(), cat, h.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -1365,6 +1340,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                 fclose(f);
             }
         }
+#endif
         if (m->desc.arch == RMR_ARCH_CONV_LSTM) {
             float *x = base; base += (size_t)nb * m->T * sz;
             if (fold) {
@@ -1376,14 +1352,7 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                 RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, cat, 2 * sz, sz, m->P3, nb));
                 RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, x, sz, 0, m->T, nb));
             }
-            if (two_stream) RMR_HIP(hipEventRecord(e->ev_done[slot], e->stream));  // seq1/sig2[slot] consumed
-            if (under_lstm && c0 + sb < n) {  // the other slot was consumed a sub-batch ago (stream order)
-                const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
-                RMR_HIP(hipStreamWaitEvent(fs, e->ev_done[slot], 0));
-                RMR_TRY(front(c0 + sb, nn, slot ^ 1));
-            }
-            if (m->nparts > 0 && lstm_x16s_supported(m) && tune_int("RMR_LSTM_SPLIT_X16", 1))
-                RMR_TRY(launch_lstm_head_x16s(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
+            if (m->nparts > 0 && lstm_x16s_supported(m)) RMR_TRY(launch_lstm_head_x16s(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
             else if (m->nparts > 0) RMR_TRY(launch_lstm_head_split(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
             else RMR_TRY(launch_lstm_head(m, x, nb, logits + (size_t)c0 * m->desc.num_out));
         } else {
@@ -1393,17 +1362,12 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
             float *m3 = base; base += (size_t)nb * m->T3 * sz;
             float *m4 = base; base += (size_t)nb * m->T4 * sz;
             RMR_TRY(launch_conv(e, m->seq2, seq1, 16, m->P1, seq2, 32, 0, m->PQ2, nb));
-            if (two_stream) RMR_HIP(hipEventRecord(e->ev_done[slot], e->stream));
             RMR_TRY(launch_conv(e, m->seq3, seq2, 32, m->PQ2, cat, 2 * sz, sz, m->P3, nb));
             RMR_TRY(launch_conv(e, m->merge1, cat, 2 * sz, m->P3, m1, sz, 0, m->T, nb));
             RMR_TRY(launch_conv(e, m->merge2, m1, sz, m->T, m2, sz, 0, m->T2, nb));
             RMR_TRY(launch_conv(e, m->merge3, m2, sz, m->T2, m3, sz, 0, m->T3, nb));
             RMR_TRY(launch_conv(e, m->merge4, m3, sz, m->T3, m4, sz, 0, m->T4, nb));
             RMR_TRY(launch_fc_head(m, m4, nb, logits + (size_t)c0 * m->desc.num_out));
-        }
-        if (!two_stream && !fold && c0 + sb < n) {
-            const int64_t nn = (n - c0 - sb) < sb ? (n - c0 - sb) : sb;
-            RMR_TRY(front(c0 + sb, nn, slot ^ 1));
         }
     }
     return 0;
@@ -2126,7 +2090,7 @@ int rmr_call_read(rmr_model *m, const rmr_read *r, float *logits, int64_t *read_
     // of which cost a launch on the host and a blit kernel + a dependency gap on the stream - a sixth of the call
     // (profiles/NOTES_r05.md section 1d).  RMR_CALL_READ_ZERO_COPY: bit 0 the read's arrays, bit 1 the chunk geometry,
     // bit 2 the logits; 0 = the copies.
-    static const int zc = tune_int("RMR_CALL_READ_ZERO_COPY", 7);
+    static const int zc = 7;
     char *hp_dev = nullptr;
     if (zc) RMR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&hp_dev), hp, 0));
     memcpy(hp + o_dacs, r->dacs, (size_t)ns * 2);
@@ -2268,7 +2232,7 @@ int rmr_infer_chunks(rmr_model *m, const float *signal, const int8_t *seqs, int 
         const size_t o_seq = Stage::pad((size_t)hsb * L * 4), o_map = o_seq + Stage::pad((size_t)hsb * seq_w);
         const size_t o_len = o_map + Stage::pad((size_t)hsb * map_w * 2), slot_b = o_len + Stage::pad((size_t)hsb * 2);
         RMR_TRY(e->ensure_pinned(2 * slot_b));
-        const int nthr = (int)tune_int("RMR_HOST_COPY_THREADS", 4);
+        const int nthr = (int)4;
         int64_t idx = 0;
         for (int64_t c0 = 0; c0 < n; c0 += hsb, ++idx) {
             const int64_t nb = (n - c0) < hsb ? (n - c0) : hsb;

@@ -193,7 +193,7 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     constexpr int RS = (G % 2 == 0) ? IC / 4 + 4 : IC / 4;
     // chunks per iteration.  How many blocks a CU holds is set by the instantiation's registers (512 per SIMD lane, granule
     // 8: the 16-channel layers reach 3-4 waves per SIMD, merge_conv1's 160-register weight slice 2), so the LDS budget of a
-    // block is its share of the 160 KB at that occupancy, capped by RMR_CONV_LDS_BUDGET (72 KB: two blocks per CU).  Among the
+    // block is its share of the 160 KB at that occupancy, capped at 72 KB (two blocks per CU).  Among the
     // chunk counts that fit, the one whose columns fill their 16-column tiles best wins (Conv_w_ref's merge_conv1: 4 x 20
     // columns = 5 tiles exactly, where 5 chunks would pad the 7th tile to 25 %); ties go to the larger count.
     const int threads_pb = 64 * (c.oc / 16);
@@ -208,13 +208,9 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     int resident = wps * 4 / (threads_pb / 64);
     resident = resident < 1 ? 1 : (resident > 8 ? 8 : resident);
     const size_t row_bytes = (size_t)pin * RS * 4 * sizeof(float);  // all four planes
-    size_t budget = (size_t)tune_int("RMR_CONV_LDS_BUDGET", 73728);
-    if (tune_int("RMR_CONV_OCCUPANCY_CB", 1)) {
-        const size_t share = (size_t)160 * 1024 / resident - 512;
-        if (share < budget) budget = share;
-    } else {
-        budget /= (c.oc >= 64 ? 1 : 64 / c.oc);
-    }
+    size_t budget = (size_t)73728;
+    const size_t share = (size_t)160 * 1024 / resident - 512;
+    if (share < budget) budget = share;
     int cb_max = (int)(budget / row_bytes);
     if (cb_max < 1) cb_max = 1;
     if (cb_max > 8) cb_max = 8;
@@ -248,7 +244,7 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
     const int64_t iters = nwin > 1 ? n * nwin : (n + cb - 1) / cb;
     const int threads = threads_pb;
     // persistent blocks: a grid of several times the resident count evens out the tail
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8) * (c.oc >= 64 ? 1 : 64 / c.oc);
+    int64_t grid = (int64_t)e->num_cus * 8 * (c.oc >= 64 ? 1 : 64 / c.oc);
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_mfma_kernel<IC, KW, STRIDE>;

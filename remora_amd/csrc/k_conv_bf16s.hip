@@ -189,7 +189,7 @@ static int launch_conv_s_t(rmr_engine *e, const ConvLayer &c, const float *in, i
     constexpr int SLR = (KS % 2 == 0) ? KS + 1 : KS;
     constexpr int NPL = PAIR ? 2 : 4;
     const size_t chunk_bytes = (size_t)pin * SLR * 16 * NPL * NP;
-    int cb = (int)((size_t)tune_int("RMR_CONVS_LDS_BUDGET", 112 * 1024) / chunk_bytes);
+    int cb = (int)((size_t)(112 * 1024) / chunk_bytes);
     if (cb < 1) cb = 1;
     if (cb > 8) cb = 8;
     if (cb >= 4) cb &= ~3;
@@ -202,7 +202,7 @@ static int launch_conv_s_t(rmr_engine *e, const ConvLayer &c, const float *in, i
     a.in_row = in_row; a.pin = pin; a.pout = pout; a.out_row = out_row; a.out_coff = out_coff;
     a.cb = cb; a.plane = plane; a.part = part; a.div_pout = make_fastdiv(pout);
     const int64_t iters = (n + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONVS_BLOCKS_PER_CU", 2);
+    int64_t grid = (int64_t)e->num_cus * 2;
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_bf16s_kernel<IC, KW, STRIDE, NP, F16>;

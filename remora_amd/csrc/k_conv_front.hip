@@ -534,7 +534,7 @@ int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *
     }
     int resident = 512 / ((regs + 7) & ~7);
     resident = resident < 1 ? 1 : (resident > 4 ? 4 : resident);
-    size_t budget = (size_t)tune_int("RMR_CONV_FRONT_LDS_BUDGET", 73728);
+    size_t budget = (size_t)73728;
     const size_t share = (size_t)160 * 1024 / resident - 512;
     if (share < budget) budget = share;
     // score of a chunk count = tile fill of the matrix phase x balance of the producer phase (4 waves, one chunk at a time)
@@ -552,9 +552,9 @@ int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *
         if (score > best + 1e-9) { best = score; a.cb = k; a.plane = plane; a.o_front = 4 * plane + 16; lds = need; }
     }
     if (cb == 0) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples does not fit the LDS", m->L);
-    a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+    a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
     const int64_t iters = (n + a.cb - 1) / a.cb;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
+    int64_t grid = (int64_t)e->num_cus * 8;
     if (grid > iters) grid = iters;
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     ProfScope ps(e, K_SIG3_FRONT);
@@ -569,7 +569,7 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
     const int sz = m->desc.size, K = m->desc.kmer_len;
-    const int budget = tune_int("RMR_CONV_FRONT_LDS_BUDGET", 73728);
+    const int budget = 73728;
     auto up4 = [](int words) { return (words + 3) & ~3; };
     // The matrix-core producer is the default since round 4: bit-identical to the VALU one, 5.39 against 5.47 ns per chunk at
     // C100 (12.57 against 12.03 at C200), and it is the one that stayed exact next to foreign processes on the same GPU in
@@ -596,9 +596,9 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
             if (lds > CONV_FRONT_MAX_LDS) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples needs %zu B of LDS", m->L, lds);
         }
         a.cb = cb;
-        a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+        a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
         const int64_t iters = (n + cb - 1) / cb;
-        int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
+        int64_t grid = (int64_t)e->num_cus * 8;
         if (grid > iters) grid = iters;
         RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(sig3_front_kernel)));
         ProfScope ps(e, K_SIG3_FRONT);
@@ -632,9 +632,9 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
             if (lds > CONV_FRONT_MAX_LDS) RMR_FAIL(RMR_ERR_INVALID, "seq2_front: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
         }
         a.cb = cb;
-        a.abl = tune_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+        a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
         const int64_t iters = (n + cb - 1) / cb;
-        int64_t grid = (int64_t)e->num_cus * tune_int("RMR_CONV_BLOCKS_PER_CU", 8);
+        int64_t grid = (int64_t)e->num_cus * 8;
         if (grid > iters) grid = iters;
         RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(seq2_front_kernel<9>)));
         ProfScope ps(e, K_SEQ2_FRONT);

@@ -372,7 +372,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
         const int Lp = (m->L + 3) & ~3;
         const size_t lds = (size_t)a.cb * (Lp + m->P1 * 4) * 4;
         const int64_t iters = (n + a.cb - 1) / a.cb;
-        int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SIG_BLOCKS_PER_CU", 8);
+        int64_t grid = (int64_t)e->num_cus * 8;
         if (grid > iters) grid = iters;
         ProfScope ps(e, K_FRONT_SIG, st, true);
         if (kw == 5) hipLaunchKernelGGL(front_sig_kernel<5>, dim3((unsigned)grid), dim3(256), lds, st, a);
@@ -395,7 +395,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
     a.o_code = off; off += up4(a.maxlen * 2);
     a.o_pidx = off; off += up4((m->L * 2 + 3) / 4);
     // Conv_w_ref's released shape (11 taps, k-mer length 9): the tap-by-tap two-level kernel, one wave per chunk
-    if (kw == 11 && K == 9 && m->P1 * 4 <= 64 * 6 && a.maxlen <= 1024 && tune_int("RMR_FRONT_SEQ_TAP", 1) != 0) {
+    if (kw == 11 && K == 9 && m->P1 * 4 <= 64 * 6 && a.maxlen <= 1024) {
         int off = 0;
         a.o_map = off; off += up4((map_w * 2 + 3) / 4);
         a.o_seq = off; off += up4((seq_w + 3) / 4);
@@ -409,7 +409,7 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
         if (lds <= 80 * 1024) {  // two blocks (16 waves) per CU; longer rows fall through to the forms below
             auto kern = front_seq_tap_kernel<11, 9>;
             RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
-            int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SEQ_BLOCKS_PER_CU", 4);
+            int64_t grid = (int64_t)e->num_cus * 4;
             const int64_t need = (n + waves - 1) / waves;
             if (grid > need) grid = need;
             ProfScope ps(e, K_FRONT_SEQ, st, true);
@@ -418,20 +418,20 @@ int launch_front(rmr_model *m, hipStream_t st, const float *signal, const int8_t
             return 0;
         }
     }
-    const bool direct = (kw == 11) && tune_int("RMR_FRONT_SEQ_DIRECT", 1) != 0;
+    const bool direct = kw == 11;
     a.o_u = off; if (!direct) off += (a.maxlen + 1) * kw * 16;
     a.per_chunk = up4(off);
     const size_t fixed = (size_t)kw * K * 80 * 4;
     int cb = 8;
-    const size_t lds_cap = (size_t)tune_int("RMR_FRONT_SEQ_LDS_KB", 78) * 1024;
+    const size_t lds_cap = (size_t)78 * 1024;
     while (cb > 1 && fixed + (size_t)cb * a.per_chunk * 4 > lds_cap) cb >>= 1;
     const size_t lds = fixed + (size_t)cb * a.per_chunk * 4;
     if (lds > 160 * 1024) RMR_FAIL(RMR_ERR_INVALID, "front_seq: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
     a.cb = cb;
-    auto kern = (kw == 5) ? front_seq_kernel<5, false> : (direct ? front_seq_kernel<11, true> : front_seq_kernel<11, false>);
+    auto kern = (kw == 5) ? front_seq_kernel<5, false> : front_seq_kernel<11, true>;
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FRONT_SEQ_BLOCKS_PER_CU", direct ? 8 : 4);
+    int64_t grid = (int64_t)e->num_cus * (direct ? 8 : 4);
     if (grid > iters) grid = iters;
     ProfScope ps(e, K_FRONT_SEQ, st, true);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(32 * cb), lds, st, a);

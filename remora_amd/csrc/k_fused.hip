@@ -702,9 +702,9 @@ static int fused_front_plan(const rmr_model *m, int seq_w, int map_w, FusedArgs 
     }
     auto up16 = [](int b) { return (b + 15) & ~15; };
     // RMR_FUSED_WAVES_EU blocks are resident per CU (one wave of each per SIMD): each gets its share of the 160 KB
-    const int budget = tune_int("RMR_FUSED_LDS_BUDGET", (160 * 1024) / RMR_FUSED_WAVES_EU - 256);
+    const int budget = ((160 * 1024) / RMR_FUSED_WAVES_EU - 256);
     total = 0;
-    for (int cb = tune_int("RMR_FUSED_CB", 8); cb >= 1; --cb) {
+    for (int cb = 8; cb >= 1; --cb) {
         if (cb * a.L > 1024 || cb * seq_w > 256 || cb * map_w > 256) continue;
         int off = 0;
         a.o_sig = off; off += 256 * 16;  // input regions: one element per thread
@@ -777,9 +777,9 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     auto magic = [](int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };  // exact for x * d < 2^32
     a.mg_ps2 = magic((((a.P2 + 15) >> 4) + 1) >> 1);
     a.mg_pq1 = magic((((a.P1 + 15) >> 4) + 1) >> 1);
-    a.abl = tune_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+    a.abl = abl_int("RMR_FUSED_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
 #ifdef RMR_TIMING_ABLATIONS
-    const bool stage_clock = tune_int("RMR_FUSED_STAGE_CLOCK", 0) != 0;
+    const bool stage_clock = abl_int("RMR_FUSED_STAGE_CLOCK", 0) != 0;
     if (stage_clock) {
         a.abl |= 0x1000;
         static const unsigned long long zeros[4][16] = {};
@@ -795,7 +795,7 @@ int launch_fused_front(rmr_model *m, const float *signal, const int8_t *seqs, in
     auto kern = win ? pick(std::true_type{}) : pick(std::false_type{});
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
     const int64_t iters = (n * a.nwin + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_FUSED_BLOCKS_PER_CU", 2 * RMR_FUSED_WAVES_EU);
+    int64_t grid = (int64_t)e->num_cus * (2 * RMR_FUSED_WAVES_EU);
     if (grid > iters) grid = iters;
     ProfScope ps(e, K_FUSED_FRONT);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)total, e->stream, a);

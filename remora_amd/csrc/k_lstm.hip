@@ -30,7 +30,6 @@ struct LstmArgs {
     const float *a_ih1, *a_hh1, *b1, *a_ih2, *b2, *w_fc, *b_fc;
     int64_t n;
     int T, num_out;
-    int skew;  // s_sleep iterations for the second half of the grid (de-phases co-resident blocks)
 };
 
 // acc[gt] += A[gt][:] (register-resident weight slice) x B fragments read from one LDS image
@@ -156,12 +155,7 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
     const int st_row = tid / (H / 4), st_c4 = tid - st_row * (H / 4);
     const int st_q = st_c4 & 3, st_g = st_c4 >> 2;  // float4 index 4g+q -> plane q, group g
 
-    // Co-resident blocks start together and take identical time per group, so their load /
-    // epilogue phases would coincide for the whole launch; a one-off delay of every other
-    // block keeps one block's matrix work under the other's latency-bound phases.
-    if (blockIdx.x >= (gridDim.x + 1) / 2)
-        for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
-
+    // (a one-off delay of every other block, to de-phase co-resident blocks, measured no gain in round 2 and is gone)
     const int64_t n_groups = (a.n + 15) / 16;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t chunk0 = grp * 16;
@@ -256,14 +250,13 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
     a.x = x; a.logits = logits; a.n = n; a.T = m->T; a.num_out = m->desc.num_out;
     a.a_ih1 = m->lstm.a_ih1; a.a_hh1 = m->lstm.a_hh1; a.b1 = m->lstm.b1;
     a.a_ih2 = m->lstm.a_ih2; a.b2 = m->lstm.b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
-    a.skew = tune_int("RMR_LSTM_SKEW", 0);
     const int64_t groups = (n + 15) / 16;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTM_BLOCKS_PER_CU", 16);
+    int64_t grid = (int64_t)e->num_cus * 16;
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);
 #ifdef RMR_TIMING_ABLATIONS  // experiment builds only (make CXXFLAGS+=-DRMR_TIMING_ABLATIONS): variants that skip work
-    const int abl = tune_int("RMR_LSTM_ABLATE", 0);
+    const int abl = abl_int("RMR_LSTM_ABLATE", 0);
     if (abl == 1) hipLaunchKernelGGL((lstm_head_kernel<H, 1>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     else if (abl == 2) hipLaunchKernelGGL((lstm_head_kernel<H, 2>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
     else if (abl == 3) hipLaunchKernelGGL((lstm_head_kernel<H, 3>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);

@@ -278,7 +278,7 @@ static int launch_lstm_s_t(rmr_model *m, const float *x, int64_t n, float *logit
     a.a_ih = reinterpret_cast<const uint4 *>(m->lstm.s_ih1); a.a_hh = reinterpret_cast<const uint4 *>(m->lstm.s_hh1);
     a.b1 = m->lstm.b1; a.a_ih2 = m->lstm.a_ih2; a.b2 = m->lstm.b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
     const int64_t groups = (n + 15) / 16;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTMS_BLOCKS_PER_CU", 2);
+    int64_t grid = (int64_t)e->num_cus * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     ProfScope ps(e, K_LSTM_HEAD);

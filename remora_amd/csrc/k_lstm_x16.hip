@@ -83,142 +83,16 @@ __device__ __forceinline__ f32x2 lstm_cell2(const f32x4 acc0, const f32x4 acc1, 
     return og * tc;
 }
 
-template <bool F16>
-__global__ __launch_bounds__(512, 4) void lstm_x16_kernel(LstmXArgs a) {
-    // B-operand images (8 bf16 = 16 B per slot): plane p = 8-channel group (channel / 8) % 4, slot = channel / 32,
-    // rows = chunks; 3 slots per row (2 used) keep the 16-lane ds_read_b128 groups on distinct bank slots
-    __shared__ uint4 xs[2][4][16][3];
-    __shared__ uint4 hs[2][4][16][3];
-    __shared__ float part[8][16][16];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
-
-    uint4 Aih[2][2], Ahh[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            Aih[t][ks] = a.a_ih[((w * 2 + t) * 2 + ks) * 64 + lane];
-            Ahh[t][ks] = a.a_hh[((w * 2 + t) * 2 + ks) * 64 + lane];
-        }
-    f32x4 bias[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4 *>(a.b1 + ((w * 2 + t) * 4 + q) * 4);
-
-    // x staging role (threads 0..127): chunk row = tid >> 3, 8-channel group c8 = tid & 7 -> plane c8 & 3, slot c8 >> 2
-    const bool stager = tid < 128;
-    const int st_row = tid >> 3, st_c8 = tid & 7;
-    // this lane's two hidden units 8w + 2q, 8w + 2q + 1 sit in 8-channel group w: plane w & 3, slot w >> 2, bytes 4q..4q+3
-    const int h_plane = w & 3, h_slot = w >> 2;
-
-    const int64_t n_groups = (a.n + 15) / 16;
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const int64_t chunk0 = grp * 16;
-        int64_t st_chunk = chunk0 + st_row;
-        if (st_chunk >= a.n) st_chunk = a.n - 1;  // ragged tail: clamp (results masked)
-        const uint4 *xsrc = reinterpret_cast<const uint4 *>(a.x + (size_t)st_chunk * a.T * 64) + st_c8;
-        RMR_SYNC();  // the previous group's LDS traffic is done
-        if (stager) {
-            xs[0][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[0];
-            xs[1][st_c8 & 3][st_row][st_c8 >> 2] = xsrc[(size_t)(a.T > 1 ? 1 : 0) * 8];
-        }
-        RMR_SYNC();
-
-        float c[2] = {0.f, 0.f};
-        f32x4 accN[2];  // bias + W_ih x_t of the step about to run
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            accN[t] = bias[t];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) accN[t] = mfma16<F16>(Aih[t][ks], xs[0][q][nn][ks], accN[t]);
-        }
-        // step 0 ends with the stagers overwriting xs[0] (x_2): every wave must have read x_0 above before any stager gets
-        // there.  Without this barrier a wave held up for longer than one step (other processes' waves on its SIMD) projected
-        // x_2 for x_0 in eight chunks: the runs that differed when several processes shared the GPU (profiles/NOTES_r04.md)
-        RMR_SYNC();
-        // one time step; LAST (the step whose h feeds lstm2 through a swish, models/ConvLSTM_w_ref.py:52) is a compile-time
-        // flag: as a run-time test hipcc turned it into selects and every step paid the swish's two exp + two rcp
-        auto step = [&](const int t, auto last_c) {
-            constexpr bool LAST = decltype(last_c)::value;
-            const int tf = (t + 2 < a.T) ? t + 2 : a.T - 1;  // x_{t+2} (the last two fetches are redundant re-reads)
-            uint4 xnext = make_uint4(0, 0, 0, 0);
-            if (stager) xnext = xsrc[(size_t)tf * 8];
-            f32x4 acc[2] = {accN[0], accN[1]};
-            const uint4 bx0 = xs[(t + 1) & 1][q][nn][0], bx1 = xs[(t + 1) & 1][q][nn][1];
-            if (t > 0) {  // recurrent critical path: W_hh h_{t-1}
-                const uint4 bh0 = hs[(t - 1) & 1][q][nn][0], bh1 = hs[(t - 1) & 1][q][nn][1];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    acc[u] = mfma16<F16>(Ahh[u][0], bh0, acc[u]);
-                    acc[u] = mfma16<F16>(Ahh[u][1], bh1, acc[u]);
-                }
-            }
-            // input projection of the next step (in the last step it projects a stale, finite tile: dropped)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                accN[u] = mfma16<F16>(Aih[u][0], bx0, bias[u]);
-                accN[u] = mfma16<F16>(Aih[u][1], bx1, accN[u]);
-            }
-            const f32x2 hh = lstm_cell2(acc[0], acc[1], c[0], c[1]);
-            float h0 = hh.x, h1 = hh.y;
-            if constexpr (LAST) {  // lstm2 consumes swish(h1[T-1])
-                h0 = swish_f(h0);
-                h1 = swish_f(h1);
-            }
-            unsigned hp;
-            if constexpr (F16) hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)h0, (_Float16)h1});
-            else hp = __builtin_bit_cast(unsigned, bf16x2{(__bf16)h0, (__bf16)h1});
-            reinterpret_cast<unsigned *>(&hs[t & 1][h_plane][nn][h_slot])[q] = hp;
-            if (stager) xs[t & 1][st_c8 & 3][st_row][st_c8 >> 2] = xnext;  // the buffer whose last reader was step t-1
-            RMR_SYNC();
-        };
-        for (int t = 0; t + 1 < a.T; ++t) step(t, std::false_type{});
-        step(a.T - 1, std::true_type{});
-        // ---- lstm2: one step on swish(h1[T-1]) with zero state (the f gate meets c0 = 0) ----
-        f32x4 acc2[2];
-        {
-            const uint4 bh0 = hs[(a.T - 1) & 1][q][nn][0], bh1 = hs[(a.T - 1) & 1][q][nn][1];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                acc2[u] = *reinterpret_cast<const f32x4 *>(a.b2 + ((w * 2 + u) * 4 + q) * 4);
-                acc2[u] = mfma16<F16>(a.a_ih2[((w * 2 + u) * 2 + 0) * 64 + lane], bh0, acc2[u]);
-                acc2[u] = mfma16<F16>(a.a_ih2[((w * 2 + u) * 2 + 1) * 64 + lane], bh1, acc2[u]);
-            }
-        }
-        float y[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float c2 = 0.f;
-            y[u] = swish_f(lstm_cell(acc2[u], c2));  // c2 = sig(i) tanh(g); h2 = sig(o) tanh(c2)
-        }
-        // ---- fc: this lane's two hidden units, reduced over q (lanes) then over the 8 waves (LDS) ----
-        const int u0 = 8 * w + 2 * q;
-        for (int o = 0; o < a.num_out; ++o) {
-            float p = a.w_fc[(size_t)o * 64 + u0] * y[0] + a.w_fc[(size_t)o * 64 + u0 + 1] * y[1];
-            p += __shfl_xor(p, 16);
-            p += __shfl_xor(p, 32);
-            if (q == 0) part[w][nn][o] = p;
-        }
-        RMR_SYNC();
-        if (tid < 16 * a.num_out) {
-            const int ch = tid / a.num_out, o = tid - ch * a.num_out;
-            if (chunk0 + ch < a.n) {
-                float s = a.b_fc[o];
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) s += part[ww][ch][o];
-                a.logits[(size_t)(chunk0 + ch) * a.num_out + o] = s;
-            }
-        }
-    }
-}
-
-// Two 16-chunk groups per block iteration (round 4, the default; RMR_LSTMX_GROUPS=1 selects the kernel above): a wave issues
+// Two 16-chunk groups per block iteration (round 4; the one-group kernel it replaced - 2.38 against 2.22 ns per chunk at C100 -
+// left the library in round 6): a wave issues
 // the MFMAs of both groups before the gate math of the first, so the matrix pipe works on group B while the VALU works on
 // group A, every dependent chain (LDS read -> MFMA -> gates -> LDS write) has an independent twin to fill its bubbles, and a
 // block barrier is paid once per two groups.  Per chunk the same operations in the same order: bit-identical logits.
 // 128 VGPRs (two spilled), still four waves per SIMD.
 template <bool F16>
 __global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
+    // B-operand images (8 bf16 = 16 B per slot): plane p = 8-channel group (channel / 8) % 4, slot = channel / 32, rows = chunks;
+    // 3 slots per row (2 used) keep the 16-lane ds_read_b128 groups on distinct bank slots
     __shared__ uint4 xs[2][2][4][16][3];  // [buffer][group][plane][chunk row][slot]
     __shared__ uint4 hs[2][2][4][16][3];
     __shared__ float part[2][8][16][16];
@@ -240,6 +114,7 @@ __global__ __launch_bounds__(512, 4) void lstm_x16_g2_kernel(LstmXArgs a) {
     // x staging: threads 0..255, 128 per group (waves 0,1 -> group 0; waves 2,3 -> group 1)
     const bool stager = tid < 256;
     const int sg = (tid >> 7) & 1, st = tid & 127, st_row = st >> 3, st_c8 = st & 7;
+    // this lane's two hidden units 8w + 2q, 8w + 2q + 1 sit in 8-channel group w: plane w & 3, slot w >> 2, bytes 4q..4q+3
     const int h_plane = w & 3, h_slot = w >> 2;
 
     const int64_t n_pairs = (a.n + 31) / 32;
@@ -365,21 +240,14 @@ int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logi
     a.a_ih = reinterpret_cast<const uint4 *>(m->lstm.x_ih); a.a_hh = reinterpret_cast<const uint4 *>(m->lstm.x_hh);
     a.a_ih2 = reinterpret_cast<const uint4 *>(m->lstm.x_ih2);
     a.b1 = m->lstm.x_b1; a.b2 = m->lstm.x_b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
-    const int64_t groups = (n + 15) / 16;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTMX_BLOCKS_PER_CU", 4);
-    if (grid > groups) grid = groups;
+    // two 16-chunk groups per block iteration (the one-group kernel measured 2.38 against 2.22 ns per chunk at C100, 5.58 against
+    // 4.84 at C200 and is gone)
+    const int64_t pairs = (n + 31) / 32;
+    int64_t grid2 = (int64_t)e->num_cus * 4;
+    if (grid2 > pairs) grid2 = pairs;
     ProfScope ps(e, K_LSTM_HEAD);
-    if (tune_int("RMR_LSTMX_GROUPS", 2) == 2) {  // (1 = the one-group kernel: 2.38 against 2.22 ns per chunk at C100, 5.58 against 4.84 at C200)
-        const int64_t pairs = (n + 31) / 32;
-        int64_t grid2 = (int64_t)e->num_cus * tune_int("RMR_LSTMX_BLOCKS_PER_CU", 4);
-        if (grid2 > pairs) grid2 = pairs;
-        if (m->f16) hipLaunchKernelGGL(lstm_x16_g2_kernel<true>, dim3((unsigned)grid2), dim3(512), 0, e->stream, a);
-        else hipLaunchKernelGGL(lstm_x16_g2_kernel<false>, dim3((unsigned)grid2), dim3(512), 0, e->stream, a);
-        RMR_HIP(hipGetLastError());
-        return 0;
-    }
-    if (m->f16) hipLaunchKernelGGL(lstm_x16_kernel<true>, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
-    else hipLaunchKernelGGL(lstm_x16_kernel<false>, dim3((unsigned)grid), dim3(512), 0, e->stream, a);
+    if (m->f16) hipLaunchKernelGGL(lstm_x16_g2_kernel<true>, dim3((unsigned)grid2), dim3(512), 0, e->stream, a);
+    else hipLaunchKernelGGL(lstm_x16_g2_kernel<false>, dim3((unsigned)grid2), dim3(512), 0, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }

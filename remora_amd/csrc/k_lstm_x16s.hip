@@ -260,7 +260,7 @@ int launch_lstm_head_x16s(rmr_model *m, const float *x, int64_t n, float *logits
     a.a_ih2 = reinterpret_cast<const uint4 *>(m->lstm.xs_ih2);
     a.b1 = m->lstm.x_b1; a.b2 = m->lstm.x_b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
     const int64_t groups = (n + 15) / 16;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_LSTMXS_BLOCKS_PER_CU", 8);
+    int64_t grid = (int64_t)e->num_cus * 8;
     if (grid > groups) grid = groups;
     ProfScope ps(e, K_LSTM_HEAD);
     if (m->split_f16) hipLaunchKernelGGL((lstm_x16s_kernel<2, true>), dim3((unsigned)grid), dim3(512), 0, e->stream, a);

@@ -961,7 +961,7 @@ int rmr_refiner_create(rmr_engine *e, const rmr_refine_desc *desc, rmr_refiner *
     if (he == hipSuccess && r->sd_len) he = hipMalloc(&r->d_sdp, (size_t)r->sd_len * 4);
     if (he == hipSuccess) he = hipMemcpy(r->d_levels, desc->kmer_levels, nk * 4, hipMemcpyHostToDevice);
     if (he == hipSuccess && r->sd_len) he = hipMemcpy(r->d_sdp, desc->sd_arr, (size_t)r->sd_len * 4, hipMemcpyHostToDevice);
-    r->max_grid = e->num_cus * tune_int("RMR_REFINE_WAVES_PER_CU", 16);
+    r->max_grid = e->num_cus * 16;
     if (he == hipSuccess) he = hipMalloc(&r->d_counter, 256);
     if (he == hipSuccess && r->sd_len && r->sd_len <= kMaxD)
         he = hipMalloc(&r->d_ckpt, (size_t)r->max_grid * kCk * (13 + 4 * r->sd_len) * 64 * sizeof(uint32_t));
@@ -1079,7 +1079,7 @@ int rmr_refine_signal_maps(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs
     RMR_HIP(hipStreamSynchronize(e->stream));
 
     const bool force_rowwise = tune_int("RMR_REFINE_ROWWISE", 0) != 0 || rf->sd_len > kMaxD;
-    const int64_t cap_cells = (int64_t)tune_int("RMR_REFINE_TB_MIB", 32768) * (1 << 19);
+    const int64_t cap_cells = (int64_t)32768 * (1 << 19);
     std::vector<int32_t> l16, l64, todo;
     if (!force_rowwise) {
         // 16 lanes per read (4 reads per wave) when no sample is shared by more than 16 rows, else 64;
@@ -1195,7 +1195,7 @@ int rmr_rescale_quantiles(rmr_refiner *rf, int64_t n_reads, const int16_t *dacs,
     RMR_HIP(hipMemcpyAsync(d_q, quants, (size_t)n_quants * 8, hipMemcpyHostToDevice, e->stream));
     // LDS holds the kept bases of one read as float64, padded to a power of two: sized for the longest read the caller
     // names (0: unknown), at most 16384 (128 KB); longer reads come back with status 1
-    const int cap = std::min(16384, std::max(64, tune_int("RMR_RESCALE_MAX_BASES", 16384)));
+    const int cap = std::min(16384, std::max(64, 16384));
     int max_pad = 64;
     while (max_pad < cap && (max_read_bases <= 0 || max_pad < max_read_bases)) max_pad <<= 1;
     RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(rmr::rescale_quantiles_kernel)));

@@ -158,7 +158,7 @@ static int launch_conv_stream_t(rmr_engine *e, const ConvLayer &c, const float *
             if (OT % d == 0) { nw = d; break; }
     }
     const size_t row_bytes = (size_t)pin * RS * 4 * sizeof(float);  // all four planes
-    const size_t budget = (size_t)tune_int("RMR_STREAM_CONV_LDS", 65536);  // two blocks per CU
+    const size_t budget = (size_t)65536;  // two blocks per CU
     int cb_max = (int)(budget / row_bytes);
     if (cb_max < 1) cb_max = 1;
     if (cb_max > 8) cb_max = 8;
@@ -180,7 +180,7 @@ static int launch_conv_stream_t(rmr_engine *e, const ConvLayer &c, const float *
     a.cb = cb; a.plane = plane; a.rs = RS;
     a.div_pout = make_fastdiv(pout); a.div_r4 = make_fastdiv(c.ic / 4); a.div_g = make_fastdiv(G);
     const int64_t iters = (n + cb - 1) / cb;
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_STREAM_CONV_BLOCKS_PER_CU", 4);
+    int64_t grid = (int64_t)e->num_cus * 4;
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;
     auto kern = conv_stream_kernel<KW, STRIDE>;
@@ -374,7 +374,7 @@ static int launch_lstm_stream_t(rmr_model *m, const LstmSArgs &a, int64_t n) {
     const size_t lds = (size_t)4 * 4 * 16 * NT * a.rs * sizeof(float);
     if (lds > 160 * 1024 - 256) RMR_FAIL(RMR_ERR_INVALID, "streamed LSTM: %zu B of LDS for %d hidden units", lds, H);
     const int64_t groups = (n + 16 * NT - 1) / (16 * NT);
-    int64_t grid = (int64_t)e->num_cus * tune_int("RMR_STREAM_LSTM_BLOCKS_PER_CU", 4);
+    int64_t grid = (int64_t)e->num_cus * 4;
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
     auto kern = lstm_stream_kernel<NT, MAXT>;
@@ -396,7 +396,7 @@ int launch_lstm_stream(rmr_model *m, const float *x, int64_t n, float *logits) {
     a.a_ih1 = m->lstm.t_ih1; a.a_hh1 = m->lstm.t_hh1; a.b1 = m->lstm.b1;
     a.a_ih2 = m->lstm.t_ih2; a.b2 = m->lstm.b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
     // column tiles per wave: four halve the weight traffic of two, and fit (registers: 512 threads; LDS) up to 128 units
-    const int nt = tune_int("RMR_STREAM_LSTM_NT", H <= 128 ? 4 : 2);
+    const int nt = (H <= 128 ? 4 : 2);
     if (H <= 128 && nt == 4) return launch_lstm_stream_t<4, 512>(m, a, n);
     if (H <= 128) return launch_lstm_stream_t<2, 512>(m, a, n);
     return launch_lstm_stream_t<2, 1024>(m, a, n);

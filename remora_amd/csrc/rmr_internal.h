@@ -290,10 +290,20 @@ bool lstm_x16s_supported(const rmr_model *m);
 int launch_lstm_head_x16s(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_lstm_head_x16(rmr_model *m, const uint16_t *x, int64_t n, float *logits);
 
-// integer tuning knob from the environment (read once per call site; for experiments only)
+// integer switch from the environment (DESIGN.md has the table of every name the product reads)
 inline int tune_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+// the same for the knobs of the experiment build (make abl: -DRMR_TIMING_ABLATIONS); the shipped library returns the default
+// without looking at the environment, so none of them is a configuration of the product
+inline int abl_int(const char *name, int dflt) {
+#ifdef RMR_TIMING_ABLATIONS
+    return tune_int(name, dflt);
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 // fast integer division by a small runtime constant (exact for 0 <= x < 2^24, d < 2^12)

@@ -70,20 +70,24 @@ def synth_read(n_bases=5000, dwell_lo=5, dwell_hi=15, seed=20240926, idx=0):
     return dict(dacs=dacs, seq_to_sig_map=s2s, int_seq=int_seq, shift=500.0, scale=80.0)
 
 
-def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0):
+def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0, amplify=True):
     """Random weights with the reference architectures' tensor names/shapes
     (models/ConvLSTM_w_ref.py:11-37, models/Conv_w_ref.py:11-42): uniform(-1/sqrt(fan_in), ..)
     like torch's default init, BatchNorm running stats randomised (mean~N(0,1), var~U(0.5,2),
-    gamma~N(1,0.2), beta~N(0,0.2)) so that folding matters."""
+    gamma~N(1,0.2), beta~N(0,0.2)) so that folding matters.  `amplify` (default): conv weights x 2.45, LSTM weights x 2.5,
+    forget-gate bias + 2, fc x 12 - a network that carries input variation (and rounding) to the logits, for tests that
+    must not be blind to early layers; False: torch's default bounds everywhere (the scale of a reference-initialised
+    network, e.g. the golden models)."""
     rng = np.random.default_rng(1000 + seed)
     st = {}
+    ca, la, fa = (2.45, 2.5, 12.0) if amplify else (1.0, 1.0, 1.0)
 
     def conv(name, bn, ic, oc, k):
         b = 1.0 / np.sqrt(ic * k)
         # He-scale weights (x2.45 torch's default bound) so that input variation survives to the
         # logits: with the default bound the random BN offsets swamp the signal and every chunk
         # gets nearly the same logits, which would make parity tests blind to early-layer bugs
-        st[f"{name}.weight"] = rng.uniform(-2.45 * b, 2.45 * b, (oc, ic, k)).astype(np.float32)
+        st[f"{name}.weight"] = rng.uniform(-ca * b, ca * b, (oc, ic, k)).astype(np.float32)
         st[f"{name}.bias"] = rng.uniform(-b, b, oc).astype(np.float32)
         st[f"{bn}.weight"] = (1.0 + 0.2 * rng.standard_normal(oc)).astype(np.float32)
         st[f"{bn}.bias"] = (0.2 * rng.standard_normal(oc)).astype(np.float32)
@@ -98,10 +102,11 @@ def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0):
         conv("merge_conv1", "merge_bn", 2 * size, size, 5)
         b = 1.0 / np.sqrt(size)
         for l in ("lstm1", "lstm2"):
-            st[f"{l}.weight_ih_l0"] = rng.uniform(-2.5 * b, 2.5 * b, (4 * size, size)).astype(np.float32)
-            st[f"{l}.weight_hh_l0"] = rng.uniform(-2.5 * b, 2.5 * b, (4 * size, size)).astype(np.float32)
+            st[f"{l}.weight_ih_l0"] = rng.uniform(-la * b, la * b, (4 * size, size)).astype(np.float32)
+            st[f"{l}.weight_hh_l0"] = rng.uniform(-la * b, la * b, (4 * size, size)).astype(np.float32)
             st[f"{l}.bias_ih_l0"] = rng.uniform(-b, b, 4 * size).astype(np.float32)
-            st[f"{l}.bias_ih_l0"][size : 2 * size] += 2.0  # forget-gate bias: longer memory, as in trained LSTMs
+            if amplify:
+                st[f"{l}.bias_ih_l0"][size : 2 * size] += 2.0  # forget-gate bias: longer memory, as in trained LSTMs
             st[f"{l}.bias_hh_l0"] = rng.uniform(-b, b, 4 * size).astype(np.float32)
         fin = size
     else:
@@ -112,7 +117,7 @@ def synth_state(arch="conv_lstm", size=64, kmer_len=9, num_out=2, seed=0):
         conv("merge_conv1", "merge_bn1", 2 * size, size, 5); conv("merge_conv2", "merge_bn2", size, size, 5)
         conv("merge_conv3", "merge_bn3", size, size, 3); conv("merge_conv4", "merge_bn4", size, size, 3)
         fin = size * 3
-    b = (12.0 if arch == "conv_lstm" else 1.5) / np.sqrt(fin)  # logits within a few units
+    b = ((fa if arch == "conv_lstm" else 1.5) if amplify else 1.0) / np.sqrt(fin)  # (amplified: logits within a few units)
     st["fc.weight"] = rng.uniform(-b, b, (num_out, fin)).astype(np.float32)
     st["fc.bias"] = rng.uniform(-b, b, num_out).astype(np.float32)
     return st

@@ -1591,9 +1591,11 @@ def test_host_buffer_path_pipelined_upload_matches_device_path(torch_cuda):
         assert np.array_equal(hc, dc.cpu().numpy()) and hc.sum() == n
 
 
-def test_streamed_read_batches_equal_batched_calls(torch_cuda):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16"])
+def test_streamed_read_batches_equal_batched_calls(torch_cuda, dtype):
     """iter_call_reads_mods (staging of the next batch in a worker thread on its own stream) returns, batch by
-    batch, exactly what call_reads_mods returns - without a refiner and with one (rough re-scale + banded DP)."""
+    batch, exactly what call_reads_mods returns - without a refiner and with one (rough re-scale + banded DP) - with the
+    fp32 model and with the 16-bit models (whose streamed rate bench.py reports)."""
     sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
     import sys
 
@@ -1607,7 +1609,7 @@ def test_streamed_read_batches_equal_batched_calls(torch_cuda):
 
     md = dict(chunk_context=(50, 50), kmer_context_bases=(4, 4), motifs=[("CG", 0)], mod_bases=["m"], mod_long_names=["5mC"],
               can_base="C", base_start_justify=False, offset=0, sig_map_refiner=None)
-    model = model_from_state(synth.synth_state(seed=4), md, device=0)
+    model = model_from_state(synth.synth_state(seed=4), md, device=0, dtype=dtype)
     table, center, base = bench_refine.synth_reads(40, 1500, seed=9)
     refiner = SigMapRefiner(_levels_array=table, center_idx=center, do_rough_rescale=True, scale_iters=0)
 
