@@ -573,8 +573,8 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
     auto up4 = [](int words) { return (words + 3) & ~3; };
     // The matrix-core producer is the default since round 4: bit-identical to the VALU one, 5.39 against 5.47 ns per chunk at
     // C100 (12.57 against 12.03 at C200), and it is the one that stayed exact next to foreign processes on the same GPU in
-    // every run (rmr_math.h, pk_fma).  RMR_SIG3_MFMA_LSTM=0 selects the VALU producer.
-    if (tune_int("RMR_SIG3_MFMA_LSTM", 1) != 0 && sig3_front_mfma_supported(m)) {
+    // every run (rmr_math.h, pk_fma).  RMR_SIG3_MFMA=0 selects the VALU producers (the comparand of tests/test_gpu_conv_front.py).
+    if (sig3_front_mfma_supported(m)) {
         RMR_TRY(launch_sig3_front_mfma(m, signal, n, cat));
     } else {   // ---- signal branch, VALU producer ----
         ConvFrontArgs a{};

@@ -59,12 +59,11 @@ void narrow_i64_to_i8(const void *src, int64_t n, int8_t *dst) {
 void stream_copy(void *dst, const void *src, size_t n) {
     char *d = static_cast<char *>(dst);
     const char *s = static_cast<const char *>(src);
-    static const bool stream = !(getenv("RMR_PACK_STREAM") && atoi(getenv("RMR_PACK_STREAM")) == 0);  // 0: plain memcpy (A/B)
 #if !defined(__SSE2__)
     memcpy(d, s, n);  // no streaming stores on this host: the plain copy
     return;
 #else
-    if (n < 2048 || !stream) {
+    if (n < 2048) {
         memcpy(d, s, n);
         return;
     }

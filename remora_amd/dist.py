@@ -100,7 +100,7 @@ def init_process_group(backend=None, set_device=True, timeout_s=None):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: never resolve the container's hostname
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         global _HOST_GROUP
-        if backend == "nccl" and world > 1 and _HOST_GROUP is None and os.environ.get("REMORA_AMD_DIST_SIDE_CHANNEL", "1") != "0":
+        if backend == "nccl" and world > 1 and _HOST_GROUP is None:
             try:  # rendezvous over the store only: no RCCL traffic
                 _HOST_GROUP = dist.new_group(backend="gloo", **kw)
             except Exception as e:  # noqa: BLE001 - without it a failing RCCL is simply a failed run, as before
@@ -402,7 +402,7 @@ def setup_ranks(gpus, procs_per_gpu=1, backend=None, timeout_s=600.0):
         torch.cuda.set_device(device)
         global LAST_BINDING
         LAST_BINDING = bind_rank(device, local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), procs_per_gpu)
-        if os.environ.get("RMR_INFER_TIMING") or os.environ.get("REMORA_AMD_PRINT_BINDING"):
+        if os.environ.get("RMR_INFER_TIMING"):
             import sys
 
             b = LAST_BINDING

@@ -238,9 +238,6 @@ def _subbatch_cuts(n, sub, lead=None):
     (default sub / 4, sub / 2; the 16-bit models, whose kernels outrun the staging, start on sub / 8:
     profiles/r05_ab_reads_lead_cuts.log)."""
     cuts, pos = [], 0
-    env = os.environ.get("RMR_READS_LEAD_CUTS")  # (experiments: e.g. "64,192")
-    if env:
-        lead = [int(x) for x in env.split(",")]
     for size in (lead or (sub // 4, sub // 2)):
         size = max(1, int(size))
         if pos < n:
@@ -472,7 +469,7 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             return
         n = len(items)
         good_pos = np.asarray([k for k, it in enumerate(items) if it is None], np.int64)
-        if len(mds) == 1 and not ref_anchored and os.environ.get("RMR_NATIVE_TAGS", "1") != "0":
+        if len(mds) == 1 and not ref_anchored:
             # one model, basecall-anchored (the common case): MM/ML strings and the rewritten records of the whole batch in
             # two native calls (rmr_format_mm_ml, rmr_records_with_mod_tags) - byte for byte the per-read Python path below
             has = np.zeros(n, np.uint8)

@@ -1706,12 +1706,12 @@ def _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_a
     Reads without sm / sd tags get the median / MAD scaling from GPU histograms of their trimmed signal (_median_mad_scaling).
     A batch that holds something the array form does not reproduce (negative trim tags, bases outside A-Z, an aligned record
     without a move table) is returned as the string "slow": the caller sends its records through the per-read path.
-    RMR_INGEST_TIMING=1: seconds per section accumulate in io.INGEST_CLOCK (tools/prof_ingest_batches.py prints them)."""
+    RMR_INFER_TIMING=1: seconds per section accumulate in io.INGEST_CLOCK (tools/prof_ingest_batches.py prints them)."""
     import torch
 
     from .data_chunks import DeviceReads
 
-    clock = _section_clock() if os.environ.get("RMR_INGEST_TIMING") else (lambda name: None)
+    clock = _section_clock() if os.environ.get("RMR_INFER_TIMING") else (lambda name: None)
     n_all = rb.n
     flag = rb.flag
     keep_mask = np.ones(n_all, bool) if not skip_non_primary else (flag & 0x900) == 0
@@ -1960,8 +1960,7 @@ def iter_ingest_batches(pod5_path, bam_path, pa_scaling=None, skip_non_primary=T
     signals = Pod5File(pod5_path)
     eng = get_ingest_engine(device)
     raw_batches = iter_bam_raw_batches(bam_path, want_ref=bool(ref_anchored), batch=batch, shard=shard)
-    if os.environ.get("RMR_BAM_READAHEAD", "1") != "0":
-        raw_batches = _readahead(raw_batches, 2)
+    raw_batches = _readahead(raw_batches, 2)  # the native parser releases the GIL: BAM batches are read one ahead
     for rb, records in raw_batches:
         got = _ingest_batch(rb, records, signals, eng, pa_scaling, skip_non_primary, ref_anchored=ref_anchored)
         if got is None:
@@ -2088,13 +2087,9 @@ def records_with_mod_tags_flat(raw, raw_start, raw_len, tags_off, mm, mm_off, ml
 
 
 _BGZF_LEVEL = int(os.environ.get("RMR_BAM_LEVEL", "6"))  # htslib's default level
-# RMR_BAM_STRATEGY = huffman | rle: zlib's Z_HUFFMAN_ONLY / Z_RLE - 1.9x / 1.4x the speed of level 1 on BAM records with
-# move tables for a 19 % / 15 % larger file (still plain deflate: any reader takes it)
-# Level 1 (`--bam-level 1`: "fast") takes Huffman-only unless RMR_BAM_STRATEGY says otherwise (default = zlib's own matcher):
-# 28.1 k -> 33.2 k reads/s file to file with six processes on 16 cores, 3.3 -> 3.9 GB of output
-# (profiles/r03_infer_cli_336k_byte_shares_huffman.log)
-_BGZF_STRATEGIES = {"huffman": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE, "default": zlib.Z_DEFAULT_STRATEGY}
-_BGZF_STRATEGY = _BGZF_STRATEGIES.get(os.environ.get("RMR_BAM_STRATEGY", ""))  # None: by level
+# Level 1 (`--bam-level 1`: "fast") takes zlib's Z_HUFFMAN_ONLY - 1.9x the speed of level 1's matcher on BAM records with move
+# tables for a 19 % larger file (still plain deflate: any reader takes it): 28.1 k -> 33.2 k reads/s file to file with six
+# processes on 16 cores, 3.3 -> 3.9 GB of output (profiles/r03_infer_cli_336k_byte_shares_huffman.log); other levels: zlib's matcher
 
 
 def _eff_cpus():
@@ -2106,7 +2101,7 @@ def _eff_cpus():
 def _bgzf_block(chunk, level=None):
     """One BGZF member (gzip with the BC extra field) for up to 64 KiB of payload."""
     level = _BGZF_LEVEL if level is None else int(level)
-    strategy = _BGZF_STRATEGY if _BGZF_STRATEGY is not None else (zlib.Z_HUFFMAN_ONLY if level == 1 else zlib.Z_DEFAULT_STRATEGY)
+    strategy = zlib.Z_HUFFMAN_ONLY if level == 1 else zlib.Z_DEFAULT_STRATEGY
     comp = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
     cdata = comp.compress(chunk) + comp.flush()
     return b"".join((b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00", struct.pack("<H", len(cdata) + 25),
@@ -2143,7 +2138,7 @@ class BamWriter:
             # the cores this process may really use (cgroup quota, not os.cpu_count()), shared with the other ranks of
             # the node when several processes run side by side
             local_ranks = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1), 1)
-            threads = int(os.environ.get("RMR_BAM_THREADS", "0")) or min(16, max(4, effective_cpu_count() // local_ranks))
+            threads = min(16, max(4, effective_cpu_count() // local_ranks))
         if max_pending is None:
             max_pending = 8 * int(threads)
 
@@ -2156,7 +2151,7 @@ class BamWriter:
         # level 1 with the default strategy (Huffman coding only): the library's own encoder, 2.5x zlib's on BAM records;
         # whole runs of 16 payloads per job instead of one payload per job (RMR_BGZF_NATIVE=0: zlib for these too)
         lvl = _BGZF_LEVEL if level is None else int(level)
-        self._native = lvl == 1 and _BGZF_STRATEGY is None and os.environ.get("RMR_BGZF_NATIVE", "1") != "0"
+        self._native = lvl == 1 and os.environ.get("RMR_BGZF_NATIVE", "1") != "0"
         # the header goes through write(): one with many reference sequences (hg38 with alt / decoy contigs: > 64 KiB) is
         # split into members of at most 0xFF00 bytes like everything else (a BGZF member holds at most 64 KiB)
         self.write(bytes(header_bytes))

@@ -193,7 +193,7 @@ class ValidationLogger:
         import os
 
         depth = 3
-        nthreads = int(os.environ.get("RMR_VALIDATE_THREADS", "0")) or max(2, min(8, effective_cpu_count() // 2))
+        nthreads = max(2, min(8, effective_cpu_count() // 2))
         free, ready = queue.Queue(), queue.Queue(maxsize=depth)
         slots = [None] * depth
         for i in range(depth):

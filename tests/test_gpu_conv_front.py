@@ -90,7 +90,7 @@ def _env(name, value, fn):
 @pytest.mark.parametrize("arch,cfg,num_out", [("conv_only", "C100", 2), ("conv_only", "C100", 3), ("conv_lstm", "C100", 2), ("conv_lstm", "C200", 3)])
 def test_signal_fold_with_matrix_core_producer_is_bit_identical(arch, cfg, num_out):
     """sig3_front_mfma_kernel (round 3): sig_conv2 as one fp32 MFMA per tap inside the staging of sig_conv3 — the shipped
-    path of Conv_w_ref (11 taps), opt-in for ConvLSTM_w_ref (RMR_SIG3_MFMA_LSTM=1).  An fp32 MFMA is a k-ordered fmaf
+    path of both architectures (RMR_SIG3_MFMA=0: the VALU producers).  An fp32 MFMA is a k-ordered fmaf
     chain, so the logits must equal those of the separate VALU front kernel + conv_mfma bit for bit, for ragged batch
     sizes; and they match the CPU restatement of the reference network within 1e-4."""
     import torch
@@ -111,11 +111,11 @@ def test_signal_fold_with_matrix_core_producer_is_bit_identical(arch, cfg, num_o
         args = (d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
         eng.profile_reset()
         eng.profile_enable(True)
-        out = _env("RMR_SIG3_MFMA_LSTM", "1", lambda: model.infer_chunks(*args))
+        out = model.infer_chunks(*args)
         eng.profile_enable(False)
         prof = eng.profile()
         assert "sig3_front" in prof and "front_sig" not in prof, sorted(prof)  # the folded kernel is what ran
-        plain = _env("RMR_SIG3_MFMA", "0", lambda: _env("RMR_SIG3_MFMA_LSTM", "0", lambda: model.infer_chunks(*args)))
+        plain = _env("RMR_SIG3_MFMA", "0", lambda: model.infer_chunks(*args))
         assert np.array_equal(out, plain), (arch, cfg, n)
         if n >= 1000:
             enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])

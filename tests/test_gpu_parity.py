@@ -508,6 +508,19 @@ def _mint_pt(tmp_path, g, O):
     return pt
 
 
+def test_load_model_dtype_from_the_environment(torch_cuda, O, tmp_path, monkeypatch):
+    """REMORA_HIP_DTYPE: the arithmetic of a model loaded through the reference's load_model signature, which has no dtype
+    argument (src/remora/model_util.py:566-578) - a caller that cannot pass one selects the 16-bit pipeline this way; an
+    explicit dtype= wins."""
+    from remora_amd.model_util import load_model, load_torchscript_model
+
+    pt = _mint_pt(tmp_path, golden("call_read_mods_cg_5mc.npz"), O)
+    assert load_model(pt, device=0, quiet=True, eval_only=True)[0].dtype == "fp32"
+    monkeypatch.setenv("REMORA_HIP_DTYPE", "f16")
+    assert load_model(pt, device=0, quiet=True, eval_only=True)[0].dtype == "f16"
+    assert load_torchscript_model(pt, device=0, dtype="bf16")[0].dtype == "bf16"
+
+
 @pytest.mark.parametrize("name", ["cg_5mc", "allc_5hmc_5mc", "conv_cg", "cg_5mc_refine"])
 def test_load_model_and_call_read_mods_golden(torch_cuda, O, tmp_path, name):
     """cg_5mc_refine carries a k-mer level table (base_start_justify, offset 1): call_read_mods then

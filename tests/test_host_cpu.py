@@ -34,6 +34,41 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes binding covers exactly the header
     assert sorted(_lib.SIGNATURES) == names
     assert b"gfx950" in _lib.lib().rmr_version()
+    # the documents quote the header's count (checked here instead of maintained by hand)
+    for doc, pat in (("DESIGN.md", r"exports exactly the (\d+) `extern \"C\"` functions"), ("INTEGRATION.md", r"whose (\d+) entry points")):
+        m = re.search(pat, open(os.path.join(ROOT, doc)).read())
+        assert m and int(m.group(1)) == len(names), (doc, m and m.group(1), len(names))
+
+
+def _product_env_names():
+    """Every RMR_* / REMORA_* name the product reads: (all names, those only the experiment build `make abl` reads)."""
+    every, abl = set(), set()
+    pkg = os.path.join(ROOT, "remora_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                txt = open(os.path.join(dp, f)).read()
+                every |= set(re.findall(r'"((?:RMR|REMORA)_[A-Z0-9_]+)"', txt))
+                abl |= set(re.findall(r'abl_int\("((?:RMR|REMORA)_[A-Z0-9_]+)"', txt))
+    abl |= {"RMR_DUMP_CAT", "RMR_FUSED_DUMP_X"}  # getenv under #ifdef RMR_TIMING_ABLATIONS (engine.hip)
+    return every, abl
+
+
+def test_every_environment_switch_is_in_the_design_table_and_there_are_few():
+    """Review item: 81 switch names had accumulated, most of them settled A/Bs shipping as untested configurations.  What the
+    shipped library and the Python host read now is the table of DESIGN.md section 11, name for name, at most 38 of them; the knobs
+    of the experiment build (abl_int / #ifdef RMR_TIMING_ABLATIONS) are listed beside it and are not read by the product."""
+    every, abl = _product_env_names()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    at = design.index("## 11. Environment switches")
+    table = design[at : design.index("\n## ", at + 5)] if "\n## " in design[at + 5 :] else design[at:]
+    listed = set(re.findall(r"`((?:RMR|REMORA)_[A-Z0-9_]+)`", table))
+    assert listed == every, (sorted(every - listed), sorted(listed - every))
+    assert len(every - abl) <= 38, sorted(every - abl)
+    eng = open(os.path.join(ROOT, "remora_amd", "csrc", "engine.hip")).read()
+    for name in ("RMR_DUMP_CAT", "RMR_FUSED_DUMP_X"):  # really behind the experiment-build macro
+        before = eng[: eng.index(f'getenv("{name}")')]
+        assert before.rfind("#ifdef RMR_TIMING_ABLATIONS") > before.rfind("#endif"), name
 
 
 def test_library_embeds_gfx950_code_object():

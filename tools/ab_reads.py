@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reads paths timed as medians inside ONE process (the boxes of the pool differ by 20 % and so do consecutive calls):
 single-read call_read_mods over six rounds of 64 reads, batched call_reads_mods over several calls of 2048 reads.  Knobs are
-environment variables (RMR_READS_STAGERS, RMR_PACK_THREADS, RMR_READS_SUBBATCH, RMR_PACK_STREAM): one process per setting.
+environment variables (RMR_READS_STAGERS, RMR_PACK_THREADS, RMR_READS_SUBBATCH): one process per setting.
     python tools/ab_reads.py [--dtypes fp32,bf16] [--calls 7]"""
 import argparse
 import os

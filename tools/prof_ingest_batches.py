@@ -41,13 +41,13 @@ t = time.perf_counter()
 n = sum(len(ib) for ib in rio.iter_ingest_batches(pod5, big, batch=BATCH, device=0, ref_anchored=REF))
 dt = time.perf_counter() - t
 print(f"iter_ingest_batches: {n} of {n_rec} records, {n / dt:.0f} records/s ({dt / n * 1e6:.1f} us per record)")
-os.environ["RMR_INGEST_TIMING"] = "1"
+os.environ["RMR_INFER_TIMING"] = "1"
 rio.INGEST_CLOCK.clear()
 t = time.perf_counter()
 n = sum(len(ib) for ib in rio.iter_ingest_batches(pod5, big, batch=BATCH, device=0, ref_anchored=REF))
 dt = time.perf_counter() - t
 print(f"sections of _ingest_batch, us per record (wall {dt / n * 1e6:.1f}): " + ", ".join(f"{k} {v / n * 1e6:.1f}" for k, v in rio.INGEST_CLOCK.items()))
-del os.environ["RMR_INGEST_TIMING"]
+del os.environ["RMR_INFER_TIMING"]
 pr = cProfile.Profile()
 pr.enable()
 for ib in rio.iter_ingest_batches(pod5, big, batch=BATCH, device=0, ref_anchored=REF):

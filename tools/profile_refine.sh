@@ -1,15 +1,12 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): occupancy sweep, kernel-trace stats and PMC passes for the
+# Run on the GPU box (via gpurun): two batch sizes, kernel-trace stats and PMC passes for the
 # signal-mapping refinement kernels (tools/bench_refine.py).
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_refine
 mkdir -p $OUT
-for wpc in 4 8 16; do
-  echo "waves_per_cu=$wpc" >> $OUT/sweep.log
-  RMR_REFINE_WAVES_PER_CU=$wpc timeout 300 python tools/bench_refine.py --reads 16384 2>/dev/null | tail -1 >> $OUT/sweep.log
-  RMR_REFINE_WAVES_PER_CU=$wpc timeout 300 python tools/bench_refine.py --reads 2048 2>/dev/null | tail -1 >> $OUT/sweep.log
-done
+timeout 300 python tools/bench_refine.py --reads 16384 2>/dev/null | tail -1 >> $OUT/sweep.log
+timeout 300 python tools/bench_refine.py --reads 2048 2>/dev/null | tail -1 >> $OUT/sweep.log
 BENCH="python tools/bench_refine.py --reads 16384 --steps 2"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_inst -- $BENCH > $OUT/bench_inst.json 2> $OUT/pmc_inst.err

@@ -1,5 +1,6 @@
 """Is the 16-bit pipeline bit-stable under load?  P processes share one GPU; each runs the same chunks through
-model.infer_chunks REPS times and hashes the logits (and, with RMR_FUSED_DUMP_X unset, nothing else): every hash of every
+model.infer_chunks REPS times and hashes the logits (and, with RMR_FUSED_DUMP_X unset, nothing else; the dump switches
+RMR_FUSED_DUMP_X / RMR_DUMP_CAT / RMR_DEBUG_SKIP_LSTM exist in the experiment build only: make abl, REMORA_HIP_LIB=.../libremora_hip_abl.so): every hash of every
 process must be the same.  (Round 4: a two-rank bf16 bench on one GPU once disagreed with the single-rank run by one argmax.)
 
     python tools/stress_determinism.py [--procs 3] [--reps 30] [--n 200000] [--dtype bf16] [--cfg C100]"""
