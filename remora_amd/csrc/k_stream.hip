@@ -38,11 +38,16 @@ struct ConvSArgs {
     int plane;            // LDS plane stride in floats (multiple of 64)
     int rs;               // floats per row per plane (rs / 4 odd)
     FastDiv div_pout, div_r4, div_g;
+    // Position windows, as in k_conv.hip (a chunk whose rows do not fit a block's LDS: chunk contexts of several hundred samples
+    // at these channel counts).  nwin > 1: an iteration is ONE window of ONE chunk (cb == 1); `pin` / `pout` are the rows staged /
+    // the columns computed per window, the chunk's own extents pin_total / pout_total; window w covers output positions
+    // [w * pout, (w + 1) * pout).
+    int nwin, pin_total, pout_total;
 };
 
 // One work item of a wave: output channels 16 ot .. 16 ot + 15 x NTV column tiles (16 columns each) from column tile `tile0`.
 template <int KW, int STRIDE, int NTV>
-__device__ __forceinline__ void conv_stream_item(const ConvSArgs &a, const float *smem, int64_t chunk0, int ncols, int ot, int tile0,
+__device__ __forceinline__ void conv_stream_item(const ConvSArgs &a, const float *smem, int64_t chunk0, int pbase, int ncols, int ot, int tile0,
                                                  int lane, int q, int nn) {
     const int G = a.ic >> 4, RS = a.rs, S4 = KW * G;
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * ot + 4 * q);
@@ -91,7 +96,7 @@ __device__ __forceinline__ void conv_stream_item(const ConvSArgs &a, const float
         if (valid[t]) {
             f32x2 lo = f32x2{acc[t][0], acc[t][1]}, hi = f32x2{acc[t][2], acc[t][3]};
             swish_pk(lo, hi);
-            float *dst = a.out + ((size_t)(chunk0 + ch[t]) * a.pout + pp[t]) * a.out_row + a.out_coff + 16 * ot + 4 * q;
+            float *dst = a.out + ((size_t)(chunk0 + ch[t]) * a.pout_total + pbase + pp[t]) * a.out_row + a.out_coff + 16 * ot + 4 * q;
             *reinterpret_cast<f32x4 *>(dst) = f32x4{lo.x, lo.y, hi.x, hi.y};
         }
     }
@@ -106,15 +111,26 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(ConvSArgs a) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15, nw = nthr >> 6;
     const int G = a.ic >> 4, RS = a.rs, R4 = a.ic >> 2, OT = a.oc >> 4;
-    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    const int64_t n_iters = a.nwin > 1 ? a.n * a.nwin : (a.n + a.cb - 1) / a.cb;
     for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
-        const int64_t chunk0 = it * a.cb;
-        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb), rows = nch * a.pin, ncols = nch * a.pout;
+        // whole chunks (nwin == 1): cb chunks from chunk0;  windows: window `win` of chunk `chunk0`, rows clipped to the chunk
+        int64_t chunk0 = it * a.cb;
+        int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb), pbase = 0, rows = nch * a.pin, ncols = nch * a.pout;
+        size_t src_row = (size_t)chunk0 * a.pin;
+        if (a.nwin > 1) {
+            chunk0 = it / a.nwin;
+            const int win = (int)(it - chunk0 * a.nwin);
+            pbase = win * a.pout;
+            nch = 1;
+            ncols = a.pout_total - pbase < a.pout ? a.pout_total - pbase : a.pout;
+            rows = a.pin_total - pbase * STRIDE < a.pin ? a.pin_total - pbase * STRIDE : a.pin;
+            src_row = (size_t)chunk0 * a.pin_total + (size_t)pbase * STRIDE;
+        }
         RMR_SYNC();  // all reads of the previous iteration are done
         {            // stage `rows` rows of ic floats into the 4 planes (plane q = channels {16 g + 4 q + j})
             constexpr int UNR = 4;
             const int total4 = rows * R4;
-            const float4 *src = reinterpret_cast<const float4 *>(a.in + (size_t)chunk0 * a.pin * a.ic);
+            const float4 *src = reinterpret_cast<const float4 *>(a.in + src_row * a.ic);
             for (int base = tid; base < total4; base += UNR * nthr) {
                 float4 v[UNR];
                 int dsto[UNR];
@@ -136,10 +152,10 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(ConvSArgs a) {
         for (int item = w; item < OT * ntg; item += nw) {  // (wave-uniform)
             const int tg = item / OT, ot = item - tg * OT;
             const int tile0 = tg * NT, nt = ntiles - tile0 < NT ? ntiles - tile0 : NT;
-            if (nt == 4) conv_stream_item<KW, STRIDE, 4>(a, smem, chunk0, ncols, ot, tile0, lane, q, nn);
-            else if (nt == 3) conv_stream_item<KW, STRIDE, 3>(a, smem, chunk0, ncols, ot, tile0, lane, q, nn);
-            else if (nt == 2) conv_stream_item<KW, STRIDE, 2>(a, smem, chunk0, ncols, ot, tile0, lane, q, nn);
-            else conv_stream_item<KW, STRIDE, 1>(a, smem, chunk0, ncols, ot, tile0, lane, q, nn);
+            if (nt == 4) conv_stream_item<KW, STRIDE, 4>(a, smem, chunk0, pbase, ncols, ot, tile0, lane, q, nn);
+            else if (nt == 3) conv_stream_item<KW, STRIDE, 3>(a, smem, chunk0, pbase, ncols, ot, tile0, lane, q, nn);
+            else if (nt == 2) conv_stream_item<KW, STRIDE, 2>(a, smem, chunk0, pbase, ncols, ot, tile0, lane, q, nn);
+            else conv_stream_item<KW, STRIDE, 1>(a, smem, chunk0, pbase, ncols, ot, tile0, lane, q, nn);
         }
     }
 }
@@ -169,17 +185,28 @@ static int launch_conv_stream_t(rmr_engine *e, const ConvLayer &c, const float *
         const double eff = (double)cols / (16.0 * ((cols + 15) / 16));
         if (eff > best + 1e-9) { best = eff; cb = k; }
     }
-    const int plane = ((cb * pin * RS) + 63) & ~63;
+    // a chunk whose rows do not fit one block's LDS at all goes through position windows: the most output positions whose input
+    // rows ((win - 1) * STRIDE + KW of them) fit the two-blocks-per-CU share, one window of one chunk per iteration
+    int nwin = 1, pin_w = pin, pout_w = pout;
+    if (row_bytes + 64 > 150 * 1024) {
+        const int rows_fit = (int)(budget / ((size_t)RS * 4 * sizeof(float)));
+        pout_w = (rows_fit - KW) / STRIDE + 1;
+        if (pout_w < 16) RMR_FAIL(RMR_ERR_INVALID, "conv layer %d -> %d channels: not even a 16-column window fits %zu B of LDS", c.ic, c.oc, budget);
+        pout_w &= ~15;  // whole column tiles
+        nwin = (pout + pout_w - 1) / pout_w;
+        pin_w = (pout_w - 1) * STRIDE + KW;
+        cb = 1;
+    }
+    const int plane = ((cb * pin_w * RS) + 63) & ~63;
     const size_t lds = (size_t)plane * 4 * sizeof(float) + 64;  // + trash slot for masked staging writes
-    if (lds > 160 * 1024 - 256)
-        RMR_FAIL(RMR_ERR_INVALID, "conv layer %d -> %d channels: one chunk of %d positions needs %zu B of LDS (chunk contexts this long are "
-                                  "supported for networks of at most 64 channels)", c.ic, c.oc, pin, lds);
+    if (lds > 160 * 1024 - 256) RMR_FAIL(RMR_ERR_INVALID, "conv layer %d -> %d channels needs %zu B of LDS", c.ic, c.oc, lds);
     ConvSArgs a;
     a.in = in; a.out = out; a.apack4 = c.apack4; a.bias = c.bias; a.n = n;
-    a.ic = c.ic; a.oc = c.oc; a.pin = pin; a.pout = pout; a.out_row = out_row; a.out_coff = out_coff;
+    a.ic = c.ic; a.oc = c.oc; a.pin = pin_w; a.pout = pout_w; a.out_row = out_row; a.out_coff = out_coff;
     a.cb = cb; a.plane = plane; a.rs = RS;
-    a.div_pout = make_fastdiv(pout); a.div_r4 = make_fastdiv(c.ic / 4); a.div_g = make_fastdiv(G);
-    const int64_t iters = (n + cb - 1) / cb;
+    a.div_pout = make_fastdiv(pout_w); a.div_r4 = make_fastdiv(c.ic / 4); a.div_g = make_fastdiv(G);
+    a.nwin = nwin; a.pin_total = pin; a.pout_total = pout;
+    const int64_t iters = nwin > 1 ? n * nwin : (n + cb - 1) / cb;
     int64_t grid = (int64_t)e->num_cus * 4;
     if (grid > iters) grid = iters;
     if (grid < 1) return 0;

@@ -432,6 +432,40 @@ def test_any_model_size_oracle_synth(torch_cuda, O, arch, cfg, size, num_out):
         assert torch.equal(model.infer_chunks(*[t[perm].contiguous() for t in dev], (4, 4)), a[perm])
 
 
+@pytest.mark.parametrize("cc,msl,size", [((200, 200), 80, 128), ((500, 500), 60, 96), ((300, 300), 60, 256)])
+def test_large_models_on_long_chunk_contexts(torch_cuda, O, cc, msl, size):
+    """The reference's default chunk_context is (200, 200) (src/remora/constants.py:7-8) and its networks are length-agnostic:
+    networks of more than 64 channels on chunks whose merge_conv1 input no longer fits a block's LDS go through the position
+    windows of the streamed convolution (k_stream.hip) and an LSTM of several hundred steps."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    # (a) torch's default weight scale (what a reference-initialised network looks like): north_star's fixed 1e-4 against float64;
+    # (b) the amplified network (LSTM x 2.5, fc x 12: every layer's error reaches the logits, and so does fp32 rounding over
+    #     several hundred steps - the oracle's OWN fp32 forward is measured against float64 and sets the scale of the allowance)
+    for amplified in (False, True):
+        if amplified:
+            net = torch_ref.random_model("conv_lstm", size, 9, 2, seed=5)
+            state = {k: v.numpy() for k, v in net.state_dict().items()}
+        else:
+            state = synth.synth_state("conv_lstm", size, 9, 2, seed=5, amplify=False)
+            net = torch_ref.from_state(state)
+        model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0)
+        for n in (3, 70):
+            d = synth.synth_chunks(n, sum(cc), msl, (4, 4), 2, True, shard=n)
+            out = model.infer_chunks(d["signal"], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"], (4, 4))
+            enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+            with torch.no_grad():
+                ref32 = net(torch.from_numpy(d["signal"]), torch.from_numpy(enc)).numpy()
+                ref = net.double()(torch.from_numpy(d["signal"]).double(), torch.from_numpy(enc).double()).numpy()
+            net.float()
+            tol = 1e-4 + (3.0 * float(np.abs(ref32 - ref).max()) if amplified else 0.0)
+            assert np.abs(out - ref).max() <= tol, (cc, size, n, amplified, float(np.abs(out - ref).max()), tol)
+            assert out.std(axis=0).min() > (1e-3 if amplified else 1e-6)  # the chunks are told apart
+
+
 def test_model_sizes_the_engine_refuses(torch_cuda):
     from oracle import torch_ref
     from remora_amd import RemoraError
