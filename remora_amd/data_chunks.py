@@ -686,17 +686,31 @@ class RemoraRead:
         """One chunk around a SIGNAL position, with the reference's arguments and return value (:331-423): the window
         `focus_sig_idx - chunk_context[0] .. + chunk_context[1]`, zero-padded where it leaves the read, the bases it covers
         with their k-mer context (-1 outside the read) and the mapping re-based to the chunk.  The same two kernels as the
-        batch path (geometry + fill) for one focus position; `signal_padding` (mirrored signal instead of zeros, which no
-        caller of the reference passes) is not built."""
-        if signal_padding:
-            raise RemoraError("extract_chunk: signal_padding is not supported by the GPU extraction path")
+        batch path (geometry + fill) for one focus position.  `signal_padding` (:357-363; no caller of the reference passes
+        it): the zeros beside a read's end are replaced by the mirrored signal - the reference's two numpy assignments on this
+        one chunk, taken from the normalised signal; a read too short to mirror from makes numpy refuse, as it does there."""
         dr = DeviceReads([self])
         arrs, _ = _extract_device(dr, np.array([int(focus_sig_idx)], np.int64), np.array([0, 1], np.int64), chunk_context,
                                   kmer_context_bases, 2, int(read_focus_base))
         sl = int(arrs.geo[0, 0])
         ctx = sum(arrs.kmer_context_bases)
         geo = arrs.geo.cpu().numpy()[0]
-        ch = Chunk(signal=arrs.signal.cpu().numpy()[0, 0], seq_w_context=arrs.sequence.cpu().numpy()[0, : sl + ctx],
+        chunk_sig = arrs.signal.cpu().numpy()[0, 0]
+        if signal_padding:
+            sig, chunk_len = self.sig, int(sum(chunk_context))
+            sig_start, sig_end = int(focus_sig_idx) - int(chunk_context[0]), int(focus_sig_idx) + int(chunk_context[1])
+            if not (sig_start >= 0 and sig_end <= sig.size):
+                fill_st, fill_en, seq_to_sig_offset = 0, chunk_len, 0
+                if sig_start < 0:
+                    fill_st = seq_to_sig_offset = -sig_start
+                    sig_start = 0
+                if sig_end > sig.size:
+                    fill_en = sig.size - sig_start + seq_to_sig_offset
+                    sig_end = sig.size
+                chunk_sig = chunk_sig.copy()
+                chunk_sig[:fill_st] = sig[sig_start + fill_st : sig_start : -1]
+                chunk_sig[fill_en:] = sig[sig_end : sig_end - chunk_sig.size + fill_en - 1 : -1]
+        ch = Chunk(signal=chunk_sig, seq_w_context=arrs.sequence.cpu().numpy()[0, : sl + ctx],
                    seq_to_sig_map=arrs.mapping.cpu().numpy()[0, : sl + 1].astype(np.int32), kmer_context_bases=arrs.kmer_context_bases,
                    chunk_sig_focus_idx=int(geo[1]), chunk_focus_base=int(geo[2]), read_focus_base=int(read_focus_base),
                    read_id=self.read_id, label=label)

@@ -290,8 +290,28 @@ def test_extract_chunk_one_signal_position_golden(torch_cuda):
     s1 = int(np.searchsorted(read.seq_to_sig_map, mid + 50, side="left"))
     assert ch.seq_len == s1 - s0 and ch.chunk_sig_focus_idx == 50 and ch.chunk_focus_base == -1 - s0
     assert np.array_equal(ch.seq_w_context[4:-4], read.int_seq[s0:s1])
-    with pytest.raises(RemoraError, match="signal_padding"):
-        read.extract_chunk(mid, (50, 50), (4, 4), signal_padding=True)
+    # signal_padding=True (:357-363): the mirrored signal in place of the zeros, against the reference's own chunks - padding in
+    # front, behind, on both sides, none; a read too short to mirror from is refused by numpy there and here
+    gp = golden("extract_chunk_padding.npz")
+    ok = refused = 0
+    for key in gp["cases"]:
+        key = str(key)
+        rname, f, c0, c1 = key.split("_")[0], int(key.split("_")[1][1:]), int(key.split("_")[2][1:]), int(key.split("_")[3])
+        shift, scale = (float(x) for x in gp[f"{rname}_shift_scale"])
+        rd = RemoraRead(dacs=gp[f"{rname}_dacs"], shift=shift, scale=scale, seq_to_sig_map=gp[f"{rname}_map"], int_seq=gp[f"{rname}_int_seq"],
+                        read_id=rname)
+        if str(gp[key + "_err"]):
+            with pytest.raises(ValueError):
+                rd.extract_chunk(f, (c0, c1), (4, 4), label=0, read_focus_base=5, signal_padding=True)
+            refused += 1
+            continue
+        ch = rd.extract_chunk(f, (c0, c1), (4, 4), label=0, read_focus_base=5, signal_padding=True)
+        assert np.array_equal(ch.signal.view(np.uint32), gp[key + "_signal"].view(np.uint32)), key
+        assert np.array_equal(ch.seq_to_sig_map, gp[key + "_map"]) and np.array_equal(ch.seq_w_context, gp[key + "_seq"]), key
+        if f - c0 >= 0 and f + c1 <= rd.dacs.size:  # nothing to pad: the plain chunk
+            assert np.array_equal(rd.extract_chunk(f, (c0, c1), (4, 4), label=0, read_focus_base=5).signal, ch.signal)
+        ok += 1
+    assert ok >= 20 and refused == 2
 
 
 def test_extract_multi_read_batch_vs_oracle(torch_cuda, O):

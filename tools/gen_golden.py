@@ -349,6 +349,39 @@ def gen_extract_chunks(R, out):
     print("extract_chunks: done", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
 
 
+def gen_extract_chunk_padding(R, out):
+    """RemoraRead.extract_chunk(..., signal_padding=True) (data_chunks.py:331-368): the zero padding replaced by the mirrored
+    signal next to the read's ends.  No caller of the reference passes it; pinned for completeness of the method.  A read
+    shorter than the padding it would have to mirror makes numpy refuse the assignment: recorded as the error text."""
+    rng = np.random.default_rng(113)
+    d = {}
+    reads = [("long", synth_read(rng, 300), 500.0, 80.0), ("short", synth_read(rng, 7), 511.25, 77.5),
+             ("mid", synth_read(rng, 30), 480.0, 91.3)]
+    d["read_names"] = np.asarray([r[0] for r in reads])
+    cases = []
+    for rname, (dacs, s2s, int_seq), shift, scale in reads:
+        read = R.data_chunks.RemoraRead(dacs=dacs, shift=shift, scale=scale, seq_to_sig_map=s2s, int_seq=int_seq, read_id=rname)
+        d[f"{rname}_dacs"], d[f"{rname}_map"], d[f"{rname}_int_seq"] = dacs, s2s, int_seq
+        d[f"{rname}_shift_scale"] = np.asarray([shift, scale], np.float64)
+        n = dacs.size
+        for f, cc in ((3, (50, 50)), (n - 2, (50, 50)), (n // 2, (50, 50)), (10, (30, 25)), (n - 1, (100, 100)), (0, (20, 20)),
+                      (n // 2, (200, 200)), (n, (10, 40))):
+            key = f"{rname}_f{f}_c{cc[0]}_{cc[1]}"
+            try:
+                ch = read.extract_chunk(f, cc, (4, 4), label=0, read_focus_base=5, signal_padding=True)
+                d[key + "_signal"] = ch.signal.astype(np.float32)
+                d[key + "_map"] = ch.seq_to_sig_map.astype(np.int32)
+                d[key + "_seq"] = np.asarray(ch.seq_w_context, np.int8)
+                err = ""
+            except ValueError as e:
+                err = str(e)
+            d[key + "_err"] = np.asarray(err)
+            cases.append(key)
+    d["cases"] = np.asarray(cases)
+    np.savez_compressed(os.path.join(out, "extract_chunk_padding.npz"), **d)
+    print("extract_chunk_padding:", len(cases), "cases,", sum(1 for c in cases if str(d[c + "_err"])), "refused by numpy")
+
+
 def gen_encode_kmers(R, out):
     """encoded_kmers.compute_encoded_kmer_batch (src/remora/encoded_kmers.pyx:13-45)."""
     rng = np.random.default_rng(14)
@@ -1345,6 +1378,7 @@ def main():
         parse_move_tag=gen_parse_move_tag,
         seq_motif=gen_seq_motif,
         extract_chunks=gen_extract_chunks,
+        extract_chunk_padding=gen_extract_chunk_padding,
         encode_kmers=gen_encode_kmers,
         trim=gen_trim,
         model_logits=gen_model_logits,
