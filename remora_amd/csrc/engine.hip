@@ -970,6 +970,24 @@ std::vector<float> pack_lstm_stream(const float *w, int H, const int *gates, int
     return ap;
 }
 
+// [4H][H] row-major (H = 64) -> [4 waves][64 k in lstm_head_kernel's order: position (g * 4 + j) * 4 + q = k 16 g + 4 q + j][64 lanes],
+// lane l = gate gates[l & 3] (a negative entry: zeros) of unit 16 w + (l >> 2)   (lstm_small_kernel, k_lstm.hip)
+std::vector<float> pack_lstm_small(const float *w, const int *gates, bool prescale) {
+    const int H = 64;
+    std::vector<float> ap((size_t)4 * H * 64);
+    for (int wv = 0; wv < 4; ++wv)
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 4; ++j)
+                for (int q = 0; q < 4; ++q)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int gate = gates[lane & 3], unit = 16 * wv + (lane >> 2), k = 16 * g + 4 * q + j;
+                        const double sc = prescale && gate >= 0 ? lstm1_gate_scale(gate) : 1.0;
+                        ap[((size_t)wv * H + (g * 4 + j) * 4 + q) * 64 + lane] =
+                            gate < 0 ? 0.0f : (float)((double)w[(size_t)(gate * H + unit) * H + k] * sc);
+                    }
+    return ap;
+}
+
 // [4H][H] row-major -> [H/16 waves][ngates][H/4][64]
 std::vector<float> pack_lstm(const float *w, int H, const int *gates, int ngates, bool prescale = false) {
     const int KS = H / 4, G = H / 16, W = H / 16;
@@ -1184,6 +1202,12 @@ static int model_create_at_kernel_size(rmr_engine *e, const rmr_model_desc *desc
             RMR_TRY(upload(m.get(), pack_lstm(wih1, H, g4, 4, true), &m->lstm.a_ih1));
             RMR_TRY(upload(m.get(), pack_lstm(whh1, H, g4, 4, true), &m->lstm.a_hh1));
             RMR_TRY(upload(m.get(), pack_lstm(wih2, H, g3, 3), &m->lstm.a_ih2));
+            if (H == 64 && m->nparts == 0) {  // the four-chunk kernel of small batches (one read per call)
+                const int g3z[4] = {0, 2, 3, -1};
+                RMR_TRY(upload(m.get(), pack_lstm_small(wih1, g4, true), &m->lstm.q_ih1));
+                RMR_TRY(upload(m.get(), pack_lstm_small(whh1, g4, true), &m->lstm.q_hh1));
+                RMR_TRY(upload(m.get(), pack_lstm_small(wih2, g3z, false), &m->lstm.q_ih2));
+            }
         }
         if (m->nparts > 0) {
             std::vector<float> si((size_t)4 * H * H), sh((size_t)4 * H * H);

@@ -221,6 +221,10 @@ static int launch_conv_t(rmr_engine *e, const ConvLayer &c, const float *in, int
         const double eff = (double)cols / (16.0 * ((cols + 15) / 16));
         if (eff > best + 1e-9) { best = eff; cb = k; }
     }
+    // a small batch (one read per call: a few hundred chunks) spread over the CUs: fewer chunks per iteration until there is a block
+    // for every CU - a chunk's columns are computed the same way whatever its neighbours in the iteration (same bits), and a
+    // half-filled tile on an otherwise idle CU costs nothing
+    while (cb > 1 && (n + cb - 1) / cb < e->num_cus) cb = (cb + 1) / 2;
     // a chunk whose rows do not fit a block's share goes through position windows: the most output positions whose input rows
     // ((win - 1) * STRIDE + KW of them) fit the share, one window of one chunk per iteration
     int nwin = 1, pin_w = pin, pout_w = pout;

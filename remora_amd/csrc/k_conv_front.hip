@@ -552,6 +552,12 @@ int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *
         if (score > best + 1e-9) { best = score; a.cb = k; a.plane = plane; a.o_front = 4 * plane + 16; lds = need; }
     }
     if (cb == 0) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples does not fit the LDS", m->L);
+    while (a.cb > 1 && (n + a.cb - 1) / a.cb < e->num_cus) {  // a small batch spread over the CUs (k_conv.hip: same bits for any count)
+        a.cb = (a.cb + 1) / 2;
+        a.plane = ((a.cb * a.pin * 4) + 63) & ~63;
+        a.o_front = 4 * a.plane + 16;
+        lds = ((size_t)4 * a.plane + 16 + 4 * (size_t)a.per_chunk) * sizeof(float);
+    }
     a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
     const int64_t iters = (n + a.cb - 1) / a.cb;
     int64_t grid = (int64_t)e->num_cus * 8;
@@ -630,6 +636,12 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
         if (cb < 1) {
             cb = 1;
             if (lds > CONV_FRONT_MAX_LDS) RMR_FAIL(RMR_ERR_INVALID, "seq2_front: max_seq_len %d needs %zu B of LDS", a.maxlen, lds);
+        }
+        while (cb > 1 && (n + cb - 1) / cb < e->num_cus) {  // a small batch spread over the CUs (same bits for any count)
+            cb = (cb + 1) / 2;
+            a.plane = ((cb * a.pin * 4) + 63) & ~63;
+            a.o_front = 4 * a.plane + 16;
+            lds = ((size_t)a.o_front + wt_words + (size_t)cb * a.per_chunk) * sizeof(float);
         }
         a.cb = cb;
         a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS

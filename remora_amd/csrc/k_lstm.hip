@@ -48,6 +48,12 @@ __device__ __forceinline__ void xproj(const float (&buf)[4][16][RS], int q, int 
     }
 }
 
+// fc partial sum over four consecutive hidden units, as ONE stated chain of operations (the small-batch kernel below forms the
+// same chain from other lanes' values and has to return the same bits)
+__device__ __forceinline__ float fc_dot4(const f32x4 wv, const f32x4 y) {
+    return fmaf(wv[3], y[3], fmaf(wv[2], y[2], fmaf(wv[1], y[1], wv[0] * y[0])));
+}
+
 // LSTM cell update for this lane's 4 hidden units (torch gate order i, f, g, o)
 __device__ __forceinline__ void gates(const f32x4 (&acc)[4], f32x4 &c, f32x4 &h) {
 #pragma unroll
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
         // ---- fc: partial dot over this lane's 4 hidden units, reduce over q then waves ----
         for (int o = 0; o < a.num_out; ++o) {
             const f32x4 wv = *reinterpret_cast<const f32x4 *>(a.w_fc + (size_t)o * H + 16 * w + 4 * q);
-            float p = wv[0] * y[0] + wv[1] * y[1] + wv[2] * y[2] + wv[3] * y[3];
+            float p = fc_dot4(wv, y);
             p += __shfl_xor(p, 16);
             p += __shfl_xor(p, 32);
             if (q == 0) part[w][nn][o] = p;
@@ -242,6 +248,156 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// Small batches (one read's few hundred chunks: rmr_call_read, inference.call_read_mods): FOUR chunks per block on
+// v_mfma_f32_4x4x1_16b_f32.  lstm_head_kernel above fills a 16-column MFMA tile per block: a 5 kb read's 312 chunks are 20
+// blocks on 256 CUs, each walking its T steps at 2 x 64 MFMAs of 32 cycles per step and wave - 64 of the call's 188 us.  The
+// 16-block 4x4x1 form (8 cycles) computes 64 rows x 4 columns x 1 k per instruction: with 4 chunks per block the same read is
+// 78 blocks and a step's recurrent product is 64 instructions of 8 cycles.
+//   lane l of wave w: hidden unit u = 16 w + (l >> 2); A operand = W[gate = l & 3][u][k] (block l >> 2 = the unit, rows = its four
+//   gates), B operand = h[k][chunk = l & 3] (the same for every block), D = f32x4 {i, f, g, o} of (u, chunk l & 3): the cell
+//   update is lane-local, one cell per lane.
+// One MFMA per k, issued in lstm_head_kernel's k order (16-channel group g, MFMA j, k-lane q: k = 16 g + 4 q + j), bias first,
+// the x projection before the recurrent product - an fp32 MFMA is a k-ordered fmaf chain, so every gate pre-activation, hence
+// every logit, equals lstm_head_kernel's bit for bit (tests/test_gpu_parity.py), whatever the batch size a chunk arrives in.
+// The fc partial sums are formed in the same tree: fc_dot4 over the four units of a (wave, q) group, (q0 + q1) + (q2 + q3), then
+// the waves in order behind the bias.
+// ---------------------------------------------------------------------------------------
+struct LstmSmallArgs {
+    const float *x;  // [n][T][64]
+    float *logits;
+    const float *s_ih1, *s_hh1, *s_ih2;  // [4 waves][64 k in issue order][64 lanes]; lstm2: gates i, g, o, (zero)
+    const float *b1, *b2, *w_fc, *b_fc;  // as LstmArgs
+    int64_t n;
+    int T, num_out;
+};
+
+// Two chains, instruction by instruction: the recurrent product of this step (acc += W_hh h_{t-1}) and the input projection of
+// the next (accN += W_ih x_{t+1}) - each keeps its own k order, neither waits for the other's 4x4x1 result, so the matrix pipe
+// issues back to back.  `hrow` / `xrow`: the 64 values of this lane's chunk.
+template <bool HAS_H, bool HAS_X>
+__device__ __forceinline__ void small_step(const float (&Ahh)[64], const float (&Aih)[64], const float *hrow, const float *xrow, f32x4 &acc,
+                                           f32x4 &accN) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 hv[4], xv[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            if (HAS_H) hv[qq] = *reinterpret_cast<const f32x4 *>(hrow + 16 * g + 4 * qq);
+            if (HAS_X) xv[qq] = *reinterpret_cast<const f32x4 *>(xrow + 16 * g + 4 * qq);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {  // k = 16 g + 4 qq + j
+                if (HAS_H) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Ahh[(g * 4 + j) * 4 + qq], hv[qq][j], acc, 0, 0, 0);
+                if (HAS_X) accN = __builtin_amdgcn_mfma_f32_4x4x1f32(Aih[(g * 4 + j) * 4 + qq], xv[qq][j], accN, 0, 0, 0);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void lstm_small_kernel(LstmSmallArgs a) {
+    constexpr int H = 64;
+    // (rows padded by four floats: the four chunk rows a ds_read_b128 touches - every lane reads its own chunk's row - start 16 bytes
+    //  apart in the bank map instead of on the same banks)
+    __shared__ __attribute__((aligned(16))) float xbuf[2][4][H + 4];
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4][H + 4];
+    __shared__ __attribute__((aligned(16))) float ybuf[4][H + 4];   // swish(h2) per chunk and unit, for the fc tree
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 3, u = 16 * w + (lane >> 2);
+    float Aih[H], Ahh[H];
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+        Aih[p] = a.s_ih1[((size_t)w * H + p) * 64 + lane];
+        Ahh[p] = a.s_hh1[((size_t)w * H + p) * 64 + lane];
+    }
+    const f32x4 bias = {a.b1[0 * H + u], a.b1[1 * H + u], a.b1[2 * H + u], a.b1[3 * H + u]};
+    const f32x4 bias2 = {a.b2[0 * H + u], a.b2[1 * H + u], a.b2[2 * H + u], 0.0f};
+    // acc += W (this lane's A values, issue order) x v (the 64 values of this lane's chunk, natural order in LDS)
+    auto mm = [&](const float (&A)[H], const float *row, f32x4 acc, bool swish) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                v[qq] = *reinterpret_cast<const f32x4 *>(row + 16 * g + 4 * qq);
+                if (swish) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[qq][j] = swish_f(v[qq][j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)  // k = 16 g + 4 qq + j
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(A[(g * 4 + j) * 4 + qq], v[qq][j], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    const int st_c = tid >> 6, st_k = tid & 63;  // staging role: one float of the block's 4 x 64 tile
+    const int64_t n_groups = (a.n + 3) / 4;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t chunk0 = grp * 4;
+        int64_t st_chunk = chunk0 + st_c;
+        if (st_chunk >= a.n) st_chunk = a.n - 1;  // clamp the ragged tail (results masked)
+        const float *xsrc = a.x + (size_t)st_chunk * a.T * H + st_k;
+        RMR_SYNC();  // the previous group's LDS traffic is done
+        xbuf[0][st_c][st_k] = xsrc[0];
+        xbuf[1][st_c][st_k] = xsrc[(size_t)(a.T > 1 ? 1 : 0) * H];  // prefetch distance 2: x_{t+2} is fetched while step t runs
+        RMR_SYNC();
+        float cst = 0.0f;
+        f32x4 accN = mm(Aih, &xbuf[0][c][0], bias, false);  // bias + W_ih x_0
+        RMR_SYNC();  // step 0 ends with xbuf[0] overwritten (x_2): every wave is past its x_0 reads (as in lstm_head_kernel)
+        for (int t = 0; t < a.T; ++t) {
+            const float xnext = xsrc[(size_t)(t + 2 < a.T ? t + 2 : a.T - 1) * H];
+            f32x4 acc = accN;
+            accN = bias;
+            const float *hrow = &hbuf[(t + 1) & 1][c][0], *xrow = &xbuf[(t + 1) & 1][c][0];
+            if (t == 0) small_step<false, true>(Ahh, Aih, hrow, xrow, acc, accN);
+            else if (t + 1 < a.T) small_step<true, true>(Ahh, Aih, hrow, xrow, acc, accN);
+            else small_step<true, false>(Ahh, Aih, hrow, xrow, acc, accN);
+            // acc rows are pre-scaled: i, f, o by -log2(e); g by 2 log2(e) (lstm_step)
+            const float ig = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0]));
+            const float fg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[1]));
+            const float gg = fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[2])), 1.0f);
+            cst = fmaf(fg, cst, ig * gg);
+            const float og = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[3]));
+            hbuf[t & 1][c][u] = og * tanh_f(cst);
+            xbuf[t & 1][st_c][st_k] = xnext;  // x_{t+2} over x_t, whose projection was read during step t - 1
+            RMR_SYNC();
+        }
+        // ---- lstm2: one step on swish(h1[T-1]), gates i, g, o (c0 = 0 kills f) ----
+        float A2[H];
+#pragma unroll
+        for (int p = 0; p < H; ++p) A2[p] = a.s_ih2[((size_t)w * H + p) * 64 + lane];
+        const f32x4 acc2 = mm(A2, &hbuf[(a.T - 1) & 1][c][0], bias2, true);
+        const float c2 = sigmoid_f(acc2[0]) * tanh_f(acc2[1]);
+        const float h2 = sigmoid_f(acc2[2]) * tanh_f(c2);
+        ybuf[c][u] = swish_f(h2);
+        RMR_SYNC();
+        // ---- fc: thread (chunk, class) sums in lstm_head_kernel's tree ----
+        if (tid < 4 * a.num_out) {
+            const int ch = tid / a.num_out, o = tid - ch * a.num_out;
+            if (chunk0 + ch < a.n) {
+                float s = a.b_fc[o];
+                for (int ww = 0; ww < 4; ++ww) {
+                    float pq[4];
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(a.w_fc + (size_t)o * H + 16 * ww + 4 * qq);
+                        const f32x4 yv = *reinterpret_cast<const f32x4 *>(&ybuf[ch][16 * ww + 4 * qq]);
+                        pq[qq] = fc_dot4(wv, yv);
+                    }
+                    s += (pq[0] + pq[1]) + (pq[2] + pq[3]);
+                }
+                a.logits[(size_t)(chunk0 + ch) * a.num_out + o] = s;
+            }
+        }
+    }
+}
+
+// batches up to this many chunks take the four-chunk kernel: one block per CU in one wave of blocks
+static constexpr int64_t kLstmSmallMaxChunks = 1024;
 
 template <int H>
 static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits) {
@@ -269,6 +425,19 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
 
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits) {
     if (m->desc.size > 64) return launch_lstm_stream(m, x, n, logits);  // k_stream.hip
+    if (m->desc.size == 64 && n <= kLstmSmallMaxChunks && m->lstm.q_ih1) {
+        rmr_engine *e = m->eng;
+        LstmSmallArgs a;
+        a.x = x; a.logits = logits; a.n = n; a.T = m->T; a.num_out = m->desc.num_out;
+        a.s_ih1 = m->lstm.q_ih1; a.s_hh1 = m->lstm.q_hh1; a.s_ih2 = m->lstm.q_ih2;
+        a.b1 = m->lstm.b1; a.b2 = m->lstm.b2; a.w_fc = m->lstm.w_fc; a.b_fc = m->lstm.b_fc;
+        const int64_t groups = (n + 3) / 4;
+        if (groups < 1) return 0;
+        ProfScope ps(e, K_LSTM_HEAD);
+        hipLaunchKernelGGL(lstm_small_kernel, dim3((unsigned)groups), dim3(256), 0, e->stream, a);
+        RMR_HIP(hipGetLastError());
+        return 0;
+    }
     switch (m->desc.size) {
         case 64: return launch_lstm_t<64>(m, x, n, logits);
         case 32: return launch_lstm_t<32>(m, x, n, logits);

@@ -201,6 +201,9 @@ struct LstmWeights {
     float *xs_ih = nullptr, *xs_hh = nullptr, *xs_ih2 = nullptr;  // the same fragments as NP split parts (k_lstm_x16s.hip)
     // k_stream.hip (more than 64 hidden units, fp32): [H/16 waves][H/16 k groups][4 gates (lstm2: 3)][64 lanes][4]
     float *t_ih1 = nullptr, *t_hh1 = nullptr, *t_ih2 = nullptr;
+    // lstm_small_kernel (k_lstm.hip; 64 hidden units, fp32, batches of a few hundred chunks): [4 waves][64 k in issue order][64 lanes],
+    // lane l = gate l & 3 (lstm2: i, g, o, zero) of unit 16 w + (l >> 2)
+    float *q_ih1 = nullptr, *q_hh1 = nullptr, *q_ih2 = nullptr;
 };
 
 }  // namespace rmr

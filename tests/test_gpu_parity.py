@@ -486,6 +486,33 @@ def test_large_models_on_long_chunk_contexts(torch_cuda, O, cc, msl, size):
             assert out.std(axis=0).min() > (1e-3 if amplified else 1e-6)  # the chunks are told apart
 
 
+@pytest.mark.parametrize("cfg,num_out", [("C100", 2), ("C200", 3)])
+def test_small_batches_take_the_four_chunk_lstm_and_return_the_same_bits(torch_cuda, O, cfg, num_out):
+    """Batches of up to 1024 chunks (one read per call: rmr_call_read, call_read_mods) run the LSTM four chunks per block on
+    v_mfma_f32_4x4x1_16b (lstm_small_kernel, k_lstm.hip) instead of sixteen per block: the same k-ordered fmaf chains, so the
+    logits of a chunk are the same bits whether it arrives alone, in a read's few hundred chunks or in a batch of thousands -
+    and within 1e-4 of the oracle."""
+    from oracle import torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    net = torch_ref.random_model("conv_lstm", 64, 9, num_out, seed=21)
+    state = {k: v.numpy() for k, v in net.state_dict().items()}
+    cc = synth.CONFIGS[cfg][0]
+    model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=(4, 4)), device=0)
+    d = synth.synth_chunks_config(cfg, 3000, shard=77)
+    keys = ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")
+    big = model.infer_chunks(*[d[k] for k in keys], (4, 4))  # sixteen chunks per block
+    enc = O.compute_encoded_kmer_batch(4, 4, d["sequence"][:600], d["sequence_to_signal_mapping"][:600], d["sequence_lengths"][:600])
+    with torch.no_grad():
+        ref = net(torch.from_numpy(d["signal"][:600]), torch.from_numpy(enc)).numpy()
+    assert np.abs(big[:600] - ref).max() <= 1e-4
+    for start, n in ((0, 1), (5, 3), (8, 4), (100, 5), (300, 313), (1000, 1024), (17, 1023)):
+        part = model.infer_chunks(*[d[k][start : start + n] for k in keys], (4, 4))
+        assert np.array_equal(part.view(np.uint32), big[start : start + n].view(np.uint32)), (cfg, start, n, float(np.abs(part - big[start : start + n]).max()))
+
+
 def test_model_sizes_the_engine_refuses(torch_cuda):
     from oracle import torch_ref
     from remora_amd import RemoraError
