@@ -41,7 +41,10 @@ BENCH_NAME = [("conv_mfma_kernel<128, 5, 1>", "conv_merge1"), ("conv_mfma_kernel
               # Conv_w_ref (merge_conv3 and merge_conv4 are the same instantiation: one row, both layers)
               ("conv_mfma_kernel<16, 11, 1>", "conv_seq2"), ("conv_mfma_kernel<32, 9, 3>", "conv_seq3"),
               ("conv_mfma_kernel<64, 5, 1>", "conv_merge2"), ("conv_mfma_kernel<64, 3, 2>", "conv_merge3+4"),
-              ("fc_head_kernel", "fc_head")]
+              ("fc_head_kernel", "fc_head"),
+              # networks of more than 64 channels (k_stream.hip), small batches (k_lstm.hip)
+              ("conv_stream_kernel<5, 1>", "conv_merge1"), ("conv_stream_kernel<13, 3>", "conv_seq2"), ("conv_stream_kernel<9, 3>", "conv_sig3"),
+              ("lstm_stream_kernel", "lstm_head"), ("lstm_small_kernel", "lstm_head")]
 
 
 def write_traffic(d, dtype, chunks_per_launch, path, commit=None, per_kernel_chunks=None):
