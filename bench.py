@@ -835,7 +835,9 @@ def main():
     binding = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         dev0 = args.force_device if args.force_device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-        binding = rdist.bind_rank(dev0)
+        # (testing, --force-device: every rank on one GPU - the plan's entry of each rank is that GPU's)
+        forced_addrs = [rdist.gpu_pci_address(dev0)] * int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if args.force_device is not None else None
+        binding = rdist.bind_rank(dev0, gpu_addrs=forced_addrs)
     ti0 = time.perf_counter()
     init_failure = None
     try:

@@ -391,10 +391,12 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
                     stats[e] += 1
             clock["prep"] += _time.perf_counter() - tq
             tg = _time.perf_counter()
-            res = call_reads_mods(batch.reads, models[0], mds[0], return_mod_probs=True, device_reads=batch.dr) if batch.good.size else []
+            # one pass per model over the SAME resident reads (no model of a multi-model batch refines: see batch_ingest below)
+            per_model = [call_reads_mods(batch.reads, mdl, md, return_mod_probs=True, device_reads=batch.dr) if batch.good.size else []
+                         for mdl, md in zip(models, mds)]
             batch.dr, batch.reads = None, []  # the results are host arrays: the batch's device memory is free for the next one
             clock["gpu"] += _time.perf_counter() - tg
-            return batch, None, [res]
+            return batch, None, per_model
         items, good = [], []  # items: per input record None (callable: the next entry of `good`) or the record to copy
         for io_read, err in batch:
             if err is None:
@@ -418,8 +420,9 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         clock["gpu"] += _time.perf_counter() - tg
         return items, good, per_model
 
-    def batch_tags(results, md, seq_bytes, seq_off):
-        """MM / ML of the callable reads of a batch in one native call -> (mm, mm_off, ml, ml_off, has uint8[n_good])."""
+    def batch_tags(results, md, seq_bytes, seq_off, mi=0, count=True):
+        """MM / ML of the callable reads of a batch for model `mi` in one native call -> (mm, mm_off, ml, ml_off, has uint8[n_good]);
+        `count`: also book the reads into `stats` (the one-model case; several models are booked by join_model_tags)."""
         from .util import format_mm_ml_tags_batch
 
         sizes = np.fromiter((r[2].size for r in results), np.int64, len(results))
@@ -428,16 +431,47 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
         probs = np.concatenate([r[0] for r in live]) if live else np.zeros((0, len(md["mod_bases"])))
         if pos.size:  # calls per label (0 = canonical): argmax over [1 - sum(p_mod), p_mod...], first maximum wins
             full = np.concatenate([1.0 - probs.sum(axis=1, keepdims=True), probs], axis=1)
-            label_counts[0] += np.bincount(full.argmax(axis=1), minlength=label_counts[0].size)
+            label_counts[mi] += np.bincount(full.argmax(axis=1), minlength=label_counts[mi].size)
         call_off = np.zeros(len(results) + 1, np.int64)
         np.cumsum(sizes, out=call_off[1:])
         mm, mm_off, ml, ml_off = format_mm_ml_tags_batch(seq_bytes, seq_off, pos, probs, call_off, md["mod_bases"], md["can_base"])
         has = (sizes > 0).astype(np.uint8)
         n_ok = int(has.sum())
-        stats[None] += n_ok
-        if n_ok < len(results):
-            stats[f"No {md['can_base']} mod calls"] += len(results) - n_ok
+        if count:
+            stats[None] += n_ok
+            if n_ok < len(results):
+                stats[f"No {md['can_base']} mod calls"] += len(results) - n_ok
         return mm, mm_off, ml, ml_off, has
+
+    def join_model_tags(parts):
+        """The tags of several models for the same reads, joined per read in model order (the per-read path's "".join(mm_all) /
+        ml_all.extend, src/remora/inference.py:429-459): parts = [(mm, mm_off, ml, ml_off, has)] per model -> one such tuple.
+        A read counts as called when any model called it; one no model called is booked under all their reasons."""
+        n_good = parts[0][4].size
+        has = np.zeros(n_good, np.uint8)
+        for p_ in parts:
+            has |= p_[4]
+        out = []
+        for col in (0, 2):  # mm bytes, ml bytes
+            lens = [np.diff(p_[col + 1]) for p_ in parts]
+            off = np.zeros(n_good + 1, np.int64)
+            np.cumsum(np.sum(lens, axis=0), out=off[1:])
+            buf = np.zeros(max(int(off[-1]), 1), np.uint8)
+            start = off[:-1].copy()
+            for p_, ln in zip(parts, lens):
+                src = np.asarray(p_[col], np.uint8)
+                tot = int(ln.sum())
+                if tot:
+                    shift = np.repeat(start - p_[col + 1][:-1], ln)  # destination minus source position, per byte
+                    idx = np.arange(tot, dtype=np.int64) + np.repeat(p_[col + 1][:-1], ln) - np.repeat(np.cumsum(ln) - ln, ln)
+                    buf[idx + shift] = src[idx]
+                start = start + ln
+            out += [buf, off]
+        n_ok = int(has.sum())
+        stats[None] += n_ok
+        if n_ok < n_good:
+            stats[",".join(sorted(f"No {md['can_base']} mod calls" for md in mds))] += n_good - n_ok
+        return out[0], out[1], out[2], out[3], has
 
     def spread(off_good, good_pos, n):
         """Offsets int64[n + 1] for all n records of a batch from those of its callable ones (positions good_pos, ascending):
@@ -457,7 +491,11 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
             rb = ib.rb
             has = np.zeros(n, np.uint8)
             if ib.good.size:
-                mm, mm_off, ml, ml_off, has_g = batch_tags(per_model[0], mds[0], ib.seq, ib.seq_off)
+                if len(mds) == 1:
+                    mm, mm_off, ml, ml_off, has_g = batch_tags(per_model[0], mds[0], ib.seq, ib.seq_off)
+                else:
+                    mm, mm_off, ml, ml_off, has_g = join_model_tags([batch_tags(per_model[mi], mds[mi], ib.seq, ib.seq_off, mi, count=False)
+                                                                     for mi in range(len(mds))])
                 has[ib.good] = has_g
                 mm_off, ml_off = spread(mm_off, ib.good, n), spread(ml_off, ib.good, n)
             else:
@@ -524,9 +562,13 @@ def infer_from_pod5_and_bam(pod5_path, in_bam_path, model, model_metadata, out_b
 
     refiner0 = mds[0].get("sig_map_refiner")
     iterative = refiner0 is not None and getattr(refiner0, "is_loaded", False) and refiner0.scale_iters > 0
-    # one model, forward signal, either anchor: the batch ingest (io.iter_ingest_batches) - trimming, move tables, scaling
-    # and the read arrays of a whole BAM batch on the GPU, no Python object per read; everything else read by read
-    batch_ingest = (len(models) == 1 and not reverse_signal and not iterative and os.environ.get("RMR_INFER_BATCH_INGEST", "1") != "0")
+    # forward signal, either anchor: the batch ingest (io.iter_ingest_batches) - trimming, move tables, scaling and the read
+    # arrays of a whole BAM batch on the GPU, no Python object per read.  Several models (one per canonical base,
+    # src/remora/inference.py:286,311-315) share the resident reads when none of them refines the mapping (refinement rewrites
+    # it per model: those, reverse signal and iterative re-scaling go read by read)
+    any_refiner = any(getattr(md.get("sig_map_refiner"), "is_loaded", False) for md in mds)
+    batch_ingest = ((len(models) == 1 or not any_refiner) and not reverse_signal and not iterative
+                    and os.environ.get("RMR_INFER_BATCH_INGEST", "1") != "0")
 
     def batches():
         if batch_ingest:

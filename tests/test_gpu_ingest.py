@@ -261,6 +261,40 @@ def test_infer_output_is_the_same_file_with_and_without_the_batch_ingest(prefix,
         assert open(tmp_path / "l1.bam", "rb").read() == open(tmp_path / "l0.bam", "rb").read()
 
 
+@pytest.mark.parametrize("ref_anchored", [False, True])
+def test_several_models_share_the_batch_ingest(ref_anchored, tmp_path, monkeypatch):
+    """One model per canonical base (src/remora/inference.py:286,311-315: `models[can_base]`): a C model (the golden 5mC CG one)
+    and an A model with a rare motif (reads without a hit carry the C model's tags only; a batch can hold reads no model calls)
+    run over the SAME resident reads of an ingest batch, their MM / ML strings joined per read in model order - the output
+    file, the per-reason counts and the per-model label tallies are those of the read-by-read path."""
+    import torch
+
+    from oracle import oracle as O
+    from oracle import torch_ref
+    from remora_amd.inference import infer_from_pod5_and_bam
+    from remora_amd.model_util import load_model, model_from_state
+    from test_gpu_parity import _mint_pt, _real_reads_golden
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    model_c, md_c = load_model(_mint_pt(tmp_path, _real_reads_golden("can"), O), device=0)
+    net = torch_ref.random_model("conv_lstm", 64, 9, 3, seed=31)
+    md_a = dict(md_c, motifs=[("GATCA", 1)], can_base="A", mod_bases=["a", "b"], mod_long_names=["6mA", "other"], sig_map_refiner=None)
+    model_a = model_from_state({k: v.numpy() for k, v in net.state_dict().items()}, md_a, device=0)
+    pod5, bam = os.path.join(DATA, "can_reads.pod5"), os.path.join(DATA, "can_mappings.bam")
+    outs, stats, counts = [], [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RMR_INFER_BATCH_INGEST", mode)
+        out = str(tmp_path / f"m{mode}.bam")
+        lc = {}
+        stats.append(infer_from_pod5_and_bam(pod5, bam, [model_c, model_a], [md_c, md_a], out, reads_per_batch=5, ref_anchored=ref_anchored,
+                                             label_counts_out=lc))
+        outs.append(open(out, "rb").read())
+        counts.append({k: np.asarray(v).tolist() for k, v in lc.items()})
+    assert stats[0] == stats[1] and counts[0] == counts[1] and set(counts[0]) == {"C", "A"}
+    assert outs[0] == outs[1]
+    assert sum(counts[0]["A"]) > 0, "the second model called something: its tags are in the joined strings"
+
+
 @pytest.mark.parametrize("scale_iters", [-1, 0])
 def test_batch_ingest_with_a_signal_mapping_refiner(scale_iters, tmp_path, monkeypatch):
     """Models with a k-mer level table re-scale (and with scale_iters 0 re-map) every read before the extraction: the
