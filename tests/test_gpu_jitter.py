@@ -14,7 +14,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PIPELINES = "fp32,bf16,f16,f16x3,bf16x3,bf16x6,fp32:C100:conv_only,bf16:C200,fp32:C200"
+# 'dtype[:cfg[:arch[:size[:chunks]]]]'; round 6: the streamed-weight kernels (128 / 96 channels, 176 = eleven waves' worth of units
+# in the LSTM) and the four-chunk LSTM of small batches (313 chunks)
+PIPELINES = ("fp32,bf16,f16,f16x3,bf16x3,bf16x6,fp32:C100:conv_only,bf16:C200,fp32:C200,"
+             "fp32:C100:conv_lstm:128,fp32:C100:conv_only:96,fp32:C200:conv_lstm:176,fp32:C100:conv_lstm:64:313")
 
 
 def test_jittered_barriers_change_no_bit_in_any_pipeline():

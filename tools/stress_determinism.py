@@ -105,10 +105,12 @@ def child_specs(args):
     for spec in args.child_specs.split(","):
         parts = spec.split(":")
         dt, cfg, arch = parts[0], (parts[1] if len(parts) > 1 else "C100"), (parts[2] if len(parts) > 2 else "conv_lstm")
+        size = int(parts[3]) if len(parts) > 3 else 64   # 'dtype[:cfg[:arch[:size[:chunks]]]]': > 64 channels = the streamed kernels,
+        n_spec = int(parts[4]) if len(parts) > 4 else args.n  # a few hundred chunks = the small-batch LSTM (k_stream.hip, k_lstm.hip)
         cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
-        state = synth.synth_state(arch, 64, 9, num_out, seed=0)
+        state = synth.synth_state(arch, size, 9, num_out, seed=0)
         model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=dt)
-        d = synth.synth_chunks_config(cfg, args.n, shard=7)
+        d = synth.synth_chunks_config(cfg, n_spec, shard=7)
         dev = [torch.from_numpy(d[k]).cuda() for k in ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")]
         hashes = {}
         t0 = time.perf_counter()
