@@ -677,23 +677,24 @@ std::vector<float> pack_split_a(const std::vector<float> &w, int K, int nw, cons
 // Channels between `size` and the padded count carry zero weights and zero bias: swish(0) = 0 and an LSTM unit with zero
 // weights stays at c = h = 0 exactly, and a zero product added to an fp32 sum leaves it unchanged - the logits are those of
 // the unpadded network (pad_model_blob below; rmr_model_pad_weights exposes the transform).
-int padded_size(int size) {
+int padded_size(int size, int dtype = 0) {
     if (size <= 16) return 16;
     if (size <= 32) return 32;
     if (size <= 64) return 64;
-    return (size + 15) & ~15;
+    return dtype == 0 ? (size + 15) & ~15 : (size + 31) & ~31;  // the 16-bit MFMA takes K in steps of 32 (k_stream16.hip)
 }
 constexpr int kMaxPaddedSize = 256;
 
 bool desc_ok(const rmr_model_desc &d) {
     if (d.arch != RMR_ARCH_CONV_LSTM && d.arch != RMR_ARCH_CONV_ONLY) return false;
-    if (d.size < 1 || padded_size(d.size) > kMaxPaddedSize) return false;
-    const int sp = padded_size(d.size);
+    if (d.size < 1 || d.dtype < 0 || d.dtype > 5 || padded_size(d.size, d.dtype) > kMaxPaddedSize) return false;
+    const int sp = padded_size(d.size, d.dtype);
     if (d.kmer_len < 1 || d.kmer_len > 64) return false;
     if (d.num_out < 1 || d.num_out > 16) return false;
     if (d.dtype < 0 || d.dtype > 5) return false;  // 5 = f16x3: two-part IEEE half split on the unfused kernels
-    if (d.dtype == 4 && (sp != 64 || (d.kmer_len != 9 && d.kmer_len != 6))) return false;  // half: the fused kernels only
-    if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || sp % 32 || sp > 64)) return false;  // 16-bit operands: up to 64 channels
+    if (d.dtype == 4 && sp <= 64 && (sp != 64 || (d.kmer_len != 9 && d.kmer_len != 6))) return false;  // half up to 64 channels: the fused kernels only
+    if (d.dtype != 0 && (d.arch != RMR_ARCH_CONV_LSTM || sp % 32)) return false;
+    if (d.dtype != 0 && sp > 64 && d.dtype != 1 && d.dtype != 4) return false;  // above 64 channels: fp32, bf16 or f16 (the split dtypes stop at 64)
     return true;
 }
 
@@ -970,6 +971,43 @@ std::vector<float> pack_lstm_stream(const float *w, int H, const int *gates, int
     return ap;
 }
 
+// LSTM weights for k_stream16.hip (H a multiple of 32 above 64): [H/16 waves][4 tiles][H/32 k-steps][64 lanes][4 dwords]; row m of tile t of
+// wave wv = (unit 16 wv + 4 (m >> 2) + t, gate m & 3); gate rows pre-scaled (lstm1_gate_scale); `skip_f` zeroes the f rows (lstm2: c0 = 0)
+std::vector<float> pack_lstm_s16(const float *w, int H, bool skip_f, bool f16) {
+    const int W = H / 16, KSH = H / 32;
+    std::vector<uint32_t> o((size_t)W * 4 * KSH * 64 * 4);
+    for (int wv = 0; wv < W; ++wv)
+        for (int t = 0; t < 4; ++t)
+            for (int ks = 0; ks < KSH; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int ql = lane >> 4, mm = lane & 15, gate = mm & 3, unit = 16 * wv + 4 * (mm >> 2) + t;
+                    uint32_t b[8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * ks + 8 * ql + j;
+                        const double v = (skip_f && gate == 1) ? 0.0 : (double)w[(size_t)(gate * H + unit) * H + k] * lstm1_gate_scale(gate);
+                        b[j] = to_op16((float)v, f16);
+                    }
+                    for (int i = 0; i < 4; ++i) o[((((size_t)wv * 4 + t) * KSH + ks) * 64 + lane) * 4 + i] = (b[2 * i] >> 16) | b[2 * i + 1];
+                }
+    std::vector<float> f(o.size());
+    memcpy(f.data(), o.data(), o.size() * 4);
+    return f;
+}
+// matching biases [H/16][4 tiles][4 q][4 gates]: (b_ih + b_hh) of unit 16 wv + 4 q + t, pre-scaled
+std::vector<float> pack_bias_s16(const float *bih, const float *bhh, int H, bool skip_f) {
+    const int W = H / 16;
+    std::vector<float> o((size_t)W * 4 * 4 * 4);
+    for (int wv = 0; wv < W; ++wv)
+        for (int t = 0; t < 4; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int gate = 0; gate < 4; ++gate) {
+                    const int unit = 16 * wv + 4 * q + t;
+                    o[(((size_t)wv * 4 + t) * 4 + q) * 4 + gate] =
+                        (skip_f && gate == 1) ? 0.0f : (float)(((double)bih[gate * H + unit] + (double)bhh[gate * H + unit]) * lstm1_gate_scale(gate));
+                }
+    return o;
+}
+
 // [4H][H] row-major (H = 64) -> [4 waves][64 k in lstm_head_kernel's order: position (g * 4 + j) * 4 + q = k 16 g + 4 q + j][64 lanes],
 // lane l = gate gates[l & 3] (a negative entry: zeros) of unit 16 w + (l >> 2)   (lstm_small_kernel, k_lstm.hip)
 std::vector<float> pack_lstm_small(const float *w, const int *gates, bool prescale) {
@@ -1033,7 +1071,7 @@ void rmr_model_destroy(rmr_model *m) {
     delete m;
 }
 
-int rmr_model_padded_size(const rmr_model_desc *d) { return (d && desc_ok(*d)) ? padded_size(d->size) : 0; }
+int rmr_model_padded_size(const rmr_model_desc *d) { return (d && desc_ok(*d)) ? padded_size(d->size, d->dtype) : 0; }
 
 int rmr_model_pad_weights(const rmr_model_desc *desc, const float *weights, size_t n_floats, rmr_model_desc *padded_desc,
                           float *out, size_t out_cap, size_t *out_n) {
@@ -1042,7 +1080,7 @@ int rmr_model_pad_weights(const rmr_model_desc *desc, const float *weights, size
     if (rmr_model_weight_count(desc) != n_floats)
         RMR_FAIL(RMR_ERR_INVALID, "weight blob has %zu floats, expected %zu", n_floats, rmr_model_weight_count(desc));
     *padded_desc = *desc;
-    padded_desc->size = padded_size(desc->size);
+    padded_desc->size = padded_size(desc->size, desc->dtype);
     *out_n = rmr_model_weight_count(padded_desc);
     if (!out) return 0;  // size query
     if (out_cap < *out_n) RMR_FAIL(RMR_ERR_INVALID, "output holds %zu floats, %zu needed", out_cap, *out_n);
@@ -1065,12 +1103,12 @@ int rmr_model_create(rmr_engine *e, const rmr_model_desc *desc, const float *wei
     if (!desc_ok(*desc))
         RMR_FAIL(RMR_ERR_INVALID,
                  "unsupported model: arch=%d size=%d kmer_len=%d num_out=%d dtype=%d "
-                 "(size 1..%d; num_out <= 16; the 16-bit dtypes need conv_lstm with at most 64 channels - f16 exactly 33..64 and "
-                 "k-mer length 9 or 6; larger networks run in fp32)",
+                 "(size 1..%d; num_out <= 16; the 16-bit dtypes need conv_lstm; up to 64 channels f16 takes 33..64 channels and a k-mer "
+                 "length of 9 or 6; above 64 channels the dtypes are fp32, bf16 and f16)",
                  desc->arch, desc->size, desc->kmer_len, desc->num_out, desc->dtype, kMaxPaddedSize);
     const size_t want = rmr_model_weight_count(desc);
     if (want != n_floats) RMR_FAIL(RMR_ERR_INVALID, "weight blob has %zu floats, expected %zu", n_floats, want);
-    const int sp = padded_size(desc->size);
+    const int sp = padded_size(desc->size, desc->dtype);
     if (sp == desc->size) return model_create_at_kernel_size(e, desc, weights, n_floats, out);
     rmr_model_desc pd = *desc;
     pd.size = sp;
@@ -1158,6 +1196,11 @@ static int model_create_at_kernel_size(rmr_engine *e, const rmr_model_desc *desc
             RMR_TRY(pack_conv_split(m.get(), convs[4], m->nparts, &m->seq2));
             RMR_TRY(pack_conv_split(m.get(), convs[5], m->nparts, &m->merge1));
         }
+        if (m->nparts == 1 && sz > 64) {  // k_stream16.hip: 16-bit A fragments of the three size-wide layers, k = tap * ic + channel
+            RMR_TRY(pack_flat_a(m.get(), convs[2], convs[2].s.ic, (convs[2].s.kw * convs[2].s.ic + 31) / 32, 1.0, &m->sig3.apack16, m->f16));
+            RMR_TRY(pack_flat_a(m.get(), convs[4], convs[4].s.ic, (convs[4].s.kw * convs[4].s.ic + 31) / 32, 1.0, &m->seq2.apack16, m->f16));
+            RMR_TRY(pack_flat_a(m.get(), convs[5], convs[5].s.ic, (convs[5].s.kw * convs[5].s.ic + 31) / 32, 1.0, &m->merge1.apack16, m->f16));
+        }
         if (m->nparts == 1 && sz == 64 && (K == 9 || K == 6) && kw1 == 5) {  // operands of the fused front kernel
             const int cg = (4 * K + 7) / 8;
             const double log2e = 1.4426950408889634;
@@ -1227,6 +1270,13 @@ static int model_create_at_kernel_size(rmr_engine *e, const rmr_model_desc *desc
             RMR_TRY(upload(m.get(), pack_bias_x16(bih1, bhh1, false), &m->lstm.x_b1));
             RMR_TRY(upload(m.get(), pack_bias_x16(bih2, bhh2, true), &m->lstm.x_b2));
         }
+        if (m->nparts == 1 && H > 64) {  // k_stream16.hip
+            RMR_TRY(upload(m.get(), pack_lstm_s16(wih1, H, false, m->f16), &m->lstm.s16_ih));
+            RMR_TRY(upload(m.get(), pack_lstm_s16(whh1, H, false, m->f16), &m->lstm.s16_hh));
+            RMR_TRY(upload(m.get(), pack_lstm_s16(wih2, H, true, m->f16), &m->lstm.s16_ih2));
+            RMR_TRY(upload(m.get(), pack_bias_s16(bih1, bhh1, H, false), &m->lstm.s16_b1));
+            RMR_TRY(upload(m.get(), pack_bias_s16(bih2, bhh2, H, true), &m->lstm.s16_b2));
+        }
         if (m->nparts == 1 && H == 64) {
             RMR_TRY(upload(m.get(), pack_lstm_x16(wih1, false, m->f16), &m->lstm.x_ih));
             RMR_TRY(upload(m.get(), pack_lstm_x16(whh1, false, m->f16), &m->lstm.x_hh));
@@ -1283,6 +1333,36 @@ int run_pipeline(rmr_model *m, const float *signal, const float *enc, const int8
                  float *logits) {
     rmr_engine *e = m->eng;
     if (n <= 0) return 0;
+    if (m->nparts == 1 && m->desc.size > 64) {
+        // bf16 / f16 above 64 channels (k_stream16.hip): fp32 front kernels (sig_conv1/2, seq_conv1: 16 channels), then the three
+        // size-wide convolutions and the LSTM on the 16-bit matrix cores with streamed weights; cat and x are 16-bit in HBM
+        const int sz = m->desc.size, L = m->L, EC = 4 * m->desc.kmer_len;
+        int64_t sb = e->subbatch > 0 ? e->subbatch : 131072;
+        if (sb > n) sb = n;
+        const size_t front_fl = (size_t)(m->P1 + m->P2) * 16;
+        const size_t cat_el = (size_t)m->P3 * 2 * sz, x_el = (size_t)m->T * sz;
+        RMR_TRY(e->ensure(e->act, (front_fl * sizeof(float) + (cat_el + x_el) * sizeof(uint16_t) + 64) * sb));
+        float *seq1 = reinterpret_cast<float *>(e->act.ptr);
+        for (int64_t c0 = 0; c0 < n; c0 += sb) {
+            const int64_t nb = (n - c0) < sb ? (n - c0) : sb;
+            float *sig2 = seq1 + (size_t)nb * m->P1 * 16;
+            uint16_t *cat = reinterpret_cast<uint16_t *>(seq1 + front_fl * sb);
+            uint16_t *x16 = cat + cat_el * sb + 32;
+            const float *sig_b = signal + (size_t)c0 * L;
+            if (enc) {
+                RMR_TRY(launch_front(m, e->stream, sig_b, nullptr, 0, nullptr, 0, nullptr, 0, 0, nb, sig2, nullptr));
+                RMR_TRY(launch_seq1_dense(m, enc + (size_t)c0 * EC * L, nb, seq1));
+            } else {
+                RMR_TRY(launch_front(m, e->stream, sig_b, seqs + (size_t)c0 * seq_w, seq_w, maps + (size_t)c0 * map_w, map_w, lens + c0, kb, ka, nb,
+                                     sig2, seq1));
+            }
+            RMR_TRY(launch_conv_stream16(m, m->sig3, sig2, false, m->P2, cat, 2 * sz, 0, m->P3, nb));
+            RMR_TRY(launch_conv_stream16(m, m->seq2, seq1, false, m->P1, cat, 2 * sz, sz, m->P3, nb));
+            RMR_TRY(launch_conv_stream16(m, m->merge1, cat, true, m->P3, x16, sz, 0, m->T, nb));
+            RMR_TRY(launch_lstm_stream16(m, x16, nb, logits + (size_t)c0 * m->desc.num_out));
+        }
+        return 0;
+    }
     if (m->f16 && (enc || !fused_front_supported(m, seq_w, map_w)))
         RMR_FAIL(RMR_ERR_INVALID, "dtype f16 runs on the fused kernels only: chunk arrays (not a dense one-hot tensor), sequence rows of at "
                                   "most 256 columns, a chunk length that is a multiple of 4");

@@ -161,6 +161,7 @@ struct ConvLayer {
     int ic = 0, oc = 0, kw = 0, stride = 1;
     float *apack = nullptr;  // device, fragment order [oc/16][kw*ic/4][64]
     float *apack4 = nullptr; // device, streamed-kernel order [oc/16][kw*ic/16][64][4] (k_stream.hip; layers of networks with > 64 channels)
+    float *apack16 = nullptr; // device, 16-bit A fragments [oc/16][ceil(kw*ic/32)][64 lanes] x 16 B, k = tap * ic + channel (k_stream16.hip)
     float *spack = nullptr;  // device, split-bf16 fragments [oc/16][steps][nparts][64] x 16 B (dtype != 0)
     float *bias = nullptr;   // device, folded bias [oc]
     int kid = 0;             // profiling id
@@ -204,6 +205,9 @@ struct LstmWeights {
     // lstm_small_kernel (k_lstm.hip; 64 hidden units, fp32, batches of a few hundred chunks): [4 waves][64 k in issue order][64 lanes],
     // lane l = gate l & 3 (lstm2: i, g, o, zero) of unit 16 w + (l >> 2)
     float *q_ih1 = nullptr, *q_hh1 = nullptr, *q_ih2 = nullptr;
+    // k_stream16.hip (more than 64 hidden units, bf16 / f16): [H/16 waves][4 tiles][H/32 k-steps][64 lanes] x 16 B, row m of tile t of
+    // wave w = (unit 16 w + 4 (m >> 2) + t, gate m & 3), pre-scaled; biases [H/16][4][4 q][4 gates]
+    float *s16_ih = nullptr, *s16_hh = nullptr, *s16_ih2 = nullptr, *s16_b1 = nullptr, *s16_b2 = nullptr;
 };
 
 }  // namespace rmr
@@ -281,6 +285,10 @@ int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_conv_stream(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out, int out_row, int out_coff,
                        int pout, int64_t n);
 int launch_lstm_stream(rmr_model *m, const float *x, int64_t n, float *logits);
+// k_stream16.hip: the same network in the 16-bit dtypes (activations 16-bit in HBM between the launches)
+int launch_conv_stream16(rmr_model *m, const ConvLayer &c, const void *in, bool in16, int pin, uint16_t *out, int out_row, int out_coff, int pout,
+                         int64_t n);
+int launch_lstm_stream16(rmr_model *m, const uint16_t *x, int64_t n, float *logits);
 int launch_lstm_head_split(rmr_model *m, const float *x, int64_t n, float *logits);
 int launch_conv_split(rmr_engine *e, const ConvLayer &c, int np, const float *in, int in_row, int pin,
                       float *out, int out_row, int out_coff, int pout, int64_t n);

@@ -229,9 +229,9 @@ class HipModel:
         want = lib.rmr_model_weight_count(ctypes.byref(desc))
         if want == 0:
             raise RemoraError(f"model not supported by the HIP engine: arch={arch} size={size} "
-                              f"kmer_len={kmer_len} num_out={num_out} dtype={dtype} (size 1..256 in fp32; the 16-bit dtypes "
-                              "need conv_lstm with at most 64 channels - f16 / bf16 on the fused kernels 33..64 and a k-mer "
-                              "length of 9 or 6; larger networks run in fp32)")
+                              f"kmer_len={kmer_len} num_out={num_out} dtype={dtype} (size 1..256; the 16-bit dtypes need conv_lstm; "
+                              "up to 64 channels f16 / bf16 on the fused kernels take 33..64 channels and a k-mer length of 9 or 6; "
+                              "above 64 channels the dtypes are fp32, bf16 and f16 - the split dtypes stop at 64)")
         if want != blob.size:
             raise RemoraError(f"weight blob has {blob.size} floats, engine expects {want}")
         h = ctypes.c_void_p()

@@ -386,6 +386,47 @@ def test_16bit_error_is_the_arithmetic_not_the_kernel(torch_cuda, O, cfg, n):
             # kernels round a little less often than it assumes: measured 0.5-0.6 of its mean in f16, 0.9-1.0 in bf16)
 
 
+STREAM16_SITES = ("wconv.sig3", "wconv.seq2", "wconv.merge1", "aconv.sig2", "aconv.seq1", "aconv.cat", "x", "wlstm", "h")
+
+
+@pytest.mark.parametrize("cfg,size", [("C100", 128), ("C100", 96), ("C200", 160), ("C100", 256), ("C100", 100)])
+def test_16bit_networks_of_more_than_64_channels(torch_cuda, O, cfg, size):
+    """bf16 / f16 above 64 channels (k_stream16.hip: fp32 front kernels, then sig_conv3 / seq_conv2 / merge_conv1 and the LSTM on the
+    16-bit matrix cores with streamed weights, 16-bit cat and x in HBM; a size that is no multiple of 32 runs with zero-weight
+    channels).  Against the float64 network and against the float64 network rounded at THIS pipeline's 16-bit sites: the error is
+    the arithmetic's, as for the fused kernels; ragged batches; chunk position does not matter; the dense-tensor entry works."""
+    from oracle import lowp_emulation, torch_ref
+    from remora_amd import synth
+    from remora_amd.model_util import model_from_state
+
+    torch = torch_cuda
+    cc, kcb, _, num_out, _ = synth.CONFIGS[cfg]
+    state = synth.synth_state("conv_lstm", size, 9, num_out, seed=3)
+    net = torch_ref.from_state(state)
+    n = 1500
+    d = synth.synth_chunks_config(cfg, n, shard=9)
+    enc_np = O.compute_encoded_kmer_batch(kcb[0], kcb[1], d["sequence"], d["sequence_to_signal_mapping"], d["sequence_lengths"])
+    enc, sig = torch.from_numpy(enc_np), torch.from_numpy(d["signal"])
+    keys = ("signal", "sequence", "sequence_to_signal_mapping", "sequence_lengths")
+    with torch.no_grad():
+        exact = lowp_emulation.forward(net, sig, enc, sites=()).numpy()
+        for dtype in ("bf16", "f16"):
+            emu = np.abs(lowp_emulation.forward(net, sig, enc, sites=STREAM16_SITES, fmt=dtype).numpy() - exact)
+            model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=dtype)
+            assert model.kernel_size == (size + 31) // 32 * 32
+            out = model.infer_chunks(*[d[k] for k in keys], kcb)
+            gpu = np.abs(out - exact)
+            stats = (cfg, size, dtype, gpu.mean(), emu.mean(), np.quantile(gpu, 0.99), np.quantile(emu, 0.99), gpu.max(), emu.max())
+            assert gpu.mean() <= 1.3 * emu.mean() + 2e-5, stats
+            assert np.quantile(gpu, 0.99) <= 1.4 * np.quantile(emu, 0.99) + 1e-4, stats
+            assert emu.mean() <= 3.0 * gpu.mean() + 2e-5, stats
+            for start, m in ((0, 1), (7, 63), (100, 65), (300, 257)):  # ragged batches return the same bits
+                part = model.infer_chunks(*[d[k][start : start + m] for k in keys], kcb)
+                assert np.array_equal(part, out[start : start + m]), (cfg, size, dtype, start, m)
+            dense = model(sig[:64].cuda(), enc[:64].cuda()).cpu().numpy()
+            assert np.array_equal(dense, out[:64])
+
+
 def test_f16_dtype_refuses_what_it_cannot_run(torch_cuda, O):
     """f16 exists on the fused kernels only: Conv_w_ref, size 16 and a dense one-hot input are refused with messages."""
     from conftest import golden

@@ -207,8 +207,12 @@ def test_state_to_blob_layout_matches_engine_count():
         assert (a, s, k, n) == (arch, size, K, no)
         desc = L.ModelDesc(0 if arch == "conv_lstm" else 1, size, K, no, 100, 0)
         assert L.lib().rmr_model_weight_count(ctypes.byref(desc)) == blob.size
-    for bad in (L.ModelDesc(0, 257, 9, 2, 100, 0), L.ModelDesc(0, 0, 9, 2, 100, 0), L.ModelDesc(0, 96, 9, 2, 100, 1),
-                L.ModelDesc(1, 64, 9, 2, 100, 1), L.ModelDesc(0, 64, 9, 17, 100, 0)):  # too wide; empty; 16-bit above 64; 16-bit conv_only
+    # 16-bit above 64 channels: bf16 / f16 on the streamed kernels, in steps of 32 channels
+    for size, dtype, want in ((96, 1, 96), (80, 1, 96), (80, 0, 80), (130, 4, 160), (256, 1, 256), (40, 4, 64)):
+        d16 = L.ModelDesc(0, size, 9, 2, 100, dtype)
+        assert L.lib().rmr_model_padded_size(ctypes.byref(d16)) == want and L.lib().rmr_model_weight_count(ctypes.byref(d16)) > 0
+    for bad in (L.ModelDesc(0, 257, 9, 2, 100, 0), L.ModelDesc(0, 0, 9, 2, 100, 0), L.ModelDesc(0, 96, 9, 2, 100, 5), L.ModelDesc(0, 260, 9, 2, 100, 1),
+                L.ModelDesc(1, 64, 9, 2, 100, 1), L.ModelDesc(0, 64, 9, 17, 100, 0)):  # too wide; empty; split dtype above 64; too wide in 16 bits; 16-bit conv_only
         assert L.lib().rmr_model_weight_count(ctypes.byref(bad)) == 0 and L.lib().rmr_model_padded_size(ctypes.byref(bad)) == 0
     from remora_amd import RemoraError
 
