@@ -826,6 +826,31 @@ int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
     out->ic = s.ic; out->oc = s.oc; out->kw = s.kw; out->stride = s.stride; out->kid = kid;
     RMR_TRY(upload(m, ap, &out->apack));
     RMR_TRY(upload(m, f.b, &out->bias));
+    if (s.kw == 5 && s.stride == 1 && s.oc == 64 && (s.ic == 128 || s.ic == 64)) {
+        // Winograd F(2, 5) filter transform U = G W at the Toom-Cook points 0, 1, -1, 2, -2, inf (k_wino.hip has BT and AT), in float64
+        // from the folded fp32 weights, ONE rounding to fp32; fragment order [oc/16][(x * G + g) * 4 + j][64 lanes].  Rows 1 and 2 carry
+        // the sign of the kernel's negated input-transform rows (wino_in_transform).
+        static const double GM[6][5] = {{1.0 / 4, 0, 0, 0, 0},
+                                        {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
+                                        {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                        {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
+                                        {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
+                                        {0, 0, 0, 0, 1.0}};
+        const int SW = 6 * s.ic / 4;
+        std::vector<float> wp((size_t)W * SW * 64);
+        for (int w = 0; w < W; ++w)
+            for (int x = 0; x < 6; ++x)
+                for (int g = 0; g < G; ++g)
+                    for (int j = 0; j < 4; ++j)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int q = lane >> 4, mm = lane & 15;
+                            const int oc = 16 * w + mm, ic = 16 * g + 4 * q + j;
+                            double u = 0.0;
+                            for (int tap = 0; tap < 5; ++tap) u += GM[x][tap] * (double)f.w[((size_t)oc * s.ic + ic) * 5 + tap];
+                            wp[((size_t)w * SW + (x * G + g) * 4 + j) * 64 + lane] = (float)u;
+                        }
+        RMR_TRY(upload(m, wp, &out->wpack));
+    }
     return 0;
 }
 

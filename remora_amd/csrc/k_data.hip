@@ -189,7 +189,8 @@ int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
     if ((size_t)4 * a.K * sig_len >= (1u << 21)) RMR_FAIL(RMR_ERR_INVALID, "encode: chunk too large");
     const int Lp = (sig_len + 7) & ~7;
     const int wide = seq_w > map_w ? seq_w : map_w;
-    const int pf = tune_int("RMR_ENCODE_PREFETCH", 1) ? (wide <= 64 ? 1 : wide <= 128 ? 2 : wide <= 256 ? 4 : 0) : 0;
+    const int form = tune_int("RMR_ENCODE_FORM", 2);  // 2: shipped; 1: no unrolled store loop; 0: no row prefetch either (round 2's kernel)
+    const int pf = form >= 1 ? (wide <= 64 ? 1 : wide <= 128 ? 2 : wide <= 256 ? 4 : 0) : 0;
     const size_t mapb = pf ? (((size_t)map_w * 2 + 15) & ~(size_t)15) : 0;
     const size_t per_wave = ((size_t)Lp * 4 + ((seq_w + 15) & ~15) + mapb + 15) & ~(size_t)15;
     const size_t lds = per_wave * 4;
@@ -199,7 +200,7 @@ int launch_encode(rmr_engine *e, int kb, int ka, const int8_t *seqs, int seq_w,
     // the shapes of the shipped models' chunk contexts get an unrolled store loop; anything else the plain one
     const int nst = (a.K * sig_len + 63) / 64;
     void (*kern)(EncodeArgs) = pf == 1 ? encode_kernel<1, 0> : pf == 2 ? encode_kernel<2, 0> : pf == 4 ? encode_kernel<4, 0> : encode_kernel<0, 0>;
-    if (pf == 1 && tune_int("RMR_ENCODE_UNROLL", 1)) {
+    if (pf == 1 && form >= 2) {
         if (nst == 15) kern = encode_kernel<1, 15>;       // 9-mer, 100 samples
         else if (nst == 29) kern = encode_kernel<1, 29>;  // 9-mer, 200 samples
         else if (nst == 10) kern = encode_kernel<1, 10>;  // 6-mer, 100 samples

@@ -411,15 +411,19 @@ def test_16bit_networks_of_more_than_64_channels(torch_cuda, O, cfg, size):
     with torch.no_grad():
         exact = lowp_emulation.forward(net, sig, enc, sites=()).numpy()
         for dtype in ("bf16", "f16"):
-            emu = np.abs(lowp_emulation.forward(net, sig, enc, sites=STREAM16_SITES, fmt=dtype).numpy() - exact)
+            # the emulation's error is one DRAW of the rounding errors; on these amplified networks its mean spreads 2-3 x between
+            # draws (lowp_emulation.forward `prescale`; profiles/r06_stream16_parity.log), so the kernel is held to the envelope of four
+            emus = [np.abs(lowp_emulation.forward(net, sig, enc, sites=STREAM16_SITES, fmt=dtype, prescale=ps).numpy() - exact)
+                    for ps in (1.0, 1.19, 1.4426950408889634, 1.7)]
+            emu_mean, emu_q99 = [e.mean() for e in emus], [np.quantile(e, 0.99) for e in emus]
             model = model_from_state(state, dict(chunk_context=cc, kmer_context_bases=kcb), device=0, dtype=dtype)
             assert model.kernel_size == (size + 31) // 32 * 32
             out = model.infer_chunks(*[d[k] for k in keys], kcb)
             gpu = np.abs(out - exact)
-            stats = (cfg, size, dtype, gpu.mean(), emu.mean(), np.quantile(gpu, 0.99), np.quantile(emu, 0.99), gpu.max(), emu.max())
-            assert gpu.mean() <= 1.3 * emu.mean() + 2e-5, stats
-            assert np.quantile(gpu, 0.99) <= 1.4 * np.quantile(emu, 0.99) + 1e-4, stats
-            assert emu.mean() <= 3.0 * gpu.mean() + 2e-5, stats
+            stats = (cfg, size, dtype, gpu.mean(), emu_mean, np.quantile(gpu, 0.99), emu_q99, gpu.max())
+            assert gpu.mean() <= 1.3 * max(emu_mean) + 2e-5, stats
+            assert np.quantile(gpu, 0.99) <= 1.4 * max(emu_q99) + 1e-4, stats
+            assert min(emu_mean) <= 3.0 * gpu.mean() + 2e-5, stats
             for start, m in ((0, 1), (7, 63), (100, 65), (300, 257)):  # ragged batches return the same bits
                 part = model.infer_chunks(*[d[k][start : start + m] for k in keys], kcb)
                 assert np.array_equal(part, out[start : start + m]), (cfg, size, dtype, start, m)

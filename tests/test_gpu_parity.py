@@ -72,7 +72,7 @@ def test_encode_kmers_oracle_synth(torch_cuda, O, cfg):
 def test_encode_kmers_every_kernel_form(torch_cuda, O, L, max_seq, kcb, monkeypatch):
     """Every instantiation of the encode kernel against the oracle, bit for bit: rows prefetched in registers one, two
     and four elements per lane (widths up to 64 / 128 / 256), rows read where needed (wider), the store loop unrolled
-    for the shipped shapes and plain for the others - and the round-2 form (RMR_ENCODE_PREFETCH=0) on the same inputs."""
+    for the shipped shapes and plain for the others - and the round-2 form (RMR_ENCODE_FORM=0) on the same inputs."""
     from remora_amd import synth
     from remora_amd.encoded_kmers import compute_encoded_kmer_batch
 
@@ -84,9 +84,9 @@ def test_encode_kmers_every_kernel_form(torch_cuda, O, L, max_seq, kcb, monkeypa
     dev = [torch.from_numpy(a).cuda() for a in args]
     got = compute_encoded_kmer_batch(kb, ka, *dev).cpu().numpy()
     assert got.shape == ref.shape == (777, 4 * (kb + ka + 1), L) and np.array_equal(got, ref)
-    monkeypatch.setenv("RMR_ENCODE_UNROLL", "0")
+    monkeypatch.setenv("RMR_ENCODE_FORM", "1")
     assert np.array_equal(compute_encoded_kmer_batch(kb, ka, *dev).cpu().numpy(), ref)
-    monkeypatch.setenv("RMR_ENCODE_PREFETCH", "0")
+    monkeypatch.setenv("RMR_ENCODE_FORM", "0")
     assert np.array_equal(compute_encoded_kmer_batch(kb, ka, *dev).cpu().numpy(), ref)
 
 
