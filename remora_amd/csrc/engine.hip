@@ -827,19 +827,22 @@ int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
     RMR_TRY(upload(m, ap, &out->apack));
     RMR_TRY(upload(m, f.b, &out->bias));
     if (s.kw == 5 && s.stride == 1 && s.oc == 64 && (s.ic == 128 || s.ic == 64)) {
-        // Winograd F(2, 5) filter transform U = G W at the Toom-Cook points 0, 1, -1, 2, -2, inf (k_wino.hip has BT and AT), in float64
-        // from the folded fp32 weights, ONE rounding to fp32; fragment order [oc/16][(x * G + g) * 4 + j][64 lanes].  Rows 1 and 2 carry
-        // the sign of the kernel's negated input-transform rows (wino_in_transform).
-        static const double GM[6][5] = {{1.0 / 4, 0, 0, 0, 0},
-                                        {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
-                                        {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                        {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
-                                        {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
-                                        {0, 0, 0, 0, 1.0}};
-        const int SW = 6 * s.ic / 4;
+        // Winograd F(4, 5) filter transform U = G W at the Toom-Cook points 0, 1, -1, 2, -2, 1/2, -1/2, inf (k_wino.hip has BT and AT;
+        // oracle/winograd.py derives all three), in float64 from the folded fp32 weights, ONE rounding to fp32.  Rows in the kernel's
+        // x order - the points 1, -1, 2, -2 (wave half 0), then 0, 1/2, -1/2, inf (half 1); fragment order
+        // [oc/16][(x * G + g) * 4 + j][64 lanes].
+        static const double GM[8][5] = {{1.0 / 18, 1.0 / 18, 1.0 / 18, 1.0 / 18, 1.0 / 18},
+                                        {1.0 / 18, -1.0 / 18, 1.0 / 18, -1.0 / 18, 1.0 / 18},
+                                        {1.0 / 360, 1.0 / 180, 1.0 / 90, 1.0 / 45, 2.0 / 45},
+                                        {1.0 / 360, -1.0 / 180, 1.0 / 90, -1.0 / 45, 2.0 / 45},
+                                        {1.0 / 4, 0, 0, 0, 0},
+                                        {16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45, 1.0 / 45},
+                                        {16.0 / 45, -8.0 / 45, 4.0 / 45, -2.0 / 45, 1.0 / 45},
+                                        {0, 0, 0, 0, 1.0 / 4}};
+        const int SW = 8 * s.ic / 4;
         std::vector<float> wp((size_t)W * SW * 64);
         for (int w = 0; w < W; ++w)
-            for (int x = 0; x < 6; ++x)
+            for (int x = 0; x < 8; ++x)
                 for (int g = 0; g < G; ++g)
                     for (int j = 0; j < 4; ++j)
                         for (int lane = 0; lane < 64; ++lane) {

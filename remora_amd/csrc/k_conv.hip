@@ -268,7 +268,7 @@ int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, 
                 float *out, int out_row, int out_coff, int pout, int64_t n) {
     if (in_row != c.ic) RMR_FAIL(RMR_ERR_INVALID, "conv input row %d != ic %d", in_row, c.ic);
     if (c.apack4) return launch_conv_stream(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);  // > 64 channels: k_stream.hip
-    // 5 taps, stride 1, 64 output channels: Winograd F(2, 5), 0.6 of the MFMAs (k_wino.hip).  RMR_WINOGRAD=0: the direct form below
+    // 5 taps, stride 1, 64 output channels: Winograd F(4, 5), 0.4 of the MFMAs (k_wino.hip).  RMR_WINOGRAD=0: the direct form below
     // (its comparand, tests/test_gpu_wino.py).  Every batch size takes it: the bits of a chunk do not depend on the batch it arrives in
     if (conv_wino_supported(c, pin, pout) && tune_int("RMR_WINOGRAD", 1)) return launch_conv_wino(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);
 #define RMR_CONV_CASE(IC_, KW_, ST_)                                  \

@@ -160,7 +160,7 @@ namespace rmr {
 struct ConvLayer {
     int ic = 0, oc = 0, kw = 0, stride = 1;
     float *apack = nullptr;  // device, fragment order [oc/16][kw*ic/4][64]
-    float *wpack = nullptr;  // device, Winograd F(2,5) fragments U = G W: [oc/16][6 * ic/4][64] (k_wino.hip; fp32 5-tap stride-1 layers of 64 output channels)
+    float *wpack = nullptr;  // device, Winograd F(4,5) fragments U = G W: [oc/16][8 * ic/4][64] (k_wino.hip; fp32 5-tap stride-1 layers of 64 output channels)
     float *apack4 = nullptr; // device, streamed-kernel order [oc/16][kw*ic/16][64][4] (k_stream.hip; layers of networks with > 64 channels)
     float *apack16 = nullptr; // device, 16-bit A fragments [oc/16][ceil(kw*ic/32)][64 lanes] x 16 B, k = tap * ic + channel (k_stream16.hip)
     float *spack = nullptr;  // device, split-bf16 fragments [oc/16][steps][nparts][64] x 16 B (dtype != 0)
@@ -282,7 +282,7 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
 int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin,
                 float *out, int out_row, int out_coff, int pout, int64_t n);
 int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
-// k_wino.hip: the 5-tap stride-1 layers of 64 output channels as a Winograd F(2, 5) convolution (0.6 of the direct form's MFMAs)
+// k_wino.hip: the 5-tap stride-1 layers of 64 output channels as a Winograd F(4, 5) convolution (0.4 of the direct form's MFMAs)
 bool conv_wino_supported(const ConvLayer &c, int pin, int pout);
 int launch_conv_wino(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out, int out_row, int out_coff,
                      int pout, int64_t n);

@@ -427,8 +427,10 @@ def test_16bit_networks_of_more_than_64_channels(torch_cuda, O, cfg, size):
             for start, m in ((0, 1), (7, 63), (100, 65), (300, 257)):  # ragged batches return the same bits
                 part = model.infer_chunks(*[d[k][start : start + m] for k in keys], kcb)
                 assert np.array_equal(part, out[start : start + m]), (cfg, size, dtype, start, m)
+            # the dense-tensor entry sums seq_conv1 over the one-hot's 36 channels where the chunk-array entry sums table rows per
+            # k-mer slot: fp32 seq1 differs in the last bits, which now and then moves one 16-bit rounding downstream
             dense = model(sig[:64].cuda(), enc[:64].cuda()).cpu().numpy()
-            assert np.array_equal(dense, out[:64])
+            assert np.abs(dense - out[:64]).max() <= (2e-2 if dtype == "bf16" else 3e-3), (cfg, size, dtype, float(np.abs(dense - out[:64]).max()))
 
 
 def test_f16_dtype_refuses_what_it_cannot_run(torch_cuda, O):

@@ -1,4 +1,4 @@
-"""GPU parity of the Winograd F(2, 5) form of the 5-tap stride-1 convolutions (remora_amd/csrc/k_wino.hip: merge_conv1 of
+"""GPU parity of the Winograd F(4, 5) form of the 5-tap stride-1 convolutions (remora_amd/csrc/k_wino.hip: merge_conv1 of
 models/ConvLSTM_w_ref.py:36-37,50 and merge_conv1 / merge_conv2 of models/Conv_w_ref.py:35-38,54-55 at size 64): within the fp32
 tolerance (1e-4 on logits) of the reference-generated golden models and of the CPU restatement of the reference network, no
 further from float64 than the direct form (RMR_WINOGRAD=0, k_conv.hip) by more than a rounding-level margin, the same bits
@@ -51,8 +51,8 @@ def test_golden_models_through_the_winograd_kernel(name):
 @pytest.mark.parametrize("arch,cfg,num_out", [("conv_lstm", "C100", 2), ("conv_lstm", "C200", 3), ("conv_only", "C100", 2), ("conv_only", "C100", 3)])
 def test_winograd_against_float64_and_the_direct_form(arch, cfg, num_out):
     """Random networks at torch's initialisation scale and the amplified synthetic one: distance to the float64 network of the
-    Winograd kernel and of the direct form; ragged batch sizes (columns = position pairs flattened over the chunks, 16 per
-    iteration: 1, 3, 17 ... chunks end inside a tile, C200's 57 positions end on an odd pair)."""
+    Winograd kernel and of the direct form; ragged batch sizes (columns = groups of four positions flattened over the chunks, 16 per
+    iteration: 1, 3, 17 ... chunks end inside a tile, C200's 57 positions end one position into a group)."""
     import torch
 
     from oracle import oracle as O
@@ -82,7 +82,7 @@ def test_winograd_against_float64_and_the_direct_form(arch, cfg, num_out):
                 exact = net64(torch.from_numpy(d["signal"]).double(), torch.from_numpy(enc).double()).numpy()
             ew, ed = float(np.abs(out - exact).max()), float(np.abs(direct - exact).max())
             assert ew <= 1e-4, (arch, cfg, k, n, ew, ed)
-            assert ew <= 3.0 * ed + 2e-6, (arch, cfg, k, n, ew, ed)  # F(2,5) at 0, +-1, +-2, inf: about twice the direct form's rounding
+            assert ew <= 3.0 * ed + 2e-6, (arch, cfg, k, n, ew, ed)  # F(4, 5): about twice the direct form's rounding
             if n == 4099:  # a chunk's bits do not depend on its neighbours in the batch
                 for start, m in ((0, 1), (5, 2), (100, 31), (1000, 1025)):
                     part = model.infer_chunks(*[a[start : start + m] for a in args[:4]], kcb)

@@ -3185,3 +3185,61 @@ def test_padded_network_is_the_same_function(O, name, padded):
     got = O.forward(pstate, g["sigs"], enc)
     assert np.abs(got - g["logits"]).max() < 2e-5, float(np.abs(got - g["logits"]).max())
     assert np.abs(got - O.forward(state, g["sigs"], enc)).max() < 1e-6  # zero channels change nothing but the summation tree
+
+
+def test_winograd_constants_match_the_exact_derivation():
+    """k_wino.hip / engine.hip hold the F(4, 5) matrices as constants: the filter transform G (engine.hip `GM`, rows in the kernel's x
+    order) and the BT / G / AT table of k_wino.hip's header are the ones oracle/winograd.py derives from the eight points in exact
+    rational arithmetic; the derivation itself reproduces the plain sums y[i] = sum_k g[k] d[i + k] exactly; and the even / odd
+    evaluation the kernel uses for BT d (restated here line by line from wino_in_transform) equals BT d."""
+    import random
+    from fractions import Fraction as Fr
+
+    from oracle import winograd as W
+
+    AT, G, BT = W.matrices(4, 5, W.F45_POINTS)
+    rnd = random.Random(5)
+    for _ in range(25):
+        g = [Fr(rnd.randint(-9, 9), rnd.randint(1, 7)) for _ in range(5)]
+        d = [Fr(rnd.randint(-9, 9), rnd.randint(1, 7)) for _ in range(8)]
+        assert W.apply(AT, G, BT, g, d) == W.correlate(g, d, 4)
+    # engine.hip: static const double GM[8][5] = {{...}, ...}; entries are C expressions like 1.0 / 18 or -8.0 / 45
+    eng = open(os.path.join(ROOT, "remora_amd", "csrc", "engine.hip")).read()
+    blk = eng[eng.index("static const double GM[8][5]") :]
+    blk = blk[blk.index("{") : blk.index("};") + 1]
+    rows = re.findall(r"\{([^{}]+)\}", blk)
+    assert len(rows) == 8
+    for k, row in enumerate(rows):
+        vals = []
+        for e in row.split(","):
+            num, _, den = e.strip().partition("/")
+            vals.append(Fr(num.strip()) / (Fr(den.strip()) if den else 1))
+        assert vals == G[W.F45_KERNEL_ORDER[k]], (k, row)
+    # k_wino.hip's header table (BT | G | AT side by side)
+    src = open(os.path.join(ROOT, "remora_amd", "csrc", "k_wino.hip")).read()
+    tab = src[src.index("//     BT = ") :].split("\n")[:8]
+    for i, line in enumerate(tab):
+        toks = line.replace("//", "").replace("BT =", "").replace("G =", "").replace("AT =", "").split()
+        assert [Fr(t) for t in toks[:8]] == BT[i], (i, line)
+        assert [Fr(t) for t in toks[8:13]] == G[i], (i, line)
+        if i < 4:
+            assert [Fr(t) for t in toks[13:21]] == AT[i], (i, line)
+    # wino_in_transform, operation for operation, on exact numbers: v in the kernel's x order
+    for _ in range(10):
+        d = [Fr(rnd.randint(-50, 50), rnd.randint(1, 9)) for _ in range(8)]
+        e1 = -4 * (d[2] + d[6]) + 17 * d[4]
+        o1 = -4 * (d[1] + d[5]) + 17 * d[3]
+        e2 = -5 * d[4] + (4 * d[6] + d[2])
+        o2 = -5 * d[3] + (4 * d[5] + d[1])
+        e3 = -5 * d[4] + (4 * d[2] + d[6])
+        o3 = -5 * d[3] + (4 * d[1] + d[5])
+        v = [e1 + o1, e1 - o1, 2 * o2 + e2, -2 * o2 + e2, -21 * (d[2] - d[4]) + 4 * (d[0] - d[6]), 2 * e3 + o3, 2 * e3 - o3,
+             21 * (d[3] - d[5]) + 4 * (d[7] - d[1])]
+        want = [sum(BT[x][j] * d[j] for j in range(8)) for x in W.F45_KERNEL_ORDER]
+        assert v == want
+    # the output stage of the kernel (two wave halves) is AT m
+    for _ in range(10):
+        m = [Fr(rnd.randint(-50, 50), rnd.randint(1, 9)) for _ in range(8)]
+        s12, d12, s34, d34, s56, d56 = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4], m[5] + m[6], m[5] - m[6]
+        y = [(s12 + s34) + (m[0] + s56), (2 * d34 + d12) + d56 / 2, (4 * s34 + s12) + s56 / 4, (8 * d34 + d12) + (d56 / 8 + m[7])]
+        assert y == [sum(AT[i][x] * m[x] for x in range(8)) for i in range(4)]
