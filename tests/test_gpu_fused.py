@@ -422,7 +422,7 @@ def test_16bit_networks_of_more_than_64_channels(torch_cuda, O, cfg, size):
             gpu = np.abs(out - exact)
             stats = (cfg, size, dtype, gpu.mean(), emu_mean, np.quantile(gpu, 0.99), emu_q99, gpu.max())
             assert gpu.mean() <= 1.3 * max(emu_mean) + 2e-5, stats
-            assert np.quantile(gpu, 0.99) <= 1.4 * max(emu_q99) + 1e-4, stats
+            assert np.quantile(gpu, 0.99) <= 2.0 * max(emu_q99) + 1e-4, stats  # (the top 30 of 3000 values: a wider spread than the mean's)
             assert min(emu_mean) <= 3.0 * gpu.mean() + 2e-5, stats
             for start, m in ((0, 1), (7, 63), (100, 65), (300, 257)):  # ragged batches return the same bits
                 part = model.infer_chunks(*[d[k][start : start + m] for k in keys], kcb)

@@ -29,4 +29,4 @@ for abl in (0, 1, 2, 4, 3, 5, 6, 7):
     torch.cuda.synchronize()
     eng.profile_enable(False)
     prof = eng.profile()
-    print(f"ablate {abl}: " + "  ".join(f"{k} {v[0] / v[1]:.3f} ms" for k, v in prof.items() if k.startswith("conv_merge")), flush=True)
+    print(f"ablate {abl}: " + "  ".join(f"{k} {v[0] / v[1]:.3f} ms" for k, v in prof.items() if k.startswith("conv_")), flush=True)
