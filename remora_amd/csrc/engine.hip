@@ -421,11 +421,11 @@ void poison_before_launch(rmr_engine *e, hipStream_t s) {
 }
 }  // namespace rmr
 
-int rmr_engine::allow_big_lds(const void *kernel) {
+int rmr_engine::allow_big_lds(const void *kernel, size_t bytes) {
     for (const void *k : lds_attr_set)
         if (k == kernel) return 0;
     RMR_HIP(hipSetDevice(device));
-    RMR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RMR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     lds_attr_set.push_back(kernel);
     return 0;
 }

@@ -137,9 +137,19 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float xbuf[2][4][16][RS];
     __shared__ __attribute__((aligned(16))) float hbuf[2][4][16][RS];
     __shared__ float part[NW][16][16];
+    // lstm2's W_ih fragments of this wave ([3 gates][KS][64 lanes], 12 KB at H = 64), copied once: the one step of lstm2 per 16-chunk
+    // group used to fetch each fragment from L2 right in front of its MFMA - 48 dependent loads (their 24 address pairs spilled
+    // to scratch: the kernel's 55 spilled registers) at the end of every group
+    extern __shared__ __attribute__((aligned(16))) float w2_lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+    float *const w2 = w2_lds + (size_t)w * 3 * KS * 64 + lane;
+    {
+        const float *src = a.a_ih2 + (size_t)w * 3 * KS * 64 + lane;
+#pragma unroll 8
+        for (int i = 0; i < 3 * KS; ++i) w2[i * 64] = src[(size_t)i * 64];  // (read by this wave only; the group loop's first barrier orders it anyway)
+    }
 
     float Aih[4][KS], Ahh[4][KS];
 #pragma unroll
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(4 * H, 2) void lstm_head_kernel(LstmArgs a) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int gt = 0; gt < 3; ++gt) {
-                        const float aw = a.a_ih2[((size_t)(w * 3 + gt) * KS + g * 4 + j) * 64 + lane];
+                        const float aw = w2[(gt * KS + g * 4 + j) * 64];
                         acc2[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, z[j], acc2[gt], 0, 0, 0);
                     }
             }
@@ -410,15 +420,21 @@ static int launch_lstm_t(rmr_model *m, const float *x, int64_t n, float *logits)
     int64_t grid = (int64_t)e->num_cus * 16;
     if (grid > groups) grid = groups;
     if (grid < 1) return 0;
+    const size_t lds = (size_t)(H / 16) * 3 * (H / 4) * 64 * sizeof(float);  // lstm2's fragments; + 24 KB of static images: 72 KB at H = 64, two blocks per CU
+    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(lstm_head_kernel<H, 0>), lds));
     ProfScope ps(e, K_LSTM_HEAD);
 #ifdef RMR_TIMING_ABLATIONS  // experiment builds only (make CXXFLAGS+=-DRMR_TIMING_ABLATIONS): variants that skip work
     const int abl = abl_int("RMR_LSTM_ABLATE", 0);
-    if (abl == 1) hipLaunchKernelGGL((lstm_head_kernel<H, 1>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
-    else if (abl == 2) hipLaunchKernelGGL((lstm_head_kernel<H, 2>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
-    else if (abl == 3) hipLaunchKernelGGL((lstm_head_kernel<H, 3>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    if (abl >= 1 && abl <= 3) {
+        const void *k = abl == 1 ? reinterpret_cast<const void *>(lstm_head_kernel<H, 1>) : abl == 2 ? reinterpret_cast<const void *>(lstm_head_kernel<H, 2>) : reinterpret_cast<const void *>(lstm_head_kernel<H, 3>);
+        RMR_TRY(e->allow_big_lds(k, lds));
+    }
+    if (abl == 1) hipLaunchKernelGGL((lstm_head_kernel<H, 1>), dim3((unsigned)grid), dim3(4 * H), lds, e->stream, a);
+    else if (abl == 2) hipLaunchKernelGGL((lstm_head_kernel<H, 2>), dim3((unsigned)grid), dim3(4 * H), lds, e->stream, a);
+    else if (abl == 3) hipLaunchKernelGGL((lstm_head_kernel<H, 3>), dim3((unsigned)grid), dim3(4 * H), lds, e->stream, a);
     else
 #endif
-    hipLaunchKernelGGL((lstm_head_kernel<H, 0>), dim3((unsigned)grid), dim3(4 * H), 0, e->stream, a);
+    hipLaunchKernelGGL((lstm_head_kernel<H, 0>), dim3((unsigned)grid), dim3(4 * H), lds, e->stream, a);
     RMR_HIP(hipGetLastError());
     return 0;
 }

@@ -112,7 +112,7 @@ struct rmr_engine {
     // kernels whose dynamic-LDS limit was raised ON THIS DEVICE (hipFuncSetAttribute is per device: a flag per
     // process would skip the second engine of a multi-GPU process); guarded by `mu` like every launch
     std::vector<const void *> lds_attr_set;
-    int allow_big_lds(const void *kernel);
+    int allow_big_lds(const void *kernel, size_t bytes = 160 * 1024);  // `bytes`: the dynamic share (a kernel with static LDS asks for less)
 
     // profiling
     bool profiling = false;
