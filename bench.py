@@ -531,6 +531,11 @@ class Job:
                     if name in kern and kern[name]["tflops"]:
                         kern[name]["executed_tflops"] = kern[name]["tflops"] * executed[name] / flops[name]
                         kern[name]["form"] = "Winograd F(4,5): 8 MFMA products per 4 outputs and input channel (direct form: 20) + 46 VALU transform operations"
+            if self.arch != "conv_lstm" and "conv_seq3" in flops:  # Conv_w_ref's seq_conv3: stride 3 as three 3-tap phases in F(4,3) form
+                executed["conv_seq3"] = flops["conv_seq3"] * (6 * ((P3 + 3) // 4)) / (3 * P3)
+                if "conv_seq3" in kern and kern["conv_seq3"]["tflops"]:
+                    kern["conv_seq3"]["executed_tflops"] = kern["conv_seq3"]["tflops"] * executed["conv_seq3"] / flops["conv_seq3"]
+                    kern["conv_seq3"]["form"] = "polyphase Winograd F(4,3): 6 MFMA products per 4 outputs, phase and input channel (direct form: 12)"
         cand = [k for k in kern if flops.get(k) and not k.startswith("front_")]
         dom = max(cand, key=lambda k: kern[k]["ms_total"])
         cpl = n * steps / kern[dom]["launches"]

@@ -854,6 +854,29 @@ int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
                         }
         RMR_TRY(upload(m, wp, &out->wpack));
     }
+    if (s.stride == 3 && s.ic == 32 && s.oc == 64 && s.kw == 9) {
+        // Conv_w_ref's seq_conv3 (models/Conv_w_ref.py:31-32,51): stride 3 as three phase filters w_p[m] = w[3 m + p] of three taps
+        // each, F(4, 3) at 0, +-1, +-2, inf (k_wino.hip wino_s3_kernel; oracle/winograd.py); natural point order; fragment order
+        // [oc/16][((x * 3 + p) * G + g) * 4 + j][64 lanes], K of a point's GEMM = (phase, channel)
+        static const double G3[6][3] = {{1.0 / 4, 0, 0}, {1.0 / 6, 1.0 / 6, 1.0 / 6}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
+                                        {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1.0}};
+        static const int XO[6] = {1, 2, 0, 3, 4, 5};  // the kernel's x order: wave half 0 (+1, -1, 0), half 1 (+2, -2, inf)
+        const int NX = 6, SW = NX * 3 * G * 4;
+        std::vector<float> wp((size_t)W * SW * 64);
+        for (int w = 0; w < W; ++w)
+            for (int x = 0; x < NX; ++x)
+                for (int ph = 0; ph < 3; ++ph)
+                    for (int g = 0; g < G; ++g)
+                        for (int j = 0; j < 4; ++j)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int q = lane >> 4, mm = lane & 15;
+                                const int oc = 16 * w + mm, ic = 16 * g + 4 * q + j;
+                                double u = 0.0;
+                                for (int t = 0; t < 3; ++t) u += G3[XO[x]][t] * (double)f.w[((size_t)oc * s.ic + ic) * s.kw + 3 * t + ph];
+                                wp[((size_t)w * SW + ((x * 3 + ph) * G + g) * 4 + j) * 64 + lane] = (float)u;
+                            }
+        RMR_TRY(upload(m, wp, &out->wpack));
+    }
     return 0;
 }
 

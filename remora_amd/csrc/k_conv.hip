@@ -271,6 +271,7 @@ int launch_conv(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, 
     // 5 taps, stride 1, 64 output channels: Winograd F(4, 5), 0.4 of the MFMAs (k_wino.hip).  RMR_WINOGRAD=0: the direct form below
     // (its comparand, tests/test_gpu_wino.py).  Every batch size takes it: the bits of a chunk do not depend on the batch it arrives in
     if (conv_wino_supported(c, pin, pout) && tune_int("RMR_WINOGRAD", 1)) return launch_conv_wino(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);
+    if (conv_wino_s3_supported(c, pin, pout) && tune_int("RMR_WINOGRAD", 1)) return launch_conv_wino_s3(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);
 #define RMR_CONV_CASE(IC_, KW_, ST_)                                  \
     if (c.ic == IC_ && c.kw == KW_ && c.stride == ST_)                \
         return launch_conv_t<IC_, KW_, ST_>(e, c, in, in_row, pin, out, out_row, out_coff, pout, n);

@@ -286,6 +286,10 @@ int launch_lstm_head(rmr_model *m, const float *x, int64_t n, float *logits);
 bool conv_wino_supported(const ConvLayer &c, int pin, int pout);
 int launch_conv_wino(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out, int out_row, int out_coff,
                      int pout, int64_t n);
+// the stride-3 layers from 16 to 64 channels (sig_conv3, seq_conv2) as polyphase Winograd convolutions
+bool conv_wino_s3_supported(const ConvLayer &c, int pin, int pout);
+int launch_conv_wino_s3(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out, int out_row, int out_coff,
+                        int pout, int64_t n);
 // k_stream.hip: the same layers with the weights streamed from L2 (channel counts above 64, any multiple of 16 up to 256)
 int launch_conv_stream(rmr_engine *e, const ConvLayer &c, const float *in, int in_row, int pin, float *out, int out_row, int out_coff,
                        int pout, int64_t n);

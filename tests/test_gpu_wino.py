@@ -1,5 +1,6 @@
-"""GPU parity of the Winograd F(4, 5) form of the 5-tap stride-1 convolutions (remora_amd/csrc/k_wino.hip: merge_conv1 of
-models/ConvLSTM_w_ref.py:36-37,50 and merge_conv1 / merge_conv2 of models/Conv_w_ref.py:35-38,54-55 at size 64): within the fp32
+"""GPU parity of the Winograd forms of k_wino.hip - F(4, 5) for the 5-tap stride-1 convolutions (merge_conv1 of
+models/ConvLSTM_w_ref.py:36-37,50 and merge_conv1 / merge_conv2 of models/Conv_w_ref.py:35-38,54-55 at size 64), polyphase F(4, 3)
+for Conv_w_ref's stride-3 seq_conv3 (models/Conv_w_ref.py:31-32,51): within the fp32
 tolerance (1e-4 on logits) of the reference-generated golden models and of the CPU restatement of the reference network, no
 further from float64 than the direct form (RMR_WINOGRAD=0, k_conv.hip) by more than a rounding-level margin, the same bits
 whatever the batch a chunk arrives in."""

@@ -3237,6 +3237,27 @@ def test_winograd_constants_match_the_exact_derivation():
              21 * (d[3] - d[5]) + 4 * (d[7] - d[1])]
         want = [sum(BT[x][j] * d[j] for j in range(8)) for x in W.F45_KERNEL_ORDER]
         assert v == want
+    # F(4, 3) of the stride-3 kernel: engine.hip `G3` (natural order) and wino_in_transform6 (kernel order 1, 2, 0, 3, 4, 5)
+    AT3, G3, BT3 = W.matrices(4, 3, (0, 1, -1, 2, -2, None))
+    blk = eng[eng.index("static const double G3[6][3]") :]
+    blk = blk[blk.index("{") : blk.index("};") + 1]
+    rows = re.findall(r"\{([^{}]+)\}", blk)
+    assert len(rows) == 6
+    for k, row in enumerate(rows):
+        vals = []
+        for e in row.split(","):
+            num, _, den = e.strip().partition("/")
+            vals.append(Fr(num.strip()) / (Fr(den.strip()) if den else 1))
+        assert vals == G3[k], (k, row)
+    for _ in range(10):
+        d = [Fr(rnd.randint(-50, 50), rnd.randint(1, 9)) for _ in range(6)]
+        a_, b_ = 4 * d[2] - d[4], 4 * d[1] - d[3]
+        c_, e_ = d[4] - d[2], d[3] - d[1]
+        v = [a_ + b_, a_ - b_, -5 * d[2] + (4 * d[0] + d[4]), 2 * e_ + c_, -2 * e_ + c_, -5 * d[3] + (4 * d[1] + d[5])]
+        assert v == [sum(BT3[x][j] * d[j] for j in range(6)) for x in (1, 2, 0, 3, 4, 5)]
+        m = [Fr(rnd.randint(-50, 50), rnd.randint(1, 9)) for _ in range(6)]
+        s12, d12, s34, d34 = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+        assert [(m[0] + s12) + s34, d12 + 2 * d34, s12 + 4 * s34, d12 + (8 * d34 + m[5])] == [sum(AT3[i][x] * m[x] for x in range(6)) for i in range(4)]
     # the output stage of the kernel (two wave halves) is AT m
     for _ in range(10):
         m = [Fr(rnd.randint(-50, 50), rnd.randint(1, 9)) for _ in range(8)]
