@@ -44,7 +44,8 @@ BENCH_NAME = [("conv_mfma_kernel<128, 5, 1>", "conv_merge1"), ("conv_mfma_kernel
               ("fc_head_kernel", "fc_head"),
               # networks of more than 64 channels (k_stream.hip), small batches (k_lstm.hip)
               ("conv_stream_kernel<5, 1>", "conv_merge1"), ("conv_stream_kernel<13, 3>", "conv_seq2"), ("conv_stream_kernel<9, 3>", "conv_sig3"),
-              ("lstm_stream_kernel", "lstm_head"), ("lstm_small_kernel", "lstm_head")]
+              ("lstm_stream_kernel", "lstm_head"), ("lstm_small_kernel", "lstm_head"),
+              ("wino_conv_kernel<128>", "conv_merge1"), ("wino_conv_kernel<64>", "conv_merge2"), ("wino_s3_kernel<32>", "conv_seq3")]
 
 
 def write_traffic(d, dtype, chunks_per_launch, path, commit=None, per_kernel_chunks=None):
