@@ -531,6 +531,11 @@ class Job:
                     if name in kern and kern[name]["tflops"]:
                         kern[name]["executed_tflops"] = kern[name]["tflops"] * executed[name] / flops[name]
                         kern[name]["form"] = "Winograd F(4,5): 8 MFMA products per 4 outputs and input channel (direct form: 20) + 46 VALU transform operations"
+            if "sig3_front" in flops:  # sig_conv3 inside the folded kernel: stride 3 as three 3-tap phases in F(4,3) form
+                executed["sig3_front"] = flops["front_sig"] + flops["conv_sig3"] * (6 * ((P3 + 3) // 4)) / (3 * P3)
+                if "sig3_front" in kern and kern["sig3_front"]["tflops"]:
+                    kern["sig3_front"]["executed_tflops"] = kern["sig3_front"]["tflops"] * executed["sig3_front"] / flops["sig3_front"]
+                    kern["sig3_front"]["form"] = "sig_conv3 as polyphase Winograd F(4,3): 6 MFMA products per 4 outputs, phase and input channel (direct form: 12)"
             if self.arch != "conv_lstm" and "conv_seq3" in flops:  # Conv_w_ref's seq_conv3: stride 3 as three 3-tap phases in F(4,3) form
                 executed["conv_seq3"] = flops["conv_seq3"] * (6 * ((P3 + 3) // 4)) / (3 * P3)
                 if "conv_seq3" in kern and kern["conv_seq3"]["tflops"]:

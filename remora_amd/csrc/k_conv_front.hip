@@ -59,6 +59,11 @@ struct ConvFrontArgs {
     int pin, pout, out_row, out_coff, cb, plane;
     FastDiv div_pout;
     int abl;  // experiment builds only (-DRMR_TIMING_ABLATIONS): 1 = skip the producer phase, 2 = skip the matrix phase
+    // sig3_front_wino_kernel: sig_conv3 in polyphase Winograd form (k_wino.hip has the algebra)
+    const float *wpack;   // [oc/16][(x * 3 + phase) * 4 + j][64 lanes], natural point order
+    int o_v, vplane;      // LDS offset (floats) of the x-domain image V, floats per (x, phase, q) plane = padded columns * 4
+    int ngrp;             // groups of four output positions per chunk
+    FastDiv div_ngrp;
 };
 
 #ifdef RMR_TIMING_ABLATIONS
@@ -341,6 +346,191 @@ __global__ __launch_bounds__(256, (KW1 <= 5 ? 3 : 2)) void sig3_front_mfma_kerne
 }
 
 // ---------------------------------------------------------------------------------------
+// The same kernel with sig_conv3 in minimal form (round 6; k_wino.hip has the algebra and the stride-1 kernels).  Stride 3 = three
+// stride-1 phase filters of three taps on d_r[i] = sig2[3 i + r]; each over groups of four outputs as F(4, 3) at 0, +-1, +-2, inf:
+// 6 products per 4 outputs where the direct form has 12, the three phases accumulating into the same x-domain accumulators
+// (K = 3 x 16 = 48 per point): 126 MFMAs per chunk at C100 instead of 252.  The producer is the one above, untouched; between
+// it and the matrix phase the block turns the staged rows into the x-domain image V[x][phase][plane q][column] (column = (chunk,
+// group), 16 B each, the columns of a 16-column tile rotated by 4 x phase so that the three phases of a column - written by
+// neighbouring lanes - sit on different bank slots): 1.5 x the rows' size, which still fits two blocks per CU at four chunks per
+// iteration.  Rows behind a chunk's last enter as zeros.  (seq_conv2's 5-tap phases need F(4, 5): V is twice the rows and does
+// not fit beside its producer's gather tables; profiles/NOTES_r06.md section 8.)
+// ---------------------------------------------------------------------------------------
+template <int KW1, int MAXT>
+__global__ __launch_bounds__(256, 2) void sig3_front_wino_kernel(ConvFrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NX = 6, S = NX * 12;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15;
+
+    float A[S];
+    {
+        const float *ap = a.wpack + (size_t)w * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) A[s] = ap[(size_t)s * 64];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
+    float A2[KW1];
+#pragma unroll
+    for (int t = 0; t < KW1; ++t) A2[t] = a.w_sig2[(t * 4 + q) * 16 + nn];
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b_sig2 + 4 * q);
+    float w1[KW1][4];
+#pragma unroll
+    for (int t = 0; t < KW1; ++t)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w1[t][o] = a.w_sig1[t * 4 + o];
+    const float b1[4] = {a.b_sig1[0], a.b_sig1[1], a.b_sig1[2], a.b_sig1[3]};
+
+    const int Lp = (a.L + 3) & ~3, Pst = (a.P1 + 16 + 3) & ~3;
+    float *s_sig = smem + a.o_front + (size_t)w * a.per_chunk;
+    float *s_sig1 = s_sig + Lp;
+    for (int i = lane; i < 4 * Pst; i += 64) s_sig1[i] = 0.0f;
+    const int ntiles = (a.pin + 15) >> 4;
+    float *const V = smem + a.o_v;
+    const int XIV = 12 * a.vplane;  // one x image of V
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        RMR_SYNC();  // the matrix phase of the previous iteration has read V
+        for (int c = w; c < nch; c += 4) {  // ---- producer: sig_conv1 -> sig_conv2 (matrix cores) -> the rows of chunk c (as in sig3_front_mfma_kernel)
+            wave_sync();
+            const float *src = a.signal + (size_t)(chunk0 + c) * a.L;
+            for (int s = lane; s < a.L; s += 64) s_sig[s] = src[s];
+            wave_sync();
+            for (int pos = lane; pos < a.P1; pos += 64) {
+                float acc[4] = {b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    const float xv = s_sig[pos + t];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[o] = fmaf(w1[t][o], xv, acc[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) s_sig1[o * Pst + pos] = swish_f(acc[o]);
+            }
+            wave_sync();
+            float *row0 = smem + (size_t)q * a.plane + (size_t)c * a.pin * 4;
+            for (int t0 = 0; t0 < ntiles; t0 += MAXT) {
+                f32x4 acc[MAXT];
+#pragma unroll
+                for (int k = 0; k < MAXT; ++k) acc[k] = b2;
+                const float *row = s_sig1 + q * Pst + 16 * t0 + nn;
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+#pragma unroll
+                    for (int k = 0; k < MAXT; ++k)
+                        if (t0 + k < ntiles) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[t], row[16 * k + t], acc[k], 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < MAXT; ++k) {
+                    const int pos = 16 * (t0 + k) + nn;
+                    if (t0 + k < ntiles && pos < a.pin) {
+                        f32x2 lo = f32x2{acc[k][0], acc[k][1]}, hi = f32x2{acc[k][2], acc[k][3]};
+                        swish_pk(lo, hi);
+                        *reinterpret_cast<float4 *>(row0 + pos * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                }
+            }
+        }
+        RMR_SYNC();
+        // ---- rows -> V: wave w takes plane w; an item = (column, phase): six rows 12 t + 3 j + phase of the column's chunk
+        const int ncols = nch * a.ngrp;
+        {
+            const float *img = smem + (size_t)w * a.plane;
+            float *vq = V + (size_t)w * a.vplane;
+            for (int i = lane; i < 3 * ncols; i += 64) {
+                const int col = i / 3, ph = i - 3 * col;
+                const int c = (int)(((float)col + 0.5f) * a.div_ngrp.inv), t = col - c * a.ngrp;
+                const int lim = a.pin - 1 - ph - 12 * t;  // highest row offset 3 j inside the chunk (>= 0)
+                const float *rp = img + (size_t)(c * a.pin + 12 * t + ph) * 4;
+                f32x4 d[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    d[j] = *reinterpret_cast<const f32x4 *>(rp + (3 * j <= lim ? 3 * j : 0) * 4);
+                    if (3 * j > lim) d[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                // BT d of F(4, 3), natural point order (0, 1, -1, 2, -2, inf)
+                f32x4 v[6];
+                const f32x4 c4 = {4.0f, 4.0f, 4.0f, 4.0f}, m5 = {-5.0f, -5.0f, -5.0f, -5.0f}, c2 = {2.0f, 2.0f, 2.0f, 2.0f};
+                v[0] = __builtin_elementwise_fma(m5, d[2], __builtin_elementwise_fma(c4, d[0], d[4]));
+                const f32x4 ea = __builtin_elementwise_fma(c4, d[2], -d[4]), eb = __builtin_elementwise_fma(c4, d[1], -d[3]);
+                v[1] = ea + eb;
+                v[2] = ea - eb;
+                const f32x4 ec = d[4] - d[2], ee = d[3] - d[1];
+                v[3] = __builtin_elementwise_fma(c2, ee, ec);
+                v[4] = __builtin_elementwise_fma(-c2, ee, ec);
+                v[5] = __builtin_elementwise_fma(m5, d[3], __builtin_elementwise_fma(c4, d[1], d[5]));
+                float *dst = vq + (size_t)ph * 4 * a.vplane + (size_t)((col & ~15) + ((col + 4 * ph) & 15)) * 4;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) *reinterpret_cast<f32x4 *>(dst + (size_t)x * XIV) = v[x];
+            }
+        }
+        RMR_SYNC();
+        // ---- six GEMMs of K = 48 per column tile; steps = (phase, half of the points); AT m, bias, swish, four stores per column
+        if (CF_ABL(2)) continue;
+        const int ntl = (ncols + 15) >> 4;
+        for (int tile = 0; tile < ntl; ++tile) {
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 acc[6] = {b4, zero, zero, zero, zero, b4};  // AT[0][0] = AT[3][5] = 1: the bias of y0 and y3
+            const float *r = V + (size_t)q * a.vplane + (size_t)tile * 64;
+            f32x4 xv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xv[k] = *reinterpret_cast<const f32x4 *>(r + (size_t)k * XIV + nn * 4);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const int p = st >> 1, x0 = (st & 1) * 3;
+                f32x4 yv[3];
+                if (st + 1 < 6) {
+                    const int p1 = (st + 1) >> 1, x1 = ((st + 1) & 1) * 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        yv[k] = *reinterpret_cast<const f32x4 *>(r + (size_t)(x1 + k) * XIV + (size_t)p1 * 4 * a.vplane + ((nn + 4 * p1) & 15) * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        acc[x0 + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[((x0 + k) * 3 + p) * 4 + j], xv[k][j], acc[x0 + k], 0, 0, 0);
+                if (st + 1 < 6) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) xv[k] = yv[k];
+                }
+            }
+            // pin the software pipeline: the reads of step st + 1 are issued before the MFMAs of step st
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                if (st + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            const int col = tile * 16 + nn;
+            if (col < ncols) {
+                const int c = (int)(((float)col + 0.5f) * a.div_ngrp.inv), t = col - c * a.ngrp;
+                const f32x4 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
+                const f32x4 c2 = {2.0f, 2.0f, 2.0f, 2.0f}, c4 = {4.0f, 4.0f, 4.0f, 4.0f}, c8 = {8.0f, 8.0f, 8.0f, 8.0f};
+                f32x4 yo[4];
+                yo[0] = (acc[0] + s12) + s34;
+                yo[1] = __builtin_elementwise_fma(c2, d34, d12) + b4;
+                yo[2] = __builtin_elementwise_fma(c4, s34, s12) + b4;
+                yo[3] = __builtin_elementwise_fma(c8, d34, d12) + acc[5];
+                float *dst = a.out + ((size_t)(chunk0 + c) * a.pout + 4 * t) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                const int nvalid = a.pout - 4 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < nvalid) {
+                        f32x2 lo = f32x2{yo[i][0], yo[i][1]}, hi = f32x2{yo[i][2], yo[i][3]};
+                        swish_pk(lo, hi);
+                        *reinterpret_cast<f32x4 *>(dst + (size_t)i * a.out_row) = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // sequence branch (two-level gather of k_front.hip's front_seq_kernel<5, false>, 64 lanes per chunk)
 // ---------------------------------------------------------------------------------------
 template <int K>
@@ -524,49 +714,66 @@ int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *
     a.pin = m->P2; a.pout = m->P3; a.out_row = 2 * sz; a.out_coff = 0; a.div_pout = make_fastdiv(m->P3);
     const int Lp = (m->L + 3) & ~3, Pst = (m->P1 + 16 + 3) & ~3;
     a.per_chunk = Lp + 4 * Pst;  // scratch per WAVE
-    auto kern = kw1 == 5 ? sig3_front_mfma_kernel<5, 6> : sig3_front_mfma_kernel<11, 5>;
-    // blocks per CU by registers, LDS share accordingly; among the chunk counts that fit, the one that fills its tiles best
-    static int regs5 = 0, regs11 = 0;
-    int &regs = kw1 == 5 ? regs5 : regs11;
-    if (regs == 0) {
-        hipFuncAttributes attr;
-        regs = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
+    // sig_conv3 in polyphase Winograd form (sig3_front_wino_kernel) where its x-domain image fits beside the rows; RMR_WINOGRAD=0 and
+    // long chunk contexts: the direct form
+    bool wino = m->sig3.wpack && tune_int("RMR_WINOGRAD", 1);
+    a.wpack = m->sig3.wpack; a.ngrp = (m->P3 + 3) / 4; a.div_ngrp = make_fastdiv(a.ngrp);
+    for (int attempt = 0; attempt < 2; ++attempt, wino = false) {
+        void (*kern)(ConvFrontArgs) = wino ? (kw1 == 5 ? sig3_front_wino_kernel<5, 6> : sig3_front_wino_kernel<11, 5>)
+                                           : (kw1 == 5 ? sig3_front_mfma_kernel<5, 6> : sig3_front_mfma_kernel<11, 5>);
+        // blocks per CU by registers, LDS share accordingly; among the chunk counts that fit, the one that fills its tiles best
+        static int regs_tab[2][2] = {{0, 0}, {0, 0}};
+        int &regs = regs_tab[wino ? 1 : 0][kw1 == 5 ? 0 : 1];
+        if (regs == 0) {
+            hipFuncAttributes attr;
+            regs = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
+        }
+        int resident = 512 / ((regs + 7) & ~7);
+        resident = resident < 1 ? 1 : (resident > 4 ? 4 : resident);
+        if (wino && resident > 2) resident = 2;  // V is 1.5 x the rows: four chunks per iteration need a half CU's LDS
+        size_t budget = (size_t)73728;
+        const size_t share = (size_t)160 * 1024 / resident - 512;
+        if (share < budget) budget = share;
+        // LDS of k chunks per iteration: the four row planes, (Winograd) V = 6 points x 12 (phase, plane) planes of the padded columns, the waves' scratch
+        auto plan = [&](int k, int *plane, int *vplane, size_t *need) {
+            *plane = ((k * a.pin * 4) + 63) & ~63;
+            *vplane = wino ? ((k * a.ngrp + 15) & ~15) * 4 : 0;
+            *need = ((size_t)4 * *plane + 16 + (size_t)72 * *vplane + 4 * (size_t)a.per_chunk) * sizeof(float);
+        };
+        // score of a chunk count = tile fill of the matrix phase x balance of the producer phase (4 waves, one chunk at a time)
+        int cb = 0;
+        size_t lds = 0;
+        double best = -1.0;
+        for (int k = 8; k >= 1; --k) {
+            int plane, vplane;
+            size_t need;
+            plan(k, &plane, &vplane, &need);
+            if (need > budget && !(k == 1 && !wino && need <= CONV_FRONT_MAX_LDS)) continue;
+            if (cb == 0) cb = k;            // the largest count that fits
+            if (2 * k < cb) break;          // never below half of it
+            const int cols = wino ? k * a.ngrp : k * a.pout;
+            const double score = (double)cols / (16.0 * ((cols + 15) / 16)) * (double)k / (4.0 * ((k + 3) / 4));
+            if (score > best + 1e-9) { best = score; a.cb = k; lds = need; }
+        }
+        if (cb == 0) {
+            if (wino) continue;  // the direct form has its own plan for one long chunk per iteration
+            RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples does not fit the LDS", m->L);
+        }
+        while (a.cb > 1 && (n + a.cb - 1) / a.cb < e->num_cus) a.cb = (a.cb + 1) / 2;  // a small batch spread over the CUs (same bits for any count)
+        plan(a.cb, &a.plane, &a.vplane, &lds);
+        a.o_v = 4 * a.plane + 16;
+        a.o_front = a.o_v + 72 * a.vplane;
+        a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
+        const int64_t iters = (n + a.cb - 1) / a.cb;
+        int64_t grid = (int64_t)e->num_cus * 8;
+        if (grid > iters) grid = iters;
+        RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
+        ProfScope ps(e, K_SIG3_FRONT);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+        RMR_HIP(hipGetLastError());
+        return 0;
     }
-    int resident = 512 / ((regs + 7) & ~7);
-    resident = resident < 1 ? 1 : (resident > 4 ? 4 : resident);
-    size_t budget = (size_t)73728;
-    const size_t share = (size_t)160 * 1024 / resident - 512;
-    if (share < budget) budget = share;
-    // score of a chunk count = tile fill of the matrix phase x balance of the producer phase (4 waves, one chunk at a time)
-    int cb = 0;
-    size_t lds = 0;
-    double best = -1.0;
-    for (int k = 8; k >= 1; --k) {
-        const int plane = ((k * a.pin * 4) + 63) & ~63;
-        const size_t need = ((size_t)4 * plane + 16 + 4 * (size_t)a.per_chunk) * sizeof(float);
-        if (need > budget && !(k == 1 && need <= CONV_FRONT_MAX_LDS)) continue;
-        if (cb == 0) cb = k;            // the largest count that fits
-        if (2 * k < cb) break;          // never below half of it
-        const int cols = k * a.pout;
-        const double score = (double)cols / (16.0 * ((cols + 15) / 16)) * (double)k / (4.0 * ((k + 3) / 4));
-        if (score > best + 1e-9) { best = score; a.cb = k; a.plane = plane; a.o_front = 4 * plane + 16; lds = need; }
-    }
-    if (cb == 0) RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples does not fit the LDS", m->L);
-    while (a.cb > 1 && (n + a.cb - 1) / a.cb < e->num_cus) {  // a small batch spread over the CUs (k_conv.hip: same bits for any count)
-        a.cb = (a.cb + 1) / 2;
-        a.plane = ((a.cb * a.pin * 4) + 63) & ~63;
-        a.o_front = 4 * a.plane + 16;
-        lds = ((size_t)4 * a.plane + 16 + 4 * (size_t)a.per_chunk) * sizeof(float);
-    }
-    a.abl = abl_int("RMR_CONV_FRONT_ABLATE", 0);  // ignored unless built with -DRMR_TIMING_ABLATIONS
-    const int64_t iters = (n + a.cb - 1) / a.cb;
-    int64_t grid = (int64_t)e->num_cus * 8;
-    if (grid > iters) grid = iters;
-    RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(kern)));
-    ProfScope ps(e, K_SIG3_FRONT);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
-    RMR_HIP(hipGetLastError());
-    return 0;
+    RMR_FAIL(RMR_ERR_INVALID, "sig3_front: no launch plan");
 }
 
 // sig_conv3 (+ sig_conv1/2) and seq_conv2 (+ seq_conv1) of `n` chunks into the two halves of cat [n][P3][128]
