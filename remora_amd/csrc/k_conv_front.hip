@@ -755,8 +755,10 @@ int launch_sig3_front_mfma(rmr_model *m, const float *signal, int64_t n, float *
             const double score = (double)cols / (16.0 * ((cols + 15) / 16)) * (double)k / (4.0 * ((k + 3) / 4));
             if (score > best + 1e-9) { best = score; a.cb = k; lds = need; }
         }
-        if (cb == 0) {
-            if (wino) continue;  // the direct form has its own plan for one long chunk per iteration
+        if (cb == 0 || (wino && a.cb < 3)) {
+            // Winograd with fewer than three chunks per iteration (C200: rows + V of ONE chunk fill a half CU) leaves three of the four
+            // producing waves idle - 4.5 against the direct form's 3.1 ms per 250 k chunks; the direct form has its own plan for long chunks
+            if (wino) continue;
             RMR_FAIL(RMR_ERR_INVALID, "sig3_front: one chunk of %d samples does not fit the LDS", m->L);
         }
         while (a.cb > 1 && (n + a.cb - 1) / a.cb < e->num_cus) a.cb = (a.cb + 1) / 2;  // a small batch spread over the CUs (same bits for any count)
