@@ -536,6 +536,11 @@ class Job:
                 if "sig3_front" in kern and kern["sig3_front"]["tflops"]:
                     kern["sig3_front"]["executed_tflops"] = kern["sig3_front"]["tflops"] * executed["sig3_front"] / flops["sig3_front"]
                     kern["sig3_front"]["form"] = "sig_conv3 as polyphase Winograd F(4,3): 6 MFMA products per 4 outputs, phase and input channel (direct form: 12)"
+            if "seq2_front" in flops:  # seq_conv2 inside the folded kernel: phases of 5, 4, 4 taps, all in F(4,5) form (8 products for 20 / 16 / 16)
+                executed["seq2_front"] = flops["front_seq"] + flops["conv_seq2"] * (8 * 3 * ((P3 + 3) // 4)) / (13 * P3)
+                if "seq2_front" in kern and kern["seq2_front"]["tflops"]:
+                    kern["seq2_front"]["executed_tflops"] = kern["seq2_front"]["tflops"] * executed["seq2_front"] / flops["seq2_front"]
+                    kern["seq2_front"]["form"] = "seq_conv2 as polyphase Winograd F(4,5): 24 MFMA products per 4 outputs and input channel (direct form: 52)"
             if self.arch != "conv_lstm" and "conv_seq3" in flops:  # Conv_w_ref's seq_conv3: stride 3 as three 3-tap phases in F(4,3) form
                 executed["conv_seq3"] = flops["conv_seq3"] * (6 * ((P3 + 3) // 4)) / (3 * P3)
                 if "conv_seq3" in kern and kern["conv_seq3"]["tflops"]:

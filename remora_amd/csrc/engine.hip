@@ -874,6 +874,34 @@ int pack_conv(rmr_model *m, const Folded &f, int kid, ConvLayer *out) {
                         }
         RMR_TRY(upload(m, wp, &out->wpack));
     }
+    if (s.stride == 3 && s.ic == 16 && s.oc == 64 && s.kw == 13) {
+        // seq_conv2 (models/ConvLSTM_w_ref.py:30-31,46) for k_conv_front.hip's seq2_front_wino_kernel: phase filters w_p[m] = w[3 m + p] of 5, 4 and
+        // 4 taps, all as F(4, 5) (a zero fifth tap where 3 m + p > 12), natural point order (0, 1, -1, 2, -2, 1/2, -1/2, inf);
+        // [oc/16][(x * 3 + p) * 4 + j][64 lanes]
+        static const double G5n[8][5] = {{1.0 / 4, 0, 0, 0, 0},
+                                         {1.0 / 18, 1.0 / 18, 1.0 / 18, 1.0 / 18, 1.0 / 18},
+                                         {1.0 / 18, -1.0 / 18, 1.0 / 18, -1.0 / 18, 1.0 / 18},
+                                         {1.0 / 360, 1.0 / 180, 1.0 / 90, 1.0 / 45, 2.0 / 45},
+                                         {1.0 / 360, -1.0 / 180, 1.0 / 90, -1.0 / 45, 2.0 / 45},
+                                         {16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45, 1.0 / 45},
+                                         {16.0 / 45, -8.0 / 45, 4.0 / 45, -2.0 / 45, 1.0 / 45},
+                                         {0, 0, 0, 0, 1.0 / 4}};
+        const int SW = 8 * 12;
+        std::vector<float> wp((size_t)W * SW * 64);
+        for (int w = 0; w < W; ++w)
+            for (int x = 0; x < 8; ++x)
+                for (int ph = 0; ph < 3; ++ph)
+                    for (int j = 0; j < 4; ++j)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int q = lane >> 4, mm = lane & 15;
+                            const int oc = 16 * w + mm, ic = 4 * q + j;
+                            double u = 0.0;
+                            for (int t = 0; t < 5; ++t)
+                                if (3 * t + ph < s.kw) u += G5n[x][t] * (double)f.w[((size_t)oc * s.ic + ic) * s.kw + 3 * t + ph];
+                            wp[((size_t)w * SW + (x * 3 + ph) * 4 + j) * 64 + lane] = (float)u;
+                        }
+        RMR_TRY(upload(m, wp, &out->wpack));
+    }
     if (s.stride == 3 && s.ic == 32 && s.oc == 64 && s.kw == 9) {
         // Conv_w_ref's seq_conv3 (models/Conv_w_ref.py:31-32,51): stride 3 as three phase filters w_p[m] = w[3 m + p] of three taps
         // each, F(4, 3) at 0, +-1, +-2, inf (k_wino.hip wino_s3_kernel; oracle/winograd.py); natural point order; fragment order

@@ -23,6 +23,8 @@
 // producer phase running under the other block's matrix phase is slowed by what it saves (shared fp32 datapath).
 // What did pay inside the producers: the K gathers of an item batched before the first add (1.22 -> 1.12), exact tile
 // groups + the next iteration's rows requested under the matrix phase (-> 1.00; sig -3 %).
+#include <algorithm>
+
 #include "rmr_internal.h"
 #include "rmr_math.h"
 
@@ -674,6 +676,263 @@ __global__ __launch_bounds__(256) void seq2_front_kernel(ConvFrontArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The sequence branch with seq_conv2 in minimal form (round 6; see sig3_front_wino_kernel and k_wino.hip).  13 taps at stride 3 = phase
+// filters of 5, 4 and 4 taps, all three taken as F(4, 5) at 0, +-1, +-2, +-1/2, inf (the 4-tap ones with a zero fifth tap): 8 points x
+// K = 48, 168 MFMAs per chunk at C100 instead of 364.  V is TWICE the rows here; it fits a half CU at four chunks per iteration only
+// because it takes the place of the producer's gather tables and scratch, which are dead once the rows are staged - the 14 KB
+// seq_conv1 table is therefore re-read from L2 every iteration (into registers under the matrix phase, into LDS behind the barrier that
+// frees V).
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256, 2) void seq2_front_wino_kernel(ConvFrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KW1 = 5, NX = 8, S = NX * 12;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, nn = lane & 15, quad = lane & 3;
+
+    float A[S];
+    {
+        const float *ap = a.wpack + (size_t)w * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) A[s] = ap[(size_t)s * 64];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * w + 4 * q);
+    constexpr int wt_words = KW1 * K * 80;
+    float *s_wt = smem + a.o_front;  // [KW1][K][5][16]
+    constexpr int WT_PER = (wt_words + 255) / 256;
+    float wt_pre[WT_PER];  // this thread's share of the table, fetched under the matrix phase for the next iteration
+#pragma unroll
+    for (int u = 0; u < WT_PER; ++u) wt_pre[u] = tid + 256 * u < wt_words ? a.wt5[tid + 256 * u] : 0.0f;
+    float *const V = smem + a.o_v;
+    const int XIV = 12 * a.vplane;
+    const f32x2 bq_lo = f32x2{a.b_seq1[4 * quad], a.b_seq1[4 * quad + 1]}, bq_hi = f32x2{a.b_seq1[4 * quad + 2], a.b_seq1[4 * quad + 3]};
+
+    const int64_t n_iters = (a.n + a.cb - 1) / a.cb;
+    // the mapping / sequence row and the length of the wave's first chunk of an iteration travel one element per lane
+    // (rows of up to 64 elements) and are requested an iteration ahead
+    const bool pre_ok = a.map_w <= 64 && a.seq_w <= 64;
+    int16_t pre_map = 0;
+    int8_t pre_seq = 0;
+    int pre_len = 0;
+    auto prefetch = [&](int64_t it) {
+        const int64_t chunk = it * a.cb + w;
+        if (!pre_ok || it >= n_iters || chunk >= a.n) return;
+        if (lane < a.map_w) pre_map = a.maps[(size_t)chunk * a.map_w + lane];
+        if (lane < a.seq_w) pre_seq = a.seqs[(size_t)chunk * a.seq_w + lane];
+        pre_len = a.lens[chunk];
+    };
+    prefetch(blockIdx.x);
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t chunk0 = it * a.cb;
+        const int nch = (int)((a.n - chunk0) < a.cb ? (a.n - chunk0) : a.cb);
+        RMR_SYNC();  // the matrix phase of the previous iteration has read V: its place is the table's and the scratch's again
+#pragma unroll
+        for (int u = 0; u < WT_PER; ++u)
+            if (tid + 256 * u < wt_words) s_wt[tid + 256 * u] = wt_pre[u];
+        RMR_SYNC();  // gather table visible
+        for (int c = w; c < nch; c += 4) {
+            const int64_t chunk = chunk0 + c;
+            float *cbase = smem + a.o_front + wt_words + (size_t)c * a.per_chunk;
+            int16_t *s_map = reinterpret_cast<int16_t *>(cbase + a.o_map);
+            int8_t *s_seq = reinterpret_cast<int8_t *>(cbase + a.o_seq);
+            unsigned long long *s_code = reinterpret_cast<unsigned long long *>(cbase + a.o_code);
+            int16_t *s_pidx = reinterpret_cast<int16_t *>(cbase + a.o_pidx);
+            float *s_u = cbase + a.o_u;  // [(maxlen+1)][KW1][16], row `maxlen` = zeros
+            int len;
+            if (c == w && pre_ok) {  // the wave's first chunk: its rows left HBM during the previous matrix phase
+                len = pre_len;
+                if (lane < a.map_w) s_map[lane] = pre_map;
+                if (lane < a.seq_w) s_seq[lane] = pre_seq;
+            } else {
+                len = a.lens[chunk];
+                const int16_t *mp = a.maps + (size_t)chunk * a.map_w;
+                for (int j = lane; j < a.map_w; j += 64) s_map[j] = mp[j];
+                const int8_t *sq = a.seqs + (size_t)chunk * a.seq_w;
+                for (int j = lane; j < a.seq_w; j += 64) s_seq[j] = sq[j];
+            }
+            len = len < 0 ? 0 : (len > a.maxlen ? a.maxlen : len);
+            for (int i = lane; i < KW1 * 16; i += 64) s_u[(size_t)a.maxlen * KW1 * 16 + i] = 0.0f;
+            for (int s = lane; s < a.L; s += 64) s_pidx[s] = (int16_t)a.maxlen;
+            wave_sync();
+            // base covering every signal position, written as runs (base p owns [map[p], map[p+1])); positions no base
+            // owns keep the zero row `maxlen` (the gather form of the reference's scatter loops, encoded_kmers.pyx:33-44)
+            for (int p = lane; p < len; p += 64) {
+                const int s0 = max((int)s_map[p], 0), s1 = min((int)s_map[p + 1], a.L);
+                for (int s = s0; s < s1; ++s) s_pidx[s] = (int16_t)p;
+                unsigned long long wv = 0;
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    const int b = s_seq[p + kp];
+                    wv |= (unsigned long long)((b >= 0 && b < 4) ? b : 4) << (3 * kp);
+                }
+                s_code[p] = wv;
+            }
+            wave_sync();
+            // U[p][tap][oc] = sum over the K k-mer slots of the table rows of base p's k-mer
+            const int items = len * KW1 * 4;
+            for (int i = lane; i < items; i += 128) {  // i & 3 == quad; two (base, tap) items per pass
+                const bool two = i + 64 < items;
+                const int pt0 = i >> 2, pt1 = two ? (i + 64) >> 2 : pt0;
+                const int p0 = pt0 / KW1, t0 = pt0 - p0 * KW1, p1 = pt1 / KW1, t1 = pt1 - p1 * KW1;
+                const unsigned long long wv0 = s_code[p0], wv1 = s_code[p1];
+                const float *wt0 = s_wt + (size_t)t0 * K * 80 + 4 * quad, *wt1 = s_wt + (size_t)t1 * K * 80 + 4 * quad;
+                // K known at compile time: the 2 K gathers of a pass are all in flight before the first add (two or three
+                // waves per SIMD here, not the eight of the standalone front kernel, so the loop must not serialise them)
+                float4 va[K], vb[K];
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    va[kp] = *reinterpret_cast<const float4 *>(wt0 + (kp * 5 + (int)((wv0 >> (3 * kp)) & 7ull)) * 16);
+                    vb[kp] = *reinterpret_cast<const float4 *>(wt1 + (kp * 5 + (int)((wv1 >> (3 * kp)) & 7ull)) * 16);
+                }
+                f32x2 lo0 = pk_splat(0.f), hi0 = pk_splat(0.f), lo1 = pk_splat(0.f), hi1 = pk_splat(0.f);
+#pragma unroll
+                for (int kp = 0; kp < K; ++kp) {
+                    lo0 += f32x2{va[kp].x, va[kp].y};
+                    hi0 += f32x2{va[kp].z, va[kp].w};
+                    lo1 += f32x2{vb[kp].x, vb[kp].y};
+                    hi1 += f32x2{vb[kp].z, vb[kp].w};
+                }
+                *reinterpret_cast<float4 *>(s_u + (size_t)pt0 * 16 + 4 * quad) = make_float4(lo0.x, lo0.y, hi0.x, hi0.y);
+                if (two) *reinterpret_cast<float4 *>(s_u + (size_t)pt1 * 16 + 4 * quad) = make_float4(lo1.x, lo1.y, hi1.x, hi1.y);
+            }
+            wave_sync();
+            float *row0 = smem + (size_t)quad * a.plane + (size_t)c * a.pin * 4;
+            const int n_pos_items = a.pin * 4;
+            for (int i = lane; i < n_pos_items; i += 128) {  // two positions per pass (same channel quad): see sig3_front_kernel
+                const bool two = i + 64 < n_pos_items;
+                const int pos0 = i >> 2, pos1 = two ? (i + 64) >> 2 : pos0;
+                f32x2 lo0 = bq_lo, hi0 = bq_hi, lo1 = bq_lo, hi1 = bq_hi;
+                int pa[KW1], pb[KW1];
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    pa[t] = s_pidx[pos0 + t];
+                    pb[t] = s_pidx[pos1 + t];
+                }
+                float4 va[KW1], vb[KW1];
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    va[t] = *reinterpret_cast<const float4 *>(s_u + ((size_t)pa[t] * KW1 + t) * 16 + 4 * quad);
+                    vb[t] = *reinterpret_cast<const float4 *>(s_u + ((size_t)pb[t] * KW1 + t) * 16 + 4 * quad);
+                }
+#pragma unroll
+                for (int t = 0; t < KW1; ++t) {
+                    lo0 += f32x2{va[t].x, va[t].y};
+                    hi0 += f32x2{va[t].z, va[t].w};
+                    lo1 += f32x2{vb[t].x, vb[t].y};
+                    hi1 += f32x2{vb[t].z, vb[t].w};
+                }
+                swish_pk(lo0, hi0);
+                swish_pk(lo1, hi1);
+                *reinterpret_cast<float4 *>(row0 + pos0 * 4) = make_float4(lo0.x, lo0.y, hi0.x, hi0.y);
+                if (two) *reinterpret_cast<float4 *>(row0 + pos1 * 4) = make_float4(lo1.x, lo1.y, hi1.x, hi1.y);
+            }
+        }
+        prefetch(it + gridDim.x);
+        RMR_SYNC();
+        // ---- rows -> V (over the table and the scratch): wave w takes plane w; an item = (column, phase): eight rows 12 t + 3 j + phase
+        const int ncols = nch * a.ngrp;
+        {
+            const float *img = smem + (size_t)w * a.plane;
+            float *vq = V + (size_t)w * a.vplane;
+            for (int i = lane; i < 3 * ncols; i += 64) {
+                const int col = i / 3, ph = i - 3 * col;
+                const int c = (int)(((float)col + 0.5f) * a.div_ngrp.inv), t = col - c * a.ngrp;
+                const int lim = a.pin - 1 - ph - 12 * t;  // highest row offset 3 j inside the chunk (>= 0)
+                const float *rp = img + (size_t)(c * a.pin + 12 * t + ph) * 4;
+                f32x4 d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    d[j] = *reinterpret_cast<const f32x4 *>(rp + (3 * j <= lim ? 3 * j : 0) * 4);
+                    if (3 * j > lim) d[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                // BT d of F(4, 5), natural point order (0, 1, -1, 2, -2, 1/2, -1/2, inf); k_wino.hip wino_in_transform has the derivation
+                auto f4 = [](float cst, f32x4 x, f32x4 y) { return __builtin_elementwise_fma(f32x4{cst, cst, cst, cst}, x, y); };
+                f32x4 v[8];
+                const f32x4 e1 = f4(-4.0f, d[2] + d[6], f32x4{17.0f, 17.0f, 17.0f, 17.0f} * d[4]);
+                const f32x4 o1 = f4(-4.0f, d[1] + d[5], f32x4{17.0f, 17.0f, 17.0f, 17.0f} * d[3]);
+                v[1] = e1 + o1;
+                v[2] = e1 - o1;
+                const f32x4 e2 = f4(-5.0f, d[4], f4(4.0f, d[6], d[2]));
+                const f32x4 o2 = f4(-5.0f, d[3], f4(4.0f, d[5], d[1]));
+                v[3] = f4(2.0f, o2, e2);
+                v[4] = f4(-2.0f, o2, e2);
+                v[0] = f4(-21.0f, d[2] - d[4], f32x4{4.0f, 4.0f, 4.0f, 4.0f} * (d[0] - d[6]));
+                const f32x4 e3 = f4(-5.0f, d[4], f4(4.0f, d[2], d[6]));
+                const f32x4 o3 = f4(-5.0f, d[3], f4(4.0f, d[1], d[5]));
+                v[5] = f4(2.0f, e3, o3);
+                v[6] = f4(2.0f, e3, -o3);
+                v[7] = f4(21.0f, d[3] - d[5], f32x4{4.0f, 4.0f, 4.0f, 4.0f} * (d[7] - d[1]));
+                float *dst = vq + (size_t)ph * 4 * a.vplane + (size_t)((col & ~15) + ((col + 4 * ph) & 15)) * 4;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) *reinterpret_cast<f32x4 *>(dst + (size_t)x * XIV) = v[x];
+            }
+        }
+        // the table for the next iteration leaves L2 now and lands under the matrix phase
+#pragma unroll
+        for (int u = 0; u < WT_PER; ++u) wt_pre[u] = tid + 256 * u < wt_words ? a.wt5[tid + 256 * u] : 0.0f;
+        RMR_SYNC();
+        // ---- eight GEMMs of K = 48 per column tile; steps = (phase, half of the points); AT m, bias, swish, four stores per column
+        const int ntl = (ncols + 15) >> 4;
+        for (int tile = 0; tile < ntl; ++tile) {
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 acc[8] = {b4, zero, zero, zero, zero, zero, zero, b4};  // AT[0][0] = AT[3][7] = 1: the bias of y0 and y3
+            const float *r = V + (size_t)q * a.vplane + (size_t)tile * 64;
+            f32x4 xv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const f32x4 *>(r + (size_t)k * XIV + nn * 4);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const int p = st >> 1, x0 = (st & 1) * 4;
+                f32x4 yv[4];
+                if (st + 1 < 6) {
+                    const int p1 = (st + 1) >> 1, x1 = ((st + 1) & 1) * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        yv[k] = *reinterpret_cast<const f32x4 *>(r + (size_t)(x1 + k) * XIV + (size_t)p1 * 4 * a.vplane + ((nn + 4 * p1) & 15) * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[x0 + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[((x0 + k) * 3 + p) * 4 + j], xv[k][j], acc[x0 + k], 0, 0, 0);
+                if (st + 1 < 6) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xv[k] = yv[k];
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                if (st + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+            const int col = tile * 16 + nn;
+            if (col < ncols) {
+                const int c = (int)(((float)col + 0.5f) * a.div_ngrp.inv), t = col - c * a.ngrp;
+                auto f4 = [](float cst, f32x4 x, f32x4 y) { return __builtin_elementwise_fma(f32x4{cst, cst, cst, cst}, x, y); };
+                const f32x4 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
+                const f32x4 s56 = acc[5] + acc[6], d56 = acc[5] - acc[6];
+                f32x4 yo[4];
+                yo[0] = ((acc[0] + s12) + s34) + s56;
+                yo[1] = f4(0.5f, d56, f4(2.0f, d34, d12)) + b4;
+                yo[2] = f4(0.25f, s56, f4(4.0f, s34, s12)) + b4;
+                yo[3] = f4(0.125f, d56, f4(8.0f, d34, d12)) + acc[7];
+                float *dst = a.out + ((size_t)(chunk0 + c) * a.pout + 4 * t) * a.out_row + a.out_coff + 16 * w + 4 * q;
+                const int nvalid = a.pout - 4 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < nvalid) {
+                        f32x2 lo = f32x2{yo[i][0], yo[i][1]}, hi = f32x2{yo[i][2], yo[i][3]};
+                        swish_pk(lo, hi);
+                        *reinterpret_cast<f32x4 *>(dst + (size_t)i * a.out_row) = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static constexpr size_t CONV_FRONT_MAX_LDS = 156 * 1024;  // of the CU's 160 KB
@@ -836,6 +1095,37 @@ int launch_conv_front(rmr_model *m, const float *signal, const int8_t *seqs, int
         const int wt_words = 5 * K * 80;
         int cb = 8;
         size_t lds = 0;
+        // seq_conv2 in polyphase Winograd form (seq2_front_wino_kernel) where at least three chunks per iteration fit a half CU with V in
+        // the place of the gather table and the scratch; RMR_WINOGRAD=0, long chunks and small batches: the direct form
+        bool wino = false;
+        if (m->seq2.wpack && tune_int("RMR_WINOGRAD", 1)) {
+            a.wpack = m->seq2.wpack; a.ngrp = (m->P3 + 3) / 4; a.div_ngrp = make_fastdiv(a.ngrp);
+            auto plan = [&](int k) {
+                a.plane = ((k * a.pin * 4) + 63) & ~63;
+                a.vplane = ((k * a.ngrp + 15) & ~15) * 4;
+                a.o_front = 4 * a.plane + 16;
+                a.o_v = a.o_front;
+                return ((size_t)a.o_front + std::max((size_t)wt_words + (size_t)k * a.per_chunk, (size_t)96 * a.vplane)) * sizeof(float);
+            };
+            for (int k = 8; k >= 3 && !wino; --k)
+                if (plan(k) <= (size_t)80 * 1024 - 512) { wino = true; cb = k; }
+            if (wino) {
+                while (cb > 1 && (n + cb - 1) / cb < e->num_cus) cb = (cb + 1) / 2;  // a small batch spread over the CUs (same bits for any count)
+                lds = plan(cb);
+            }
+        }
+        if (wino) {
+            a.cb = cb;
+            a.abl = 0;
+            const int64_t iters = (n + cb - 1) / cb;
+            int64_t grid = (int64_t)e->num_cus * 8;
+            if (grid > iters) grid = iters;
+            RMR_TRY(e->allow_big_lds(reinterpret_cast<const void *>(seq2_front_wino_kernel<9>)));
+            ProfScope ps(e, K_SEQ2_FRONT);
+            hipLaunchKernelGGL(seq2_front_wino_kernel<9>, dim3((unsigned)grid), dim3(256), lds, e->stream, a);
+            RMR_HIP(hipGetLastError());
+            return 0;
+        }
         for (; cb >= 1; --cb) {
             a.plane = ((cb * a.pin * 4) + 63) & ~63;
             a.o_front = 4 * a.plane + 16;

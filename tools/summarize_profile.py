@@ -37,7 +37,7 @@ BENCH_NAME = [("conv_mfma_kernel<128, 5, 1>", "conv_merge1"), ("conv_mfma_kernel
               ("conv_bf16s_kernel<16, 9, 3", "conv_sig3"), ("lstm_bf16s_kernel", "lstm_head"),
               ("front_sig_kernel", "front_sig"), ("front_seq_kernel", "front_seq"), ("front_seq_tap_kernel", "front_seq"), ("fused_front_kernel", "fused_front"),
               ("lstm_x16_kernel", "lstm_head"), ("lstm_x16_g2_kernel", "lstm_head"), ("encode_kernel", "encode_kmers"),
-              ("sig3_front_kernel", "sig3_front"), ("sig3_front_mfma_kernel", "sig3_front"), ("sig3_front_wino_kernel", "sig3_front"), ("seq2_front_kernel", "seq2_front"),
+              ("sig3_front_kernel", "sig3_front"), ("sig3_front_mfma_kernel", "sig3_front"), ("sig3_front_wino_kernel", "sig3_front"), ("seq2_front_kernel", "seq2_front"), ("seq2_front_wino_kernel", "seq2_front"),
               # Conv_w_ref (merge_conv3 and merge_conv4 are the same instantiation: one row, both layers)
               ("conv_mfma_kernel<16, 11, 1>", "conv_seq2"), ("conv_mfma_kernel<32, 9, 3>", "conv_seq3"),
               ("conv_mfma_kernel<64, 5, 1>", "conv_merge2"), ("conv_mfma_kernel<64, 3, 2>", "conv_merge3+4"),
